@@ -1,0 +1,372 @@
+"""Python face of the CPU oracle (TEST INFRASTRUCTURE - see oracle/midas_oracle.c header).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+It wraps oracle/libmidas_oracle.so (built by `make -C oracle`) with numpy in / numpy out
+functions named after the reference operations they restate, plus `OracleFilter`, the
+reference's per-frame loop body (filter/filter.py:150-190) as one `step()`.
+
+Reference citations are relative to /root/reference/midastouch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmidas_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (a few hundred ms)."""
+    src = os.path.join(_HERE, "midas_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B", "-s"], check=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.mo_atan2f.restype = C.c_float
+        _lib.mo_atan2f.argtypes = [C.c_float, C.c_float]
+        _lib.mo_logf.restype = C.c_float
+        _lib.mo_logf.argtypes = [C.c_float]
+        _lib.mo_philox_uniform32.restype = C.c_float
+        _lib.mo_philox_uniform32.argtypes = [C.c_uint64, C.c_uint64]
+        _lib.mo_blocked_scan.restype = C.c_double
+        _lib.mo_softmax.restype = C.c_int
+        _lib.mo_cdf.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+# ------------------------------------------------------------------------------------------
+# elementary spec functions (exposed for the HIP bit-exactness tests)
+# ------------------------------------------------------------------------------------------
+def sincosf(a):
+    a = _f32(a).ravel()
+    s, c = np.empty_like(a), np.empty_like(a)
+    sv, cv = C.c_float(), C.c_float()
+    L = lib()
+    for i, x in enumerate(a):
+        L.mo_sincosf(C.c_float(float(x)), C.byref(sv), C.byref(cv))
+        s[i], c[i] = sv.value, cv.value
+    return s, c
+
+
+def atan2f(y, x):
+    y, x = _f32(y).ravel(), _f32(x).ravel()
+    L = lib()
+    return np.array([L.mo_atan2f(float(a), float(b)) for a, b in zip(y, x)], dtype=np.float32)
+
+
+def logf(x):
+    L = lib()
+    return np.array([L.mo_logf(float(a)) for a in _f32(x).ravel()], dtype=np.float32)
+
+
+def euler_zyx_rad(ang):
+    """pose.euler_angles_to_matrix(ang, "ZYX") (modules/pose.py:215-269)."""
+    ang = _f32(ang).reshape(-1, 3)
+    R = np.empty((ang.shape[0], 3, 3), dtype=np.float32)
+    lib().mo_euler_zyx_rad(C.c_int64(ang.shape[0]), _p(ang), _p(R))
+    return R
+
+
+# ------------------------------------------------------------------------------------------
+# propagate
+# ------------------------------------------------------------------------------------------
+def propagate(poses, odom, tn, rot_deg):
+    """motionModel arithmetic: poses @ (odom @ Tn(tn, Rz Ry Rx(deg2rad(rot)))) (particle_filter.py:319-375)."""
+    poses, odom, tn, rot_deg = _f32(poses), _f32(odom), _f32(tn), _f32(rot_deg)
+    out = np.empty_like(poses)
+    lib().mo_propagate(C.c_int64(poses.shape[0]), _p(poses), _p(odom), _p(tn), _p(rot_deg), _p(out))
+    return out
+
+
+def philox_noise(N, seed, step, std_t, std_r):
+    tn = np.empty((N, 3), dtype=np.float32)
+    rot = np.empty((N, 3), dtype=np.float32)
+    lib().mo_philox_noise(C.c_int64(N), C.c_uint64(seed), C.c_uint64(step), C.c_float(std_t),
+                          C.c_float(std_r), _p(tn), _p(rot))
+    return tn, rot
+
+
+def philox_uniform64(N, seed, step):
+    u = np.empty(N, dtype=np.float64)
+    lib().mo_philox_uniform64(C.c_int64(N), C.c_uint64(seed), C.c_uint64(step), _p(u))
+    return u
+
+
+def philox_raw(ctr, key):
+    ctr = np.ascontiguousarray(ctr, dtype=np.uint32)
+    key = np.ascontiguousarray(key, dtype=np.uint32)
+    out = np.empty(4, dtype=np.uint32)
+    lib().mo_philox_raw(_p(ctr), _p(key), _p(out))
+    return out
+
+
+def philox_uniform32(seed, step) -> float:
+    return float(lib().mo_philox_uniform32(C.c_uint64(seed), C.c_uint64(step)))
+
+
+# ------------------------------------------------------------------------------------------
+# feature + NN
+# ------------------------------------------------------------------------------------------
+def so3_log(poses):
+    poses = _f32(poses).reshape(-1, 4, 4)
+    out = np.empty((poses.shape[0], 3), dtype=np.float32)
+    lib().mo_so3_log(C.c_int64(poses.shape[0]), _p(poses), _p(out))
+    return out
+
+
+def R3_SE3(poses, w: float = 0.01):
+    """tactile_tree.R3_SE3 (tactile_tree/tactile_tree.py:73-77)."""
+    poses = _f32(poses).reshape(-1, 4, 4)
+    out = np.empty((poses.shape[0], 6), dtype=np.float32)
+    lib().mo_se3_feature(C.c_int64(poses.shape[0]), _p(poses), C.c_float(np.float32(1.0 - w)),
+                         C.c_float(np.float32(w)), _p(out))
+    return out
+
+
+def nn6(query_feat, cb_feat):
+    q, c = _f32(query_feat), _f32(cb_feat)
+    idx = np.empty(q.shape[0], dtype=np.int32)
+    d2 = np.empty(q.shape[0], dtype=np.float32)
+    lib().mo_nn6(C.c_int64(q.shape[0]), C.c_int64(c.shape[0]), _p(q), _p(c), _p(idx), _p(d2))
+    return idx, d2
+
+
+def nn3_dist(poses, verts):
+    poses, verts = _f32(poses).reshape(-1, 4, 4), _f64(verts)
+    dist = np.empty(poses.shape[0], dtype=np.float64)
+    lib().mo_nn3(C.c_int64(poses.shape[0]), C.c_int64(verts.shape[0]), _p(poses), _p(verts), _p(dist))
+    return dist
+
+
+# ------------------------------------------------------------------------------------------
+# scores / weights
+# ------------------------------------------------------------------------------------------
+def score_codebook(emb, code):
+    """cosine of one code against every row (get_similarity(..., softmax=False) on all embeddings)."""
+    code = _f64(code).ravel()
+    emb = np.ascontiguousarray(emb)
+    out = np.empty(emb.shape[0], dtype=np.float64)
+    if emb.dtype == np.float32:
+        lib().mo_score_f32(C.c_int64(emb.shape[0]), C.c_int64(emb.shape[1]), _p(emb), _p(code), _p(out))
+    else:
+        emb = _f64(emb)
+        lib().mo_score_f64(C.c_int64(emb.shape[0]), C.c_int64(emb.shape[1]), _p(emb), _p(code), _p(out))
+    return out
+
+
+def softmax_weights(x, softmax: bool = True):
+    x = _f64(x).ravel()
+    w = np.empty_like(x)
+    applied = lib().mo_softmax(C.c_int64(x.shape[0]), _p(x), C.c_int(int(softmax)), _p(w))
+    return w, bool(applied)
+
+
+def get_similarity(code, targets, softmax: bool = True):
+    """particle_filter.get_similarity (particle_filter.py:449-469): targets (N,D) gathered rows."""
+    x = score_codebook(np.atleast_2d(targets), code)
+    if x.shape[0] == 1:
+        return x.reshape(())  # .squeeze() of a single target; softmax is skipped (max == min)
+    return softmax_weights(x, softmax)[0]
+
+
+def blocked_scan(w):
+    w = _f64(w).ravel()
+    out = np.empty_like(w)
+    total = lib().mo_blocked_scan(C.c_int64(w.shape[0]), _p(w), _p(out))
+    return out, float(total)
+
+
+def cdf(w):
+    w = _f64(w).ravel()
+    out = np.empty_like(w)
+    status = lib().mo_cdf(C.c_int64(w.shape[0]), _p(w), _p(out))
+    return out, int(status)
+
+
+def cdf_sequential(w):
+    """The reference-true order: ATen's multinomial does a sequential float64 running sum,
+    divides by the total and forces the last bucket to 1 (torch.multinomial CPU kernel)."""
+    w = _f64(w).ravel()
+    p = w / w.sum()
+    c = np.cumsum(p)
+    c = c / c[-1]
+    c[-1] = 1.0
+    return c
+
+
+def search_lower(cdf_arr, u):
+    cdf_arr, u = _f64(cdf_arr), _f64(u).ravel()
+    idx = np.empty(u.shape[0], dtype=np.int32)
+    lib().mo_search_lower(C.c_int64(cdf_arr.shape[0]), _p(cdf_arr), C.c_int64(u.shape[0]), _p(u), _p(idx))
+    return idx
+
+
+def search_systematic(cdf_arr, M, u32):
+    cdf_arr = _f64(cdf_arr)
+    idx = np.empty(M, dtype=np.int32)
+    lib().mo_search_systematic(C.c_int64(cdf_arr.shape[0]), _p(cdf_arr), C.c_int64(M), C.c_float(u32), _p(idx))
+    return idx
+
+
+def resample_indices(weights, mode: str = "weighted_random", u=None, u32=None):
+    """particle_filter.resampler index selection (particle_filter.py:230-307).
+
+    Returns (idx or None, status); status != 0 means the reference returns its input unchanged.
+    `u`: N float64 uniforms (torch.rand(N, dtype=float64) stream == torch.multinomial's);
+    `u32`: the single float32 torch.rand(1) of the low-variance modes.
+    """
+    c, status = cdf(weights)
+    if status:
+        return None, status
+    n = c.shape[0]
+    if mode == "weighted_random":
+        return search_lower(c, u), 0
+    if mode in ("low_var", "low_var_batch"):
+        return search_systematic(c, n, float(u32)), 0
+    raise ValueError(mode)
+
+
+def particle_rmse(poses, gt):
+    poses, gt = _f32(poses).reshape(-1, 4, 4), _f32(gt)
+    out = np.empty(2, dtype=np.float64)
+    lib().mo_rmse(C.c_int64(poses.shape[0]), _p(poses), _p(gt), _p(out))
+    return float(out[0]), float(out[1])
+
+
+# ------------------------------------------------------------------------------------------
+# host logic restated: init_filter, annealing
+# ------------------------------------------------------------------------------------------
+def init_filter_compose(gt, tn, rot_deg):
+    """init_filter (particle_filter.py:129-145): gt @ T(from_euler('zyx', rot, degrees), tn).
+
+    The reference builds Rn with scipy in float64 and torch promotes gt(f32) @ Tn(f32 storage of
+    the f64 matrix): Tn is allocated with gt's dtype, so Rn is rounded to float32 first.
+    """
+    from scipy.spatial.transform import Rotation
+    n = tn.shape[0]
+    Rn = Rotation.from_euler("zyx", np.asarray(rot_deg, dtype=np.float32), degrees=True).as_matrix()
+    Tn = np.zeros((n, 4, 4), dtype=np.float32)
+    Tn[:, :3, :3], Tn[:, :3, 3], Tn[:, 3, 3] = Rn.astype(np.float32), _f32(tn), 1.0
+    return (np.asarray(gt, dtype=np.float32)[None] @ Tn).astype(np.float32)
+
+
+class Annealer:
+    """particle_filter.annealing (particle_filter.py:405-447) on index sets.
+
+    `step(weights, var, floor)` returns the index array (into the current particles) of the
+    particles that survive, with duplicates appended for growth - same order as the reference
+    (`Particles.remove` keeps the original order, `add` appends in topk order).
+    """
+
+    def __init__(self):
+        self.particle_var = float("inf")
+        self.init_particles = None
+
+    def step(self, weights, var: float, floor: int = 1000):
+        w = np.asarray(weights)
+        n = w.shape[0]
+        keep = np.arange(n)
+        # `var` is a float32 torch scalar in the reference (torch.mean(cluster_stds)), so the
+        # ratio and the counts derived from it are float32 arithmetic.
+        var = np.float32(var)
+        if np.isinf(self.particle_var):
+            self.particle_var = var
+            self.init_particles = n
+            return keep
+        if var == 0.0:
+            return keep
+        ratio = np.float32(var / np.float32(self.particle_var))
+        self.particle_var = var
+        one = np.float32(1.0)
+        if ratio < 1:
+            num_remove = min(int(np.float32(one - ratio) * np.float32(n)), abs(n - floor), n // 3)
+            if not num_remove:
+                return keep
+            order = np.argsort(w, kind="stable")[:num_remove]
+            mask = np.ones(n, dtype=bool)
+            mask[order] = False
+            return keep[mask]
+        if ratio > 1:
+            num_increase = min(int(np.float32(ratio - one) * np.float32(n)), n // 3)
+            if num_increase + n > self.init_particles:
+                return keep
+            order = np.argsort(-w, kind="stable")[:num_increase]
+            return np.concatenate([keep, order])
+        return keep
+
+
+# ------------------------------------------------------------------------------------------
+# the per-frame loop body as one object
+# ------------------------------------------------------------------------------------------
+class OracleFilter:
+    """filter/filter.py:150-190 without clustering/annealing (the fixed-N headline step).
+
+    State: poses (N,4,4) f32, weights (N,) f64.  Random draws are supplied by the caller
+    (host mt19937 draws in parity mode, or the Philox spec streams in device mode).
+    """
+
+    def __init__(self, cb_poses, cb_embeddings, mesh_verts, pen_max=0.002):
+        self.cb_poses = _f32(cb_poses)
+        self.cb_feat = R3_SE3(self.cb_poses)
+        self.emb = np.ascontiguousarray(cb_embeddings)
+        self.verts = _f64(mesh_verts)
+        self.pen_max = float(pen_max)
+
+    def SE3_NN_idx(self, poses):
+        return nn6(R3_SE3(poses), self.cb_feat)[0]
+
+    def step(self, poses, odom, code, tn, rot_deg, u=None, mode="weighted_random", u32=None, softmax=True):
+        """Returns dict with every intermediate the parity tests compare."""
+        out = {}
+        p1 = propagate(poses, odom, tn, rot_deg)
+        out["poses_prop"] = p1
+        feat = R3_SE3(p1)
+        idx, d2 = nn6(feat, self.cb_feat)
+        out["feat"], out["nn_idx"], out["nn_d2"] = feat, idx, d2
+        scores = score_codebook(self.emb, code)
+        out["scores"] = scores
+        x = scores[idx]
+        w, _ = softmax_weights(x, softmax)
+        out["weights_pre"] = w.copy()
+        dist = nn3_dist(p1, self.verts)
+        mask = ~(dist > self.pen_max)
+        out["dist"], out["mask"] = dist, mask
+        w = w * mask
+        out["weights"] = w
+        out["drifted"] = bool(mask.sum() == 0)
+        ridx, status = resample_indices(w, mode, u=u, u32=u32)
+        out["status"] = status
+        if status:
+            out["ridx"] = np.arange(len(w), dtype=np.int32)
+        else:
+            out["ridx"] = ridx
+        out["poses"] = p1[out["ridx"]]
+        out["weights_res"] = w[out["ridx"]]
+        out["nn_idx_res"] = idx[out["ridx"]]
+        return out

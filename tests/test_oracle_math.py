@@ -1,0 +1,125 @@
+"""Independent pins for the oracle pieces whose reference implementation is third-party and absent
+from the checkout (theseus SO3.log_map, pynanoflann KD-tree) - checked against scipy - and for the
+self-contained float32 elementary functions of the arithmetic spec.  CPU-only."""
+import numpy as np
+from scipy.spatial import cKDTree
+from scipy.spatial.transform import Rotation
+
+
+def _poses_from_R(R, t=None):
+    n = R.shape[0]
+    P = np.zeros((n, 4, 4), dtype=np.float32)
+    P[:, :3, :3] = R
+    P[:, 3, 3] = 1
+    if t is not None:
+        P[:, :3, 3] = t
+    return P
+
+
+def test_sincos_atan2_log_accuracy(oracle):
+    rng = np.random.default_rng(0)
+    a = np.concatenate([rng.uniform(-20, 20, 4000), rng.standard_normal(2000) * 1e-2, [0.0, np.pi, -np.pi / 2]]).astype(np.float32)
+    s, c = oracle.sincosf(a)
+    assert np.max(np.abs(s - np.sin(a.astype(np.float64)))) < 2.5e-7
+    assert np.max(np.abs(c - np.cos(a.astype(np.float64)))) < 2.5e-7
+    y = rng.standard_normal(4000).astype(np.float32)
+    x = rng.standard_normal(4000).astype(np.float32)
+    t = oracle.atan2f(y, x)
+    assert np.max(np.abs(t - np.arctan2(y.astype(np.float64), x.astype(np.float64)))) < 5e-7
+    assert oracle.atan2f([0.0], [1.0])[0] == 0.0
+    assert abs(oracle.atan2f([0.0], [-1.0])[0] - np.pi) < 1e-6
+    v = np.exp(rng.uniform(-16, 0, 4000)).astype(np.float32)
+    lg = oracle.logf(v)
+    assert np.max(np.abs(lg - np.log(v.astype(np.float64))) / np.maximum(1.0, np.abs(np.log(v.astype(np.float64))))) < 3e-7
+
+
+def test_so3_log_vs_scipy(oracle):
+    rng = np.random.default_rng(1)
+    rv = rng.standard_normal((5000, 3))
+    rv = rv / np.linalg.norm(rv, axis=1, keepdims=True) * rng.uniform(0, np.pi * 0.98, size=(5000, 1))
+    R = Rotation.from_rotvec(rv).as_matrix().astype(np.float32)
+    w = oracle.so3_log(_poses_from_R(R))
+    ref = Rotation.from_matrix(R.astype(np.float64)).as_rotvec()
+    assert np.max(np.abs(w - ref)) < 2e-5
+    # near zero
+    rv0 = rng.standard_normal((2000, 3)) * 1e-3
+    R0 = Rotation.from_rotvec(rv0).as_matrix().astype(np.float32)
+    w0 = oracle.so3_log(_poses_from_R(R0))
+    assert np.max(np.abs(w0 - Rotation.from_matrix(R0.astype(np.float64)).as_rotvec())) < 2e-7
+    assert np.all(oracle.so3_log(_poses_from_R(np.eye(3)[None])) == 0)
+    # near pi: the rotation vector is defined up to sign at exactly pi; compare the rotations
+    ax = rng.standard_normal((2000, 3))
+    ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+    ang = np.pi - rng.uniform(0, 0.1, size=(2000, 1))
+    Rp = Rotation.from_rotvec(ax * ang).as_matrix().astype(np.float32)
+    wp = oracle.so3_log(_poses_from_R(Rp))
+    back = Rotation.from_rotvec(wp.astype(np.float64)).as_matrix()
+    assert np.max(np.abs(back - Rp)) < 2e-3
+    assert np.max(np.abs(np.linalg.norm(wp, axis=1) - ang[:, 0])) < 2e-3
+
+
+def test_r3_se3_feature(oracle):
+    rng = np.random.default_rng(2)
+    R = Rotation.random(1000, random_state=3).as_matrix().astype(np.float32)
+    t = rng.uniform(-0.1, 0.1, size=(1000, 3)).astype(np.float32)
+    f = oracle.R3_SE3(_poses_from_R(R, t))
+    ref = np.concatenate([0.99 * t, 0.01 * Rotation.from_matrix(R.astype(np.float64)).as_rotvec()], axis=1)
+    ok = np.linalg.norm(Rotation.from_matrix(R.astype(np.float64)).as_rotvec(), axis=1) < 3.0
+    assert np.max(np.abs(f[ok] - ref[ok])) < 1e-6
+
+
+def test_nn6_exact_vs_ckdtree(oracle):
+    from midastouch_amd.synthetic import make_codebook
+    cb = make_codebook(K=3000, D=8, seed=5, mode="iid")
+    feat = oracle.R3_SE3(cb.poses)
+    rng = np.random.default_rng(4)
+    q = feat[rng.integers(0, 3000, 2000)] + rng.standard_normal((2000, 6)).astype(np.float32) * 1e-3
+    idx, d2 = oracle.nn6(q, feat)
+    dk, ik = cKDTree(feat.astype(np.float64)).query(q.astype(np.float64), k=1)
+    # exact NN: same distance as the float64 tree (to float32 rounding); index equal except near-ties
+    np.testing.assert_allclose(np.sqrt(d2.astype(np.float64)), dk, rtol=2e-5, atol=1e-9)
+    assert np.mean(idx == ik) > 0.999
+    # duplicates: ties resolve to the smallest index
+    feat2 = np.concatenate([feat[:10], feat[:10]])
+    idx2, _ = oracle.nn6(feat[:10], feat2)
+    assert np.array_equal(idx2, np.arange(10))
+
+
+def test_blocked_scan_structure(oracle):
+    rng = np.random.default_rng(6)
+    for n in (1, 15, 16, 17, 4095, 4096, 4097, 10000):
+        w = rng.uniform(size=n)
+        pre, total = oracle.blocked_scan(w)
+        assert total == pre[-1]
+        np.testing.assert_allclose(pre, np.cumsum(w), rtol=1e-13)
+        # restate the order with numpy: chunk-local cumsum, sequential chunk totals per block, blocks
+        pad = (-n) % 4096
+        wp = np.concatenate([w, np.zeros(pad)]).reshape(-1, 256, 16)
+        local = np.cumsum(wp, axis=2)
+        tot = local[:, :, -1]
+        tp = np.concatenate([np.zeros((tot.shape[0], 1)), np.cumsum(tot, axis=1)[:, :-1]], axis=1)
+        W = np.cumsum(tot, axis=1)[:, -1]
+        bp = np.concatenate([[0.0], np.cumsum(W)[:-1]])
+        expect = (bp[:, None, None] + (tp[:, :, None] + local)).reshape(-1)[:n]
+        assert np.array_equal(pre, expect)
+
+
+def test_philox_streams(oracle):
+    tn, rot = oracle.philox_noise(200000, 4000, 7, 1.0, 1.0)
+    z = np.concatenate([tn.ravel(), rot.ravel()]).astype(np.float64)
+    assert abs(z.mean()) < 5e-3 and abs(z.std() - 1.0) < 5e-3
+    assert abs(np.mean(z**4) - 3.0) < 0.05
+    u = oracle.philox_uniform64(200000, 4000, 7)
+    assert u.min() >= 0.0 and u.max() < 1.0 and abs(u.mean() - 0.5) < 3e-3
+    assert len(np.unique(u)) == len(u)
+    # known-answer vectors of Philox4x32-10 (Random123 kat_vectors)
+    kat = [
+        ([0, 0, 0, 0], [0, 0], [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]),
+        ([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2, [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]),
+        ([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0],
+         [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]),
+    ]
+    for ctr, key, exp in kat:
+        assert [int(v) for v in oracle.philox_raw(ctr, key)] == exp
+    u2 = oracle.philox_uniform64(4, 4000, 8)
+    assert not np.array_equal(u[:4], u2)
