@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py - filter steps/s of the MidasTouch particle-filter hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], "c2"): 004_sugar_box synthetic trajectory, N = 100 000 particles
+per GPU, 50 000 x 512-d codebook.  A step = one frame of the filter loop body
+(score codebook -> propagate -> feature -> NN -> softmax weights -> prune -> CDF -> resample -> gather,
+rmse epilogue), inputs (codebook, trajectory, particles) resident in HBM, random draws from the
+on-device Philox streams (real work inside the timed region).
+
+Multi-GPU (N>1): one filter whose particles are sharded across the ranks (N_total = gpus x 100k,
+weak scaling); per frame the ranks exchange (max, sum-exp, weight-total) and the resampled particles
+over RCCL.  `value` = frames processed by all ranks / wall time = gpus x steps / t.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec peak (6.3 TB/s achievable)
+PER_PARTICLE_UPDATE = 140  # bytes, SURVEY.md section 8(d): propagate 128 + idx w 4 + score gather 4 + dist w 4
+PER_PARTICLE_TAIL = 200    # the remaining 200 of the 340 B/particle
+
+
+def algorithmic_bytes(N, K, D, B=1):
+    """Bytes = K(4D+24) + B(4D+4K) + B*N*340, split per kernel group."""
+    score = K * 4 * D + B * (4 * D + 4 * K)
+    update = K * 24 + B * N * PER_PARTICLE_UPDATE
+    tail = B * N * PER_PARTICLE_TAIL
+    return {"score_codebook": score, "particle_update": update, "tail": tail, "step": score + update + tail}
+
+
+def cpu_baseline(cb, traj, N, budget_s=12.0, max_steps=12):
+    """The reference-shaped CPU path (oracle/ref_shaped.py) on the host cores, bounded sample."""
+    from oracle.ref_shaped import RefShapedFilter
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    flt = RefShapedFilter(cb.poses, cb.embeddings, cb.mesh_vertices)
+    rng = np.random.default_rng(0)
+    poses = torch.as_tensor(cb.poses[rng.integers(0, cb.K, N)])
+    odoms, codes = torch.as_tensor(traj.odoms), torch.as_tensor(traj.codes)
+    torch.manual_seed(0)
+    poses, _ = flt.step(poses, odoms[1], codes[1][None])  # warm-up (thread pools, page faults)
+    t0 = time.perf_counter()
+    done = 0
+    while done < max_steps and (time.perf_counter() - t0) < budget_s:
+        t = 2 + done % (len(odoms) - 2)
+        poses, _ = flt.step(poses, odoms[t], codes[t][None])
+        done += 1
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"{done} frames of the same workload (N={N}, K={cb.K}, D={cb.D}) through the reference-shaped "
+                      f"torch-CPU path (gather (N,D) f64 + cosine + softmax + multinomial; scipy cKDTree workers=-1 "
+                      f"stands in for pynanoflann n_jobs=16), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--particles", type=int, default=100_000, help="particles per GPU")
+    ap.add_argument("--codebook", type=int, default=50_000)
+    ap.add_argument("--dim", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from midastouch_amd.engine import FilterEngine
+    from midastouch_amd.synthetic import make_codebook, make_trajectory
+
+    N, K, D = args.particles, args.codebook, args.dim
+    cb = make_codebook("004_sugar_box", K=K, D=D, seed=1001)
+    T = min(args.warmup + args.steps + 2, 512)
+    traj = make_trajectory(cb, T=T, seed=2001)
+
+    if world == 1:
+        eng = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4000, device=dev)
+    else:
+        from midastouch_amd.dist import ShardedFilterEngine
+        eng = ShardedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4000, device=dev)
+    rng = np.random.default_rng(100 + rank)
+    # particles start on codebook poses within ~2 cm of the first ground-truth pose
+    d0 = np.linalg.norm(cb.poses[:, :3, 3] - traj.gt_poses[0][:3, 3], axis=1)
+    near = np.argsort(d0)[: max(64, K // 20)]
+    eng.set_particles(torch.as_tensor(cb.poses[rng.choice(near, N)]))
+    eng.project_to_codebook()
+    odoms = torch.as_tensor(traj.odoms).to(dev)
+    codes = torch.as_tensor(traj.codes).to(dev)
+    gts = torch.as_tensor(traj.gt_poses).to(dev)
+
+    def frame(i):
+        t = 1 + i % (T - 1)
+        eng.step(odoms[t], codes[t], gt=gts[t])
+
+    for i in range(args.warmup):
+        frame(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        frame(args.warmup + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    status = eng.status.cpu().numpy().tolist()
+
+    ab = algorithmic_bytes(N, K, D)
+    out = {
+        "metric": "filter_steps_per_sec", "value": world * args.steps / dt, "unit": "steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "c2: 004_sugar_box synthetic trajectory, N=%d particles/GPU x K=%d x D=%d codebook, "
+                               "device Philox draws, multinomial resample" % (N, K, D),
+                   "particles_per_gpu": N, "particles_total": N * world, "codebook_rows": K, "embedding_dim": D,
+                   "parallelism": "single" if world == 1 else "particle-sharded x%d" % world,
+                   "arith": "f32 poses/NN, f64 scores/weights/CDF", "last_status": status},
+    }
+
+    # per-kernel HIP-event timing (separate pass so the events do not perturb the headline)
+    if world == 1 and not args.no_profile:
+        eng.profile(True)
+        eng.profile_read(reset=True)
+        nprof = min(50, args.steps)
+        for i in range(nprof):
+            frame(i)
+        ms, calls = eng.profile_read(reset=True)
+        eng.profile(False)
+        per = {k: v / calls for k, v in ms.items()}
+        groups = {"score_codebook": per["score_codebook"], "particle_update": per["particle_update"],
+                  "tail": per["tail_exp"] + per["tail_scan"] + per["tail_cdf"] + per["tail_resample"]}
+        dom = max(("score_codebook", "particle_update"), key=lambda k: groups[k])
+        achieved = ab[dom] / (groups[dom] * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "algorithmic_bytes_per_launch": ab[dom], "kernel_ms": groups[dom],
+                           "per_kernel_ms": per,
+                           "step_bytes": ab["step"],
+                           "step_frac": ab["step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cb, traj, N)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

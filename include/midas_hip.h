@@ -1,0 +1,176 @@
+/*
+ * midas_hip.h - C ABI of libmidas_hip.so, the MI355X (gfx950) implementation of the MidasTouch
+ * particle-filter hot path.
+ *
+ * The reference (facebookresearch/MidasTouch) has NO FFI for this path: it is reached by direct
+ * Python method calls on two classes from the Hydra runner (midastouch/filter/filter.py:82,89-93,
+ * 155,159-160,170-173,176,183-190).  This header is therefore the boundary a maintainer binds with
+ * ctypes underneath those classes; each entry point cites the reference
+ * call site whose arithmetic it replaces (paths relative to /root/reference/midastouch).
+ *
+ * Conventions
+ *  - every pointer named *_dev is a DEVICE pointer owned by the caller (e.g. torch tensor data_ptr());
+ *    the library allocates only its own handles and scratch;
+ *  - every call is asynchronous on the context's HIP stream unless stated otherwise;
+ *  - every function returns an int status: 0 = MIDAS_OK, < 0 = error (midas_strerror); nothing throws
+ *    across the boundary; midas_last_error(ctx) holds the detailed text of the last failure;
+ *  - a context is not thread-safe; use one context per thread / stream.  Calls may come from any
+ *    host thread (the reference runs its filter on a worker thread, filter/filter.py:269-273).
+ */
+#ifndef MIDAS_HIP_H
+#define MIDAS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIDAS_OK 0
+#define MIDAS_ERR_INVALID (-1)  /* bad argument */
+#define MIDAS_ERR_HIP (-2)      /* a HIP runtime call failed */
+#define MIDAS_ERR_NOMEM (-3)    /* device allocation failed */
+#define MIDAS_ERR_NODEVICE (-4) /* no usable gfx950 device */
+
+#define MIDAS_F32 0
+#define MIDAS_F64 1
+
+#define MIDAS_RESAMPLE_MULTINOMIAL 0 /* "weighted_random" (default), modules/particle_filter.py:243-249 */
+#define MIDAS_RESAMPLE_SYSTEMATIC 1  /* "low_var" / "low_var_batch", modules/particle_filter.py:251-307 */
+
+typedef struct midas_ctx midas_ctx;
+typedef struct midas_codebook midas_codebook;
+typedef struct midas_tree midas_tree;
+
+/* ---- context --------------------------------------------------------------------------------- */
+/* `hip_stream` is a hipStream_t (NULL = the library creates its own stream). */
+int midas_ctx_create(int device, void* hip_stream, midas_ctx** out);
+int midas_ctx_destroy(midas_ctx* ctx);
+int midas_ctx_set_stream(midas_ctx* ctx, void* hip_stream);
+int midas_sync(midas_ctx* ctx); /* hipStreamSynchronize */
+const char* midas_strerror(int code);
+const char* midas_last_error(const midas_ctx* ctx);
+const char* midas_version(void);
+
+/* ---- codebook: embeddings + cosine scores  (K1) ---------------------------------------------- */
+/* Wraps (does not copy) a K x D row-major embedding matrix and precomputes max(|C_k|, 1e-8).
+ * Replaces tactile_tree.embeddings (tactile_tree/tactile_tree.py:17-19,29-32). dtype MIDAS_F32/F64. */
+int midas_codebook_create(midas_ctx* ctx, int64_t K, int32_t D, const void* emb_dev, int32_t dtype,
+                          midas_codebook** out);
+int midas_codebook_destroy(midas_codebook* cb);
+/* scores[b*K + k] = cos(codes[b], C_k), float64.  One pass over the codebook per call.
+ * Replaces cosine_similarity over gathered rows (modules/particle_filter.py:455-457) and the
+ * heat-map call (filter/filter.py:213-215).  B >= 1 tactile codes (B*D doubles). */
+int midas_score(midas_ctx* ctx, const midas_codebook* cb, int32_t B, const double* codes_dev,
+                double* scores_dev);
+
+/* ---- SE(3) feature and exact nearest neighbour  (K3, K4) ------------------------------------- */
+/* feat6 = [ (1-w) t , w log(R) ]  - R3_SE3 (tactile_tree/tactile_tree.py:73-77, modules/pose.py:19-23) */
+int midas_se3_feature(midas_ctx* ctx, int64_t N, const float* poses_dev, float w, float* feat6_dev);
+/* Static KD-tree over K points: dim 6 -> float32 (codebook features, replaces pynanoflann
+ * tactile_tree.init_tree, tactile_tree/tactile_tree.py:34-41); dim 3 -> float64 (mesh vertices, replaces
+ * sklearn KDTree, modules/particle_filter.py:108-110).  Synchronous (built on the host once). */
+int midas_tree_build(midas_ctx* ctx, int32_t dim, int64_t K, const void* points_dev, midas_tree** out);
+int midas_tree_destroy(midas_tree* tree);
+/* idx[n] = argmin_k |feat6[n] - F_k|^2 (ties -> smallest k); hint_dev (nullable) = a candidate index
+ * per query that seeds the search bound; d2_dev nullable.  Replaces kneighbors (tactile_tree.py:50-52). */
+int midas_nn6(midas_ctx* ctx, const midas_tree* tree, int64_t N, const float* feat6_dev,
+              const int32_t* hint_dev, int32_t* idx_dev, float* d2_dev);
+/* dist[n] = float64 distance from pose n's translation to the nearest vertex.
+ * Replaces mesh_kdtree.query (modules/particle_filter.py:386-392). */
+int midas_nn3(midas_ctx* ctx, const midas_tree* tree, int64_t N, const float* poses_dev, double* dist_dev);
+
+/* ---- motion model  (K2) ---------------------------------------------------------------------- */
+/* poses_out[n] = poses_in[n] @ (odom @ Tn(tn[n], Rz Ry Rx(deg2rad(rot[n])))).
+ * tn_dev/rot_dev (N x 3 float32 each) are the already-scaled host draws of add_noise_to_odom
+ * (modules/particle_filter.py:326-335); when both are NULL the kernel draws them itself from the
+ * Philox spec streams keyed by (seed, step) and scales by std_t / std_r.
+ * Replaces add_noise_to_odom + the compose in motionModel (modules/particle_filter.py:319-345,370-375). */
+int midas_propagate(midas_ctx* ctx, int64_t N, const float* poses_in_dev, float* poses_out_dev,
+                    const float* odom16_dev, const float* tn_dev, const float* rot_dev, float std_t,
+                    float std_r, uint64_t seed, uint64_t step);
+/* flag[n] = 1 when pose n's rotation gives a NaN / zero-norm quaternion (check_quats,
+ * modules/particle_filter.py:347-357); count_dev[0] = number of flagged particles. */
+int midas_check_poses(midas_ctx* ctx, int64_t N, const float* poses_dev, uint8_t* flag_dev,
+                      int32_t* count_dev);
+
+/* ---- weights  (K5) --------------------------------------------------------------------------- */
+/* out[n] = table[idx[n]] (float64): x_n = scores[nn_idx[n]] */
+int midas_gather_f64(midas_ctx* ctx, int64_t N, const double* table_dev, const int32_t* idx_dev,
+                     double* out_dev);
+/* get_similarity tail (modules/particle_filter.py:459-468): if softmax and |max-min| > 1e-8,
+ * w = exp(x-max)/sum exp(x-max); else w = x.  In place allowed. */
+int midas_softmax(midas_ctx* ctx, int64_t N, const double* x_dev, int32_t softmax, double* w_dev);
+/* remove_invalid_particles tail (modules/particle_filter.py:394-402): w[n] *= !(dist[n] > thr);
+ * nvalid_dev[0] = number of particles kept (0 => "drifted"). */
+int midas_prune(midas_ctx* ctx, int64_t N, double* w_dev, const double* dist_dev, double thr,
+                int32_t* nvalid_dev);
+
+/* ---- resample  (K6, K7, K8) ------------------------------------------------------------------ */
+/* cdf = blocked_prefix(w) / total, cdf[N-1] = 1 (float64, fixed summation order - DESIGN.md).
+ * status_dev[0] = 0 ok, 1 all weights zero, 2 NaN present (resampler returns its input unchanged,
+ * modules/particle_filter.py:240-241).  Replaces :237-239,252 and the cumsum inside torch.multinomial. */
+int midas_cdf(midas_ctx* ctx, int64_t N, const double* w_dev, double* cdf_dev, int32_t* status_dev);
+/* idx[i] for M output slots. MULTINOMIAL: first j with cdf[j] >= u[i]; u_dev = M float64 uniforms
+ * (NULL -> Philox spec stream (seed, step)).  SYSTEMATIC: first j with cdf[j] > fmod(i/M + u32/M, 1);
+ * u32 < 0 -> Philox.  Replaces torch.multinomial / the low_var loop (particle_filter.py:245,295-303). */
+int midas_resample_search(midas_ctx* ctx, int64_t N, const double* cdf_dev, int64_t M, int32_t mode,
+                          const double* u_dev, float u32, uint64_t seed, uint64_t step,
+                          int32_t* idx_dev);
+/* dst[i] = src[idx[i]] for rows of row_bytes bytes (poses 64, weights 8, labels 4/8).
+ * Replaces the fancy-index gathers (modules/particle_filter.py:246-248, tactile_tree.py:54-58). */
+int midas_gather_rows(midas_ctx* ctx, int64_t M, const int32_t* idx_dev, const void* src_dev,
+                      void* dst_dev, int32_t row_bytes);
+
+/* ---- metric epilogue ------------------------------------------------------------------------- */
+/* out2 = { rmse_t [m], rmse_r [deg] } float64 - particle_rmse (modules/particle_filter.py:472-496). */
+int midas_rmse(midas_ctx* ctx, int64_t N, const float* poses_dev, const float* gt16_dev,
+               double* out2_dev);
+
+/* ---- the fused per-frame step ---------------------------------------------------------------- */
+/* One call = filter/filter.py:150-190 minus clustering/annealing:
+ *   score codebook -> propagate -> feature -> NN -> x = s[idx] -> softmax -> prune -> cdf ->
+ *   resample search -> gather (poses, weights, hints).  All device-resident, no host sync. */
+typedef struct midas_step_args {
+    int64_t N;
+    const float* poses_in_dev;   /* N x 16 */
+    float* poses_prop_dev;       /* N x 16 scratch: propagated, pre-resample poses */
+    float* poses_out_dev;        /* N x 16 resampled poses (may alias poses_in_dev) */
+    double* weights_dev;         /* N: softmax weights x prune mask, BEFORE resampling */
+    double* weights_out_dev;     /* N: the same, gathered by the resample indices */
+    const int32_t* hint_in_dev;  /* N or NULL: NN index of each particle's ancestor (search seed) */
+    int32_t* nn_idx_dev;         /* N: nearest codebook entry of each propagated particle */
+    int32_t* hint_out_dev;       /* N: nn_idx gathered by the resample indices */
+    int32_t* ridx_dev;           /* N: resample indices */
+    const float* odom16_dev;     /* 16 */
+    const double* code_dev;      /* D: tactile code of this frame */
+    const float* gt16_dev;       /* 16 or NULL: ground truth pose for the rmse epilogue */
+    double* rmse_dev;            /* 2 or NULL */
+    const float* tn_dev;         /* parity mode: host draws (see midas_propagate); NULL -> Philox */
+    const float* rot_dev;
+    const double* u_dev;         /* parity mode: N float64 uniforms; NULL -> Philox */
+    float u32;                   /* systematic offset draw; < 0 -> Philox */
+    float std_t, std_r;
+    uint64_t seed, step;
+    double prune_thr;            /* pen_max (config/tdn/default.yaml:18) */
+    int32_t softmax;
+    int32_t resample_mode;
+    int32_t* status_dev;         /* [0] cdf status (see midas_cdf), [1] particles kept by the prune */
+} midas_step_args;
+
+int midas_filter_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
+                      const midas_tree* tree3, const midas_step_args* args);
+
+/* per-kernel timing of midas_filter_step (HIP events on the context stream).  When enabled every
+ * kernel of the step is bracketed by events; midas_profile_read synchronises and returns the
+ * accumulated milliseconds per kernel slot since the last reset. */
+#define MIDAS_PROF_SLOTS 8
+int midas_profile_enable(midas_ctx* ctx, int32_t on);
+int midas_profile_read(midas_ctx* ctx, double* ms_out /*MIDAS_PROF_SLOTS*/, int64_t* calls_out,
+                       int32_t reset);
+const char* midas_profile_slot_name(int32_t slot);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIDAS_HIP_H */

@@ -1,0 +1,198 @@
+"""ctypes binding of libmidas_hip.so (include/midas_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing, cannot be loaded, or no
+gfx950 device is visible, every entry point raises.  torch is used only as the owner of device
+memory (`tensor.data_ptr()`) and of the HIP stream the kernels are enqueued on.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libmidas_hip.so")
+
+MIDAS_F32, MIDAS_F64 = 0, 1
+RESAMPLE_MULTINOMIAL, RESAMPLE_SYSTEMATIC = 0, 1
+PROF_SLOTS = 8
+
+
+class MidasError(RuntimeError):
+    pass
+
+
+class StepArgs(C.Structure):
+    """midas_step_args (include/midas_hip.h)."""
+
+    _fields_ = [
+        ("N", C.c_int64),
+        ("poses_in", C.c_void_p),
+        ("poses_prop", C.c_void_p),
+        ("poses_out", C.c_void_p),
+        ("weights", C.c_void_p),
+        ("weights_out", C.c_void_p),
+        ("hint_in", C.c_void_p),
+        ("nn_idx", C.c_void_p),
+        ("hint_out", C.c_void_p),
+        ("ridx", C.c_void_p),
+        ("odom16", C.c_void_p),
+        ("code", C.c_void_p),
+        ("gt16", C.c_void_p),
+        ("rmse", C.c_void_p),
+        ("tn", C.c_void_p),
+        ("rot", C.c_void_p),
+        ("u", C.c_void_p),
+        ("u32", C.c_float),
+        ("std_t", C.c_float),
+        ("std_r", C.c_float),
+        ("seed", C.c_uint64),
+        ("step", C.c_uint64),
+        ("prune_thr", C.c_double),
+        ("softmax", C.c_int32),
+        ("resample_mode", C.c_int32),
+        ("status", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/midas_hip.h declares
+_P, _I32, _I64, _U64, _F, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
+SIGNATURES = {
+    "midas_ctx_create": (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
+    "midas_ctx_destroy": (C.c_int, [_P]),
+    "midas_ctx_set_stream": (C.c_int, [_P, _P]),
+    "midas_sync": (C.c_int, [_P]),
+    "midas_strerror": (C.c_char_p, [C.c_int]),
+    "midas_last_error": (C.c_char_p, [_P]),
+    "midas_version": (C.c_char_p, []),
+    "midas_codebook_create": (C.c_int, [_P, _I64, _I32, _P, _I32, C.POINTER(_P)]),
+    "midas_codebook_destroy": (C.c_int, [_P]),
+    "midas_score": (C.c_int, [_P, _P, _I32, _P, _P]),
+    "midas_se3_feature": (C.c_int, [_P, _I64, _P, _F, _P]),
+    "midas_tree_build": (C.c_int, [_P, _I32, _I64, _P, C.POINTER(_P)]),
+    "midas_tree_destroy": (C.c_int, [_P]),
+    "midas_nn6": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P]),
+    "midas_nn3": (C.c_int, [_P, _P, _I64, _P, _P]),
+    "midas_propagate": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P, _F, _F, _U64, _U64]),
+    "midas_check_poses": (C.c_int, [_P, _I64, _P, _P, _P]),
+    "midas_gather_f64": (C.c_int, [_P, _I64, _P, _P, _P]),
+    "midas_softmax": (C.c_int, [_P, _I64, _P, _I32, _P]),
+    "midas_prune": (C.c_int, [_P, _I64, _P, _P, _D, _P]),
+    "midas_cdf": (C.c_int, [_P, _I64, _P, _P, _P]),
+    "midas_resample_search": (C.c_int, [_P, _I64, _P, _I64, _I32, _P, _F, _U64, _U64, _P]),
+    "midas_gather_rows": (C.c_int, [_P, _I64, _P, _P, _P, _I32]),
+    "midas_rmse": (C.c_int, [_P, _I64, _P, _P, _P]),
+    "midas_filter_step": (C.c_int, [_P, _P, _P, _P, C.POINTER(StepArgs)]),
+    "midas_profile_enable": (C.c_int, [_P, _I32]),
+    "midas_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64), _I32]),
+    "midas_profile_slot_name": (C.c_char_p, [_I32]),
+}
+
+
+def build(force: bool = False) -> str:
+    """Compile libmidas_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "midas_hip.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", CSRC, "-j4", "-s"] + (["-B"] if force else []), check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load the library and bind every declared symbol; raises MidasError when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MidasError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise MidasError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise MidasError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """One midas_ctx bound to a device and to torch's current HIP stream on that device."""
+
+    def __init__(self, device=None):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise MidasError("no HIP device visible (torch.cuda.is_available() is False); the filter kernels "
+                             "run only on an MI355X - there is no CPU fallback")
+        self.lib = load()
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if dev.type != "cuda":
+            raise MidasError(f"device must be a HIP device, got {dev}")
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        self._stream = torch.cuda.current_stream(self.device)
+        h = C.c_void_p()
+        rc = self.lib.midas_ctx_create(self.device.index, C.c_void_p(self._stream.cuda_stream), C.byref(h))
+        if rc != 0:
+            raise MidasError(f"midas_ctx_create failed: {self.lib.midas_strerror(rc).decode()}")
+        self.h = h
+
+    def check(self, rc: int):
+        if rc != 0:
+            detail = self.lib.midas_last_error(self.h)
+            raise MidasError(detail.decode() if detail else self.lib.midas_strerror(rc).decode())
+
+    def call(self, name: str, *args):
+        self.check(getattr(self.lib, name)(self.h, *args))
+
+    def sync(self):
+        self.call("midas_sync")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.midas_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_contexts = {}
+
+
+def context(device=None) -> Context:
+    """Process-wide context per device (created on first use)."""
+    import torch
+
+    if not torch.cuda.is_available():
+        raise MidasError("no HIP device visible (torch.cuda.is_available() is False); the filter kernels "
+                         "run only on an MI355X - there is no CPU fallback")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.type != "cuda":
+        raise MidasError(f"tensors must live on a HIP device, got {dev}; there is no CPU fallback")
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _contexts:
+        _contexts[idx] = Context(torch.device("cuda", idx))
+    return _contexts[idx]

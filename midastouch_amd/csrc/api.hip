@@ -1,0 +1,428 @@
+// api.hip - context, scratch, profiling and the extern "C" surface of libmidas_hip.so.
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "midas_internal.hpp"
+
+using namespace midas;
+
+namespace midas {
+int tree_build_impl(midas_ctx* ctx, int32_t dim, int64_t K, const void* points_dev, midas_tree* out);
+}
+
+// ---- scratch: bump allocator over library-owned device chunks, reset at every API entry ----------
+struct ScratchChunk { void* p; size_t cap; };
+struct ScratchState {
+    std::vector<ScratchChunk> chunks;
+    size_t used = 0;   // in chunks.back()
+    size_t total = 0;  // bytes requested since the last reset
+};
+static ScratchState* scratch_of(midas_ctx* ctx) { return reinterpret_cast<ScratchState*>(ctx->scratch); }
+
+static int scratch_reset(midas_ctx* ctx) {
+    ScratchState* s = scratch_of(ctx);
+    if (s->chunks.size() > 1) {  // consolidate: one chunk large enough for the last call's total
+        MIDAS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        for (auto& c : s->chunks) (void)hipFree(c.p);
+        s->chunks.clear();
+        void* p = nullptr;
+        size_t cap = s->total + (s->total >> 2) + 4096;
+        if (hipMalloc(&p, cap) != hipSuccess) return midas_set_error(ctx, MIDAS_ERR_NOMEM, "hipMalloc(scratch)", "out of device memory");
+        s->chunks.push_back({p, cap});
+    }
+    s->used = 0;
+    s->total = 0;
+    return MIDAS_OK;
+}
+
+int midas_scratch(midas_ctx* ctx, size_t bytes, void** out) {
+    ScratchState* s = scratch_of(ctx);
+    bytes = (bytes + 255) & ~(size_t)255;
+    s->total += bytes;
+    if (s->chunks.empty() || s->used + bytes > s->chunks.back().cap) {
+        void* p = nullptr;
+        size_t cap = bytes > (size_t)(1 << 20) ? bytes : (size_t)(1 << 20);
+        if (hipMalloc(&p, cap) != hipSuccess) return midas_set_error(ctx, MIDAS_ERR_NOMEM, "hipMalloc(scratch)", "out of device memory");
+        s->chunks.push_back({p, cap});
+        s->used = 0;
+    }
+    *out = (char*)s->chunks.back().p + s->used;
+    s->used += bytes;
+    return MIDAS_OK;
+}
+
+int midas_set_error(midas_ctx* ctx, int code, const char* what, const char* detail) {
+    if (ctx) {
+        ctx->last_error = std::string(midas_strerror(code)) + ": " + (what ? what : "") + " (" + (detail ? detail : "") + ")";
+    }
+    return code;
+}
+
+namespace midas {
+void prof_mark(midas_ctx* ctx, int slot) {
+    if (ctx->prof && ctx->ev_ready && slot <= MIDAS_PROF_SLOTS) (void)hipEventRecord(ctx->ev[slot], ctx->stream);
+}
+}  // namespace midas
+
+static const char* kSlotNames[MIDAS_PROF_SLOTS] = {
+    "score_codebook", "particle_update", "tail_exp", "tail_scan", "tail_cdf", "tail_resample", "", ""};
+
+// entry guard: bind the device, reset the scratch bump pointer
+#define MIDAS_ENTER(ctx)                                                     \
+    do {                                                                     \
+        if (!(ctx)) return MIDAS_ERR_INVALID;                                \
+        MIDAS_HIP_CHECK((ctx), hipSetDevice((ctx)->device));                 \
+        int _rc = scratch_reset(ctx);                                        \
+        if (_rc) return _rc;                                                 \
+    } while (0)
+
+extern "C" {
+
+#define MIDAS_EXPORT __attribute__((visibility("default")))
+
+MIDAS_EXPORT const char* midas_version(void) { return "midas-hip 0.1 (gfx950)"; }
+
+MIDAS_EXPORT const char* midas_strerror(int code) {
+    switch (code) {
+        case MIDAS_OK: return "ok";
+        case MIDAS_ERR_INVALID: return "invalid argument";
+        case MIDAS_ERR_HIP: return "HIP runtime error";
+        case MIDAS_ERR_NOMEM: return "out of device memory";
+        case MIDAS_ERR_NODEVICE: return "no usable HIP device";
+        default: return "unknown error";
+    }
+}
+
+MIDAS_EXPORT const char* midas_last_error(const midas_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+MIDAS_EXPORT int midas_ctx_create(int device, void* hip_stream, midas_ctx** out) {
+    if (!out) return MIDAS_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return MIDAS_ERR_NODEVICE;
+    if (hipSetDevice(device) != hipSuccess) return MIDAS_ERR_NODEVICE;
+    midas_ctx* ctx = new (std::nothrow) midas_ctx();
+    if (!ctx) return MIDAS_ERR_NOMEM;
+    ctx->device = device;
+    ctx->scratch = new (std::nothrow) ScratchState();
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete scratch_of(ctx);
+            delete ctx;
+            return MIDAS_ERR_HIP;
+        }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return MIDAS_OK;
+}
+
+MIDAS_EXPORT int midas_ctx_destroy(midas_ctx* ctx) {
+    if (!ctx) return MIDAS_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ScratchState* s = scratch_of(ctx);
+    for (auto& c : s->chunks) (void)hipFree(c.p);
+    delete s;
+    if (ctx->ev_ready)
+        for (auto& e : ctx->ev) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return MIDAS_OK;
+}
+
+MIDAS_EXPORT int midas_ctx_set_stream(midas_ctx* ctx, void* hip_stream) {
+    if (!ctx) return MIDAS_ERR_INVALID;
+    MIDAS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream) {
+        (void)hipStreamDestroy(ctx->stream);
+        ctx->own_stream = false;
+    }
+    ctx->stream = (hipStream_t)hip_stream;
+    return MIDAS_OK;
+}
+
+MIDAS_EXPORT int midas_sync(midas_ctx* ctx) {
+    if (!ctx) return MIDAS_ERR_INVALID;
+    MIDAS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return MIDAS_OK;
+}
+
+// ---- codebook ------------------------------------------------------------------------------------
+MIDAS_EXPORT int midas_codebook_create(midas_ctx* ctx, int64_t K, int32_t D, const void* emb_dev, int32_t dtype,
+                                       midas_codebook** out) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, out && emb_dev && K > 0 && D > 0 && (dtype == MIDAS_F32 || dtype == MIDAS_F64));
+    midas_codebook* cb = new (std::nothrow) midas_codebook();
+    if (!cb) return midas_set_error(ctx, MIDAS_ERR_NOMEM, "new midas_codebook", "");
+    cb->ctx = ctx; cb->K = K; cb->D = D; cb->dtype = dtype; cb->emb = emb_dev; cb->norms = nullptr;
+    if (hipMalloc((void**)&cb->norms, (size_t)K * sizeof(double)) != hipSuccess) {
+        delete cb;
+        return midas_set_error(ctx, MIDAS_ERR_NOMEM, "hipMalloc(norms)", "");
+    }
+    int rc = launch_row_norms(ctx, K, D, emb_dev, dtype, cb->norms);
+    if (rc) { (void)hipFree(cb->norms); delete cb; return rc; }
+    *out = cb;
+    return MIDAS_OK;
+}
+
+MIDAS_EXPORT int midas_codebook_destroy(midas_codebook* cb) {
+    if (!cb) return MIDAS_OK;
+    (void)hipStreamSynchronize(cb->ctx->stream);
+    (void)hipFree(cb->norms);
+    delete cb;
+    return MIDAS_OK;
+}
+
+MIDAS_EXPORT int midas_score(midas_ctx* ctx, const midas_codebook* cb, int32_t B, const double* codes_dev,
+                             double* scores_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, cb && B >= 1 && codes_dev && scores_dev);
+    return launch_score(ctx, cb, B, codes_dev, scores_dev);
+}
+
+// ---- features / trees ----------------------------------------------------------------------------
+MIDAS_EXPORT int midas_se3_feature(midas_ctx* ctx, int64_t N, const float* poses_dev, float w, float* feat6_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, N >= 0 && (N == 0 || (poses_dev && feat6_dev)));
+    return launch_se3_feature(ctx, N, poses_dev, w, feat6_dev);
+}
+
+MIDAS_EXPORT int midas_tree_build(midas_ctx* ctx, int32_t dim, int64_t K, const void* points_dev, midas_tree** out) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, out && points_dev && K > 0 && K < ((int64_t)1 << 30) && (dim == 6 || dim == 3));
+    midas_tree* t = new (std::nothrow) midas_tree();
+    if (!t) return midas_set_error(ctx, MIDAS_ERR_NOMEM, "new midas_tree", "");
+    std::memset(t, 0, sizeof(*t));
+    t->ctx = ctx;
+    t->dim = dim;
+    int rc = tree_build_impl(ctx, dim, K, points_dev, t);
+    if (rc) { midas_tree_destroy(t); return rc; }
+    *out = t;
+    return MIDAS_OK;
+}
+
+MIDAS_EXPORT int midas_tree_destroy(midas_tree* t) {
+    if (!t) return MIDAS_OK;
+    (void)hipStreamSynchronize(t->ctx->stream);
+    if (t->nodes) (void)hipFree(t->nodes);
+    if (t->pts) (void)hipFree(t->pts);
+    if (t->leaf_start) (void)hipFree(t->leaf_start);
+    if (t->inv_perm) (void)hipFree(t->inv_perm);
+    delete t;
+    return MIDAS_OK;
+}
+
+MIDAS_EXPORT int midas_nn6(midas_ctx* ctx, const midas_tree* tree, int64_t N, const float* feat6_dev,
+                           const int32_t* hint_dev, int32_t* idx_dev, float* d2_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, tree && tree->dim == 6 && N >= 0 && (N == 0 || (feat6_dev && idx_dev)));
+    return launch_nn6(ctx, tree, N, feat6_dev, hint_dev, idx_dev, d2_dev);
+}
+
+MIDAS_EXPORT int midas_nn3(midas_ctx* ctx, const midas_tree* tree, int64_t N, const float* poses_dev, double* dist_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, tree && tree->dim == 3 && N >= 0 && (N == 0 || (poses_dev && dist_dev)));
+    return launch_nn3(ctx, tree, N, poses_dev, dist_dev);
+}
+
+// ---- motion model --------------------------------------------------------------------------------
+MIDAS_EXPORT int midas_propagate(midas_ctx* ctx, int64_t N, const float* poses_in_dev, float* poses_out_dev,
+                                 const float* odom16_dev, const float* tn_dev, const float* rot_dev, float std_t,
+                                 float std_r, uint64_t seed, uint64_t step) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, N >= 0 && odom16_dev && (N == 0 || (poses_in_dev && poses_out_dev)));
+    MIDAS_REQUIRE(ctx, (tn_dev == nullptr) == (rot_dev == nullptr));
+    return launch_propagate(ctx, N, poses_in_dev, poses_out_dev, odom16_dev, tn_dev, rot_dev, std_t, std_r, seed, step);
+}
+
+MIDAS_EXPORT int midas_check_poses(midas_ctx* ctx, int64_t N, const float* poses_dev, uint8_t* flag_dev,
+                                   int32_t* count_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, N >= 0 && count_dev && (N == 0 || (poses_dev && flag_dev)));
+    return launch_check_poses(ctx, N, poses_dev, flag_dev, count_dev);
+}
+
+// ---- weights -------------------------------------------------------------------------------------
+MIDAS_EXPORT int midas_gather_f64(midas_ctx* ctx, int64_t N, const double* table_dev, const int32_t* idx_dev,
+                                  double* out_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, N >= 0 && (N == 0 || (table_dev && idx_dev && out_dev)));
+    return launch_gather_f64(ctx, N, table_dev, idx_dev, out_dev);
+}
+
+MIDAS_EXPORT int midas_softmax(midas_ctx* ctx, int64_t N, const double* x_dev, int32_t softmax, double* w_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, N >= 0 && (N == 0 || (x_dev && w_dev)));
+    return launch_softmax(ctx, N, x_dev, softmax, w_dev);
+}
+
+MIDAS_EXPORT int midas_prune(midas_ctx* ctx, int64_t N, double* w_dev, const double* dist_dev, double thr,
+                             int32_t* nvalid_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, N >= 0 && nvalid_dev && (N == 0 || (w_dev && dist_dev)));
+    return launch_prune(ctx, N, w_dev, dist_dev, thr, nvalid_dev);
+}
+
+// ---- resample ------------------------------------------------------------------------------------
+MIDAS_EXPORT int midas_cdf(midas_ctx* ctx, int64_t N, const double* w_dev, double* cdf_dev, int32_t* status_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, N >= 0 && status_dev && (N == 0 || (w_dev && cdf_dev)));
+    return launch_cdf(ctx, N, w_dev, cdf_dev, status_dev);
+}
+
+MIDAS_EXPORT int midas_resample_search(midas_ctx* ctx, int64_t N, const double* cdf_dev, int64_t M, int32_t mode,
+                                       const double* u_dev, float u32, uint64_t seed, uint64_t step, int32_t* idx_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, N > 0 && M >= 0 && cdf_dev && (M == 0 || idx_dev));
+    MIDAS_REQUIRE(ctx, mode == MIDAS_RESAMPLE_MULTINOMIAL || mode == MIDAS_RESAMPLE_SYSTEMATIC);
+    return launch_search(ctx, N, cdf_dev, M, mode, u_dev, u32, seed, step, idx_dev);
+}
+
+MIDAS_EXPORT int midas_gather_rows(midas_ctx* ctx, int64_t M, const int32_t* idx_dev, const void* src_dev, void* dst_dev,
+                                   int32_t row_bytes) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, M >= 0 && row_bytes > 0 && (M == 0 || (idx_dev && src_dev && dst_dev)));
+    return launch_gather_rows(ctx, M, idx_dev, src_dev, dst_dev, row_bytes);
+}
+
+MIDAS_EXPORT int midas_rmse(midas_ctx* ctx, int64_t N, const float* poses_dev, const float* gt16_dev, double* out2_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, N > 0 && poses_dev && gt16_dev && out2_dev);
+    return launch_rmse(ctx, N, poses_dev, gt16_dev, out2_dev);
+}
+
+// ---- fused step ----------------------------------------------------------------------------------
+// largest float64 t2 with sqrt(t2) <= thr, so that  sqrt(d2) > thr  <=>  d2 > t2  exactly
+static double squared_threshold(double thr) {
+    if (!(thr >= 0.0)) return -1.0;  // nothing is within a negative / NaN threshold
+    if (std::isinf(thr)) return INFINITY;
+    double t = thr * thr;
+    while (std::sqrt(t) > thr) t = std::nextafter(t, 0.0);
+    while (std::sqrt(std::nextafter(t, INFINITY)) <= thr) t = std::nextafter(t, INFINITY);
+    return t;
+}
+
+MIDAS_EXPORT int midas_filter_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
+                                   const midas_tree* tree3, const midas_step_args* args) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, cb && tree6 && tree3 && args && tree6->dim == 6 && tree3->dim == 3);
+    const midas_step_args& s = *args;
+    MIDAS_REQUIRE(ctx, s.N > 0 && s.poses_in_dev && s.poses_prop_dev && s.poses_out_dev && s.weights_dev &&
+                           s.weights_out_dev && s.nn_idx_dev && s.hint_out_dev && s.ridx_dev && s.odom16_dev &&
+                           s.code_dev && s.status_dev);
+    MIDAS_REQUIRE(ctx, s.poses_prop_dev != s.poses_in_dev && s.poses_prop_dev != s.poses_out_dev);
+    MIDAS_REQUIRE(ctx, (s.tn_dev == nullptr) == (s.rot_dev == nullptr));
+    MIDAS_REQUIRE(ctx, tree6->K == cb->K);
+    const int64_t N = s.N;
+    const int npart = particle_update_blocks(N);
+    void *scores, *x, *valid, *pmax, *pmin, *prm = nullptr, *cdf;
+    int rc;
+    if ((rc = midas_scratch(ctx, (size_t)cb->K * sizeof(double), &scores))) return rc;
+    if ((rc = midas_scratch(ctx, (size_t)N * sizeof(double), &x))) return rc;
+    if ((rc = midas_scratch(ctx, (size_t)N, &valid))) return rc;
+    if ((rc = midas_scratch(ctx, (size_t)npart * sizeof(double), &pmax))) return rc;
+    if ((rc = midas_scratch(ctx, (size_t)npart * sizeof(double), &pmin))) return rc;
+    if (s.gt16_dev && s.rmse_dev)
+        if ((rc = midas_scratch(ctx, (size_t)npart * 2 * sizeof(double), &prm))) return rc;
+    if ((rc = midas_scratch(ctx, (size_t)N * sizeof(double), &cdf))) return rc;
+
+    prof_mark(ctx, 0);
+    if ((rc = launch_score(ctx, cb, 1, s.code_dev, (double*)scores))) return rc;
+    prof_mark(ctx, 1);
+
+    ParticleUpdateArgs pa;
+    pa.N = N;
+    pa.poses_in = s.poses_in_dev;
+    pa.poses_prop = s.poses_prop_dev;
+    pa.odom16 = s.odom16_dev;
+    pa.tn = s.tn_dev;
+    pa.rot = s.rot_dev;
+    pa.std_t = s.std_t;
+    pa.std_r = s.std_r;
+    pa.seed = s.seed;
+    pa.step = s.step;
+    pa.hint_in = s.hint_in_dev;
+    pa.nn_idx = s.nn_idx_dev;
+    pa.scores = (const double*)scores;
+    pa.x = (double*)x;
+    pa.valid = (uint8_t*)valid;
+    pa.t2 = squared_threshold(s.prune_thr);
+    pa.part_max = (double*)pmax;
+    pa.part_min = (double*)pmin;
+    pa.gt16 = prm ? s.gt16_dev : nullptr;
+    pa.part_rmse = (double*)prm;
+    if ((rc = launch_particle_update(ctx, tree6, tree3, pa))) return rc;
+    prof_mark(ctx, 2);
+
+    StepTailArgs ta;
+    ta.N = N;
+    ta.npart = npart;
+    ta.x = (const double*)x;
+    ta.valid = (const uint8_t*)valid;
+    ta.part_max = (const double*)pmax;
+    ta.part_min = (const double*)pmin;
+    ta.softmax = s.softmax;
+    ta.weights = s.weights_dev;
+    ta.cdf = (double*)cdf;
+    ta.status = s.status_dev;
+    ta.mode = s.resample_mode;
+    ta.u = s.u_dev;
+    ta.u32 = s.u32;
+    ta.seed = s.seed;
+    ta.step = s.step;
+    ta.ridx = s.ridx_dev;
+    ta.poses_prop = s.poses_prop_dev;
+    ta.poses_out = s.poses_out_dev;
+    ta.weights_out = s.weights_out_dev;
+    ta.nn_idx = s.nn_idx_dev;
+    ta.hint_out = s.hint_out_dev;
+    ta.part_rmse = (const double*)prm;
+    ta.rmse_out = s.rmse_dev;
+    if ((rc = launch_step_tail(ctx, ta, 2))) return rc;
+
+    if (ctx->prof && ctx->ev_ready) {
+        MIDAS_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev[6]));
+        for (int i = 0; i < 6; ++i) {
+            float ms = 0.f;
+            MIDAS_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
+            ctx->prof_ms[i] += (double)ms;
+        }
+        ctx->prof_calls += 1;
+    }
+    return MIDAS_OK;
+}
+
+// ---- profiling -----------------------------------------------------------------------------------
+MIDAS_EXPORT int midas_profile_enable(midas_ctx* ctx, int32_t on) {
+    if (!ctx) return MIDAS_ERR_INVALID;
+    MIDAS_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (on && !ctx->ev_ready) {
+        for (auto& e : ctx->ev) MIDAS_HIP_CHECK(ctx, hipEventCreate(&e));
+        ctx->ev_ready = true;
+    }
+    ctx->prof = on != 0;
+    return MIDAS_OK;
+}
+
+MIDAS_EXPORT int midas_profile_read(midas_ctx* ctx, double* ms_out, int64_t* calls_out, int32_t reset) {
+    if (!ctx || !ms_out || !calls_out) return MIDAS_ERR_INVALID;
+    MIDAS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < MIDAS_PROF_SLOTS; ++i) ms_out[i] = ctx->prof_ms[i];
+    *calls_out = ctx->prof_calls;
+    if (reset) {
+        for (auto& v : ctx->prof_ms) v = 0.0;
+        ctx->prof_calls = 0;
+    }
+    return MIDAS_OK;
+}
+
+MIDAS_EXPORT const char* midas_profile_slot_name(int32_t slot) {
+    return (slot >= 0 && slot < MIDAS_PROF_SLOTS) ? kSlotNames[slot] : "";
+}
+
+}  // extern "C"

@@ -1,0 +1,185 @@
+// midas_internal.hpp - shared declarations of the libmidas_hip.so translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/midas_hip.h"
+
+namespace midas {
+
+// ---- KD-tree layouts (shared host/device) ------------------------------------------------------
+// Complete binary tree in 1-based heap order: node n has children 2n, 2n+1; the 2^L leaves are the
+// nodes [2^L, 2^(L+1)).  Points are stored in leaf order; leaf l owns [leaf_start[l], leaf_start[l+1]).
+struct alignas(16) Node6 { float lo_max, hi_min; int32_t dim; int32_t pad; };
+struct alignas(16) Point6 { float c[6]; int32_t idx; int32_t pad; };
+struct alignas(8) Node3 { double lo_max, hi_min; int32_t dim; int32_t pad; };
+struct alignas(16) Point3 { double c[3]; int64_t idx; };
+
+struct Kd6 {
+    using T = float;
+    using Node = Node6;
+    using Point = Point6;
+    static constexpr int DIM = 6;
+};
+struct Kd3 {
+    using T = double;
+    using Node = Node3;
+    using Point = Point3;
+    static constexpr int DIM = 3;
+};
+
+template <class KD>
+struct TreeView {
+    const typename KD::Node* nodes;  // [2^L], entry 0 unused
+    const typename KD::Point* pts;   // [K]
+    const int32_t* leaf_start;       // [2^L + 1]
+    const int32_t* inv_perm;         // [K] original index -> position in pts
+    int32_t levels;
+    int64_t K;
+};
+
+constexpr int LEAF_CAP = 8;  // leaves hold ceil(K / 2^L) <= 8 points
+
+}  // namespace midas
+
+// ---- opaque handles ---------------------------------------------------------------------------
+struct midas_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // growable scratch
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    std::string last_error;
+    // profiling
+    bool prof = false;
+    hipEvent_t ev[MIDAS_PROF_SLOTS + 1] = {};
+    bool ev_ready = false;
+    double prof_ms[MIDAS_PROF_SLOTS] = {};
+    int64_t prof_calls = 0;
+};
+
+struct midas_codebook {
+    midas_ctx* ctx;
+    int64_t K;
+    int32_t D;
+    int32_t dtype;
+    const void* emb;  // caller-owned
+    double* norms;    // [K] max(|C_k|, 1e-8), library-owned
+};
+
+struct midas_tree {
+    midas_ctx* ctx;
+    int32_t dim;
+    int64_t K;
+    int32_t levels;
+    void* nodes;
+    void* pts;
+    int32_t* leaf_start;
+    int32_t* inv_perm;
+};
+
+// ---- error helpers ----------------------------------------------------------------------------
+int midas_set_error(midas_ctx* ctx, int code, const char* what, const char* detail);
+
+#define MIDAS_HIP_CHECK(ctx, expr)                                                     \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess) return midas_set_error((ctx), MIDAS_ERR_HIP, #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+#define MIDAS_REQUIRE(ctx, cond)                                                       \
+    do {                                                                               \
+        if (!(cond)) return midas_set_error((ctx), MIDAS_ERR_INVALID, #cond, "invalid argument"); \
+    } while (0)
+
+// scratch carve-out (stream-ordered reuse; one stream per context)
+int midas_scratch(midas_ctx* ctx, size_t bytes, void** out);
+
+namespace midas {
+
+// blocked-scan spec constants (DESIGN.md "Summation order")
+constexpr int SCAN_CHUNK = 16;
+constexpr int SCAN_TPB = 256;
+constexpr int SCAN_BLOCK = SCAN_CHUNK * SCAN_TPB;  // 4096 values per block
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- launchers (each enqueues on ctx->stream and returns a status) --------------------------------
+// score.hip
+int launch_row_norms(midas_ctx* ctx, int64_t K, int32_t D, const void* emb, int32_t dtype, double* norms);
+int launch_score(midas_ctx* ctx, const midas_codebook* cb, int32_t B, const double* codes, double* scores);
+
+// particles.hip
+int launch_se3_feature(midas_ctx* ctx, int64_t N, const float* poses, float w, float* feat6);
+int launch_propagate(midas_ctx* ctx, int64_t N, const float* in, float* out, const float* odom,
+                     const float* tn, const float* rot, float std_t, float std_r, uint64_t seed, uint64_t step);
+int launch_check_poses(midas_ctx* ctx, int64_t N, const float* poses, uint8_t* flag, int32_t* count);
+int launch_nn6(midas_ctx* ctx, const midas_tree* t, int64_t N, const float* feat6, const int32_t* hint,
+               int32_t* idx, float* d2);
+int launch_nn3(midas_ctx* ctx, const midas_tree* t, int64_t N, const float* poses, double* dist);
+int launch_rmse(midas_ctx* ctx, int64_t N, const float* poses, const float* gt16, double* out2);
+struct ParticleUpdateArgs {
+    int64_t N;
+    const float* poses_in;
+    float* poses_prop;
+    const float* odom16;
+    const float* tn;
+    const float* rot;
+    float std_t, std_r;
+    uint64_t seed, step;
+    const int32_t* hint_in;
+    int32_t* nn_idx;
+    const double* scores;  // [K]
+    double* x;             // [N] gathered score
+    uint8_t* valid;        // [N] prune mask
+    double t2;             // squared prune threshold (exact: sqrt(d2) > thr  <=>  d2 > t2)
+    double* part_max;      // [nblocks]
+    double* part_min;      // [nblocks]
+    const float* gt16;     // nullable
+    double* part_rmse;     // [2*nblocks] when gt16
+};
+int particle_update_blocks(int64_t N);
+int launch_particle_update(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t3, const ParticleUpdateArgs& a);
+
+// resample.hip
+int launch_gather_f64(midas_ctx* ctx, int64_t N, const double* table, const int32_t* idx, double* out);
+int launch_softmax(midas_ctx* ctx, int64_t N, const double* x, int32_t softmax, double* w);
+int launch_prune(midas_ctx* ctx, int64_t N, double* w, const double* dist, double thr, int32_t* nvalid);
+int launch_cdf(midas_ctx* ctx, int64_t N, const double* w, double* cdf, int32_t* status);
+int launch_search(midas_ctx* ctx, int64_t N, const double* cdf, int64_t M, int32_t mode, const double* u,
+                  float u32, uint64_t seed, uint64_t step, int32_t* idx);
+int launch_gather_rows(midas_ctx* ctx, int64_t M, const int32_t* idx, const void* src, void* dst, int32_t row_bytes);
+// fused tail of the step: x,valid,partials -> weights (masked) -> cdf -> search -> gather
+struct StepTailArgs {
+    int64_t N;
+    int npart;               // number of part_max/part_min entries
+    const double* x;
+    const uint8_t* valid;
+    const double* part_max;
+    const double* part_min;
+    int32_t softmax;
+    double* weights;         // [N] masked weights (pre-resample)
+    double* cdf;             // [N] scratch
+    int32_t* status;         // [2]
+    int32_t mode;
+    const double* u;
+    float u32;
+    uint64_t seed, step;
+    int32_t* ridx;
+    const float* poses_prop;
+    float* poses_out;
+    double* weights_out;
+    const int32_t* nn_idx;
+    int32_t* hint_out;
+    const double* part_rmse;  // nullable
+    double* rmse_out;
+};
+int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base);
+
+// profiling hook used by the step: record event `slot` on the stream when profiling is on
+void prof_mark(midas_ctx* ctx, int slot);
+
+}  // namespace midas

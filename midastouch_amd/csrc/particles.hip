@@ -1,0 +1,539 @@
+// particles.hip - per-particle kernels: SE(3) propagate (K2), 6-d pose feature (K3), exact nearest
+// neighbour on static KD-trees (K4), the fused particle update of the step, rmse and pose checks.
+//
+// One lane owns one particle.  The NN search is latency-bound pointer chasing over a tree that lives
+// in L2 (K=50k: 128 KB of nodes + 1.6 MB of points), so workgroups are single waves (64 threads) to
+// spread the N/64 waves evenly over the 256 CUs, and the traversal is stack-free (a bit-trail of
+// pending far children in one register) so it needs no LDS and no scratch.
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <vector>
+
+#include "midas_internal.hpp"
+#include "midas_math.hpp"
+
+namespace midas {
+
+// =================================================================================================
+// KD-tree: host build
+// =================================================================================================
+template <class KD>
+struct HostTree {
+    std::vector<typename KD::Node> nodes;
+    std::vector<typename KD::Point> pts;
+    std::vector<int32_t> leaf_start;
+    std::vector<int32_t> inv_perm;
+    int levels = 0;
+};
+
+template <class KD>
+static void build_rec(HostTree<KD>& t, const typename KD::T* P, std::vector<int32_t>& perm, uint32_t node, int64_t lo,
+                      int64_t hi, int level) {
+    using T = typename KD::T;
+    constexpr int DIM = KD::DIM;
+    if (level == t.levels) {
+        t.leaf_start[node - (1u << t.levels)] = (int32_t)lo;
+        std::sort(perm.begin() + lo, perm.begin() + hi);
+        return;
+    }
+    int best_dim = 0;
+    T best_spread = -1;
+    for (int d = 0; d < DIM; ++d) {
+        T mn = INFINITY, mx = -INFINITY;
+        for (int64_t i = lo; i < hi; ++i) {
+            T v = P[(int64_t)perm[i] * DIM + d];
+            mn = v < mn ? v : mn;
+            mx = v > mx ? v : mx;
+        }
+        if (mx - mn > best_spread) { best_spread = mx - mn; best_dim = d; }
+    }
+    const int64_t mid = lo + (hi - lo + 1) / 2;
+    auto cmp = [&](int32_t a, int32_t b) {
+        T va = P[(int64_t)a * DIM + best_dim], vb = P[(int64_t)b * DIM + best_dim];
+        return va < vb || (va == vb && a < b);
+    };
+    if (mid < hi) std::nth_element(perm.begin() + lo, perm.begin() + mid, perm.begin() + hi, cmp);
+    T lo_max = -INFINITY, hi_min = INFINITY;
+    for (int64_t i = lo; i < mid; ++i) lo_max = std::max(lo_max, P[(int64_t)perm[i] * DIM + best_dim]);
+    for (int64_t i = mid; i < hi; ++i) hi_min = std::min(hi_min, P[(int64_t)perm[i] * DIM + best_dim]);
+    typename KD::Node nd;
+    nd.lo_max = lo_max;
+    nd.hi_min = hi_min;
+    nd.dim = best_dim;
+    nd.pad = 0;
+    t.nodes[node] = nd;
+    build_rec(t, P, perm, 2 * node, lo, mid, level + 1);
+    build_rec(t, P, perm, 2 * node + 1, mid, hi, level + 1);
+}
+
+template <class KD>
+static HostTree<KD> build_tree(const typename KD::T* P, int64_t K) {
+    HostTree<KD> t;
+    int levels = 0;
+    while (((int64_t)LEAF_CAP << levels) < K) ++levels;
+    t.levels = levels;
+    const int64_t nleaves = (int64_t)1 << levels;
+    t.nodes.resize(nleaves);
+    t.leaf_start.assign(nleaves + 1, (int32_t)K);
+    std::vector<int32_t> perm(K);
+    std::iota(perm.begin(), perm.end(), 0);
+    build_rec(t, P, perm, 1u, 0, K, 0);
+    t.leaf_start[nleaves] = (int32_t)K;
+    t.pts.resize(K);
+    t.inv_perm.resize(K);
+    for (int64_t i = 0; i < K; ++i) {
+        typename KD::Point p;
+        for (int d = 0; d < KD::DIM; ++d) p.c[d] = P[(int64_t)perm[i] * KD::DIM + d];
+        p.idx = perm[i];
+        if constexpr (KD::DIM == 6) p.pad = 0;
+        t.pts[i] = p;
+        t.inv_perm[perm[i]] = (int32_t)i;
+    }
+    return t;
+}
+
+template <class KD>
+static int upload_tree(midas_ctx* ctx, const HostTree<KD>& h, int64_t K, midas_tree* out) {
+    auto up = [&](const void* src, size_t bytes, void** dst) -> int {
+        MIDAS_HIP_CHECK(ctx, hipMalloc(dst, bytes ? bytes : 16));
+        if (bytes) MIDAS_HIP_CHECK(ctx, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        return MIDAS_OK;
+    };
+    int rc;
+    if ((rc = up(h.nodes.data(), h.nodes.size() * sizeof(typename KD::Node), &out->nodes))) return rc;
+    if ((rc = up(h.pts.data(), h.pts.size() * sizeof(typename KD::Point), &out->pts))) return rc;
+    if ((rc = up(h.leaf_start.data(), h.leaf_start.size() * sizeof(int32_t), (void**)&out->leaf_start))) return rc;
+    if ((rc = up(h.inv_perm.data(), h.inv_perm.size() * sizeof(int32_t), (void**)&out->inv_perm))) return rc;
+    out->levels = h.levels;
+    out->K = K;
+    return MIDAS_OK;
+}
+
+int tree_build_impl(midas_ctx* ctx, int32_t dim, int64_t K, const void* points_dev, midas_tree* out) {
+    MIDAS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (dim == 6) {
+        std::vector<float> host((size_t)K * 6);
+        MIDAS_HIP_CHECK(ctx, hipMemcpy(host.data(), points_dev, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+        HostTree<Kd6> h = build_tree<Kd6>(host.data(), K);
+        return upload_tree<Kd6>(ctx, h, K, out);
+    }
+    std::vector<double> host((size_t)K * 3);
+    MIDAS_HIP_CHECK(ctx, hipMemcpy(host.data(), points_dev, host.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HostTree<Kd3> h = build_tree<Kd3>(host.data(), K);
+    return upload_tree<Kd3>(ctx, h, K, out);
+}
+
+template <class KD>
+static TreeView<KD> view_of(const midas_tree* t) {
+    TreeView<KD> v;
+    v.nodes = (const typename KD::Node*)t->nodes;
+    v.pts = (const typename KD::Point*)t->pts;
+    v.leaf_start = t->leaf_start;
+    v.inv_perm = t->inv_perm;
+    v.levels = t->levels;
+    v.K = t->K;
+    return v;
+}
+
+// =================================================================================================
+// KD-tree: device traversal
+// =================================================================================================
+MD float sel(const float* q, int d) {  // q[d] without dynamic register indexing
+    float r = q[0];
+    r = d == 1 ? q[1] : r;
+    r = d == 2 ? q[2] : r;
+    r = d == 3 ? q[3] : r;
+    r = d == 4 ? q[4] : r;
+    r = d == 5 ? q[5] : r;
+    return r;
+}
+MD double sel(const double* q, int d) {
+    double r = q[0];
+    r = d == 1 ? q[1] : r;
+    r = d == 2 ? q[2] : r;
+    return r;
+}
+
+MD float dist2(const float* q, const Point6& p) {
+    float d0 = q[0] - p.c[0], d1 = q[1] - p.c[1], d2 = q[2] - p.c[2];
+    float d3 = q[3] - p.c[3], d4 = q[4] - p.c[4], d5 = q[5] - p.c[5];
+    float d = d0 * d0;
+    d = fmaf_(d1, d1, d);
+    d = fmaf_(d2, d2, d);
+    d = fmaf_(d3, d3, d);
+    d = fmaf_(d4, d4, d);
+    d = fmaf_(d5, d5, d);
+    return d;
+}
+MD double dist2(const double* q, const Point3& p) {
+    double d0 = q[0] - p.c[0], d1 = q[1] - p.c[1], d2 = q[2] - p.c[2];
+    double d = d0 * d0;
+    d = fma_(d1, d1, d);
+    d = fma_(d2, d2, d);
+    return d;
+}
+
+// Exact 1-NN.  On entry (best_d, best_i) is a valid candidate or (+inf, 0); on exit the minimum of
+// the spec distance with ties resolved to the smallest original index.  EXISTS: return as soon as any
+// point with d <= best_d (the entry bound) is seen; `found` reports it.
+template <class KD, bool EXISTS>
+MD bool kd_search(const TreeView<KD>& tv, const typename KD::T* q, typename KD::T& best_d, int64_t& best_i) {
+    using T = typename KD::T;
+    const int L = tv.levels;
+    const uint32_t first_leaf = 1u << L;
+    uint32_t node = 1u, pending = 0u;
+    bool found = false;
+    for (;;) {
+        while (node < first_leaf) {
+            const typename KD::Node nd = tv.nodes[node];
+            const T qd = sel(q, nd.dim);
+            const T dl = qd - nd.lo_max, dh = nd.hi_min - qd;
+            const bool go_left = dl <= dh;
+            const T fd = go_left ? dh : dl;
+            const T fb = fd > (T)0 ? fd * fd : (T)0;
+            const int lvl = 31 - __builtin_clz(node);
+            if (fb <= best_d) pending |= 1u << lvl;
+            node = 2u * node + (go_left ? 0u : 1u);
+        }
+        const int32_t leaf = (int32_t)(node - first_leaf);
+        const int32_t s = tv.leaf_start[leaf], e = tv.leaf_start[leaf + 1];
+#pragma unroll
+        for (int j = 0; j < LEAF_CAP; ++j) {
+            if (s + j < e) {
+                const typename KD::Point p = tv.pts[s + j];
+                const T d = dist2(q, p);
+                if (EXISTS) {
+                    if (d <= best_d) { best_d = d; best_i = p.idx; found = true; }
+                } else if (d < best_d || (d == best_d && (int64_t)p.idx < best_i)) {
+                    best_d = d;
+                    best_i = p.idx;
+                }
+            }
+        }
+        if (EXISTS && found) return true;
+        bool resumed = false;
+        while (pending) {
+            const int lvl = 31 - __builtin_clz(pending);
+            pending &= ~(1u << lvl);
+            const uint32_t anc = node >> (L - lvl);
+            const uint32_t far = (node >> (L - lvl - 1)) ^ 1u;
+            const typename KD::Node nd = tv.nodes[anc];
+            const T qd = sel(q, nd.dim);
+            const T fd = (far & 1u) ? (nd.hi_min - qd) : (qd - nd.lo_max);
+            const T fb = fd > (T)0 ? fd * fd : (T)0;
+            if (fb <= best_d) {
+                node = far;
+                resumed = true;
+                break;
+            }
+        }
+        if (!resumed) break;
+    }
+    return found;
+}
+
+MD void nn6_query(const TreeView<Kd6>& tv, const float* q, int32_t hint, int32_t& idx, float& d2) {
+    float best = INFINITY;
+    int64_t bi = 0;
+    if (hint >= 0 && (int64_t)hint < tv.K) {
+        const Point6 p = tv.pts[tv.inv_perm[hint]];
+        const float d = dist2(q, p);
+        if (d < best) { best = d; bi = hint; }
+    }
+    kd_search<Kd6, false>(tv, q, best, bi);
+    idx = (int32_t)bi;
+    d2 = best;
+}
+
+// =================================================================================================
+// standalone kernels
+// =================================================================================================
+MD void load_pose(const float* p, float* P) {
+    const float4* v = reinterpret_cast<const float4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float4 r = v[i];
+        P[i * 4 + 0] = r.x; P[i * 4 + 1] = r.y; P[i * 4 + 2] = r.z; P[i * 4 + 3] = r.w;
+    }
+}
+MD void store_pose(float* p, const float* P) {
+    float4* v = reinterpret_cast<float4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = make_float4(P[i * 4 + 0], P[i * 4 + 1], P[i * 4 + 2], P[i * 4 + 3]);
+}
+
+MD void propagate_one(int64_t n, const float* P, const float* O, const float* tn_arr, const float* rot_arr,
+                      float std_t, float std_r, uint64_t seed, uint64_t step, float* out) {
+    float tn[3], rot[3];
+    if (tn_arr) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { tn[j] = tn_arr[n * 3 + j]; rot[j] = rot_arr[n * 3 + j]; }
+    } else {
+        float z[6];
+        philox_normals6((uint64_t)n, seed, step, z);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { tn[j] = z[j] * std_t; rot[j] = z[3 + j] * std_r; }
+    }
+    float Tn[16], NO[16];
+    noise_transform(tn, rot, Tn);
+    mat4_mul(O, Tn, NO);
+    mat4_mul(P, NO, out);
+}
+
+__global__ __launch_bounds__(64) void k_propagate(int64_t N, const float* __restrict__ in, float* __restrict__ out,
+                                                  const float* __restrict__ odom, const float* __restrict__ tn,
+                                                  const float* __restrict__ rot, float std_t, float std_r,
+                                                  uint64_t seed, uint64_t step) {
+    const int64_t n = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (n >= N) return;
+    float P[16], O[16], R[16];
+    load_pose(in + n * 16, P);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) O[i] = odom[i];
+    propagate_one(n, P, O, tn, rot, std_t, std_r, seed, step, R);
+    store_pose(out + n * 16, R);
+}
+
+__global__ __launch_bounds__(64) void k_feature(int64_t N, const float* __restrict__ poses, float wt, float wr,
+                                                float* __restrict__ feat) {
+    const int64_t n = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (n >= N) return;
+    float P[16], f[6];
+    load_pose(poses + n * 16, P);
+    se3_feature(P, wt, wr, f);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) feat[n * 6 + j] = f[j];
+}
+
+__global__ __launch_bounds__(64) void k_nn6(TreeView<Kd6> tv, int64_t N, const float* __restrict__ feat,
+                                            const int32_t* __restrict__ hint, int32_t* __restrict__ idx,
+                                            float* __restrict__ d2out) {
+    const int64_t n = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (n >= N) return;
+    float q[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) q[j] = feat[n * 6 + j];
+    int32_t bi;
+    float bd;
+    nn6_query(tv, q, hint ? hint[n] : -1, bi, bd);
+    idx[n] = bi;
+    if (d2out) d2out[n] = bd;
+}
+
+__global__ __launch_bounds__(64) void k_nn3(TreeView<Kd3> tv, int64_t N, const float* __restrict__ poses,
+                                            double* __restrict__ dist) {
+    const int64_t n = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (n >= N) return;
+    double q[3] = {(double)poses[n * 16 + 3], (double)poses[n * 16 + 7], (double)poses[n * 16 + 11]};
+    double best = INFINITY;
+    int64_t bi = 0;
+    kd_search<Kd3, false>(tv, q, best, bi);
+    dist[n] = __builtin_sqrt(best);
+}
+
+// check_quats (modules/particle_filter.py:347-357): flag poses whose rotation yields a NaN or
+// zero-norm quaternion.  theseus' to_quaternion is derived from trace / off-diagonal terms; a pose
+// is flagged when any rotation entry is non-finite or the quaternion's squared norm
+// (1 + tr)/4 + |axis|^2-style reconstruction collapses to 0 - in practice only NaN/Inf poses.
+__global__ __launch_bounds__(256) void k_check_poses(int64_t N, const float* __restrict__ poses,
+                                                     uint8_t* __restrict__ flag, int32_t* __restrict__ count) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool bad = false;
+    if (n < N) {
+        const float* P = poses + n * 16;
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc += P[i * 4 + j] * P[i * 4 + j];
+        bad = !(acc > 0.0f) || !(acc < INFINITY);  // NaN, Inf or all-zero rotation
+        flag[n] = bad ? 1 : 0;
+    }
+    unsigned long long m = __ballot(bad);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (int32_t)__popcll(m));
+}
+
+// rmse partials: per-wave (sum e_t^2, sum ang^2) in float64
+MD void rmse_terms(const float* P, const float* G, double& et2, double& ang2) {
+    float dx = G[3] - P[3], dy = G[7] - P[7], dz = G[11] - P[11];
+    float e2 = fmaf_(dz, dz, fmaf_(dy, dy, dx * dx));
+    float tr = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float acc = G[i * 4] * P[i * 4];
+        acc = fmaf_(G[i * 4 + 1], P[i * 4 + 1], acc);
+        acc = fmaf_(G[i * 4 + 2], P[i * 4 + 2], acc);
+        tr += acc;
+    }
+    float ang = acosf((tr - 1.0f) * 0.5f) * 57.2957795130823209f;
+    if (ang != ang) ang = 0.0f;
+    if (ang > 180.0f) ang -= 360.0f;
+    if (ang < -180.0f) ang += 360.0f;
+    et2 = (double)e2;
+    ang2 = (double)ang * (double)ang;
+}
+
+MD double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+MD double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o); v = t > v ? t : v; }
+    return v;
+}
+MD double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o); v = t < v ? t : v; }
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_rmse_part(int64_t N, const float* __restrict__ poses,
+                                                  const float* __restrict__ gt, double* __restrict__ part) {
+    const int64_t n = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    double a = 0.0, b = 0.0;
+    if (n < N) {
+        float P[16], G[16];
+        load_pose(poses + n * 16, P);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) G[i] = gt[i];
+        rmse_terms(P, G, a, b);
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = a; part[2 * blockIdx.x + 1] = b; }
+}
+
+__global__ __launch_bounds__(256) void k_rmse_final(int64_t N, int nb, const double* __restrict__ part,
+                                                    double* __restrict__ out2) {
+    __shared__ double sa[4], sb[4];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) { a += part[2 * i]; b += part[2 * i + 1]; }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = a; sb[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+        b = (sb[0] + sb[1]) + (sb[2] + sb[3]);
+        out2[0] = __builtin_sqrt(a / (double)N);
+        out2[1] = __builtin_sqrt(b / (double)N);
+    }
+}
+
+// =================================================================================================
+// fused particle update of the step
+// =================================================================================================
+__global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a) {
+    const int64_t n = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = n < a.N;
+    double x = 0.0, et2 = 0.0, ang2 = 0.0;
+    if (live) {
+        float P[16], O[16], R[16];
+        load_pose(a.poses_in + n * 16, P);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) O[i] = a.odom16[i];
+        propagate_one(n, P, O, a.tn, a.rot, a.std_t, a.std_r, a.seed, a.step, R);
+        store_pose(a.poses_prop + n * 16, R);
+        float f[6];
+        se3_feature(R, 0.99f, 0.01f, f);
+        int32_t bi;
+        float bd;
+        nn6_query(t6, f, a.hint_in ? a.hint_in[n] : -1, bi, bd);
+        a.nn_idx[n] = bi;
+        x = a.scores[bi];
+        a.x[n] = x;
+        // prune: valid <=> some mesh vertex within sqrt(t2)
+        double q3[3] = {(double)R[3], (double)R[7], (double)R[11]};
+        double best = a.t2;
+        int64_t vi = 0;
+        const bool ok = kd_search<Kd3, true>(t3, q3, best, vi);
+        a.valid[n] = ok ? 1 : 0;
+        if (a.gt16) {
+            float G[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) G[i] = a.gt16[i];
+            rmse_terms(R, G, et2, ang2);
+        }
+    }
+    // per-wave extrema of x over live lanes
+    const double NEG = -INFINITY, POS = INFINITY;
+    double mx = wave_max(live ? x : NEG), mn = wave_min(live ? x : POS);
+    if (threadIdx.x == 0) { a.part_max[blockIdx.x] = mx; a.part_min[blockIdx.x] = mn; }
+    if (a.gt16) {
+        et2 = wave_sum(et2);
+        ang2 = wave_sum(ang2);
+        if (threadIdx.x == 0) { a.part_rmse[2 * blockIdx.x] = et2; a.part_rmse[2 * blockIdx.x + 1] = ang2; }
+    }
+}
+
+// =================================================================================================
+// launchers
+// =================================================================================================
+int launch_se3_feature(midas_ctx* ctx, int64_t N, const float* poses, float w, float* feat6) {
+    if (N == 0) return MIDAS_OK;
+    // (1.0 - w) * t is a python-float times a float32 tensor in the reference: the scalar is rounded to float32
+    const float wt = (float)(1.0 - (double)w), wr = w;
+    hipLaunchKernelGGL(k_feature, dim3((unsigned)ceil_div(N, 64)), dim3(64), 0, ctx->stream, N, poses, wt, wr, feat6);
+    MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    return MIDAS_OK;
+}
+
+int launch_propagate(midas_ctx* ctx, int64_t N, const float* in, float* out, const float* odom, const float* tn,
+                     const float* rot, float std_t, float std_r, uint64_t seed, uint64_t step) {
+    if (N == 0) return MIDAS_OK;
+    hipLaunchKernelGGL(k_propagate, dim3((unsigned)ceil_div(N, 64)), dim3(64), 0, ctx->stream, N, in, out, odom, tn,
+                       rot, std_t, std_r, seed, step);
+    MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    return MIDAS_OK;
+}
+
+int launch_check_poses(midas_ctx* ctx, int64_t N, const float* poses, uint8_t* flag, int32_t* count) {
+    MIDAS_HIP_CHECK(ctx, hipMemsetAsync(count, 0, sizeof(int32_t), ctx->stream));
+    if (N == 0) return MIDAS_OK;
+    hipLaunchKernelGGL(k_check_poses, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, N, poses, flag, count);
+    MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    return MIDAS_OK;
+}
+
+int launch_nn6(midas_ctx* ctx, const midas_tree* t, int64_t N, const float* feat6, const int32_t* hint, int32_t* idx,
+               float* d2) {
+    if (N == 0) return MIDAS_OK;
+    hipLaunchKernelGGL(k_nn6, dim3((unsigned)ceil_div(N, 64)), dim3(64), 0, ctx->stream, view_of<Kd6>(t), N, feat6, hint,
+                       idx, d2);
+    MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    return MIDAS_OK;
+}
+
+int launch_nn3(midas_ctx* ctx, const midas_tree* t, int64_t N, const float* poses, double* dist) {
+    if (N == 0) return MIDAS_OK;
+    hipLaunchKernelGGL(k_nn3, dim3((unsigned)ceil_div(N, 64)), dim3(64), 0, ctx->stream, view_of<Kd3>(t), N, poses, dist);
+    MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    return MIDAS_OK;
+}
+
+int launch_rmse(midas_ctx* ctx, int64_t N, const float* poses, const float* gt16, double* out2) {
+    MIDAS_REQUIRE(ctx, N > 0);
+    const int nb = (int)ceil_div(N, 64);
+    void* part;
+    int rc = midas_scratch(ctx, (size_t)nb * 2 * sizeof(double), &part);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_rmse_part, dim3(nb), dim3(64), 0, ctx->stream, N, poses, gt16, (double*)part);
+    hipLaunchKernelGGL(k_rmse_final, dim3(1), dim3(256), 0, ctx->stream, N, nb, (const double*)part, out2);
+    MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    return MIDAS_OK;
+}
+
+int particle_update_blocks(int64_t N) { return (int)ceil_div(N, 64); }
+
+int launch_particle_update(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t3, const ParticleUpdateArgs& a) {
+    if (a.N == 0) return MIDAS_OK;
+    hipLaunchKernelGGL(k_particle_update, dim3((unsigned)particle_update_blocks(a.N)), dim3(64), 0, ctx->stream,
+                       view_of<Kd6>(t6), view_of<Kd3>(t3), a);
+    MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    return MIDAS_OK;
+}
+
+}  // namespace midas

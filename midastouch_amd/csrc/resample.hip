@@ -1,0 +1,509 @@
+// resample.hip - weights (K5), float64 CDF in the fixed blocked order (K6), inverse-CDF search (K7),
+// gather-resample (K8) and the fused tail of the per-frame step.
+//
+// Summation order (DESIGN.md "Summation order", oracle/midas_oracle.c mo_blocked_scan): 16 values =
+// chunk (one lane), 16 chunks = group (a quarter-wave), 16 groups = block (one 256-thread workgroup,
+// 4096 values); every level is a sequential float64 sum in index order starting from +0.0.
+#include "midas_internal.hpp"
+#include "midas_math.hpp"
+
+namespace midas {
+
+constexpr double ISCLOSE_ATOL = 1e-8;  // torch.isclose default atol (particle_filter.py:460-463)
+
+MD double wsum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+MD double wmax(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o); v = t > v ? t : v; }
+    return v;
+}
+MD double wmin(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o); v = t < v ? t : v; }
+    return v;
+}
+
+// Block-local part of the spec scan.  v[16] = this lane's chunk (absent values = +0.0).
+// l[j] = GP_g + (TP_c + local_j); returns the block total W (identical in every thread).
+// Needs 16 doubles of LDS (s_gtot) and contains one __syncthreads().
+MD double block_scan(const double* v, double* l, double* s_gtot) {
+    double loc[SCAN_CHUNK];
+    double run = 0.0;
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) { run = run + v[j]; loc[j] = run; }
+    const double T = run;
+    const int lane = threadIdx.x & 63, c = threadIdx.x & 15, gbase = lane & ~15;
+    double TP = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double t = __shfl(T, gbase + j);
+        if (j < c) TP = TP + t;
+    }
+    if (c == 15) s_gtot[threadIdx.x >> 4] = TP + T;
+    __syncthreads();
+    const int g = threadIdx.x >> 4;
+    double GP = 0.0, W = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double t = s_gtot[j];
+        if (j < g) GP = GP + t;
+        W = W + t;
+    }
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) l[j] = GP + (TP + loc[j]);
+    return W;
+}
+
+// sequential sum of per-block totals part[0..nb), exclusive prefix up to `b` returned in bp
+MD void seq_totals(const double* __restrict__ part, int nb, int b, double& bp, double& total) {
+    double acc = 0.0, pre = 0.0;
+    for (int i = 0; i < nb; ++i) {
+        if (i == b) pre = acc;
+        acc = acc + part[i];
+    }
+    bp = pre;
+    total = acc;
+}
+
+// block-wide max/min over an array of partials
+MD void block_extrema(const double* __restrict__ pmax, const double* __restrict__ pmin, int np, double* s_red,
+                      double& mx, double& mn) {
+    double a = -INFINITY, b = INFINITY;
+    bool nan = false;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) {
+        double u = pmax[i], v = pmin[i];
+        nan |= (u != u) || (v != v);
+        a = u > a ? u : a;
+        b = v < b ? v : b;
+    }
+    a = wmax(a);
+    b = wmin(b);
+    const bool wnan = __any(nan);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_red[w] = a; s_red[8 + w] = b; s_red[16 + w] = wnan ? 1.0 : 0.0; }
+    __syncthreads();
+    a = s_red[0]; b = s_red[8];
+    double f = s_red[16];
+    for (int i = 1; i < nw; ++i) {
+        a = s_red[i] > a ? s_red[i] : a;
+        b = s_red[8 + i] < b ? s_red[8 + i] : b;
+        f += s_red[16 + i];
+    }
+    __syncthreads();
+    if (f != 0.0) { a = NAN; b = NAN; }  // torch.max/min propagate NaN
+    mx = a;
+    mn = b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// standalone kernels
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather_f64(int64_t N, const double* __restrict__ table,
+                                                    const int32_t* __restrict__ idx, double* __restrict__ out) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n < N) out[n] = table[idx[n]];
+}
+
+// per-block extrema of x (4096 values per block)
+__global__ __launch_bounds__(256) void k_extrema(int64_t N, const double* __restrict__ x, double* __restrict__ pmax,
+                                                 double* __restrict__ pmin) {
+    __shared__ double s_red[24];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK;
+    double a = -INFINITY, b = INFINITY;
+    bool nan = false;
+    for (int j = 0; j < SCAN_CHUNK; ++j) {
+        const int64_t i = base + (int64_t)j * 256 + threadIdx.x;
+        if (i < N) {
+            double v = x[i];
+            nan |= v != v;
+            a = v > a ? v : a;
+            b = v < b ? v : b;
+        }
+    }
+    a = wmax(a);
+    b = wmin(b);
+    const bool wnan = __any(nan);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_red[w] = a; s_red[8 + w] = b; s_red[16 + w] = wnan ? 1.0 : 0.0; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double f = 0.0;
+        for (int i = 0; i < 4; ++i) {
+            a = s_red[i] > a ? s_red[i] : a;
+            b = s_red[8 + i] < b ? s_red[8 + i] : b;
+            f += s_red[16 + i];
+        }
+        pmax[blockIdx.x] = f != 0.0 ? NAN : a;
+        pmin[blockIdx.x] = f != 0.0 ? NAN : b;
+    }
+}
+
+// e = exp(x - max) (or x when the softmax is skipped) ; per-block totals of e in the spec order.
+// valid (nullable) is NOT applied here.  flag_out[0] = 1 when the softmax is applied.
+__global__ __launch_bounds__(256) void k_exp_partial(int64_t N, const double* __restrict__ x, int np,
+                                                     const double* __restrict__ pmax, const double* __restrict__ pmin,
+                                                     int32_t softmax, double* __restrict__ e_out,
+                                                     double* __restrict__ part_sum, int32_t* __restrict__ flag_out) {
+    __shared__ double s_red[24];
+    __shared__ double s_gtot[16];
+    double mx, mn;
+    block_extrema(pmax, pmin, np, s_red, mx, mn);
+    // not isclose(max - min, 0): |max-min| > atol, or NaN (isclose(NaN, 0) is False)
+    const double spread = mx - mn;
+    const bool apply = softmax && !(__builtin_fabs(spread) <= ISCLOSE_ATOL);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && flag_out) flag_out[0] = apply ? 1 : 0;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_CHUNK;
+    double v[SCAN_CHUNK], l[SCAN_CHUNK];
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) {
+        const int64_t i = base + j;
+        double e = 0.0;
+        if (i < N) {
+            const double xi = x[i];
+            e = apply ? exp(xi - mx) : xi;
+            e_out[i] = e;
+        }
+        v[j] = e;
+    }
+    const double W = block_scan(v, l, s_gtot);
+    if (threadIdx.x == 0) part_sum[blockIdx.x] = W;
+}
+
+// w = e / S with S = sequential sum of the block totals (only when flag[0])
+__global__ __launch_bounds__(256) void k_normalise(int64_t N, double* __restrict__ w, int nb,
+                                                   const double* __restrict__ part_sum,
+                                                   const int32_t* __restrict__ flag) {
+    if (!flag[0]) return;
+    double bp, S;
+    seq_totals(part_sum, nb, 0, bp, S);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < N) w[i] = w[i] / S;
+}
+
+__global__ __launch_bounds__(256) void k_prune(int64_t N, double* __restrict__ w, const double* __restrict__ dist,
+                                               double thr, int32_t* __restrict__ nvalid) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    if (i < N) {
+        keep = !(dist[i] > thr);
+        w[i] = w[i] * (keep ? 1.0 : 0.0);
+    }
+    unsigned long long m = __ballot(keep);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(nvalid, (int32_t)__popcll(m));
+}
+
+// block-local prefix of w (spec order) -> lp ; block totals -> part ; NaN detection -> status[0] |= 2
+__global__ __launch_bounds__(256) void k_scan_local(int64_t N, const double* __restrict__ w, double* __restrict__ lp,
+                                                    double* __restrict__ part, int32_t* __restrict__ status) {
+    __shared__ double s_gtot[16];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_CHUNK;
+    double v[SCAN_CHUNK], l[SCAN_CHUNK];
+    bool nan = false;
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) {
+        const int64_t i = base + j;
+        double t = 0.0;
+        if (i < N) { t = w[i]; nan |= t != t; }
+        v[j] = t;
+    }
+    const double W = block_scan(v, l, s_gtot);
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j)
+        if (base + j < N) lp[base + j] = l[j];
+    if (threadIdx.x == 0) part[blockIdx.x] = W;
+    const bool wnan = __any(nan);
+    if (wnan && (threadIdx.x & 63) == 0) atomicOr(status, 2);
+}
+
+// cdf_i = (BP_b + lp_i) / total ; cdf_{N-1} = 1 ; status[0] = 1 when total == 0 (2 already set on NaN)
+__global__ __launch_bounds__(256) void k_cdf_final(int64_t N, double* __restrict__ cdf, int nb,
+                                                   const double* __restrict__ part, int32_t* __restrict__ status) {
+    double bp, total;
+    seq_totals(part, nb, blockIdx.x, bp, total);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (total != total) atomicOr(status, 2);
+        else if (total == 0.0) atomicOr(status, 1);
+    }
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK;
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) {
+        const int64_t i = base + (int64_t)j * 256 + threadIdx.x;
+        if (i < N) cdf[i] = (i == N - 1) ? 1.0 : (bp + cdf[i]) / total;
+    }
+}
+
+MD int32_t search_lower(const double* __restrict__ cdf, int64_t N, double u) {
+    int64_t lo = 0, hi = N;
+    while (hi > lo) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        if (cdf[mid] < u) lo = mid + 1; else hi = mid;
+    }
+    return (int32_t)(lo < N ? lo : N - 1);
+}
+MD int32_t search_upper(const double* __restrict__ cdf, int64_t N, double u) {
+    int64_t lo = 0, hi = N;
+    while (hi > lo) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+    }
+    return (int32_t)(lo < N ? lo : N - 1);
+}
+
+MD int32_t resample_slot(const double* __restrict__ cdf, int64_t N, int64_t M, int64_t i, int32_t mode,
+                         const double* __restrict__ u, float u32, uint64_t seed, uint64_t step) {
+    if (mode == MIDAS_RESAMPLE_MULTINOMIAL) {
+        const double ui = u ? u[i] : philox_uniform53((uint64_t)i, seed, step);
+        return search_lower(cdf, N, ui);
+    }
+    const float r = u32 >= 0.0f ? u32 : philox_uniform24(seed, step);
+    const float off = r / (float)M;
+    double loc = (double)i / (double)M + (double)off;
+    loc = loc >= 1.0 ? loc - 1.0 : loc;  // fmod(loc, 1) for loc in [0, 2)
+    return search_upper(cdf, N, loc);
+}
+
+__global__ __launch_bounds__(256) void k_search(int64_t N, const double* __restrict__ cdf, int64_t M, int32_t mode,
+                                                const double* __restrict__ u, float u32, uint64_t seed, uint64_t step,
+                                                int32_t* __restrict__ idx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < M) idx[i] = resample_slot(cdf, N, M, i, mode, u, u32, seed, step);
+}
+
+// rows of 16-byte multiples: one lane per 16-byte piece ; other sizes: one lane per byte group of 4/8/1
+template <typename V>
+__global__ __launch_bounds__(256) void k_gather_rows(int64_t M, const int32_t* __restrict__ idx,
+                                                     const V* __restrict__ src, V* __restrict__ dst, int per_row) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = t / per_row;
+    const int k = (int)(t - i * per_row);
+    if (i < M) dst[i * per_row + k] = src[(int64_t)idx[i] * per_row + k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused step tail
+// ------------------------------------------------------------------------------------------------
+// T1: m = max x ; e = exp(x - m) ; block totals of e
+__global__ __launch_bounds__(256) void k_tail_exp(StepTailArgs a, double* __restrict__ part_sum,
+                                                  int32_t* __restrict__ flag) {
+    __shared__ double s_red[24];
+    __shared__ double s_gtot[16];
+    double mx, mn;
+    block_extrema(a.part_max, a.part_min, a.npart, s_red, mx, mn);
+    const bool apply = a.softmax && !(__builtin_fabs(mx - mn) <= ISCLOSE_ATOL);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        flag[0] = apply ? 1 : 0;
+        a.status[0] = 0;
+        a.status[1] = 0;
+    }
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_CHUNK;
+    double v[SCAN_CHUNK], l[SCAN_CHUNK];
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) {
+        const int64_t i = base + j;
+        double e = 0.0;
+        if (i < a.N) {
+            const double xi = a.x[i];
+            e = apply ? exp(xi - mx) : xi;
+            a.weights[i] = e;
+        }
+        v[j] = e;
+    }
+    const double W = block_scan(v, l, s_gtot);
+    if (threadIdx.x == 0) part_sum[blockIdx.x] = W;
+}
+
+// T2: w = e / S ; wm = w * valid -> weights ; block-local prefix of wm -> cdf ; block totals
+__global__ __launch_bounds__(256) void k_tail_scan(StepTailArgs a, int nb, const double* __restrict__ part_sum,
+                                                   const int32_t* __restrict__ flag, double* __restrict__ part_w) {
+    __shared__ double s_gtot[16];
+    double bp, S = 1.0;
+    const bool apply = flag[0] != 0;
+    if (apply) seq_totals(part_sum, nb, 0, bp, S);
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_CHUNK;
+    double v[SCAN_CHUNK], l[SCAN_CHUNK];
+    bool nan = false;
+    int kept = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) {
+        const int64_t i = base + j;
+        double t = 0.0;
+        if (i < a.N) {
+            const double e = a.weights[i];
+            const double w = apply ? e / S : e;
+            const bool ok = a.valid[i] != 0;
+            t = w * (ok ? 1.0 : 0.0);
+            kept += ok ? 1 : 0;
+            nan |= t != t;
+            a.weights[i] = t;
+        }
+        v[j] = t;
+    }
+    const double W = block_scan(v, l, s_gtot);
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j)
+        if (base + j < a.N) a.cdf[base + j] = l[j];
+    if (threadIdx.x == 0) part_w[blockIdx.x] = W;
+    const bool wnan = __any(nan);
+    if (wnan && (threadIdx.x & 63) == 0) atomicOr(&a.status[0], 2);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
+    if ((threadIdx.x & 63) == 0 && kept) atomicAdd(&a.status[1], kept);
+}
+
+// T3: cdf = (BP + lp) / total
+__global__ __launch_bounds__(256) void k_tail_cdf(StepTailArgs a, int nb, const double* __restrict__ part_w) {
+    double bp, total;
+    seq_totals(part_w, nb, blockIdx.x, bp, total);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (total != total) atomicOr(&a.status[0], 2);
+        else if (total == 0.0) atomicOr(&a.status[0], 1);
+    }
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK;
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) {
+        const int64_t i = base + (int64_t)j * 256 + threadIdx.x;
+        if (i < a.N) a.cdf[i] = (i == a.N - 1) ? 1.0 : (bp + a.cdf[i]) / total;
+    }
+}
+
+// T4: resample slot i (identity when the weights are unusable) and gather pose / weight / hint
+__global__ __launch_bounds__(256) void k_tail_resample(StepTailArgs a, int nrm) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < a.N) {
+        int32_t src = (int32_t)i;
+        if (a.status[0] == 0) src = resample_slot(a.cdf, a.N, a.N, i, a.mode, a.u, a.u32, a.seed, a.step);
+        a.ridx[i] = src;
+        const float4* ps = reinterpret_cast<const float4*>(a.poses_prop + (int64_t)src * 16);
+        float4* pd = reinterpret_cast<float4*>(a.poses_out + i * 16);
+        float4 r0 = ps[0], r1 = ps[1], r2 = ps[2], r3 = ps[3];
+        pd[0] = r0; pd[1] = r1; pd[2] = r2; pd[3] = r3;
+        a.weights_out[i] = a.weights[src];
+        a.hint_out[i] = a.nn_idx[src];
+    }
+    if (a.part_rmse && blockIdx.x == 0) {
+        __shared__ double sa[4], sb[4];
+        double p = 0.0, q = 0.0;
+        for (int k = threadIdx.x; k < nrm; k += 256) { p += a.part_rmse[2 * k]; q += a.part_rmse[2 * k + 1]; }
+        p = wsum(p);
+        q = wsum(q);
+        if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = p; sb[threadIdx.x >> 6] = q; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            p = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+            q = (sb[0] + sb[1]) + (sb[2] + sb[3]);
+            a.rmse_out[0] = __builtin_sqrt(p / (double)a.N);
+            a.rmse_out[1] = __builtin_sqrt(q / (double)a.N);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+#define LAUNCH_CHECK(ctx) MIDAS_HIP_CHECK(ctx, hipGetLastError())
+
+int launch_gather_f64(midas_ctx* ctx, int64_t N, const double* table, const int32_t* idx, double* out) {
+    if (N == 0) return MIDAS_OK;
+    hipLaunchKernelGGL(k_gather_f64, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, N, table, idx, out);
+    LAUNCH_CHECK(ctx);
+    return MIDAS_OK;
+}
+
+int launch_softmax(midas_ctx* ctx, int64_t N, const double* x, int32_t softmax, double* w) {
+    if (N == 0) return MIDAS_OK;
+    const int nb = (int)ceil_div(N, SCAN_BLOCK);
+    void* sc;
+    int rc = midas_scratch(ctx, (size_t)nb * 3 * sizeof(double) + 64, &sc);
+    if (rc) return rc;
+    double* pmax = (double*)sc;
+    double* pmin = pmax + nb;
+    double* psum = pmin + nb;
+    int32_t* flag = (int32_t*)(psum + nb);
+    hipLaunchKernelGGL(k_extrema, dim3(nb), dim3(256), 0, ctx->stream, N, x, pmax, pmin);
+    hipLaunchKernelGGL(k_exp_partial, dim3(nb), dim3(256), 0, ctx->stream, N, x, nb, pmax, pmin, softmax, w, psum, flag);
+    hipLaunchKernelGGL(k_normalise, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, N, w, nb, psum, flag);
+    LAUNCH_CHECK(ctx);
+    return MIDAS_OK;
+}
+
+int launch_prune(midas_ctx* ctx, int64_t N, double* w, const double* dist, double thr, int32_t* nvalid) {
+    MIDAS_HIP_CHECK(ctx, hipMemsetAsync(nvalid, 0, sizeof(int32_t), ctx->stream));
+    if (N == 0) return MIDAS_OK;
+    hipLaunchKernelGGL(k_prune, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, N, w, dist, thr, nvalid);
+    LAUNCH_CHECK(ctx);
+    return MIDAS_OK;
+}
+
+int launch_cdf(midas_ctx* ctx, int64_t N, const double* w, double* cdf, int32_t* status) {
+    MIDAS_HIP_CHECK(ctx, hipMemsetAsync(status, 0, sizeof(int32_t), ctx->stream));
+    if (N == 0) return MIDAS_OK;
+    const int nb = (int)ceil_div(N, SCAN_BLOCK);
+    void* sc;
+    int rc = midas_scratch(ctx, (size_t)nb * sizeof(double), &sc);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(256), 0, ctx->stream, N, w, cdf, (double*)sc, status);
+    hipLaunchKernelGGL(k_cdf_final, dim3(nb), dim3(256), 0, ctx->stream, N, cdf, nb, (const double*)sc, status);
+    LAUNCH_CHECK(ctx);
+    return MIDAS_OK;
+}
+
+int launch_search(midas_ctx* ctx, int64_t N, const double* cdf, int64_t M, int32_t mode, const double* u, float u32,
+                  uint64_t seed, uint64_t step, int32_t* idx) {
+    if (M == 0) return MIDAS_OK;
+    hipLaunchKernelGGL(k_search, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, ctx->stream, N, cdf, M, mode, u, u32,
+                       seed, step, idx);
+    LAUNCH_CHECK(ctx);
+    return MIDAS_OK;
+}
+
+int launch_gather_rows(midas_ctx* ctx, int64_t M, const int32_t* idx, const void* src, void* dst, int32_t row_bytes) {
+    if (M == 0) return MIDAS_OK;
+    const bool a16 = row_bytes % 16 == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0;
+    const bool a8 = row_bytes % 8 == 0 && (uintptr_t)src % 8 == 0 && (uintptr_t)dst % 8 == 0;
+    const bool a4 = row_bytes % 4 == 0 && (uintptr_t)src % 4 == 0 && (uintptr_t)dst % 4 == 0;
+    if (a16) {
+        const int per = row_bytes / 16;
+        hipLaunchKernelGGL((k_gather_rows<float4>), dim3((unsigned)ceil_div(M * per, 256)), dim3(256), 0, ctx->stream, M,
+                           idx, (const float4*)src, (float4*)dst, per);
+    } else if (a8) {
+        const int per = row_bytes / 8;
+        hipLaunchKernelGGL((k_gather_rows<double>), dim3((unsigned)ceil_div(M * per, 256)), dim3(256), 0, ctx->stream, M,
+                           idx, (const double*)src, (double*)dst, per);
+    } else if (a4) {
+        const int per = row_bytes / 4;
+        hipLaunchKernelGGL((k_gather_rows<float>), dim3((unsigned)ceil_div(M * per, 256)), dim3(256), 0, ctx->stream, M,
+                           idx, (const float*)src, (float*)dst, per);
+    } else {
+        hipLaunchKernelGGL((k_gather_rows<uint8_t>), dim3((unsigned)ceil_div(M * row_bytes, 256)), dim3(256), 0,
+                           ctx->stream, M, idx, (const uint8_t*)src, (uint8_t*)dst, row_bytes);
+    }
+    LAUNCH_CHECK(ctx);
+    return MIDAS_OK;
+}
+
+int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base) {
+    const int nb = (int)ceil_div(a.N, SCAN_BLOCK);
+    void* sc;
+    int rc = midas_scratch(ctx, (size_t)nb * 2 * sizeof(double) + 64, &sc);
+    if (rc) return rc;
+    double* psum = (double*)sc;
+    double* pw = psum + nb;
+    int32_t* flag = (int32_t*)(pw + nb);
+    hipLaunchKernelGGL(k_tail_exp, dim3(nb), dim3(256), 0, ctx->stream, a, psum, flag);
+    prof_mark(ctx, prof_slot_base + 1);
+    hipLaunchKernelGGL(k_tail_scan, dim3(nb), dim3(256), 0, ctx->stream, a, nb, (const double*)psum, (const int32_t*)flag, pw);
+    prof_mark(ctx, prof_slot_base + 2);
+    hipLaunchKernelGGL(k_tail_cdf, dim3(nb), dim3(256), 0, ctx->stream, a, nb, (const double*)pw);
+    prof_mark(ctx, prof_slot_base + 3);
+    hipLaunchKernelGGL(k_tail_resample, dim3((unsigned)ceil_div(a.N, 256)), dim3(256), 0, ctx->stream, a,
+                       a.part_rmse ? particle_update_blocks(a.N) : 0);
+    prof_mark(ctx, prof_slot_base + 4);
+    LAUNCH_CHECK(ctx);
+    return MIDAS_OK;
+}
+
+}  // namespace midas

@@ -1,0 +1,105 @@
+"""Device-resident filter engine: the reference's per-frame loop body as ONE C-ABI call per frame.
+
+`FilterEngine.step()` is the fast path behind the north-star aliases `step()/update_weights()/
+resample()` (midastouch_amd/filter.py): score codebook -> propagate -> feature -> NN -> gather score ->
+softmax -> prune -> CDF -> resample -> gather, all on the GPU with no host synchronisation
+(reference loop body: filter/filter.py:150-190, clustering/annealing excluded = fixed N).
+
+Two random-draw modes:
+  * parity mode  - the caller supplies the host draws of the reference (torch CPU mt19937:
+                   tn, rot from torch.normal in that order, then N float64 uniforms);
+  * device mode  - the kernels draw from the Philox spec streams keyed by (seed, step).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib, ops
+from ._lib import MidasError, StepArgs, _ptr
+
+
+class FilterEngine:
+    def __init__(self, cb_poses, cb_embeddings, mesh_vertices, num_particles: int, *, sig_t=2e-4, sig_r=0.5,
+                 pen_max=0.002, seed=4000, softmax=True, resample="weighted_random", device=None):
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.ctx = _lib.context(dev)
+        self.device = self.ctx.device
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.cb_poses = torch.as_tensor(cb_poses).to(**f32).contiguous()
+        self.cb_feat = ops.se3_feature(self.cb_poses)
+        self.tree6 = ops.Tree(self.cb_feat)
+        self.codebook = ops.Codebook(torch.as_tensor(cb_embeddings).to(self.device))
+        self.tree3 = ops.Tree(torch.as_tensor(mesh_vertices).to(self.device, torch.float64))
+        self.K, self.D = self.codebook.K, self.codebook.D
+        self.sig_t, self.sig_r, self.pen_max = float(sig_t), float(sig_r), float(pen_max)
+        self.seed, self.softmax = int(seed), bool(softmax)
+        self.mode = {"weighted_random": _lib.RESAMPLE_MULTINOMIAL, "low_var": _lib.RESAMPLE_SYSTEMATIC,
+                     "low_var_batch": _lib.RESAMPLE_SYSTEMATIC}[resample]
+        self.N = int(num_particles)
+        N = self.N
+        self.poses = torch.zeros((N, 4, 4), **f32)
+        self.poses_prop = torch.zeros((N, 4, 4), **f32)
+        self.weights = torch.zeros(N, dtype=torch.float64, device=self.device)      # pre-resample, masked
+        self.weights_res = torch.ones(N, dtype=torch.float64, device=self.device)   # gathered by resample
+        self.nn_idx = torch.zeros(N, dtype=torch.int32, device=self.device)
+        self.hint = torch.full((N,), -1, dtype=torch.int32, device=self.device)
+        self.hint_next = torch.full((N,), -1, dtype=torch.int32, device=self.device)
+        self.ridx = torch.zeros(N, dtype=torch.int32, device=self.device)
+        self.status = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self.rmse = torch.zeros(2, dtype=torch.float64, device=self.device)
+        self.step_count = 0
+        self.use_hint = True
+
+    # ---- state ----------------------------------------------------------------------------------
+    def set_particles(self, poses: torch.Tensor):
+        poses = torch.as_tensor(poses).to(self.device, torch.float32).contiguous()
+        if poses.shape != (self.N, 4, 4):
+            raise MidasError(f"expected ({self.N},4,4) poses, got {tuple(poses.shape)}")
+        self.poses.copy_(poses)
+        self.hint.fill_(-1)
+
+    def project_to_codebook(self):
+        """poses := codebook pose nearest to each particle (filter/filter.py:159-160)."""
+        idx = ops.nn6(self.tree6, ops.se3_feature(self.poses))
+        self.poses.copy_(ops.gather_rows(self.cb_poses, idx))
+        self.hint.copy_(idx)
+        return idx
+
+    # ---- one frame ------------------------------------------------------------------------------
+    def step(self, odom, code, gt=None, tn=None, rot=None, u=None, u32=-1.0, multiplier: float = 1.0):
+        """Runs one frame; results stay on the device (self.poses, self.weights, self.ridx ...)."""
+        a = StepArgs()
+        a.N = self.N
+        a.poses_in, a.poses_prop, a.poses_out = _ptr(self.poses), _ptr(self.poses_prop), _ptr(self.poses)
+        a.weights, a.weights_out = _ptr(self.weights), _ptr(self.weights_res)
+        a.hint_in = _ptr(self.hint) if self.use_hint else None
+        a.nn_idx, a.hint_out, a.ridx = _ptr(self.nn_idx), _ptr(self.hint_next), _ptr(self.ridx)
+        a.odom16, a.code = _ptr(odom), _ptr(code)
+        a.gt16 = _ptr(gt)
+        a.rmse = _ptr(self.rmse) if gt is not None else None
+        a.tn, a.rot, a.u = _ptr(tn), _ptr(rot), _ptr(u)
+        a.u32 = float(u32)
+        mul = max(float(multiplier), 1.0)  # motionModel clamps multiplier >= 1 (particle_filter.py:365-366)
+        a.std_t, a.std_r = mul * self.sig_t, mul * self.sig_r
+        a.seed, a.step = self.seed, self.step_count
+        a.prune_thr = self.pen_max
+        a.softmax, a.resample_mode = int(self.softmax), self.mode
+        a.status = _ptr(self.status)
+        self._keep = (odom, code, gt, tn, rot, u)  # keep operands alive until the stream has consumed them
+        self.ctx.check(self.ctx.lib.midas_filter_step(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h,
+                                                      C.byref(a)))
+        self.hint, self.hint_next = self.hint_next, self.hint
+        self.step_count += 1
+
+    # ---- profiling --------------------------------------------------------------------------------
+    def profile(self, on: bool):
+        self.ctx.call("midas_profile_enable", int(on))
+
+    def profile_read(self, reset=True):
+        ms = (C.c_double * _lib.PROF_SLOTS)()
+        calls = C.c_int64()
+        self.ctx.call("midas_profile_read", ms, C.byref(calls), int(reset))
+        names = [self.ctx.lib.midas_profile_slot_name(i).decode() for i in range(_lib.PROF_SLOTS)]
+        return {n: ms[i] for i, n in enumerate(names) if n}, calls.value

@@ -425,38 +425,40 @@ MO_API void mo_score_f64(int64_t K, int64_t D, const double* emb, const double* 
 /* float64 blocked scan (the summation-order spec)                                            */
 /* ------------------------------------------------------------------------------------------ */
 /*
- * Elements are grouped in chunks of MO_CHUNK = 16 consecutive values; MO_TPB = 256 chunks form a
- * block of 4096 values.
- *   local_i  = sequential inclusive sum inside the chunk
- *   TP_t     = sequential exclusive sum of the chunk totals inside the block
- *   BP_b     = sequential exclusive sum of the block totals, block total W_b = TP_255 + T_255
- *   prefix_i = BP_b + (TP_t + local_i)
- * The grand total is prefix_{N-1}.  Missing trailing elements behave as absent.
+ * Three-level fixed order.  16 consecutive values form a chunk, 16 chunks a group (256 values),
+ * 16 groups a block (4096 values).  Every accumulator starts at +0.0 and adds in index order:
+ *   local_i  = inclusive sum inside the chunk
+ *   TP_c     = exclusive sum of the chunk totals inside the group
+ *   GP_g     = exclusive sum of the group totals inside the block (group total = sum of its chunk totals)
+ *   BP_b     = exclusive sum of the block totals            (block total = sum of its group totals)
+ *   prefix_i = BP_b + (GP_g + (TP_c + local_i))
+ * The grand total is the sum of the block totals in order (== prefix_{N-1}).  Missing trailing
+ * elements count as +0.0.
  */
 #define MO_CHUNK 16
-#define MO_TPB 256
+#define MO_GROUP 16
+#define MO_BLOCK 16
 
 MO_API double mo_blocked_scan(int64_t N, const double* w, double* prefix) {
-    const int64_t BLK = (int64_t)MO_CHUNK * MO_TPB;
-    double BP = 0.0, total = 0.0;
+    const int64_t GRP = (int64_t)MO_CHUNK * MO_GROUP, BLK = GRP * MO_BLOCK;
+    double BP = 0.0;
     for (int64_t b0 = 0; b0 < N; b0 += BLK) {
-        double TP = 0.0;
-        int64_t bend = b0 + BLK < N ? b0 + BLK : N;
-        for (int64_t c0 = b0; c0 < bend; c0 += MO_CHUNK) {
-            int64_t cend = c0 + MO_CHUNK < bend ? c0 + MO_CHUNK : bend;
-            double local = 0.0;
-            for (int64_t i = c0; i < cend; ++i) {
-                local = (i == c0) ? w[i] : local + w[i];
-                double v = BP + (TP + local);
-                if (prefix) prefix[i] = v;
-                total = v;
+        double GP = 0.0;
+        for (int64_t g0 = b0; g0 < b0 + BLK && g0 < N; g0 += GRP) {
+            double TP = 0.0;
+            for (int64_t c0 = g0; c0 < g0 + GRP && c0 < N; c0 += MO_CHUNK) {
+                double local = 0.0;
+                for (int64_t i = c0; i < c0 + MO_CHUNK && i < N; ++i) {
+                    local = local + w[i];
+                    if (prefix) prefix[i] = BP + (GP + (TP + local));
+                }
+                TP = TP + local;
             }
-            TP = (c0 == b0) ? local : TP + local;
+            GP = GP + TP;
         }
-        /* W_b = TP (inclusive over all chunks) ; BP_{b+1} = BP_b + W_b */
-        BP = (b0 == 0) ? TP : BP + TP;
+        BP = BP + GP;
     }
-    return total;
+    return BP;
 }
 
 /*

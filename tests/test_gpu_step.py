@@ -1,0 +1,165 @@
+"""The fused per-frame step (midas_filter_step through FilterEngine) against the oracle's loop body,
+free-running over a synthetic trajectory: both sides start from the same particles and consume the
+same random draws; every frame must give bit-identical propagated poses, NN indices, prune masks and
+resample indices, and weights within 1e-12 relative (north-star bar: 1e-5).  Needs an MI355X.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda", 0)
+
+
+def _setup(N, K, D, seed=0, obj="004_sugar_box"):
+    from midastouch_amd.synthetic import make_codebook, make_trajectory, mesh_scale
+    cb = make_codebook(obj, K=K, D=D, seed=1000 + seed)
+    traj = make_trajectory(cb, T=24, seed=2000 + seed)
+    return cb, traj, mesh_scale(cb.extents)
+
+
+def _init_particles(oracle, cb, traj, scale, N, seed):
+    g = torch.Generator().manual_seed(seed)
+    tn = torch.normal(0.0, scale / 3.0 * 0.05, size=(N, 3), generator=g).numpy()
+    rot = torch.normal(0.0, 60.0 * 0.05, size=(N, 3), generator=g).numpy()
+    return oracle.init_filter_compose(traj.gt_poses[0], tn, rot)
+
+
+def _compare_step(eng, ref, t, check_rmse=None):
+    assert np.array_equal(eng.poses_prop.cpu().numpy(), ref["poses_prop"]), f"frame {t}: propagated poses"
+    assert np.array_equal(eng.nn_idx.cpu().numpy(), ref["nn_idx"]), f"frame {t}: NN index"
+    w = eng.weights.cpu().numpy()
+    assert np.array_equal(w == 0, ref["weights"] == 0), f"frame {t}: prune mask"
+    np.testing.assert_allclose(w, ref["weights"], rtol=1e-12, atol=0, err_msg=f"frame {t}")
+    assert np.max(np.abs(w - ref["weights"])) < 1e-5
+    status = eng.status.cpu().numpy()
+    assert status[0] == ref["status"]
+    assert status[1] == int(ref["mask"].sum())
+    assert np.array_equal(eng.ridx.cpu().numpy(), ref["ridx"]), f"frame {t}: resample indices"
+    assert np.array_equal(eng.poses.cpu().numpy(), ref["poses"]), f"frame {t}: resampled poses"
+    np.testing.assert_allclose(eng.weights_res.cpu().numpy(), ref["weights_res"], rtol=1e-12)
+    assert np.array_equal(eng.hint.cpu().numpy(), ref["nn_idx_res"])
+
+
+@pytest.mark.parametrize("mode", ["weighted_random", "low_var"])
+def test_step_parity_host_draws(dev, oracle, mode):
+    """Parity mode: torch CPU mt19937 draws in the reference's order (tn, rot, then the uniforms)."""
+    from midastouch_amd.engine import FilterEngine
+    N, K, D = 2000, 5000, 256
+    cb, traj, scale = _setup(N, K, D)
+    ofl = oracle.OracleFilter(cb.poses, cb.embeddings, cb.mesh_vertices)
+    eng = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, resample=mode, device=dev)
+    poses = _init_particles(oracle, cb, traj, scale, N, 5)
+    # t = 0: project onto the codebook (filter/filter.py:159-160)
+    idx0 = ofl.SE3_NN_idx(poses)
+    poses = cb.poses[idx0]
+    eng.set_particles(torch.as_tensor(poses))
+    eng.project_to_codebook()
+    assert np.array_equal(eng.poses.cpu().numpy(), poses)
+    for t in range(1, 20):
+        torch.manual_seed(3000 + t)
+        tn = torch.normal(mean=0.0, std=2e-4, size=(N, 3))
+        rot = torch.normal(mean=0.0, std=0.5, size=(N, 3))
+        if mode == "weighted_random":
+            u, u32 = torch.rand(N, dtype=torch.float64), -1.0
+        else:
+            u, u32 = None, float(torch.rand(1).item())
+        ref = ofl.step(poses, traj.odoms[t], traj.codes[t], tn.numpy(), rot.numpy(),
+                       u=None if u is None else u.numpy(), mode=mode, u32=u32)
+        eng.step(torch.as_tensor(traj.odoms[t]).to(dev), torch.as_tensor(traj.codes[t]).to(dev),
+                 gt=torch.as_tensor(traj.gt_poses[t]).to(dev), tn=tn.to(dev), rot=rot.to(dev),
+                 u=None if u is None else u.to(dev), u32=u32)
+        _compare_step(eng, ref, t)
+        rt, rr = oracle.particle_rmse(ref["poses_prop"], traj.gt_poses[t])
+        rm = eng.rmse.cpu().numpy()
+        assert rm[0] == pytest.approx(rt, rel=1e-9) and rm[1] == pytest.approx(rr, rel=1e-4, abs=0.03)
+        poses = ref["poses"]
+    assert len(np.unique(eng.ridx.cpu().numpy())) < N  # resampling actually concentrated the particles
+
+
+def test_step_parity_device_philox(dev, oracle):
+    """Device mode: the kernels' Philox streams are restated by the oracle, so the run is still exact."""
+    from midastouch_amd.engine import FilterEngine
+    N, K, D = 3000, 4000, 512
+    cb, traj, scale = _setup(N, K, D, seed=1)
+    ofl = oracle.OracleFilter(cb.poses, cb.embeddings, cb.mesh_vertices)
+    eng = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4000, device=dev)
+    poses = cb.poses[ofl.SE3_NN_idx(_init_particles(oracle, cb, traj, scale, N, 6))]
+    eng.set_particles(torch.as_tensor(poses))
+    for t in range(1, 16):
+        tn, rot = oracle.philox_noise(N, 4000, t - 1, np.float32(2e-4), np.float32(0.5))
+        u = oracle.philox_uniform64(N, 4000, t - 1)
+        ref = ofl.step(poses, traj.odoms[t], traj.codes[t], tn, rot, u=u)
+        eng.step(torch.as_tensor(traj.odoms[t]).to(dev), torch.as_tensor(traj.codes[t]).to(dev))
+        _compare_step(eng, ref, t)
+        poses = ref["poses"]
+
+
+def test_step_hint_does_not_change_results(dev, oracle):
+    from midastouch_amd.engine import FilterEngine
+    N, K, D = 1500, 3000, 256
+    cb, traj, scale = _setup(N, K, D, seed=2)
+    outs = []
+    for use_hint in (True, False):
+        eng = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, device=dev)
+        eng.use_hint = use_hint
+        eng.set_particles(torch.as_tensor(_init_particles(oracle, cb, traj, scale, N, 7)))
+        eng.project_to_codebook()
+        for t in range(1, 10):
+            eng.step(torch.as_tensor(traj.odoms[t]).to(dev), torch.as_tensor(traj.codes[t]).to(dev))
+        outs.append((eng.poses.cpu().numpy(), eng.ridx.cpu().numpy(), eng.weights.cpu().numpy()))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
+def test_step_all_drifted_and_guards(dev, oracle):
+    """Every particle off the surface -> weights all zero -> resampler keeps the particles (status 1)."""
+    from midastouch_amd.engine import FilterEngine
+    N, K, D = 512, 1000, 256
+    cb, traj, scale = _setup(N, K, D, seed=3)
+    eng = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, device=dev)
+    poses = _init_particles(oracle, cb, traj, scale, N, 8)
+    poses[:, :3, 3] += 1.0
+    eng.set_particles(torch.as_tensor(poses))
+    eng.step(torch.as_tensor(np.eye(4, dtype=np.float32)).to(dev), torch.as_tensor(traj.codes[1]).to(dev))
+    st = eng.status.cpu().numpy()
+    assert st[0] == 1 and st[1] == 0
+    assert np.array_equal(eng.ridx.cpu().numpy(), np.arange(N))
+    assert np.array_equal(eng.poses.cpu().numpy(), eng.poses_prop.cpu().numpy())
+    assert float(eng.weights.abs().sum().item()) == 0.0
+
+
+def test_step_full_size_properties(dev):
+    """BASELINE config 2 sizes (N=100k, K=50k, D=512): size-independent properties."""
+    from midastouch_amd.engine import FilterEngine
+    from midastouch_amd.synthetic import make_codebook, make_trajectory
+    N, K, D = 100_000, 50_000, 512
+    cb = make_codebook(K=K, D=D, seed=1002)
+    traj = make_trajectory(cb, T=8, seed=2002)
+    eng = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, device=dev)
+    rng = np.random.default_rng(0)
+    start = cb.poses[rng.integers(0, K, N)]
+    eng.set_particles(torch.as_tensor(start))
+    eng.project_to_codebook()
+    for t in range(1, 6):
+        eng.step(torch.as_tensor(traj.odoms[t]).to(dev), torch.as_tensor(traj.codes[t]).to(dev))
+        w = eng.weights
+        st = eng.status.cpu().numpy()
+        assert st[0] == 0
+        assert 0.0 < float(w.sum().item()) <= 1.0 + 1e-9
+        ridx = eng.ridx.cpu().numpy()
+        assert ridx.min() >= 0 and ridx.max() < N
+        assert float(w[torch.as_tensor(ridx).to(dev).long()].min().item()) > 0.0  # never picks a pruned particle
+        # gathered poses are exactly the propagated poses at ridx
+        assert torch.equal(eng.poses, eng.poses_prop[torch.as_tensor(ridx).to(dev).long()])
+        # NN indices are the true nearest codebook entries: re-check a sample by brute force on the GPU
+        feat = __import__("midastouch_amd.ops", fromlist=["ops"]).se3_feature(eng.poses_prop[:512])
+        d = torch.cdist(feat.double(), eng.cb_feat.double())
+        assert torch.equal(d.argmin(dim=1).int(), eng.nn_idx[:512])

@@ -92,16 +92,24 @@ def test_blocked_scan_structure(oracle):
         pre, total = oracle.blocked_scan(w)
         assert total == pre[-1]
         np.testing.assert_allclose(pre, np.cumsum(w), rtol=1e-13)
-        # restate the order with numpy: chunk-local cumsum, sequential chunk totals per block, blocks
+        # restate the order with numpy: chunk (16) / group (16 chunks) / block (16 groups)
         pad = (-n) % 4096
-        wp = np.concatenate([w, np.zeros(pad)]).reshape(-1, 256, 16)
-        local = np.cumsum(wp, axis=2)
-        tot = local[:, :, -1]
-        tp = np.concatenate([np.zeros((tot.shape[0], 1)), np.cumsum(tot, axis=1)[:, :-1]], axis=1)
-        W = np.cumsum(tot, axis=1)[:, -1]
+        wp = np.concatenate([w, np.zeros(pad)]).reshape(-1, 16, 16, 16)  # block, group, chunk, elem
+        local = np.cumsum(wp, axis=3)
+        ctot = local[..., -1]
+        tp_inc = np.cumsum(ctot, axis=2)
+        tp = tp_inc - ctot
+        tp[..., 0] = 0.0
+        tp[..., 1:] = tp_inc[..., :-1]
+        gtot = tp_inc[..., -1]
+        gp_inc = np.cumsum(gtot, axis=1)
+        gp = np.zeros_like(gp_inc)
+        gp[:, 1:] = gp_inc[:, :-1]
+        W = gp_inc[:, -1]
         bp = np.concatenate([[0.0], np.cumsum(W)[:-1]])
-        expect = (bp[:, None, None] + (tp[:, :, None] + local)).reshape(-1)[:n]
+        expect = (bp[:, None, None, None] + (gp[:, :, None, None] + (tp[..., None] + local))).reshape(-1)[:n]
         assert np.array_equal(pre, expect)
+        assert total == np.cumsum(W)[-1]
 
 
 def test_philox_streams(oracle):
