@@ -43,7 +43,8 @@ typedef struct midas_codebook midas_codebook;
 typedef struct midas_tree midas_tree;
 
 /* ---- context --------------------------------------------------------------------------------- */
-/* `hip_stream` is a hipStream_t (NULL = the library creates its own stream). */
+/* `hip_stream` is a hipStream_t; NULL = the device's default (null) stream, which is what torch's
+ * default stream is on ROCm.  The library never creates streams of its own. */
 int midas_ctx_create(int device, void* hip_stream, midas_ctx** out);
 int midas_ctx_destroy(midas_ctx* ctx);
 int midas_ctx_set_stream(midas_ctx* ctx, void* hip_stream);
@@ -76,6 +77,9 @@ int midas_tree_destroy(midas_tree* tree);
  * per query that seeds the search bound; d2_dev nullable.  Replaces kneighbors (tactile_tree.py:50-52). */
 int midas_nn6(midas_ctx* ctx, const midas_tree* tree, int64_t N, const float* feat6_dev,
               const int32_t* hint_dev, int32_t* idx_dev, float* d2_dev);
+/* Diagnostic twin of midas_nn6: leaves / tree nodes visited per query (used to tune the tree). */
+int midas_nn6_stats(midas_ctx* ctx, const midas_tree* tree, int64_t N, const float* feat6_dev,
+                    const int32_t* hint_dev, int32_t* leaves_dev, int32_t* nodes_dev);
 /* dist[n] = float64 distance from pose n's translation to the nearest vertex.
  * Replaces mesh_kdtree.query (modules/particle_filter.py:386-392). */
 int midas_nn3(midas_ctx* ctx, const midas_tree* tree, int64_t N, const float* poses_dev, double* dist_dev);

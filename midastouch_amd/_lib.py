@@ -73,6 +73,7 @@ SIGNATURES = {
     "midas_tree_build": (C.c_int, [_P, _I32, _I64, _P, C.POINTER(_P)]),
     "midas_tree_destroy": (C.c_int, [_P]),
     "midas_nn6": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P]),
+    "midas_nn6_stats": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P]),
     "midas_nn3": (C.c_int, [_P, _P, _I64, _P, _P]),
     "midas_propagate": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P, _F, _F, _U64, _U64]),
     "midas_check_poses": (C.c_int, [_P, _I64, _P, _P, _P]),
@@ -161,7 +162,17 @@ class Context:
             detail = self.lib.midas_last_error(self.h)
             raise MidasError(detail.decode() if detail else self.lib.midas_strerror(rc).decode())
 
+    def bind_current_stream(self):
+        """Follow torch's current stream on this device (kernels stay ordered with torch's own work)."""
+        import torch
+
+        s = torch.cuda.current_stream(self.device)
+        if s.cuda_stream != self._stream.cuda_stream:
+            self.check(self.lib.midas_ctx_set_stream(self.h, C.c_void_p(s.cuda_stream)))
+            self._stream = s
+
     def call(self, name: str, *args):
+        self.bind_current_stream()
         self.check(getattr(self.lib, name)(self.h, *args))
 
     def sync(self):

@@ -107,16 +107,10 @@ MIDAS_EXPORT int midas_ctx_create(int device, void* hip_stream, midas_ctx** out)
     if (!ctx) return MIDAS_ERR_NOMEM;
     ctx->device = device;
     ctx->scratch = new (std::nothrow) ScratchState();
-    if (hip_stream) {
-        ctx->stream = (hipStream_t)hip_stream;
-    } else {
-        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
-            delete scratch_of(ctx);
-            delete ctx;
-            return MIDAS_ERR_HIP;
-        }
-        ctx->own_stream = true;
-    }
+    // NULL selects the device's default (null) stream - torch's default stream on ROCm - so that
+    // kernels stay ordered with the caller's other work; the library never creates a stream.
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
     *out = ctx;
     return MIDAS_OK;
 }
@@ -209,9 +203,8 @@ MIDAS_EXPORT int midas_tree_build(midas_ctx* ctx, int32_t dim, int64_t K, const 
 MIDAS_EXPORT int midas_tree_destroy(midas_tree* t) {
     if (!t) return MIDAS_OK;
     (void)hipStreamSynchronize(t->ctx->stream);
-    if (t->nodes) (void)hipFree(t->nodes);
+    if (t->boxes) (void)hipFree(t->boxes);
     if (t->pts) (void)hipFree(t->pts);
-    if (t->leaf_start) (void)hipFree(t->leaf_start);
     if (t->inv_perm) (void)hipFree(t->inv_perm);
     delete t;
     return MIDAS_OK;
@@ -222,6 +215,13 @@ MIDAS_EXPORT int midas_nn6(midas_ctx* ctx, const midas_tree* tree, int64_t N, co
     MIDAS_ENTER(ctx);
     MIDAS_REQUIRE(ctx, tree && tree->dim == 6 && N >= 0 && (N == 0 || (feat6_dev && idx_dev)));
     return launch_nn6(ctx, tree, N, feat6_dev, hint_dev, idx_dev, d2_dev);
+}
+
+MIDAS_EXPORT int midas_nn6_stats(midas_ctx* ctx, const midas_tree* tree, int64_t N, const float* feat6_dev,
+                                 const int32_t* hint_dev, int32_t* leaves_dev, int32_t* nodes_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, tree && tree->dim == 6 && N >= 0 && (N == 0 || (feat6_dev && leaves_dev && nodes_dev)));
+    return launch_nn6_stats(ctx, tree, N, feat6_dev, hint_dev, leaves_dev, nodes_dev);
 }
 
 MIDAS_EXPORT int midas_nn3(midas_ctx* ctx, const midas_tree* tree, int64_t N, const float* poses_dev, double* dist_dev) {

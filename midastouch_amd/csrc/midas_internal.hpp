@@ -11,36 +11,38 @@ namespace midas {
 
 // ---- KD-tree layouts (shared host/device) ------------------------------------------------------
 // Complete binary tree in 1-based heap order: node n has children 2n, 2n+1; the 2^L leaves are the
-// nodes [2^L, 2^(L+1)).  Points are stored in leaf order; leaf l owns [leaf_start[l], leaf_start[l+1]).
-struct alignas(16) Node6 { float lo_max, hi_min; int32_t dim; int32_t pad; };
+// nodes [2^L, 2^(L+1)).  Every node (leaves included) stores the axis-aligned bounding box of its
+// points, so the two child boxes of node n are the 96 contiguous bytes boxes[2n], boxes[2n+1].
+// Leaf l owns the LEAF_CAP fixed point slots pts[l*LEAF_CAP ..); unused slots hold +inf coordinates.
+struct alignas(16) Box6 { float lo[6], hi[6]; };
 struct alignas(16) Point6 { float c[6]; int32_t idx; int32_t pad; };
-struct alignas(8) Node3 { double lo_max, hi_min; int32_t dim; int32_t pad; };
+struct alignas(16) Box3 { double lo[3], hi[3]; };
 struct alignas(16) Point3 { double c[3]; int64_t idx; };
 
 struct Kd6 {
     using T = float;
-    using Node = Node6;
+    using Box = Box6;
     using Point = Point6;
     static constexpr int DIM = 6;
 };
 struct Kd3 {
     using T = double;
-    using Node = Node3;
+    using Box = Box3;
     using Point = Point3;
     static constexpr int DIM = 3;
 };
 
 template <class KD>
 struct TreeView {
-    const typename KD::Node* nodes;  // [2^L], entry 0 unused
-    const typename KD::Point* pts;   // [K]
-    const int32_t* leaf_start;       // [2^L + 1]
-    const int32_t* inv_perm;         // [K] original index -> position in pts
+    const typename KD::Box* boxes;  // [2^(L+1)], entries 0 and 1 unused/root
+    const typename KD::Point* pts;  // [2^L * LEAF_CAP]
+    const int32_t* inv_perm;        // [K] original index -> slot in pts
     int32_t levels;
     int64_t K;
 };
 
-constexpr int LEAF_CAP = 8;  // leaves hold ceil(K / 2^L) <= 8 points
+constexpr int LEAF_CAP = 8;     // point slots per leaf; leaves hold ceil(K / 2^L) <= 8 points
+constexpr int KD_MAX_LEVELS = 28;
 
 }  // namespace midas
 
@@ -75,9 +77,8 @@ struct midas_tree {
     int32_t dim;
     int64_t K;
     int32_t levels;
-    void* nodes;
+    void* boxes;
     void* pts;
-    int32_t* leaf_start;
     int32_t* inv_perm;
 };
 
@@ -120,6 +121,8 @@ int launch_check_poses(midas_ctx* ctx, int64_t N, const float* poses, uint8_t* f
 int launch_nn6(midas_ctx* ctx, const midas_tree* t, int64_t N, const float* feat6, const int32_t* hint,
                int32_t* idx, float* d2);
 int launch_nn3(midas_ctx* ctx, const midas_tree* t, int64_t N, const float* poses, double* dist);
+int launch_nn6_stats(midas_ctx* ctx, const midas_tree* t, int64_t N, const float* feat6, const int32_t* hint,
+                     int32_t* leaves, int32_t* nodes);
 int launch_rmse(midas_ctx* ctx, int64_t N, const float* poses, const float* gt16, double* out2);
 struct ParticleUpdateArgs {
     int64_t N;

@@ -20,9 +20,8 @@ namespace midas {
 // =================================================================================================
 template <class KD>
 struct HostTree {
-    std::vector<typename KD::Node> nodes;
+    std::vector<typename KD::Box> boxes;
     std::vector<typename KD::Point> pts;
-    std::vector<int32_t> leaf_start;
     std::vector<int32_t> inv_perm;
     int levels = 0;
 };
@@ -32,37 +31,40 @@ static void build_rec(HostTree<KD>& t, const typename KD::T* P, std::vector<int3
                       int64_t hi, int level) {
     using T = typename KD::T;
     constexpr int DIM = KD::DIM;
+    // bounding box of this node's points (+inf/-inf when empty: its distance to any query is +inf)
+    typename KD::Box bx;
+    for (int d = 0; d < DIM; ++d) { bx.lo[d] = INFINITY; bx.hi[d] = -INFINITY; }
+    for (int64_t i = lo; i < hi; ++i)
+        for (int d = 0; d < DIM; ++d) {
+            T v = P[(int64_t)perm[i] * DIM + d];
+            bx.lo[d] = v < bx.lo[d] ? v : bx.lo[d];
+            bx.hi[d] = v > bx.hi[d] ? v : bx.hi[d];
+        }
+    t.boxes[node] = bx;
     if (level == t.levels) {
-        t.leaf_start[node - (1u << t.levels)] = (int32_t)lo;
+        const int64_t leaf = (int64_t)node - ((int64_t)1 << t.levels);
         std::sort(perm.begin() + lo, perm.begin() + hi);
+        for (int64_t i = lo; i < hi; ++i) {
+            typename KD::Point p;
+            for (int d = 0; d < DIM; ++d) p.c[d] = P[(int64_t)perm[i] * DIM + d];
+            p.idx = perm[i];
+            if constexpr (DIM == 6) p.pad = 0;
+            const int64_t slot = leaf * LEAF_CAP + (i - lo);
+            t.pts[slot] = p;
+            t.inv_perm[perm[i]] = (int32_t)slot;
+        }
         return;
     }
     int best_dim = 0;
     T best_spread = -1;
-    for (int d = 0; d < DIM; ++d) {
-        T mn = INFINITY, mx = -INFINITY;
-        for (int64_t i = lo; i < hi; ++i) {
-            T v = P[(int64_t)perm[i] * DIM + d];
-            mn = v < mn ? v : mn;
-            mx = v > mx ? v : mx;
-        }
-        if (mx - mn > best_spread) { best_spread = mx - mn; best_dim = d; }
-    }
+    for (int d = 0; d < DIM; ++d)
+        if (bx.hi[d] - bx.lo[d] > best_spread) { best_spread = bx.hi[d] - bx.lo[d]; best_dim = d; }
     const int64_t mid = lo + (hi - lo + 1) / 2;
     auto cmp = [&](int32_t a, int32_t b) {
         T va = P[(int64_t)a * DIM + best_dim], vb = P[(int64_t)b * DIM + best_dim];
         return va < vb || (va == vb && a < b);
     };
     if (mid < hi) std::nth_element(perm.begin() + lo, perm.begin() + mid, perm.begin() + hi, cmp);
-    T lo_max = -INFINITY, hi_min = INFINITY;
-    for (int64_t i = lo; i < mid; ++i) lo_max = std::max(lo_max, P[(int64_t)perm[i] * DIM + best_dim]);
-    for (int64_t i = mid; i < hi; ++i) hi_min = std::min(hi_min, P[(int64_t)perm[i] * DIM + best_dim]);
-    typename KD::Node nd;
-    nd.lo_max = lo_max;
-    nd.hi_min = hi_min;
-    nd.dim = best_dim;
-    nd.pad = 0;
-    t.nodes[node] = nd;
     build_rec(t, P, perm, 2 * node, lo, mid, level + 1);
     build_rec(t, P, perm, 2 * node + 1, mid, hi, level + 1);
 }
@@ -74,22 +76,17 @@ static HostTree<KD> build_tree(const typename KD::T* P, int64_t K) {
     while (((int64_t)LEAF_CAP << levels) < K) ++levels;
     t.levels = levels;
     const int64_t nleaves = (int64_t)1 << levels;
-    t.nodes.resize(nleaves);
-    t.leaf_start.assign(nleaves + 1, (int32_t)K);
+    t.boxes.resize(2 * nleaves);
+    typename KD::Point pad;
+    for (int d = 0; d < KD::DIM; ++d) pad.c[d] = INFINITY;
+    pad.idx = 0x7fffffff;
+    if constexpr (KD::DIM == 6) pad.pad = 0;
+    t.pts.assign(nleaves * LEAF_CAP, pad);
+    t.inv_perm.resize(K);
     std::vector<int32_t> perm(K);
     std::iota(perm.begin(), perm.end(), 0);
+    t.boxes[0] = typename KD::Box();
     build_rec(t, P, perm, 1u, 0, K, 0);
-    t.leaf_start[nleaves] = (int32_t)K;
-    t.pts.resize(K);
-    t.inv_perm.resize(K);
-    for (int64_t i = 0; i < K; ++i) {
-        typename KD::Point p;
-        for (int d = 0; d < KD::DIM; ++d) p.c[d] = P[(int64_t)perm[i] * KD::DIM + d];
-        p.idx = perm[i];
-        if constexpr (KD::DIM == 6) p.pad = 0;
-        t.pts[i] = p;
-        t.inv_perm[perm[i]] = (int32_t)i;
-    }
     return t;
 }
 
@@ -101,9 +98,8 @@ static int upload_tree(midas_ctx* ctx, const HostTree<KD>& h, int64_t K, midas_t
         return MIDAS_OK;
     };
     int rc;
-    if ((rc = up(h.nodes.data(), h.nodes.size() * sizeof(typename KD::Node), &out->nodes))) return rc;
+    if ((rc = up(h.boxes.data(), h.boxes.size() * sizeof(typename KD::Box), &out->boxes))) return rc;
     if ((rc = up(h.pts.data(), h.pts.size() * sizeof(typename KD::Point), &out->pts))) return rc;
-    if ((rc = up(h.leaf_start.data(), h.leaf_start.size() * sizeof(int32_t), (void**)&out->leaf_start))) return rc;
     if ((rc = up(h.inv_perm.data(), h.inv_perm.size() * sizeof(int32_t), (void**)&out->inv_perm))) return rc;
     out->levels = h.levels;
     out->K = K;
@@ -127,9 +123,8 @@ int tree_build_impl(midas_ctx* ctx, int32_t dim, int64_t K, const void* points_d
 template <class KD>
 static TreeView<KD> view_of(const midas_tree* t) {
     TreeView<KD> v;
-    v.nodes = (const typename KD::Node*)t->nodes;
+    v.boxes = (const typename KD::Box*)t->boxes;
     v.pts = (const typename KD::Point*)t->pts;
-    v.leaf_start = t->leaf_start;
     v.inv_perm = t->inv_perm;
     v.levels = t->levels;
     v.K = t->K;
@@ -139,22 +134,6 @@ static TreeView<KD> view_of(const midas_tree* t) {
 // =================================================================================================
 // KD-tree: device traversal
 // =================================================================================================
-MD float sel(const float* q, int d) {  // q[d] without dynamic register indexing
-    float r = q[0];
-    r = d == 1 ? q[1] : r;
-    r = d == 2 ? q[2] : r;
-    r = d == 3 ? q[3] : r;
-    r = d == 4 ? q[4] : r;
-    r = d == 5 ? q[5] : r;
-    return r;
-}
-MD double sel(const double* q, int d) {
-    double r = q[0];
-    r = d == 1 ? q[1] : r;
-    r = d == 2 ? q[2] : r;
-    return r;
-}
-
 MD float dist2(const float* q, const Point6& p) {
     float d0 = q[0] - p.c[0], d1 = q[1] - p.c[1], d2 = q[2] - p.c[2];
     float d3 = q[3] - p.c[3], d4 = q[4] - p.c[4], d5 = q[5] - p.c[5];
@@ -174,34 +153,72 @@ MD double dist2(const double* q, const Point3& p) {
     return d;
 }
 
-// Exact 1-NN.  On entry (best_d, best_i) is a valid candidate or (+inf, 0); on exit the minimum of
-// the spec distance with ties resolved to the smallest original index.  EXISTS: return as soon as any
-// point with d <= best_d (the entry bound) is seen; `found` reports it.
-template <class KD, bool EXISTS>
-MD bool kd_search(const TreeView<KD>& tv, const typename KD::T* q, typename KD::T& best_d, int64_t& best_i) {
+// Lower bound of dist2(q, p) over every p inside the box, IN THE COMPUTED ARITHMETIC: each per-axis
+// offset is <= |q_j - p_j| after rounding (subtraction and max are monotone) and the fma chain has the
+// same shape as dist2, so monotonicity of rounding carries the bound through.
+MD float box_dist2(const float* q, const Box6& b) {
+    float t[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float a = b.lo[j] - q[j], c = q[j] - b.hi[j];
+        float m = a > c ? a : c;
+        t[j] = m > 0.0f ? m : 0.0f;
+    }
+    float d = t[0] * t[0];
+#pragma unroll
+    for (int j = 1; j < 6; ++j) d = fmaf_(t[j], t[j], d);
+    return d;
+}
+MD double box_dist2(const double* q, const Box3& b) {
+    double t[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double a = b.lo[j] - q[j], c = q[j] - b.hi[j];
+        double m = a > c ? a : c;
+        t[j] = m > 0.0 ? m : 0.0;
+    }
+    double d = t[0] * t[0];
+    d = fma_(t[1], t[1], d);
+    d = fma_(t[2], t[2], d);
+    return d;
+}
+
+// Exact 1-NN, stack-free: `pending` has bit l set when the far child below the level-l node of the
+// current path may still hold a closer point; its box distance sits in fb[l*64] (LDS, one column per
+// lane).  Each loop iteration costs ONE round of global loads per lane (two child boxes, or the eight
+// point slots of a leaf), so a wave's time is the longest lane's chain, not a sum of per-phase maxima.
+// On entry (best_d, best_i) is a valid candidate or (+inf, 0); on exit the minimum of the spec distance
+// with ties resolved to the smallest original index.  EXISTS: stop at the first point with
+// d <= best_d (the entry bound) and return true.
+template <class KD, bool EXISTS, bool STATS = false>
+MD bool kd_search(const TreeView<KD>& tv, const typename KD::T* q, typename KD::T& best_d, int64_t& best_i,
+                  typename KD::T* fb, int* n_leaves = nullptr, int* n_nodes = nullptr) {
     using T = typename KD::T;
     const int L = tv.levels;
     const uint32_t first_leaf = 1u << L;
     uint32_t node = 1u, pending = 0u;
     bool found = false;
     for (;;) {
-        while (node < first_leaf) {
-            const typename KD::Node nd = tv.nodes[node];
-            const T qd = sel(q, nd.dim);
-            const T dl = qd - nd.lo_max, dh = nd.hi_min - qd;
-            const bool go_left = dl <= dh;
-            const T fd = go_left ? dh : dl;
-            const T fb = fd > (T)0 ? fd * fd : (T)0;
+        bool back;
+        if (node < first_leaf) {
+            const typename KD::Box bl = tv.boxes[2u * node], br = tv.boxes[2u * node + 1u];
+            if (STATS) ++*n_nodes;
+            const T dl = box_dist2(q, bl), dr = box_dist2(q, br);
+            const bool left = dl <= dr;
+            const T dn = left ? dl : dr, df = left ? dr : dl;
             const int lvl = 31 - __builtin_clz(node);
-            if (fb <= best_d) pending |= 1u << lvl;
-            node = 2u * node + (go_left ? 0u : 1u);
-        }
-        const int32_t leaf = (int32_t)(node - first_leaf);
-        const int32_t s = tv.leaf_start[leaf], e = tv.leaf_start[leaf + 1];
+            if (df <= best_d) {
+                pending |= 1u << lvl;
+                fb[lvl * 64] = df;
+            }
+            back = !(dn <= best_d);
+            if (!back) node = 2u * node + (left ? 0u : 1u);
+        } else {
+            const typename KD::Point* lp = tv.pts + (size_t)(node - first_leaf) * LEAF_CAP;
+            if (STATS) ++*n_leaves;
 #pragma unroll
-        for (int j = 0; j < LEAF_CAP; ++j) {
-            if (s + j < e) {
-                const typename KD::Point p = tv.pts[s + j];
+            for (int j = 0; j < LEAF_CAP; ++j) {
+                const typename KD::Point p = lp[j];
                 const T d = dist2(q, p);
                 if (EXISTS) {
                     if (d <= best_d) { best_d = d; best_i = p.idx; found = true; }
@@ -210,30 +227,28 @@ MD bool kd_search(const TreeView<KD>& tv, const typename KD::T* q, typename KD::
                     best_i = p.idx;
                 }
             }
+            if (EXISTS && found) return true;
+            back = true;
         }
-        if (EXISTS && found) return true;
-        bool resumed = false;
-        while (pending) {
-            const int lvl = 31 - __builtin_clz(pending);
-            pending &= ~(1u << lvl);
-            const uint32_t anc = node >> (L - lvl);
-            const uint32_t far = (node >> (L - lvl - 1)) ^ 1u;
-            const typename KD::Node nd = tv.nodes[anc];
-            const T qd = sel(q, nd.dim);
-            const T fd = (far & 1u) ? (nd.hi_min - qd) : (qd - nd.lo_max);
-            const T fb = fd > (T)0 ? fd * fd : (T)0;
-            if (fb <= best_d) {
-                node = far;
-                resumed = true;
-                break;
+        if (back) {
+            bool resumed = false;
+            while (pending) {
+                const int lvl = 31 - __builtin_clz(pending);
+                pending &= ~(1u << lvl);
+                if (fb[lvl * 64] <= best_d) {
+                    const int depth = 31 - __builtin_clz(node);
+                    node = (node >> (depth - lvl - 1)) ^ 1u;
+                    resumed = true;
+                    break;
+                }
             }
+            if (!resumed) break;
         }
-        if (!resumed) break;
     }
     return found;
 }
 
-MD void nn6_query(const TreeView<Kd6>& tv, const float* q, int32_t hint, int32_t& idx, float& d2) {
+MD void nn6_query(const TreeView<Kd6>& tv, const float* q, int32_t hint, int32_t& idx, float& d2, float* fb) {
     float best = INFINITY;
     int64_t bi = 0;
     if (hint >= 0 && (int64_t)hint < tv.K) {
@@ -241,7 +256,7 @@ MD void nn6_query(const TreeView<Kd6>& tv, const float* q, int32_t hint, int32_t
         const float d = dist2(q, p);
         if (d < best) { best = d; bi = hint; }
     }
-    kd_search<Kd6, false>(tv, q, best, bi);
+    kd_search<Kd6, false>(tv, q, best, bi, fb);
     idx = (int32_t)bi;
     d2 = best;
 }
@@ -309,6 +324,7 @@ __global__ __launch_bounds__(64) void k_feature(int64_t N, const float* __restri
 __global__ __launch_bounds__(64) void k_nn6(TreeView<Kd6> tv, int64_t N, const float* __restrict__ feat,
                                             const int32_t* __restrict__ hint, int32_t* __restrict__ idx,
                                             float* __restrict__ d2out) {
+    __shared__ float s_fb[KD_MAX_LEVELS * 64];
     const int64_t n = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (n >= N) return;
     float q[6];
@@ -316,19 +332,44 @@ __global__ __launch_bounds__(64) void k_nn6(TreeView<Kd6> tv, int64_t N, const f
     for (int j = 0; j < 6; ++j) q[j] = feat[n * 6 + j];
     int32_t bi;
     float bd;
-    nn6_query(tv, q, hint ? hint[n] : -1, bi, bd);
+    nn6_query(tv, q, hint ? hint[n] : -1, bi, bd, s_fb + threadIdx.x);
     idx[n] = bi;
     if (d2out) d2out[n] = bd;
 }
 
+// diagnostic: leaves / nodes visited per query (tree tuning; same traversal as k_nn6)
+__global__ __launch_bounds__(64) void k_nn6_stats(TreeView<Kd6> tv, int64_t N, const float* __restrict__ feat,
+                                                  const int32_t* __restrict__ hint, int32_t* __restrict__ leaves,
+                                                  int32_t* __restrict__ nodes) {
+    __shared__ float s_fb[KD_MAX_LEVELS * 64];
+    const int64_t n = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (n >= N) return;
+    float q[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) q[j] = feat[n * 6 + j];
+    float best = INFINITY;
+    int64_t bi = 0;
+    const int32_t h = hint ? hint[n] : -1;
+    if (h >= 0 && (int64_t)h < tv.K) {
+        const Point6 p = tv.pts[tv.inv_perm[h]];
+        best = dist2(q, p);
+        bi = h;
+    }
+    int nl = 0, nn = 0;
+    kd_search<Kd6, false, true>(tv, q, best, bi, s_fb + threadIdx.x, &nl, &nn);
+    leaves[n] = nl;
+    nodes[n] = nn;
+}
+
 __global__ __launch_bounds__(64) void k_nn3(TreeView<Kd3> tv, int64_t N, const float* __restrict__ poses,
                                             double* __restrict__ dist) {
+    __shared__ double s_fb[KD_MAX_LEVELS * 64];
     const int64_t n = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (n >= N) return;
     double q[3] = {(double)poses[n * 16 + 3], (double)poses[n * 16 + 7], (double)poses[n * 16 + 11]};
     double best = INFINITY;
     int64_t bi = 0;
-    kd_search<Kd3, false>(tv, q, best, bi);
+    kd_search<Kd3, false>(tv, q, best, bi, s_fb + threadIdx.x);
     dist[n] = __builtin_sqrt(best);
 }
 
@@ -427,6 +468,7 @@ __global__ __launch_bounds__(256) void k_rmse_final(int64_t N, int nb, const dou
 // fused particle update of the step
 // =================================================================================================
 __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a) {
+    __shared__ double s_fb[KD_MAX_LEVELS * 64];  // far-bound columns, reused by both searches
     const int64_t n = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool live = n < a.N;
     double x = 0.0, et2 = 0.0, ang2 = 0.0;
@@ -441,7 +483,7 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
         se3_feature(R, 0.99f, 0.01f, f);
         int32_t bi;
         float bd;
-        nn6_query(t6, f, a.hint_in ? a.hint_in[n] : -1, bi, bd);
+        nn6_query(t6, f, a.hint_in ? a.hint_in[n] : -1, bi, bd, reinterpret_cast<float*>(s_fb) + threadIdx.x);
         a.nn_idx[n] = bi;
         x = a.scores[bi];
         a.x[n] = x;
@@ -449,7 +491,7 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
         double q3[3] = {(double)R[3], (double)R[7], (double)R[11]};
         double best = a.t2;
         int64_t vi = 0;
-        const bool ok = kd_search<Kd3, true>(t3, q3, best, vi);
+        const bool ok = kd_search<Kd3, true>(t3, q3, best, vi, s_fb + threadIdx.x);
         a.valid[n] = ok ? 1 : 0;
         if (a.gt16) {
             float G[16];
@@ -503,6 +545,15 @@ int launch_nn6(midas_ctx* ctx, const midas_tree* t, int64_t N, const float* feat
     if (N == 0) return MIDAS_OK;
     hipLaunchKernelGGL(k_nn6, dim3((unsigned)ceil_div(N, 64)), dim3(64), 0, ctx->stream, view_of<Kd6>(t), N, feat6, hint,
                        idx, d2);
+    MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    return MIDAS_OK;
+}
+
+int launch_nn6_stats(midas_ctx* ctx, const midas_tree* t, int64_t N, const float* feat6, const int32_t* hint,
+                     int32_t* leaves, int32_t* nodes) {
+    if (N == 0) return MIDAS_OK;
+    hipLaunchKernelGGL(k_nn6_stats, dim3((unsigned)ceil_div(N, 64)), dim3(64), 0, ctx->stream, view_of<Kd6>(t), N, feat6,
+                       hint, leaves, nodes);
     MIDAS_HIP_CHECK(ctx, hipGetLastError());
     return MIDAS_OK;
 }

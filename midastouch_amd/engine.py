@@ -88,6 +88,7 @@ class FilterEngine:
         a.softmax, a.resample_mode = int(self.softmax), self.mode
         a.status = _ptr(self.status)
         self._keep = (odom, code, gt, tn, rot, u)  # keep operands alive until the stream has consumed them
+        self.ctx.bind_current_stream()
         self.ctx.check(self.ctx.lib.midas_filter_step(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h,
                                                       C.byref(a)))
         self.hint, self.hint_next = self.hint_next, self.hint

@@ -111,6 +111,18 @@ def nn6(tree: Tree, feat: torch.Tensor, hint: torch.Tensor | None = None, want_d
     return (idx, d2) if want_d2 else idx
 
 
+def nn6_stats(tree: Tree, feat: torch.Tensor, hint: torch.Tensor | None = None):
+    """Diagnostic: (leaves visited, nodes visited) per query."""
+    feat = feat.float().contiguous()
+    n = feat.shape[0]
+    leaves = torch.empty(n, dtype=torch.int32, device=feat.device)
+    nodes = torch.empty(n, dtype=torch.int32, device=feat.device)
+    if hint is not None:
+        hint = hint.to(torch.int32).contiguous()
+    _ctx(feat).call("midas_nn6_stats", tree.h, n, _ptr(feat), _ptr(hint), _ptr(leaves), _ptr(nodes))
+    return leaves, nodes
+
+
 def nn3_dist(tree: Tree, poses: torch.Tensor) -> torch.Tensor:
     poses = _poses(poses)
     dist = torch.empty(poses.shape[0], dtype=torch.float64, device=poses.device)

@@ -145,10 +145,12 @@ def test_score_codebook(dev, ops, oracle, D):
     code = rng.standard_normal(D)
     code /= np.linalg.norm(code)
     ref = oracle.score_codebook(E, code)
-    for emb in (T(E, dev), T(E, dev).double(), T(E.astype(np.float64) + 1e-12, dev)):
+    E64 = E.astype(np.float64) * (1.0 + 1e-9)  # not float32-representable -> stays float64 in HBM
+    for emb, want in ((T(E, dev), ref), (T(E, dev).double(), ref), (T(E64, dev), oracle.score_codebook(E64, code))):
         cbk = ops.Codebook(emb)
+        assert cbk.emb.dtype == (torch.float64 if emb is not None and want is not ref else torch.float32)
         s = cbk.score(T(code, dev)).cpu().numpy()[0]
-        np.testing.assert_allclose(s, ref, rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(s, want, rtol=1e-12, atol=1e-13)
     # batch of codes
     codes = rng.standard_normal((3, D))
     cbk = ops.Codebook(T(E, dev))

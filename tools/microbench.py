@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Per-op timing + KD-tree traversal statistics on a realistic particle state (GPU box only)."""
+import argparse, json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from midastouch_amd import ops, _lib
+from midastouch_amd.engine import FilterEngine
+from midastouch_amd.synthetic import make_codebook, make_trajectory
+
+
+def timeit(fn, n=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e3  # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--particles", type=int, default=100_000)
+    ap.add_argument("--codebook", type=int, default=50_000)
+    ap.add_argument("--dim", type=int, default=512)
+    ap.add_argument("--frames", type=int, default=30)
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    N, K, D = a.particles, a.codebook, a.dim
+    cb = make_codebook(K=K, D=D, seed=1001)
+    traj = make_trajectory(cb, T=a.frames + 2, seed=2001)
+    eng = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, device=dev)
+    rng = np.random.default_rng(100)
+    d0 = np.linalg.norm(cb.poses[:, :3, 3] - traj.gt_poses[0][:3, 3], axis=1)
+    near = np.argsort(d0)[: max(64, K // 20)]
+    eng.set_particles(torch.as_tensor(cb.poses[rng.choice(near, N)]))
+    eng.project_to_codebook()
+    odoms, codes = torch.as_tensor(traj.odoms).to(dev), torch.as_tensor(traj.codes).to(dev)
+    res = {}
+    for t in range(1, a.frames + 1):
+        eng.step(odoms[t], codes[t])
+        if t in (1, 5, a.frames):
+            feat = ops.se3_feature(eng.poses_prop)
+            for tag, hint in (("hint", eng.hint_prev if hasattr(eng, "hint_prev") else None), ("nohint", None)):
+                pass
+            lv, nd = ops.nn6_stats(eng.tree6, feat, None)
+            lvh, ndh = ops.nn6_stats(eng.tree6, feat, eng.nn_idx)  # best-case hint = the answer itself
+            uniq = int(torch.unique(eng.nn_idx).numel())
+            res[f"frame{t}"] = {
+                "leaves_nohint_mean": float(lv.float().mean()), "leaves_nohint_max": int(lv.max()),
+                "nodes_nohint_mean": float(nd.float().mean()),
+                "leaves_hint_mean": float(lvh.float().mean()), "leaves_hint_max": int(lvh.max()),
+                "nodes_hint_mean": float(ndh.float().mean()),
+                "wave_max_leaves_hint_mean": float(lvh.view(-1, 64)[: N // 64].max(dim=1).values.float().mean()) if N % 64 == 0 else None,
+                "unique_nn": uniq, "kept": int(eng.status[1])}
+    P = eng.poses_prop.clone()
+    feat = ops.se3_feature(P)
+    hint = eng.nn_idx.clone()
+    od, code = odoms[3], codes[3]
+    res["us"] = {
+        "score": timeit(lambda: eng.codebook.score(code)),
+        "propagate_philox": timeit(lambda: ops.propagate(P, od, None, None, 2e-4, 0.5, 1, 2)),
+        "se3_feature": timeit(lambda: ops.se3_feature(P)),
+        "nn6_nohint": timeit(lambda: ops.nn6(eng.tree6, feat)),
+        "nn6_hint_exact": timeit(lambda: ops.nn6(eng.tree6, feat, hint)),
+        "nn3_dist": timeit(lambda: ops.nn3_dist(eng.tree3, P)),
+        "step": timeit(lambda: eng.step(od, code)),
+    }
+    x = ops.gather_f64(eng.codebook.score(code)[0], hint)
+    w = ops.softmax_weights(x)
+    c, _ = ops.cdf(w)
+    res["us"].update({
+        "softmax": timeit(lambda: ops.softmax_weights(x)),
+        "cdf": timeit(lambda: ops.cdf(w)),
+        "search": timeit(lambda: ops.resample_search(c, N, 0, seed=1, step=1)),
+        "gather_poses": timeit(lambda: ops.gather_rows(P, hint % N)),
+        "empty_torch": timeit(lambda: torch.empty(N, device=dev)),
+    })
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
