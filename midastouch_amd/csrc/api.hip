@@ -206,6 +206,8 @@ MIDAS_EXPORT int midas_tree_destroy(midas_tree* t) {
     if (t->boxes) (void)hipFree(t->boxes);
     if (t->pts) (void)hipFree(t->pts);
     if (t->inv_perm) (void)hipFree(t->inv_perm);
+    if (t->nbrs) (void)hipFree(t->nbrs);
+    if (t->rho_out) (void)hipFree(t->rho_out);
     delete t;
     return MIDAS_OK;
 }

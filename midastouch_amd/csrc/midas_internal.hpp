@@ -32,11 +32,20 @@ struct Kd3 {
     static constexpr int DIM = 3;
 };
 
+// Neighbour record of the hint fast path (dim 6 only): entry k owns NBR_M records sorted by the
+// distance rho from F_k to that neighbour (rounded down), coordinates inlined so that one 32-byte
+// read is one candidate.  Unused records are sentinels (+inf coordinates, rho = +inf).
+struct alignas(16) Nbr6 { float c[6]; int32_t idx; float rho; };
+constexpr int NBR_M = 32;
+constexpr int NBR_REC = NBR_M + 1;  // record 0 = the entry itself
+
 template <class KD>
 struct TreeView {
     const typename KD::Box* boxes;  // [2^(L+1)], entries 0 and 1 unused/root
     const typename KD::Point* pts;  // [2^L * LEAF_CAP]
     const int32_t* inv_perm;        // [K] original index -> slot in pts
+    const Nbr6* nbrs;               // [K * NBR_REC] (dim 6) or nullptr
+    const float* rho_out;           // [K] distance from F_k to its (NBR_M+1)-th neighbour, rounded down
     int32_t levels;
     int64_t K;
 };
@@ -80,6 +89,8 @@ struct midas_tree {
     void* boxes;
     void* pts;
     int32_t* inv_perm;
+    void* nbrs;      // Nbr6[K * NBR_REC] (dim 6)
+    float* rho_out;  // [K] (dim 6)
 };
 
 // ---- error helpers ----------------------------------------------------------------------------
@@ -143,6 +154,7 @@ struct ParticleUpdateArgs {
     double* part_min;      // [nblocks]
     const float* gt16;     // nullable
     double* part_rmse;     // [2*nblocks] when gt16
+    int ablate = 0;        // profiling only (MIDAS_ABLATE)
 };
 int particle_update_blocks(int64_t N);
 int launch_particle_update(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t3, const ParticleUpdateArgs& a);

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 #include "midas_internal.hpp"
@@ -23,6 +24,8 @@ struct HostTree {
     std::vector<typename KD::Box> boxes;
     std::vector<typename KD::Point> pts;
     std::vector<int32_t> inv_perm;
+    std::vector<Nbr6> nbrs;      // dim 6 only
+    std::vector<float> rho_out;  // dim 6 only
     int levels = 0;
 };
 
@@ -90,6 +93,98 @@ static HostTree<KD> build_tree(const typename KD::T* P, int64_t K) {
     return t;
 }
 
+// ---- neighbour graph of the codebook features (hint fast path) ---------------------------------
+// For every entry k: its NBR_M nearest other entries sorted by (distance, index), float64 distances,
+// rho rounded DOWN to float32 so that it never over-states a true distance.
+namespace {
+struct HeapItem { double d; int32_t idx; };
+inline bool heap_less(const HeapItem& a, const HeapItem& b) { return a.d < b.d || (a.d == b.d && a.idx < b.idx); }
+
+double host_box_d2(const float* q, const Box6& b) {
+    double d = 0.0;
+    for (int j = 0; j < 6; ++j) {
+        double a = (double)b.lo[j] - (double)q[j], c = (double)q[j] - (double)b.hi[j];
+        double m = a > c ? a : c;
+        if (m > 0) d += m * m;
+    }
+    return d;
+}
+
+void knn_rec(const HostTree<Kd6>& t, const float* q, int32_t self, uint32_t node, std::vector<HeapItem>& heap, size_t k) {
+    const uint32_t first_leaf = 1u << t.levels;
+    if (node >= first_leaf) {
+        const Point6* lp = t.pts.data() + (size_t)(node - first_leaf) * LEAF_CAP;
+        for (int j = 0; j < LEAF_CAP; ++j) {
+            if (lp[j].idx == 0x7fffffff || lp[j].idx == self) continue;
+            double d = 0.0;
+            for (int a = 0; a < 6; ++a) { double x = (double)q[a] - (double)lp[j].c[a]; d += x * x; }
+            HeapItem it{d, lp[j].idx};
+            if (heap.size() < k) {
+                heap.push_back(it);
+                std::push_heap(heap.begin(), heap.end(), heap_less);
+            } else if (heap_less(it, heap.front())) {
+                std::pop_heap(heap.begin(), heap.end(), heap_less);
+                heap.back() = it;
+                std::push_heap(heap.begin(), heap.end(), heap_less);
+            }
+        }
+        return;
+    }
+    const double dl = host_box_d2(q, t.boxes[2 * node]), dr = host_box_d2(q, t.boxes[2 * node + 1]);
+    const uint32_t near = dl <= dr ? 2 * node : 2 * node + 1, far = near ^ 1u;
+    const double dn = dl <= dr ? dl : dr, df = dl <= dr ? dr : dl;
+    if (heap.size() < k || dn <= heap.front().d) knn_rec(t, q, self, near, heap, k);
+    if (heap.size() < k || df <= heap.front().d) knn_rec(t, q, self, far, heap, k);
+}
+
+inline float round_down_f32(double v) {
+    float f = (float)v;
+    if ((double)f > v) f = std::nextafterf(f, 0.0f);
+    return f;
+}
+}  // namespace
+
+static void build_neighbour_graph(HostTree<Kd6>& t, const float* P, int64_t K) {
+    t.nbrs.resize((size_t)K * NBR_REC);
+    t.rho_out.resize(K);
+    auto work = [&](int64_t k0, int64_t k1) {
+        std::vector<HeapItem> heap;
+        for (int64_t k = k0; k < k1; ++k) {
+            heap.clear();
+            knn_rec(t, P + k * 6, (int32_t)k, 1u, heap, (size_t)NBR_M + 1);
+            std::sort(heap.begin(), heap.end(), heap_less);
+            {   // record 0 = the entry itself (rho 0): the scan needs no other lookup
+                Nbr6 r;
+                for (int a = 0; a < 6; ++a) r.c[a] = P[k * 6 + a];
+                r.idx = (int32_t)k;
+                r.rho = 0.0f;
+                t.nbrs[(size_t)k * NBR_REC] = r;
+            }
+            for (int s2 = 0; s2 < NBR_M; ++s2) {
+                Nbr6 r;
+                if ((size_t)s2 < heap.size()) {
+                    const int32_t j = heap[s2].idx;
+                    for (int a = 0; a < 6; ++a) r.c[a] = P[(int64_t)j * 6 + a];
+                    r.idx = j;
+                    r.rho = round_down_f32(std::sqrt(heap[s2].d));
+                } else {
+                    for (int a = 0; a < 6; ++a) r.c[a] = INFINITY;
+                    r.idx = 0x7fffffff;
+                    r.rho = INFINITY;
+                }
+                t.nbrs[(size_t)k * NBR_REC + 1 + s2] = r;
+            }
+            t.rho_out[k] = heap.size() > (size_t)NBR_M ? round_down_f32(std::sqrt(heap[NBR_M].d)) : INFINITY;
+        }
+    };
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt == 0 ? 1 : (nt > 32 ? 32 : nt);
+    if (K < 4096) nt = 1;
+    std::vector<std::thread> th;
+    for (unsigned i = 0; i < nt; ++i) th.emplace_back(work, K * i / nt, K * (i + 1) / nt);
+    for (auto& x : th) x.join();
+}
+
 template <class KD>
 static int upload_tree(midas_ctx* ctx, const HostTree<KD>& h, int64_t K, midas_tree* out) {
     auto up = [&](const void* src, size_t bytes, void** dst) -> int {
@@ -101,6 +196,10 @@ static int upload_tree(midas_ctx* ctx, const HostTree<KD>& h, int64_t K, midas_t
     if ((rc = up(h.boxes.data(), h.boxes.size() * sizeof(typename KD::Box), &out->boxes))) return rc;
     if ((rc = up(h.pts.data(), h.pts.size() * sizeof(typename KD::Point), &out->pts))) return rc;
     if ((rc = up(h.inv_perm.data(), h.inv_perm.size() * sizeof(int32_t), (void**)&out->inv_perm))) return rc;
+    if (!h.nbrs.empty()) {
+        if ((rc = up(h.nbrs.data(), h.nbrs.size() * sizeof(Nbr6), &out->nbrs))) return rc;
+        if ((rc = up(h.rho_out.data(), h.rho_out.size() * sizeof(float), (void**)&out->rho_out))) return rc;
+    }
     out->levels = h.levels;
     out->K = K;
     return MIDAS_OK;
@@ -112,6 +211,7 @@ int tree_build_impl(midas_ctx* ctx, int32_t dim, int64_t K, const void* points_d
         std::vector<float> host((size_t)K * 6);
         MIDAS_HIP_CHECK(ctx, hipMemcpy(host.data(), points_dev, host.size() * sizeof(float), hipMemcpyDeviceToHost));
         HostTree<Kd6> h = build_tree<Kd6>(host.data(), K);
+        build_neighbour_graph(h, host.data(), K);
         return upload_tree<Kd6>(ctx, h, K, out);
     }
     std::vector<double> host((size_t)K * 3);
@@ -126,6 +226,8 @@ static TreeView<KD> view_of(const midas_tree* t) {
     v.boxes = (const typename KD::Box*)t->boxes;
     v.pts = (const typename KD::Point*)t->pts;
     v.inv_perm = t->inv_perm;
+    v.nbrs = (const Nbr6*)t->nbrs;
+    v.rho_out = t->rho_out;
     v.levels = t->levels;
     v.K = t->K;
     return v;
@@ -248,15 +350,63 @@ MD bool kd_search(const TreeView<KD>& tv, const typename KD::T* q, typename KD::
     return found;
 }
 
+// Hint fast path.  h = a codebook entry near q (the NN of the particle's ancestor).  The candidates
+// {h} U N(h) are scanned in order of rho = |F_h - F_s|; every entry not yet scanned is at least
+// rho - |q - F_h| away from q (triangle inequality), so once that exceeds the best distance found the
+// search is certified complete and returns the exact answer of the full search.  The comparison
+// carries a 3e-5 relative margin on squared distances, two orders above float32 rounding of the
+// six-term sums, so "certified" also holds for the COMPUTED distances and their tie rule.
+// Returns true when certified; otherwise (best, bi) is a valid bound for the tree search.
+MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t h, float& best, int64_t& bi, int* n_scanned) {
+    const Nbr6* nb = tv.nbrs + (size_t)h * NBR_REC;
+    {
+        const Nbr6 self = nb[0];
+        Point6 p;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) p.c[a] = self.c[a];
+        best = dist2(q, p);
+        bi = h;
+    }
+    const float r = __builtin_sqrtf(best);
+    const float rslack = -8e-7f * r;
+    int scanned = 0;
+    bool certified = false;
+    for (int s0 = 1; s0 <= NBR_M && !certified; s0 += 4) {
+        Nbr6 e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = nb[s0 + j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!certified) {
+                // lower bound of |q - F| for this and every later record, with slack for the rounding of r and rho
+                const float g = fmaf_(e[j].rho - r, 0.9999996f, rslack);
+                if (g > 0.0f && g * g * 0.99997f > best) {
+                    certified = true;
+                } else {
+                    Point6 p;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) p.c[a] = e[j].c[a];
+                    const float d = dist2(q, p);
+                    if (d < best || (d == best && (int64_t)e[j].idx < bi)) { best = d; bi = e[j].idx; }
+                    ++scanned;
+                }
+            }
+        }
+    }
+    if (!certified) {
+        const float g = fmaf_(tv.rho_out[h] - r, 0.9999996f, rslack);
+        certified = g > 0.0f && g * g * 0.99997f > best;
+    }
+    if (n_scanned) *n_scanned = scanned;
+    return certified;
+}
+
 MD void nn6_query(const TreeView<Kd6>& tv, const float* q, int32_t hint, int32_t& idx, float& d2, float* fb) {
     float best = INFINITY;
     int64_t bi = 0;
-    if (hint >= 0 && (int64_t)hint < tv.K) {
-        const Point6 p = tv.pts[tv.inv_perm[hint]];
-        const float d = dist2(q, p);
-        if (d < best) { best = d; bi = hint; }
-    }
-    kd_search<Kd6, false>(tv, q, best, bi, fb);
+    bool done = false;
+    if (hint >= 0 && (int64_t)hint < tv.K) done = nn6_hint_scan(tv, q, hint, best, bi, nullptr);
+    if (!done) kd_search<Kd6, false>(tv, q, best, bi, fb);
     idx = (int32_t)bi;
     d2 = best;
 }
@@ -350,13 +500,12 @@ __global__ __launch_bounds__(64) void k_nn6_stats(TreeView<Kd6> tv, int64_t N, c
     float best = INFINITY;
     int64_t bi = 0;
     const int32_t h = hint ? hint[n] : -1;
-    if (h >= 0 && (int64_t)h < tv.K) {
-        const Point6 p = tv.pts[tv.inv_perm[h]];
-        best = dist2(q, p);
-        bi = h;
-    }
-    int nl = 0, nn = 0;
-    kd_search<Kd6, false, true>(tv, q, best, bi, s_fb + threadIdx.x, &nl, &nn);
+    int nl = 0, nn = 0, ns = 0;
+    bool done = false;
+    if (h >= 0 && (int64_t)h < tv.K) done = nn6_hint_scan(tv, q, h, best, bi, &ns);
+    if (!done) kd_search<Kd6, false, true>(tv, q, best, bi, s_fb + threadIdx.x, &nl, &nn);
+    // certified lanes report 0 leaves and -(1 + neighbour records scanned)
+    if (done) nn = -(ns + 1);
     leaves[n] = nl;
     nodes[n] = nn;
 }
@@ -483,7 +632,12 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
         se3_feature(R, 0.99f, 0.01f, f);
         int32_t bi;
         float bd;
-        nn6_query(t6, f, a.hint_in ? a.hint_in[n] : -1, bi, bd, reinterpret_cast<float*>(s_fb) + threadIdx.x);
+        if (a.ablate & 1) {  // profiling only: trust the hint
+            bi = a.hint_in ? a.hint_in[n] : 0;
+            bi = bi < 0 ? 0 : bi;
+        } else {
+            nn6_query(t6, f, a.hint_in ? a.hint_in[n] : -1, bi, bd, reinterpret_cast<float*>(s_fb) + threadIdx.x);
+        }
         a.nn_idx[n] = bi;
         x = a.scores[bi];
         a.x[n] = x;
@@ -491,7 +645,7 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
         double q3[3] = {(double)R[3], (double)R[7], (double)R[11]};
         double best = a.t2;
         int64_t vi = 0;
-        const bool ok = kd_search<Kd3, true>(t3, q3, best, vi, s_fb + threadIdx.x);
+        const bool ok = (a.ablate & 2) ? true : kd_search<Kd3, true>(t3, q3, best, vi, s_fb + threadIdx.x);
         a.valid[n] = ok ? 1 : 0;
         if (a.gt16) {
             float G[16];
@@ -579,8 +733,12 @@ int launch_rmse(midas_ctx* ctx, int64_t N, const float* poses, const float* gt16
 
 int particle_update_blocks(int64_t N) { return (int)ceil_div(N, 64); }
 
-int launch_particle_update(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t3, const ParticleUpdateArgs& a) {
-    if (a.N == 0) return MIDAS_OK;
+int launch_particle_update(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t3, const ParticleUpdateArgs& a_in) {
+    if (a_in.N == 0) return MIDAS_OK;
+    ParticleUpdateArgs a = a_in;
+    // MIDAS_ABLATE (profiling only, results become wrong): bit 0 skips the NN search, bit 1 the mesh prune
+    static const int ablate = getenv("MIDAS_ABLATE") ? atoi(getenv("MIDAS_ABLATE")) : 0;
+    a.ablate = ablate;
     hipLaunchKernelGGL(k_particle_update, dim3((unsigned)particle_update_blocks(a.N)), dim3(64), 0, ctx->stream,
                        view_of<Kd6>(t6), view_of<Kd3>(t3), a);
     MIDAS_HIP_CHECK(ctx, hipGetLastError());

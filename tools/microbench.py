@@ -42,20 +42,31 @@ def main():
     res = {}
     for t in range(1, a.frames + 1):
         eng.step(odoms[t], codes[t])
-        if t in (1, 5, a.frames):
+        if t in (1, 2, 3, 5, 10, a.frames):
             feat = ops.se3_feature(eng.poses_prop)
-            for tag, hint in (("hint", eng.hint_prev if hasattr(eng, "hint_prev") else None), ("nohint", None)):
-                pass
             lv, nd = ops.nn6_stats(eng.tree6, feat, None)
-            lvh, ndh = ops.nn6_stats(eng.tree6, feat, eng.nn_idx)  # best-case hint = the answer itself
-            uniq = int(torch.unique(eng.nn_idx).numel())
-            res[f"frame{t}"] = {
-                "leaves_nohint_mean": float(lv.float().mean()), "leaves_nohint_max": int(lv.max()),
-                "nodes_nohint_mean": float(nd.float().mean()),
-                "leaves_hint_mean": float(lvh.float().mean()), "leaves_hint_max": int(lvh.max()),
-                "nodes_hint_mean": float(ndh.float().mean()),
-                "wave_max_leaves_hint_mean": float(lvh.view(-1, 64)[: N // 64].max(dim=1).values.float().mean()) if N % 64 == 0 else None,
-                "unique_nn": uniq, "kept": int(eng.status[1])}
+            hint_prev = eng.hint_next  # after the swap: the hints this frame's particle update consumed
+            lvh, ndh = ops.nn6_stats(eng.tree6, feat, hint_prev)
+            cert = ndh < 0
+            scanned = (-ndh - 1).clamp(min=0)
+            nw = N // 64
+            wv_fb = (~cert)[: nw * 64].view(nw, 64).any(dim=1).float().mean()
+            wv_sc = scanned[: nw * 64].view(nw, 64).max(dim=1).values.float().mean()
+            _, d2 = ops.nn6(eng.tree6, feat, None, want_d2=True)
+            dnn = d2.sqrt()
+            rh = (feat - eng.cb_feat[hint_prev.long().clamp(min=0)]).norm(dim=1)
+            qs = torch.tensor([0.5, 0.9, 0.99, 0.999], device=dev)
+            res[f"frame{t}"] = " ".join([
+                f"leaves_nohint={float(lv.float().mean()):.2f}", f"nodes_nohint={float(nd.float().mean()):.1f}",
+                f"certified={float(cert.float().mean()):.4f}", f"waves_with_fallback={float(wv_fb):.3f}",
+                f"scanned_mean={float(scanned[cert].float().mean()):.2f}", f"wave_max_scanned={float(wv_sc):.1f}",
+                f"fb_nodes={float(ndh[~cert].float().mean()) if (~cert).any() else 0:.1f}",
+                f"fb_leaves={float(lvh[~cert].float().mean()) if (~cert).any() else 0:.1f}",
+                f"uniq={int(torch.unique(eng.nn_idx).numel())}",
+                "dnn_mm=" + "/".join(f"{float(v)*1e3:.2f}" for v in torch.quantile(dnn, qs)),
+                "rhint_mm=" + "/".join(f"{float(v)*1e3:.2f}" for v in torch.quantile(rh, qs))])
+            if t == a.frames:
+                feat_keep, hint_keep = feat.clone(), hint_prev.clone()
     P = eng.poses_prop.clone()
     feat = ops.se3_feature(P)
     hint = eng.nn_idx.clone()
@@ -66,6 +77,7 @@ def main():
         "se3_feature": timeit(lambda: ops.se3_feature(P)),
         "nn6_nohint": timeit(lambda: ops.nn6(eng.tree6, feat)),
         "nn6_hint_exact": timeit(lambda: ops.nn6(eng.tree6, feat, hint)),
+        "nn6_hint_real": timeit(lambda: ops.nn6(eng.tree6, feat_keep, hint_keep)),
         "nn3_dist": timeit(lambda: ops.nn3_dist(eng.tree3, P)),
         "step": timeit(lambda: eng.step(od, code)),
     }
