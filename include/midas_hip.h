@@ -165,6 +165,66 @@ typedef struct midas_step_args {
 int midas_filter_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
                       const midas_tree* tree3, const midas_step_args* args);
 
+
+/* ---- particle-sharded step (one process per GPU; the caller runs the collectives between the calls) ---- */
+/* The frame of midas_filter_step split at its three global reductions so that N_total particles can be
+ * sharded across ranks: shard r owns the global slots [slot_base, slot_base + N) and the
+ * global summation blocks [block_base, ...) (4096 slots per block; slot_base must be a multiple of 4096
+ * on every rank but the last for results identical to a single-GPU run).  Arrays named *_all span all
+ * shards in rank order and are assembled by the caller (torch.distributed all_gather over RCCL). */
+typedef struct midas_shard_update_args {
+    int64_t N;                  /* local particles */
+    int64_t slot_base;          /* global index of local particle 0 (keys the Philox streams) */
+    const float* poses_in_dev;  /* N x 16 */
+    float* poses_prop_dev;      /* N x 16 out */
+    const int32_t* hint_in_dev; /* N or NULL */
+    int32_t* nn_idx_dev;        /* N out */
+    double* x_dev;              /* N out: score of the nearest codebook entry */
+    uint8_t* valid_dev;         /* N out: prune mask */
+    double* extrema_dev;        /* 2 out: max(x), min(x) over the local particles */
+    const float* odom16_dev;
+    const double* code_dev;
+    const float* gt16_dev;      /* NULL or 16 */
+    double* rmse_sums_dev;      /* NULL or 2 out: sum |dt|^2, sum angle^2 over the local particles */
+    const float* tn_dev;        /* local host draws or NULL -> Philox */
+    const float* rot_dev;
+    float std_t, std_r;
+    uint64_t seed, step;
+    double prune_thr;
+} midas_shard_update_args;
+/* score codebook + propagate + feature + NN + prune + score gather for the local particles */
+int midas_shard_update(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
+                       const midas_tree* tree3, const midas_shard_update_args* args);
+/* e = exp(x - max(pmax_all)) (or x when the softmax is skipped) ; block_sums[b] for the local blocks ;
+ * flag[0] = softmax applied ; status[0..1] reset */
+int midas_tail_exp(midas_ctx* ctx, int64_t N, const double* x_dev, int32_t np, const double* pmax_all_dev,
+                   const double* pmin_all_dev, int32_t softmax, double* e_dev, double* block_sums_dev,
+                   int32_t* flag_dev, int32_t* status_dev);
+/* w = e / sum(block_sums_all) * valid (in place) ; lp = block-local prefix ; block_totals for the local blocks */
+int midas_tail_scan(midas_ctx* ctx, int64_t N, double* w_dev, const uint8_t* valid_dev, int32_t nb_all,
+                    const double* block_sums_all_dev, const int32_t* flag_dev, double* lp_dev,
+                    double* block_totals_dev, int32_t* status_dev);
+/* cdf = (BP + lp) / total in place, BP/total from block_totals_all ; is_last forces the final slot to 1 */
+int midas_tail_cdf(midas_ctx* ctx, int64_t N, double* cdf_dev, int32_t nb_all,
+                   const double* block_totals_all_dev, int32_t block_base, int32_t is_last, int32_t* status_dev);
+typedef struct midas_tail_resample_args {
+    int64_t N, N_all, slot_base;
+    const double* cdf_all_dev;      /* N_all */
+    const int32_t* status_dev;      /* [0] != 0 -> identity resample */
+    int32_t mode;
+    const double* u_dev;            /* N local uniforms or NULL -> Philox keyed by the global slot */
+    float u32;
+    uint64_t seed, step;
+    int32_t* ridx_dev;              /* N out: GLOBAL source index of each local slot */
+    const float* poses_all_dev;     /* N_all x 16 propagated poses of every shard */
+    float* poses_out_dev;           /* N x 16 */
+    const double* weights_all_dev;  /* N_all */
+    double* weights_out_dev;        /* N */
+    const int32_t* nn_all_dev;      /* N_all */
+    int32_t* hint_out_dev;          /* N */
+} midas_tail_resample_args;
+int midas_tail_resample(midas_ctx* ctx, const midas_tail_resample_args* args);
+
 /* per-kernel timing of midas_filter_step (HIP events on the context stream).  When enabled every
  * kernel of the step is bracketed by events; midas_profile_read synchronises and returns the
  * accumulated milliseconds per kernel slot since the last reset. */

@@ -56,6 +56,31 @@ class StepArgs(C.Structure):
     ]
 
 
+class ShardUpdateArgs(C.Structure):
+    """midas_shard_update_args (include/midas_hip.h)."""
+
+    _fields_ = [
+        ("N", C.c_int64), ("slot_base", C.c_int64),
+        ("poses_in", C.c_void_p), ("poses_prop", C.c_void_p), ("hint_in", C.c_void_p), ("nn_idx", C.c_void_p),
+        ("x", C.c_void_p), ("valid", C.c_void_p), ("extrema", C.c_void_p), ("odom16", C.c_void_p),
+        ("code", C.c_void_p), ("gt16", C.c_void_p), ("rmse_sums", C.c_void_p), ("tn", C.c_void_p), ("rot", C.c_void_p),
+        ("std_t", C.c_float), ("std_r", C.c_float), ("seed", C.c_uint64), ("step", C.c_uint64),
+        ("prune_thr", C.c_double),
+    ]
+
+
+class TailResampleArgs(C.Structure):
+    """midas_tail_resample_args (include/midas_hip.h)."""
+
+    _fields_ = [
+        ("N", C.c_int64), ("N_all", C.c_int64), ("slot_base", C.c_int64),
+        ("cdf_all", C.c_void_p), ("status", C.c_void_p), ("mode", C.c_int32), ("u", C.c_void_p), ("u32", C.c_float),
+        ("seed", C.c_uint64), ("step", C.c_uint64), ("ridx", C.c_void_p),
+        ("poses_all", C.c_void_p), ("poses_out", C.c_void_p), ("weights_all", C.c_void_p), ("weights_out", C.c_void_p),
+        ("nn_all", C.c_void_p), ("hint_out", C.c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol include/midas_hip.h declares
 _P, _I32, _I64, _U64, _F, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
 SIGNATURES = {
@@ -85,6 +110,11 @@ SIGNATURES = {
     "midas_gather_rows": (C.c_int, [_P, _I64, _P, _P, _P, _I32]),
     "midas_rmse": (C.c_int, [_P, _I64, _P, _P, _P]),
     "midas_filter_step": (C.c_int, [_P, _P, _P, _P, C.POINTER(StepArgs)]),
+    "midas_shard_update": (C.c_int, [_P, _P, _P, _P, C.POINTER(ShardUpdateArgs)]),
+    "midas_tail_exp": (C.c_int, [_P, _I64, _P, _I32, _P, _P, _I32, _P, _P, _P, _P]),
+    "midas_tail_scan": (C.c_int, [_P, _I64, _P, _P, _I32, _P, _P, _P, _P, _P]),
+    "midas_tail_cdf": (C.c_int, [_P, _I64, _P, _I32, _P, _I32, _I32, _P]),
+    "midas_tail_resample": (C.c_int, [_P, C.POINTER(TailResampleArgs)]),
     "midas_profile_enable": (C.c_int, [_P, _I32]),
     "midas_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64), _I32]),
     "midas_profile_slot_name": (C.c_char_p, [_I32]),

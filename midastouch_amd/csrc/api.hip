@@ -399,6 +399,86 @@ MIDAS_EXPORT int midas_filter_step(midas_ctx* ctx, const midas_codebook* cb, con
     return MIDAS_OK;
 }
 
+
+// ---- particle-sharded step pieces -------------------------------------------------------------------
+MIDAS_EXPORT int midas_shard_update(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
+                                    const midas_tree* tree3, const midas_shard_update_args* args) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, cb && tree6 && tree3 && args && tree6->dim == 6 && tree3->dim == 3 && tree6->K == cb->K);
+    const midas_shard_update_args& s = *args;
+    MIDAS_REQUIRE(ctx, s.N > 0 && s.poses_in_dev && s.poses_prop_dev && s.nn_idx_dev && s.x_dev && s.valid_dev &&
+                           s.extrema_dev && s.odom16_dev && s.code_dev && s.poses_in_dev != s.poses_prop_dev);
+    MIDAS_REQUIRE(ctx, (s.tn_dev == nullptr) == (s.rot_dev == nullptr));
+    const int npart = particle_update_blocks(s.N);
+    void *scores, *pmax, *pmin, *prm = nullptr;
+    int rc;
+    if ((rc = midas_scratch(ctx, (size_t)cb->K * sizeof(double), &scores))) return rc;
+    if ((rc = midas_scratch(ctx, (size_t)npart * sizeof(double), &pmax))) return rc;
+    if ((rc = midas_scratch(ctx, (size_t)npart * sizeof(double), &pmin))) return rc;
+    if (s.gt16_dev && s.rmse_sums_dev)
+        if ((rc = midas_scratch(ctx, (size_t)npart * 2 * sizeof(double), &prm))) return rc;
+    if ((rc = launch_score(ctx, cb, 1, s.code_dev, (double*)scores))) return rc;
+    ParticleUpdateArgs pa;
+    pa.N = s.N;
+    pa.poses_in = s.poses_in_dev;
+    pa.poses_prop = s.poses_prop_dev;
+    pa.odom16 = s.odom16_dev;
+    pa.tn = s.tn_dev;
+    pa.rot = s.rot_dev;
+    pa.std_t = s.std_t;
+    pa.std_r = s.std_r;
+    pa.seed = s.seed;
+    pa.step = s.step;
+    pa.slot_base = s.slot_base;
+    pa.hint_in = s.hint_in_dev;
+    pa.nn_idx = s.nn_idx_dev;
+    pa.scores = (const double*)scores;
+    pa.x = s.x_dev;
+    pa.valid = s.valid_dev;
+    pa.t2 = squared_threshold(s.prune_thr);
+    pa.part_max = (double*)pmax;
+    pa.part_min = (double*)pmin;
+    pa.gt16 = prm ? s.gt16_dev : nullptr;
+    pa.part_rmse = (double*)prm;
+    if ((rc = launch_particle_update(ctx, tree6, tree3, pa))) return rc;
+    return launch_reduce_partials(ctx, npart, (const double*)pmax, (const double*)pmin, (const double*)prm, s.extrema_dev,
+                                  prm ? s.rmse_sums_dev : nullptr);
+}
+
+MIDAS_EXPORT int midas_tail_exp(midas_ctx* ctx, int64_t N, const double* x_dev, int32_t np, const double* pmax_all_dev,
+                                const double* pmin_all_dev, int32_t softmax, double* e_dev, double* block_sums_dev,
+                                int32_t* flag_dev, int32_t* status_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, N > 0 && np > 0 && x_dev && pmax_all_dev && pmin_all_dev && e_dev && block_sums_dev && flag_dev && status_dev);
+    return launch_tail_exp(ctx, N, x_dev, np, pmax_all_dev, pmin_all_dev, softmax, e_dev, block_sums_dev, flag_dev, status_dev);
+}
+
+MIDAS_EXPORT int midas_tail_scan(midas_ctx* ctx, int64_t N, double* w_dev, const uint8_t* valid_dev, int32_t nb_all,
+                                 const double* block_sums_all_dev, const int32_t* flag_dev, double* lp_dev,
+                                 double* block_totals_dev, int32_t* status_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, N > 0 && nb_all > 0 && w_dev && valid_dev && block_sums_all_dev && flag_dev && lp_dev && block_totals_dev && status_dev);
+    return launch_tail_scan(ctx, N, w_dev, valid_dev, nb_all, block_sums_all_dev, flag_dev, lp_dev, block_totals_dev, status_dev);
+}
+
+MIDAS_EXPORT int midas_tail_cdf(midas_ctx* ctx, int64_t N, double* cdf_dev, int32_t nb_all,
+                                const double* block_totals_all_dev, int32_t block_base, int32_t is_last,
+                                int32_t* status_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, N > 0 && nb_all > 0 && block_base >= 0 && cdf_dev && block_totals_all_dev && status_dev);
+    return launch_tail_cdf(ctx, N, cdf_dev, nb_all, block_totals_all_dev, block_base, is_last, status_dev);
+}
+
+MIDAS_EXPORT int midas_tail_resample(midas_ctx* ctx, const midas_tail_resample_args* args) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, args && args->N > 0 && args->N_all >= args->N && args->slot_base >= 0 &&
+                           args->slot_base + args->N <= args->N_all && args->cdf_all_dev && args->status_dev &&
+                           args->ridx_dev && args->poses_all_dev && args->poses_out_dev && args->weights_all_dev &&
+                           args->weights_out_dev && args->nn_all_dev && args->hint_out_dev);
+    MIDAS_REQUIRE(ctx, args->mode == MIDAS_RESAMPLE_MULTINOMIAL || args->mode == MIDAS_RESAMPLE_SYSTEMATIC);
+    return launch_tail_resample(ctx, *args, nullptr, 0, 1.0, nullptr);
+}
+
 // ---- profiling -----------------------------------------------------------------------------------
 MIDAS_EXPORT int midas_profile_enable(midas_ctx* ctx, int32_t on) {
     if (!ctx) return MIDAS_ERR_INVALID;

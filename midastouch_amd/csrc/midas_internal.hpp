@@ -144,6 +144,7 @@ struct ParticleUpdateArgs {
     const float* rot;
     float std_t, std_r;
     uint64_t seed, step;
+    int64_t slot_base = 0;  // global index of local particle 0 (Philox key)
     const int32_t* hint_in;
     int32_t* nn_idx;
     const double* scores;  // [K]
@@ -193,6 +194,16 @@ struct StepTailArgs {
     double* rmse_out;
 };
 int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base);
+int launch_tail_exp(midas_ctx* ctx, int64_t N, const double* x, int np, const double* pmax_all, const double* pmin_all,
+                    int32_t softmax, double* e_out, double* block_sums, int32_t* flag, int32_t* status);
+int launch_tail_scan(midas_ctx* ctx, int64_t N, double* w_io, const uint8_t* valid, int nb_all, const double* block_sums_all,
+                     const int32_t* flag, double* lp_out, double* block_totals, int32_t* status);
+int launch_tail_cdf(midas_ctx* ctx, int64_t N, double* cdf_io, int nb_all, const double* block_totals_all, int block_base,
+                    int32_t is_last, int32_t* status);
+int launch_tail_resample(midas_ctx* ctx, const midas_tail_resample_args& r, const double* part_rmse, int nrm,
+                         double rmse_count, double* rmse_out);
+int launch_reduce_partials(midas_ctx* ctx, int np, const double* pmax, const double* pmin, const double* prm,
+                           double* extrema2, double* rmse_sums2);
 
 // profiling hook used by the step: record event `slot` on the stream when profiling is on
 void prof_mark(midas_ctx* ctx, int slot);

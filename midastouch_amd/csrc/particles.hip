@@ -428,15 +428,15 @@ MD void store_pose(float* p, const float* P) {
     for (int i = 0; i < 4; ++i) v[i] = make_float4(P[i * 4 + 0], P[i * 4 + 1], P[i * 4 + 2], P[i * 4 + 3]);
 }
 
-MD void propagate_one(int64_t n, const float* P, const float* O, const float* tn_arr, const float* rot_arr,
-                      float std_t, float std_r, uint64_t seed, uint64_t step, float* out) {
+MD void propagate_one(int64_t n, int64_t n_global, const float* P, const float* O, const float* tn_arr,
+                      const float* rot_arr, float std_t, float std_r, uint64_t seed, uint64_t step, float* out) {
     float tn[3], rot[3];
     if (tn_arr) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) { tn[j] = tn_arr[n * 3 + j]; rot[j] = rot_arr[n * 3 + j]; }
     } else {
         float z[6];
-        philox_normals6((uint64_t)n, seed, step, z);
+        philox_normals6((uint64_t)n_global, seed, step, z);
 #pragma unroll
         for (int j = 0; j < 3; ++j) { tn[j] = z[j] * std_t; rot[j] = z[3 + j] * std_r; }
     }
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(64) void k_propagate(int64_t N, const float* __rest
     load_pose(in + n * 16, P);
 #pragma unroll
     for (int i = 0; i < 16; ++i) O[i] = odom[i];
-    propagate_one(n, P, O, tn, rot, std_t, std_r, seed, step, R);
+    propagate_one(n, n, P, O, tn, rot, std_t, std_r, seed, step, R);
     store_pose(out + n * 16, R);
 }
 
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
         load_pose(a.poses_in + n * 16, P);
 #pragma unroll
         for (int i = 0; i < 16; ++i) O[i] = a.odom16[i];
-        propagate_one(n, P, O, a.tn, a.rot, a.std_t, a.std_r, a.seed, a.step, R);
+        propagate_one(n, n + a.slot_base, P, O, a.tn, a.rot, a.std_t, a.std_r, a.seed, a.step, R);
         store_pose(a.poses_prop + n * 16, R);
         float f[6];
         se3_feature(R, 0.99f, 0.01f, f);
@@ -741,6 +741,53 @@ int launch_particle_update(midas_ctx* ctx, const midas_tree* t6, const midas_tre
     a.ablate = ablate;
     hipLaunchKernelGGL(k_particle_update, dim3((unsigned)particle_update_blocks(a.N)), dim3(64), 0, ctx->stream,
                        view_of<Kd6>(t6), view_of<Kd3>(t3), a);
+    MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    return MIDAS_OK;
+}
+
+// per-wave partials of the particle update -> two extrema and (optionally) two rmse sums
+__global__ __launch_bounds__(256) void k_reduce_partials(int np, const double* __restrict__ pmax,
+                                                         const double* __restrict__ pmin, const double* __restrict__ prm,
+                                                         double* __restrict__ extrema2, double* __restrict__ rmse_sums2) {
+    __shared__ double s0[4], s1[4], s2[4], s3[4];
+    double a = -INFINITY, b = INFINITY, p = 0.0, q = 0.0;
+    bool nan = false;
+    for (int i = threadIdx.x; i < np; i += 256) {
+        double u = pmax[i], v = pmin[i];
+        nan |= (u != u) || (v != v);
+        a = u > a ? u : a;
+        b = v < b ? v : b;
+        if (prm) { p += prm[2 * i]; q += prm[2 * i + 1]; }
+    }
+    a = wave_max(a);
+    b = wave_min(b);
+    p = wave_sum(p);
+    q = wave_sum(q);
+    const bool wnan = __any(nan);
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        s0[w] = wnan ? NAN : a; s1[w] = wnan ? NAN : b; s2[w] = p; s3[w] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bool bad = false;
+        for (int i = 0; i < 4; ++i) {
+            bad |= s0[i] != s0[i];
+            a = s0[i] > a ? s0[i] : a;
+            b = s1[i] < b ? s1[i] : b;
+        }
+        extrema2[0] = bad ? NAN : a;
+        extrema2[1] = bad ? NAN : b;
+        if (rmse_sums2) {
+            rmse_sums2[0] = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+            rmse_sums2[1] = (s3[0] + s3[1]) + (s3[2] + s3[3]);
+        }
+    }
+}
+
+int launch_reduce_partials(midas_ctx* ctx, int np, const double* pmax, const double* pmin, const double* prm,
+                           double* extrema2, double* rmse_sums2) {
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, ctx->stream, np, pmax, pmin, prm, extrema2, rmse_sums2);
     MIDAS_HIP_CHECK(ctx, hipGetLastError());
     return MIDAS_OK;
 }

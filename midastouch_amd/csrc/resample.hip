@@ -284,20 +284,27 @@ __global__ __launch_bounds__(256) void k_gather_rows(int64_t M, const int32_t* _
 }
 
 // ------------------------------------------------------------------------------------------------
-// fused step tail
+// step tail (shared by the fused single-GPU step and the particle-sharded multi-GPU step)
 // ------------------------------------------------------------------------------------------------
-// T1: m = max x ; e = exp(x - m) ; block totals of e
-__global__ __launch_bounds__(256) void k_tail_exp(StepTailArgs a, double* __restrict__ part_sum,
-                                                  int32_t* __restrict__ flag) {
+// A shard owns N local particles = the global slots [slot_base, slot_base + N) and the global blocks
+// [block_base, block_base + nb_local) of the summation spec; arrays suffixed _all span every shard.
+// Single GPU: slot_base = block_base = 0 and the _all arrays are the local ones.
+
+// T1: m = max over all partial maxima ; e = exp(x - m) (or x) -> e_out ; local block totals of e
+__global__ __launch_bounds__(256) void k_tail_exp(int64_t N, const double* __restrict__ x, int np,
+                                                  const double* __restrict__ pmax_all, const double* __restrict__ pmin_all,
+                                                  int32_t softmax, double* __restrict__ e_out,
+                                                  double* __restrict__ block_sums, int32_t* __restrict__ flag,
+                                                  int32_t* __restrict__ status) {
     __shared__ double s_red[24];
     __shared__ double s_gtot[16];
     double mx, mn;
-    block_extrema(a.part_max, a.part_min, a.npart, s_red, mx, mn);
-    const bool apply = a.softmax && !(__builtin_fabs(mx - mn) <= ISCLOSE_ATOL);
+    block_extrema(pmax_all, pmin_all, np, s_red, mx, mn);
+    const bool apply = softmax && !(__builtin_fabs(mx - mn) <= ISCLOSE_ATOL);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         flag[0] = apply ? 1 : 0;
-        a.status[0] = 0;
-        a.status[1] = 0;
+        status[0] = 0;
+        status[1] = 0;
     }
     const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_CHUNK;
     double v[SCAN_CHUNK], l[SCAN_CHUNK];
@@ -305,24 +312,27 @@ __global__ __launch_bounds__(256) void k_tail_exp(StepTailArgs a, double* __rest
     for (int j = 0; j < SCAN_CHUNK; ++j) {
         const int64_t i = base + j;
         double e = 0.0;
-        if (i < a.N) {
-            const double xi = a.x[i];
+        if (i < N) {
+            const double xi = x[i];
             e = apply ? exp(xi - mx) : xi;
-            a.weights[i] = e;
+            e_out[i] = e;
         }
         v[j] = e;
     }
     const double W = block_scan(v, l, s_gtot);
-    if (threadIdx.x == 0) part_sum[blockIdx.x] = W;
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = W;
 }
 
-// T2: w = e / S ; wm = w * valid -> weights ; block-local prefix of wm -> cdf ; block totals
-__global__ __launch_bounds__(256) void k_tail_scan(StepTailArgs a, int nb, const double* __restrict__ part_sum,
-                                                   const int32_t* __restrict__ flag, double* __restrict__ part_w) {
+// T2: S = sequential sum of ALL block sums ; w = e / S ; wm = w * valid -> w_io ; block-local prefix of wm
+//     -> lp_out ; local block totals ; status[0] |= 2 on NaN ; status[1] += particles kept
+__global__ __launch_bounds__(256) void k_tail_scan(int64_t N, double* __restrict__ w_io, const uint8_t* __restrict__ valid,
+                                                   int nb_all, const double* __restrict__ block_sums_all,
+                                                   const int32_t* __restrict__ flag, double* __restrict__ lp_out,
+                                                   double* __restrict__ block_totals, int32_t* __restrict__ status) {
     __shared__ double s_gtot[16];
     double bp, S = 1.0;
     const bool apply = flag[0] != 0;
-    if (apply) seq_totals(part_sum, nb, 0, bp, S);
+    if (apply) seq_totals(block_sums_all, nb_all, 0, bp, S);
     const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_CHUNK;
     double v[SCAN_CHUNK], l[SCAN_CHUNK];
     bool nan = false;
@@ -331,63 +341,92 @@ __global__ __launch_bounds__(256) void k_tail_scan(StepTailArgs a, int nb, const
     for (int j = 0; j < SCAN_CHUNK; ++j) {
         const int64_t i = base + j;
         double t = 0.0;
-        if (i < a.N) {
-            const double e = a.weights[i];
+        if (i < N) {
+            const double e = w_io[i];
             const double w = apply ? e / S : e;
-            const bool ok = a.valid[i] != 0;
+            const bool ok = valid[i] != 0;
             t = w * (ok ? 1.0 : 0.0);
             kept += ok ? 1 : 0;
             nan |= t != t;
-            a.weights[i] = t;
+            w_io[i] = t;
         }
         v[j] = t;
     }
     const double W = block_scan(v, l, s_gtot);
 #pragma unroll
     for (int j = 0; j < SCAN_CHUNK; ++j)
-        if (base + j < a.N) a.cdf[base + j] = l[j];
-    if (threadIdx.x == 0) part_w[blockIdx.x] = W;
+        if (base + j < N) lp_out[base + j] = l[j];
+    if (threadIdx.x == 0) block_totals[blockIdx.x] = W;
     const bool wnan = __any(nan);
-    if (wnan && (threadIdx.x & 63) == 0) atomicOr(&a.status[0], 2);
+    if (wnan && (threadIdx.x & 63) == 0) atomicOr(&status[0], 2);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
-    if ((threadIdx.x & 63) == 0 && kept) atomicAdd(&a.status[1], kept);
+    if ((threadIdx.x & 63) == 0 && kept) atomicAdd(&status[1], kept);
 }
 
-// T3: cdf = (BP + lp) / total
-__global__ __launch_bounds__(256) void k_tail_cdf(StepTailArgs a, int nb, const double* __restrict__ part_w) {
+// T3: cdf = (BP + lp) / total over ALL block totals ; the globally last slot is forced to 1
+__global__ __launch_bounds__(256) void k_tail_cdf(int64_t N, double* __restrict__ cdf_io, int nb_all,
+                                                  const double* __restrict__ block_totals_all, int block_base,
+                                                  int32_t is_last, int32_t* __restrict__ status) {
     double bp, total;
-    seq_totals(part_w, nb, blockIdx.x, bp, total);
+    seq_totals(block_totals_all, nb_all, block_base + (int)blockIdx.x, bp, total);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (total != total) atomicOr(&a.status[0], 2);
-        else if (total == 0.0) atomicOr(&a.status[0], 1);
+        if (total != total) atomicOr(&status[0], 2);
+        else if (total == 0.0) atomicOr(&status[0], 1);
     }
     const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK;
 #pragma unroll
     for (int j = 0; j < SCAN_CHUNK; ++j) {
         const int64_t i = base + (int64_t)j * 256 + threadIdx.x;
-        if (i < a.N) a.cdf[i] = (i == a.N - 1) ? 1.0 : (bp + a.cdf[i]) / total;
+        if (i < N) cdf_io[i] = (is_last && i == N - 1) ? 1.0 : (bp + cdf_io[i]) / total;
     }
 }
 
-// T4: resample slot i (identity when the weights are unusable) and gather pose / weight / hint
-__global__ __launch_bounds__(256) void k_tail_resample(StepTailArgs a, int nrm) {
+// T4: resample local slot i (global slot slot_base + i) from the GLOBAL cdf and gather pose / weight /
+//     hint rows from the global arrays; identity when the weights are unusable.  Optionally finishes the
+//     rmse epilogue from per-wave partial sums.
+struct TailResampleArgs {
+    int64_t N;            // local slots
+    int64_t N_all;        // global particles (length of cdf_all and of the *_all arrays)
+    int64_t slot_base;
+    const double* cdf_all;
+    const int32_t* status;
+    int32_t mode;
+    const double* u;      // local uniforms or null
+    float u32;
+    uint64_t seed, step;
+    int32_t* ridx;        // local out: global source index
+    const float* poses_all;
+    float* poses_out;
+    const double* weights_all;
+    double* weights_out;
+    const int32_t* nn_all;
+    int32_t* hint_out;
+    const double* part_rmse;  // nullable: [2*nrm] per-wave partials
+    int nrm;
+    double rmse_count;        // number of particles behind the partials
+    double* rmse_out;
+};
+
+__global__ __launch_bounds__(256) void k_tail_resample(TailResampleArgs a) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < a.N) {
-        int32_t src = (int32_t)i;
-        if (a.status[0] == 0) src = resample_slot(a.cdf, a.N, a.N, i, a.mode, a.u, a.u32, a.seed, a.step);
+        const int64_t slot = a.slot_base + i;
+        int32_t src = (int32_t)slot;
+        if (a.status[0] == 0) src = resample_slot(a.cdf_all, a.N_all, a.N_all, slot, a.mode, a.u ? a.u - a.slot_base : nullptr,
+                                                 a.u32, a.seed, a.step);
         a.ridx[i] = src;
-        const float4* ps = reinterpret_cast<const float4*>(a.poses_prop + (int64_t)src * 16);
+        const float4* ps = reinterpret_cast<const float4*>(a.poses_all + (int64_t)src * 16);
         float4* pd = reinterpret_cast<float4*>(a.poses_out + i * 16);
         float4 r0 = ps[0], r1 = ps[1], r2 = ps[2], r3 = ps[3];
         pd[0] = r0; pd[1] = r1; pd[2] = r2; pd[3] = r3;
-        a.weights_out[i] = a.weights[src];
-        a.hint_out[i] = a.nn_idx[src];
+        a.weights_out[i] = a.weights_all[src];
+        a.hint_out[i] = a.nn_all[src];
     }
     if (a.part_rmse && blockIdx.x == 0) {
         __shared__ double sa[4], sb[4];
         double p = 0.0, q = 0.0;
-        for (int k = threadIdx.x; k < nrm; k += 256) { p += a.part_rmse[2 * k]; q += a.part_rmse[2 * k + 1]; }
+        for (int k = threadIdx.x; k < a.nrm; k += 256) { p += a.part_rmse[2 * k]; q += a.part_rmse[2 * k + 1]; }
         p = wsum(p);
         q = wsum(q);
         if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = p; sb[threadIdx.x >> 6] = q; }
@@ -395,8 +434,8 @@ __global__ __launch_bounds__(256) void k_tail_resample(StepTailArgs a, int nrm) 
         if (threadIdx.x == 0) {
             p = (sa[0] + sa[1]) + (sa[2] + sa[3]);
             q = (sb[0] + sb[1]) + (sb[2] + sb[3]);
-            a.rmse_out[0] = __builtin_sqrt(p / (double)a.N);
-            a.rmse_out[1] = __builtin_sqrt(q / (double)a.N);
+            a.rmse_out[0] = __builtin_sqrt(p / a.rmse_count);
+            a.rmse_out[1] = __builtin_sqrt(q / a.rmse_count);
         }
     }
 }
@@ -485,6 +524,45 @@ int launch_gather_rows(midas_ctx* ctx, int64_t M, const int32_t* idx, const void
     return MIDAS_OK;
 }
 
+int launch_tail_exp(midas_ctx* ctx, int64_t N, const double* x, int np, const double* pmax_all, const double* pmin_all,
+                    int32_t softmax, double* e_out, double* block_sums, int32_t* flag, int32_t* status) {
+    hipLaunchKernelGGL(k_tail_exp, dim3((unsigned)ceil_div(N, SCAN_BLOCK)), dim3(256), 0, ctx->stream, N, x, np, pmax_all,
+                       pmin_all, softmax, e_out, block_sums, flag, status);
+    LAUNCH_CHECK(ctx);
+    return MIDAS_OK;
+}
+
+int launch_tail_scan(midas_ctx* ctx, int64_t N, double* w_io, const uint8_t* valid, int nb_all, const double* block_sums_all,
+                     const int32_t* flag, double* lp_out, double* block_totals, int32_t* status) {
+    hipLaunchKernelGGL(k_tail_scan, dim3((unsigned)ceil_div(N, SCAN_BLOCK)), dim3(256), 0, ctx->stream, N, w_io, valid,
+                       nb_all, block_sums_all, flag, lp_out, block_totals, status);
+    LAUNCH_CHECK(ctx);
+    return MIDAS_OK;
+}
+
+int launch_tail_cdf(midas_ctx* ctx, int64_t N, double* cdf_io, int nb_all, const double* block_totals_all, int block_base,
+                    int32_t is_last, int32_t* status) {
+    hipLaunchKernelGGL(k_tail_cdf, dim3((unsigned)ceil_div(N, SCAN_BLOCK)), dim3(256), 0, ctx->stream, N, cdf_io, nb_all,
+                       block_totals_all, block_base, is_last, status);
+    LAUNCH_CHECK(ctx);
+    return MIDAS_OK;
+}
+
+int launch_tail_resample(midas_ctx* ctx, const midas_tail_resample_args& r, const double* part_rmse, int nrm,
+                         double rmse_count, double* rmse_out) {
+    TailResampleArgs a;
+    a.N = r.N; a.N_all = r.N_all; a.slot_base = r.slot_base;
+    a.cdf_all = r.cdf_all_dev; a.status = r.status_dev; a.mode = r.mode; a.u = r.u_dev; a.u32 = r.u32;
+    a.seed = r.seed; a.step = r.step; a.ridx = r.ridx_dev;
+    a.poses_all = r.poses_all_dev; a.poses_out = r.poses_out_dev;
+    a.weights_all = r.weights_all_dev; a.weights_out = r.weights_out_dev;
+    a.nn_all = r.nn_all_dev; a.hint_out = r.hint_out_dev;
+    a.part_rmse = part_rmse; a.nrm = nrm; a.rmse_count = rmse_count; a.rmse_out = rmse_out;
+    hipLaunchKernelGGL(k_tail_resample, dim3((unsigned)ceil_div(r.N, 256)), dim3(256), 0, ctx->stream, a);
+    LAUNCH_CHECK(ctx);
+    return MIDAS_OK;
+}
+
 int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base) {
     const int nb = (int)ceil_div(a.N, SCAN_BLOCK);
     void* sc;
@@ -493,16 +571,22 @@ int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base) 
     double* psum = (double*)sc;
     double* pw = psum + nb;
     int32_t* flag = (int32_t*)(pw + nb);
-    hipLaunchKernelGGL(k_tail_exp, dim3(nb), dim3(256), 0, ctx->stream, a, psum, flag);
+    if ((rc = launch_tail_exp(ctx, a.N, a.x, a.npart, a.part_max, a.part_min, a.softmax, a.weights, psum, flag, a.status))) return rc;
     prof_mark(ctx, prof_slot_base + 1);
-    hipLaunchKernelGGL(k_tail_scan, dim3(nb), dim3(256), 0, ctx->stream, a, nb, (const double*)psum, (const int32_t*)flag, pw);
+    if ((rc = launch_tail_scan(ctx, a.N, a.weights, a.valid, nb, psum, flag, a.cdf, pw, a.status))) return rc;
     prof_mark(ctx, prof_slot_base + 2);
-    hipLaunchKernelGGL(k_tail_cdf, dim3(nb), dim3(256), 0, ctx->stream, a, nb, (const double*)pw);
+    if ((rc = launch_tail_cdf(ctx, a.N, a.cdf, nb, pw, 0, 1, a.status))) return rc;
     prof_mark(ctx, prof_slot_base + 3);
-    hipLaunchKernelGGL(k_tail_resample, dim3((unsigned)ceil_div(a.N, 256)), dim3(256), 0, ctx->stream, a,
-                       a.part_rmse ? particle_update_blocks(a.N) : 0);
+    midas_tail_resample_args r;
+    r.N = a.N; r.N_all = a.N; r.slot_base = 0;
+    r.cdf_all_dev = a.cdf; r.status_dev = a.status; r.mode = a.mode; r.u_dev = a.u; r.u32 = a.u32;
+    r.seed = a.seed; r.step = a.step; r.ridx_dev = a.ridx;
+    r.poses_all_dev = a.poses_prop; r.poses_out_dev = a.poses_out;
+    r.weights_all_dev = a.weights; r.weights_out_dev = a.weights_out;
+    r.nn_all_dev = a.nn_idx; r.hint_out_dev = a.hint_out;
+    if ((rc = launch_tail_resample(ctx, r, a.part_rmse, a.part_rmse ? particle_update_blocks(a.N) : 0, (double)a.N, a.rmse_out)))
+        return rc;
     prof_mark(ctx, prof_slot_base + 4);
-    LAUNCH_CHECK(ctx);
     return MIDAS_OK;
 }
 

@@ -1,0 +1,238 @@
+"""Particle-sharded filter across the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+SURVEY.md 8(e): rank r owns the global particle slots [r*N, (r+1)*N) and a full replica of the codebook,
+the NN index and the mesh index.  One frame is the single-GPU frame (engine.FilterEngine.step) cut at
+its global reductions; between the local kernels the ranks exchange, with `all_gather`:
+
+  G1  4 doubles/rank   max x, min x (softmax shift + isclose guard), rmse partial sums
+  G2  nb doubles/rank  block sums of exp(x - max)           -> softmax denominator (fixed order)
+  G3  nb+2 doubles     block totals of the masked weights   -> CDF offsets / total, NaN flag, kept count
+  G4  N doubles/rank   the CDF slice     G5 N x 16 f32 propagated poses
+  G6  N doubles        masked weights    G7 N int32 NN indices      (resample reads any rank's particle)
+
+The float64 summation order is the single-GPU one (per-block totals are gathered and every rank adds
+them sequentially in global block order), so with N a multiple of 4096 the sharded run reproduces the
+single-GPU run of G*N particles bit for bit - same weights, same resample indices.
+
+The frame is written as a generator that yields at every exchange, so the same code runs under
+torch.distributed (`step`) and, for tests, as several shards of one process stepped in lock-step by
+`run_lockstep` (no collective library involved).  Compute goes through a backend object: the product
+backend is HIP-only (`HipShardBackend`); tests may inject another one.  There is no CPU fallback here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib, ops
+from ._lib import MidasError, ShardUpdateArgs, TailResampleArgs, _ptr
+
+BLOCK = 4096  # summation block of the CDF spec (csrc/resample.hip)
+
+
+class HipShardBackend:
+    """Local kernels of one shard (libmidas_hip.so)."""
+
+    def __init__(self, cb_poses, cb_embeddings, mesh_vertices, device):
+        self.ctx = _lib.context(device)
+        self.device = self.ctx.device
+        self.cb_poses = torch.as_tensor(cb_poses).to(self.device, torch.float32).contiguous()
+        self.cb_feat = ops.se3_feature(self.cb_poses)
+        self.tree6 = ops.Tree(self.cb_feat)
+        self.codebook = ops.Codebook(torch.as_tensor(cb_embeddings).to(self.device))
+        self.tree3 = ops.Tree(torch.as_tensor(mesh_vertices).to(self.device, torch.float64))
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def project(self, poses):
+        idx = ops.nn6(self.tree6, ops.se3_feature(poses))
+        return ops.gather_rows(self.cb_poses, idx), idx
+
+    def update(self, st, odom, code, gt, tn, rot, std_t, std_r, seed, step, prune_thr, use_hint=True):
+        a = ShardUpdateArgs()
+        a.N, a.slot_base = st.N, st.slot_base
+        a.poses_in, a.poses_prop = _ptr(st.poses), _ptr(st.poses_prop)
+        a.hint_in = _ptr(st.hint) if use_hint else None
+        a.nn_idx, a.x, a.valid, a.extrema = _ptr(st.nn_idx), _ptr(st.x), _ptr(st.valid), _ptr(st.g1[:2])
+        a.odom16, a.code, a.gt16 = _ptr(odom), _ptr(code), _ptr(gt)
+        a.rmse_sums = _ptr(st.g1[2:]) if gt is not None else None
+        a.tn, a.rot = _ptr(tn), _ptr(rot)
+        a.std_t, a.std_r, a.seed, a.step, a.prune_thr = std_t, std_r, seed, step, prune_thr
+        self.ctx.bind_current_stream()
+        self.ctx.check(self.ctx.lib.midas_shard_update(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h, C.byref(a)))
+
+    def tail_exp(self, st, pmax_all, pmin_all, softmax):
+        self.ctx.call("midas_tail_exp", st.N, _ptr(st.x), pmax_all.shape[0], _ptr(pmax_all), _ptr(pmin_all), int(softmax),
+                      _ptr(st.weights), _ptr(st.g2), _ptr(st.flag), _ptr(st.status))
+
+    def tail_scan(self, st, block_sums_all):
+        self.ctx.call("midas_tail_scan", st.N, _ptr(st.weights), _ptr(st.valid), block_sums_all.shape[0],
+                      _ptr(block_sums_all), _ptr(st.flag), _ptr(st.cdf), _ptr(st.g3[: st.nb]), _ptr(st.status))
+
+    def tail_cdf(self, st, block_totals_all, block_base, is_last):
+        self.ctx.call("midas_tail_cdf", st.N, _ptr(st.cdf), block_totals_all.shape[0], _ptr(block_totals_all),
+                      block_base, int(is_last), _ptr(st.status))
+
+    def tail_resample(self, st, cdf_all, poses_all, weights_all, nn_all, mode, u, u32, seed, step):
+        a = TailResampleArgs()
+        a.N, a.N_all, a.slot_base = st.N, cdf_all.shape[0], st.slot_base
+        a.cdf_all, a.status, a.mode, a.u, a.u32 = _ptr(cdf_all), _ptr(st.status), mode, _ptr(u), float(u32)
+        a.seed, a.step, a.ridx = seed, step, _ptr(st.ridx)
+        a.poses_all, a.poses_out = _ptr(poses_all), _ptr(st.poses)
+        a.weights_all, a.weights_out = _ptr(weights_all), _ptr(st.weights_res)
+        a.nn_all, a.hint_out = _ptr(nn_all), _ptr(st.hint)
+        self.ctx.bind_current_stream()
+        self.ctx.check(self.ctx.lib.midas_tail_resample(self.ctx.h, C.byref(a)))
+
+
+class ShardState:
+    """Per-shard tensors (allocated through the backend so tests can keep them on the CPU)."""
+
+    def __init__(self, backend, N, slot_base):
+        e = backend.empty
+        self.N, self.slot_base = int(N), int(slot_base)
+        self.nb = (self.N + BLOCK - 1) // BLOCK
+        self.poses = e((N, 4, 4), torch.float32)
+        self.poses_prop = e((N, 4, 4), torch.float32)
+        self.weights = e((N,), torch.float64)
+        self.weights_res = e((N,), torch.float64)
+        self.cdf = e((N,), torch.float64)
+        self.x = e((N,), torch.float64)
+        self.valid = e((N,), torch.uint8)
+        self.nn_idx = e((N,), torch.int32)
+        self.hint = e((N,), torch.int32)
+        self.ridx = e((N,), torch.int32)
+        self.g1 = e((4,), torch.float64)            # max, min, rmse sums
+        self.g2 = e((self.nb,), torch.float64)      # block sums of e
+        self.g3 = e((self.nb + 2,), torch.float64)  # block totals of w*mask, NaN flag, kept
+        self.flag = e((1,), torch.int32)
+        self.status = e((2,), torch.int32)
+        self.rmse = e((2,), torch.float64)
+        self.hint.fill_(-1)
+        self.g1.zero_()
+
+
+class TorchDistComm:
+    """all_gather over torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" on CPU)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self._into = dist.get_backend(group) == "nccl"
+
+    def all_gather(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.contiguous()
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        if self._into:
+            self.dist.all_gather_into_tensor(out, t, group=self.group)
+        else:
+            self.dist.all_gather(list(out.chunk(self.world)), t, group=self.group)
+        return out
+
+
+class SingleComm:
+    rank, world = 0, 1
+
+    def all_gather(self, t):
+        return t
+
+
+class ShardedFilterEngine:
+    def __init__(self, cb_poses=None, cb_embeddings=None, mesh_vertices=None, num_particles: int = 0, *, sig_t=2e-4,
+                 sig_r=0.5, pen_max=0.002, seed=4000, softmax=True, resample="weighted_random", device=None,
+                 comm=None, backend=None, rank=None, world=None):
+        if comm is None:
+            import torch.distributed as dist
+
+            comm = TorchDistComm() if dist.is_available() and dist.is_initialized() else SingleComm()
+        self.comm = comm
+        self.rank = comm.rank if rank is None else rank
+        self.world = comm.world if world is None else world
+        self.backend = backend if backend is not None else HipShardBackend(cb_poses, cb_embeddings, mesh_vertices, device)
+        self.N = int(num_particles)
+        self.N_total = self.N * self.world
+        self.st = ShardState(self.backend, self.N, self.rank * self.N)
+        self.sig_t, self.sig_r, self.pen_max = float(sig_t), float(sig_r), float(pen_max)
+        self.seed, self.softmax = int(seed), bool(softmax)
+        self.mode = {"weighted_random": _lib.RESAMPLE_MULTINOMIAL, "low_var": _lib.RESAMPLE_SYSTEMATIC,
+                     "low_var_batch": _lib.RESAMPLE_SYSTEMATIC}[resample]
+        self.step_count = 0
+        self.use_hint = True
+
+    # convenience views used by bench.py / tests (same names as FilterEngine)
+    poses = property(lambda self: self.st.poses)
+    poses_prop = property(lambda self: self.st.poses_prop)
+    weights = property(lambda self: self.st.weights)
+    weights_res = property(lambda self: self.st.weights_res)
+    nn_idx = property(lambda self: self.st.nn_idx)
+    hint = property(lambda self: self.st.hint)
+    ridx = property(lambda self: self.st.ridx)
+    status = property(lambda self: self.st.status)
+    rmse = property(lambda self: self.st.rmse)
+
+    def set_particles(self, poses):
+        poses = torch.as_tensor(poses).to(self.st.poses.device, torch.float32)
+        if tuple(poses.shape) != (self.N, 4, 4):
+            raise MidasError(f"expected ({self.N},4,4) local poses, got {tuple(poses.shape)}")
+        self.st.poses.copy_(poses)
+        self.st.hint.fill_(-1)
+
+    def project_to_codebook(self):
+        p, idx = self.backend.project(self.st.poses)
+        self.st.poses.copy_(p)
+        self.st.hint.copy_(idx)
+
+    # -- one frame as a generator: yields the local tensor of each exchange, receives the gathered one -----
+    def step_gen(self, odom, code, gt=None, tn=None, rot=None, u=None, u32=-1.0, multiplier: float = 1.0):
+        st, b, G = self.st, self.backend, self.world
+        mul = max(float(multiplier), 1.0)
+        b.update(st, odom, code, gt, tn, rot, mul * self.sig_t, mul * self.sig_r, self.seed, self.step_count,
+                 self.pen_max, self.use_hint)
+        g1 = (yield st.g1).reshape(G, 4)
+        b.tail_exp(st, g1[:, 0].contiguous(), g1[:, 1].contiguous(), self.softmax)
+        g2 = yield st.g2
+        b.tail_scan(st, g2)
+        st.g3[st.nb:] = st.status.to(torch.float64)  # NaN flag (status[0]), kept count (status[1])
+        g3 = (yield st.g3).reshape(G, st.nb + 2)
+        st.status[0] = (g3[:, st.nb] != 0).any().to(torch.int32) * 2
+        st.status[1] = g3[:, st.nb + 1].sum().to(torch.int32)
+        b.tail_cdf(st, g3[:, : st.nb].contiguous().reshape(-1), self.rank * st.nb, self.rank == G - 1)
+        cdf_all = yield st.cdf
+        poses_all = yield st.poses_prop
+        weights_all = yield st.weights
+        nn_all = yield st.nn_idx
+        b.tail_resample(st, cdf_all, poses_all, weights_all, nn_all, self.mode, u, u32, self.seed, self.step_count)
+        if gt is not None:
+            st.rmse.copy_(torch.sqrt(g1[:, 2:].sum(dim=0) / float(self.N_total)))
+        self.step_count += 1
+
+    def step(self, odom, code, gt=None, **draws):
+        gen = self.step_gen(odom, code, gt, **draws)
+        try:
+            msg = next(gen)
+            while True:
+                msg = gen.send(self.comm.all_gather(msg))
+        except StopIteration:
+            pass
+
+
+def run_lockstep(engines, per_rank_args):
+    """Step several shards of ONE process in lock-step (tests): gathers are concatenations in rank order."""
+    gens = [e.step_gen(*a[0], **a[1]) for e, a in zip(engines, per_rank_args)]
+    msgs = [next(g) for g in gens]
+    while True:
+        gathered = torch.cat([m.reshape((m.shape[0],) + tuple(m.shape[1:])) for m in msgs], dim=0)
+        nxt, done = [], 0
+        for g in gens:
+            try:
+                nxt.append(g.send(gathered))
+            except StopIteration:
+                done += 1
+        if done:
+            assert done == len(gens), "shards fell out of step"
+            return
+        msgs = nxt

@@ -1,0 +1,185 @@
+"""Filter runner: the reference's per-frame loop (`midastouch/filter/filter.py:42-256`) on the MI355X path.
+
+Two ways to run a sequence:
+
+* `filter(cfg, ...)`  - the reference's loop body call for call (motionModel -> particle_rmse -> SE3_NN ->
+  get_similarity -> remove_invalid_particles -> cluster_particles/get_cluster_centers -> annealing ->
+  resampler), same order of operations, same RNG draw order, same guards and the same `filter_stats`
+  keys (:99-116).  It is the counterpart of row H of SURVEY.md 8(a).
+* `step(...) / update_weights(...) / resample(...)` - the north-star aliases.  `step` drives a
+  `FilterEngine` (one fused C-ABI call per frame, fixed N); `update_weights` is SE3_NN + get_similarity
+  without the (N, D) gather; `resample` is `particle_filter.resampler`.
+
+Upstream perception (TDN/TCN, `filter.py:144-147`) is out of scope: tactile codes are inputs.  The
+datasets of the reference are external downloads, so sequences come from `synthetic.py`.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .engine import FilterEngine
+from .particle_filter import Particles, particle_filter, particle_rmse
+from .synthetic import make_codebook, make_trajectory
+from .tactile_tree import tactile_tree
+
+
+@dataclass
+class Sequence:
+    """What the reference loads per log: gt / measured poses (`extract_poses_sim`, pose.py:272-300) and,
+    instead of tactile images, the tactile codes the TCN would emit for them."""
+    gt_p: torch.Tensor       # (T,4,4) f32
+    meas_p: torch.Tensor     # (T,4,4) f32
+    codes: torch.Tensor      # (T,D)   f64
+    codebook: tactile_tree
+    mesh_vertices: np.ndarray
+    obj_model: str
+
+
+def synthetic_sequence(cfg, device, T: int = 100, D: Optional[int] = None, seed: int = 0) -> Sequence:
+    obj = cfg.expt.obj_model
+    K = int(cfg.expt.codebook_size)
+    D = int(D if D is not None else cfg.tcn.model.output_dim)
+    cb = make_codebook(obj, K=K, D=D, seed=1000 + seed)
+    traj = make_trajectory(cb, T=T, seed=2000 + seed)
+    tree = tactile_tree(torch.as_tensor(cb.poses), torch.as_tensor(cb.cam_poses), torch.as_tensor(cb.embeddings))
+    tree.to_device(device)
+    return Sequence(torch.as_tensor(traj.gt_poses).to(device), torch.as_tensor(traj.meas_poses).to(device),
+                    torch.as_tensor(traj.codes).to(device), tree, cb.mesh_vertices, obj)
+
+
+# ---- north-star aliases ---------------------------------------------------------------------------
+def update_weights(pf: particle_filter, codebook: tactile_tree, particles: Particles, tactile_code: torch.Tensor,
+                   softmax: bool = True) -> Particles:
+    """particles.weights <- similarity of the tactile code to each particle's nearest codebook pose
+    (filter/filter.py:170-173) - the codebook is scored once, no (N, D) gather."""
+    _, _, nn_codes = codebook.SE3_NN(particles.poses)
+    particles.weights = pf.get_similarity(tactile_code, nn_codes, softmax=softmax)
+    return particles
+
+
+def resample(pf: particle_filter, particles: Particles, mode: str = "weighted_random") -> Particles:
+    return pf.resampler(particles, resample=mode)
+
+
+def step(engine: FilterEngine, odom: torch.Tensor, tactile_code: torch.Tensor, gt_pose: torch.Tensor = None, **draws):
+    """One fused frame on a FilterEngine (propagate -> score/NN -> weights -> prune -> resample)."""
+    engine.step(odom, tactile_code, gt=gt_pose, **draws)
+    return engine
+
+
+# ---- the reference loop -----------------------------------------------------------------------------
+def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str = "fixed", max_frames: int = None,
+           cluster: bool = True, progress: bool = False) -> dict:
+    """Run the filter over a sequence; returns the reference's `filter_stats` dict (filter.py:99-116).
+
+    pace="fixed" steps one frame per iteration (deterministic); pace="wallclock" reproduces
+    `idx = int(frame_rate * total_time)` (:134-135): slow iterations skip frames, fast ones repeat.
+    """
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    expt_cfg = cfg.expt
+    init_particles = int(expt_cfg.params.num_particles)
+    noise_ratio = expt_cfg.params.noise_ratio
+    frame_rate = expt_cfg.frame_rate
+    if seq is None:
+        seq = synthetic_sequence(cfg, device)
+    gt_p, meas_p, codebook = seq.gt_p, seq.meas_p, seq.codebook
+    traj_size = gt_p.shape[0] if expt_cfg.max_length in (None, "None") else min(gt_p.shape[0], int(expt_cfg.max_length))
+    if max_frames is not None:
+        traj_size = min(traj_size, max_frames)
+    pf = particle_filter(cfg, seq.mesh_vertices, noise_ratio, downsample=1, device=device)
+    heatmap_poses, _ = codebook.get_poses()
+    heatmap_embeddings = codebook.get_embeddings()
+
+    timer = dict.fromkeys(["tactile", "motion", "meas"], 0.0)
+    avg_timer = {"tactile": [], "motion": [], "meas": []}
+    filter_stats = {
+        "rmse_t": [], "rmse_r": [], "time": [], "traj_size": traj_size, "avg_time": None, "total_time": 0,
+        "cluster_poses": [], "cluster_stds": [], "obj_name": seq.obj_model, "tree_size": len(codebook),
+        "noise_ratio": noise_ratio, "init_noise": pf.init_noise, "init_particles": init_particles,
+        "num_particles": [], "log_id": str(expt_cfg.log_id).zfill(2), "trial_id": 0,
+    }
+    prev_idx, count, fixed_idx = 0, 0, 0
+    particles = None
+    while True:
+        if pace == "wallclock":
+            idx = int(frame_rate * filter_stats["total_time"])
+        else:
+            idx = fixed_idx
+            fixed_idx += 1
+        if idx >= traj_size:
+            break
+        tactile_code = seq.codes[idx][None]
+        timer["tactile"] = 0.0  # perception is upstream of this path
+
+        start = time.time()
+        if prev_idx > 0:  # (filter.py:152) - like the reference, frames seen while prev_idx == 0 re-initialise
+            odom = torch.inverse(meas_p[prev_idx, :]) @ meas_p[idx, :]
+            particles = pf.motionModel(particles, odom, multiplier=1.0)
+        else:
+            particles = pf.init_filter(gt_p[idx, :], init_particles)
+            particles.poses, _, _ = codebook.SE3_NN(particles.poses)
+        torch.cuda.synchronize(device)
+        timer["motion"] = time.time() - start
+
+        rmse_t, rmse_r = particle_rmse(particles, gt_p[idx, :])
+        filter_stats["rmse_t"].append(rmse_t.item())
+        filter_stats["rmse_r"].append(rmse_r.item())
+
+        start = time.time()
+        _, _, nn_tactile_codes = codebook.SE3_NN(particles.poses)
+        particles.weights = pf.get_similarity(tactile_code, nn_tactile_codes, softmax=True)
+        particles, drifted = pf.remove_invalid_particles(particles)
+        if drifted:
+            particles.poses, _, _ = codebook.SE3_NN(particles.poses)
+        if cluster:
+            if count % 50 == 0:
+                particles = pf.cluster_particles(particles)
+            cluster_poses, cluster_stds = pf.get_cluster_centers(particles, method="quat_avg")
+            particles = pf.annealing(particles, torch.mean(cluster_stds).cpu())
+        else:
+            cluster_poses = torch.zeros((0, 4, 4), device=device)
+            cluster_stds = torch.zeros((0, 3), device=device)
+        particles = pf.resampler(particles)
+        torch.cuda.synchronize(device)
+        timer["meas"] = time.time() - start
+
+        filter_stats["cluster_poses"].append(cluster_poses)
+        filter_stats["cluster_stds"].append(cluster_stds)
+        filter_stats["num_particles"].append(len(particles))
+        filter_stats["time"].append(sum(timer.values()))
+        for k in timer:
+            avg_timer[k].append(timer[k])
+        if viz is not None:
+            heatmap_weights = pf.get_similarity(tactile_code, heatmap_embeddings, softmax=False)
+            # the visualiser reads particles.poses asynchronously (viz/visualizer.py:329-361): hand it a snapshot
+            snap = Particles(particles.poses.clone(), particles.weights.clone(), particles.labels.clone())
+            viz.update(snap, cluster_poses, cluster_stds, gt_p[idx, :], heatmap_poses, heatmap_weights, None, None, None, idx)
+        if progress:
+            print(f"[{idx}] RMSE {1000 * filter_stats['rmse_t'][-1]:.1f} mm {filter_stats['rmse_r'][-1]:.0f} deg "
+                  f"P {len(particles)} rate {1.0 / max(filter_stats['time'][-1], 1e-9):.1f} Hz")
+        prev_idx = idx
+        count += 1
+        filter_stats["total_time"] = sum(filter_stats["time"])
+    filter_stats["avg_time"] = sum(filter_stats["time"]) / max(len(filter_stats["time"]), 1)
+    filter_stats["avg_timer"] = {k: float(np.average(v)) if v else 0.0 for k, v in avg_timer.items()}
+    return filter_stats
+
+
+def main(argv=None):
+    import sys
+
+    from .config import load_config
+
+    cfg = load_config(list(sys.argv[1:] if argv is None else argv))
+    stats = filter(cfg, progress=True)
+    print(f"Total time: {stats['total_time']:.3f}, Per iteration time: {stats['avg_time']:.4f}")
+    np.save("filter_stats.npy", {k: v for k, v in stats.items() if k not in ("cluster_poses", "cluster_stds")})
+
+
+if __name__ == "__main__":
+    main()

@@ -20,7 +20,7 @@ def _ctx(t: torch.Tensor):
 
 
 def _poses(p: torch.Tensor) -> torch.Tensor:
-    p = torch.atleast_3d(p) if p.dim() == 2 else p
+    p = p[None] if p.dim() == 2 else p
     if p.dtype != torch.float32 or not p.is_contiguous():
         p = p.float().contiguous()
     return p

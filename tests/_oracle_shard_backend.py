@@ -1,0 +1,110 @@
+"""CPU stand-in for dist.HipShardBackend built on the oracle (TESTS ONLY): lets the sharded frame logic and
+its collectives run under gloo without a GPU.  The product never imports this."""
+import math
+
+import numpy as np
+import torch
+
+from oracle import oracle as orc
+
+BLOCK = 4096
+
+
+def _seq_sum(a):
+    acc = 0.0
+    for v in np.asarray(a, dtype=np.float64):
+        acc = acc + float(v)
+    return acc
+
+
+class OracleShardBackend:
+    device = torch.device("cpu")
+
+    def __init__(self, cb_poses, cb_embeddings, mesh_vertices):
+        self.ofl = orc.OracleFilter(cb_poses, cb_embeddings, mesh_vertices)
+        self.cb_poses = np.asarray(cb_poses, dtype=np.float32)
+
+    def empty(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype)
+
+    def project(self, poses):
+        idx = self.ofl.SE3_NN_idx(poses.numpy())
+        return torch.as_tensor(self.cb_poses[idx]), torch.as_tensor(idx)
+
+    def update(self, st, odom, code, gt, tn, rot, std_t, std_r, seed, step, prune_thr, use_hint=True):
+        N, base = st.N, st.slot_base
+        if tn is None:
+            tn_all, rot_all = orc.philox_noise(base + N, seed, step, np.float32(std_t), np.float32(std_r))
+            tn, rot = tn_all[base:], rot_all[base:]
+        else:
+            tn, rot = tn.numpy(), rot.numpy()
+        p1 = orc.propagate(st.poses.numpy(), odom.numpy(), tn, rot)
+        idx, _ = orc.nn6(orc.R3_SE3(p1), self.ofl.cb_feat)
+        scores = orc.score_codebook(self.ofl.emb, code.numpy())
+        x = scores[idx]
+        dist = orc.nn3_dist(p1, self.ofl.verts)
+        st.poses_prop.copy_(torch.as_tensor(p1))
+        st.nn_idx.copy_(torch.as_tensor(idx))
+        st.x.copy_(torch.as_tensor(x))
+        st.valid.copy_(torch.as_tensor((~(dist > prune_thr)).astype(np.uint8)))
+        st.g1[0], st.g1[1] = float(x.max()), float(x.min())
+        if gt is not None:
+            rt, rr = orc.particle_rmse(p1, gt.numpy())
+            st.g1[2], st.g1[3] = rt * rt * N, rr * rr * N
+
+    def tail_exp(self, st, pmax_all, pmin_all, softmax):
+        mx, mn = float(pmax_all.max()), float(pmin_all.min())
+        apply = bool(softmax) and not (abs(mx - mn) <= 1e-8)
+        x = st.x.numpy()
+        # math.exp is glibc's exp, the function the C oracle calls (numpy's vectorised exp can differ by an ulp)
+        e = np.array([math.exp(v) for v in (x - mx)]) if apply else x.copy()
+        st.weights.copy_(torch.as_tensor(e))
+        for b in range(st.nb):
+            st.g2[b] = orc.blocked_scan(e[b * BLOCK:(b + 1) * BLOCK])[1]
+        st.flag[0] = int(apply)
+        st.status.zero_()
+
+    def tail_scan(self, st, block_sums_all):
+        e = st.weights.numpy()
+        w = e / _seq_sum(block_sums_all.numpy()) if int(st.flag[0]) else e.copy()
+        valid = st.valid.numpy().astype(bool)
+        wm = w * valid
+        st.weights.copy_(torch.as_tensor(wm))
+        for b in range(st.nb):
+            lp, tot = orc.blocked_scan(wm[b * BLOCK:(b + 1) * BLOCK])
+            st.cdf[b * BLOCK:(b + 1) * BLOCK] = torch.as_tensor(lp)
+            st.g3[b] = tot
+        st.status[0] = 2 if np.isnan(wm).any() else 0
+        st.status[1] = int(valid.sum())
+
+    def tail_cdf(self, st, block_totals_all, block_base, is_last):
+        tot = block_totals_all.numpy()
+        total = _seq_sum(tot)
+        lp = st.cdf.numpy().copy()
+        out = np.empty_like(lp)
+        for b in range(st.nb):
+            bp = _seq_sum(tot[: block_base + b])
+            out[b * BLOCK:(b + 1) * BLOCK] = (bp + lp[b * BLOCK:(b + 1) * BLOCK]) / total if total != 0 else np.nan
+        if is_last:
+            out[-1] = 1.0
+        st.cdf.copy_(torch.as_tensor(out))
+        if np.isnan(total):
+            st.status[0] |= 2
+        elif total == 0.0:
+            st.status[0] |= 1
+
+    def tail_resample(self, st, cdf_all, poses_all, weights_all, nn_all, mode, u, u32, seed, step):
+        N, base, Nall = st.N, st.slot_base, cdf_all.shape[0]
+        if int(st.status[0]) != 0:
+            src = np.arange(base, base + N, dtype=np.int32)
+        elif mode == 0:
+            uu = u.numpy() if u is not None else orc.philox_uniform64(base + N, seed, step)[base:]
+            src = orc.search_lower(cdf_all.numpy(), uu)
+        else:
+            r = u32 if u32 >= 0 else orc.philox_uniform32(seed, step)
+            src = orc.search_systematic(cdf_all.numpy(), Nall, r)[base:base + N]
+        st.ridx.copy_(torch.as_tensor(src))
+        s = torch.as_tensor(src).long()
+        st.poses.copy_(poses_all[s])
+        st.weights_res.copy_(weights_all[s])
+        st.hint.copy_(nn_all[s])

@@ -1,0 +1,186 @@
+"""The reference-named Python surface (Particles / particle_filter / tactile_tree / particle_rmse) on the
+GPU against the golden fixtures of the real reference and against the oracle.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def setup(dev):
+    from midastouch_amd.config import load_config
+    from midastouch_amd.particle_filter import particle_filter
+    from midastouch_amd.synthetic import make_codebook
+    from midastouch_amd.tactile_tree import tactile_tree
+    cfg = load_config(["expt.params.num_particles=1500", "expt.codebook_size=3000"])
+    cb = make_codebook(K=3000, D=256, seed=1000)
+    pf = particle_filter(cfg, cb.mesh_vertices, 1.0, downsample=1, device=dev)
+    tree = tactile_tree(torch.as_tensor(cb.poses), torch.as_tensor(cb.cam_poses), torch.as_tensor(cb.embeddings).double())
+    tree.to_device(dev)
+    return cfg, cb, pf, tree
+
+
+def test_motion_model_matches_reference_golden(dev, setup, golden):
+    """motionModel with the seed the reference used: same draws, poses within float tolerance."""
+    from midastouch_amd.particle_filter import Particles
+    cfg, cb, pf, tree = setup
+    g = golden("g3_motion")
+    for tag in ("sim", "mul3"):
+        sig_r, sig_t, mul, seed = g[f"{tag}_params"]
+        pf.motion_noise = {"mu": 0, "sig_r": float(sig_r), "sig_t": float(sig_t)}
+        parts = Particles(torch.as_tensor(g[f"{tag}_poses"]).to(dev))
+        torch.manual_seed(int(seed))
+        out = pf.motionModel(parts, torch.as_tensor(g[f"{tag}_odom"]).to(dev), multiplier=float(mul))
+        np.testing.assert_allclose(out.poses.cpu().numpy(), g[f"{tag}_new_poses"], rtol=0, atol=2e-6)
+        assert out is not parts and len(out) == len(parts)
+    pf.motion_noise = {"mu": 0, "sig_r": 0.5, "sig_t": 2e-4}
+
+
+def test_init_filter_matches_reference_golden(dev, setup, golden):
+    cfg, cb, pf, tree = setup
+    g = golden("g8_init")
+    keep = pf.init_noise
+    pf.init_noise = [float(v) for v in g["init_noise"]]
+    torch.manual_seed(int(g["seed"]))
+    parts = pf.init_filter(torch.as_tensor(g["gt"]).to(dev), 1024)
+    pf.init_noise = keep
+    np.testing.assert_allclose(parts.poses.cpu().numpy(), g["poses"], rtol=0, atol=2e-6)
+    assert parts.weights.dtype == torch.float32 and float(parts.weights.sum()) == 1024
+
+
+def test_get_similarity_matches_reference_golden(dev, setup, golden):
+    from midastouch_amd.tactile_tree import tactile_tree
+    cfg, cb, pf, _ = setup
+    g = golden("g1_similarity")
+    for tag in ("a", "b"):
+        C, idx, q = g[f"{tag}_C"], g[f"{tag}_idx"], g[f"{tag}_q"]
+        qt = torch.as_tensor(q).double()[None].to(dev)
+        T = torch.as_tensor(C).double()[idx].to(dev)
+        w = pf.get_similarity(qt, T, softmax=True)  # plain (N, D) tensor, as the reference passes
+        assert w.dtype == torch.float64
+        np.testing.assert_allclose(w.cpu().numpy(), g[f"{tag}_w_softmax"], rtol=1e-12)
+        assert np.max(np.abs(w.cpu().numpy() - g[f"{tag}_w_softmax"])) < 1e-5
+        np.testing.assert_allclose(pf.get_similarity(qt, T, softmax=False).cpu().numpy(), g[f"{tag}_w_raw"], atol=1e-14)
+        # the NNCodes view and the heat-map view give the same numbers
+        K = C.shape[0]
+        poses = torch.eye(4)[None].repeat(K, 1, 1)
+        tr = tactile_tree(poses, poses, torch.as_tensor(C).double())
+        tr.to_device(dev)
+        from midastouch_amd.tactile_tree import NNCodes
+        w2 = pf.get_similarity(qt, NNCodes(tr, torch.as_tensor(idx).to(dev)), softmax=True)
+        np.testing.assert_allclose(w2.cpu().numpy(), g[f"{tag}_w_softmax"], rtol=1e-12)
+        heat = pf.get_similarity(qt, tr.get_embeddings(), softmax=False)
+        np.testing.assert_allclose(heat.cpu().numpy(), g[f"{tag}_heat"], atol=1e-14)
+    deg = pf.get_similarity(torch.as_tensor(g["a_q"]).double()[None].to(dev),
+                            torch.as_tensor(g["a_C"]).double()[[3] * 50].to(dev), softmax=True)
+    np.testing.assert_allclose(deg.cpu().numpy(), g["deg_w"], atol=1e-14)
+    one = pf.get_similarity(torch.as_tensor(g["a_q"]).double()[None].to(dev),
+                            torch.as_tensor(g["a_C"]).double()[[5]].to(dev), softmax=True)
+    assert one.shape == () and abs(float(one) - float(g["one_w"])) < 1e-14
+
+
+def test_resampler_matches_reference_golden_bit_exact(dev, setup, golden):
+    """pf.resampler under the reference's seed reproduces the reference's indices exactly."""
+    from midastouch_amd.particle_filter import Particles
+    cfg, cb, pf, tree = setup
+    g = golden("g2_resampler")
+    for tag in ["soft4096", "soft1000", "peaky2048", "masked3000", "n1", "n2", "n65"]:
+        n = len(g[f"{tag}_w"])
+        poses = torch.eye(4)[None].repeat(n, 1, 1).clone()
+        poses[:, 0, 3] = torch.arange(n, dtype=torch.float32)
+        for mode in ("weighted_random", "low_var"):
+            parts = Particles(poses.to(dev), torch.as_tensor(g[f"{tag}_w"]).to(dev), torch.arange(n, dtype=torch.float32).to(dev))
+            torch.manual_seed(int(g[f"{tag}_{mode}_seed"]))
+            out = pf.resampler(parts, resample=mode)
+            idx = out.poses[:, 0, 3].cpu().numpy().astype(np.int64)
+            assert np.array_equal(idx, g[f"{tag}_{mode}_idx"]), (tag, mode)
+            assert np.array_equal(out.labels.cpu().numpy().astype(np.int64), idx)
+            assert np.array_equal(out.weights.cpu().numpy(), g[f"{tag}_w"][idx])  # weights kept, not reset
+    # float32 weights, and the guards
+    parts = Particles(torch.eye(4)[None].repeat(500, 1, 1).to(dev), torch.as_tensor(g["f32_w"]).to(dev))
+    parts.poses[:, 0, 3] = torch.arange(500, dtype=torch.float32, device=dev)
+    torch.manual_seed(77)
+    out = pf.resampler(parts)
+    assert np.array_equal(out.poses[:, 0, 3].cpu().numpy().astype(np.int32), g["f32_weighted_random_idx"])
+    for w in (torch.zeros(10, dtype=torch.float64), torch.tensor([0.1, float("nan"), 0.3], dtype=torch.float64)):
+        parts = Particles(torch.eye(4)[None].repeat(len(w), 1, 1).to(dev), w.to(dev))
+        assert pf.resampler(parts).poses is parts.poses
+
+
+def test_remove_invalid_particles_in_place(dev, setup, golden):
+    from midastouch_amd.config import load_config
+    from midastouch_amd.particle_filter import Particles, particle_filter
+    g = golden("g4_prune")
+    pf = particle_filter(load_config(), g["verts"], 1.0, downsample=1, device=dev)
+    for tag in ("near", "far", "thr"):
+        pos = g[f"{tag}_pos"]
+        P = torch.eye(4)[None].repeat(len(pos), 1, 1).clone()
+        P[:, :3, 3] = torch.as_tensor(pos)
+        w = torch.as_tensor(g[f"{tag}_w_in"]).to(dev)
+        parts = Particles(P.to(dev), w)
+        thr = None if tag != "thr" else float(g["thr_thr"])
+        out, drifted = pf.remove_invalid_particles(parts, invalid_dist=thr)
+        assert out.weights is w  # mutated in place, like the reference (:401)
+        assert np.array_equal(w.cpu().numpy(), g[f"{tag}_w_out"])
+        assert bool(drifted) == bool(g[f"{tag}_drifted"])
+
+
+def test_annealing_matches_reference_golden(dev, setup, golden):
+    from midastouch_amd.config import load_config
+    from midastouch_amd.particle_filter import Particles, particle_filter
+    g = golden("g5_anneal")
+    for tag in ("shrink", "grow", "floor"):
+        pf = particle_filter(load_config(), np.zeros((4, 3)), 1.0, downsample=1, device=dev)
+        w0 = g[f"{tag}_w0"]
+        n = len(w0)
+        poses = torch.eye(4)[None].repeat(n, 1, 1).clone()
+        poses[:, 0, 3] = torch.arange(n, dtype=torch.float32)
+        parts = Particles(poses.to(dev), torch.as_tensor(w0).to(dev), torch.arange(n, dtype=torch.float32).to(dev))
+        for i, v in enumerate(g[f"{tag}_vars"]):
+            parts = pf.annealing(parts, torch.tensor(v), floor=int(g[f"{tag}_floor"]))
+            assert np.array_equal(parts.poses[:, 0, 3].cpu().numpy().astype(np.int32), g[f"{tag}_ids_{i}"]), (tag, i)
+
+
+def test_particle_rmse_and_se3_nn(dev, setup, oracle, golden):
+    from midastouch_amd.particle_filter import Particles, particle_rmse
+    cfg, cb, pf, tree = setup
+    g = golden("g6_rmse")
+    rt, rr = particle_rmse(Particles(torch.as_tensor(g["small_poses"]).to(dev)), torch.as_tensor(g["small_gt"]).to(dev))
+    assert float(rt) == pytest.approx(float(g["small_rmse_t"]), rel=1e-5)
+    assert float(rr) == pytest.approx(float(g["small_rmse_r"]), rel=1e-4, abs=0.03)
+    rng = np.random.default_rng(3)
+    q = cb.poses[rng.integers(0, cb.K, 800)].copy()
+    q[:, :3, 3] += rng.standard_normal((800, 3)).astype(np.float32) * 5e-4
+    p, c, codes = tree.SE3_NN(torch.as_tensor(q).to(dev))
+    idx = oracle.nn6(oracle.R3_SE3(q), oracle.R3_SE3(cb.poses))[0]
+    assert np.array_equal(codes.idx.cpu().numpy(), idx)
+    assert np.array_equal(p.cpu().numpy(), cb.poses[idx]) and np.array_equal(c.cpu().numpy(), cb.cam_poses[idx])
+    assert codes.shape == (800, 256) and codes.to_tensor().dtype == torch.float64
+    assert np.array_equal(codes.to_tensor().cpu().numpy(), cb.embeddings.astype(np.float64)[idx])
+    assert len(tree) == cb.K and tree.get_pose(5).shape == (4, 4) and tree.get_embedding(5).dtype == torch.float64
+
+
+def test_reference_loop_runs_and_tracks(dev):
+    """filter(): the reference's loop order end to end on a synthetic sequence; the estimate tracks."""
+    from midastouch_amd.config import load_config
+    from midastouch_amd.filter import filter as run_filter, synthetic_sequence
+    cfg = load_config(["expt.params.num_particles=3000", "expt.codebook_size=4000"])
+    seq = synthetic_sequence(cfg, dev, T=40)
+    torch.manual_seed(0)
+    stats = run_filter(cfg, seq=seq, device=dev)
+    for key in ("rmse_t", "rmse_r", "time", "traj_size", "avg_time", "total_time", "cluster_poses", "cluster_stds",
+                "obj_name", "tree_size", "noise_ratio", "init_noise", "init_particles", "num_particles", "log_id", "trial_id"):
+        assert key in stats
+    assert len(stats["rmse_t"]) == 40 and stats["tree_size"] == 4000
+    assert np.isfinite(stats["rmse_t"]).all()
+    # converged: the particle cloud ends within a few mm of the ground truth
+    assert stats["rmse_t"][-1] < 0.02
+    assert min(stats["num_particles"]) >= 1000

@@ -1,0 +1,88 @@
+"""The HIP backend of the particle-sharded frame: shards of ONE GPU stepped in lock-step must reproduce the
+fused single-engine frame of all particles bit for bit (kernels + shard offsets; the collectives themselves
+are covered by tests/test_dist_cpu.py under gloo).  Needs an MI355X."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda", 0)
+
+
+class FakeComm:
+    def __init__(self, r, w):
+        self.rank, self.world = r, w
+
+    def all_gather(self, t):
+        raise AssertionError("lock-step test never calls the communicator")
+
+
+@pytest.mark.parametrize("shards,mode", [(2, "weighted_random"), (3, "low_var"), (1, "weighted_random")])
+def test_sharded_hip_equals_fused_engine(dev, shards, mode):
+    from midastouch_amd.dist import HipShardBackend, ShardedFilterEngine, run_lockstep
+    from midastouch_amd.engine import FilterEngine
+    from midastouch_amd.synthetic import make_codebook, make_trajectory
+    n_loc, K, D = 4096 * 2, 4000, 256
+    N = shards * n_loc
+    cb = make_codebook(K=K, D=D, seed=1000)
+    traj = make_trajectory(cb, T=12, seed=2000)
+    rng = np.random.default_rng(0)
+    start = cb.poses[rng.integers(0, K, N)]
+    single = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, resample=mode, device=dev)
+    single.set_particles(torch.as_tensor(start))
+    single.project_to_codebook()
+    be = HipShardBackend(cb.poses, cb.embeddings, cb.mesh_vertices, dev)
+    engs = [ShardedFilterEngine(num_particles=n_loc, backend=be, comm=FakeComm(r, shards), resample=mode) for r in range(shards)]
+    for r, e in enumerate(engs):
+        e.set_particles(torch.as_tensor(start[r * n_loc:(r + 1) * n_loc]))
+        e.project_to_codebook()
+    for t in range(1, 10):
+        od, code, gt = (torch.as_tensor(a[t]).to(dev) for a in (traj.odoms, traj.codes, traj.gt_poses))
+        single.step(od, code, gt=gt)
+        run_lockstep(engs, [((od, code), {"gt": gt}) for _ in engs])
+        cat = lambda name: torch.cat([getattr(e, name) for e in engs]).cpu().numpy()
+        assert np.array_equal(cat("nn_idx"), single.nn_idx.cpu().numpy()), t
+        assert np.array_equal(cat("weights"), single.weights.cpu().numpy()), t
+        assert np.array_equal(cat("ridx"), single.ridx.cpu().numpy()), t
+        assert np.array_equal(cat("poses"), single.poses.cpu().numpy()), t
+        assert np.array_equal(cat("weights_res"), single.weights_res.cpu().numpy()), t
+        assert np.array_equal(cat("hint"), single.hint.cpu().numpy()), t
+        for e in engs:
+            assert np.array_equal(e.status.cpu().numpy(), single.status.cpu().numpy())
+            np.testing.assert_allclose(e.rmse.cpu().numpy(), single.rmse.cpu().numpy(), rtol=1e-12)
+
+
+def test_single_rank_process_group_nccl(dev):
+    """world_size 1 through torch.distributed's nccl (= RCCL) backend: the real communicator path."""
+    import os
+    import torch.distributed as dist
+    from midastouch_amd.dist import ShardedFilterEngine
+    from midastouch_amd.engine import FilterEngine
+    from midastouch_amd.synthetic import make_codebook, make_trajectory
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        n, K, D = 4096, 2000, 256
+        cb = make_codebook(K=K, D=D, seed=1000)
+        traj = make_trajectory(cb, T=6, seed=2000)
+        start = cb.poses[np.random.default_rng(0).integers(0, K, n)]
+        a = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, n, device=dev)
+        b = ShardedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, n, device=dev)
+        assert b.world == 1
+        for e in (a, b):
+            e.set_particles(torch.as_tensor(start))
+            e.project_to_codebook()
+        for t in range(1, 5):
+            od, code = torch.as_tensor(traj.odoms[t]).to(dev), torch.as_tensor(traj.codes[t]).to(dev)
+            a.step(od, code)
+            b.step(od, code)
+            assert torch.equal(a.ridx, b.ridx) and torch.equal(a.weights, b.weights) and torch.equal(a.poses, b.poses)
+    finally:
+        dist.destroy_process_group()
