@@ -145,7 +145,7 @@ def test_annealing_matches_reference_golden(dev, setup, golden):
         poses[:, 0, 3] = torch.arange(n, dtype=torch.float32)
         parts = Particles(poses.to(dev), torch.as_tensor(w0).to(dev), torch.arange(n, dtype=torch.float32).to(dev))
         for i, v in enumerate(g[f"{tag}_vars"]):
-            parts = pf.annealing(parts, torch.tensor(v), floor=int(g[f"{tag}_floor"]))
+            parts = pf.annealing(parts, torch.tensor(float(v)), floor=int(g[f"{tag}_floor"]))  # float32 scalar, as in the reference loop
             assert np.array_equal(parts.poses[:, 0, 3].cpu().numpy().astype(np.int32), g[f"{tag}_ids_{i}"]), (tag, i)
 
 
