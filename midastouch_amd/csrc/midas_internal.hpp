@@ -9,11 +9,12 @@
 
 namespace midas {
 
-// ---- KD-tree layouts (shared host/device) ------------------------------------------------------
-// Complete binary tree in 1-based heap order: node n has children 2n, 2n+1; the 2^L leaves are the
-// nodes [2^L, 2^(L+1)).  Every node (leaves included) stores the axis-aligned bounding box of its
-// points, so the two child boxes of node n are the 96 contiguous bytes boxes[2n], boxes[2n+1].
-// Leaf l owns the LEAF_CAP fixed point slots pts[l*LEAF_CAP ..); unused slots hold +inf coordinates.
+// ---- spatial index layouts (shared host/device) ------------------------------------------------
+// Complete 8-ary tree of axis-aligned boxes in 0-based heap order: node n has children 8n+1 .. 8n+8,
+// level l starts at id (8^l - 1)/7; the 8^L nodes of level L are leaves.  Every node stores the box of
+// its points, so the eight child boxes of a node are 384 contiguous bytes (one 48-byte box per lane of
+// an octet).  Leaf i owns the LEAF_CAP fixed point slots pts[i*LEAF_CAP ..); unused slots hold +inf
+// coordinates.  Built from balanced median splits (three binary splits per 8-ary level).
 struct alignas(16) Box6 { float lo[6], hi[6]; };
 struct alignas(16) Point6 { float c[6]; int32_t idx; int32_t pad; };
 struct alignas(16) Box3 { double lo[3], hi[3]; };
@@ -32,6 +33,9 @@ struct Kd3 {
     static constexpr int DIM = 3;
 };
 
+constexpr int LEAF_CAP = 16;      // point slots per leaf (two per lane of an octet)
+constexpr int KD_MAX_LEVELS = 10; // 8-ary levels (8^10 leaves x 16 slots is far beyond any codebook)
+
 // Neighbour record of the hint fast path (dim 6 only): entry k owns NBR_M records sorted by the
 // distance rho from F_k to that neighbour (rounded down), coordinates inlined so that one 32-byte
 // read is one candidate.  Unused records are sentinels (+inf coordinates, rho = +inf).
@@ -41,17 +45,15 @@ constexpr int NBR_REC = NBR_M + 1;  // record 0 = the entry itself
 
 template <class KD>
 struct TreeView {
-    const typename KD::Box* boxes;  // [2^(L+1)], entries 0 and 1 unused/root
-    const typename KD::Point* pts;  // [2^L * LEAF_CAP]
+    const typename KD::Box* boxes;  // [(8^(L+1) - 1)/7]
+    const typename KD::Point* pts;  // [8^L * LEAF_CAP]
     const int32_t* inv_perm;        // [K] original index -> slot in pts
     const Nbr6* nbrs;               // [K * NBR_REC] (dim 6) or nullptr
     const float* rho_out;           // [K] distance from F_k to its (NBR_M+1)-th neighbour, rounded down
-    int32_t levels;
+    int32_t levels;                 // L: number of 8-ary levels above the leaves
     int64_t K;
 };
 
-constexpr int LEAF_CAP = 8;     // point slots per leaf; leaves hold ceil(K / 2^L) <= 8 points
-constexpr int KD_MAX_LEVELS = 28;
 
 }  // namespace midas
 

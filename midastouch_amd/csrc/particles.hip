@@ -17,7 +17,7 @@
 namespace midas {
 
 // =================================================================================================
-// KD-tree: host build
+// spatial index: host build (balanced median splits, three binary splits per 8-ary level)
 // =================================================================================================
 template <class KD>
 struct HostTree {
@@ -26,15 +26,17 @@ struct HostTree {
     std::vector<int32_t> inv_perm;
     std::vector<Nbr6> nbrs;      // dim 6 only
     std::vector<float> rho_out;  // dim 6 only
-    int levels = 0;
+    int levels = 0;              // 8-ary levels
 };
 
+static inline int64_t level_offset(int l) { return (((int64_t)1 << (3 * l)) - 1) / 7; }
+
+// binary node `b` (1-based heap) at binary depth `depth`; every third depth is an 8-ary node
 template <class KD>
-static void build_rec(HostTree<KD>& t, const typename KD::T* P, std::vector<int32_t>& perm, uint32_t node, int64_t lo,
-                      int64_t hi, int level) {
+static void build_rec(HostTree<KD>& t, const typename KD::T* P, std::vector<int32_t>& perm, uint64_t b, int64_t lo,
+                      int64_t hi, int depth) {
     using T = typename KD::T;
     constexpr int DIM = KD::DIM;
-    // bounding box of this node's points (+inf/-inf when empty: its distance to any query is +inf)
     typename KD::Box bx;
     for (int d = 0; d < DIM; ++d) { bx.lo[d] = INFINITY; bx.hi[d] = -INFINITY; }
     for (int64_t i = lo; i < hi; ++i)
@@ -43,43 +45,46 @@ static void build_rec(HostTree<KD>& t, const typename KD::T* P, std::vector<int3
             bx.lo[d] = v < bx.lo[d] ? v : bx.lo[d];
             bx.hi[d] = v > bx.hi[d] ? v : bx.hi[d];
         }
-    t.boxes[node] = bx;
-    if (level == t.levels) {
-        const int64_t leaf = (int64_t)node - ((int64_t)1 << t.levels);
-        std::sort(perm.begin() + lo, perm.begin() + hi);
-        for (int64_t i = lo; i < hi; ++i) {
-            typename KD::Point p;
-            for (int d = 0; d < DIM; ++d) p.c[d] = P[(int64_t)perm[i] * DIM + d];
-            p.idx = perm[i];
-            if constexpr (DIM == 6) p.pad = 0;
-            const int64_t slot = leaf * LEAF_CAP + (i - lo);
-            t.pts[slot] = p;
-            t.inv_perm[perm[i]] = (int32_t)slot;
+    if (depth % 3 == 0) {
+        const int l = depth / 3;
+        const int64_t local = (int64_t)b - ((int64_t)1 << depth);
+        t.boxes[level_offset(l) + local] = bx;
+        if (l == t.levels) {
+            std::sort(perm.begin() + lo, perm.begin() + hi);
+            for (int64_t i = lo; i < hi; ++i) {
+                typename KD::Point p;
+                for (int d = 0; d < DIM; ++d) p.c[d] = P[(int64_t)perm[i] * DIM + d];
+                p.idx = perm[i];
+                if constexpr (DIM == 6) p.pad = 0;
+                const int64_t slot = local * LEAF_CAP + (i - lo);
+                t.pts[slot] = p;
+                t.inv_perm[perm[i]] = (int32_t)slot;
+            }
+            return;
         }
-        return;
     }
     int best_dim = 0;
     T best_spread = -1;
     for (int d = 0; d < DIM; ++d)
         if (bx.hi[d] - bx.lo[d] > best_spread) { best_spread = bx.hi[d] - bx.lo[d]; best_dim = d; }
     const int64_t mid = lo + (hi - lo + 1) / 2;
-    auto cmp = [&](int32_t a, int32_t b) {
-        T va = P[(int64_t)a * DIM + best_dim], vb = P[(int64_t)b * DIM + best_dim];
-        return va < vb || (va == vb && a < b);
+    auto cmp = [&](int32_t a, int32_t c) {
+        T va = P[(int64_t)a * DIM + best_dim], vc = P[(int64_t)c * DIM + best_dim];
+        return va < vc || (va == vc && a < c);
     };
     if (mid < hi) std::nth_element(perm.begin() + lo, perm.begin() + mid, perm.begin() + hi, cmp);
-    build_rec(t, P, perm, 2 * node, lo, mid, level + 1);
-    build_rec(t, P, perm, 2 * node + 1, mid, hi, level + 1);
+    build_rec(t, P, perm, 2 * b, lo, mid, depth + 1);
+    build_rec(t, P, perm, 2 * b + 1, mid, hi, depth + 1);
 }
 
 template <class KD>
 static HostTree<KD> build_tree(const typename KD::T* P, int64_t K) {
     HostTree<KD> t;
     int levels = 0;
-    while (((int64_t)LEAF_CAP << levels) < K) ++levels;
+    while ((((int64_t)LEAF_CAP) << (3 * levels)) < K) ++levels;
     t.levels = levels;
-    const int64_t nleaves = (int64_t)1 << levels;
-    t.boxes.resize(2 * nleaves);
+    const int64_t nleaves = (int64_t)1 << (3 * levels);
+    t.boxes.resize(level_offset(levels + 1) + 1);  // +1: the 64-byte unified fetch reads 16 bytes past a box
     typename KD::Point pad;
     for (int d = 0; d < KD::DIM; ++d) pad.c[d] = INFINITY;
     pad.idx = 0x7fffffff;
@@ -88,7 +93,6 @@ static HostTree<KD> build_tree(const typename KD::T* P, int64_t K) {
     t.inv_perm.resize(K);
     std::vector<int32_t> perm(K);
     std::iota(perm.begin(), perm.end(), 0);
-    t.boxes[0] = typename KD::Box();
     build_rec(t, P, perm, 1u, 0, K, 0);
     return t;
 }
@@ -110,10 +114,10 @@ double host_box_d2(const float* q, const Box6& b) {
     return d;
 }
 
-void knn_rec(const HostTree<Kd6>& t, const float* q, int32_t self, uint32_t node, std::vector<HeapItem>& heap, size_t k) {
-    const uint32_t first_leaf = 1u << t.levels;
-    if (node >= first_leaf) {
-        const Point6* lp = t.pts.data() + (size_t)(node - first_leaf) * LEAF_CAP;
+void knn_rec(const HostTree<Kd6>& t, const float* q, int32_t self, int64_t node, int level, std::vector<HeapItem>& heap,
+             size_t k) {
+    if (level == t.levels) {
+        const Point6* lp = t.pts.data() + (size_t)(node - level_offset(level)) * LEAF_CAP;
         for (int j = 0; j < LEAF_CAP; ++j) {
             if (lp[j].idx == 0x7fffffff || lp[j].idx == self) continue;
             double d = 0.0;
@@ -130,11 +134,11 @@ void knn_rec(const HostTree<Kd6>& t, const float* q, int32_t self, uint32_t node
         }
         return;
     }
-    const double dl = host_box_d2(q, t.boxes[2 * node]), dr = host_box_d2(q, t.boxes[2 * node + 1]);
-    const uint32_t near = dl <= dr ? 2 * node : 2 * node + 1, far = near ^ 1u;
-    const double dn = dl <= dr ? dl : dr, df = dl <= dr ? dr : dl;
-    if (heap.size() < k || dn <= heap.front().d) knn_rec(t, q, self, near, heap, k);
-    if (heap.size() < k || df <= heap.front().d) knn_rec(t, q, self, far, heap, k);
+    std::pair<double, int> order[8];
+    for (int j = 0; j < 8; ++j) order[j] = {host_box_d2(q, t.boxes[8 * node + 1 + j]), j};
+    std::sort(order, order + 8);
+    for (int j = 0; j < 8; ++j)
+        if (heap.size() < k || order[j].first <= heap.front().d) knn_rec(t, q, self, 8 * node + 1 + order[j].second, level + 1, heap, k);
 }
 
 inline float round_down_f32(double v) {
@@ -151,7 +155,7 @@ static void build_neighbour_graph(HostTree<Kd6>& t, const float* P, int64_t K) {
         std::vector<HeapItem> heap;
         for (int64_t k = k0; k < k1; ++k) {
             heap.clear();
-            knn_rec(t, P + k * 6, (int32_t)k, 1u, heap, (size_t)NBR_M + 1);
+            knn_rec(t, P + k * 6, (int32_t)k, 0, 0, heap, (size_t)NBR_M + 1);
             std::sort(heap.begin(), heap.end(), heap_less);
             {   // record 0 = the entry itself (rho 0): the scan needs no other lookup
                 Nbr6 r;
@@ -285,67 +289,177 @@ MD double box_dist2(const double* q, const Box3& b) {
     return d;
 }
 
-// Exact 1-NN, stack-free: `pending` has bit l set when the far child below the level-l node of the
-// current path may still hold a closer point; its box distance sits in fb[l*64] (LDS, one column per
-// lane).  Each loop iteration costs ONE round of global loads per lane (two child boxes, or the eight
-// point slots of a leaf), so a wave's time is the longest lane's chain, not a sum of per-phase maxima.
-// On entry (best_d, best_i) is a valid candidate or (+inf, 0); on exit the minimum of the spec distance
-// with ties resolved to the smallest original index.  EXISTS: stop at the first point with
-// d <= best_d (the entry bound) and return true.
+MD int64_t level_offset_dev(int l) { return (((int64_t)1 << (3 * l)) - 1) / 7; }
+
+// ---- octet-cooperative exact search ------------------------------------------------------------
+// Eight lanes (an octet) serve ONE query: at a node each lane tests one child box, at a leaf two point
+// slots.  The child distances of every level on the current path stay in an LDS column (cd[level][lane]),
+// so backtracking touches no memory; each loop iteration issues one round of global loads (a 48-byte box
+// or two 32-byte points per lane).  A wave therefore advances eight queries at a time and finishes a query
+// in ~(levels + a few) rounds instead of the ~13-level descents of a binary tree walked per lane.
+//
+// All state below is octet-uniform except the lane's own child distance.  `cand` packs, per level, the
+// 8-bit set of children still worth visiting.  Children are visited in order of box distance (3 low
+// mantissa bits replaced by the child number: that only orders the visits, pruning uses exact values).
+MD uint32_t octet_bits(bool pred, int octet) { return (uint32_t)((__ballot(pred) >> (8 * octet)) & 0xffull); }
+
+// Cross-lane moves inside an octet as DPP modifiers (no LDS round trip): lane^1, lane^2 (quad permutes)
+// and lane <-> 7-lane (row_half_mirror); applied in that order they form an 8-lane all-reduce butterfly.
+template <int CTRL>
+MD uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141;
+
+MD uint32_t octet_min(uint32_t v) {
+    uint32_t t = dpp_u32<DPP_XOR1>(v); v = t < v ? t : v;
+    t = dpp_u32<DPP_XOR2>(v); v = t < v ? t : v;
+    t = dpp_u32<DPP_HALF_MIRROR>(v); v = t < v ? t : v;
+    return v;
+}
+
+MD uint32_t order_key(float d, int j) { return (__float_as_uint(d) & ~7u) | (uint32_t)j; }
+MD uint32_t order_key(double d, int j) { return (__float_as_uint(__double2float_rd(d)) & ~7u) | (uint32_t)j; }
+
+template <int CTRL>
+MD void best_step(float& d, int64_t& i) {
+    const float od = __uint_as_float(dpp_u32<CTRL>(__float_as_uint(d)));
+    const int oi = (int)dpp_u32<CTRL>((uint32_t)(int)i);
+    if (od < d || (od == d && (int64_t)oi < i)) { d = od; i = oi; }
+}
+template <int CTRL>
+MD void best_step(double& d, int64_t& i) {  // mesh search: only the distance matters
+    const uint64_t b = (uint64_t)__double_as_longlong(d);
+    const uint64_t ob = ((uint64_t)dpp_u32<CTRL>((uint32_t)(b >> 32)) << 32) | dpp_u32<CTRL>((uint32_t)b);
+    const double od = __longlong_as_double((long long)ob);
+    if (od < d) d = od;
+    (void)i;
+}
+// butterfly minimum over the octet; for the 6-d tree with the tie rule (smaller index wins)
+template <typename T>
+MD void octet_best(T& d, int64_t& i) {
+    best_step<DPP_XOR1>(d, i);
+    best_step<DPP_XOR2>(d, i);
+    best_step<DPP_HALF_MIRROR>(d, i);
+}
+
+// One octet, one query.  `run` is octet-uniform; inactive octets fall through.  On entry (best, bi) is a
+// valid candidate or (+inf, 0); on exit the exact minimum of the spec distance, ties to the smallest index.
+// EXISTS: stop at the first point with d <= best (the entry bound); returns whether one was found.
 template <class KD, bool EXISTS, bool STATS = false>
-MD bool kd_search(const TreeView<KD>& tv, const typename KD::T* q, typename KD::T& best_d, int64_t& best_i,
-                  typename KD::T* fb, int* n_leaves = nullptr, int* n_nodes = nullptr) {
+MD bool octet_search(const TreeView<KD>& tv, const typename KD::T* q, typename KD::T& best, int64_t& bi, bool run,
+                     typename KD::T* cd, int* n_leaves = nullptr, int* n_nodes = nullptr) {
     using T = typename KD::T;
+    static_assert(sizeof(typename KD::Box) == 48 && sizeof(typename KD::Point) == 32, "64-byte unified fetch");
+    const int lane = threadIdx.x & 63, octet = lane >> 3, j = lane & 7;
     const int L = tv.levels;
-    const uint32_t first_leaf = 1u << L;
-    uint32_t node = 1u, pending = 0u;
+    const int64_t leaf0 = level_offset_dev(L);
+    int l = 0;
+    int64_t n = 0;
+    uint64_t cand = 0;
     bool found = false;
-    for (;;) {
-        bool back;
-        if (node < first_leaf) {
-            const typename KD::Box bl = tv.boxes[2u * node], br = tv.boxes[2u * node + 1u];
-            if (STATS) ++*n_nodes;
-            const T dl = box_dist2(q, bl), dr = box_dist2(q, br);
-            const bool left = dl <= dr;
-            const T dn = left ? dl : dr, df = left ? dr : dl;
-            const int lvl = 31 - __builtin_clz(node);
-            if (df <= best_d) {
-                pending |= 1u << lvl;
-                fb[lvl * 64] = df;
-            }
-            back = !(dn <= best_d);
-            if (!back) node = 2u * node + (left ? 0u : 1u);
-        } else {
-            const typename KD::Point* lp = tv.pts + (size_t)(node - first_leaf) * LEAF_CAP;
-            if (STATS) ++*n_leaves;
-#pragma unroll
-            for (int j = 0; j < LEAF_CAP; ++j) {
-                const typename KD::Point p = lp[j];
-                const T d = dist2(q, p);
+    bool enter = run && L > 0;   // fetch + test the children of n (level l)
+    bool leaf = run && L == 0;   // fetch + scan leaf n
+    while (__any(run)) {
+        // one fetch per iteration whatever the octet is doing: this lane's child box (48 B) or its two
+        // point slots (2 x 32 B) - 64 bytes from one base address, so a single wait covers both cases
+        const uint4* src = reinterpret_cast<const uint4*>(tv.boxes);
+        if (enter) src = reinterpret_cast<const uint4*>(tv.boxes + (8 * n + 1 + j));
+        if (leaf) src = reinterpret_cast<const uint4*>(tv.pts + (size_t)(n - leaf0) * LEAF_CAP + 2 * j);
+        uint4 r[4];
+        if (run && (enter || leaf)) { r[0] = src[0]; r[1] = src[1]; r[2] = src[2]; r[3] = src[3]; }
+        if (run) {
+            if (enter) {
+                typename KD::Box bx;
+                __builtin_memcpy(&bx, r, sizeof(bx));
+                const T d = box_dist2(q, bx);
+                cd[l * 64] = d;
+                if (STATS) ++*n_nodes;
+                const uint32_t m = octet_bits(d <= best, octet);
+                cand = (cand & ~(0xffull << (8 * l))) | ((uint64_t)m << (8 * l));
+                enter = false;
+            } else if (leaf) {
+                typename KD::Point p0, p1;
+                __builtin_memcpy(&p0, r, sizeof(p0));
+                __builtin_memcpy(&p1, r + 2, sizeof(p1));
+                if (STATS) ++*n_leaves;
+                T d0 = dist2(q, p0), d1 = dist2(q, p1);
+                int64_t i0 = p0.idx, i1 = p1.idx;
+                if (d1 < d0 || (d1 == d0 && i1 < i0)) { d0 = d1; i0 = i1; }
+                if (!(d0 == d0)) { d0 = INFINITY; i0 = 0x7fffffff; }  // NaN never wins
+                octet_best(d0, i0);
                 if (EXISTS) {
-                    if (d <= best_d) { best_d = d; best_i = p.idx; found = true; }
-                } else if (d < best_d || (d == best_d && (int64_t)p.idx < best_i)) {
-                    best_d = d;
-                    best_i = p.idx;
+                    if (d0 <= best) { best = d0; bi = i0; found = true; run = false; }
+                } else if (d0 < best || (d0 == best && i0 < bi)) {
+                    best = d0;
+                    bi = i0;
                 }
+                leaf = false;
+                if (L == 0) run = false;
+                else n = (n - 1) >> 3;  // back to the parent; l already points at it
             }
-            if (EXISTS && found) return true;
-            back = true;
         }
-        if (back) {
-            bool resumed = false;
-            while (pending) {
-                const int lvl = 31 - __builtin_clz(pending);
-                pending &= ~(1u << lvl);
-                if (fb[lvl * 64] <= best_d) {
-                    const int depth = 31 - __builtin_clz(node);
-                    node = (node >> (depth - lvl - 1)) ^ 1u;
-                    resumed = true;
-                    break;
-                }
+        if (run) {
+            // next child at level l: the nearest still-alive candidate
+            const T d = cd[l * 64];
+            const bool alive = ((cand >> (8 * l + j)) & 1ull) && (d <= best);
+            const uint32_t m = octet_bits(alive, octet);
+            if (m == 0) {
+                if (l == 0) run = false;
+                else { --l; n = (n - 1) >> 3; }
+            } else {
+                const uint32_t jm = octet_min(alive ? order_key(d, j) : 0xffffffffu) & 7u;
+                cand = (cand & ~(0xffull << (8 * l))) | ((uint64_t)(m & ~(1u << jm)) << (8 * l));
+                n = 8 * n + 1 + jm;
+                if (l + 1 == L) leaf = true;
+                else { ++l; enter = true; }
             }
-            if (!resumed) break;
         }
+    }
+    return found;
+}
+
+// Wave-level driver: lanes with `need` set get their query served by an octet, eight queries per round.
+template <class KD, bool EXISTS, bool STATS = false>
+MD bool wave_search(const TreeView<KD>& tv, const typename KD::T* q, typename KD::T& best, int64_t& bi, bool need,
+                    typename KD::T* cd_base, int* n_leaves = nullptr, int* n_nodes = nullptr) {
+    using T = typename KD::T;
+    constexpr int DIM = KD::DIM;
+    const int lane = threadIdx.x & 63, octet = lane >> 3;
+    uint64_t todo = __ballot(need);
+    bool found = false;
+    while (todo) {
+        // owner of this octet = the octet-th set bit of todo
+        uint64_t t = todo;
+        int owner = -1;
+        for (int k = 0; k <= octet && t; ++k) {
+            owner = k == octet ? (int)__builtin_ctzll(t) : -1;
+            t &= t - 1;
+        }
+        const bool active = owner >= 0;
+        const int src = active ? owner : lane;
+        T qq[DIM];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) qq[d] = __shfl(q[d], src);
+        T b = __shfl(best, src);
+        int64_t i = (int64_t)__shfl((long long)bi, src);
+        int nl = 0, nn = 0;
+        const bool f = octet_search<KD, EXISTS, STATS>(tv, qq, b, i, active, cd_base + lane, &nl, &nn);
+        // hand the result back to the owner lanes
+        const int rank = (int)__builtin_popcountll(todo & ((1ull << lane) - 1ull));
+        const bool served = ((todo >> lane) & 1ull) && rank < 8;
+        const int from = 8 * (rank < 8 ? rank : 0);
+        const T rb = __shfl(b, from);
+        const int64_t ri = (int64_t)__shfl((long long)i, from);
+        const int rf = __shfl((int)f, from);
+        const int rl = __shfl(nl, from), rn = __shfl(nn, from);
+        if (served) {
+            best = rb;
+            bi = ri;
+            found = rf != 0;
+            if (STATS) { *n_leaves += rl; *n_nodes += rn; }
+        }
+        for (int k = 0; k < 8 && todo; ++k) todo &= todo - 1;
     }
     return found;
 }
@@ -401,12 +515,16 @@ MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t h, float&
     return certified;
 }
 
-MD void nn6_query(const TreeView<Kd6>& tv, const float* q, int32_t hint, int32_t& idx, float& d2, float* fb) {
+// Wave-level NN: per-lane hint scan, then the octets serve the lanes it could not certify.
+// Must be called by every lane of the wave (`live` = this lane holds a query).
+template <bool STATS = false>
+MD void nn6_wave(const TreeView<Kd6>& tv, const float* q, bool live, int32_t hint, int32_t& idx, float& d2, float* cd,
+                 int* n_leaves = nullptr, int* n_nodes = nullptr, int* n_scanned = nullptr) {
     float best = INFINITY;
     int64_t bi = 0;
-    bool done = false;
-    if (hint >= 0 && (int64_t)hint < tv.K) done = nn6_hint_scan(tv, q, hint, best, bi, nullptr);
-    if (!done) kd_search<Kd6, false>(tv, q, best, bi, fb);
+    bool done = !live;
+    if (live && hint >= 0 && (int64_t)hint < tv.K) done = nn6_hint_scan(tv, q, hint, best, bi, n_scanned);
+    wave_search<Kd6, false, STATS>(tv, q, best, bi, !done, cd, n_leaves, n_nodes);
     idx = (int32_t)bi;
     d2 = best;
 }
@@ -474,52 +592,57 @@ __global__ __launch_bounds__(64) void k_feature(int64_t N, const float* __restri
 __global__ __launch_bounds__(64) void k_nn6(TreeView<Kd6> tv, int64_t N, const float* __restrict__ feat,
                                             const int32_t* __restrict__ hint, int32_t* __restrict__ idx,
                                             float* __restrict__ d2out) {
-    __shared__ float s_fb[KD_MAX_LEVELS * 64];
+    __shared__ float s_cd[KD_MAX_LEVELS * 64];
     const int64_t n = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (n >= N) return;
-    float q[6];
+    const bool live = n < N;
+    float q[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) q[j] = feat[n * 6 + j];
+        for (int j = 0; j < 6; ++j) q[j] = feat[n * 6 + j];
+    }
     int32_t bi;
     float bd;
-    nn6_query(tv, q, hint ? hint[n] : -1, bi, bd, s_fb + threadIdx.x);
-    idx[n] = bi;
-    if (d2out) d2out[n] = bd;
+    nn6_wave(tv, q, live, (live && hint) ? hint[n] : -1, bi, bd, s_cd);
+    if (live) {
+        idx[n] = bi;
+        if (d2out) d2out[n] = bd;
+    }
 }
 
-// diagnostic: leaves / nodes visited per query (tree tuning; same traversal as k_nn6)
+// diagnostic twin: per query, leaves / nodes visited by the octet search (0 / -(1 + records scanned) when the
+// hint scan certified the answer)
 __global__ __launch_bounds__(64) void k_nn6_stats(TreeView<Kd6> tv, int64_t N, const float* __restrict__ feat,
                                                   const int32_t* __restrict__ hint, int32_t* __restrict__ leaves,
                                                   int32_t* __restrict__ nodes) {
-    __shared__ float s_fb[KD_MAX_LEVELS * 64];
+    __shared__ float s_cd[KD_MAX_LEVELS * 64];
     const int64_t n = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (n >= N) return;
-    float q[6];
+    const bool live = n < N;
+    float q[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) q[j] = feat[n * 6 + j];
-    float best = INFINITY;
-    int64_t bi = 0;
-    const int32_t h = hint ? hint[n] : -1;
-    int nl = 0, nn = 0, ns = 0;
-    bool done = false;
-    if (h >= 0 && (int64_t)h < tv.K) done = nn6_hint_scan(tv, q, h, best, bi, &ns);
-    if (!done) kd_search<Kd6, false, true>(tv, q, best, bi, s_fb + threadIdx.x, &nl, &nn);
-    // certified lanes report 0 leaves and -(1 + neighbour records scanned)
-    if (done) nn = -(ns + 1);
-    leaves[n] = nl;
-    nodes[n] = nn;
+        for (int j = 0; j < 6; ++j) q[j] = feat[n * 6 + j];
+    }
+    int32_t bi;
+    float bd;
+    int nl = 0, nn = 0, ns = -1;
+    nn6_wave<true>(tv, q, live, (live && hint) ? hint[n] : -1, bi, bd, s_cd, &nl, &nn, &ns);
+    if (live) {
+        leaves[n] = nl;
+        nodes[n] = (nl == 0 && nn == 0 && ns >= 0) ? -(ns + 1) : nn;
+    }
 }
 
 __global__ __launch_bounds__(64) void k_nn3(TreeView<Kd3> tv, int64_t N, const float* __restrict__ poses,
                                             double* __restrict__ dist) {
-    __shared__ double s_fb[KD_MAX_LEVELS * 64];
+    __shared__ double s_cd[KD_MAX_LEVELS * 64];
     const int64_t n = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (n >= N) return;
-    double q[3] = {(double)poses[n * 16 + 3], (double)poses[n * 16 + 7], (double)poses[n * 16 + 11]};
+    const bool live = n < N;
+    double q[3] = {0.0, 0.0, 0.0};
+    if (live) { q[0] = (double)poses[n * 16 + 3]; q[1] = (double)poses[n * 16 + 7]; q[2] = (double)poses[n * 16 + 11]; }
     double best = INFINITY;
     int64_t bi = 0;
-    kd_search<Kd3, false>(tv, q, best, bi, s_fb + threadIdx.x);
-    dist[n] = __builtin_sqrt(best);
+    wave_search<Kd3, false>(tv, q, best, bi, live, s_cd);
+    if (live) dist[n] = __builtin_sqrt(best);
 }
 
 // check_quats (modules/particle_filter.py:347-357): flag poses whose rotation yields a NaN or
@@ -617,35 +740,40 @@ __global__ __launch_bounds__(256) void k_rmse_final(int64_t N, int nb, const dou
 // fused particle update of the step
 // =================================================================================================
 __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a) {
-    __shared__ double s_fb[KD_MAX_LEVELS * 64];  // far-bound columns, reused by both searches
+    __shared__ double s_cd[KD_MAX_LEVELS * 64];  // child-distance columns, reused by both searches
     const int64_t n = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool live = n < a.N;
     double x = 0.0, et2 = 0.0, ang2 = 0.0;
+    float R[16], f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) R[i] = 0.f;
     if (live) {
-        float P[16], O[16], R[16];
+        float P[16], O[16];
         load_pose(a.poses_in + n * 16, P);
 #pragma unroll
         for (int i = 0; i < 16; ++i) O[i] = a.odom16[i];
         propagate_one(n, n + a.slot_base, P, O, a.tn, a.rot, a.std_t, a.std_r, a.seed, a.step, R);
         store_pose(a.poses_prop + n * 16, R);
-        float f[6];
         se3_feature(R, 0.99f, 0.01f, f);
-        int32_t bi;
-        float bd;
-        if (a.ablate & 1) {  // profiling only: trust the hint
-            bi = a.hint_in ? a.hint_in[n] : 0;
-            bi = bi < 0 ? 0 : bi;
-        } else {
-            nn6_query(t6, f, a.hint_in ? a.hint_in[n] : -1, bi, bd, reinterpret_cast<float*>(s_fb) + threadIdx.x);
-        }
+    }
+    // nearest codebook entry
+    int32_t bi = 0;
+    float bd;
+    const int32_t hint = (live && a.hint_in) ? a.hint_in[n] : -1;
+    if (a.ablate & 1) {  // profiling only: trust the hint
+        bi = hint < 0 ? 0 : hint;
+    } else {
+        nn6_wave(t6, f, live, hint, bi, bd, reinterpret_cast<float*>(s_cd));
+    }
+    // prune: valid <=> some mesh vertex within sqrt(t2) of the particle
+    double q3[3] = {(double)R[3], (double)R[7], (double)R[11]};
+    double best = a.t2;
+    int64_t vi = 0;
+    const bool ok = (a.ablate & 2) ? true : wave_search<Kd3, true>(t3, q3, best, vi, live, s_cd);
+    if (live) {
         a.nn_idx[n] = bi;
         x = a.scores[bi];
         a.x[n] = x;
-        // prune: valid <=> some mesh vertex within sqrt(t2)
-        double q3[3] = {(double)R[3], (double)R[7], (double)R[11]};
-        double best = a.t2;
-        int64_t vi = 0;
-        const bool ok = (a.ablate & 2) ? true : kd_search<Kd3, true>(t3, q3, best, vi, s_fb + threadIdx.x);
         a.valid[n] = ok ? 1 : 0;
         if (a.gt16) {
             float G[16];

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Small driver for rocprofv3: a few launches of the step and of the standalone NN kernel on a realistic state."""
+"""Small driver for rocprofv3: the standalone NN kernel (no hint / real hints) on a realistic particle state."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,12 +18,12 @@ near = np.argsort(d0)[: max(64, K // 20)]
 eng.set_particles(torch.as_tensor(cb.poses[rng.choice(near, N)]))
 eng.project_to_codebook()
 odoms, codes = torch.as_tensor(traj.odoms).to(dev), torch.as_tensor(traj.codes).to(dev)
-for t in range(1, 25):
+for t in range(1, 12):
     eng.step(odoms[t], codes[t])
 feat = ops.se3_feature(eng.poses_prop)
-hint = eng.nn_idx.clone()
-for _ in range(3):
-    ops.nn6(eng.tree6, feat, hint)
-    ops.nn6(eng.tree6, feat, None)
-    ops.nn3_dist(eng.tree3, eng.poses_prop)
+hint = eng.hint_next.clone()
+torch.cuda.synchronize()
+ops.nn6(eng.tree6, feat, None)
+ops.nn6(eng.tree6, feat, hint)
+ops.nn3_dist(eng.tree3, eng.poses_prop)
 torch.cuda.synchronize()
