@@ -145,6 +145,8 @@ def main():
         dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
     status = eng.status.cpu().numpy().tolist()
+    tele = (eng.telemetry if world == 1 else eng.st.telemetry).cpu().numpy().tolist()
+    frames_run = args.warmup + args.steps
 
     ab = algorithmic_bytes(N, K, D)
     out = {
@@ -156,7 +158,8 @@ def main():
                                "device Philox draws, multinomial resample" % (N, K, D),
                    "particles_per_gpu": N, "particles_total": N * world, "codebook_rows": K, "embedding_dim": D,
                    "parallelism": "single" if world == 1 else "particle-sharded x%d" % world,
-                   "arith": "f32 poses/NN, f64 scores/weights/CDF", "last_status": status},
+                   "arith": "f32 poses/NN, f64 scores/weights/CDF", "last_status": status,
+                   "tree_search_fallbacks_per_frame": {"nn": tele[0] / frames_run, "prune": tele[1] / frames_run}},
     }
 
     # per-kernel HIP-event timing (separate pass so the events do not perturb the headline)
@@ -170,7 +173,7 @@ def main():
         eng.profile(False)
         per = {k: v / calls for k, v in ms.items()}
         groups = {"score_codebook": per["score_codebook"], "particle_update": per["particle_update"],
-                  "tail": per["tail_exp"] + per["tail_scan"] + per["tail_cdf"] + per["tail_resample"]}
+                  "tail": per["tail_a"] + per["tail_b"]}
         dom = max(("score_codebook", "particle_update"), key=lambda k: groups[k])
         achieved = ab[dom] / (groups[dom] * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -73,6 +73,11 @@ int midas_se3_feature(midas_ctx* ctx, int64_t N, const float* poses_dev, float w
  * sklearn KDTree, modules/particle_filter.py:108-110).  Synchronous (built on the host once). */
 int midas_tree_build(midas_ctx* ctx, int32_t dim, int64_t K, const void* points_dev, midas_tree** out);
 int midas_tree_destroy(midas_tree* tree);
+/* Optional accelerator of the fused step's prune: for every codebook entry, the mesh vertices nearest to
+ * its translation (cb_poses_dev: K x 16 float32), so that most particles are classified from the list of
+ * their NN entry with the same exact predicate and only the rest search the mesh tree.  Synchronous. */
+int midas_tree_attach_mesh(midas_ctx* ctx, midas_tree* tree6, const midas_tree* tree3,
+                           const float* cb_poses_dev);
 /* idx[n] = argmin_k |feat6[n] - F_k|^2 (ties -> smallest k); hint_dev (nullable) = a candidate index
  * per query that seeds the search bound; d2_dev nullable.  Replaces kneighbors (tactile_tree.py:50-52). */
 int midas_nn6(midas_ctx* ctx, const midas_tree* tree, int64_t N, const float* feat6_dev,
@@ -160,6 +165,7 @@ typedef struct midas_step_args {
     int32_t softmax;
     int32_t resample_mode;
     int32_t* status_dev;         /* [0] cdf status (see midas_cdf), [1] particles kept by the prune */
+    uint64_t* telemetry_dev;     /* NULL or 2 cumulative counters: particles whose NN / prune needed the tree search */
 } midas_step_args;
 
 int midas_filter_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
@@ -191,22 +197,25 @@ typedef struct midas_shard_update_args {
     float std_t, std_r;
     uint64_t seed, step;
     double prune_thr;
+    uint64_t* telemetry_dev;    /* NULL or 2 cumulative counters (see midas_step_args) */
+    int32_t* status_dev;        /* 2: zeroed here, filled by midas_tail_a / midas_tail_fin */
 } midas_shard_update_args;
 /* score codebook + propagate + feature + NN + prune + score gather for the local particles */
 int midas_shard_update(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
                        const midas_tree* tree3, const midas_shard_update_args* args);
-/* e = exp(x - max(pmax_all)) (or x when the softmax is skipped) ; block_sums[b] for the local blocks ;
- * flag[0] = softmax applied ; status[0..1] reset */
-int midas_tail_exp(midas_ctx* ctx, int64_t N, const double* x_dev, int32_t np, const double* pmax_all_dev,
-                   const double* pmin_all_dev, int32_t softmax, double* e_dev, double* block_sums_dev,
-                   int32_t* flag_dev, int32_t* status_dev);
-/* w = e / sum(block_sums_all) * valid (in place) ; lp = block-local prefix ; block_totals for the local blocks */
-int midas_tail_scan(midas_ctx* ctx, int64_t N, double* w_dev, const uint8_t* valid_dev, int32_t nb_all,
-                    const double* block_sums_all_dev, const int32_t* flag_dev, double* lp_dev,
-                    double* block_totals_dev, int32_t* status_dev);
-/* cdf = (BP + lp) / total in place, BP/total from block_totals_all ; is_last forces the final slot to 1 */
-int midas_tail_cdf(midas_ctx* ctx, int64_t N, double* cdf_dev, int32_t nb_all,
-                   const double* block_totals_all_dev, int32_t block_base, int32_t is_last, int32_t* status_dev);
+/* e = exp(x - max(pmax_all)) (or x when the softmax is skipped) -> e ; lp = block-local prefix (fixed order) of
+ * e * valid ; block_sums / block_totals = the local 4096-slot block totals of e and of e * valid ;
+ * flag[0] = softmax applied ; status[0] = 2 on NaN, status[1] = particles kept */
+int midas_tail_a(midas_ctx* ctx, int64_t N, const double* x_dev, const uint8_t* valid_dev, int32_t np,
+                 const double* pmax_all_dev, const double* pmin_all_dev, int32_t softmax, double* e_dev,
+                 double* lp_dev, double* block_sums_dev, double* block_totals_dev, int32_t* flag_dev,
+                 int32_t* status_dev);
+/* weights = e / sum(block_sums_all) * valid ; cdf = (BP + lp) / total in place, BP / total summed sequentially
+ * over block_totals_all ; is_last forces the final slot to 1 ; status[0] |= 1 when the total is zero */
+int midas_tail_fin(midas_ctx* ctx, int64_t N, const double* e_dev, const uint8_t* valid_dev, double* weights_dev,
+                   double* cdf_dev, int32_t nb_all, const double* block_sums_all_dev,
+                   const double* block_totals_all_dev, int32_t block_base, int32_t is_last,
+                   const int32_t* flag_dev, int32_t* status_dev);
 typedef struct midas_tail_resample_args {
     int64_t N, N_all, slot_base;
     const double* cdf_all_dev;      /* N_all */

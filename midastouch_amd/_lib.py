@@ -53,6 +53,7 @@ class StepArgs(C.Structure):
         ("softmax", C.c_int32),
         ("resample_mode", C.c_int32),
         ("status", C.c_void_p),
+        ("telemetry", C.c_void_p),
     ]
 
 
@@ -66,6 +67,8 @@ class ShardUpdateArgs(C.Structure):
         ("code", C.c_void_p), ("gt16", C.c_void_p), ("rmse_sums", C.c_void_p), ("tn", C.c_void_p), ("rot", C.c_void_p),
         ("std_t", C.c_float), ("std_r", C.c_float), ("seed", C.c_uint64), ("step", C.c_uint64),
         ("prune_thr", C.c_double),
+        ("telemetry", C.c_void_p),
+        ("status", C.c_void_p),
     ]
 
 
@@ -97,6 +100,7 @@ SIGNATURES = {
     "midas_se3_feature": (C.c_int, [_P, _I64, _P, _F, _P]),
     "midas_tree_build": (C.c_int, [_P, _I32, _I64, _P, C.POINTER(_P)]),
     "midas_tree_destroy": (C.c_int, [_P]),
+    "midas_tree_attach_mesh": (C.c_int, [_P, _P, _P, _P]),
     "midas_nn6": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P]),
     "midas_nn6_stats": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P]),
     "midas_nn3": (C.c_int, [_P, _P, _I64, _P, _P]),
@@ -111,9 +115,8 @@ SIGNATURES = {
     "midas_rmse": (C.c_int, [_P, _I64, _P, _P, _P]),
     "midas_filter_step": (C.c_int, [_P, _P, _P, _P, C.POINTER(StepArgs)]),
     "midas_shard_update": (C.c_int, [_P, _P, _P, _P, C.POINTER(ShardUpdateArgs)]),
-    "midas_tail_exp": (C.c_int, [_P, _I64, _P, _I32, _P, _P, _I32, _P, _P, _P, _P]),
-    "midas_tail_scan": (C.c_int, [_P, _I64, _P, _P, _I32, _P, _P, _P, _P, _P]),
-    "midas_tail_cdf": (C.c_int, [_P, _I64, _P, _I32, _P, _I32, _I32, _P]),
+    "midas_tail_a": (C.c_int, [_P, _I64, _P, _P, _I32, _P, _P, _I32, _P, _P, _P, _P, _P, _P]),
+    "midas_tail_fin": (C.c_int, [_P, _I64, _P, _P, _P, _P, _I32, _P, _P, _I32, _I32, _P, _P]),
     "midas_tail_resample": (C.c_int, [_P, C.POINTER(TailResampleArgs)]),
     "midas_profile_enable": (C.c_int, [_P, _I32]),
     "midas_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64), _I32]),

@@ -10,6 +10,8 @@ using namespace midas;
 
 namespace midas {
 int tree_build_impl(midas_ctx* ctx, int32_t dim, int64_t K, const void* points_dev, midas_tree* out);
+int attach_mesh_impl(midas_ctx* ctx, midas_tree* t6, const midas_tree* t3, const float* cb_poses_dev);
+void tree_free_host(midas_tree* t);
 }
 
 // ---- scratch: bump allocator over library-owned device chunks, reset at every API entry ----------
@@ -67,7 +69,7 @@ void prof_mark(midas_ctx* ctx, int slot) {
 }  // namespace midas
 
 static const char* kSlotNames[MIDAS_PROF_SLOTS] = {
-    "score_codebook", "particle_update", "tail_exp", "tail_scan", "tail_cdf", "tail_resample", "", ""};
+    "score_codebook", "particle_update", "tail_a", "tail_b", "", "", "", ""};
 
 // entry guard: bind the device, reset the scratch bump pointer
 #define MIDAS_ENTER(ctx)                                                     \
@@ -200,6 +202,13 @@ MIDAS_EXPORT int midas_tree_build(midas_ctx* ctx, int32_t dim, int64_t K, const 
     return MIDAS_OK;
 }
 
+MIDAS_EXPORT int midas_tree_attach_mesh(midas_ctx* ctx, midas_tree* tree6, const midas_tree* tree3,
+                                        const float* cb_poses_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, tree6 && tree3 && cb_poses_dev && tree6->dim == 6 && tree3->dim == 3);
+    return attach_mesh_impl(ctx, tree6, tree3, cb_poses_dev);
+}
+
 MIDAS_EXPORT int midas_tree_destroy(midas_tree* t) {
     if (!t) return MIDAS_OK;
     (void)hipStreamSynchronize(t->ctx->stream);
@@ -208,6 +217,8 @@ MIDAS_EXPORT int midas_tree_destroy(midas_tree* t) {
     if (t->inv_perm) (void)hipFree(t->inv_perm);
     if (t->nbrs) (void)hipFree(t->nbrs);
     if (t->rho_out) (void)hipFree(t->rho_out);
+    if (t->vlist) (void)hipFree(t->vlist);
+    tree_free_host(t);
     delete t;
     return MIDAS_OK;
 }
@@ -354,6 +365,10 @@ MIDAS_EXPORT int midas_filter_step(midas_ctx* ctx, const midas_codebook* cb, con
     pa.x = (double*)x;
     pa.valid = (uint8_t*)valid;
     pa.t2 = squared_threshold(s.prune_thr);
+    pa.thr = s.prune_thr;
+    pa.vlist = (tree6->vlist && tree6->vlist_mesh == tree3) ? (const MeshRec*)tree6->vlist : nullptr;
+    pa.telemetry = (unsigned long long*)s.telemetry_dev;
+    pa.status_reset = s.status_dev;
     pa.part_max = (double*)pmax;
     pa.part_min = (double*)pmin;
     pa.gt16 = prm ? s.gt16_dev : nullptr;
@@ -388,8 +403,8 @@ MIDAS_EXPORT int midas_filter_step(midas_ctx* ctx, const midas_codebook* cb, con
     if ((rc = launch_step_tail(ctx, ta, 2))) return rc;
 
     if (ctx->prof && ctx->ev_ready) {
-        MIDAS_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev[6]));
-        for (int i = 0; i < 6; ++i) {
+        MIDAS_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev[4]));
+        for (int i = 0; i < 4; ++i) {
             float ms = 0.f;
             MIDAS_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
             ctx->prof_ms[i] += (double)ms;
@@ -436,6 +451,10 @@ MIDAS_EXPORT int midas_shard_update(midas_ctx* ctx, const midas_codebook* cb, co
     pa.x = s.x_dev;
     pa.valid = s.valid_dev;
     pa.t2 = squared_threshold(s.prune_thr);
+    pa.thr = s.prune_thr;
+    pa.vlist = (tree6->vlist && tree6->vlist_mesh == tree3) ? (const MeshRec*)tree6->vlist : nullptr;
+    pa.telemetry = (unsigned long long*)s.telemetry_dev;
+    pa.status_reset = s.status_dev;
     pa.part_max = (double*)pmax;
     pa.part_min = (double*)pmin;
     pa.gt16 = prm ? s.gt16_dev : nullptr;
@@ -445,28 +464,26 @@ MIDAS_EXPORT int midas_shard_update(midas_ctx* ctx, const midas_codebook* cb, co
                                   prm ? s.rmse_sums_dev : nullptr);
 }
 
-MIDAS_EXPORT int midas_tail_exp(midas_ctx* ctx, int64_t N, const double* x_dev, int32_t np, const double* pmax_all_dev,
-                                const double* pmin_all_dev, int32_t softmax, double* e_dev, double* block_sums_dev,
-                                int32_t* flag_dev, int32_t* status_dev) {
+MIDAS_EXPORT int midas_tail_a(midas_ctx* ctx, int64_t N, const double* x_dev, const uint8_t* valid_dev, int32_t np,
+                              const double* pmax_all_dev, const double* pmin_all_dev, int32_t softmax, double* e_dev,
+                              double* lp_dev, double* block_sums_dev, double* block_totals_dev, int32_t* flag_dev,
+                              int32_t* status_dev) {
     MIDAS_ENTER(ctx);
-    MIDAS_REQUIRE(ctx, N > 0 && np > 0 && x_dev && pmax_all_dev && pmin_all_dev && e_dev && block_sums_dev && flag_dev && status_dev);
-    return launch_tail_exp(ctx, N, x_dev, np, pmax_all_dev, pmin_all_dev, softmax, e_dev, block_sums_dev, flag_dev, status_dev);
+    MIDAS_REQUIRE(ctx, N > 0 && np > 0 && x_dev && valid_dev && pmax_all_dev && pmin_all_dev && e_dev && lp_dev &&
+                           block_sums_dev && block_totals_dev && flag_dev && status_dev);
+    return launch_tail_a(ctx, N, x_dev, valid_dev, np, pmax_all_dev, pmin_all_dev, softmax, e_dev, lp_dev, block_sums_dev,
+                         block_totals_dev, flag_dev, status_dev);
 }
 
-MIDAS_EXPORT int midas_tail_scan(midas_ctx* ctx, int64_t N, double* w_dev, const uint8_t* valid_dev, int32_t nb_all,
-                                 const double* block_sums_all_dev, const int32_t* flag_dev, double* lp_dev,
-                                 double* block_totals_dev, int32_t* status_dev) {
-    MIDAS_ENTER(ctx);
-    MIDAS_REQUIRE(ctx, N > 0 && nb_all > 0 && w_dev && valid_dev && block_sums_all_dev && flag_dev && lp_dev && block_totals_dev && status_dev);
-    return launch_tail_scan(ctx, N, w_dev, valid_dev, nb_all, block_sums_all_dev, flag_dev, lp_dev, block_totals_dev, status_dev);
-}
-
-MIDAS_EXPORT int midas_tail_cdf(midas_ctx* ctx, int64_t N, double* cdf_dev, int32_t nb_all,
+MIDAS_EXPORT int midas_tail_fin(midas_ctx* ctx, int64_t N, const double* e_dev, const uint8_t* valid_dev, double* weights_dev,
+                                double* cdf_dev, int32_t nb_all, const double* block_sums_all_dev,
                                 const double* block_totals_all_dev, int32_t block_base, int32_t is_last,
-                                int32_t* status_dev) {
+                                const int32_t* flag_dev, int32_t* status_dev) {
     MIDAS_ENTER(ctx);
-    MIDAS_REQUIRE(ctx, N > 0 && nb_all > 0 && block_base >= 0 && cdf_dev && block_totals_all_dev && status_dev);
-    return launch_tail_cdf(ctx, N, cdf_dev, nb_all, block_totals_all_dev, block_base, is_last, status_dev);
+    MIDAS_REQUIRE(ctx, N > 0 && nb_all > 0 && block_base >= 0 && e_dev && valid_dev && weights_dev && cdf_dev &&
+                           block_sums_all_dev && block_totals_all_dev && flag_dev && status_dev);
+    return launch_tail_fin(ctx, N, e_dev, valid_dev, weights_dev, cdf_dev, nb_all, block_sums_all_dev, block_totals_all_dev,
+                           block_base, is_last, flag_dev, status_dev);
 }
 
 MIDAS_EXPORT int midas_tail_resample(midas_ctx* ctx, const midas_tail_resample_args* args) {

@@ -40,8 +40,14 @@ constexpr int KD_MAX_LEVELS = 10; // 8-ary levels (8^10 leaves x 16 slots is far
 // distance rho from F_k to that neighbour (rounded down), coordinates inlined so that one 32-byte
 // read is one candidate.  Unused records are sentinels (+inf coordinates, rho = +inf).
 struct alignas(16) Nbr6 { float c[6]; int32_t idx; float rho; };
-constexpr int NBR_M = 32;
+constexpr int NBR_M = 64;
 constexpr int NBR_REC = NBR_M + 1;  // record 0 = the entry itself
+
+// Mesh-vertex record of the prune fast path: the vertices nearest to a codebook entry's translation.
+struct alignas(16) MeshRec { double c[3]; float rho; int32_t pad; };
+constexpr int MESH_M = 64;
+constexpr int MESH_REC = MESH_M + 1;  // record 0 = header: c = the entry's translation, rho = distance of the
+                                      // first vertex NOT in the list
 
 template <class KD>
 struct TreeView {
@@ -93,6 +99,9 @@ struct midas_tree {
     int32_t* inv_perm;
     void* nbrs;      // Nbr6[K * NBR_REC] (dim 6)
     float* rho_out;  // [K] (dim 6)
+    void* vlist;     // MeshRec[K * MESH_REC] (dim 6, after midas_tree_attach_mesh)
+    const midas_tree* vlist_mesh;  // the mesh tree the lists were built from
+    void* host;      // host copy of the tree (dim 3: used to build the lists)
 };
 
 // ---- error helpers ----------------------------------------------------------------------------
@@ -153,11 +162,15 @@ struct ParticleUpdateArgs {
     double* x;             // [N] gathered score
     uint8_t* valid;        // [N] prune mask
     double t2;             // squared prune threshold (exact: sqrt(d2) > thr  <=>  d2 > t2)
+    double thr;            // the threshold itself (triangle-inequality tests of the vertex lists)
+    const MeshRec* vlist;  // nullable: per-codebook-entry mesh vertex lists
     double* part_max;      // [nblocks]
     double* part_min;      // [nblocks]
     const float* gt16;     // nullable
     double* part_rmse;     // [2*nblocks] when gt16
     int ablate = 0;        // profiling only (MIDAS_ABLATE)
+    unsigned long long* telemetry = nullptr;  // nullable: cumulative [NN tree searches, mesh tree searches]
+    int32_t* status_reset = nullptr;          // nullable: status[0..1] zeroed here for the tail kernels' atomics
 };
 int particle_update_blocks(int64_t N);
 int launch_particle_update(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t3, const ParticleUpdateArgs& a);
@@ -196,12 +209,12 @@ struct StepTailArgs {
     double* rmse_out;
 };
 int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base);
-int launch_tail_exp(midas_ctx* ctx, int64_t N, const double* x, int np, const double* pmax_all, const double* pmin_all,
-                    int32_t softmax, double* e_out, double* block_sums, int32_t* flag, int32_t* status);
-int launch_tail_scan(midas_ctx* ctx, int64_t N, double* w_io, const uint8_t* valid, int nb_all, const double* block_sums_all,
-                     const int32_t* flag, double* lp_out, double* block_totals, int32_t* status);
-int launch_tail_cdf(midas_ctx* ctx, int64_t N, double* cdf_io, int nb_all, const double* block_totals_all, int block_base,
-                    int32_t is_last, int32_t* status);
+int launch_tail_a(midas_ctx* ctx, int64_t N, const double* x, const uint8_t* valid, int np, const double* pmax_all,
+                  const double* pmin_all, int32_t softmax, double* e_out, double* lp_out, double* block_sums_e,
+                  double* block_totals_em, int32_t* flag, int32_t* status);
+int launch_tail_fin(midas_ctx* ctx, int64_t N, const double* e, const uint8_t* valid, double* weights, double* cdf_io,
+                    int nb_all, const double* block_sums_all, const double* block_totals_all, int block_base,
+                    int32_t is_last, const int32_t* flag, int32_t* status);
 int launch_tail_resample(midas_ctx* ctx, const midas_tail_resample_args& r, const double* part_rmse, int nrm,
                          double rmse_count, double* rmse_out);
 int launch_reduce_partials(midas_ctx* ctx, int np, const double* pmax, const double* pmin, const double* prm,

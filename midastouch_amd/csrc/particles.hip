@@ -101,28 +101,31 @@ static HostTree<KD> build_tree(const typename KD::T* P, int64_t K) {
 // For every entry k: its NBR_M nearest other entries sorted by (distance, index), float64 distances,
 // rho rounded DOWN to float32 so that it never over-states a true distance.
 namespace {
-struct HeapItem { double d; int32_t idx; };
+struct HeapItem { double d; int64_t idx; };
 inline bool heap_less(const HeapItem& a, const HeapItem& b) { return a.d < b.d || (a.d == b.d && a.idx < b.idx); }
 
-double host_box_d2(const float* q, const Box6& b) {
+template <class KD>
+double host_box_d2(const double* q, const typename KD::Box& b) {
     double d = 0.0;
-    for (int j = 0; j < 6; ++j) {
-        double a = (double)b.lo[j] - (double)q[j], c = (double)q[j] - (double)b.hi[j];
+    for (int j = 0; j < KD::DIM; ++j) {
+        double a = (double)b.lo[j] - q[j], c = q[j] - (double)b.hi[j];
         double m = a > c ? a : c;
         if (m > 0) d += m * m;
     }
     return d;
 }
 
-void knn_rec(const HostTree<Kd6>& t, const float* q, int32_t self, int64_t node, int level, std::vector<HeapItem>& heap,
+// k nearest points of q (float64 distances), excluding original index `self` (-1: none)
+template <class KD>
+void knn_rec(const HostTree<KD>& t, const double* q, int64_t self, int64_t node, int level, std::vector<HeapItem>& heap,
              size_t k) {
     if (level == t.levels) {
-        const Point6* lp = t.pts.data() + (size_t)(node - level_offset(level)) * LEAF_CAP;
+        const typename KD::Point* lp = t.pts.data() + (size_t)(node - level_offset(level)) * LEAF_CAP;
         for (int j = 0; j < LEAF_CAP; ++j) {
-            if (lp[j].idx == 0x7fffffff || lp[j].idx == self) continue;
+            if (lp[j].idx == 0x7fffffff || (int64_t)lp[j].idx == self) continue;
             double d = 0.0;
-            for (int a = 0; a < 6; ++a) { double x = (double)q[a] - (double)lp[j].c[a]; d += x * x; }
-            HeapItem it{d, lp[j].idx};
+            for (int a = 0; a < KD::DIM; ++a) { double x = q[a] - (double)lp[j].c[a]; d += x * x; }
+            HeapItem it{d, (int64_t)lp[j].idx};
             if (heap.size() < k) {
                 heap.push_back(it);
                 std::push_heap(heap.begin(), heap.end(), heap_less);
@@ -135,10 +138,21 @@ void knn_rec(const HostTree<Kd6>& t, const float* q, int32_t self, int64_t node,
         return;
     }
     std::pair<double, int> order[8];
-    for (int j = 0; j < 8; ++j) order[j] = {host_box_d2(q, t.boxes[8 * node + 1 + j]), j};
+    for (int j = 0; j < 8; ++j) order[j] = {host_box_d2<KD>(q, t.boxes[8 * node + 1 + j]), j};
     std::sort(order, order + 8);
     for (int j = 0; j < 8; ++j)
-        if (heap.size() < k || order[j].first <= heap.front().d) knn_rec(t, q, self, 8 * node + 1 + order[j].second, level + 1, heap, k);
+        if (heap.size() < k || order[j].first <= heap.front().d)
+            knn_rec<KD>(t, q, self, 8 * node + 1 + order[j].second, level + 1, heap, k);
+}
+
+template <class F>
+void parallel_for(int64_t n, F&& work) {
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt == 0 ? 1 : (nt > 32 ? 32 : nt);
+    if (n < 4096) nt = 1;
+    std::vector<std::thread> th;
+    for (unsigned i = 0; i < nt; ++i) th.emplace_back(work, n * i / nt, n * (i + 1) / nt);
+    for (auto& x : th) x.join();
 }
 
 inline float round_down_f32(double v) {
@@ -151,11 +165,13 @@ inline float round_down_f32(double v) {
 static void build_neighbour_graph(HostTree<Kd6>& t, const float* P, int64_t K) {
     t.nbrs.resize((size_t)K * NBR_REC);
     t.rho_out.resize(K);
-    auto work = [&](int64_t k0, int64_t k1) {
+    parallel_for(K, [&](int64_t k0, int64_t k1) {
         std::vector<HeapItem> heap;
         for (int64_t k = k0; k < k1; ++k) {
             heap.clear();
-            knn_rec(t, P + k * 6, (int32_t)k, 0, 0, heap, (size_t)NBR_M + 1);
+            double q[6];
+            for (int a = 0; a < 6; ++a) q[a] = (double)P[k * 6 + a];
+            knn_rec<Kd6>(t, q, k, 0, 0, heap, (size_t)NBR_M + 1);
             std::sort(heap.begin(), heap.end(), heap_less);
             {   // record 0 = the entry itself (rho 0): the scan needs no other lookup
                 Nbr6 r;
@@ -167,9 +183,9 @@ static void build_neighbour_graph(HostTree<Kd6>& t, const float* P, int64_t K) {
             for (int s2 = 0; s2 < NBR_M; ++s2) {
                 Nbr6 r;
                 if ((size_t)s2 < heap.size()) {
-                    const int32_t j = heap[s2].idx;
-                    for (int a = 0; a < 6; ++a) r.c[a] = P[(int64_t)j * 6 + a];
-                    r.idx = j;
+                    const int64_t j = heap[s2].idx;
+                    for (int a = 0; a < 6; ++a) r.c[a] = P[j * 6 + a];
+                    r.idx = (int32_t)j;
                     r.rho = round_down_f32(std::sqrt(heap[s2].d));
                 } else {
                     for (int a = 0; a < 6; ++a) r.c[a] = INFINITY;
@@ -180,13 +196,54 @@ static void build_neighbour_graph(HostTree<Kd6>& t, const float* P, int64_t K) {
             }
             t.rho_out[k] = heap.size() > (size_t)NBR_M ? round_down_f32(std::sqrt(heap[NBR_M].d)) : INFINITY;
         }
-    };
-    unsigned nt = std::thread::hardware_concurrency();
-    nt = nt == 0 ? 1 : (nt > 32 ? 32 : nt);
-    if (K < 4096) nt = 1;
-    std::vector<std::thread> th;
-    for (unsigned i = 0; i < nt; ++i) th.emplace_back(work, K * i / nt, K * (i + 1) / nt);
-    for (auto& x : th) x.join();
+    });
+}
+
+// ---- mesh-vertex lists anchored at the codebook entries (prune fast path) --------------------------
+// For entry k: the MESH_M mesh vertices nearest to its translation t_k, sorted by rho = |v - t_k|
+// (rounded down), and rho_out = distance of the next vertex.  A particle whose NN entry is k can only be
+// within thr of a vertex v if rho_v <= thr + |t_q - t_k|, so scanning the list in order decides the prune
+// exactly unless the list runs out first.
+int attach_mesh_impl(midas_ctx* ctx, midas_tree* t6, const midas_tree* t3, const float* cb_poses_dev) {
+    MIDAS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const HostTree<Kd3>* mesh = reinterpret_cast<const HostTree<Kd3>*>(t3->host);
+    if (!mesh) return midas_set_error(ctx, MIDAS_ERR_INVALID, "attach_mesh", "mesh tree has no host copy");
+    const int64_t K = t6->K;
+    std::vector<float> poses((size_t)K * 16);
+    MIDAS_HIP_CHECK(ctx, hipMemcpy(poses.data(), cb_poses_dev, poses.size() * sizeof(float), hipMemcpyDeviceToHost));
+    std::vector<MeshRec> recs((size_t)K * MESH_REC);
+    parallel_for(K, [&](int64_t k0, int64_t k1) {
+        std::vector<HeapItem> heap;
+        for (int64_t k = k0; k < k1; ++k) {
+            heap.clear();
+            const double q[3] = {(double)poses[k * 16 + 3], (double)poses[k * 16 + 7], (double)poses[k * 16 + 11]};
+            knn_rec<Kd3>(*mesh, q, -1, 0, 0, heap, (size_t)MESH_M + 1);
+            std::sort(heap.begin(), heap.end(), heap_less);
+            for (int s2 = 0; s2 < MESH_M; ++s2) {
+                MeshRec r;
+                if ((size_t)s2 < heap.size()) {
+                    const typename Kd3::Point& p = mesh->pts[mesh->inv_perm[heap[s2].idx]];
+                    r.c[0] = p.c[0]; r.c[1] = p.c[1]; r.c[2] = p.c[2];
+                    r.rho = round_down_f32(std::sqrt(heap[s2].d));
+                } else {
+                    r.c[0] = r.c[1] = r.c[2] = INFINITY;
+                    r.rho = INFINITY;
+                }
+                r.pad = 0;
+                recs[(size_t)k * MESH_REC + 1 + s2] = r;
+            }
+            MeshRec hd;
+            hd.c[0] = q[0]; hd.c[1] = q[1]; hd.c[2] = q[2];
+            hd.rho = heap.size() > (size_t)MESH_M ? round_down_f32(std::sqrt(heap[MESH_M].d)) : INFINITY;
+            hd.pad = 0;
+            recs[(size_t)k * MESH_REC] = hd;
+        }
+    });
+    if (t6->vlist) { (void)hipFree(t6->vlist); t6->vlist = nullptr; }
+    MIDAS_HIP_CHECK(ctx, hipMalloc(&t6->vlist, recs.size() * sizeof(MeshRec)));
+    MIDAS_HIP_CHECK(ctx, hipMemcpy(t6->vlist, recs.data(), recs.size() * sizeof(MeshRec), hipMemcpyHostToDevice));
+    t6->vlist_mesh = t3;
+    return MIDAS_OK;
 }
 
 template <class KD>
@@ -220,8 +277,16 @@ int tree_build_impl(midas_ctx* ctx, int32_t dim, int64_t K, const void* points_d
     }
     std::vector<double> host((size_t)K * 3);
     MIDAS_HIP_CHECK(ctx, hipMemcpy(host.data(), points_dev, host.size() * sizeof(double), hipMemcpyDeviceToHost));
-    HostTree<Kd3> h = build_tree<Kd3>(host.data(), K);
-    return upload_tree<Kd3>(ctx, h, K, out);
+    HostTree<Kd3>* h = new HostTree<Kd3>(build_tree<Kd3>(host.data(), K));
+    out->host = h;  // kept for attach_mesh (host k-NN over the mesh vertices)
+    return upload_tree<Kd3>(ctx, *h, K, out);
+}
+
+void tree_free_host(midas_tree* t) {
+    if (t->host) {
+        if (t->dim == 3) delete reinterpret_cast<HostTree<Kd3>*>(t->host);
+        t->host = nullptr;
+    }
 }
 
 template <class KD>
@@ -515,10 +580,36 @@ MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t h, float&
     return certified;
 }
 
+// Prune fast path: decide "some mesh vertex within thr of tq" from the vertex list of the particle's NN
+// entry h.  Returns 1 (valid: an actual vertex passes the exact test d2 <= t2), 0 (invalid: every vertex not
+// yet scanned is provably farther than thr, triangle inequality with slack far above float64 rounding) or
+// -1 (list exhausted: the caller runs the tree search).
+MD int mesh_list_check(const MeshRec* __restrict__ vlist, int32_t h, const double* tq, double t2, double thr) {
+    const MeshRec* vl = vlist + (size_t)h * MESH_REC;
+    const MeshRec hd = vl[0];
+    Point3 ph;
+    ph.c[0] = hd.c[0]; ph.c[1] = hd.c[1]; ph.c[2] = hd.c[2];
+    const double delta = __builtin_sqrt(dist2(tq, ph)) * (1.0 + 1e-12);
+    const double lim = thr * (1.0 + 1e-9) + delta + 1e-12;  // a vertex with rho*(1-1e-7) > lim cannot be within thr of tq
+    for (int s0 = 1; s0 <= MESH_M; s0 += 4) {
+        MeshRec e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = vl[s0 + j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if ((double)e[j].rho * (1.0 - 1e-7) > lim) return 0;
+            Point3 p;
+            p.c[0] = e[j].c[0]; p.c[1] = e[j].c[1]; p.c[2] = e[j].c[2];
+            if (dist2(tq, p) <= t2) return 1;
+        }
+    }
+    return ((double)hd.rho * (1.0 - 1e-7) > lim) ? 0 : -1;
+}
+
 // Wave-level NN: per-lane hint scan, then the octets serve the lanes it could not certify.
 // Must be called by every lane of the wave (`live` = this lane holds a query).
 template <bool STATS = false>
-MD void nn6_wave(const TreeView<Kd6>& tv, const float* q, bool live, int32_t hint, int32_t& idx, float& d2, float* cd,
+MD bool nn6_wave(const TreeView<Kd6>& tv, const float* q, bool live, int32_t hint, int32_t& idx, float& d2, float* cd,
                  int* n_leaves = nullptr, int* n_nodes = nullptr, int* n_scanned = nullptr) {
     float best = INFINITY;
     int64_t bi = 0;
@@ -527,6 +618,7 @@ MD void nn6_wave(const TreeView<Kd6>& tv, const float* q, bool live, int32_t hin
     wave_search<Kd6, false, STATS>(tv, q, best, bi, !done, cd, n_leaves, n_nodes);
     idx = (int32_t)bi;
     d2 = best;
+    return !done;  // this lane needed the tree search
 }
 
 // =================================================================================================
@@ -743,6 +835,7 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
     __shared__ double s_cd[KD_MAX_LEVELS * 64];  // child-distance columns, reused by both searches
     const int64_t n = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool live = n < a.N;
+    if (a.status_reset && blockIdx.x == 0 && threadIdx.x == 0) { a.status_reset[0] = 0; a.status_reset[1] = 0; }
     double x = 0.0, et2 = 0.0, ang2 = 0.0;
     float R[16], f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -763,13 +856,25 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
     if (a.ablate & 1) {  // profiling only: trust the hint
         bi = hint < 0 ? 0 : hint;
     } else {
-        nn6_wave(t6, f, live, hint, bi, bd, reinterpret_cast<float*>(s_cd));
+        const bool fb = nn6_wave(t6, f, live, hint, bi, bd, reinterpret_cast<float*>(s_cd));
+        if (a.telemetry) {
+            const unsigned long long m = __ballot(fb);
+            if (threadIdx.x == 0 && m) atomicAdd(&a.telemetry[0], (unsigned long long)__popcll(m));
+        }
     }
     // prune: valid <=> some mesh vertex within sqrt(t2) of the particle
     double q3[3] = {(double)R[3], (double)R[7], (double)R[11]};
     double best = a.t2;
     int64_t vi = 0;
-    const bool ok = (a.ablate & 2) ? true : wave_search<Kd3, true>(t3, q3, best, vi, live, s_cd);
+    int mv = -1;  // 1 valid, 0 invalid, -1 undecided
+    if (a.ablate & 2) mv = 1;
+    else if (live && a.vlist) mv = mesh_list_check(a.vlist, bi, q3, a.t2, a.thr);
+    bool ok = wave_search<Kd3, true>(t3, q3, best, vi, live && mv < 0, s_cd);
+    if (a.telemetry) {
+        const unsigned long long m = __ballot(live && mv < 0);
+        if (threadIdx.x == 0 && m) atomicAdd(&a.telemetry[1], (unsigned long long)__popcll(m));
+    }
+    if (mv >= 0) ok = mv == 1;
     if (live) {
         a.nn_idx[n] = bi;
         x = a.scores[bi];

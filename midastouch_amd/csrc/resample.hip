@@ -290,73 +290,49 @@ __global__ __launch_bounds__(256) void k_gather_rows(int64_t M, const int32_t* _
 // [block_base, block_base + nb_local) of the summation spec; arrays suffixed _all span every shard.
 // Single GPU: slot_base = block_base = 0 and the _all arrays are the local ones.
 
-// T1: m = max over all partial maxima ; e = exp(x - m) (or x) -> e_out ; local block totals of e
-__global__ __launch_bounds__(256) void k_tail_exp(int64_t N, const double* __restrict__ x, int np,
-                                                  const double* __restrict__ pmax_all, const double* __restrict__ pmin_all,
-                                                  int32_t softmax, double* __restrict__ e_out,
-                                                  double* __restrict__ block_sums, int32_t* __restrict__ flag,
-                                                  int32_t* __restrict__ status) {
+// TA: m = max over all partial maxima ; e = exp(x - m) (or x) -> e_out ; em = e * valid ;
+//     block-local prefix of em -> lp_out ; local block totals of e (softmax denominator) and of em
+//     (CDF total) ; status[0] = 2 on NaN ; status[1] = particles kept.
+//     The CDF is built from e*valid directly: the softmax normalisation cancels in prefix / total.
+__global__ __launch_bounds__(256) void k_tail_a(int64_t N, const double* __restrict__ x, const uint8_t* __restrict__ valid,
+                                                int np, const double* __restrict__ pmax_all,
+                                                const double* __restrict__ pmin_all, int32_t softmax,
+                                                double* __restrict__ e_out, double* __restrict__ lp_out,
+                                                double* __restrict__ block_sums_e, double* __restrict__ block_totals_em,
+                                                int32_t* __restrict__ flag, int32_t* __restrict__ status) {
     __shared__ double s_red[24];
     __shared__ double s_gtot[16];
     double mx, mn;
     block_extrema(pmax_all, pmin_all, np, s_red, mx, mn);
     const bool apply = softmax && !(__builtin_fabs(mx - mn) <= ISCLOSE_ATOL);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        flag[0] = apply ? 1 : 0;
-        status[0] = 0;
-        status[1] = 0;
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) flag[0] = apply ? 1 : 0;
     const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_CHUNK;
-    double v[SCAN_CHUNK], l[SCAN_CHUNK];
-#pragma unroll
-    for (int j = 0; j < SCAN_CHUNK; ++j) {
-        const int64_t i = base + j;
-        double e = 0.0;
-        if (i < N) {
-            const double xi = x[i];
-            e = apply ? exp(xi - mx) : xi;
-            e_out[i] = e;
-        }
-        v[j] = e;
-    }
-    const double W = block_scan(v, l, s_gtot);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = W;
-}
-
-// T2: S = sequential sum of ALL block sums ; w = e / S ; wm = w * valid -> w_io ; block-local prefix of wm
-//     -> lp_out ; local block totals ; status[0] |= 2 on NaN ; status[1] += particles kept
-__global__ __launch_bounds__(256) void k_tail_scan(int64_t N, double* __restrict__ w_io, const uint8_t* __restrict__ valid,
-                                                   int nb_all, const double* __restrict__ block_sums_all,
-                                                   const int32_t* __restrict__ flag, double* __restrict__ lp_out,
-                                                   double* __restrict__ block_totals, int32_t* __restrict__ status) {
-    __shared__ double s_gtot[16];
-    double bp, S = 1.0;
-    const bool apply = flag[0] != 0;
-    if (apply) seq_totals(block_sums_all, nb_all, 0, bp, S);
-    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_CHUNK;
-    double v[SCAN_CHUNK], l[SCAN_CHUNK];
+    double v[SCAN_CHUNK], vm[SCAN_CHUNK], l[SCAN_CHUNK];
     bool nan = false;
     int kept = 0;
 #pragma unroll
     for (int j = 0; j < SCAN_CHUNK; ++j) {
         const int64_t i = base + j;
-        double t = 0.0;
+        double e = 0.0, em = 0.0;
         if (i < N) {
-            const double e = w_io[i];
-            const double w = apply ? e / S : e;
+            const double xi = x[i];
+            e = apply ? exp(xi - mx) : xi;
+            e_out[i] = e;
             const bool ok = valid[i] != 0;
-            t = w * (ok ? 1.0 : 0.0);
+            em = e * (ok ? 1.0 : 0.0);
             kept += ok ? 1 : 0;
-            nan |= t != t;
-            w_io[i] = t;
+            nan |= em != em;
         }
-        v[j] = t;
+        v[j] = e;
+        vm[j] = em;
     }
-    const double W = block_scan(v, l, s_gtot);
+    const double We = block_scan(v, l, s_gtot);
+    __syncthreads();
+    const double Wm = block_scan(vm, l, s_gtot);
 #pragma unroll
     for (int j = 0; j < SCAN_CHUNK; ++j)
         if (base + j < N) lp_out[base + j] = l[j];
-    if (threadIdx.x == 0) block_totals[blockIdx.x] = W;
+    if (threadIdx.x == 0) { block_sums_e[blockIdx.x] = We; block_totals_em[blockIdx.x] = Wm; }
     const bool wnan = __any(nan);
     if (wnan && (threadIdx.x & 63) == 0) atomicOr(&status[0], 2);
 #pragma unroll
@@ -364,12 +340,17 @@ __global__ __launch_bounds__(256) void k_tail_scan(int64_t N, double* __restrict
     if ((threadIdx.x & 63) == 0 && kept) atomicAdd(&status[1], kept);
 }
 
-// T3: cdf = (BP + lp) / total over ALL block totals ; the globally last slot is forced to 1
-__global__ __launch_bounds__(256) void k_tail_cdf(int64_t N, double* __restrict__ cdf_io, int nb_all,
+// TF (sharded path): weights = e / S * valid ; cdf = (BP + lp) / total with S, BP, total summed
+//     sequentially over ALL shards' block partials ; the globally last slot is forced to 1.
+__global__ __launch_bounds__(256) void k_tail_fin(int64_t N, const double* __restrict__ e, const uint8_t* __restrict__ valid,
+                                                  double* __restrict__ weights, double* __restrict__ cdf_io, int nb_all,
+                                                  const double* __restrict__ block_sums_all,
                                                   const double* __restrict__ block_totals_all, int block_base,
-                                                  int32_t is_last, int32_t* __restrict__ status) {
-    double bp, total;
+                                                  int32_t is_last, const int32_t* __restrict__ flag,
+                                                  int32_t* __restrict__ status) {
+    double bp, total, S = 1.0, dummy;
     seq_totals(block_totals_all, nb_all, block_base + (int)blockIdx.x, bp, total);
+    if (flag[0]) seq_totals(block_sums_all, nb_all, 0, dummy, S);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (total != total) atomicOr(&status[0], 2);
         else if (total == 0.0) atomicOr(&status[0], 1);
@@ -378,7 +359,136 @@ __global__ __launch_bounds__(256) void k_tail_cdf(int64_t N, double* __restrict_
 #pragma unroll
     for (int j = 0; j < SCAN_CHUNK; ++j) {
         const int64_t i = base + (int64_t)j * 256 + threadIdx.x;
-        if (i < N) cdf_io[i] = (is_last && i == N - 1) ? 1.0 : (bp + cdf_io[i]) / total;
+        if (i < N) {
+            weights[i] = (e[i] / S) * (valid[i] ? 1.0 : 0.0);
+            cdf_io[i] = (is_last && i == N - 1) ? 1.0 : (bp + cdf_io[i]) / total;
+        }
+    }
+}
+
+// TB (single-GPU path): everything after TA in one kernel.  Each workgroup rebuilds the small tables (S,
+// total, BP[b], cdf at the block ends) in LDS, writes the weights of its own 256 slots, then resamples
+// them: the block holding the draw is found in the LDS table, the slot by a 12-step search over the
+// block-local prefix with cdf(i) = (BP_b + lp_i) / total evaluated on the fly - the same values the
+// sharded path materialises, so both give identical indices.
+constexpr int TB_MAX_BLOCKS = 1024;  // 4 M particles per GPU
+
+MD double cdf_at(const double* __restrict__ lp, const double* s_bp, double total, int64_t i, int64_t N) {
+    return (i == N - 1) ? 1.0 : (s_bp[i >> 12] + lp[i]) / total;
+}
+
+struct TailBArgs {
+    int64_t N;
+    int nb;
+    const double* e;
+    const uint8_t* valid;
+    const double* lp;
+    const double* block_sums_e;
+    const double* block_totals_em;
+    const int32_t* flag;
+    int32_t* status;
+    double* weights;       // out: e/S*valid of the own slots
+    int32_t mode;
+    const double* u;
+    float u32;
+    uint64_t seed, step;
+    int32_t* ridx;
+    const float* poses_prop;
+    float* poses_out;
+    double* weights_out;
+    const int32_t* nn_idx;
+    int32_t* hint_out;
+    const double* part_rmse;
+    int nrm;
+    double* rmse_out;
+};
+
+__global__ __launch_bounds__(256) void k_tail_b(TailBArgs a) {
+    __shared__ double s_bp[TB_MAX_BLOCKS];
+    __shared__ double s_end[TB_MAX_BLOCKS];
+    __shared__ double s_tot[2];
+    if (threadIdx.x == 0) {
+        double acc = 0.0;
+        for (int b = 0; b < a.nb; ++b) { s_bp[b] = acc; acc = acc + a.block_totals_em[b]; }
+        s_tot[0] = acc;
+        double S = 1.0;
+        if (a.flag[0]) {
+            S = 0.0;
+            for (int b = 0; b < a.nb; ++b) S = S + a.block_sums_e[b];
+        }
+        s_tot[1] = S;
+    }
+    __syncthreads();
+    const double total = s_tot[0], S = s_tot[1];
+    const int64_t N = a.N;
+    // cdf at the last slot of every block (the last block ends at N-1, forced to 1)
+    for (int b = threadIdx.x; b < a.nb; b += 256) {
+        const int64_t last = ((int64_t)(b + 1) << 12) - 1 < N - 1 ? ((int64_t)(b + 1) << 12) - 1 : N - 1;
+        s_end[b] = cdf_at(a.lp, s_bp, total, last, N);
+    }
+    __syncthreads();
+    const bool bad_total = !(total == total) || total == 0.0;
+    const int st0 = a.status[0];
+    const bool usable = st0 == 0 && !bad_total;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && bad_total) a.status[0] = st0 | ((total != total) ? 2 : 1);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < N) {
+        a.weights[i] = (a.e[i] / S) * (a.valid[i] ? 1.0 : 0.0);
+        int32_t src = (int32_t)i;
+        if (usable) {
+            double t;
+            bool upper;
+            if (a.mode == MIDAS_RESAMPLE_MULTINOMIAL) {
+                t = a.u ? a.u[i] : philox_uniform53((uint64_t)i, a.seed, a.step);
+                upper = false;
+            } else {
+                const float r = a.u32 >= 0.0f ? a.u32 : philox_uniform24(a.seed, a.step);
+                const float off = r / (float)N;
+                t = (double)i / (double)N + (double)off;
+                t = t >= 1.0 ? t - 1.0 : t;
+                upper = true;
+            }
+            // block: first b whose end value is >= t (lower) / > t (upper)
+            int lo = 0, hi = a.nb;
+            while (hi > lo) {
+                const int mid = lo + ((hi - lo) >> 1);
+                const double c = s_end[mid];
+                if (upper ? (c <= t) : (c < t)) lo = mid + 1; else hi = mid;
+            }
+            if (lo >= a.nb) {
+                src = (int32_t)(N - 1);
+            } else {
+                int64_t l2 = (int64_t)lo << 12, h2 = l2 + SCAN_BLOCK < N ? l2 + SCAN_BLOCK : N;
+                while (h2 > l2) {
+                    const int64_t mid = l2 + ((h2 - l2) >> 1);
+                    const double c = cdf_at(a.lp, s_bp, total, mid, N);
+                    if (upper ? (c <= t) : (c < t)) l2 = mid + 1; else h2 = mid;
+                }
+                src = (int32_t)(l2 < N ? l2 : N - 1);
+            }
+        }
+        a.ridx[i] = src;
+        const float4* ps = reinterpret_cast<const float4*>(a.poses_prop + (int64_t)src * 16);
+        float4* pd = reinterpret_cast<float4*>(a.poses_out + i * 16);
+        float4 r0 = ps[0], r1 = ps[1], r2 = ps[2], r3 = ps[3];
+        pd[0] = r0; pd[1] = r1; pd[2] = r2; pd[3] = r3;
+        a.weights_out[i] = (a.e[src] / S) * (a.valid[src] ? 1.0 : 0.0);
+        a.hint_out[i] = a.nn_idx[src];
+    }
+    if (a.part_rmse && blockIdx.x == 0) {
+        __shared__ double sa[4], sb[4];
+        double p = 0.0, q = 0.0;
+        for (int k = threadIdx.x; k < a.nrm; k += 256) { p += a.part_rmse[2 * k]; q += a.part_rmse[2 * k + 1]; }
+        p = wsum(p);
+        q = wsum(q);
+        if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = p; sb[threadIdx.x >> 6] = q; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            p = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+            q = (sb[0] + sb[1]) + (sb[2] + sb[3]);
+            a.rmse_out[0] = __builtin_sqrt(p / (double)N);
+            a.rmse_out[1] = __builtin_sqrt(q / (double)N);
+        }
     }
 }
 
@@ -524,26 +634,20 @@ int launch_gather_rows(midas_ctx* ctx, int64_t M, const int32_t* idx, const void
     return MIDAS_OK;
 }
 
-int launch_tail_exp(midas_ctx* ctx, int64_t N, const double* x, int np, const double* pmax_all, const double* pmin_all,
-                    int32_t softmax, double* e_out, double* block_sums, int32_t* flag, int32_t* status) {
-    hipLaunchKernelGGL(k_tail_exp, dim3((unsigned)ceil_div(N, SCAN_BLOCK)), dim3(256), 0, ctx->stream, N, x, np, pmax_all,
-                       pmin_all, softmax, e_out, block_sums, flag, status);
+int launch_tail_a(midas_ctx* ctx, int64_t N, const double* x, const uint8_t* valid, int np, const double* pmax_all,
+                  const double* pmin_all, int32_t softmax, double* e_out, double* lp_out, double* block_sums_e,
+                  double* block_totals_em, int32_t* flag, int32_t* status) {
+    hipLaunchKernelGGL(k_tail_a, dim3((unsigned)ceil_div(N, SCAN_BLOCK)), dim3(256), 0, ctx->stream, N, x, valid, np, pmax_all,
+                       pmin_all, softmax, e_out, lp_out, block_sums_e, block_totals_em, flag, status);
     LAUNCH_CHECK(ctx);
     return MIDAS_OK;
 }
 
-int launch_tail_scan(midas_ctx* ctx, int64_t N, double* w_io, const uint8_t* valid, int nb_all, const double* block_sums_all,
-                     const int32_t* flag, double* lp_out, double* block_totals, int32_t* status) {
-    hipLaunchKernelGGL(k_tail_scan, dim3((unsigned)ceil_div(N, SCAN_BLOCK)), dim3(256), 0, ctx->stream, N, w_io, valid,
-                       nb_all, block_sums_all, flag, lp_out, block_totals, status);
-    LAUNCH_CHECK(ctx);
-    return MIDAS_OK;
-}
-
-int launch_tail_cdf(midas_ctx* ctx, int64_t N, double* cdf_io, int nb_all, const double* block_totals_all, int block_base,
-                    int32_t is_last, int32_t* status) {
-    hipLaunchKernelGGL(k_tail_cdf, dim3((unsigned)ceil_div(N, SCAN_BLOCK)), dim3(256), 0, ctx->stream, N, cdf_io, nb_all,
-                       block_totals_all, block_base, is_last, status);
+int launch_tail_fin(midas_ctx* ctx, int64_t N, const double* e, const uint8_t* valid, double* weights, double* cdf_io,
+                    int nb_all, const double* block_sums_all, const double* block_totals_all, int block_base,
+                    int32_t is_last, const int32_t* flag, int32_t* status) {
+    hipLaunchKernelGGL(k_tail_fin, dim3((unsigned)ceil_div(N, SCAN_BLOCK)), dim3(256), 0, ctx->stream, N, e, valid, weights,
+                       cdf_io, nb_all, block_sums_all, block_totals_all, block_base, is_last, flag, status);
     LAUNCH_CHECK(ctx);
     return MIDAS_OK;
 }
@@ -565,28 +669,26 @@ int launch_tail_resample(midas_ctx* ctx, const midas_tail_resample_args& r, cons
 
 int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base) {
     const int nb = (int)ceil_div(a.N, SCAN_BLOCK);
+    if (nb > TB_MAX_BLOCKS) return midas_set_error(ctx, MIDAS_ERR_INVALID, "N", "more than 4 M particles per GPU: shard them");
     void* sc;
-    int rc = midas_scratch(ctx, (size_t)nb * 2 * sizeof(double) + 64, &sc);
+    int rc = midas_scratch(ctx, (size_t)nb * 2 * sizeof(double) + (size_t)a.N * sizeof(double) + 64, &sc);
     if (rc) return rc;
     double* psum = (double*)sc;
     double* pw = psum + nb;
-    int32_t* flag = (int32_t*)(pw + nb);
-    if ((rc = launch_tail_exp(ctx, a.N, a.x, a.npart, a.part_max, a.part_min, a.softmax, a.weights, psum, flag, a.status))) return rc;
-    prof_mark(ctx, prof_slot_base + 1);
-    if ((rc = launch_tail_scan(ctx, a.N, a.weights, a.valid, nb, psum, flag, a.cdf, pw, a.status))) return rc;
-    prof_mark(ctx, prof_slot_base + 2);
-    if ((rc = launch_tail_cdf(ctx, a.N, a.cdf, nb, pw, 0, 1, a.status))) return rc;
-    prof_mark(ctx, prof_slot_base + 3);
-    midas_tail_resample_args r;
-    r.N = a.N; r.N_all = a.N; r.slot_base = 0;
-    r.cdf_all_dev = a.cdf; r.status_dev = a.status; r.mode = a.mode; r.u_dev = a.u; r.u32 = a.u32;
-    r.seed = a.seed; r.step = a.step; r.ridx_dev = a.ridx;
-    r.poses_all_dev = a.poses_prop; r.poses_out_dev = a.poses_out;
-    r.weights_all_dev = a.weights; r.weights_out_dev = a.weights_out;
-    r.nn_all_dev = a.nn_idx; r.hint_out_dev = a.hint_out;
-    if ((rc = launch_tail_resample(ctx, r, a.part_rmse, a.part_rmse ? particle_update_blocks(a.N) : 0, (double)a.N, a.rmse_out)))
+    double* e = pw + nb;
+    int32_t* flag = (int32_t*)(e + a.N);
+    if ((rc = launch_tail_a(ctx, a.N, a.x, a.valid, a.npart, a.part_max, a.part_min, a.softmax, e, a.cdf, psum, pw, flag, a.status)))
         return rc;
-    prof_mark(ctx, prof_slot_base + 4);
+    prof_mark(ctx, prof_slot_base + 1);
+    TailBArgs b;
+    b.N = a.N; b.nb = nb; b.e = e; b.valid = a.valid; b.lp = a.cdf; b.block_sums_e = psum; b.block_totals_em = pw;
+    b.flag = flag; b.status = a.status; b.weights = a.weights; b.mode = a.mode; b.u = a.u; b.u32 = a.u32;
+    b.seed = a.seed; b.step = a.step; b.ridx = a.ridx; b.poses_prop = a.poses_prop; b.poses_out = a.poses_out;
+    b.weights_out = a.weights_out; b.nn_idx = a.nn_idx; b.hint_out = a.hint_out;
+    b.part_rmse = a.part_rmse; b.nrm = a.part_rmse ? particle_update_blocks(a.N) : 0; b.rmse_out = a.rmse_out;
+    hipLaunchKernelGGL(k_tail_b, dim3((unsigned)ceil_div(a.N, 256)), dim3(256), 0, ctx->stream, b);
+    LAUNCH_CHECK(ctx);
+    prof_mark(ctx, prof_slot_base + 2);
     return MIDAS_OK;
 }
 

@@ -5,8 +5,8 @@ the NN index and the mesh index.  One frame is the single-GPU frame (engine.Filt
 its global reductions; between the local kernels the ranks exchange, with `all_gather`:
 
   G1  4 doubles/rank   max x, min x (softmax shift + isclose guard), rmse partial sums
-  G2  nb doubles/rank  block sums of exp(x - max)           -> softmax denominator (fixed order)
-  G3  nb+2 doubles     block totals of the masked weights   -> CDF offsets / total, NaN flag, kept count
+  G2  2nb+2 doubles    block sums of exp(x - max) (softmax denominator), block totals of exp * mask
+                       (CDF offsets / total), NaN flag, kept count - all in the fixed summation order
   G4  N doubles/rank   the CDF slice     G5 N x 16 f32 propagated poses
   G6  N doubles        masked weights    G7 N int32 NN indices      (resample reads any rank's particle)
 
@@ -42,6 +42,7 @@ class HipShardBackend:
         self.tree6 = ops.Tree(self.cb_feat)
         self.codebook = ops.Codebook(torch.as_tensor(cb_embeddings).to(self.device))
         self.tree3 = ops.Tree(torch.as_tensor(mesh_vertices).to(self.device, torch.float64))
+        self.tree6.attach_mesh(self.tree3, self.cb_poses)
 
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.device)
@@ -60,20 +61,20 @@ class HipShardBackend:
         a.rmse_sums = _ptr(st.g1[2:]) if gt is not None else None
         a.tn, a.rot = _ptr(tn), _ptr(rot)
         a.std_t, a.std_r, a.seed, a.step, a.prune_thr = std_t, std_r, seed, step, prune_thr
+        a.telemetry = _ptr(st.telemetry)
+        a.status = _ptr(st.status)
         self.ctx.bind_current_stream()
         self.ctx.check(self.ctx.lib.midas_shard_update(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h, C.byref(a)))
 
-    def tail_exp(self, st, pmax_all, pmin_all, softmax):
-        self.ctx.call("midas_tail_exp", st.N, _ptr(st.x), pmax_all.shape[0], _ptr(pmax_all), _ptr(pmin_all), int(softmax),
-                      _ptr(st.weights), _ptr(st.g2), _ptr(st.flag), _ptr(st.status))
+    def tail_a(self, st, pmax_all, pmin_all, softmax):
+        self.ctx.call("midas_tail_a", st.N, _ptr(st.x), _ptr(st.valid), pmax_all.shape[0], _ptr(pmax_all), _ptr(pmin_all),
+                      int(softmax), _ptr(st.e), _ptr(st.cdf), _ptr(st.g2[: st.nb]), _ptr(st.g2[st.nb: 2 * st.nb]),
+                      _ptr(st.flag), _ptr(st.status))
 
-    def tail_scan(self, st, block_sums_all):
-        self.ctx.call("midas_tail_scan", st.N, _ptr(st.weights), _ptr(st.valid), block_sums_all.shape[0],
-                      _ptr(block_sums_all), _ptr(st.flag), _ptr(st.cdf), _ptr(st.g3[: st.nb]), _ptr(st.status))
-
-    def tail_cdf(self, st, block_totals_all, block_base, is_last):
-        self.ctx.call("midas_tail_cdf", st.N, _ptr(st.cdf), block_totals_all.shape[0], _ptr(block_totals_all),
-                      block_base, int(is_last), _ptr(st.status))
+    def tail_fin(self, st, block_sums_all, block_totals_all, block_base, is_last):
+        self.ctx.call("midas_tail_fin", st.N, _ptr(st.e), _ptr(st.valid), _ptr(st.weights), _ptr(st.cdf),
+                      block_sums_all.shape[0], _ptr(block_sums_all), _ptr(block_totals_all), block_base, int(is_last),
+                      _ptr(st.flag), _ptr(st.status))
 
     def tail_resample(self, st, cdf_all, poses_all, weights_all, nn_all, mode, u, u32, seed, step):
         a = TailResampleArgs()
@@ -105,11 +106,13 @@ class ShardState:
         self.hint = e((N,), torch.int32)
         self.ridx = e((N,), torch.int32)
         self.g1 = e((4,), torch.float64)            # max, min, rmse sums
-        self.g2 = e((self.nb,), torch.float64)      # block sums of e
-        self.g3 = e((self.nb + 2,), torch.float64)  # block totals of w*mask, NaN flag, kept
+        self.e = e((N,), torch.float64)
+        self.g2 = e((2 * self.nb + 2,), torch.float64)  # block sums of e, block totals of e*mask, NaN flag, kept
         self.flag = e((1,), torch.int32)
         self.status = e((2,), torch.int32)
         self.rmse = e((2,), torch.float64)
+        self.telemetry = e((2,), torch.int64)
+        self.telemetry.zero_()
         self.hint.fill_(-1)
         self.g1.zero_()
 
@@ -193,14 +196,13 @@ class ShardedFilterEngine:
         b.update(st, odom, code, gt, tn, rot, mul * self.sig_t, mul * self.sig_r, self.seed, self.step_count,
                  self.pen_max, self.use_hint)
         g1 = (yield st.g1).reshape(G, 4)
-        b.tail_exp(st, g1[:, 0].contiguous(), g1[:, 1].contiguous(), self.softmax)
-        g2 = yield st.g2
-        b.tail_scan(st, g2)
-        st.g3[st.nb:] = st.status.to(torch.float64)  # NaN flag (status[0]), kept count (status[1])
-        g3 = (yield st.g3).reshape(G, st.nb + 2)
-        st.status[0] = (g3[:, st.nb] != 0).any().to(torch.int32) * 2
-        st.status[1] = g3[:, st.nb + 1].sum().to(torch.int32)
-        b.tail_cdf(st, g3[:, : st.nb].contiguous().reshape(-1), self.rank * st.nb, self.rank == G - 1)
+        b.tail_a(st, g1[:, 0].contiguous(), g1[:, 1].contiguous(), self.softmax)
+        st.g2[2 * st.nb:] = st.status.to(torch.float64)  # NaN flag (status[0]), kept count (status[1])
+        g2 = (yield st.g2).reshape(G, 2 * st.nb + 2)
+        st.status[0] = (g2[:, 2 * st.nb] != 0).any().to(torch.int32) * 2
+        st.status[1] = g2[:, 2 * st.nb + 1].sum().to(torch.int32)
+        b.tail_fin(st, g2[:, : st.nb].contiguous().reshape(-1), g2[:, st.nb: 2 * st.nb].contiguous().reshape(-1),
+                   self.rank * st.nb, self.rank == G - 1)
         cdf_all = yield st.cdf
         poses_all = yield st.poses_prop
         weights_all = yield st.weights

@@ -32,6 +32,7 @@ class FilterEngine:
         self.tree6 = ops.Tree(self.cb_feat)
         self.codebook = ops.Codebook(torch.as_tensor(cb_embeddings).to(self.device))
         self.tree3 = ops.Tree(torch.as_tensor(mesh_vertices).to(self.device, torch.float64))
+        self.tree6.attach_mesh(self.tree3, self.cb_poses)
         self.K, self.D = self.codebook.K, self.codebook.D
         self.sig_t, self.sig_r, self.pen_max = float(sig_t), float(sig_r), float(pen_max)
         self.seed, self.softmax = int(seed), bool(softmax)
@@ -49,6 +50,7 @@ class FilterEngine:
         self.ridx = torch.zeros(N, dtype=torch.int32, device=self.device)
         self.status = torch.zeros(2, dtype=torch.int32, device=self.device)
         self.rmse = torch.zeros(2, dtype=torch.float64, device=self.device)
+        self.telemetry = torch.zeros(2, dtype=torch.int64, device=self.device)  # cumulative tree-search fallbacks
         self.step_count = 0
         self.use_hint = True
 
@@ -87,6 +89,7 @@ class FilterEngine:
         a.prune_thr = self.pen_max
         a.softmax, a.resample_mode = int(self.softmax), self.mode
         a.status = _ptr(self.status)
+        a.telemetry = _ptr(self.telemetry)
         self._keep = (odom, code, gt, tn, rot, u)  # keep operands alive until the stream has consumed them
         self.ctx.bind_current_stream()
         self.ctx.check(self.ctx.lib.midas_filter_step(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h,

@@ -83,6 +83,14 @@ class Tree:
         ctx.call("midas_tree_build", dim, self.K, _ptr(pts), C.byref(h))
         self.h = h
 
+    def attach_mesh(self, mesh_tree: "Tree", cb_poses: torch.Tensor):
+        """Per-codebook-entry mesh vertex lists: the prune of the fused step then rarely walks the mesh tree."""
+        if self.dim != 6 or mesh_tree.dim != 3:
+            raise MidasError("attach_mesh: self must be the 6-d codebook tree, mesh_tree the 3-d vertex tree")
+        cb_poses = cb_poses.to(torch.float32).contiguous()
+        self.ctx.call("midas_tree_attach_mesh", self.h, mesh_tree.h, _ptr(cb_poses))
+        self._mesh = mesh_tree  # keep the mesh tree alive while the lists refer to it
+
     def __del__(self):  # pragma: no cover
         try:
             if self.h:

@@ -187,6 +187,17 @@ def softmax_weights(x, softmax: bool = True):
     return w, bool(applied)
 
 
+def softmax_numerators(x, softmax: bool = True):
+    """e = exp(x - max(x)) (libm exp), or x itself when the softmax is skipped; returns (e, applied)."""
+    import math
+    x = _f64(x).ravel()
+    mx, mn = float(np.max(x)), float(np.min(x))
+    applied = bool(softmax) and not (abs(mx - mn) <= 1e-8)
+    if not applied:
+        return x.copy(), False
+    return np.array([math.exp(v) for v in (x - mx)], dtype=np.float64), True
+
+
 def get_similarity(code, targets, softmax: bool = True):
     """particle_filter.get_similarity (particle_filter.py:449-469): targets (N,D) gathered rows."""
     x = score_codebook(np.atleast_2d(targets), code)
@@ -352,15 +363,20 @@ class OracleFilter:
         scores = score_codebook(self.emb, code)
         out["scores"] = scores
         x = scores[idx]
-        w, _ = softmax_weights(x, softmax)
-        out["weights_pre"] = w.copy()
         dist = nn3_dist(p1, self.verts)
         mask = ~(dist > self.pen_max)
         out["dist"], out["mask"] = dist, mask
-        w = w * mask
+        # fused-step spec (csrc/resample.hip k_tail_a/k_tail_b): e = exp(x - max) (or x when the softmax is
+        # skipped); weights = e / blocked_sum(e) * mask; the CDF is built from e * mask directly - the
+        # normalisation by sum(e) cancels in prefix / total
+        e, applied = softmax_numerators(x, softmax)
+        S = blocked_scan(e)[1] if applied else 1.0
+        w_pre = e / S
+        out["weights_pre"] = w_pre.copy()
+        w = w_pre * mask
         out["weights"] = w
         out["drifted"] = bool(mask.sum() == 0)
-        ridx, status = resample_indices(w, mode, u=u, u32=u32)
+        ridx, status = resample_indices(e * mask, mode, u=u, u32=u32)
         out["status"] = status
         if status:
             out["ridx"] = np.arange(len(w), dtype=np.int32)

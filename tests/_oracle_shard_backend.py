@@ -52,32 +52,28 @@ class OracleShardBackend:
             rt, rr = orc.particle_rmse(p1, gt.numpy())
             st.g1[2], st.g1[3] = rt * rt * N, rr * rr * N
 
-    def tail_exp(self, st, pmax_all, pmin_all, softmax):
+    def tail_a(self, st, pmax_all, pmin_all, softmax):
         mx, mn = float(pmax_all.max()), float(pmin_all.min())
         apply = bool(softmax) and not (abs(mx - mn) <= 1e-8)
         x = st.x.numpy()
         # math.exp is glibc's exp, the function the C oracle calls (numpy's vectorised exp can differ by an ulp)
         e = np.array([math.exp(v) for v in (x - mx)]) if apply else x.copy()
-        st.weights.copy_(torch.as_tensor(e))
+        valid = st.valid.numpy().astype(bool)
+        em = e * valid
+        st.e.copy_(torch.as_tensor(e))
         for b in range(st.nb):
             st.g2[b] = orc.blocked_scan(e[b * BLOCK:(b + 1) * BLOCK])[1]
-        st.flag[0] = int(apply)
-        st.status.zero_()
-
-    def tail_scan(self, st, block_sums_all):
-        e = st.weights.numpy()
-        w = e / _seq_sum(block_sums_all.numpy()) if int(st.flag[0]) else e.copy()
-        valid = st.valid.numpy().astype(bool)
-        wm = w * valid
-        st.weights.copy_(torch.as_tensor(wm))
-        for b in range(st.nb):
-            lp, tot = orc.blocked_scan(wm[b * BLOCK:(b + 1) * BLOCK])
+            lp, tot = orc.blocked_scan(em[b * BLOCK:(b + 1) * BLOCK])
             st.cdf[b * BLOCK:(b + 1) * BLOCK] = torch.as_tensor(lp)
-            st.g3[b] = tot
-        st.status[0] = 2 if np.isnan(wm).any() else 0
+            st.g2[st.nb + b] = tot
+        st.flag[0] = int(apply)
+        st.status[0] = 2 if np.isnan(em).any() else 0
         st.status[1] = int(valid.sum())
 
-    def tail_cdf(self, st, block_totals_all, block_base, is_last):
+    def tail_fin(self, st, block_sums_all, block_totals_all, block_base, is_last):
+        S = _seq_sum(block_sums_all.numpy()) if int(st.flag[0]) else 1.0
+        valid = st.valid.numpy().astype(bool)
+        st.weights.copy_(torch.as_tensor((st.e.numpy() / S) * valid))
         tot = block_totals_all.numpy()
         total = _seq_sum(tot)
         lp = st.cdf.numpy().copy()
