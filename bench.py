@@ -103,7 +103,8 @@ def main():
 
     N, K, D = args.particles, args.codebook, args.dim
     cb = make_codebook("004_sugar_box", K=K, D=D, seed=1001)
-    T = min(args.warmup + args.steps + 2, 512)
+    NPROF = 50  # frames of the per-kernel timing pass; it continues the trajectory after the timed region
+    T = min(args.warmup + args.steps + NPROF + 2, 1024)
     traj = make_trajectory(cb, T=T, seed=2001)
 
     if world == 1:
@@ -166,9 +167,8 @@ def main():
     if world == 1 and not args.no_profile:
         eng.profile(True)
         eng.profile_read(reset=True)
-        nprof = min(50, args.steps)
-        for i in range(nprof):
-            frame(i)
+        for i in range(NPROF):
+            frame(args.warmup + args.steps + i)
         ms, calls = eng.profile_read(reset=True)
         eng.profile(False)
         per = {k: v / calls for k, v in ms.items()}

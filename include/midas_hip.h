@@ -186,6 +186,7 @@ typedef struct midas_shard_update_args {
     const int32_t* hint_in_dev; /* N or NULL */
     int32_t* nn_idx_dev;        /* N out */
     double* x_dev;              /* N out: score of the nearest codebook entry */
+    double* e_dev;              /* N out: exp(x - 1), the softmax numerator with the constant shift 1 */
     uint8_t* valid_dev;         /* N out: prune mask */
     double* extrema_dev;        /* 2 out: max(x), min(x) over the local particles */
     const float* odom16_dev;
@@ -203,7 +204,8 @@ typedef struct midas_shard_update_args {
 /* score codebook + propagate + feature + NN + prune + score gather for the local particles */
 int midas_shard_update(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
                        const midas_tree* tree3, const midas_shard_update_args* args);
-/* e = exp(x - max(pmax_all)) (or x when the softmax is skipped) -> e ; lp = block-local prefix (fixed order) of
+/* e (in/out) = exp(x - 1) from midas_shard_update, replaced by x when the softmax is skipped (|max - min| of the
+ * gathered extrema <= 1e-8 or softmax == 0) ; lp = block-local prefix (fixed order) of
  * e * valid ; block_sums / block_totals = the local 4096-slot block totals of e and of e * valid ;
  * flag[0] = softmax applied ; status[0] = 2 on NaN, status[1] = particles kept */
 int midas_tail_a(midas_ctx* ctx, int64_t N, const double* x_dev, const uint8_t* valid_dev, int32_t np,

@@ -217,6 +217,7 @@ MIDAS_EXPORT int midas_tree_destroy(midas_tree* t) {
     if (t->inv_perm) (void)hipFree(t->inv_perm);
     if (t->nbrs) (void)hipFree(t->nbrs);
     if (t->rho_out) (void)hipFree(t->rho_out);
+    if (t->twin) (void)hipFree(t->twin);
     if (t->vlist) (void)hipFree(t->vlist);
     tree_free_host(t);
     delete t;
@@ -333,10 +334,11 @@ MIDAS_EXPORT int midas_filter_step(midas_ctx* ctx, const midas_codebook* cb, con
     MIDAS_REQUIRE(ctx, tree6->K == cb->K);
     const int64_t N = s.N;
     const int npart = particle_update_blocks(N);
-    void *scores, *x, *valid, *pmax, *pmin, *prm = nullptr, *cdf;
+    void *scores, *x, *e, *valid, *pmax, *pmin, *prm = nullptr, *cdf;
     int rc;
     if ((rc = midas_scratch(ctx, (size_t)cb->K * sizeof(double), &scores))) return rc;
     if ((rc = midas_scratch(ctx, (size_t)N * sizeof(double), &x))) return rc;
+    if ((rc = midas_scratch(ctx, (size_t)N * sizeof(double), &e))) return rc;
     if ((rc = midas_scratch(ctx, (size_t)N, &valid))) return rc;
     if ((rc = midas_scratch(ctx, (size_t)npart * sizeof(double), &pmax))) return rc;
     if ((rc = midas_scratch(ctx, (size_t)npart * sizeof(double), &pmin))) return rc;
@@ -363,6 +365,7 @@ MIDAS_EXPORT int midas_filter_step(midas_ctx* ctx, const midas_codebook* cb, con
     pa.nn_idx = s.nn_idx_dev;
     pa.scores = (const double*)scores;
     pa.x = (double*)x;
+    pa.e = (double*)e;
     pa.valid = (uint8_t*)valid;
     pa.t2 = squared_threshold(s.prune_thr);
     pa.thr = s.prune_thr;
@@ -380,6 +383,7 @@ MIDAS_EXPORT int midas_filter_step(midas_ctx* ctx, const midas_codebook* cb, con
     ta.N = N;
     ta.npart = npart;
     ta.x = (const double*)x;
+    ta.e = (double*)e;
     ta.valid = (const uint8_t*)valid;
     ta.part_max = (const double*)pmax;
     ta.part_min = (const double*)pmin;
@@ -421,7 +425,7 @@ MIDAS_EXPORT int midas_shard_update(midas_ctx* ctx, const midas_codebook* cb, co
     MIDAS_ENTER(ctx);
     MIDAS_REQUIRE(ctx, cb && tree6 && tree3 && args && tree6->dim == 6 && tree3->dim == 3 && tree6->K == cb->K);
     const midas_shard_update_args& s = *args;
-    MIDAS_REQUIRE(ctx, s.N > 0 && s.poses_in_dev && s.poses_prop_dev && s.nn_idx_dev && s.x_dev && s.valid_dev &&
+    MIDAS_REQUIRE(ctx, s.N > 0 && s.poses_in_dev && s.poses_prop_dev && s.nn_idx_dev && s.x_dev && s.e_dev && s.valid_dev &&
                            s.extrema_dev && s.odom16_dev && s.code_dev && s.poses_in_dev != s.poses_prop_dev);
     MIDAS_REQUIRE(ctx, (s.tn_dev == nullptr) == (s.rot_dev == nullptr));
     const int npart = particle_update_blocks(s.N);
@@ -449,6 +453,7 @@ MIDAS_EXPORT int midas_shard_update(midas_ctx* ctx, const midas_codebook* cb, co
     pa.nn_idx = s.nn_idx_dev;
     pa.scores = (const double*)scores;
     pa.x = s.x_dev;
+    pa.e = s.e_dev;
     pa.valid = s.valid_dev;
     pa.t2 = squared_threshold(s.prune_thr);
     pa.thr = s.prune_thr;

@@ -40,12 +40,12 @@ constexpr int KD_MAX_LEVELS = 10; // 8-ary levels (8^10 leaves x 16 slots is far
 // distance rho from F_k to that neighbour (rounded down), coordinates inlined so that one 32-byte
 // read is one candidate.  Unused records are sentinels (+inf coordinates, rho = +inf).
 struct alignas(16) Nbr6 { float c[6]; int32_t idx; float rho; };
-constexpr int NBR_M = 64;
+constexpr int NBR_M = 128;
 constexpr int NBR_REC = NBR_M + 1;  // record 0 = the entry itself
 
 // Mesh-vertex record of the prune fast path: the vertices nearest to a codebook entry's translation.
 struct alignas(16) MeshRec { double c[3]; float rho; int32_t pad; };
-constexpr int MESH_M = 64;
+constexpr int MESH_M = 128;
 constexpr int MESH_REC = MESH_M + 1;  // record 0 = header: c = the entry's translation, rho = distance of the
                                       // first vertex NOT in the list
 
@@ -56,6 +56,7 @@ struct TreeView {
     const int32_t* inv_perm;        // [K] original index -> slot in pts
     const Nbr6* nbrs;               // [K * NBR_REC] (dim 6) or nullptr
     const float* rho_out;           // [K] distance from F_k to its (NBR_M+1)-th neighbour, rounded down
+    const int32_t* twin;            // [K] entry across the |log R| = pi cut (or -1) - second hint of the scan
     int32_t levels;                 // L: number of 8-ary levels above the leaves
     int64_t K;
 };
@@ -99,6 +100,7 @@ struct midas_tree {
     int32_t* inv_perm;
     void* nbrs;      // Nbr6[K * NBR_REC] (dim 6)
     float* rho_out;  // [K] (dim 6)
+    int32_t* twin;   // [K] (dim 6)
     void* vlist;     // MeshRec[K * MESH_REC] (dim 6, after midas_tree_attach_mesh)
     const midas_tree* vlist_mesh;  // the mesh tree the lists were built from
     void* host;      // host copy of the tree (dim 3: used to build the lists)
@@ -160,6 +162,7 @@ struct ParticleUpdateArgs {
     int32_t* nn_idx;
     const double* scores;  // [K]
     double* x;             // [N] gathered score
+    double* e;             // [N] exp(x - 1): softmax numerator with the constant shift 1 (scores are cosines)
     uint8_t* valid;        // [N] prune mask
     double t2;             // squared prune threshold (exact: sqrt(d2) > thr  <=>  d2 > t2)
     double thr;            // the threshold itself (triangle-inequality tests of the vertex lists)
@@ -188,6 +191,7 @@ struct StepTailArgs {
     int64_t N;
     int npart;               // number of part_max/part_min entries
     const double* x;
+    double* e;               // exp(x - 1) from the particle update (replaced by x when the softmax is skipped)
     const uint8_t* valid;
     const double* part_max;
     const double* part_min;
@@ -210,7 +214,7 @@ struct StepTailArgs {
 };
 int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base);
 int launch_tail_a(midas_ctx* ctx, int64_t N, const double* x, const uint8_t* valid, int np, const double* pmax_all,
-                  const double* pmin_all, int32_t softmax, double* e_out, double* lp_out, double* block_sums_e,
+                  const double* pmin_all, int32_t softmax, double* e_io, double* lp_out, double* block_sums_e,
                   double* block_totals_em, int32_t* flag, int32_t* status);
 int launch_tail_fin(midas_ctx* ctx, int64_t N, const double* e, const uint8_t* valid, double* weights, double* cdf_io,
                     int nb_all, const double* block_sums_all, const double* block_totals_all, int block_base,

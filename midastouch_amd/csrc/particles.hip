@@ -26,6 +26,7 @@ struct HostTree {
     std::vector<int32_t> inv_perm;
     std::vector<Nbr6> nbrs;      // dim 6 only
     std::vector<float> rho_out;  // dim 6 only
+    std::vector<int32_t> twin;   // dim 6 only
     int levels = 0;              // 8-ary levels
 };
 
@@ -165,6 +166,7 @@ inline float round_down_f32(double v) {
 static void build_neighbour_graph(HostTree<Kd6>& t, const float* P, int64_t K) {
     t.nbrs.resize((size_t)K * NBR_REC);
     t.rho_out.resize(K);
+    t.twin.resize(K);
     parallel_for(K, [&](int64_t k0, int64_t k1) {
         std::vector<HeapItem> heap;
         for (int64_t k = k0; k < k1; ++k) {
@@ -195,6 +197,19 @@ static void build_neighbour_graph(HostTree<Kd6>& t, const float* P, int64_t K) {
                 t.nbrs[(size_t)k * NBR_REC + 1 + s2] = r;
             }
             t.rho_out[k] = heap.size() > (size_t)NBR_M ? round_down_f32(std::sqrt(heap[NBR_M].d)) : INFINITY;
+            // twin across the rotation-angle-pi cut: the feature's rotation part is w = 0.01 log(R); a pose whose
+            // angle crosses pi reappears at w - 2 pi 0.01 w/|w|.  The entry nearest to that image is the right
+            // second hint for a particle whose own feature has just flipped.
+            const double wn = std::sqrt(q[3] * q[3] + q[4] * q[4] + q[5] * q[5]);
+            t.twin[k] = -1;
+            if (wn > 0.01 * (M_PI - 0.6)) {
+                double qf[6] = {q[0], q[1], q[2], 0, 0, 0};
+                const double sc = (wn - 0.01 * 2.0 * M_PI) / wn;
+                for (int a = 3; a < 6; ++a) qf[a] = q[a] * sc;
+                heap.clear();
+                knn_rec<Kd6>(t, qf, -1, 0, 0, heap, 1);
+                if (!heap.empty() && heap[0].idx != k) t.twin[k] = (int32_t)heap[0].idx;
+            }
         }
     });
 }
@@ -260,6 +275,7 @@ static int upload_tree(midas_ctx* ctx, const HostTree<KD>& h, int64_t K, midas_t
     if (!h.nbrs.empty()) {
         if ((rc = up(h.nbrs.data(), h.nbrs.size() * sizeof(Nbr6), &out->nbrs))) return rc;
         if ((rc = up(h.rho_out.data(), h.rho_out.size() * sizeof(float), (void**)&out->rho_out))) return rc;
+        if ((rc = up(h.twin.data(), h.twin.size() * sizeof(int32_t), (void**)&out->twin))) return rc;
     }
     out->levels = h.levels;
     out->K = K;
@@ -297,6 +313,7 @@ static TreeView<KD> view_of(const midas_tree* t) {
     v.inv_perm = t->inv_perm;
     v.nbrs = (const Nbr6*)t->nbrs;
     v.rho_out = t->rho_out;
+    v.twin = t->twin;
     v.levels = t->levels;
     v.K = t->K;
     return v;
@@ -536,6 +553,8 @@ MD bool wave_search(const TreeView<KD>& tv, const typename KD::T* q, typename KD
 // carries a 3e-5 relative margin on squared distances, two orders above float32 rounding of the
 // six-term sums, so "certified" also holds for the COMPUTED distances and their tie rule.
 // Returns true when certified; otherwise (best, bi) is a valid bound for the tree search.
+constexpr int SCAN_BATCH = 8;  // records fetched per round trip of the list scans (NBR_M, MESH_M are multiples)
+
 MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t h, float& best, int64_t& bi, int* n_scanned) {
     const Nbr6* nb = tv.nbrs + (size_t)h * NBR_REC;
     {
@@ -550,12 +569,12 @@ MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t h, float&
     const float rslack = -8e-7f * r;
     int scanned = 0;
     bool certified = false;
-    for (int s0 = 1; s0 <= NBR_M && !certified; s0 += 4) {
-        Nbr6 e[4];
+    for (int s0 = 1; s0 <= NBR_M && !certified; s0 += SCAN_BATCH) {
+        Nbr6 e[SCAN_BATCH];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) e[j] = nb[s0 + j];
+        for (int j = 0; j < SCAN_BATCH; ++j) e[j] = nb[s0 + j];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < SCAN_BATCH; ++j) {
             if (!certified) {
                 // lower bound of |q - F| for this and every later record, with slack for the rounding of r and rho
                 const float g = fmaf_(e[j].rho - r, 0.9999996f, rslack);
@@ -591,12 +610,12 @@ MD int mesh_list_check(const MeshRec* __restrict__ vlist, int32_t h, const doubl
     ph.c[0] = hd.c[0]; ph.c[1] = hd.c[1]; ph.c[2] = hd.c[2];
     const double delta = __builtin_sqrt(dist2(tq, ph)) * (1.0 + 1e-12);
     const double lim = thr * (1.0 + 1e-9) + delta + 1e-12;  // a vertex with rho*(1-1e-7) > lim cannot be within thr of tq
-    for (int s0 = 1; s0 <= MESH_M; s0 += 4) {
-        MeshRec e[4];
+    for (int s0 = 1; s0 <= MESH_M; s0 += SCAN_BATCH) {
+        MeshRec e[SCAN_BATCH];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) e[j] = vl[s0 + j];
+        for (int j = 0; j < SCAN_BATCH; ++j) e[j] = vl[s0 + j];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < SCAN_BATCH; ++j) {
             if ((double)e[j].rho * (1.0 - 1e-7) > lim) return 0;
             Point3 p;
             p.c[0] = e[j].c[0]; p.c[1] = e[j].c[1]; p.c[2] = e[j].c[2];
@@ -614,7 +633,18 @@ MD bool nn6_wave(const TreeView<Kd6>& tv, const float* q, bool live, int32_t hin
     float best = INFINITY;
     int64_t bi = 0;
     bool done = !live;
-    if (live && hint >= 0 && (int64_t)hint < tv.K) done = nn6_hint_scan(tv, q, hint, best, bi, n_scanned);
+    if (live && hint >= 0 && (int64_t)hint < tv.K) {
+        done = nn6_hint_scan(tv, q, hint, best, bi, n_scanned);
+        if (!done) {  // second chance from the entry across the angle-pi cut
+            const int32_t tw = tv.twin[hint];
+            if (tw >= 0) {
+                float b2;
+                int64_t i2;
+                if (nn6_hint_scan(tv, q, tw, b2, i2, nullptr)) { best = b2; bi = i2; done = true; }
+                else if (b2 < best || (b2 == best && i2 < bi)) { best = b2; bi = i2; }
+            }
+        }
+    }
     wave_search<Kd6, false, STATS>(tv, q, best, bi, !done, cd, n_leaves, n_nodes);
     idx = (int32_t)bi;
     d2 = best;
@@ -879,6 +909,7 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
         a.nn_idx[n] = bi;
         x = a.scores[bi];
         a.x[n] = x;
+        a.e[n] = exp(x - 1.0);
         a.valid[n] = ok ? 1 : 0;
         if (a.gt16) {
             float G[16];

@@ -290,14 +290,15 @@ __global__ __launch_bounds__(256) void k_gather_rows(int64_t M, const int32_t* _
 // [block_base, block_base + nb_local) of the summation spec; arrays suffixed _all span every shard.
 // Single GPU: slot_base = block_base = 0 and the _all arrays are the local ones.
 
-// TA: m = max over all partial maxima ; e = exp(x - m) (or x) -> e_out ; em = e * valid ;
+// TA: e = exp(x - 1) comes from the particle update (x replaces it when the isclose guard skips the softmax);
+//     em = e * valid ;
 //     block-local prefix of em -> lp_out ; local block totals of e (softmax denominator) and of em
 //     (CDF total) ; status[0] = 2 on NaN ; status[1] = particles kept.
 //     The CDF is built from e*valid directly: the softmax normalisation cancels in prefix / total.
 __global__ __launch_bounds__(256) void k_tail_a(int64_t N, const double* __restrict__ x, const uint8_t* __restrict__ valid,
                                                 int np, const double* __restrict__ pmax_all,
                                                 const double* __restrict__ pmin_all, int32_t softmax,
-                                                double* __restrict__ e_out, double* __restrict__ lp_out,
+                                                double* __restrict__ e_io, double* __restrict__ lp_out,
                                                 double* __restrict__ block_sums_e, double* __restrict__ block_totals_em,
                                                 int32_t* __restrict__ flag, int32_t* __restrict__ status) {
     __shared__ double s_red[24];
@@ -315,9 +316,8 @@ __global__ __launch_bounds__(256) void k_tail_a(int64_t N, const double* __restr
         const int64_t i = base + j;
         double e = 0.0, em = 0.0;
         if (i < N) {
-            const double xi = x[i];
-            e = apply ? exp(xi - mx) : xi;
-            e_out[i] = e;
+            if (apply) e = e_io[i];
+            else { e = x[i]; e_io[i] = e; }
             const bool ok = valid[i] != 0;
             em = e * (ok ? 1.0 : 0.0);
             kept += ok ? 1 : 0;
@@ -635,10 +635,10 @@ int launch_gather_rows(midas_ctx* ctx, int64_t M, const int32_t* idx, const void
 }
 
 int launch_tail_a(midas_ctx* ctx, int64_t N, const double* x, const uint8_t* valid, int np, const double* pmax_all,
-                  const double* pmin_all, int32_t softmax, double* e_out, double* lp_out, double* block_sums_e,
+                  const double* pmin_all, int32_t softmax, double* e_io, double* lp_out, double* block_sums_e,
                   double* block_totals_em, int32_t* flag, int32_t* status) {
     hipLaunchKernelGGL(k_tail_a, dim3((unsigned)ceil_div(N, SCAN_BLOCK)), dim3(256), 0, ctx->stream, N, x, valid, np, pmax_all,
-                       pmin_all, softmax, e_out, lp_out, block_sums_e, block_totals_em, flag, status);
+                       pmin_all, softmax, e_io, lp_out, block_sums_e, block_totals_em, flag, status);
     LAUNCH_CHECK(ctx);
     return MIDAS_OK;
 }
@@ -671,12 +671,12 @@ int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base) 
     const int nb = (int)ceil_div(a.N, SCAN_BLOCK);
     if (nb > TB_MAX_BLOCKS) return midas_set_error(ctx, MIDAS_ERR_INVALID, "N", "more than 4 M particles per GPU: shard them");
     void* sc;
-    int rc = midas_scratch(ctx, (size_t)nb * 2 * sizeof(double) + (size_t)a.N * sizeof(double) + 64, &sc);
+    int rc = midas_scratch(ctx, (size_t)nb * 2 * sizeof(double) + 64, &sc);
     if (rc) return rc;
     double* psum = (double*)sc;
     double* pw = psum + nb;
-    double* e = pw + nb;
-    int32_t* flag = (int32_t*)(e + a.N);
+    double* e = a.e;
+    int32_t* flag = (int32_t*)(pw + nb);
     if ((rc = launch_tail_a(ctx, a.N, a.x, a.valid, a.npart, a.part_max, a.part_min, a.softmax, e, a.cdf, psum, pw, flag, a.status)))
         return rc;
     prof_mark(ctx, prof_slot_base + 1);

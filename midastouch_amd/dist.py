@@ -56,7 +56,7 @@ class HipShardBackend:
         a.N, a.slot_base = st.N, st.slot_base
         a.poses_in, a.poses_prop = _ptr(st.poses), _ptr(st.poses_prop)
         a.hint_in = _ptr(st.hint) if use_hint else None
-        a.nn_idx, a.x, a.valid, a.extrema = _ptr(st.nn_idx), _ptr(st.x), _ptr(st.valid), _ptr(st.g1[:2])
+        a.nn_idx, a.x, a.e, a.valid, a.extrema = _ptr(st.nn_idx), _ptr(st.x), _ptr(st.e), _ptr(st.valid), _ptr(st.g1[:2])
         a.odom16, a.code, a.gt16 = _ptr(odom), _ptr(code), _ptr(gt)
         a.rmse_sums = _ptr(st.g1[2:]) if gt is not None else None
         a.tn, a.rot = _ptr(tn), _ptr(rot)

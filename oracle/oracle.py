@@ -187,15 +187,20 @@ def softmax_weights(x, softmax: bool = True):
     return w, bool(applied)
 
 
-def softmax_numerators(x, softmax: bool = True):
-    """e = exp(x - max(x)) (libm exp), or x itself when the softmax is skipped; returns (e, applied)."""
+def softmax_numerators(x, softmax: bool = True, shift=None):
+    """e = exp(x - shift) (libm exp), or x itself when the softmax is skipped; returns (e, applied).
+
+    shift None -> max(x) (torch's Softmax).  The fused step uses the constant shift 1.0: the scores are
+    cosines (<= 1), the softmax is shift-invariant, and a constant lets every particle take its exponential
+    without waiting for a global maximum (csrc/particles.hip k_particle_update)."""
     import math
     x = _f64(x).ravel()
     mx, mn = float(np.max(x)), float(np.min(x))
     applied = bool(softmax) and not (abs(mx - mn) <= 1e-8)
     if not applied:
         return x.copy(), False
-    return np.array([math.exp(v) for v in (x - mx)], dtype=np.float64), True
+    c = mx if shift is None else float(shift)
+    return np.array([math.exp(v) for v in (x - c)], dtype=np.float64), True
 
 
 def get_similarity(code, targets, softmax: bool = True):
@@ -366,10 +371,10 @@ class OracleFilter:
         dist = nn3_dist(p1, self.verts)
         mask = ~(dist > self.pen_max)
         out["dist"], out["mask"] = dist, mask
-        # fused-step spec (csrc/resample.hip k_tail_a/k_tail_b): e = exp(x - max) (or x when the softmax is
+        # fused-step spec (csrc/resample.hip k_tail_a/k_tail_b): e = exp(x - 1) (or x when the softmax is
         # skipped); weights = e / blocked_sum(e) * mask; the CDF is built from e * mask directly - the
         # normalisation by sum(e) cancels in prefix / total
-        e, applied = softmax_numerators(x, softmax)
+        e, applied = softmax_numerators(x, softmax, shift=1.0)
         S = blocked_scan(e)[1] if applied else 1.0
         w_pre = e / S
         out["weights_pre"] = w_pre.copy()

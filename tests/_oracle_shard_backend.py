@@ -46,6 +46,7 @@ class OracleShardBackend:
         st.poses_prop.copy_(torch.as_tensor(p1))
         st.nn_idx.copy_(torch.as_tensor(idx))
         st.x.copy_(torch.as_tensor(x))
+        st.e.copy_(torch.as_tensor(np.array([math.exp(v) for v in (x - 1.0)])))  # glibc exp, constant shift 1
         st.valid.copy_(torch.as_tensor((~(dist > prune_thr)).astype(np.uint8)))
         st.g1[0], st.g1[1] = float(x.max()), float(x.min())
         if gt is not None:
@@ -56,8 +57,7 @@ class OracleShardBackend:
         mx, mn = float(pmax_all.max()), float(pmin_all.min())
         apply = bool(softmax) and not (abs(mx - mn) <= 1e-8)
         x = st.x.numpy()
-        # math.exp is glibc's exp, the function the C oracle calls (numpy's vectorised exp can differ by an ulp)
-        e = np.array([math.exp(v) for v in (x - mx)]) if apply else x.copy()
+        e = st.e.numpy().copy() if apply else x.copy()
         valid = st.valid.numpy().astype(bool)
         em = e * valid
         st.e.copy_(torch.as_tensor(e))
