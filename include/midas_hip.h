@@ -65,6 +65,13 @@ int midas_codebook_destroy(midas_codebook* cb);
 int midas_score(midas_ctx* ctx, const midas_codebook* cb, int32_t B, const double* codes_dev,
                 double* scores_dev);
 
+/* Batched form for B concurrent trajectories (BASELINE config 5): one pass over the codebook on the matrix
+ * cores (v_mfma_f32_16x16x4_f32).  The codes are rounded to float32 (they are float32 network outputs) and
+ * the dot products are float32 fma chains in a fixed order, then divided by the float64 norms:
+ * scores agree with midas_score to ~1e-7.  Needs float32 embeddings and D % 16 == 0. */
+int midas_score_batch(midas_ctx* ctx, const midas_codebook* cb, int32_t B, const double* codes_dev,
+                      double* scores_dev);
+
 /* ---- SE(3) feature and exact nearest neighbour  (K3, K4) ------------------------------------- */
 /* feat6 = [ (1-w) t , w log(R) ]  - R3_SE3 (tactile_tree/tactile_tree.py:73-77, modules/pose.py:19-23) */
 int midas_se3_feature(midas_ctx* ctx, int64_t N, const float* poses_dev, float w, float* feat6_dev);

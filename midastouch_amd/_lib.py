@@ -97,6 +97,7 @@ SIGNATURES = {
     "midas_codebook_create": (C.c_int, [_P, _I64, _I32, _P, _I32, C.POINTER(_P)]),
     "midas_codebook_destroy": (C.c_int, [_P]),
     "midas_score": (C.c_int, [_P, _P, _I32, _P, _P]),
+    "midas_score_batch": (C.c_int, [_P, _P, _I32, _P, _P]),
     "midas_se3_feature": (C.c_int, [_P, _I64, _P, _F, _P]),
     "midas_tree_build": (C.c_int, [_P, _I32, _I64, _P, C.POINTER(_P)]),
     "midas_tree_destroy": (C.c_int, [_P]),

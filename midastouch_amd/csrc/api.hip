@@ -181,6 +181,13 @@ MIDAS_EXPORT int midas_score(midas_ctx* ctx, const midas_codebook* cb, int32_t B
     return launch_score(ctx, cb, B, codes_dev, scores_dev);
 }
 
+MIDAS_EXPORT int midas_score_batch(midas_ctx* ctx, const midas_codebook* cb, int32_t B, const double* codes_dev,
+                                   double* scores_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, cb && B >= 1 && codes_dev && scores_dev);
+    return launch_score_batch(ctx, cb, B, codes_dev, scores_dev);
+}
+
 // ---- features / trees ----------------------------------------------------------------------------
 MIDAS_EXPORT int midas_se3_feature(midas_ctx* ctx, int64_t N, const float* poses_dev, float w, float* feat6_dev) {
     MIDAS_ENTER(ctx);

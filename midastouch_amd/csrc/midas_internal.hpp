@@ -136,6 +136,7 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // score.hip
 int launch_row_norms(midas_ctx* ctx, int64_t K, int32_t D, const void* emb, int32_t dtype, double* norms);
 int launch_score(midas_ctx* ctx, const midas_codebook* cb, int32_t B, const double* codes, double* scores);
+int launch_score_batch(midas_ctx* ctx, const midas_codebook* cb, int32_t B, const double* codes, double* scores);
 
 // particles.hip
 int launch_se3_feature(midas_ctx* ctx, int64_t N, const float* poses, float w, float* feat6);

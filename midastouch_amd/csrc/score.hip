@@ -163,4 +163,126 @@ int launch_score(midas_ctx* ctx, const midas_codebook* cb, int32_t B, const doub
     return MIDAS_OK;
 }
 
+// ================================================================================================
+// Batched scoring on the matrix cores: scores[b][k] for B tactile codes in ONE pass over the codebook
+// ================================================================================================
+// S = C (K x D) . E^T (D x B) as a float32 GEMM on v_mfma_f32_16x16x4_f32 (exact f32 fma chains at the f32
+// vector rate; bf16/fp8 would lose the bits the softmax weights need).  Tile: a wave owns 16 codebook rows
+// (MFMA M) x up to 64 codes (4 N-tiles of 16, 16 accumulator registers); the reduction runs over D in
+// chunks of 16: each lane fetches ONE float4 of its row (A operand: lane (g = l>>4, i = l&15) holds
+// C[row0+i][16c+4g .. +3], so a wave-level load reads 16 rows x 64 contiguous bytes) and feeds its four
+// components to four consecutive MFMAs; the codes sit in LDS as float32 with the same (g, n) ownership.
+// Accumulation order (the spec the oracle restates, mo_score_batch_f32): for c, for s in 0..3, for g in
+// 0..3: acc = fmaf(C[k][16c+4g+s], E[b][16c+4g+s], acc).  Epilogue: float64 division by the norms.
+// HBM: K*D*4 bytes once (102 MB at c2) vs B times for the GEMV loop; MFMA: 2*K*D*B flop.
+constexpr int MF_ROWS_PER_WAVE = 16;
+constexpr int MF_WAVES = 16;   // 1024-thread workgroups: four waves per SIMD share one staged copy of the codes
+constexpr int MF_CODES = 64;   // codes per pass (4 N-tiles)
+constexpr int MF_DC = 512;     // D-chunk staged in LDS
+constexpr int MF_PAD = 4;      // floats of padding per staged code row (bank spread)
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// codes (B x D float64) -> float32 rows padded to a multiple of 64 codes (zeros), row stride D
+__global__ __launch_bounds__(256) void k_codes_to_f32(const double* __restrict__ codes, float* __restrict__ out, int B,
+                                                      int Bpad, int D) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < (int64_t)Bpad * D) {
+        const int b = (int)(idx / D);
+        out[idx] = b < B ? (float)codes[idx] : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_score_mfma(const float* __restrict__ emb, const double* __restrict__ norms,
+                                                     const float* __restrict__ codes32, const double* __restrict__ code_norms,
+                                                     double* __restrict__ out, int64_t K, int D, int B, int b0) {
+    extern __shared__ __attribute__((aligned(16))) float s_e[];  // [MF_CODES][dc + MF_PAD]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int64_t row0 = ((int64_t)blockIdx.x * MF_WAVES + wave) * MF_ROWS_PER_WAVE;
+    const int nb = B - b0 < MF_CODES ? B - b0 : MF_CODES;  // codes of this pass
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t row = row0 + i < K ? row0 + i : K - 1;  // clamp: surplus rows are computed and dropped
+    const float* arow = emb + row * (int64_t)D;
+    for (int d0 = 0; d0 < D; d0 += MF_DC) {
+        const int dc = D - d0 < MF_DC ? D - d0 : MF_DC;
+        const int ld = dc + MF_PAD;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < MF_CODES * (dc / 4); idx += 1024) {  // stage this D-chunk of the 64 codes
+            const int b = idx / (dc / 4), d = (idx - b * (dc / 4)) * 4;
+            *reinterpret_cast<float4*>(&s_e[b * ld + d]) =
+                *reinterpret_cast<const float4*>(&codes32[(int64_t)(b0 + b) * D + d0 + d]);
+        }
+        __syncthreads();
+        for (int c = 0; c < dc; c += 16) {
+            const float4 a = *reinterpret_cast<const float4*>(arow + d0 + c + 4 * g);
+            float4 e[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) e[t] = *reinterpret_cast<const float4*>(&s_e[(16 * t + i) * ld + c + 4 * g]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, e[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, e[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, e[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, e[t].w, acc[t], 0, 0, 0);
+        }
+    }
+    // D[row = 4g + r][code = i] in register r of lane (g, i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int b = 16 * t + i;
+        if (b < nb) {
+            const double ne = code_norms[b0 + b];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t k = row0 + 4 * g + r;
+                if (k < K) out[(int64_t)(b0 + b) * K + k] = (double)acc[t][r] / (ne * norms[k]);
+            }
+        }
+    }
+}
+
+// max(|e_b|, eps) of every code, float64, one quarter-wave per code
+__global__ __launch_bounds__(256) void k_code_norms(const double* __restrict__ codes, double* __restrict__ out, int B, int D) {
+    const int lane = threadIdx.x & 63, s = lane & 15;
+    const int b = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    double acc = 0.0;
+    if (b < B)
+        for (int j = s; j < D; j += 16) { const double v = codes[(int64_t)b * D + j]; acc = fma_(v, v, acc); }
+    acc = quarter_reduce(acc);
+    if (b < B && s == 0) { const double n = __builtin_sqrt(acc); out[b] = n < COS_EPS ? COS_EPS : n; }
+}
+
+int launch_score_batch(midas_ctx* ctx, const midas_codebook* cb, int32_t B, const double* codes, double* scores) {
+    if (cb->dtype != MIDAS_F32 || cb->D % 16 != 0 || (uintptr_t)cb->emb % 16 != 0)
+        return midas_set_error(ctx, MIDAS_ERR_INVALID, "midas_score_batch", "needs float32 embeddings with D % 16 == 0");
+    const int D = cb->D;
+    const int Bpad = (int)ceil_div(B, MF_CODES) * MF_CODES;
+    void *cn, *c32;
+    int rc = midas_scratch(ctx, (size_t)B * sizeof(double), &cn);
+    if (rc) return rc;
+    if ((rc = midas_scratch(ctx, (size_t)Bpad * D * sizeof(float), &c32))) return rc;
+    hipLaunchKernelGGL(k_code_norms, dim3((unsigned)ceil_div(B, 16)), dim3(256), 0, ctx->stream, codes, (double*)cn, B, D);
+    hipLaunchKernelGGL(k_codes_to_f32, dim3((unsigned)ceil_div((int64_t)Bpad * D, 256)), dim3(256), 0, ctx->stream, codes,
+                       (float*)c32, B, Bpad, D);
+    const int dc = D < MF_DC ? D : MF_DC;
+    const size_t lds = (size_t)MF_CODES * (dc + MF_PAD) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        MIDAS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_score_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)ceil_div(cb->K, MF_ROWS_PER_WAVE * MF_WAVES);
+    for (int b0 = 0; b0 < B; b0 += MF_CODES) {
+        hipLaunchKernelGGL(k_score_mfma, dim3(grid), dim3(1024), lds, ctx->stream, (const float*)cb->emb, cb->norms,
+                           (const float*)c32, (const double*)cn, scores, cb->K, D, B, b0);
+    }
+    MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    return MIDAS_OK;
+}
+
 }  // namespace midas

@@ -57,6 +57,15 @@ class Codebook:
         self.ctx.call("midas_score", self.h, codes.shape[0], _ptr(codes), _ptr(out))
         return out
 
+    def score_batch(self, codes: torch.Tensor) -> torch.Tensor:
+        """(B, K) scores of B codes in one pass over the codebook on the matrix cores (float32 fma chains)."""
+        codes = torch.atleast_2d(codes).to(self.emb.device, torch.float64).contiguous()
+        if codes.shape[1] != self.D:
+            raise MidasError(f"tactile code has {codes.shape[1]} dims, codebook has {self.D}")
+        out = torch.empty((codes.shape[0], self.K), dtype=torch.float64, device=self.emb.device)
+        self.ctx.call("midas_score_batch", self.h, codes.shape[0], _ptr(codes), _ptr(out))
+        return out
+
     def __del__(self):  # pragma: no cover
         try:
             if self.h:

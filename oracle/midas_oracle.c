@@ -421,6 +421,37 @@ MO_API void mo_score_f64(int64_t K, int64_t D, const double* emb, const double* 
     }
 }
 
+/*
+ * Batched scoring spec (the MFMA kernel k_score_mfma): the code is rounded to float32 and the dot product is
+ * a float32 fma chain in the order of the matrix-core schedule - D in chunks of 16; inside a chunk the four
+ * components s of a lane's float4, and for each the four k-slots g of v_mfma_f32_16x16x4_f32:
+ * d = 16c + 4g + s.  The division by the float64 norms is as in mo_score_f32.
+ */
+MO_API void mo_score_batch_f32(int64_t K, int64_t D, int64_t B, const float* emb, const double* codes, double* scores) {
+    for (int64_t b = 0; b < B; ++b) {
+        const double* code = codes + b * D;
+        double ne = 0.0;
+        for (int64_t j = 0; j < D; ++j) ne = fma(code[j], code[j], ne);
+        ne = sqrt(ne);
+        if (ne < 1e-8) ne = 1e-8;
+        for (int64_t k = 0; k < K; ++k) {
+            const float* row = emb + k * D;
+            float acc = 0.0f;
+            double nr = 0.0;
+            for (int64_t c = 0; c < D; c += 16)
+                for (int s2 = 0; s2 < 4; ++s2)
+                    for (int g = 0; g < 4; ++g) {
+                        int64_t d = c + 4 * g + s2;
+                        acc = fmaf(row[d], (float)code[d], acc);
+                    }
+            for (int64_t j = 0; j < D; ++j) nr += (double)row[j] * (double)row[j];
+            nr = sqrt(nr);
+            if (nr < 1e-8) nr = 1e-8;
+            scores[b * K + k] = (double)acc / (ne * nr);
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* float64 blocked scan (the summation-order spec)                                            */
 /* ------------------------------------------------------------------------------------------ */

@@ -180,6 +180,16 @@ def score_codebook(emb, code):
     return out
 
 
+def score_codebook_batch(emb, codes):
+    """Batched scoring spec of the MFMA kernel: float32 fma chains in the matrix-core order -> (B, K) float64."""
+    emb = np.ascontiguousarray(emb, dtype=np.float32)
+    codes = _f64(np.atleast_2d(codes))
+    out = np.empty((codes.shape[0], emb.shape[0]), dtype=np.float64)
+    lib().mo_score_batch_f32(C.c_int64(emb.shape[0]), C.c_int64(emb.shape[1]), C.c_int64(codes.shape[0]), _p(emb),
+                             _p(codes), _p(out))
+    return out
+
+
 def softmax_weights(x, softmax: bool = True):
     x = _f64(x).ravel()
     w = np.empty_like(x)

@@ -159,6 +159,25 @@ def test_score_codebook(dev, ops, oracle, D):
         np.testing.assert_allclose(sb[b], oracle.score_codebook(E, codes[b]), rtol=1e-12, atol=1e-13)
 
 
+@pytest.mark.parametrize("K,D,B", [(3001, 512, 64), (1000, 256, 16), (517, 1024, 70), (64, 512, 1), (4096, 512, 33)])
+def test_score_batch_mfma(dev, ops, oracle, K, D, B):
+    """Batched scoring on the matrix cores: float32 fma chains in the documented order, restated by the oracle
+    (numerators bit-identical; the float64 norms differ by an ulp of summation order) and within float32
+    rounding of the float64 GEMV path."""
+    rng = np.random.default_rng(K + D + B)
+    E = rng.standard_normal((K, D)).astype(np.float32)
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    codes = rng.standard_normal((B, D)).astype(np.float32).astype(np.float64)
+    codes /= np.linalg.norm(codes, axis=1, keepdims=True)
+    codes = codes.astype(np.float32).astype(np.float64)
+    cbk = ops.Codebook(T(E, dev))
+    sb = cbk.score_batch(T(codes, dev)).cpu().numpy()
+    ref = oracle.score_codebook_batch(E, codes)
+    np.testing.assert_allclose(sb, ref, rtol=1e-14, atol=0)
+    s64 = cbk.score(T(codes, dev)).cpu().numpy()
+    assert np.max(np.abs(sb - s64)) < 2e-6
+
+
 def test_score_golden(dev, ops, golden):
     g = golden("g1_similarity")
     for tag in ("a", "b"):
