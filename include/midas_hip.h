@@ -225,20 +225,22 @@ int midas_tail_fin(midas_ctx* ctx, int64_t N, const double* e_dev, const uint8_t
                    double* cdf_dev, int32_t nb_all, const double* block_sums_all_dev,
                    const double* block_totals_all_dev, int32_t block_base, int32_t is_last,
                    const int32_t* flag_dev, int32_t* status_dev);
+/* The cross-rank resample reads any shard's particles from ONE gathered buffer: every rank contributes a
+ * record block of rank_stride bytes laid out as
+ *     [ cdf: n x f64 | weights: n x f64 | propagated poses: n x 16 f32 | nn_idx: n x i32 ]   (n = n_per_rank,
+ * even; rank_stride >= 84 n and a multiple of 16), blocks in rank order (torch.distributed all_gather). */
 typedef struct midas_tail_resample_args {
     int64_t N, N_all, slot_base;
-    const double* cdf_all_dev;      /* N_all */
+    const void* pack_all_dev;       /* world x rank_stride bytes */
+    int64_t rank_stride, n_per_rank;
     const int32_t* status_dev;      /* [0] != 0 -> identity resample */
     int32_t mode;
     const double* u_dev;            /* N local uniforms or NULL -> Philox keyed by the global slot */
     float u32;
     uint64_t seed, step;
     int32_t* ridx_dev;              /* N out: GLOBAL source index of each local slot */
-    const float* poses_all_dev;     /* N_all x 16 propagated poses of every shard */
     float* poses_out_dev;           /* N x 16 */
-    const double* weights_all_dev;  /* N_all */
     double* weights_out_dev;        /* N */
-    const int32_t* nn_all_dev;      /* N_all */
     int32_t* hint_out_dev;          /* N */
 } midas_tail_resample_args;
 int midas_tail_resample(midas_ctx* ctx, const midas_tail_resample_args* args);
@@ -247,6 +249,7 @@ int midas_tail_resample(midas_ctx* ctx, const midas_tail_resample_args* args);
  * kernel of the step is bracketed by events; midas_profile_read synchronises and returns the
  * accumulated milliseconds per kernel slot since the last reset. */
 #define MIDAS_PROF_SLOTS 8
+/* on: 0 = off, 1 = bracket every kernel, 2 + k = bracket only kernel slot k (least perturbation) */
 int midas_profile_enable(midas_ctx* ctx, int32_t on);
 int midas_profile_read(midas_ctx* ctx, double* ms_out /*MIDAS_PROF_SLOTS*/, int64_t* calls_out,
                        int32_t reset);

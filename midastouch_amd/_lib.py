@@ -77,10 +77,10 @@ class TailResampleArgs(C.Structure):
 
     _fields_ = [
         ("N", C.c_int64), ("N_all", C.c_int64), ("slot_base", C.c_int64),
-        ("cdf_all", C.c_void_p), ("status", C.c_void_p), ("mode", C.c_int32), ("u", C.c_void_p), ("u32", C.c_float),
+        ("pack_all", C.c_void_p), ("rank_stride", C.c_int64), ("n_per_rank", C.c_int64),
+        ("status", C.c_void_p), ("mode", C.c_int32), ("u", C.c_void_p), ("u32", C.c_float),
         ("seed", C.c_uint64), ("step", C.c_uint64), ("ridx", C.c_void_p),
-        ("poses_all", C.c_void_p), ("poses_out", C.c_void_p), ("weights_all", C.c_void_p), ("weights_out", C.c_void_p),
-        ("nn_all", C.c_void_p), ("hint_out", C.c_void_p),
+        ("poses_out", C.c_void_p), ("weights_out", C.c_void_p), ("hint_out", C.c_void_p),
     ]
 
 

@@ -64,12 +64,16 @@ int midas_set_error(midas_ctx* ctx, int code, const char* what, const char* deta
 
 namespace midas {
 void prof_mark(midas_ctx* ctx, int slot) {
-    if (ctx->prof && ctx->ev_ready && slot <= MIDAS_PROF_SLOTS) (void)hipEventRecord(ctx->ev[slot], ctx->stream);
+    if (!ctx->prof || !ctx->ev_ready || slot > MIDAS_PROF_SLOTS) return;
+    // prof_only >= 0: bracket a single kernel (events slot and slot+1 only) so that the other kernels run
+    // back to back as in an untimed frame
+    if (ctx->prof_only >= 0 && slot != ctx->prof_only && slot != ctx->prof_only + 1) return;
+    (void)hipEventRecord(ctx->ev[slot], ctx->stream);
 }
 }  // namespace midas
 
 static const char* kSlotNames[MIDAS_PROF_SLOTS] = {
-    "score_codebook", "particle_update", "tail_a", "tail_b", "", "", "", ""};
+    "score_codebook", "particle_update", "tail_a", "tail_b", "", "", "", "event_pair_overhead"};
 
 // entry guard: bind the device, reset the scratch bump pointer
 #define MIDAS_ENTER(ctx)                                                     \
@@ -353,6 +357,10 @@ MIDAS_EXPORT int midas_filter_step(midas_ctx* ctx, const midas_codebook* cb, con
         if ((rc = midas_scratch(ctx, (size_t)npart * 2 * sizeof(double), &prm))) return rc;
     if ((rc = midas_scratch(ctx, (size_t)N * sizeof(double), &cdf))) return rc;
 
+    if (ctx->prof && ctx->ev_ready) {  // calibration: an empty event pair measures the bracket overhead itself
+        (void)hipEventRecord(ctx->ev[6], ctx->stream);
+        (void)hipEventRecord(ctx->ev[7], ctx->stream);
+    }
     prof_mark(ctx, 0);
     if ((rc = launch_score(ctx, cb, 1, s.code_dev, (double*)scores))) return rc;
     prof_mark(ctx, 1);
@@ -414,12 +422,16 @@ MIDAS_EXPORT int midas_filter_step(midas_ctx* ctx, const midas_codebook* cb, con
     if ((rc = launch_step_tail(ctx, ta, 2))) return rc;
 
     if (ctx->prof && ctx->ev_ready) {
-        MIDAS_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev[4]));
-        for (int i = 0; i < 4; ++i) {
+        const int lo = ctx->prof_only >= 0 ? ctx->prof_only : 0, hi = ctx->prof_only >= 0 ? ctx->prof_only + 1 : 4;
+        MIDAS_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev[hi]));
+        for (int i = lo; i < hi; ++i) {
             float ms = 0.f;
             MIDAS_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
             ctx->prof_ms[i] += (double)ms;
         }
+        float cal = 0.f;
+        MIDAS_HIP_CHECK(ctx, hipEventElapsedTime(&cal, ctx->ev[6], ctx->ev[7]));
+        ctx->prof_ms[7] += (double)cal;
         ctx->prof_calls += 1;
     }
     return MIDAS_OK;
@@ -500,12 +512,13 @@ MIDAS_EXPORT int midas_tail_fin(midas_ctx* ctx, int64_t N, const double* e_dev, 
 
 MIDAS_EXPORT int midas_tail_resample(midas_ctx* ctx, const midas_tail_resample_args* args) {
     MIDAS_ENTER(ctx);
-    MIDAS_REQUIRE(ctx, args && args->N > 0 && args->N_all >= args->N && args->slot_base >= 0 &&
-                           args->slot_base + args->N <= args->N_all && args->cdf_all_dev && args->status_dev &&
-                           args->ridx_dev && args->poses_all_dev && args->poses_out_dev && args->weights_all_dev &&
-                           args->weights_out_dev && args->nn_all_dev && args->hint_out_dev);
+    MIDAS_REQUIRE(ctx, args && args->N > 0 && args->n_per_rank > 0 && args->N_all >= args->N && args->slot_base >= 0 &&
+                           args->slot_base + args->N <= args->N_all && args->pack_all_dev &&
+                           args->rank_stride >= 84 * args->n_per_rank && args->rank_stride % 16 == 0 &&
+                           args->n_per_rank % 2 == 0 && args->status_dev && args->ridx_dev && args->poses_out_dev &&
+                           args->weights_out_dev && args->hint_out_dev);
     MIDAS_REQUIRE(ctx, args->mode == MIDAS_RESAMPLE_MULTINOMIAL || args->mode == MIDAS_RESAMPLE_SYSTEMATIC);
-    return launch_tail_resample(ctx, *args, nullptr, 0, 1.0, nullptr);
+    return launch_tail_resample(ctx, *args);
 }
 
 // ---- profiling -----------------------------------------------------------------------------------
@@ -517,6 +530,7 @@ MIDAS_EXPORT int midas_profile_enable(midas_ctx* ctx, int32_t on) {
         ctx->ev_ready = true;
     }
     ctx->prof = on != 0;
+    ctx->prof_only = on >= 2 ? on - 2 : -1;  // 1: every kernel of the step; 2 + k: only kernel slot k
     return MIDAS_OK;
 }
 

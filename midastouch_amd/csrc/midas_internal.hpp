@@ -75,6 +75,7 @@ struct midas_ctx {
     std::string last_error;
     // profiling
     bool prof = false;
+    int prof_only = -1;
     hipEvent_t ev[MIDAS_PROF_SLOTS + 1] = {};
     bool ev_ready = false;
     double prof_ms[MIDAS_PROF_SLOTS] = {};
@@ -220,8 +221,7 @@ int launch_tail_a(midas_ctx* ctx, int64_t N, const double* x, const uint8_t* val
 int launch_tail_fin(midas_ctx* ctx, int64_t N, const double* e, const uint8_t* valid, double* weights, double* cdf_io,
                     int nb_all, const double* block_sums_all, const double* block_totals_all, int block_base,
                     int32_t is_last, const int32_t* flag, int32_t* status);
-int launch_tail_resample(midas_ctx* ctx, const midas_tail_resample_args& r, const double* part_rmse, int nrm,
-                         double rmse_count, double* rmse_out);
+int launch_tail_resample(midas_ctx* ctx, const midas_tail_resample_args& r);
 int launch_reduce_partials(midas_ctx* ctx, int np, const double* pmax, const double* pmin, const double* prm,
                            double* extrema2, double* rmse_sums2);
 

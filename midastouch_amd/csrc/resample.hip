@@ -58,6 +58,21 @@ MD double block_scan(const double* v, double* l, double* s_gtot) {
     return W;
 }
 
+// Block-cooperative version of seq_totals: the partials are fetched in parallel into LDS (one round trip
+// instead of nb dependent ones), then every thread adds them in order from LDS.  s_buf holds >= nb doubles.
+MD void seq_totals_lds(const double* __restrict__ part, int nb, int b, double* s_buf, double& bp, double& total) {
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) s_buf[i] = part[i];
+    __syncthreads();
+    double acc = 0.0, pre = 0.0;
+    for (int i = 0; i < nb; ++i) {
+        if (i == b) pre = acc;
+        acc = acc + s_buf[i];
+    }
+    bp = pre;
+    total = acc;
+    __syncthreads();
+}
+
 // sequential sum of per-block totals part[0..nb), exclusive prefix up to `b` returned in bp
 MD void seq_totals(const double* __restrict__ part, int nb, int b, double& bp, double& total) {
     double acc = 0.0, pre = 0.0;
@@ -340,6 +355,8 @@ __global__ __launch_bounds__(256) void k_tail_a(int64_t N, const double* __restr
     if ((threadIdx.x & 63) == 0 && kept) atomicAdd(&status[1], kept);
 }
 
+constexpr int TB_MAX_BLOCKS = 1024;  // 4 M particles (per GPU in the fused step, in total in the sharded step)
+
 // TF (sharded path): weights = e / S * valid ; cdf = (BP + lp) / total with S, BP, total summed
 //     sequentially over ALL shards' block partials ; the globally last slot is forced to 1.
 __global__ __launch_bounds__(256) void k_tail_fin(int64_t N, const double* __restrict__ e, const uint8_t* __restrict__ valid,
@@ -348,9 +365,10 @@ __global__ __launch_bounds__(256) void k_tail_fin(int64_t N, const double* __res
                                                   const double* __restrict__ block_totals_all, int block_base,
                                                   int32_t is_last, const int32_t* __restrict__ flag,
                                                   int32_t* __restrict__ status) {
+    __shared__ double s_buf[TB_MAX_BLOCKS];
     double bp, total, S = 1.0, dummy;
-    seq_totals(block_totals_all, nb_all, block_base + (int)blockIdx.x, bp, total);
-    if (flag[0]) seq_totals(block_sums_all, nb_all, 0, dummy, S);
+    seq_totals_lds(block_totals_all, nb_all, block_base + (int)blockIdx.x, s_buf, bp, total);
+    if (flag[0]) seq_totals_lds(block_sums_all, nb_all, 0, s_buf, dummy, S);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (total != total) atomicOr(&status[0], 2);
         else if (total == 0.0) atomicOr(&status[0], 1);
@@ -371,8 +389,6 @@ __global__ __launch_bounds__(256) void k_tail_fin(int64_t N, const double* __res
 // them: the block holding the draw is found in the LDS table, the slot by a 12-step search over the
 // block-local prefix with cdf(i) = (BP_b + lp_i) / total evaluated on the fly - the same values the
 // sharded path materialises, so both give identical indices.
-constexpr int TB_MAX_BLOCKS = 1024;  // 4 M particles per GPU
-
 MD double cdf_at(const double* __restrict__ lp, const double* s_bp, double total, int64_t i, int64_t N) {
     return (i == N - 1) ? 1.0 : (s_bp[i >> 12] + lp[i]) / total;
 }
@@ -407,14 +423,19 @@ __global__ __launch_bounds__(256) void k_tail_b(TailBArgs a) {
     __shared__ double s_bp[TB_MAX_BLOCKS];
     __shared__ double s_end[TB_MAX_BLOCKS];
     __shared__ double s_tot[2];
+    const bool apply = a.flag[0] != 0;
+    // fetch the block partials in parallel (s_bp <- totals of e*valid, s_end <- sums of e), then one thread
+    // turns them into the sequential prefixes the spec asks for - no dependent global loads
+    for (int b = threadIdx.x; b < a.nb; b += 256) { s_bp[b] = a.block_totals_em[b]; s_end[b] = a.block_sums_e[b]; }
+    __syncthreads();
     if (threadIdx.x == 0) {
         double acc = 0.0;
-        for (int b = 0; b < a.nb; ++b) { s_bp[b] = acc; acc = acc + a.block_totals_em[b]; }
+        for (int b = 0; b < a.nb; ++b) { const double w = s_bp[b]; s_bp[b] = acc; acc = acc + w; }
         s_tot[0] = acc;
         double S = 1.0;
-        if (a.flag[0]) {
+        if (apply) {
             S = 0.0;
-            for (int b = 0; b < a.nb; ++b) S = S + a.block_sums_e[b];
+            for (int b = 0; b < a.nb; ++b) S = S + s_end[b];
         }
         s_tot[1] = S;
     }
@@ -492,62 +513,75 @@ __global__ __launch_bounds__(256) void k_tail_b(TailBArgs a) {
     }
 }
 
-// T4: resample local slot i (global slot slot_base + i) from the GLOBAL cdf and gather pose / weight /
-//     hint rows from the global arrays; identity when the weights are unusable.  Optionally finishes the
-//     rmse epilogue from per-wave partial sums.
+// T4 (sharded path): resample local slot i (global slot slot_base + i) from the GLOBAL cdf and gather pose /
+//     weight / hint rows of any shard; identity when the weights are unusable.  The shards' data arrive as ONE
+//     all_gather of a packed per-rank record block:
+//        [ cdf: n x f64 | weights: n x f64 | poses: n x 16 f32 | nn_idx: n x i32 ]   (n = particles per rank)
+//     so global particle p lives in block p / n at row p % n.
+struct PackView {
+    const char* base;
+    int64_t stride;  // bytes between rank blocks
+    int64_t n;       // particles per rank
+    MD const char* blk(int64_t p, int64_t& row) const {
+        const int64_t r = p / n;
+        row = p - r * n;
+        return base + r * stride;
+    }
+    MD double cdf(int64_t p) const { int64_t row; const char* b = blk(p, row); return reinterpret_cast<const double*>(b)[row]; }
+    MD double weight(int64_t p) const { int64_t row; const char* b = blk(p, row); return reinterpret_cast<const double*>(b + 8 * n)[row]; }
+    MD const float4* pose(int64_t p) const { int64_t row; const char* b = blk(p, row); return reinterpret_cast<const float4*>(b + 16 * n) + 4 * row; }
+    MD int32_t nn(int64_t p) const { int64_t row; const char* b = blk(p, row); return reinterpret_cast<const int32_t*>(b + 80 * n)[row]; }
+};
+
 struct TailResampleArgs {
     int64_t N;            // local slots
-    int64_t N_all;        // global particles (length of cdf_all and of the *_all arrays)
+    int64_t N_all;        // global particles
     int64_t slot_base;
-    const double* cdf_all;
+    PackView pk;
     const int32_t* status;
     int32_t mode;
     const double* u;      // local uniforms or null
     float u32;
     uint64_t seed, step;
     int32_t* ridx;        // local out: global source index
-    const float* poses_all;
     float* poses_out;
-    const double* weights_all;
     double* weights_out;
-    const int32_t* nn_all;
     int32_t* hint_out;
-    const double* part_rmse;  // nullable: [2*nrm] per-wave partials
-    int nrm;
-    double rmse_count;        // number of particles behind the partials
-    double* rmse_out;
 };
 
 __global__ __launch_bounds__(256) void k_tail_resample(TailResampleArgs a) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < a.N) {
-        const int64_t slot = a.slot_base + i;
-        int32_t src = (int32_t)slot;
-        if (a.status[0] == 0) src = resample_slot(a.cdf_all, a.N_all, a.N_all, slot, a.mode, a.u ? a.u - a.slot_base : nullptr,
-                                                 a.u32, a.seed, a.step);
-        a.ridx[i] = src;
-        const float4* ps = reinterpret_cast<const float4*>(a.poses_all + (int64_t)src * 16);
-        float4* pd = reinterpret_cast<float4*>(a.poses_out + i * 16);
-        float4 r0 = ps[0], r1 = ps[1], r2 = ps[2], r3 = ps[3];
-        pd[0] = r0; pd[1] = r1; pd[2] = r2; pd[3] = r3;
-        a.weights_out[i] = a.weights_all[src];
-        a.hint_out[i] = a.nn_all[src];
-    }
-    if (a.part_rmse && blockIdx.x == 0) {
-        __shared__ double sa[4], sb[4];
-        double p = 0.0, q = 0.0;
-        for (int k = threadIdx.x; k < a.nrm; k += 256) { p += a.part_rmse[2 * k]; q += a.part_rmse[2 * k + 1]; }
-        p = wsum(p);
-        q = wsum(q);
-        if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = p; sb[threadIdx.x >> 6] = q; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            p = (sa[0] + sa[1]) + (sa[2] + sa[3]);
-            q = (sb[0] + sb[1]) + (sb[2] + sb[3]);
-            a.rmse_out[0] = __builtin_sqrt(p / a.rmse_count);
-            a.rmse_out[1] = __builtin_sqrt(q / a.rmse_count);
+    if (i >= a.N) return;
+    const int64_t slot = a.slot_base + i, N = a.N_all;
+    int64_t src = slot;
+    if (a.status[0] == 0) {
+        double t;
+        bool upper;
+        if (a.mode == MIDAS_RESAMPLE_MULTINOMIAL) {
+            t = a.u ? a.u[i] : philox_uniform53((uint64_t)slot, a.seed, a.step);
+            upper = false;
+        } else {
+            const float r = a.u32 >= 0.0f ? a.u32 : philox_uniform24(a.seed, a.step);
+            const float off = r / (float)N;
+            t = (double)slot / (double)N + (double)off;
+            t = t >= 1.0 ? t - 1.0 : t;
+            upper = true;
         }
+        int64_t lo = 0, hi = N;
+        while (hi > lo) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            const double c = a.pk.cdf(mid);
+            if (upper ? (c <= t) : (c < t)) lo = mid + 1; else hi = mid;
+        }
+        src = lo < N ? lo : N - 1;
     }
+    a.ridx[i] = (int32_t)src;
+    const float4* ps = a.pk.pose(src);
+    float4* pd = reinterpret_cast<float4*>(a.poses_out + i * 16);
+    float4 r0 = ps[0], r1 = ps[1], r2 = ps[2], r3 = ps[3];
+    pd[0] = r0; pd[1] = r1; pd[2] = r2; pd[3] = r3;
+    a.weights_out[i] = a.pk.weight(src);
+    a.hint_out[i] = a.pk.nn(src);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -646,22 +680,21 @@ int launch_tail_a(midas_ctx* ctx, int64_t N, const double* x, const uint8_t* val
 int launch_tail_fin(midas_ctx* ctx, int64_t N, const double* e, const uint8_t* valid, double* weights, double* cdf_io,
                     int nb_all, const double* block_sums_all, const double* block_totals_all, int block_base,
                     int32_t is_last, const int32_t* flag, int32_t* status) {
+    if (nb_all > TB_MAX_BLOCKS)
+        return midas_set_error(ctx, MIDAS_ERR_INVALID, "nb_all", "more than 4 M particles in total in the sharded step");
     hipLaunchKernelGGL(k_tail_fin, dim3((unsigned)ceil_div(N, SCAN_BLOCK)), dim3(256), 0, ctx->stream, N, e, valid, weights,
                        cdf_io, nb_all, block_sums_all, block_totals_all, block_base, is_last, flag, status);
     LAUNCH_CHECK(ctx);
     return MIDAS_OK;
 }
 
-int launch_tail_resample(midas_ctx* ctx, const midas_tail_resample_args& r, const double* part_rmse, int nrm,
-                         double rmse_count, double* rmse_out) {
+int launch_tail_resample(midas_ctx* ctx, const midas_tail_resample_args& r) {
     TailResampleArgs a;
     a.N = r.N; a.N_all = r.N_all; a.slot_base = r.slot_base;
-    a.cdf_all = r.cdf_all_dev; a.status = r.status_dev; a.mode = r.mode; a.u = r.u_dev; a.u32 = r.u32;
+    a.pk.base = (const char*)r.pack_all_dev; a.pk.stride = r.rank_stride; a.pk.n = r.n_per_rank;
+    a.status = r.status_dev; a.mode = r.mode; a.u = r.u_dev; a.u32 = r.u32;
     a.seed = r.seed; a.step = r.step; a.ridx = r.ridx_dev;
-    a.poses_all = r.poses_all_dev; a.poses_out = r.poses_out_dev;
-    a.weights_all = r.weights_all_dev; a.weights_out = r.weights_out_dev;
-    a.nn_all = r.nn_all_dev; a.hint_out = r.hint_out_dev;
-    a.part_rmse = part_rmse; a.nrm = nrm; a.rmse_count = rmse_count; a.rmse_out = rmse_out;
+    a.poses_out = r.poses_out_dev; a.weights_out = r.weights_out_dev; a.hint_out = r.hint_out_dev;
     hipLaunchKernelGGL(k_tail_resample, dim3((unsigned)ceil_div(r.N, 256)), dim3(256), 0, ctx->stream, a);
     LAUNCH_CHECK(ctx);
     return MIDAS_OK;

@@ -7,8 +7,8 @@ its global reductions; between the local kernels the ranks exchange, with `all_g
   G1  4 doubles/rank   max x, min x (softmax shift + isclose guard), rmse partial sums
   G2  2nb+2 doubles    block sums of exp(x - max) (softmax denominator), block totals of exp * mask
                        (CDF offsets / total), NaN flag, kept count - all in the fixed summation order
-  G4  N doubles/rank   the CDF slice     G5 N x 16 f32 propagated poses
-  G6  N doubles        masked weights    G7 N int32 NN indices      (resample reads any rank's particle)
+  G3  84 N bytes/rank  ONE packed record block [cdf | weights | propagated poses | NN indices]: the
+                       cross-rank resample reads any rank's particle from the gathered blocks
 
 The float64 summation order is the single-GPU one (per-block totals are gathered and every rank adds
 them sequentially in global block order), so with N a multiple of 4096 the sharded run reproduces the
@@ -76,14 +76,13 @@ class HipShardBackend:
                       block_sums_all.shape[0], _ptr(block_sums_all), _ptr(block_totals_all), block_base, int(is_last),
                       _ptr(st.flag), _ptr(st.status))
 
-    def tail_resample(self, st, cdf_all, poses_all, weights_all, nn_all, mode, u, u32, seed, step):
+    def tail_resample(self, st, pack_all, n_all, mode, u, u32, seed, step):
         a = TailResampleArgs()
-        a.N, a.N_all, a.slot_base = st.N, cdf_all.shape[0], st.slot_base
-        a.cdf_all, a.status, a.mode, a.u, a.u32 = _ptr(cdf_all), _ptr(st.status), mode, _ptr(u), float(u32)
+        a.N, a.N_all, a.slot_base = st.N, n_all, st.slot_base
+        a.pack_all, a.rank_stride, a.n_per_rank = _ptr(pack_all), st.stride, st.N
+        a.status, a.mode, a.u, a.u32 = _ptr(st.status), mode, _ptr(u), float(u32)
         a.seed, a.step, a.ridx = seed, step, _ptr(st.ridx)
-        a.poses_all, a.poses_out = _ptr(poses_all), _ptr(st.poses)
-        a.weights_all, a.weights_out = _ptr(weights_all), _ptr(st.weights_res)
-        a.nn_all, a.hint_out = _ptr(nn_all), _ptr(st.hint)
+        a.poses_out, a.weights_out, a.hint_out = _ptr(st.poses), _ptr(st.weights_res), _ptr(st.hint)
         self.ctx.bind_current_stream()
         self.ctx.check(self.ctx.lib.midas_tail_resample(self.ctx.h, C.byref(a)))
 
@@ -95,14 +94,20 @@ class ShardState:
         e = backend.empty
         self.N, self.slot_base = int(N), int(slot_base)
         self.nb = (self.N + BLOCK - 1) // BLOCK
+        if N % 2:
+            raise MidasError("the sharded step needs an even number of particles per rank")
         self.poses = e((N, 4, 4), torch.float32)
-        self.poses_prop = e((N, 4, 4), torch.float32)
-        self.weights = e((N,), torch.float64)
         self.weights_res = e((N,), torch.float64)
-        self.cdf = e((N,), torch.float64)
+        # packed record block exchanged in one all_gather: [cdf | weights | poses_prop | nn_idx] (midas_hip.h)
+        self.stride = (84 * N + 255) // 256 * 256
+        self.pack = e((self.stride,), torch.uint8)
+        self.pack.zero_()
+        self.cdf = self.pack[0:8 * N].view(torch.float64)
+        self.weights = self.pack[8 * N:16 * N].view(torch.float64)
+        self.poses_prop = self.pack[16 * N:80 * N].view(torch.float32).view(N, 4, 4)
+        self.nn_idx = self.pack[80 * N:84 * N].view(torch.int32)
         self.x = e((N,), torch.float64)
         self.valid = e((N,), torch.uint8)
-        self.nn_idx = e((N,), torch.int32)
         self.hint = e((N,), torch.int32)
         self.ridx = e((N,), torch.int32)
         self.g1 = e((4,), torch.float64)            # max, min, rmse sums
@@ -203,11 +208,8 @@ class ShardedFilterEngine:
         st.status[1] = g2[:, 2 * st.nb + 1].sum().to(torch.int32)
         b.tail_fin(st, g2[:, : st.nb].contiguous().reshape(-1), g2[:, st.nb: 2 * st.nb].contiguous().reshape(-1),
                    self.rank * st.nb, self.rank == G - 1)
-        cdf_all = yield st.cdf
-        poses_all = yield st.poses_prop
-        weights_all = yield st.weights
-        nn_all = yield st.nn_idx
-        b.tail_resample(st, cdf_all, poses_all, weights_all, nn_all, self.mode, u, u32, self.seed, self.step_count)
+        pack_all = yield st.pack
+        b.tail_resample(st, pack_all, self.N_total, self.mode, u, u32, self.seed, self.step_count)
         if gt is not None:
             st.rmse.copy_(torch.sqrt(g1[:, 2:].sum(dim=0) / float(self.N_total)))
         self.step_count += 1

@@ -98,8 +98,9 @@ class FilterEngine:
         self.step_count += 1
 
     # ---- profiling --------------------------------------------------------------------------------
-    def profile(self, on: bool):
-        self.ctx.call("midas_profile_enable", int(on))
+    def profile(self, on, only_slot: int = None):
+        """HIP-event timing of the step's kernels: all of them, or only slot `only_slot` (least perturbation)."""
+        self.ctx.call("midas_profile_enable", 0 if not on else (1 if only_slot is None else 2 + int(only_slot)))
 
     def profile_read(self, reset=True):
         ms = (C.c_double * _lib.PROF_SLOTS)()

@@ -89,8 +89,13 @@ class OracleShardBackend:
         elif total == 0.0:
             st.status[0] |= 1
 
-    def tail_resample(self, st, cdf_all, poses_all, weights_all, nn_all, mode, u, u32, seed, step):
-        N, base, Nall = st.N, st.slot_base, cdf_all.shape[0]
+    def tail_resample(self, st, pack_all, n_all, mode, u, u32, seed, step):
+        N, base, G = st.N, st.slot_base, n_all // st.N
+        blocks = pack_all.reshape(G, st.stride)
+        cdf_all = torch.cat([blocks[r, 0:8 * N].view(torch.float64) for r in range(G)])
+        weights_all = torch.cat([blocks[r, 8 * N:16 * N].view(torch.float64) for r in range(G)])
+        poses_all = torch.cat([blocks[r, 16 * N:80 * N].view(torch.float32).view(N, 4, 4) for r in range(G)])
+        nn_all = torch.cat([blocks[r, 80 * N:84 * N].view(torch.int32) for r in range(G)])
         if int(st.status[0]) != 0:
             src = np.arange(base, base + N, dtype=np.int32)
         elif mode == 0:
@@ -98,7 +103,7 @@ class OracleShardBackend:
             src = orc.search_lower(cdf_all.numpy(), uu)
         else:
             r = u32 if u32 >= 0 else orc.philox_uniform32(seed, step)
-            src = orc.search_systematic(cdf_all.numpy(), Nall, r)[base:base + N]
+            src = orc.search_systematic(cdf_all.numpy(), n_all, r)[base:base + N]
         st.ridx.copy_(torch.as_tensor(src))
         s = torch.as_tensor(src).long()
         st.poses.copy_(poses_all[s])
