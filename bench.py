@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--sharded", action="store_true", help="use the particle-sharded engine even on one GPU (smoke test)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -93,10 +94,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.sharded:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from midastouch_amd.engine import FilterEngine
     from midastouch_amd.synthetic import make_codebook, make_trajectory
@@ -107,7 +110,8 @@ def main():
     T = min(args.warmup + args.steps + 4 * NPROF + 2, 1024)
     traj = make_trajectory(cb, T=T, seed=2001)
 
-    if world == 1:
+    sharded = world > 1 or args.sharded
+    if not sharded:
         eng = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4000, device=dev)
     else:
         from midastouch_amd.dist import ShardedFilterEngine
@@ -146,7 +150,7 @@ def main():
         dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
     status = eng.status.cpu().numpy().tolist()
-    tele = (eng.telemetry if world == 1 else eng.st.telemetry).cpu().numpy().tolist()
+    tele = (eng.st.telemetry if sharded else eng.telemetry).cpu().numpy().tolist()
     frames_run = args.warmup + args.steps
 
     ab = algorithmic_bytes(N, K, D)
@@ -158,13 +162,13 @@ def main():
         "config": {"workload": "c2: 004_sugar_box synthetic trajectory, N=%d particles/GPU x K=%d x D=%d codebook, "
                                "device Philox draws, multinomial resample" % (N, K, D),
                    "particles_per_gpu": N, "particles_total": N * world, "codebook_rows": K, "embedding_dim": D,
-                   "parallelism": "single" if world == 1 else "particle-sharded x%d" % world,
+                   "parallelism": "particle-sharded x%d" % world if sharded else "single",
                    "arith": "f32 poses/NN, f64 scores/weights/CDF", "last_status": status,
                    "tree_search_fallbacks_per_frame": {"nn": tele[0] / frames_run, "prune": tele[1] / frames_run}},
     }
 
     # per-kernel HIP-event timing (separate pass so the events do not perturb the headline)
-    if world == 1 and not args.no_profile:
+    if not sharded and not args.no_profile:
         # one kernel bracketed at a time (two events per frame) so the others run back to back
         names = ["score_codebook", "particle_update", "tail_a", "tail_b"]
         per, fi = {}, args.warmup + args.steps

@@ -207,24 +207,26 @@ typedef struct midas_shard_update_args {
     double prune_thr;
     uint64_t* telemetry_dev;    /* NULL or 2 cumulative counters (see midas_step_args) */
     int32_t* status_dev;        /* 2: zeroed here, filled by midas_tail_a / midas_tail_fin */
+    double* flags_dev;          /* the last two doubles of this rank's g2 record (zeroed here, see midas_tail_a) */
 } midas_shard_update_args;
 /* score codebook + propagate + feature + NN + prune + score gather for the local particles */
 int midas_shard_update(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
                        const midas_tree* tree3, const midas_shard_update_args* args);
-/* e (in/out) = exp(x - 1) from midas_shard_update, replaced by x when the softmax is skipped (|max - min| of the
- * gathered extrema <= 1e-8 or softmax == 0) ; lp = block-local prefix (fixed order) of
- * e * valid ; block_sums / block_totals = the local 4096-slot block totals of e and of e * valid ;
- * flag[0] = softmax applied ; status[0] = 2 on NaN, status[1] = particles kept */
-int midas_tail_a(midas_ctx* ctx, int64_t N, const double* x_dev, const uint8_t* valid_dev, int32_t np,
-                 const double* pmax_all_dev, const double* pmin_all_dev, int32_t softmax, double* e_dev,
-                 double* lp_dev, double* block_sums_dev, double* block_totals_dev, int32_t* flag_dev,
-                 int32_t* status_dev);
-/* weights = e / sum(block_sums_all) * valid ; cdf = (BP + lp) / total in place, BP / total summed sequentially
- * over block_totals_all ; is_last forces the final slot to 1 ; status[0] |= 1 when the total is zero */
+/* Exchange records (float64), one per rank, gathered by the caller in rank order:
+ *   g1 = { max x, min x, sum |dt|^2, sum angle^2 }                       written by midas_shard_update
+ *   g2 = { nb block sums of e | nb block totals of e*valid | NaN count | kept count },  nb = ceil(N / 4096)
+ * midas_tail_a: e (in/out) = exp(x - 1) from midas_shard_update, replaced by x when the softmax is skipped
+ * (softmax == 0 or |max - min| over g1_all <= 1e-8); lp = block-local prefix (fixed order) of e*valid; fills this
+ * rank's g2 record; flag[0] = softmax applied; status[0] = 2 on NaN, status[1] = local particles kept. */
+int midas_tail_a(midas_ctx* ctx, int64_t N, const double* x_dev, const uint8_t* valid_dev, int32_t G,
+                 const double* g1_all_dev, int32_t softmax, double* e_dev, double* lp_dev, double* g2_dev,
+                 int32_t* flag_dev, int32_t* status_dev);
+/* midas_tail_fin: weights = e / S * valid; cdf = (BP + lp) / total in place, with S, BP, total summed
+ * sequentially in global block order over g2_all; the globally last slot is forced to 1; status = global cdf
+ * status + total kept count; rmse_dev (nullable, 2 doubles) from the sums in g1_all over N_total particles. */
 int midas_tail_fin(midas_ctx* ctx, int64_t N, const double* e_dev, const uint8_t* valid_dev, double* weights_dev,
-                   double* cdf_dev, int32_t nb_all, const double* block_sums_all_dev,
-                   const double* block_totals_all_dev, int32_t block_base, int32_t is_last,
-                   const int32_t* flag_dev, int32_t* status_dev);
+                   double* cdf_dev, int32_t G, const double* g2_all_dev, int32_t rank, const double* g1_all_dev,
+                   int64_t N_total, double* rmse_dev, const int32_t* flag_dev, int32_t* status_dev);
 /* The cross-rank resample reads any shard's particles from ONE gathered buffer: every rank contributes a
  * record block of rank_stride bytes laid out as
  *     [ cdf: n x f64 | weights: n x f64 | propagated poses: n x 16 f32 | nn_idx: n x i32 ]   (n = n_per_rank,

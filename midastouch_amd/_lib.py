@@ -69,6 +69,7 @@ class ShardUpdateArgs(C.Structure):
         ("prune_thr", C.c_double),
         ("telemetry", C.c_void_p),
         ("status", C.c_void_p),
+        ("flags", C.c_void_p),
     ]
 
 
@@ -116,8 +117,8 @@ SIGNATURES = {
     "midas_rmse": (C.c_int, [_P, _I64, _P, _P, _P]),
     "midas_filter_step": (C.c_int, [_P, _P, _P, _P, C.POINTER(StepArgs)]),
     "midas_shard_update": (C.c_int, [_P, _P, _P, _P, C.POINTER(ShardUpdateArgs)]),
-    "midas_tail_a": (C.c_int, [_P, _I64, _P, _P, _I32, _P, _P, _I32, _P, _P, _P, _P, _P, _P]),
-    "midas_tail_fin": (C.c_int, [_P, _I64, _P, _P, _P, _P, _I32, _P, _P, _I32, _I32, _P, _P]),
+    "midas_tail_a": (C.c_int, [_P, _I64, _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _P]),
+    "midas_tail_fin": (C.c_int, [_P, _I64, _P, _P, _P, _P, _I32, _P, _I32, _P, _I64, _P, _P, _P]),
     "midas_tail_resample": (C.c_int, [_P, C.POINTER(TailResampleArgs)]),
     "midas_profile_enable": (C.c_int, [_P, _I32]),
     "midas_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64), _I32]),

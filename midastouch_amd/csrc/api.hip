@@ -479,6 +479,7 @@ MIDAS_EXPORT int midas_shard_update(midas_ctx* ctx, const midas_codebook* cb, co
     pa.vlist = (tree6->vlist && tree6->vlist_mesh == tree3) ? (const MeshRec*)tree6->vlist : nullptr;
     pa.telemetry = (unsigned long long*)s.telemetry_dev;
     pa.status_reset = s.status_dev;
+    pa.flags_reset = s.flags_dev;
     pa.part_max = (double*)pmax;
     pa.part_min = (double*)pmin;
     pa.gt16 = prm ? s.gt16_dev : nullptr;
@@ -488,26 +489,26 @@ MIDAS_EXPORT int midas_shard_update(midas_ctx* ctx, const midas_codebook* cb, co
                                   prm ? s.rmse_sums_dev : nullptr);
 }
 
-MIDAS_EXPORT int midas_tail_a(midas_ctx* ctx, int64_t N, const double* x_dev, const uint8_t* valid_dev, int32_t np,
-                              const double* pmax_all_dev, const double* pmin_all_dev, int32_t softmax, double* e_dev,
-                              double* lp_dev, double* block_sums_dev, double* block_totals_dev, int32_t* flag_dev,
-                              int32_t* status_dev) {
+MIDAS_EXPORT int midas_tail_a(midas_ctx* ctx, int64_t N, const double* x_dev, const uint8_t* valid_dev, int32_t G,
+                              const double* g1_all_dev, int32_t softmax, double* e_dev, double* lp_dev, double* g2_dev,
+                              int32_t* flag_dev, int32_t* status_dev) {
     MIDAS_ENTER(ctx);
-    MIDAS_REQUIRE(ctx, N > 0 && np > 0 && x_dev && valid_dev && pmax_all_dev && pmin_all_dev && e_dev && lp_dev &&
-                           block_sums_dev && block_totals_dev && flag_dev && status_dev);
-    return launch_tail_a(ctx, N, x_dev, valid_dev, np, pmax_all_dev, pmin_all_dev, softmax, e_dev, lp_dev, block_sums_dev,
-                         block_totals_dev, flag_dev, status_dev);
+    MIDAS_REQUIRE(ctx, N > 0 && G > 0 && x_dev && valid_dev && g1_all_dev && e_dev && lp_dev && g2_dev && flag_dev && status_dev);
+    const int nb = (int)ceil_div(N, SCAN_BLOCK);
+    return launch_tail_a(ctx, N, x_dev, valid_dev, G, 4, g1_all_dev, g1_all_dev + 1, softmax, e_dev, lp_dev, g2_dev, g2_dev + nb,
+                         g2_dev + 2 * nb, flag_dev, status_dev);
 }
 
 MIDAS_EXPORT int midas_tail_fin(midas_ctx* ctx, int64_t N, const double* e_dev, const uint8_t* valid_dev, double* weights_dev,
-                                double* cdf_dev, int32_t nb_all, const double* block_sums_all_dev,
-                                const double* block_totals_all_dev, int32_t block_base, int32_t is_last,
-                                const int32_t* flag_dev, int32_t* status_dev) {
+                                double* cdf_dev, int32_t G, const double* g2_all_dev, int32_t rank,
+                                const double* g1_all_dev, int64_t N_total, double* rmse_dev, const int32_t* flag_dev,
+                                int32_t* status_dev) {
     MIDAS_ENTER(ctx);
-    MIDAS_REQUIRE(ctx, N > 0 && nb_all > 0 && block_base >= 0 && e_dev && valid_dev && weights_dev && cdf_dev &&
-                           block_sums_all_dev && block_totals_all_dev && flag_dev && status_dev);
-    return launch_tail_fin(ctx, N, e_dev, valid_dev, weights_dev, cdf_dev, nb_all, block_sums_all_dev, block_totals_all_dev,
-                           block_base, is_last, flag_dev, status_dev);
+    MIDAS_REQUIRE(ctx, N > 0 && G > 0 && rank >= 0 && rank < G && e_dev && valid_dev && weights_dev && cdf_dev && g2_all_dev &&
+                           g1_all_dev && N_total >= N && flag_dev && status_dev);
+    const int nb = (int)ceil_div(N, SCAN_BLOCK);
+    return launch_tail_fin(ctx, N, e_dev, valid_dev, weights_dev, cdf_dev, G, nb, g2_all_dev, rank, g1_all_dev, (double)N_total,
+                           rmse_dev, flag_dev, status_dev);
 }
 
 MIDAS_EXPORT int midas_tail_resample(midas_ctx* ctx, const midas_tail_resample_args* args) {

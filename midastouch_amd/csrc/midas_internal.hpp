@@ -176,6 +176,7 @@ struct ParticleUpdateArgs {
     int ablate = 0;        // profiling only (MIDAS_ABLATE)
     unsigned long long* telemetry = nullptr;  // nullable: cumulative [NN tree searches, mesh tree searches]
     int32_t* status_reset = nullptr;          // nullable: status[0..1] zeroed here for the tail kernels' atomics
+    double* flags_reset = nullptr;            // nullable: two float64 counters zeroed here (sharded exchange record)
 };
 int particle_update_blocks(int64_t N);
 int launch_particle_update(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t3, const ParticleUpdateArgs& a);
@@ -215,12 +216,12 @@ struct StepTailArgs {
     double* rmse_out;
 };
 int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base);
-int launch_tail_a(midas_ctx* ctx, int64_t N, const double* x, const uint8_t* valid, int np, const double* pmax_all,
-                  const double* pmin_all, int32_t softmax, double* e_io, double* lp_out, double* block_sums_e,
-                  double* block_totals_em, int32_t* flag, int32_t* status);
-int launch_tail_fin(midas_ctx* ctx, int64_t N, const double* e, const uint8_t* valid, double* weights, double* cdf_io,
-                    int nb_all, const double* block_sums_all, const double* block_totals_all, int block_base,
-                    int32_t is_last, const int32_t* flag, int32_t* status);
+int launch_tail_a(midas_ctx* ctx, int64_t N, const double* x, const uint8_t* valid, int np, int pstride,
+                  const double* pmax_all, const double* pmin_all, int32_t softmax, double* e_io, double* lp_out,
+                  double* block_sums_e, double* block_totals_em, double* flags_out, int32_t* flag, int32_t* status);
+int launch_tail_fin(midas_ctx* ctx, int64_t N, const double* e, const uint8_t* valid, double* weights, double* cdf_io, int G,
+                    int nb, const double* g2_all, int rank, const double* g1_all, double n_total, double* rmse_out,
+                    const int32_t* flag, int32_t* status);
 int launch_tail_resample(midas_ctx* ctx, const midas_tail_resample_args& r);
 int launch_reduce_partials(midas_ctx* ctx, int np, const double* pmax, const double* pmin, const double* prm,
                            double* extrema2, double* rmse_sums2);

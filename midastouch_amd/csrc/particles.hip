@@ -865,7 +865,10 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
     __shared__ double s_cd[KD_MAX_LEVELS * 64];  // child-distance columns, reused by both searches
     const int64_t n = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool live = n < a.N;
-    if (a.status_reset && blockIdx.x == 0 && threadIdx.x == 0) { a.status_reset[0] = 0; a.status_reset[1] = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (a.status_reset) { a.status_reset[0] = 0; a.status_reset[1] = 0; }
+        if (a.flags_reset) { a.flags_reset[0] = 0.0; a.flags_reset[1] = 0.0; }
+    }
     double x = 0.0, et2 = 0.0, ang2 = 0.0;
     float R[16], f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll

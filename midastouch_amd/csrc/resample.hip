@@ -85,12 +85,12 @@ MD void seq_totals(const double* __restrict__ part, int nb, int b, double& bp, d
 }
 
 // block-wide max/min over an array of partials
-MD void block_extrema(const double* __restrict__ pmax, const double* __restrict__ pmin, int np, double* s_red,
-                      double& mx, double& mn) {
+MD void block_extrema(const double* __restrict__ pmax, const double* __restrict__ pmin, int np, int stride,
+                      double* s_red, double& mx, double& mn) {
     double a = -INFINITY, b = INFINITY;
     bool nan = false;
     for (int i = threadIdx.x; i < np; i += blockDim.x) {
-        double u = pmax[i], v = pmin[i];
+        double u = pmax[(int64_t)i * stride], v = pmin[(int64_t)i * stride];
         nan |= (u != u) || (v != v);
         a = u > a ? u : a;
         b = v < b ? v : b;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void k_exp_partial(int64_t N, const double* __
     __shared__ double s_red[24];
     __shared__ double s_gtot[16];
     double mx, mn;
-    block_extrema(pmax, pmin, np, s_red, mx, mn);
+    block_extrema(pmax, pmin, np, 1, s_red, mx, mn);
     // not isclose(max - min, 0): |max-min| > atol, or NaN (isclose(NaN, 0) is False)
     const double spread = mx - mn;
     const bool apply = softmax && !(__builtin_fabs(spread) <= ISCLOSE_ATOL);
@@ -311,15 +311,16 @@ __global__ __launch_bounds__(256) void k_gather_rows(int64_t M, const int32_t* _
 //     (CDF total) ; status[0] = 2 on NaN ; status[1] = particles kept.
 //     The CDF is built from e*valid directly: the softmax normalisation cancels in prefix / total.
 __global__ __launch_bounds__(256) void k_tail_a(int64_t N, const double* __restrict__ x, const uint8_t* __restrict__ valid,
-                                                int np, const double* __restrict__ pmax_all,
+                                                int np, int pstride, const double* __restrict__ pmax_all,
                                                 const double* __restrict__ pmin_all, int32_t softmax,
                                                 double* __restrict__ e_io, double* __restrict__ lp_out,
                                                 double* __restrict__ block_sums_e, double* __restrict__ block_totals_em,
-                                                int32_t* __restrict__ flag, int32_t* __restrict__ status) {
+                                                double* __restrict__ flags_out, int32_t* __restrict__ flag,
+                                                int32_t* __restrict__ status) {
     __shared__ double s_red[24];
     __shared__ double s_gtot[16];
     double mx, mn;
-    block_extrema(pmax_all, pmin_all, np, s_red, mx, mn);
+    block_extrema(pmax_all, pmin_all, np, pstride, s_red, mx, mn);
     const bool apply = softmax && !(__builtin_fabs(mx - mn) <= ISCLOSE_ATOL);
     if (blockIdx.x == 0 && threadIdx.x == 0) flag[0] = apply ? 1 : 0;
     const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_CHUNK;
@@ -349,30 +350,61 @@ __global__ __launch_bounds__(256) void k_tail_a(int64_t N, const double* __restr
         if (base + j < N) lp_out[base + j] = l[j];
     if (threadIdx.x == 0) { block_sums_e[blockIdx.x] = We; block_totals_em[blockIdx.x] = Wm; }
     const bool wnan = __any(nan);
-    if (wnan && (threadIdx.x & 63) == 0) atomicOr(&status[0], 2);
+    if (wnan && (threadIdx.x & 63) == 0) {
+        atomicOr(&status[0], 2);
+        if (flags_out) atomicAdd(&flags_out[0], 1.0);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
-    if ((threadIdx.x & 63) == 0 && kept) atomicAdd(&status[1], kept);
+    if ((threadIdx.x & 63) == 0 && kept) {
+        atomicAdd(&status[1], kept);
+        if (flags_out) atomicAdd(&flags_out[1], (double)kept);  // exact: integers far below 2^53
+    }
 }
 
 constexpr int TB_MAX_BLOCKS = 1024;  // 4 M particles (per GPU in the fused step, in total in the sharded step)
 
-// TF (sharded path): weights = e / S * valid ; cdf = (BP + lp) / total with S, BP, total summed
-//     sequentially over ALL shards' block partials ; the globally last slot is forced to 1.
+// TF (sharded path): weights = e / S * valid ; cdf = (BP + lp) / total with S, BP, total summed sequentially
+//     over ALL shards' block partials, read straight from the gathered exchange buffer g2_all
+//     (per rank: nb block sums of e | nb block totals of e*valid | NaN count | kept count) ; the globally last
+//     slot is forced to 1 ; status and (optionally) the rmse of all shards are finalised by block 0.
 __global__ __launch_bounds__(256) void k_tail_fin(int64_t N, const double* __restrict__ e, const uint8_t* __restrict__ valid,
-                                                  double* __restrict__ weights, double* __restrict__ cdf_io, int nb_all,
-                                                  const double* __restrict__ block_sums_all,
-                                                  const double* __restrict__ block_totals_all, int block_base,
-                                                  int32_t is_last, const int32_t* __restrict__ flag,
+                                                  double* __restrict__ weights, double* __restrict__ cdf_io, int G, int nb,
+                                                  const double* __restrict__ g2_all, int rank,
+                                                  const double* __restrict__ g1_all, double n_total,
+                                                  double* __restrict__ rmse_out, const int32_t* __restrict__ flag,
                                                   int32_t* __restrict__ status) {
     __shared__ double s_buf[TB_MAX_BLOCKS];
-    double bp, total, S = 1.0, dummy;
-    seq_totals_lds(block_totals_all, nb_all, block_base + (int)blockIdx.x, s_buf, bp, total);
-    if (flag[0]) seq_totals_lds(block_sums_all, nb_all, 0, s_buf, dummy, S);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (total != total) atomicOr(&status[0], 2);
-        else if (total == 0.0) atomicOr(&status[0], 1);
+    const int nb_all = G * nb, rec = 2 * nb + 2;
+    const int my = rank * nb + (int)blockIdx.x;
+    // totals of e*valid of every block, in global block order
+    for (int i = threadIdx.x; i < nb_all; i += 256) s_buf[i] = g2_all[(int64_t)(i / nb) * rec + nb + (i % nb)];
+    __syncthreads();
+    double bp = 0.0, total = 0.0;
+    for (int i = 0; i < nb_all; ++i) { if (i == my) bp = total; total = total + s_buf[i]; }
+    __syncthreads();
+    double S = 1.0;
+    if (flag[0]) {
+        for (int i = threadIdx.x; i < nb_all; i += 256) s_buf[i] = g2_all[(int64_t)(i / nb) * rec + (i % nb)];
+        __syncthreads();
+        S = 0.0;
+        for (int i = 0; i < nb_all; ++i) S = S + s_buf[i];
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double nans = 0.0, kept = 0.0, st2 = 0.0, sr2 = 0.0;
+        for (int r = 0; r < G; ++r) {
+            nans += g2_all[(int64_t)r * rec + 2 * nb];
+            kept += g2_all[(int64_t)r * rec + 2 * nb + 1];
+            if (rmse_out) { st2 += g1_all[4 * r + 2]; sr2 += g1_all[4 * r + 3]; }
+        }
+        int st = nans != 0.0 ? 2 : 0;
+        if (total != total) st |= 2;
+        else if (total == 0.0) st |= 1;
+        status[0] = st;
+        status[1] = (int32_t)kept;
+        if (rmse_out) { rmse_out[0] = __builtin_sqrt(st2 / n_total); rmse_out[1] = __builtin_sqrt(sr2 / n_total); }
+    }
+    const bool is_last = rank == G - 1;
     const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK;
 #pragma unroll
     for (int j = 0; j < SCAN_CHUNK; ++j) {
@@ -668,22 +700,22 @@ int launch_gather_rows(midas_ctx* ctx, int64_t M, const int32_t* idx, const void
     return MIDAS_OK;
 }
 
-int launch_tail_a(midas_ctx* ctx, int64_t N, const double* x, const uint8_t* valid, int np, const double* pmax_all,
-                  const double* pmin_all, int32_t softmax, double* e_io, double* lp_out, double* block_sums_e,
-                  double* block_totals_em, int32_t* flag, int32_t* status) {
-    hipLaunchKernelGGL(k_tail_a, dim3((unsigned)ceil_div(N, SCAN_BLOCK)), dim3(256), 0, ctx->stream, N, x, valid, np, pmax_all,
-                       pmin_all, softmax, e_io, lp_out, block_sums_e, block_totals_em, flag, status);
+int launch_tail_a(midas_ctx* ctx, int64_t N, const double* x, const uint8_t* valid, int np, int pstride,
+                  const double* pmax_all, const double* pmin_all, int32_t softmax, double* e_io, double* lp_out,
+                  double* block_sums_e, double* block_totals_em, double* flags_out, int32_t* flag, int32_t* status) {
+    hipLaunchKernelGGL(k_tail_a, dim3((unsigned)ceil_div(N, SCAN_BLOCK)), dim3(256), 0, ctx->stream, N, x, valid, np, pstride,
+                       pmax_all, pmin_all, softmax, e_io, lp_out, block_sums_e, block_totals_em, flags_out, flag, status);
     LAUNCH_CHECK(ctx);
     return MIDAS_OK;
 }
 
-int launch_tail_fin(midas_ctx* ctx, int64_t N, const double* e, const uint8_t* valid, double* weights, double* cdf_io,
-                    int nb_all, const double* block_sums_all, const double* block_totals_all, int block_base,
-                    int32_t is_last, const int32_t* flag, int32_t* status) {
-    if (nb_all > TB_MAX_BLOCKS)
-        return midas_set_error(ctx, MIDAS_ERR_INVALID, "nb_all", "more than 4 M particles in total in the sharded step");
+int launch_tail_fin(midas_ctx* ctx, int64_t N, const double* e, const uint8_t* valid, double* weights, double* cdf_io, int G,
+                    int nb, const double* g2_all, int rank, const double* g1_all, double n_total, double* rmse_out,
+                    const int32_t* flag, int32_t* status) {
+    if ((int64_t)G * nb > TB_MAX_BLOCKS)
+        return midas_set_error(ctx, MIDAS_ERR_INVALID, "G*nb", "more than 4 M particles in total in the sharded step");
     hipLaunchKernelGGL(k_tail_fin, dim3((unsigned)ceil_div(N, SCAN_BLOCK)), dim3(256), 0, ctx->stream, N, e, valid, weights,
-                       cdf_io, nb_all, block_sums_all, block_totals_all, block_base, is_last, flag, status);
+                       cdf_io, G, nb, g2_all, rank, g1_all, n_total, rmse_out, flag, status);
     LAUNCH_CHECK(ctx);
     return MIDAS_OK;
 }
@@ -710,7 +742,8 @@ int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base) 
     double* pw = psum + nb;
     double* e = a.e;
     int32_t* flag = (int32_t*)(pw + nb);
-    if ((rc = launch_tail_a(ctx, a.N, a.x, a.valid, a.npart, a.part_max, a.part_min, a.softmax, e, a.cdf, psum, pw, flag, a.status)))
+    if ((rc = launch_tail_a(ctx, a.N, a.x, a.valid, a.npart, 1, a.part_max, a.part_min, a.softmax, e, a.cdf, psum, pw, nullptr,
+                            flag, a.status)))
         return rc;
     prof_mark(ctx, prof_slot_base + 1);
     TailBArgs b;

@@ -63,18 +63,17 @@ class HipShardBackend:
         a.std_t, a.std_r, a.seed, a.step, a.prune_thr = std_t, std_r, seed, step, prune_thr
         a.telemetry = _ptr(st.telemetry)
         a.status = _ptr(st.status)
+        a.flags = _ptr(st.g2[2 * st.nb:])
         self.ctx.bind_current_stream()
         self.ctx.check(self.ctx.lib.midas_shard_update(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h, C.byref(a)))
 
-    def tail_a(self, st, pmax_all, pmin_all, softmax):
-        self.ctx.call("midas_tail_a", st.N, _ptr(st.x), _ptr(st.valid), pmax_all.shape[0], _ptr(pmax_all), _ptr(pmin_all),
-                      int(softmax), _ptr(st.e), _ptr(st.cdf), _ptr(st.g2[: st.nb]), _ptr(st.g2[st.nb: 2 * st.nb]),
-                      _ptr(st.flag), _ptr(st.status))
+    def tail_a(self, st, g1_all, softmax):
+        self.ctx.call("midas_tail_a", st.N, _ptr(st.x), _ptr(st.valid), g1_all.shape[0] // 4, _ptr(g1_all), int(softmax),
+                      _ptr(st.e), _ptr(st.cdf), _ptr(st.g2), _ptr(st.flag), _ptr(st.status))
 
-    def tail_fin(self, st, block_sums_all, block_totals_all, block_base, is_last):
-        self.ctx.call("midas_tail_fin", st.N, _ptr(st.e), _ptr(st.valid), _ptr(st.weights), _ptr(st.cdf),
-                      block_sums_all.shape[0], _ptr(block_sums_all), _ptr(block_totals_all), block_base, int(is_last),
-                      _ptr(st.flag), _ptr(st.status))
+    def tail_fin(self, st, g2_all, g1_all, rank, world, n_total, want_rmse):
+        self.ctx.call("midas_tail_fin", st.N, _ptr(st.e), _ptr(st.valid), _ptr(st.weights), _ptr(st.cdf), world, _ptr(g2_all),
+                      rank, _ptr(g1_all), n_total, _ptr(st.rmse) if want_rmse else None, _ptr(st.flag), _ptr(st.status))
 
     def tail_resample(self, st, pack_all, n_all, mode, u, u32, seed, step):
         a = TailResampleArgs()
@@ -200,18 +199,12 @@ class ShardedFilterEngine:
         mul = max(float(multiplier), 1.0)
         b.update(st, odom, code, gt, tn, rot, mul * self.sig_t, mul * self.sig_r, self.seed, self.step_count,
                  self.pen_max, self.use_hint)
-        g1 = (yield st.g1).reshape(G, 4)
-        b.tail_a(st, g1[:, 0].contiguous(), g1[:, 1].contiguous(), self.softmax)
-        st.g2[2 * st.nb:] = st.status.to(torch.float64)  # NaN flag (status[0]), kept count (status[1])
-        g2 = (yield st.g2).reshape(G, 2 * st.nb + 2)
-        st.status[0] = (g2[:, 2 * st.nb] != 0).any().to(torch.int32) * 2
-        st.status[1] = g2[:, 2 * st.nb + 1].sum().to(torch.int32)
-        b.tail_fin(st, g2[:, : st.nb].contiguous().reshape(-1), g2[:, st.nb: 2 * st.nb].contiguous().reshape(-1),
-                   self.rank * st.nb, self.rank == G - 1)
+        g1_all = yield st.g1
+        b.tail_a(st, g1_all, self.softmax)
+        g2_all = yield st.g2
+        b.tail_fin(st, g2_all, g1_all, self.rank, G, self.N_total, gt is not None)
         pack_all = yield st.pack
         b.tail_resample(st, pack_all, self.N_total, self.mode, u, u32, self.seed, self.step_count)
-        if gt is not None:
-            st.rmse.copy_(torch.sqrt(g1[:, 2:].sum(dim=0) / float(self.N_total)))
         self.step_count += 1
 
     def step(self, odom, code, gt=None, **draws):

@@ -53,8 +53,9 @@ class OracleShardBackend:
             rt, rr = orc.particle_rmse(p1, gt.numpy())
             st.g1[2], st.g1[3] = rt * rt * N, rr * rr * N
 
-    def tail_a(self, st, pmax_all, pmin_all, softmax):
-        mx, mn = float(pmax_all.max()), float(pmin_all.min())
+    def tail_a(self, st, g1_all, softmax):
+        g1 = g1_all.numpy().reshape(-1, 4)
+        mx, mn = float(g1[:, 0].max()), float(g1[:, 1].min())
         apply = bool(softmax) and not (abs(mx - mn) <= 1e-8)
         x = st.x.numpy()
         e = st.e.numpy().copy() if apply else x.copy()
@@ -66,28 +67,37 @@ class OracleShardBackend:
             lp, tot = orc.blocked_scan(em[b * BLOCK:(b + 1) * BLOCK])
             st.cdf[b * BLOCK:(b + 1) * BLOCK] = torch.as_tensor(lp)
             st.g2[st.nb + b] = tot
+        st.g2[2 * st.nb] = float(np.isnan(em).sum())
+        st.g2[2 * st.nb + 1] = float(valid.sum())
         st.flag[0] = int(apply)
-        st.status[0] = 2 if np.isnan(em).any() else 0
-        st.status[1] = int(valid.sum())
 
-    def tail_fin(self, st, block_sums_all, block_totals_all, block_base, is_last):
-        S = _seq_sum(block_sums_all.numpy()) if int(st.flag[0]) else 1.0
+    def tail_fin(self, st, g2_all, g1_all, rank, world, n_total, want_rmse):
+        nb = st.nb
+        g2 = g2_all.numpy().reshape(world, 2 * nb + 2)
+        S = _seq_sum(g2[:, :nb].reshape(-1)) if int(st.flag[0]) else 1.0
         valid = st.valid.numpy().astype(bool)
         st.weights.copy_(torch.as_tensor((st.e.numpy() / S) * valid))
-        tot = block_totals_all.numpy()
+        tot = g2[:, nb:2 * nb].reshape(-1)
         total = _seq_sum(tot)
         lp = st.cdf.numpy().copy()
         out = np.empty_like(lp)
-        for b in range(st.nb):
-            bp = _seq_sum(tot[: block_base + b])
+        for b in range(nb):
+            bp = _seq_sum(tot[: rank * nb + b])
             out[b * BLOCK:(b + 1) * BLOCK] = (bp + lp[b * BLOCK:(b + 1) * BLOCK]) / total if total != 0 else np.nan
-        if is_last:
+        if rank == world - 1:
             out[-1] = 1.0
         st.cdf.copy_(torch.as_tensor(out))
+        status = 2 if g2[:, 2 * nb].sum() != 0 else 0
         if np.isnan(total):
-            st.status[0] |= 2
+            status |= 2
         elif total == 0.0:
-            st.status[0] |= 1
+            status |= 1
+        st.status[0] = status
+        st.status[1] = int(g2[:, 2 * nb + 1].sum())
+        if want_rmse:
+            g1 = g1_all.numpy().reshape(world, 4)
+            st.rmse[0] = float(np.sqrt(g1[:, 2].sum() / n_total))
+            st.rmse[1] = float(np.sqrt(g1[:, 3].sum() / n_total))
 
     def tail_resample(self, st, pack_all, n_all, mode, u, u32, seed, step):
         N, base, G = st.N, st.slot_base, n_all // st.N
