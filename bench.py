@@ -188,8 +188,16 @@ def main():
                   "tail": per["tail_a"] + per["tail_b"]}
         dom = max(("score_codebook", "particle_update"), key=lambda k: groups[k])
         achieved = ab[dom] / (groups[dom] * 1e-3) / 1e9
+        # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (PMC counters
+        # cannot be read from inside the process): profiles/r01_traffic.json, tools/pmc_traffic.sh
+        traffic, traffic_src = None, None
+        try:
+            tj = json.load(open(os.path.join(REPO, "profiles", "r01_traffic.json")))
+            traffic, traffic_src = tj["kernels"][dom]["hbm_bytes"], "profiles/r01_traffic.json"
+        except Exception:
+            pass
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                            "algorithmic_bytes_per_launch": ab[dom], "kernel_ms": groups[dom],
                            "per_kernel_ms": per, "event_pair_overhead_ms": overhead,
                            "step_bytes": ab["step"],

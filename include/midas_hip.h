@@ -197,7 +197,8 @@ typedef struct midas_shard_update_args {
     uint8_t* valid_dev;         /* N out: prune mask */
     double* extrema_dev;        /* 2 out: max(x), min(x) over the local particles */
     const float* odom16_dev;
-    const double* code_dev;
+    const double* code_dev;     /* D: tactile code (ignored when scores_dev is given) */
+    const double* scores_dev;   /* NULL, or K precomputed scores (codebook rows sharded across ranks and gathered) */
     const float* gt16_dev;      /* NULL or 16 */
     double* rmse_sums_dev;      /* NULL or 2 out: sum |dt|^2, sum angle^2 over the local particles */
     const float* tn_dev;        /* local host draws or NULL -> Philox */

@@ -64,7 +64,8 @@ class ShardUpdateArgs(C.Structure):
         ("N", C.c_int64), ("slot_base", C.c_int64),
         ("poses_in", C.c_void_p), ("poses_prop", C.c_void_p), ("hint_in", C.c_void_p), ("nn_idx", C.c_void_p),
         ("x", C.c_void_p), ("e", C.c_void_p), ("valid", C.c_void_p), ("extrema", C.c_void_p), ("odom16", C.c_void_p),
-        ("code", C.c_void_p), ("gt16", C.c_void_p), ("rmse_sums", C.c_void_p), ("tn", C.c_void_p), ("rot", C.c_void_p),
+        ("code", C.c_void_p), ("scores", C.c_void_p), ("gt16", C.c_void_p), ("rmse_sums", C.c_void_p),
+        ("tn", C.c_void_p), ("rot", C.c_void_p),
         ("std_t", C.c_float), ("std_r", C.c_float), ("seed", C.c_uint64), ("step", C.c_uint64),
         ("prune_thr", C.c_double),
         ("telemetry", C.c_void_p),

@@ -442,20 +442,26 @@ MIDAS_EXPORT int midas_filter_step(midas_ctx* ctx, const midas_codebook* cb, con
 MIDAS_EXPORT int midas_shard_update(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
                                     const midas_tree* tree3, const midas_shard_update_args* args) {
     MIDAS_ENTER(ctx);
-    MIDAS_REQUIRE(ctx, cb && tree6 && tree3 && args && tree6->dim == 6 && tree3->dim == 3 && tree6->K == cb->K);
+    MIDAS_REQUIRE(ctx, tree6 && tree3 && args && tree6->dim == 6 && tree3->dim == 3);
+    MIDAS_REQUIRE(ctx, args->scores_dev || (cb && tree6->K == cb->K));
     const midas_shard_update_args& s = *args;
     MIDAS_REQUIRE(ctx, s.N > 0 && s.poses_in_dev && s.poses_prop_dev && s.nn_idx_dev && s.x_dev && s.e_dev && s.valid_dev &&
-                           s.extrema_dev && s.odom16_dev && s.code_dev && s.poses_in_dev != s.poses_prop_dev);
+                           s.extrema_dev && s.odom16_dev && (s.code_dev || s.scores_dev) && s.poses_in_dev != s.poses_prop_dev);
     MIDAS_REQUIRE(ctx, (s.tn_dev == nullptr) == (s.rot_dev == nullptr));
     const int npart = particle_update_blocks(s.N);
     void *scores, *pmax, *pmin, *prm = nullptr;
     int rc;
-    if ((rc = midas_scratch(ctx, (size_t)cb->K * sizeof(double), &scores))) return rc;
+    if (s.scores_dev) {
+        scores = const_cast<double*>(s.scores_dev);
+    } else {
+        if ((rc = midas_scratch(ctx, (size_t)cb->K * sizeof(double), &scores))) return rc;
+    }
     if ((rc = midas_scratch(ctx, (size_t)npart * sizeof(double), &pmax))) return rc;
     if ((rc = midas_scratch(ctx, (size_t)npart * sizeof(double), &pmin))) return rc;
     if (s.gt16_dev && s.rmse_sums_dev)
         if ((rc = midas_scratch(ctx, (size_t)npart * 2 * sizeof(double), &prm))) return rc;
-    if ((rc = launch_score(ctx, cb, 1, s.code_dev, (double*)scores))) return rc;
+    if (!s.scores_dev)
+        if ((rc = launch_score(ctx, cb, 1, s.code_dev, (double*)scores))) return rc;
     ParticleUpdateArgs pa;
     pa.N = s.N;
     pa.poses_in = s.poses_in_dev;

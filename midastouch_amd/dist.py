@@ -32,15 +32,28 @@ BLOCK = 4096  # summation block of the CDF spec (csrc/resample.hip)
 
 
 class HipShardBackend:
-    """Local kernels of one shard (libmidas_hip.so)."""
+    """Local kernels of one shard (libmidas_hip.so).
 
-    def __init__(self, cb_poses, cb_embeddings, mesh_vertices, device):
+    row_shard = (rank, world) keeps only this rank's contiguous slice of the embedding rows in HBM
+    (SURVEY.md 8(e) codebook-row sharding, BASELINE config 4): the frame then starts with one extra
+    all_gather of the per-rank score slices; poses, the NN index and the mesh index stay replicated.
+    """
+
+    def __init__(self, cb_poses, cb_embeddings, mesh_vertices, device, row_shard=None):
         self.ctx = _lib.context(device)
         self.device = self.ctx.device
         self.cb_poses = torch.as_tensor(cb_poses).to(self.device, torch.float32).contiguous()
         self.cb_feat = ops.se3_feature(self.cb_poses)
         self.tree6 = ops.Tree(self.cb_feat)
-        self.codebook = ops.Codebook(torch.as_tensor(cb_embeddings).to(self.device))
+        emb = torch.as_tensor(cb_embeddings)
+        self.row_shard = row_shard
+        if row_shard is not None:
+            r, w = row_shard
+            K = emb.shape[0]
+            if K % w:
+                raise MidasError("codebook-row sharding needs K divisible by the number of ranks")
+            emb = emb[r * (K // w):(r + 1) * (K // w)]
+        self.codebook = ops.Codebook(emb.to(self.device))
         self.tree3 = ops.Tree(torch.as_tensor(mesh_vertices).to(self.device, torch.float64))
         self.tree6.attach_mesh(self.tree3, self.cb_poses)
 
@@ -51,13 +64,18 @@ class HipShardBackend:
         idx = ops.nn6(self.tree6, ops.se3_feature(poses))
         return ops.gather_rows(self.cb_poses, idx), idx
 
-    def update(self, st, odom, code, gt, tn, rot, std_t, std_r, seed, step, prune_thr, use_hint=True):
+    def score_slice(self, code):
+        """This rank's slice of the frame's scores (row-sharded codebook)."""
+        return self.codebook.score(code)[0]
+
+    def update(self, st, odom, code, gt, tn, rot, std_t, std_r, seed, step, prune_thr, use_hint=True, scores=None):
         a = ShardUpdateArgs()
         a.N, a.slot_base = st.N, st.slot_base
         a.poses_in, a.poses_prop = _ptr(st.poses), _ptr(st.poses_prop)
         a.hint_in = _ptr(st.hint) if use_hint else None
         a.nn_idx, a.x, a.e, a.valid, a.extrema = _ptr(st.nn_idx), _ptr(st.x), _ptr(st.e), _ptr(st.valid), _ptr(st.g1[:2])
         a.odom16, a.code, a.gt16 = _ptr(odom), _ptr(code), _ptr(gt)
+        a.scores = _ptr(scores)
         a.rmse_sums = _ptr(st.g1[2:]) if gt is not None else None
         a.tn, a.rot = _ptr(tn), _ptr(rot)
         a.std_t, a.std_r, a.seed, a.step, a.prune_thr = std_t, std_r, seed, step, prune_thr
@@ -65,7 +83,8 @@ class HipShardBackend:
         a.status = _ptr(st.status)
         a.flags = _ptr(st.g2[2 * st.nb:])
         self.ctx.bind_current_stream()
-        self.ctx.check(self.ctx.lib.midas_shard_update(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h, C.byref(a)))
+        self.ctx.check(self.ctx.lib.midas_shard_update(self.ctx.h, None if scores is not None else self.codebook.h,
+                                                       self.tree6.h, self.tree3.h, C.byref(a)))
 
     def tail_a(self, st, g1_all, softmax):
         self.ctx.call("midas_tail_a", st.N, _ptr(st.x), _ptr(st.valid), g1_all.shape[0] // 4, _ptr(g1_all), int(softmax),
@@ -151,7 +170,7 @@ class SingleComm:
 class ShardedFilterEngine:
     def __init__(self, cb_poses=None, cb_embeddings=None, mesh_vertices=None, num_particles: int = 0, *, sig_t=2e-4,
                  sig_r=0.5, pen_max=0.002, seed=4000, softmax=True, resample="weighted_random", device=None,
-                 comm=None, backend=None, rank=None, world=None):
+                 comm=None, backend=None, rank=None, world=None, shard_codebook_rows=False):
         if comm is None:
             import torch.distributed as dist
 
@@ -159,7 +178,10 @@ class ShardedFilterEngine:
         self.comm = comm
         self.rank = comm.rank if rank is None else rank
         self.world = comm.world if world is None else world
-        self.backend = backend if backend is not None else HipShardBackend(cb_poses, cb_embeddings, mesh_vertices, device)
+        if backend is None:
+            backend = HipShardBackend(cb_poses, cb_embeddings, mesh_vertices, device,
+                                      row_shard=(self.rank, self.world) if shard_codebook_rows else None)
+        self.backend = backend
         self.N = int(num_particles)
         self.N_total = self.N * self.world
         self.st = ShardState(self.backend, self.N, self.rank * self.N)
@@ -197,8 +219,11 @@ class ShardedFilterEngine:
     def step_gen(self, odom, code, gt=None, tn=None, rot=None, u=None, u32=-1.0, multiplier: float = 1.0):
         st, b, G = self.st, self.backend, self.world
         mul = max(float(multiplier), 1.0)
+        scores = None
+        if getattr(b, "row_shard", None) is not None:  # codebook rows sharded: gather the score slices first
+            scores = yield b.score_slice(code)
         b.update(st, odom, code, gt, tn, rot, mul * self.sig_t, mul * self.sig_r, self.seed, self.step_count,
-                 self.pen_max, self.use_hint)
+                 self.pen_max, self.use_hint, scores=scores)
         g1_all = yield st.g1
         b.tail_a(st, g1_all, self.softmax)
         g2_all = yield st.g2

@@ -31,7 +31,7 @@ class OracleShardBackend:
         idx = self.ofl.SE3_NN_idx(poses.numpy())
         return torch.as_tensor(self.cb_poses[idx]), torch.as_tensor(idx)
 
-    def update(self, st, odom, code, gt, tn, rot, std_t, std_r, seed, step, prune_thr, use_hint=True):
+    def update(self, st, odom, code, gt, tn, rot, std_t, std_r, seed, step, prune_thr, use_hint=True, scores=None):
         N, base = st.N, st.slot_base
         if tn is None:
             tn_all, rot_all = orc.philox_noise(base + N, seed, step, np.float32(std_t), np.float32(std_r))

@@ -58,6 +58,35 @@ def test_sharded_hip_equals_fused_engine(dev, shards, mode):
             np.testing.assert_allclose(e.rmse.cpu().numpy(), single.rmse.cpu().numpy(), rtol=1e-12)
 
 
+def test_codebook_row_sharding_equals_replicated(dev):
+    """BASELINE config 4 shape: embedding rows sharded over the ranks, score slices gathered - same frame bit for bit."""
+    from midastouch_amd.dist import HipShardBackend, ShardedFilterEngine, run_lockstep
+    from midastouch_amd.engine import FilterEngine
+    from midastouch_amd.synthetic import make_codebook, make_trajectory
+    shards, n_loc, K, D = 2, 4096, 4000, 256
+    N = shards * n_loc
+    cb = make_codebook(K=K, D=D, seed=1000)
+    traj = make_trajectory(cb, T=8, seed=2000)
+    start = cb.poses[np.random.default_rng(0).integers(0, K, N)]
+    single = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, device=dev)
+    single.set_particles(torch.as_tensor(start))
+    engs = []
+    for r in range(shards):
+        be = HipShardBackend(cb.poses, cb.embeddings, cb.mesh_vertices, dev, row_shard=(r, shards))
+        assert be.codebook.K == K // shards
+        e = ShardedFilterEngine(num_particles=n_loc, backend=be, comm=FakeComm(r, shards))
+        e.set_particles(torch.as_tensor(start[r * n_loc:(r + 1) * n_loc]))
+        engs.append(e)
+    for t in range(1, 6):
+        od, code = torch.as_tensor(traj.odoms[t]).to(dev), torch.as_tensor(traj.codes[t]).to(dev)
+        single.step(od, code)
+        run_lockstep(engs, [((od, code), {}) for _ in engs])
+        cat = lambda name: torch.cat([getattr(e, name) for e in engs]).cpu().numpy()
+        assert np.array_equal(cat("weights"), single.weights.cpu().numpy()), t
+        assert np.array_equal(cat("ridx"), single.ridx.cpu().numpy()), t
+        assert np.array_equal(cat("poses"), single.poses.cpu().numpy()), t
+
+
 def test_single_rank_process_group_nccl(dev):
     """world_size 1 through torch.distributed's nccl (= RCCL) backend: the real communicator path."""
     import os
