@@ -248,6 +248,15 @@ typedef struct midas_tail_resample_args {
 } midas_tail_resample_args;
 int midas_tail_resample(midas_ctx* ctx, const midas_tail_resample_args* args);
 
+/* B concurrent trajectories against one codebook (BASELINE config 5, "throughput mode"): every per-trajectory
+ * array of `args` carries a leading batch dimension, contiguous - poses (B,N,16), weights (B,N), hints (B,N),
+ * odom16 (B,16), code (B,D), gt16 (B,16), rmse (B,2), status (B,2), tn/rot (B,N,3), u (B,N); scalars are shared.
+ * The B codes are scored in ONE pass over the codebook on the matrix cores (midas_score_batch) when the
+ * embeddings are float32 and D % 16 == 0; the remaining kernels run with the trajectory as grid.y.  Philox
+ * streams are keyed by the flattened particle index b*N + n, so trajectories draw independent noise. */
+int midas_filter_step_batch(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
+                            const midas_tree* tree3, const midas_step_args* args, int32_t B);
+
 /* per-kernel timing of midas_filter_step (HIP events on the context stream).  When enabled every
  * kernel of the step is bracketed by events; midas_profile_read synchronises and returns the
  * accumulated milliseconds per kernel slot since the last reset. */

@@ -117,6 +117,7 @@ SIGNATURES = {
     "midas_gather_rows": (C.c_int, [_P, _I64, _P, _P, _P, _I32]),
     "midas_rmse": (C.c_int, [_P, _I64, _P, _P, _P]),
     "midas_filter_step": (C.c_int, [_P, _P, _P, _P, C.POINTER(StepArgs)]),
+    "midas_filter_step_batch": (C.c_int, [_P, _P, _P, _P, C.POINTER(StepArgs), _I32]),
     "midas_shard_update": (C.c_int, [_P, _P, _P, _P, C.POINTER(ShardUpdateArgs)]),
     "midas_tail_a": (C.c_int, [_P, _I64, _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _P]),
     "midas_tail_fin": (C.c_int, [_P, _I64, _P, _P, _P, _P, _I32, _P, _I32, _P, _I64, _P, _P, _P]),

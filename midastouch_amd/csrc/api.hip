@@ -332,9 +332,24 @@ static double squared_threshold(double thr) {
     return t;
 }
 
+static int filter_step_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
+                            const midas_step_args* args, int32_t B);
+
 MIDAS_EXPORT int midas_filter_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
                                    const midas_tree* tree3, const midas_step_args* args) {
     MIDAS_ENTER(ctx);
+    return filter_step_impl(ctx, cb, tree6, tree3, args, 1);
+}
+
+MIDAS_EXPORT int midas_filter_step_batch(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
+                                         const midas_tree* tree3, const midas_step_args* args, int32_t B) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, B >= 1 && B <= 65535);
+    return filter_step_impl(ctx, cb, tree6, tree3, args, B);
+}
+
+static int filter_step_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
+                            const midas_step_args* args, int32_t B) {
     MIDAS_REQUIRE(ctx, cb && tree6 && tree3 && args && tree6->dim == 6 && tree3->dim == 3);
     const midas_step_args& s = *args;
     MIDAS_REQUIRE(ctx, s.N > 0 && s.poses_in_dev && s.poses_prop_dev && s.poses_out_dev && s.weights_dev &&
@@ -347,25 +362,32 @@ MIDAS_EXPORT int midas_filter_step(midas_ctx* ctx, const midas_codebook* cb, con
     const int npart = particle_update_blocks(N);
     void *scores, *x, *e, *valid, *pmax, *pmin, *prm = nullptr, *cdf;
     int rc;
-    if ((rc = midas_scratch(ctx, (size_t)cb->K * sizeof(double), &scores))) return rc;
-    if ((rc = midas_scratch(ctx, (size_t)N * sizeof(double), &x))) return rc;
-    if ((rc = midas_scratch(ctx, (size_t)N * sizeof(double), &e))) return rc;
-    if ((rc = midas_scratch(ctx, (size_t)N, &valid))) return rc;
-    if ((rc = midas_scratch(ctx, (size_t)npart * sizeof(double), &pmax))) return rc;
-    if ((rc = midas_scratch(ctx, (size_t)npart * sizeof(double), &pmin))) return rc;
+    const size_t Bz = (size_t)B;
+    if ((rc = midas_scratch(ctx, Bz * cb->K * sizeof(double), &scores))) return rc;
+    if ((rc = midas_scratch(ctx, Bz * N * sizeof(double), &x))) return rc;
+    if ((rc = midas_scratch(ctx, Bz * N * sizeof(double), &e))) return rc;
+    if ((rc = midas_scratch(ctx, Bz * N, &valid))) return rc;
+    if ((rc = midas_scratch(ctx, Bz * npart * sizeof(double), &pmax))) return rc;
+    if ((rc = midas_scratch(ctx, Bz * npart * sizeof(double), &pmin))) return rc;
     if (s.gt16_dev && s.rmse_dev)
-        if ((rc = midas_scratch(ctx, (size_t)npart * 2 * sizeof(double), &prm))) return rc;
-    if ((rc = midas_scratch(ctx, (size_t)N * sizeof(double), &cdf))) return rc;
+        if ((rc = midas_scratch(ctx, Bz * npart * 2 * sizeof(double), &prm))) return rc;
+    if ((rc = midas_scratch(ctx, Bz * N * sizeof(double), &cdf))) return rc;
 
     if (ctx->prof && ctx->ev_ready) {  // calibration: an empty event pair measures the bracket overhead itself
         (void)hipEventRecord(ctx->ev[6], ctx->stream);
         (void)hipEventRecord(ctx->ev[7], ctx->stream);
     }
     prof_mark(ctx, 0);
-    if ((rc = launch_score(ctx, cb, 1, s.code_dev, (double*)scores))) return rc;
+    // a batch scores all its codes in one pass over the codebook on the matrix cores when the layout allows it
+    const bool mfma = B > 1 && cb->dtype == MIDAS_F32 && cb->D % 16 == 0 && (uintptr_t)cb->emb % 16 == 0;
+    if ((rc = mfma ? launch_score_batch(ctx, cb, B, s.code_dev, (double*)scores)
+                   : launch_score(ctx, cb, B, s.code_dev, (double*)scores)))
+        return rc;
     prof_mark(ctx, 1);
 
     ParticleUpdateArgs pa;
+    pa.batch = B;
+    pa.score_stride = cb->K;
     pa.N = N;
     pa.poses_in = s.poses_in_dev;
     pa.poses_prop = s.poses_prop_dev;
@@ -395,6 +417,7 @@ MIDAS_EXPORT int midas_filter_step(midas_ctx* ctx, const midas_codebook* cb, con
     prof_mark(ctx, 2);
 
     StepTailArgs ta;
+    ta.batch = B;
     ta.N = N;
     ta.npart = npart;
     ta.x = (const double*)x;

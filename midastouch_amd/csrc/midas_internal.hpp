@@ -160,6 +160,8 @@ struct ParticleUpdateArgs {
     float std_t, std_r;
     uint64_t seed, step;
     int64_t slot_base = 0;  // global index of local particle 0 (Philox key)
+    int32_t batch = 1;      // trajectories (grid.y); per-trajectory arrays are (batch, ...) contiguous
+    int64_t score_stride = 0;  // K: scores are (batch, K)
     const int32_t* hint_in;
     int32_t* nn_idx;
     const double* scores;  // [K]
@@ -191,6 +193,7 @@ int launch_search(midas_ctx* ctx, int64_t N, const double* cdf, int64_t M, int32
 int launch_gather_rows(midas_ctx* ctx, int64_t M, const int32_t* idx, const void* src, void* dst, int32_t row_bytes);
 // fused tail of the step: x,valid,partials -> weights (masked) -> cdf -> search -> gather
 struct StepTailArgs {
+    int32_t batch = 1;       // trajectories (grid.y)
     int64_t N;
     int npart;               // number of part_max/part_min entries
     const double* x;
@@ -218,7 +221,8 @@ struct StepTailArgs {
 int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base);
 int launch_tail_a(midas_ctx* ctx, int64_t N, const double* x, const uint8_t* valid, int np, int pstride,
                   const double* pmax_all, const double* pmin_all, int32_t softmax, double* e_io, double* lp_out,
-                  double* block_sums_e, double* block_totals_em, double* flags_out, int32_t* flag, int32_t* status);
+                  double* block_sums_e, double* block_totals_em, double* flags_out, int32_t* flag, int32_t* status,
+                  int batch = 1);
 int launch_tail_fin(midas_ctx* ctx, int64_t N, const double* e, const uint8_t* valid, double* weights, double* cdf_io, int G,
                     int nb, const double* g2_all, int rank, const double* g1_all, double n_total, double* rmse_out,
                     const int32_t* flag, int32_t* status);

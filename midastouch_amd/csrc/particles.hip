@@ -863,6 +863,17 @@ __global__ __launch_bounds__(256) void k_rmse_final(int64_t N, int nb, const dou
 // =================================================================================================
 __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a) {
     __shared__ double s_cd[KD_MAX_LEVELS * 64];  // child-distance columns, reused by both searches
+    if (blockIdx.y) {  // batch of trajectories: every per-trajectory array is (B, ...) contiguous
+        const int64_t b = blockIdx.y, o = b * a.N;
+        a.poses_in += o * 16; a.poses_prop += o * 16; a.odom16 += b * 16;
+        if (a.tn) { a.tn += o * 3; a.rot += o * 3; }
+        if (a.hint_in) a.hint_in += o;
+        a.nn_idx += o; a.scores += b * a.score_stride; a.x += o; a.e += o; a.valid += o;
+        a.part_max += b * gridDim.x; a.part_min += b * gridDim.x;
+        if (a.gt16) { a.gt16 += b * 16; a.part_rmse += 2 * b * gridDim.x; }
+        if (a.status_reset) a.status_reset += 2 * b;
+        a.slot_base += o;
+    }
     const int64_t n = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool live = n < a.N;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1006,7 +1017,7 @@ int launch_particle_update(midas_ctx* ctx, const midas_tree* t6, const midas_tre
     // MIDAS_ABLATE (profiling only, results become wrong): bit 0 skips the NN search, bit 1 the mesh prune
     static const int ablate = getenv("MIDAS_ABLATE") ? atoi(getenv("MIDAS_ABLATE")) : 0;
     a.ablate = ablate;
-    hipLaunchKernelGGL(k_particle_update, dim3((unsigned)particle_update_blocks(a.N)), dim3(64), 0, ctx->stream,
+    hipLaunchKernelGGL(k_particle_update, dim3((unsigned)particle_update_blocks(a.N), (unsigned)(a.batch > 1 ? a.batch : 1)), dim3(64), 0, ctx->stream,
                        view_of<Kd6>(t6), view_of<Kd3>(t3), a);
     MIDAS_HIP_CHECK(ctx, hipGetLastError());
     return MIDAS_OK;

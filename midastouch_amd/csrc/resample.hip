@@ -319,6 +319,13 @@ __global__ __launch_bounds__(256) void k_tail_a(int64_t N, const double* __restr
                                                 int32_t* __restrict__ status) {
     __shared__ double s_red[24];
     __shared__ double s_gtot[16];
+    if (blockIdx.y) {  // batch of trajectories
+        const int64_t b = blockIdx.y, o = b * N;
+        x += o; valid += o; e_io += o; lp_out += o;
+        pmax_all += b * np; pmin_all += b * np;
+        block_sums_e += b * gridDim.x; block_totals_em += b * gridDim.x;
+        flag += b; status += 2 * b;
+    }
     double mx, mn;
     block_extrema(pmax_all, pmin_all, np, pstride, s_red, mx, mn);
     const bool apply = softmax && !(__builtin_fabs(mx - mn) <= ISCLOSE_ATOL);
@@ -449,12 +456,22 @@ struct TailBArgs {
     const double* part_rmse;
     int nrm;
     double* rmse_out;
+    int64_t slot_base;     // Philox key offset of slot 0 (b * N for trajectory b of a batch)
 };
 
 __global__ __launch_bounds__(256) void k_tail_b(TailBArgs a) {
     __shared__ double s_bp[TB_MAX_BLOCKS];
     __shared__ double s_end[TB_MAX_BLOCKS];
     __shared__ double s_tot[2];
+    if (blockIdx.y) {  // batch of trajectories
+        const int64_t b = blockIdx.y, o = b * a.N;
+        a.e += o; a.valid += o; a.lp += o; a.block_sums_e += b * a.nb; a.block_totals_em += b * a.nb;
+        a.flag += b; a.status += 2 * b; a.weights += o;
+        if (a.u) a.u += o;
+        a.ridx += o; a.poses_prop += o * 16; a.poses_out += o * 16; a.weights_out += o; a.nn_idx += o; a.hint_out += o;
+        if (a.part_rmse) { a.part_rmse += 2 * b * a.nrm; a.rmse_out += 2 * b; }
+        a.slot_base += o;
+    }
     const bool apply = a.flag[0] != 0;
     // fetch the block partials in parallel (s_bp <- totals of e*valid, s_end <- sums of e), then one thread
     // turns them into the sequential prefixes the spec asks for - no dependent global loads
@@ -492,10 +509,10 @@ __global__ __launch_bounds__(256) void k_tail_b(TailBArgs a) {
             double t;
             bool upper;
             if (a.mode == MIDAS_RESAMPLE_MULTINOMIAL) {
-                t = a.u ? a.u[i] : philox_uniform53((uint64_t)i, a.seed, a.step);
+                t = a.u ? a.u[i] : philox_uniform53((uint64_t)(a.slot_base + i), a.seed, a.step);
                 upper = false;
             } else {
-                const float r = a.u32 >= 0.0f ? a.u32 : philox_uniform24(a.seed, a.step);
+                const float r = a.u32 >= 0.0f ? a.u32 : philox_uniform24(a.seed + (uint64_t)blockIdx.y, a.step);
                 const float off = r / (float)N;
                 t = (double)i / (double)N + (double)off;
                 t = t >= 1.0 ? t - 1.0 : t;
@@ -702,8 +719,9 @@ int launch_gather_rows(midas_ctx* ctx, int64_t M, const int32_t* idx, const void
 
 int launch_tail_a(midas_ctx* ctx, int64_t N, const double* x, const uint8_t* valid, int np, int pstride,
                   const double* pmax_all, const double* pmin_all, int32_t softmax, double* e_io, double* lp_out,
-                  double* block_sums_e, double* block_totals_em, double* flags_out, int32_t* flag, int32_t* status) {
-    hipLaunchKernelGGL(k_tail_a, dim3((unsigned)ceil_div(N, SCAN_BLOCK)), dim3(256), 0, ctx->stream, N, x, valid, np, pstride,
+                  double* block_sums_e, double* block_totals_em, double* flags_out, int32_t* flag, int32_t* status,
+                  int batch) {
+    hipLaunchKernelGGL(k_tail_a, dim3((unsigned)ceil_div(N, SCAN_BLOCK), (unsigned)(batch > 1 ? batch : 1)), dim3(256), 0, ctx->stream, N, x, valid, np, pstride,
                        pmax_all, pmin_all, softmax, e_io, lp_out, block_sums_e, block_totals_em, flags_out, flag, status);
     LAUNCH_CHECK(ctx);
     return MIDAS_OK;
@@ -736,14 +754,15 @@ int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base) 
     const int nb = (int)ceil_div(a.N, SCAN_BLOCK);
     if (nb > TB_MAX_BLOCKS) return midas_set_error(ctx, MIDAS_ERR_INVALID, "N", "more than 4 M particles per GPU: shard them");
     void* sc;
-    int rc = midas_scratch(ctx, (size_t)nb * 2 * sizeof(double) + 64, &sc);
+    const int B = a.batch > 1 ? a.batch : 1;
+    int rc = midas_scratch(ctx, (size_t)B * nb * 2 * sizeof(double) + (size_t)B * sizeof(int32_t) + 64, &sc);
     if (rc) return rc;
     double* psum = (double*)sc;
-    double* pw = psum + nb;
+    double* pw = psum + (size_t)B * nb;
     double* e = a.e;
-    int32_t* flag = (int32_t*)(pw + nb);
+    int32_t* flag = (int32_t*)(pw + (size_t)B * nb);
     if ((rc = launch_tail_a(ctx, a.N, a.x, a.valid, a.npart, 1, a.part_max, a.part_min, a.softmax, e, a.cdf, psum, pw, nullptr,
-                            flag, a.status)))
+                            flag, a.status, B)))
         return rc;
     prof_mark(ctx, prof_slot_base + 1);
     TailBArgs b;
@@ -752,7 +771,8 @@ int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base) 
     b.seed = a.seed; b.step = a.step; b.ridx = a.ridx; b.poses_prop = a.poses_prop; b.poses_out = a.poses_out;
     b.weights_out = a.weights_out; b.nn_idx = a.nn_idx; b.hint_out = a.hint_out;
     b.part_rmse = a.part_rmse; b.nrm = a.part_rmse ? particle_update_blocks(a.N) : 0; b.rmse_out = a.rmse_out;
-    hipLaunchKernelGGL(k_tail_b, dim3((unsigned)ceil_div(a.N, 256)), dim3(256), 0, ctx->stream, b);
+    b.slot_base = 0;
+    hipLaunchKernelGGL(k_tail_b, dim3((unsigned)ceil_div(a.N, 256), (unsigned)B), dim3(256), 0, ctx->stream, b);
     LAUNCH_CHECK(ctx);
     prof_mark(ctx, prof_slot_base + 2);
     return MIDAS_OK;

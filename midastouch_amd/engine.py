@@ -108,3 +108,78 @@ class FilterEngine:
         self.ctx.call("midas_profile_read", ms, C.byref(calls), int(reset))
         names = [self.ctx.lib.midas_profile_slot_name(i).decode() for i in range(_lib.PROF_SLOTS)]
         return {n: ms[i] for i, n in enumerate(names) if n}, calls.value
+
+
+class BatchFilterEngine:
+    """B independent trajectories against one codebook, one C-ABI call per frame of the whole batch
+    (BASELINE config 5, "throughput mode": SURVEY.md 8(e) batch mode).
+
+    State tensors carry a leading batch dimension.  The B tactile codes of a frame are scored in one pass
+    over the codebook on the matrix cores (float32 fma chains, `midas_score_batch`), so a trajectory's
+    scores differ from the single-trajectory engine's float64 GEMV in the 7th digit; everything else is the
+    same kernels with the trajectory as grid.y.  Device-mode Philox streams are keyed by b*N + n.
+    """
+
+    def __init__(self, cb_poses, cb_embeddings, mesh_vertices, batch: int, num_particles: int, *, sig_t=1e-4, sig_r=0.5,
+                 pen_max=0.002, seed=4000, softmax=True, resample="weighted_random", device=None):
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.ctx = _lib.context(dev)
+        self.device = self.ctx.device
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.cb_poses = torch.as_tensor(cb_poses).to(**f32).contiguous()
+        self.cb_feat = ops.se3_feature(self.cb_poses)
+        self.tree6 = ops.Tree(self.cb_feat)
+        self.codebook = ops.Codebook(torch.as_tensor(cb_embeddings).to(self.device))
+        self.tree3 = ops.Tree(torch.as_tensor(mesh_vertices).to(self.device, torch.float64))
+        self.tree6.attach_mesh(self.tree3, self.cb_poses)
+        self.B, self.N = int(batch), int(num_particles)
+        self.sig_t, self.sig_r, self.pen_max = float(sig_t), float(sig_r), float(pen_max)
+        self.seed, self.softmax = int(seed), bool(softmax)
+        self.mode = {"weighted_random": _lib.RESAMPLE_MULTINOMIAL, "low_var": _lib.RESAMPLE_SYSTEMATIC,
+                     "low_var_batch": _lib.RESAMPLE_SYSTEMATIC}[resample]
+        B, N, d = self.B, self.N, self.device
+        self.poses = torch.zeros((B, N, 4, 4), **f32)
+        self.poses_prop = torch.zeros((B, N, 4, 4), **f32)
+        self.weights = torch.zeros((B, N), dtype=torch.float64, device=d)
+        self.weights_res = torch.ones((B, N), dtype=torch.float64, device=d)
+        self.nn_idx = torch.zeros((B, N), dtype=torch.int32, device=d)
+        self.hint = torch.full((B, N), -1, dtype=torch.int32, device=d)
+        self.hint_next = torch.full((B, N), -1, dtype=torch.int32, device=d)
+        self.ridx = torch.zeros((B, N), dtype=torch.int32, device=d)
+        self.status = torch.zeros((B, 2), dtype=torch.int32, device=d)
+        self.rmse = torch.zeros((B, 2), dtype=torch.float64, device=d)
+        self.telemetry = torch.zeros(2, dtype=torch.int64, device=d)
+        self.step_count = 0
+
+    def set_particles(self, poses):
+        poses = torch.as_tensor(poses).to(self.device, torch.float32)
+        if tuple(poses.shape) != (self.B, self.N, 4, 4):
+            raise MidasError(f"expected ({self.B},{self.N},4,4) poses, got {tuple(poses.shape)}")
+        self.poses.copy_(poses)
+        self.hint.fill_(-1)
+
+    def project_to_codebook(self):
+        flat = self.poses.view(-1, 4, 4)
+        idx = ops.nn6(self.tree6, ops.se3_feature(flat))
+        self.poses.copy_(ops.gather_rows(self.cb_poses, idx).view_as(self.poses))
+        self.hint.copy_(idx.view_as(self.hint))
+
+    def step(self, odoms, codes, gts=None, tn=None, rot=None, u=None, u32=-1.0):
+        """odoms (B,4,4) f32, codes (B,D) f64, gts (B,4,4) f32 or None; optional host draws tn/rot (B,N,3), u (B,N)."""
+        a = StepArgs()
+        a.N = self.N
+        a.poses_in, a.poses_prop, a.poses_out = _ptr(self.poses), _ptr(self.poses_prop), _ptr(self.poses)
+        a.weights, a.weights_out = _ptr(self.weights), _ptr(self.weights_res)
+        a.hint_in, a.nn_idx, a.hint_out, a.ridx = _ptr(self.hint), _ptr(self.nn_idx), _ptr(self.hint_next), _ptr(self.ridx)
+        a.odom16, a.code, a.gt16 = _ptr(odoms), _ptr(codes), _ptr(gts)
+        a.rmse = _ptr(self.rmse) if gts is not None else None
+        a.tn, a.rot, a.u, a.u32 = _ptr(tn), _ptr(rot), _ptr(u), float(u32)
+        a.std_t, a.std_r, a.seed, a.step = self.sig_t, self.sig_r, self.seed, self.step_count
+        a.prune_thr, a.softmax, a.resample_mode = self.pen_max, int(self.softmax), self.mode
+        a.status, a.telemetry = _ptr(self.status), _ptr(self.telemetry)
+        self._keep = (odoms, codes, gts, tn, rot, u)
+        self.ctx.bind_current_stream()
+        self.ctx.check(self.ctx.lib.midas_filter_step_batch(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h,
+                                                            C.byref(a), self.B))
+        self.hint, self.hint_next = self.hint_next, self.hint
+        self.step_count += 1

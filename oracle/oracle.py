@@ -367,7 +367,7 @@ class OracleFilter:
     def SE3_NN_idx(self, poses):
         return nn6(R3_SE3(poses), self.cb_feat)[0]
 
-    def step(self, poses, odom, code, tn, rot_deg, u=None, mode="weighted_random", u32=None, softmax=True):
+    def step(self, poses, odom, code, tn, rot_deg, u=None, mode="weighted_random", u32=None, softmax=True, scores=None):
         """Returns dict with every intermediate the parity tests compare."""
         out = {}
         p1 = propagate(poses, odom, tn, rot_deg)
@@ -375,7 +375,8 @@ class OracleFilter:
         feat = R3_SE3(p1)
         idx, d2 = nn6(feat, self.cb_feat)
         out["feat"], out["nn_idx"], out["nn_d2"] = feat, idx, d2
-        scores = score_codebook(self.emb, code)
+        if scores is None:  # batch mode passes the matrix-core scores (score_codebook_batch)
+            scores = score_codebook(self.emb, code)
         out["scores"] = scores
         x = scores[idx]
         dist = nn3_dist(p1, self.verts)

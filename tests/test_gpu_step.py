@@ -163,3 +163,38 @@ def test_step_full_size_properties(dev):
         feat = __import__("midastouch_amd.ops", fromlist=["ops"]).se3_feature(eng.poses_prop[:512])
         d = torch.cdist(feat.double(), eng.cb_feat.double())
         assert torch.equal(d.argmin(dim=1).int(), eng.nn_idx[:512])
+
+
+def test_batch_engine_matches_oracle_per_trajectory(dev, oracle):
+    """BASELINE config 5 shape (B trajectories per frame): each trajectory of the batch equals the oracle run with
+    the matrix-core scores and the Philox streams keyed by b*N + n - indices exact, weights 1e-12."""
+    from midastouch_amd.engine import BatchFilterEngine
+    B, N, K, D = 5, 1024, 3000, 256
+    cb, traj, scale = _setup(N, K, D, seed=4, obj="cotter-pin")
+    from midastouch_amd.synthetic import make_trajectory
+    trajs = [make_trajectory(cb, T=8, seed=2100 + b) for b in range(B)]
+    ofl = oracle.OracleFilter(cb.poses, cb.embeddings, cb.mesh_vertices)
+    eng = BatchFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, B, N, sig_t=1e-4, sig_r=0.5, seed=4000, device=dev)
+    rng = np.random.default_rng(3)
+    poses = np.stack([cb.poses[rng.integers(0, K, N)] for _ in range(B)])
+    eng.set_particles(torch.as_tensor(poses))
+    for t in range(1, 6):
+        odoms = torch.as_tensor(np.stack([tr.odoms[t] for tr in trajs])).to(dev)
+        codes = torch.as_tensor(np.stack([tr.codes[t] for tr in trajs])).to(dev)
+        gts = torch.as_tensor(np.stack([tr.gt_poses[t] for tr in trajs])).to(dev)
+        eng.step(odoms, codes, gts)
+        sc = oracle.score_codebook_batch(cb.embeddings, codes.cpu().numpy())
+        tn_all, rot_all = oracle.philox_noise(B * N, 4000, t - 1, np.float32(1e-4), np.float32(0.5))
+        u_all = oracle.philox_uniform64(B * N, 4000, t - 1)
+        for b in range(B):
+            sl = slice(b * N, (b + 1) * N)
+            ref = ofl.step(poses[b], trajs[b].odoms[t], trajs[b].codes[t], tn_all[sl], rot_all[sl], u=u_all[sl], scores=sc[b])
+            assert np.array_equal(eng.nn_idx[b].cpu().numpy(), ref["nn_idx"]), (t, b)
+            np.testing.assert_allclose(eng.weights[b].cpu().numpy(), ref["weights"], rtol=1e-12, atol=0)
+            assert np.array_equal(eng.ridx[b].cpu().numpy(), ref["ridx"]), (t, b)
+            assert np.array_equal(eng.poses[b].cpu().numpy(), ref["poses"]), (t, b)
+            st = eng.status[b].cpu().numpy()
+            assert st[0] == ref["status"] and st[1] == int(ref["mask"].sum())
+            rt, rr = oracle.particle_rmse(ref["poses_prop"], trajs[b].gt_poses[t])
+            assert eng.rmse[b, 0].item() == pytest.approx(rt, rel=1e-9)
+            poses[b] = ref["poses"]
