@@ -40,12 +40,12 @@ constexpr int KD_MAX_LEVELS = 10; // 8-ary levels (8^10 leaves x 16 slots is far
 // distance rho from F_k to that neighbour (rounded down), coordinates inlined so that one 32-byte
 // read is one candidate.  Unused records are sentinels (+inf coordinates, rho = +inf).
 struct alignas(16) Nbr6 { float c[6]; int32_t idx; float rho; };
-constexpr int NBR_M = 128;
+constexpr int NBR_M = 256;
 constexpr int NBR_REC = NBR_M + 1;  // record 0 = the entry itself
 
 // Mesh-vertex record of the prune fast path: the vertices nearest to a codebook entry's translation.
 struct alignas(16) MeshRec { double c[3]; float rho; int32_t pad; };
-constexpr int MESH_M = 128;
+constexpr int MESH_M = 256;
 constexpr int MESH_REC = MESH_M + 1;  // record 0 = header: c = the entry's translation, rho = distance of the
                                       // first vertex NOT in the list
 

@@ -528,11 +528,30 @@ __global__ __launch_bounds__(256) void k_tail_b(TailBArgs a) {
             if (lo >= a.nb) {
                 src = (int32_t)(N - 1);
             } else {
-                int64_t l2 = (int64_t)lo << 12, h2 = l2 + SCAN_BLOCK < N ? l2 + SCAN_BLOCK : N;
+                // Inside the 4096-slot block: a binary search on the division-free comparison (BP + lp_i) vs t * total
+                // locates the slot to within rounding (probes are what this kernel pays for: 12 is the minimum);
+                // the exact predicate cdf_i = (BP + lp_i) / total < t (<= for the systematic mode) then walks to the
+                // true boundary - it is monotone in i, so the result is exactly the lower/upper bound over the cdf
+                // values the sharded path materialises.
+                const int64_t b_lo = (int64_t)lo << 12, b_hi = b_lo + SCAN_BLOCK < N ? b_lo + SCAN_BLOCK : N;
+                const double bp = s_bp[lo], tt = t * total;
+                int64_t l2 = b_lo, h2 = b_hi;
                 while (h2 > l2) {
                     const int64_t mid = l2 + ((h2 - l2) >> 1);
-                    const double c = cdf_at(a.lp, s_bp, total, mid, N);
-                    if (upper ? (c <= t) : (c < t)) l2 = mid + 1; else h2 = mid;
+                    const double c = bp + a.lp[mid];
+                    if (upper ? (c <= tt) : (c < tt)) l2 = mid + 1; else h2 = mid;
+                }
+                if (l2 >= b_hi) l2 = b_hi - 1;
+                // exact fix-up
+                while (l2 > b_lo) {
+                    const double c = cdf_at(a.lp, s_bp, total, l2 - 1, N);
+                    if (upper ? (c <= t) : (c < t)) break;
+                    --l2;
+                }
+                while (l2 < b_hi - 1) {
+                    const double c = cdf_at(a.lp, s_bp, total, l2, N);
+                    if (!(upper ? (c <= t) : (c < t))) break;
+                    ++l2;
                 }
                 src = (int32_t)(l2 < N ? l2 : N - 1);
             }
