@@ -554,8 +554,11 @@ MD bool wave_search(const TreeView<KD>& tv, const typename KD::T* q, typename KD
 // six-term sums, so "certified" also holds for the COMPUTED distances and their tie rule.
 // Returns true when certified; otherwise (best, bi) is a valid bound for the tree search.
 constexpr int SCAN_BATCH = 8;  // records fetched per round trip of the list scans (NBR_M, MESH_M are multiples)
+constexpr int NN_SOLO = 32;    // records a lane scans by itself before the wave takes over its list
+constexpr int MESH_SOLO = 16;
 
-MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t h, float& best, int64_t& bi, int* n_scanned) {
+MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t h, float& best, int64_t& bi, int* n_scanned,
+                      int max_records = NBR_M) {
     const Nbr6* nb = tv.nbrs + (size_t)h * NBR_REC;
     {
         const Nbr6 self = nb[0];
@@ -569,7 +572,7 @@ MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t h, float&
     const float rslack = -8e-7f * r;
     int scanned = 0;
     bool certified = false;
-    for (int s0 = 1; s0 <= NBR_M && !certified; s0 += SCAN_BATCH) {
+    for (int s0 = 1; s0 <= max_records && !certified; s0 += SCAN_BATCH) {
         Nbr6 e[SCAN_BATCH];
 #pragma unroll
         for (int j = 0; j < SCAN_BATCH; ++j) e[j] = nb[s0 + j];
@@ -591,7 +594,7 @@ MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t h, float&
             }
         }
     }
-    if (!certified) {
+    if (!certified && max_records >= NBR_M) {
         const float g = fmaf_(tv.rho_out[h] - r, 0.9999996f, rslack);
         certified = g > 0.0f && g * g * 0.99997f > best;
     }
@@ -599,18 +602,162 @@ MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t h, float&
     return certified;
 }
 
+// ---- wave-cooperative continuation of the list scans ------------------------------------------------
+// Most lanes certify inside their first batch of records; the few that do not used to walk the rest of
+// their list alone (up to 32 dependent round trips) while 60 lanes idled.  Here the whole wave serves
+// them one at a time: 64 records per round trip, one per lane, reduced with the exact (distance, index)
+// tie rule.  Any evaluated candidate bounds the answer from above, so after a chunk the proof is the same
+// triangle-inequality test on the chunk's LAST record (largest rho): everything beyond it is farther.
+MD float rl_f32(float v, int lane) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), lane)); }
+MD int rl_i32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+// minimum over the wave of (d, idx) with ties to the smaller idx; result uniform
+MD void wave_best(float& d, int& i) {
+#define MIDAS_STEP(CTRL)                                                              \
+    {                                                                                 \
+        const float od = __uint_as_float(dpp_u32<CTRL>(__float_as_uint(d)));          \
+        const int oi = (int)dpp_u32<CTRL>((uint32_t)i);                                \
+        if (od < d || (od == d && oi < i)) { d = od; i = oi; }                         \
+    }
+    MIDAS_STEP(DPP_XOR1) MIDAS_STEP(DPP_XOR2) MIDAS_STEP(DPP_HALF_MIRROR) MIDAS_STEP(0x140 /* row_mirror */)
+#undef MIDAS_STEP
+    float bd = rl_f32(d, 0);
+    int bi = rl_i32(i, 0);
+#pragma unroll
+    for (int r = 16; r < 64; r += 16) {
+        const float od = rl_f32(d, r);
+        const int oi = rl_i32(i, r);
+        if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+    }
+    d = bd;
+    i = bi;
+}
+
+// one full cooperative scan of entry h's list for the query of lane `owner`, records [first, NBR_M];
+// returns certified; (bb, bi) in/out uniform
+MD bool coop_scan_list(const TreeView<Kd6>& tv, const float* qq, int h, int first, float rr, float& bb, int& bi) {
+    const int lane = threadIdx.x & 63;
+    const Nbr6* nb = tv.nbrs + (size_t)h * NBR_REC;
+    const float rslack = -8e-7f * rr;
+    for (int c0 = first; c0 <= NBR_M; c0 += 64) {
+        const int s = c0 + lane;
+        float d = INFINITY, rho = INFINITY;
+        int id = 0x7fffffff;
+        if (s <= NBR_M) {
+            const Nbr6 e = nb[s];
+            Point6 p;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) p.c[a] = e.c[a];
+            d = dist2(qq, p);
+            if (!(d == d)) d = INFINITY;
+            id = e.idx;
+            rho = e.rho;
+        }
+        wave_best(d, id);
+        if (d < bb || (d == bb && id < bi)) { bb = d; bi = id; }
+        const int last = (c0 + 63 <= NBR_M ? c0 + 63 : NBR_M) - c0;
+        const float g = fmaf_(rl_f32(rho, last) - rr, 0.9999996f, rslack);
+        if (g > 0.0f && g * g * 0.99997f > bb) return true;
+    }
+    const float g = fmaf_(tv.rho_out[h] - rr, 0.9999996f, rslack);
+    return g > 0.0f && g * g * 0.99997f > bb;
+}
+
+// serve the lanes in `need`: continue their hint scan after the first batch, then try the twin entry
+MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float& best, int64_t& bi, bool need, bool& done) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(need);
+    while (todo) {
+        const int owner = (int)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        float qq[6];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) qq[d] = rl_f32(q[d], owner);
+        const int h = rl_i32(hint, owner);
+        float bb = rl_f32(best, owner);
+        int b_i = rl_i32((int)bi, owner);
+        // r = |q - F_h| recomputed from the self record (uniform)
+        const Nbr6 self = tv.nbrs[(size_t)h * NBR_REC];
+        Point6 ps;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) ps.c[a] = self.c[a];
+        const float rr = __builtin_sqrtf(dist2(qq, ps));
+        bool cert = coop_scan_list(tv, qq, h, 1 + NN_SOLO, rr, bb, b_i);
+        if (!cert) {
+            const int tw = tv.twin[h];
+            if (tw >= 0) {  // second chance from the entry across the angle-pi cut (record 0 = the twin itself)
+                const Nbr6 ts = tv.nbrs[(size_t)tw * NBR_REC];
+                Point6 pt;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) pt.c[a] = ts.c[a];
+                const float r2 = __builtin_sqrtf(dist2(qq, pt));
+                cert = coop_scan_list(tv, qq, tw, 0, r2, bb, b_i);
+            }
+        }
+        if (lane == owner) { best = bb; bi = b_i; done = cert; }
+    }
+}
+
+// prune: continue the vertex-list scan of the lanes in `need` (mv < 0 after their first batch)
+MD void mesh_coop(const MeshRec* __restrict__ vlist, int32_t h, const double* tq, double t2, double thr, bool need, int& mv) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(need);
+    while (todo) {
+        const int owner = (int)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        double q3[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const long long b = __double_as_longlong(tq[d]);
+            const unsigned lo = (unsigned)rl_i32((int)(unsigned)b, owner), hi = (unsigned)rl_i32((int)(unsigned)(b >> 32), owner);
+            q3[d] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        }
+        const int hh = rl_i32(h, owner);
+        const MeshRec* vl = vlist + (size_t)hh * MESH_REC;
+        const MeshRec hd = vl[0];
+        Point3 ph;
+        ph.c[0] = hd.c[0]; ph.c[1] = hd.c[1]; ph.c[2] = hd.c[2];
+        const double delta = __builtin_sqrt(dist2(q3, ph)) * (1.0 + 1e-12);
+        const double lim = thr * (1.0 + 1e-9) + delta + 1e-12;
+        int res = -1;
+        for (int c0 = 1 + MESH_SOLO; c0 <= MESH_M && res < 0; c0 += 64) {
+            const int s = c0 + lane;
+            bool hit = false;
+            float rho = INFINITY;
+            if (s <= MESH_M) {
+                const MeshRec e = vl[s];
+                Point3 p;
+                p.c[0] = e.c[0]; p.c[1] = e.c[1]; p.c[2] = e.c[2];
+                rho = e.rho;
+                // a record counts only if no EARLIER record already proves "invalid" - identical to the serial scan
+                hit = dist2(q3, p) <= t2;
+            }
+            const unsigned long long hits = __ballot(hit);
+            const unsigned long long stops = __ballot((double)rho * (1.0 - 1e-7) > lim);
+            // serial semantics: walk the records in order; the first event decides
+            const int fh = hits ? (int)__builtin_ctzll(hits) : 64, fs = stops ? (int)__builtin_ctzll(stops) : 64;
+            if (fh < 64 && fh < fs) res = 1;
+            else if (fs < 64) res = 0;
+        }
+        if (res < 0) res = ((double)hd.rho * (1.0 - 1e-7) > lim) ? 0 : -1;
+        if (lane == owner) mv = res;
+    }
+}
+
+
 // Prune fast path: decide "some mesh vertex within thr of tq" from the vertex list of the particle's NN
 // entry h.  Returns 1 (valid: an actual vertex passes the exact test d2 <= t2), 0 (invalid: every vertex not
 // yet scanned is provably farther than thr, triangle inequality with slack far above float64 rounding) or
 // -1 (list exhausted: the caller runs the tree search).
-MD int mesh_list_check(const MeshRec* __restrict__ vlist, int32_t h, const double* tq, double t2, double thr) {
+MD int mesh_list_check(const MeshRec* __restrict__ vlist, int32_t h, const double* tq, double t2, double thr,
+                       int max_records = MESH_M) {
     const MeshRec* vl = vlist + (size_t)h * MESH_REC;
     const MeshRec hd = vl[0];
     Point3 ph;
     ph.c[0] = hd.c[0]; ph.c[1] = hd.c[1]; ph.c[2] = hd.c[2];
     const double delta = __builtin_sqrt(dist2(tq, ph)) * (1.0 + 1e-12);
     const double lim = thr * (1.0 + 1e-9) + delta + 1e-12;  // a vertex with rho*(1-1e-7) > lim cannot be within thr of tq
-    for (int s0 = 1; s0 <= MESH_M; s0 += SCAN_BATCH) {
+    for (int s0 = 1; s0 <= max_records; s0 += SCAN_BATCH) {
         MeshRec e[SCAN_BATCH];
 #pragma unroll
         for (int j = 0; j < SCAN_BATCH; ++j) e[j] = vl[s0 + j];
@@ -622,6 +769,7 @@ MD int mesh_list_check(const MeshRec* __restrict__ vlist, int32_t h, const doubl
             if (dist2(tq, p) <= t2) return 1;
         }
     }
+    if (max_records < MESH_M) return -1;
     return ((double)hd.rho * (1.0 - 1e-7) > lim) ? 0 : -1;
 }
 
@@ -633,18 +781,9 @@ MD bool nn6_wave(const TreeView<Kd6>& tv, const float* q, bool live, int32_t hin
     float best = INFINITY;
     int64_t bi = 0;
     bool done = !live;
-    if (live && hint >= 0 && (int64_t)hint < tv.K) {
-        done = nn6_hint_scan(tv, q, hint, best, bi, n_scanned);
-        if (!done) {  // second chance from the entry across the angle-pi cut
-            const int32_t tw = tv.twin[hint];
-            if (tw >= 0) {
-                float b2;
-                int64_t i2;
-                if (nn6_hint_scan(tv, q, tw, b2, i2, nullptr)) { best = b2; bi = i2; done = true; }
-                else if (b2 < best || (b2 == best && i2 < bi)) { best = b2; bi = i2; }
-            }
-        }
-    }
+    const bool hinted = live && hint >= 0 && (int64_t)hint < tv.K;
+    if (hinted) done = nn6_hint_scan(tv, q, hint, best, bi, n_scanned, NN_SOLO);  // first records, per lane
+    nn6_coop(tv, q, hint, best, bi, hinted && !done, done);                         // the rest, whole wave per lane
     wave_search<Kd6, false, STATS>(tv, q, best, bi, !done, cd, n_leaves, n_nodes);
     idx = (int32_t)bi;
     d2 = best;
@@ -912,7 +1051,10 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
     int64_t vi = 0;
     int mv = -1;  // 1 valid, 0 invalid, -1 undecided
     if (a.ablate & 2) mv = 1;
-    else if (live && a.vlist) mv = mesh_list_check(a.vlist, bi, q3, a.t2, a.thr);
+    else if (a.vlist) {
+        if (live) mv = mesh_list_check(a.vlist, bi, q3, a.t2, a.thr, MESH_SOLO);  // first records, per lane
+        mesh_coop(a.vlist, bi, q3, a.t2, a.thr, live && mv < 0, mv);              // the rest, whole wave per lane
+    }
     bool ok = wave_search<Kd3, true>(t3, q3, best, vi, live && mv < 0, s_cd);
     if (a.telemetry) {
         const unsigned long long m = __ballot(live && mv < 0);
