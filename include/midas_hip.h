@@ -172,7 +172,7 @@ typedef struct midas_step_args {
     int32_t softmax;
     int32_t resample_mode;
     int32_t* status_dev;         /* [0] cdf status (see midas_cdf), [1] particles kept by the prune */
-    uint64_t* telemetry_dev;     /* NULL or 2 cumulative counters: particles whose NN / prune needed the tree search */
+    uint64_t* telemetry_dev;     /* NULL or 16 cumulative counters: [0],[1] particles whose NN / prune needed the tree search; [2..15] scan statistics and phase clocks (MIDAS_ABLATE=4) */
 } midas_step_args;
 
 int midas_filter_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
@@ -206,7 +206,7 @@ typedef struct midas_shard_update_args {
     float std_t, std_r;
     uint64_t seed, step;
     double prune_thr;
-    uint64_t* telemetry_dev;    /* NULL or 2 cumulative counters (see midas_step_args) */
+    uint64_t* telemetry_dev;    /* NULL or 16 cumulative counters (see midas_step_args) */
     int32_t* status_dev;        /* 2: zeroed here, filled by midas_tail_a / midas_tail_fin */
     double* flags_dev;          /* the last two doubles of this rank's g2 record (zeroed here, see midas_tail_a) */
 } midas_shard_update_args;

@@ -12,7 +12,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libmidas_hip.so")
+# MIDAS_HIP_LIB: another build of the same library (kernel-tuning sweeps, tools/variants.sh)
+LIB_PATH = os.environ.get("MIDAS_HIP_LIB") or os.path.join(CSRC, "libmidas_hip.so")
 
 MIDAS_F32, MIDAS_F64 = 0, 1
 RESAMPLE_MULTINOMIAL, RESAMPLE_SYSTEMATIC = 0, 1

@@ -1,5 +1,6 @@
 // api.hip - context, scratch, profiling and the extern "C" surface of libmidas_hip.so.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -117,6 +118,7 @@ MIDAS_EXPORT int midas_ctx_create(int device, void* hip_stream, midas_ctx** out)
     // kernels stay ordered with the caller's other work; the library never creates a stream.
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
+    if (const char* ov = getenv("MIDAS_OVERLAP")) ctx->overlap = atoi(ov) != 0;
     *out = ctx;
     return MIDAS_OK;
 }
@@ -372,19 +374,16 @@ static int filter_step_impl(midas_ctx* ctx, const midas_codebook* cb, const mida
     if (s.gt16_dev && s.rmse_dev)
         if ((rc = midas_scratch(ctx, Bz * npart * 2 * sizeof(double), &prm))) return rc;
     if ((rc = midas_scratch(ctx, Bz * N * sizeof(double), &cdf))) return rc;
+    // Single trajectory: the codebook scoring and the particle update share one launch (k_frame_front); the
+    // tail then gathers the scores.  Other layouts / batches: scoring, then the particle update with the scores.
+    void* lp_raw = nullptr;
+    if (B == 1 && ctx->overlap)
+        if ((rc = midas_scratch(ctx, N * sizeof(double), &lp_raw))) return rc;
 
     if (ctx->prof && ctx->ev_ready) {  // calibration: an empty event pair measures the bracket overhead itself
         (void)hipEventRecord(ctx->ev[6], ctx->stream);
         (void)hipEventRecord(ctx->ev[7], ctx->stream);
     }
-    prof_mark(ctx, 0);
-    // a batch scores all its codes in one pass over the codebook on the matrix cores when the layout allows it
-    const bool mfma = B > 1 && cb->dtype == MIDAS_F32 && cb->D % 16 == 0 && (uintptr_t)cb->emb % 16 == 0;
-    if ((rc = mfma ? launch_score_batch(ctx, cb, B, s.code_dev, (double*)scores)
-                   : launch_score(ctx, cb, B, s.code_dev, (double*)scores)))
-        return rc;
-    prof_mark(ctx, 1);
-
     ParticleUpdateArgs pa;
     pa.batch = B;
     pa.score_stride = cb->K;
@@ -413,14 +412,31 @@ static int filter_step_impl(midas_ctx* ctx, const midas_codebook* cb, const mida
     pa.part_min = (double*)pmin;
     pa.gt16 = prm ? s.gt16_dev : nullptr;
     pa.part_rmse = (double*)prm;
-    if ((rc = launch_particle_update(ctx, tree6, tree3, pa))) return rc;
+    bool defer = false;
+    if (B == 1 && ctx->overlap) {
+        prof_mark(ctx, 1);  // fused front: reported in the particle_update slot, the score slot stays empty
+        if ((rc = launch_frame_front(ctx, tree6, tree3, pa, cb, s.code_dev, (double*)scores, &defer))) return rc;
+    }
+    if (!defer) {
+        prof_mark(ctx, 0);
+        // a batch scores all its codes in one pass over the codebook on the matrix cores when the layout allows it
+        const bool mfma = B > 1 && cb->dtype == MIDAS_F32 && cb->D % 16 == 0 && (uintptr_t)cb->emb % 16 == 0;
+        if ((rc = mfma ? launch_score_batch(ctx, cb, B, s.code_dev, (double*)scores)
+                       : launch_score(ctx, cb, B, s.code_dev, (double*)scores)))
+            return rc;
+        prof_mark(ctx, 1);
+        if ((rc = launch_particle_update(ctx, tree6, tree3, pa))) return rc;
+    }
     prof_mark(ctx, 2);
 
     StepTailArgs ta;
     ta.batch = B;
     ta.N = N;
     ta.npart = npart;
-    ta.x = (const double*)x;
+    ta.x = defer ? nullptr : (const double*)x;
+    ta.scores = (const double*)scores;
+    ta.x_raw = (double*)x;
+    ta.lp_raw = (double*)lp_raw;
     ta.e = (double*)e;
     ta.valid = (const uint8_t*)valid;
     ta.part_max = (const double*)pmax;
@@ -449,6 +465,7 @@ static int filter_step_impl(midas_ctx* ctx, const midas_codebook* cb, const mida
         MIDAS_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev[hi]));
         for (int i = lo; i < hi; ++i) {
             float ms = 0.f;
+            if (i == 0 && defer) continue;  // no separate scoring kernel in the fused front
             MIDAS_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
             ctx->prof_ms[i] += (double)ms;
         }

@@ -80,6 +80,7 @@ struct midas_ctx {
     bool ev_ready = false;
     double prof_ms[MIDAS_PROF_SLOTS] = {};
     int64_t prof_calls = 0;
+    bool overlap = true;  // MIDAS_OVERLAP=0: separate scoring and particle-update launches (the pre-fusion path)
 };
 
 struct midas_codebook {
@@ -181,6 +182,8 @@ struct ParticleUpdateArgs {
     double* flags_reset = nullptr;            // nullable: two float64 counters zeroed here (sharded exchange record)
 };
 int particle_update_blocks(int64_t N);
+int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t3, const ParticleUpdateArgs& a,
+                       const midas_codebook* cb, const double* code, double* scores, bool* launched);
 int launch_particle_update(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t3, const ParticleUpdateArgs& a);
 
 // resample.hip
@@ -217,6 +220,11 @@ struct StepTailArgs {
     int32_t* hint_out;
     const double* part_rmse;  // nullable
     double* rmse_out;
+    // deferred mode (x == nullptr): the particle update ran without the scores (concurrently with the scoring);
+    // the tail gathers x = scores[nn_idx], takes the exponentials and decides the isclose guard itself
+    const double* scores = nullptr;
+    double* x_raw = nullptr;   // [N] scratch: raw scores, written only where the guard may fire
+    double* lp_raw = nullptr;  // [N] scratch: block-local prefix of x*valid, likewise
 };
 int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base);
 int launch_tail_a(midas_ctx* ctx, int64_t N, const double* x, const uint8_t* valid, int np, int pstride,

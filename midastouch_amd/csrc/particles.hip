@@ -13,6 +13,7 @@
 
 #include "midas_internal.hpp"
 #include "midas_math.hpp"
+#include "score_body.hpp"
 
 namespace midas {
 
@@ -553,12 +554,26 @@ MD bool wave_search(const TreeView<KD>& tv, const typename KD::T* q, typename KD
 // carries a 3e-5 relative margin on squared distances, two orders above float32 rounding of the
 // six-term sums, so "certified" also holds for the COMPUTED distances and their tie rule.
 // Returns true when certified; otherwise (best, bi) is a valid bound for the tree search.
-constexpr int SCAN_BATCH = 8;  // records fetched per round trip of the list scans (NBR_M, MESH_M are multiples)
-constexpr int NN_SOLO = 32;    // records a lane scans by itself before the wave takes over its list
-constexpr int MESH_SOLO = 16;
+#ifndef MIDAS_NN_BATCH
+#define MIDAS_NN_BATCH 8
+#endif
+#ifndef MIDAS_MESH_BATCH
+#define MIDAS_MESH_BATCH 8
+#endif
+#ifndef MIDAS_NN_SOLO
+#define MIDAS_NN_SOLO 32
+#endif
+#ifndef MIDAS_MESH_SOLO
+#define MIDAS_MESH_SOLO 16
+#endif
+constexpr int NN_BATCH = MIDAS_NN_BATCH, MESH_BATCH = MIDAS_MESH_BATCH;  // records per round trip of the per-lane scans
+constexpr int NN_SOLO = MIDAS_NN_SOLO;      // records a lane scans by itself before the wave takes over its list
+constexpr int MESH_SOLO = MIDAS_MESH_SOLO;
+static_assert(NN_SOLO % NN_BATCH == 0 && NBR_M % NN_BATCH == 0 && MESH_SOLO % MESH_BATCH == 0 && MESH_M % MESH_BATCH == 0,
+              "scan batches must tile the solo prefixes and the lists");
 
 MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t h, float& best, int64_t& bi, int* n_scanned,
-                      int max_records = NBR_M) {
+                      int max_records = NBR_M, float* r_out = nullptr) {
     const Nbr6* nb = tv.nbrs + (size_t)h * NBR_REC;
     {
         const Nbr6 self = nb[0];
@@ -569,15 +584,16 @@ MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t h, float&
         bi = h;
     }
     const float r = __builtin_sqrtf(best);
+    if (r_out) *r_out = r;
     const float rslack = -8e-7f * r;
     int scanned = 0;
     bool certified = false;
-    for (int s0 = 1; s0 <= max_records && !certified; s0 += SCAN_BATCH) {
-        Nbr6 e[SCAN_BATCH];
+    for (int s0 = 1; s0 <= max_records && !certified; s0 += NN_BATCH) {
+        Nbr6 e[NN_BATCH];
 #pragma unroll
-        for (int j = 0; j < SCAN_BATCH; ++j) e[j] = nb[s0 + j];
+        for (int j = 0; j < NN_BATCH; ++j) e[j] = nb[s0 + j];
 #pragma unroll
-        for (int j = 0; j < SCAN_BATCH; ++j) {
+        for (int j = 0; j < NN_BATCH; ++j) {
             if (!certified) {
                 // lower bound of |q - F| for this and every later record, with slack for the rounding of r and rho
                 const float g = fmaf_(e[j].rho - r, 0.9999996f, rslack);
@@ -663,84 +679,117 @@ MD bool coop_scan_list(const TreeView<Kd6>& tv, const float* qq, int h, int firs
     return g > 0.0f && g * g * 0.99997f > bb;
 }
 
-// serve the lanes in `need`: continue their hint scan after the first batch, then try the twin entry
-MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float& best, int64_t& bi, bool need, bool& done) {
+// serve the lanes in `need`: continue their hint scan after the solo records, then try the twin entry.
+// Owners are taken COOP_G at a time so that their first chunks (records NN_SOLO+1 .. NN_SOLO+64, which decide
+// almost all of them) travel in one round trip; r = |q - F_h| comes from the owner lane (no header fetch).
+constexpr int COOP_G = 4;
+MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_lane, float& best, int64_t& bi, bool need,
+                 bool& done) {
     const int lane = threadIdx.x & 63;
     unsigned long long todo = __ballot(need);
     while (todo) {
-        const int owner = (int)__builtin_ctzll(todo);
-        todo &= todo - 1;
-        float qq[6];
+        int owner[COOP_G], hh[COOP_G];
+        Nbr6 e[COOP_G];
 #pragma unroll
-        for (int d = 0; d < 6; ++d) qq[d] = rl_f32(q[d], owner);
-        const int h = rl_i32(hint, owner);
-        float bb = rl_f32(best, owner);
-        int b_i = rl_i32((int)bi, owner);
-        // r = |q - F_h| recomputed from the self record (uniform)
-        const Nbr6 self = tv.nbrs[(size_t)h * NBR_REC];
-        Point6 ps;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) ps.c[a] = self.c[a];
-        const float rr = __builtin_sqrtf(dist2(qq, ps));
-        bool cert = coop_scan_list(tv, qq, h, 1 + NN_SOLO, rr, bb, b_i);
-        if (!cert) {
-            const int tw = tv.twin[h];
-            if (tw >= 0) {  // second chance from the entry across the angle-pi cut (record 0 = the twin itself)
-                const Nbr6 ts = tv.nbrs[(size_t)tw * NBR_REC];
-                Point6 pt;
-#pragma unroll
-                for (int a = 0; a < 6; ++a) pt.c[a] = ts.c[a];
-                const float r2 = __builtin_sqrtf(dist2(qq, pt));
-                cert = coop_scan_list(tv, qq, tw, 0, r2, bb, b_i);
+        for (int g = 0; g < COOP_G; ++g) {
+            owner[g] = todo ? (int)__builtin_ctzll(todo) : -1;
+            todo &= todo - 1;  // 0 & anything stays 0
+            if (owner[g] >= 0) {
+                hh[g] = rl_i32(hint, owner[g]);
+                e[g] = tv.nbrs[(size_t)hh[g] * NBR_REC + (1 + NN_SOLO) + lane];
             }
         }
-        if (lane == owner) { best = bb; bi = b_i; done = cert; }
+#pragma unroll
+        for (int g = 0; g < COOP_G; ++g) {
+            if (owner[g] < 0) continue;
+            float qq[6];
+#pragma unroll
+            for (int d = 0; d < 6; ++d) qq[d] = rl_f32(q[d], owner[g]);
+            const float rr = rl_f32(r_lane, owner[g]);
+            float bb = rl_f32(best, owner[g]);
+            int b_i = rl_i32((int)bi, owner[g]);
+            Point6 p;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) p.c[a] = e[g].c[a];
+            float d = dist2(qq, p);
+            if (!(d == d)) d = INFINITY;
+            int id = e[g].idx;
+            wave_best(d, id);
+            if (d < bb || (d == bb && id < b_i)) { bb = d; b_i = id; }
+            const float gg = fmaf_(rl_f32(e[g].rho, 63) - rr, 0.9999996f, -8e-7f * rr);
+            bool cert = gg > 0.0f && gg * gg * 0.99997f > bb;
+            if (!cert) {
+                cert = coop_scan_list(tv, qq, hh[g], 1 + NN_SOLO + 64, rr, bb, b_i);
+                if (!cert) {
+                    const int tw = tv.twin[hh[g]];
+                    if (tw >= 0) {  // second chance from the entry across the angle-pi cut (record 0 = the twin itself)
+                        const Nbr6 ts = tv.nbrs[(size_t)tw * NBR_REC];
+                        Point6 pt;
+#pragma unroll
+                        for (int a = 0; a < 6; ++a) pt.c[a] = ts.c[a];
+                        const float r2 = __builtin_sqrtf(dist2(qq, pt));
+                        cert = coop_scan_list(tv, qq, tw, 0, r2, bb, b_i);
+                    }
+                }
+            }
+            if (lane == owner[g]) { best = bb; bi = b_i; done = cert; }
+        }
     }
 }
 
-// prune: continue the vertex-list scan of the lanes in `need` (mv < 0 after their first batch)
-MD void mesh_coop(const MeshRec* __restrict__ vlist, int32_t h, const double* tq, double t2, double thr, bool need, int& mv) {
+// prune: continue the vertex-list scan of the lanes in `need` (mv < 0 after their solo records); owners in
+// groups of COOP_G as above, `lim` (the "cannot be within thr" radius) comes from the owner lane
+MD double rl_f64(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)rl_i32((int)(unsigned)b, lane), hi = (unsigned)rl_i32((int)(unsigned)(b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+MD void mesh_coop(const MeshRec* __restrict__ vlist, int32_t h, const double* tq, double t2, double lim_lane, bool need, int& mv) {
     const int lane = threadIdx.x & 63;
     unsigned long long todo = __ballot(need);
     while (todo) {
-        const int owner = (int)__builtin_ctzll(todo);
-        todo &= todo - 1;
-        double q3[3];
+        int owner[COOP_G], hh[COOP_G];
+        MeshRec e[COOP_G];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const long long b = __double_as_longlong(tq[d]);
-            const unsigned lo = (unsigned)rl_i32((int)(unsigned)b, owner), hi = (unsigned)rl_i32((int)(unsigned)(b >> 32), owner);
-            q3[d] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-        }
-        const int hh = rl_i32(h, owner);
-        const MeshRec* vl = vlist + (size_t)hh * MESH_REC;
-        const MeshRec hd = vl[0];
-        Point3 ph;
-        ph.c[0] = hd.c[0]; ph.c[1] = hd.c[1]; ph.c[2] = hd.c[2];
-        const double delta = __builtin_sqrt(dist2(q3, ph)) * (1.0 + 1e-12);
-        const double lim = thr * (1.0 + 1e-9) + delta + 1e-12;
-        int res = -1;
-        for (int c0 = 1 + MESH_SOLO; c0 <= MESH_M && res < 0; c0 += 64) {
-            const int s = c0 + lane;
-            bool hit = false;
-            float rho = INFINITY;
-            if (s <= MESH_M) {
-                const MeshRec e = vl[s];
-                Point3 p;
-                p.c[0] = e.c[0]; p.c[1] = e.c[1]; p.c[2] = e.c[2];
-                rho = e.rho;
-                // a record counts only if no EARLIER record already proves "invalid" - identical to the serial scan
-                hit = dist2(q3, p) <= t2;
+        for (int g = 0; g < COOP_G; ++g) {
+            owner[g] = todo ? (int)__builtin_ctzll(todo) : -1;
+            todo &= todo - 1;
+            if (owner[g] >= 0) {
+                hh[g] = rl_i32(h, owner[g]);
+                e[g] = vlist[(size_t)hh[g] * MESH_REC + (1 + MESH_SOLO) + lane];
             }
-            const unsigned long long hits = __ballot(hit);
-            const unsigned long long stops = __ballot((double)rho * (1.0 - 1e-7) > lim);
-            // serial semantics: walk the records in order; the first event decides
-            const int fh = hits ? (int)__builtin_ctzll(hits) : 64, fs = stops ? (int)__builtin_ctzll(stops) : 64;
-            if (fh < 64 && fh < fs) res = 1;
-            else if (fs < 64) res = 0;
         }
-        if (res < 0) res = ((double)hd.rho * (1.0 - 1e-7) > lim) ? 0 : -1;
-        if (lane == owner) mv = res;
+#pragma unroll
+        for (int g = 0; g < COOP_G; ++g) {
+            if (owner[g] < 0) continue;
+            double q3[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) q3[d] = rl_f64(tq[d], owner[g]);
+            const double lim = rl_f64(lim_lane, owner[g]);
+            const MeshRec* vl = vlist + (size_t)hh[g] * MESH_REC;
+            int res = -1;
+            for (int c0 = 1 + MESH_SOLO; c0 <= MESH_M && res < 0; c0 += 64) {
+                const int s = c0 + lane;
+                bool hit = false;
+                float rho = INFINITY;
+                if (s <= MESH_M) {
+                    const MeshRec r = (c0 == 1 + MESH_SOLO) ? e[g] : vl[s];
+                    Point3 p;
+                    p.c[0] = r.c[0]; p.c[1] = r.c[1]; p.c[2] = r.c[2];
+                    rho = r.rho;
+                    hit = dist2(q3, p) <= t2;
+                }
+                const unsigned long long hits = __ballot(hit);
+                const unsigned long long stops = __ballot((double)rho * (1.0 - 1e-7) > lim);
+                // serial semantics: walk the records in order; the first event decides
+                const int fh = hits ? (int)__builtin_ctzll(hits) : 64, fs = stops ? (int)__builtin_ctzll(stops) : 64;
+                if (fh < 64 && fh < fs) res = 1;
+                else if (fs < 64) res = 0;
+            }
+            if (res < 0) res = ((double)vl[0].rho * (1.0 - 1e-7) > lim) ? 0 : -1;
+            if (lane == owner[g]) mv = res;
+        }
     }
 }
 
@@ -750,23 +799,31 @@ MD void mesh_coop(const MeshRec* __restrict__ vlist, int32_t h, const double* tq
 // yet scanned is provably farther than thr, triangle inequality with slack far above float64 rounding) or
 // -1 (list exhausted: the caller runs the tree search).
 MD int mesh_list_check(const MeshRec* __restrict__ vlist, int32_t h, const double* tq, double t2, double thr,
-                       int max_records = MESH_M) {
+                       int max_records = MESH_M, double* lim_out = nullptr) {
     const MeshRec* vl = vlist + (size_t)h * MESH_REC;
     const MeshRec hd = vl[0];
     Point3 ph;
     ph.c[0] = hd.c[0]; ph.c[1] = hd.c[1]; ph.c[2] = hd.c[2];
     const double delta = __builtin_sqrt(dist2(tq, ph)) * (1.0 + 1e-12);
     const double lim = thr * (1.0 + 1e-9) + delta + 1e-12;  // a vertex with rho*(1-1e-7) > lim cannot be within thr of tq
-    for (int s0 = 1; s0 <= max_records; s0 += SCAN_BATCH) {
-        MeshRec e[SCAN_BATCH];
+    if (lim_out) *lim_out = lim;
+    // a batch is evaluated branch-free (all its loads in one round trip), then resolved in record order:
+    // per record "provably too far" is tested before "hit", so the first event decides
+    for (int s0 = 1; s0 <= max_records; s0 += MESH_BATCH) {
+        MeshRec e[MESH_BATCH];
 #pragma unroll
-        for (int j = 0; j < SCAN_BATCH; ++j) e[j] = vl[s0 + j];
+        for (int j = 0; j < MESH_BATCH; ++j) e[j] = vl[s0 + j];
+        unsigned hits = 0, stops = 0;
 #pragma unroll
-        for (int j = 0; j < SCAN_BATCH; ++j) {
-            if ((double)e[j].rho * (1.0 - 1e-7) > lim) return 0;
+        for (int j = 0; j < MESH_BATCH; ++j) {
             Point3 p;
             p.c[0] = e[j].c[0]; p.c[1] = e[j].c[1]; p.c[2] = e[j].c[2];
-            if (dist2(tq, p) <= t2) return 1;
+            stops |= ((double)e[j].rho * (1.0 - 1e-7) > lim ? 1u : 0u) << j;
+            hits |= (dist2(tq, p) <= t2 ? 1u : 0u) << j;
+        }
+        if (hits | stops) {
+            const int fh = hits ? __builtin_ctz(hits) : 32, fs = stops ? __builtin_ctz(stops) : 32;
+            return fh < fs ? 1 : 0;
         }
     }
     if (max_records < MESH_M) return -1;
@@ -777,13 +834,15 @@ MD int mesh_list_check(const MeshRec* __restrict__ vlist, int32_t h, const doubl
 // Must be called by every lane of the wave (`live` = this lane holds a query).
 template <bool STATS = false>
 MD bool nn6_wave(const TreeView<Kd6>& tv, const float* q, bool live, int32_t hint, int32_t& idx, float& d2, float* cd,
-                 int* n_leaves = nullptr, int* n_nodes = nullptr, int* n_scanned = nullptr) {
+                 int* n_leaves = nullptr, int* n_nodes = nullptr, int* n_scanned = nullptr, long long* t_solo = nullptr) {
     float best = INFINITY;
     int64_t bi = 0;
     bool done = !live;
     const bool hinted = live && hint >= 0 && (int64_t)hint < tv.K;
-    if (hinted) done = nn6_hint_scan(tv, q, hint, best, bi, n_scanned, NN_SOLO);  // first records, per lane
-    nn6_coop(tv, q, hint, best, bi, hinted && !done, done);                         // the rest, whole wave per lane
+    float r_lane = 0.f;
+    if (hinted) done = nn6_hint_scan(tv, q, hint, best, bi, n_scanned, NN_SOLO, &r_lane);  // first records, per lane
+    if (t_solo) *t_solo = clock64();
+    nn6_coop(tv, q, hint, r_lane, best, bi, hinted && !done, done);                         // the rest, whole wave per lane
     wave_search<Kd6, false, STATS>(tv, q, best, bi, !done, cd, n_leaves, n_nodes);
     idx = (int32_t)bi;
     d2 = best;
@@ -1000,25 +1059,32 @@ __global__ __launch_bounds__(256) void k_rmse_final(int64_t N, int nb, const dou
 // =================================================================================================
 // fused particle update of the step
 // =================================================================================================
-__global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a) {
-    __shared__ double s_cd[KD_MAX_LEVELS * 64];  // child-distance columns, reused by both searches
-    if (blockIdx.y) {  // batch of trajectories: every per-trajectory array is (B, ...) contiguous
-        const int64_t b = blockIdx.y, o = b * a.N;
+// One wave = 64 consecutive particles of trajectory `traj`; `wave` counts the waves of that trajectory,
+// `nwaves` = waves per trajectory (strides of the per-wave partial arrays), s_cd = this wave's LDS columns.
+MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, ParticleUpdateArgs a, int64_t wave,
+                             int nwaves, int traj, double* s_cd) {
+    const int lane = threadIdx.x & 63;
+    if (traj) {  // batch of trajectories: every per-trajectory array is (B, ...) contiguous
+        const int64_t b = traj, o = b * a.N;
         a.poses_in += o * 16; a.poses_prop += o * 16; a.odom16 += b * 16;
         if (a.tn) { a.tn += o * 3; a.rot += o * 3; }
         if (a.hint_in) a.hint_in += o;
-        a.nn_idx += o; a.scores += b * a.score_stride; a.x += o; a.e += o; a.valid += o;
-        a.part_max += b * gridDim.x; a.part_min += b * gridDim.x;
-        if (a.gt16) { a.gt16 += b * 16; a.part_rmse += 2 * b * gridDim.x; }
+        a.nn_idx += o; a.valid += o;
+        if (a.scores) { a.scores += b * a.score_stride; a.x += o; a.e += o; a.part_max += b * nwaves; a.part_min += b * nwaves; }
+        if (a.gt16) { a.gt16 += b * 16; a.part_rmse += 2 * b * nwaves; }
         if (a.status_reset) a.status_reset += 2 * b;
         a.slot_base += o;
     }
-    const int64_t n = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t n = wave * 64 + lane;
     const bool live = n < a.N;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (wave == 0 && lane == 0) {
         if (a.status_reset) { a.status_reset[0] = 0; a.status_reset[1] = 0; }
         if (a.flags_reset) { a.flags_reset[0] = 0.0; a.flags_reset[1] = 0.0; }
     }
+    unsigned long long st_nn = 0, st_mesh = 0, st_scan = 0;
+    long long tc[10];  // phase clocks, reported with MIDAS_ABLATE=4
+    tc[0] = clock64();
+    const long long wall0 = wall_clock64();  // 100 MHz
     double x = 0.0, et2 = 0.0, ang2 = 0.0;
     float R[16], f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1032,6 +1098,7 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
         store_pose(a.poses_prop + n * 16, R);
         se3_feature(R, 0.99f, 0.01f, f);
     }
+    tc[1] = clock64();
     // nearest codebook entry
     int32_t bi = 0;
     float bd;
@@ -1039,10 +1106,16 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
     if (a.ablate & 1) {  // profiling only: trust the hint
         bi = hint < 0 ? 0 : hint;
     } else {
-        const bool fb = nn6_wave(t6, f, live, hint, bi, bd, reinterpret_cast<float*>(s_cd));
+        int nscan = 0;
+        const bool fb = nn6_wave(t6, f, live, hint, bi, bd, reinterpret_cast<float*>(s_cd), nullptr, nullptr, &nscan, &tc[2]);
+        tc[3] = clock64();
+        if (a.telemetry && (a.ablate & 4)) {  // MIDAS_ABLATE=4: scan statistics (profiling only), flushed at the end
+            st_nn = __ballot(live && nscan >= NN_SOLO);
+            st_scan = (unsigned long long)wave_sum((double)nscan);
+        }
         if (a.telemetry) {
             const unsigned long long m = __ballot(fb);
-            if (threadIdx.x == 0 && m) atomicAdd(&a.telemetry[0], (unsigned long long)__popcll(m));
+            if (lane == 0 && m) atomicAdd(&a.telemetry[0], (unsigned long long)__popcll(m));
         }
     }
     // prune: valid <=> some mesh vertex within sqrt(t2) of the particle
@@ -1052,20 +1125,27 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
     int mv = -1;  // 1 valid, 0 invalid, -1 undecided
     if (a.ablate & 2) mv = 1;
     else if (a.vlist) {
-        if (live) mv = mesh_list_check(a.vlist, bi, q3, a.t2, a.thr, MESH_SOLO);  // first records, per lane
-        mesh_coop(a.vlist, bi, q3, a.t2, a.thr, live && mv < 0, mv);              // the rest, whole wave per lane
+        double lim_lane = 0.0;
+        if (live) mv = mesh_list_check(a.vlist, bi, q3, a.t2, a.thr, MESH_SOLO, &lim_lane);  // first records, per lane
+        tc[4] = clock64();
+        if (a.telemetry && (a.ablate & 4)) st_mesh = __ballot(live && mv < 0);
+        mesh_coop(a.vlist, bi, q3, a.t2, lim_lane, live && mv < 0, mv);             // the rest, whole wave per lane
     }
+    tc[5] = clock64();
     bool ok = wave_search<Kd3, true>(t3, q3, best, vi, live && mv < 0, s_cd);
     if (a.telemetry) {
         const unsigned long long m = __ballot(live && mv < 0);
-        if (threadIdx.x == 0 && m) atomicAdd(&a.telemetry[1], (unsigned long long)__popcll(m));
+        if (lane == 0 && m) atomicAdd(&a.telemetry[1], (unsigned long long)__popcll(m));
     }
     if (mv >= 0) ok = mv == 1;
+    tc[6] = clock64();
     if (live) {
         a.nn_idx[n] = bi;
-        x = a.scores[bi];
-        a.x[n] = x;
-        a.e[n] = exp(x - 1.0);
+        if (a.scores) {  // nullptr: the scoring runs concurrently, the tail gathers the scores
+            x = a.scores[bi];
+            a.x[n] = x;
+            a.e[n] = exp(x - 1.0);
+        }
         a.valid[n] = ok ? 1 : 0;
         if (a.gt16) {
             float G[16];
@@ -1074,14 +1154,54 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
             rmse_terms(R, G, et2, ang2);
         }
     }
+    tc[7] = clock64();
     // per-wave extrema of x over live lanes
     const double NEG = -INFINITY, POS = INFINITY;
-    double mx = wave_max(live ? x : NEG), mn = wave_min(live ? x : POS);
-    if (threadIdx.x == 0) { a.part_max[blockIdx.x] = mx; a.part_min[blockIdx.x] = mn; }
+    if (a.scores) {
+        double mx = wave_max(live ? x : NEG), mn = wave_min(live ? x : POS);
+        if (lane == 0) { a.part_max[wave] = mx; a.part_min[wave] = mn; }
+    }
     if (a.gt16) {
         et2 = wave_sum(et2);
         ang2 = wave_sum(ang2);
-        if (threadIdx.x == 0) { a.part_rmse[2 * blockIdx.x] = et2; a.part_rmse[2 * blockIdx.x + 1] = ang2; }
+        if (lane == 0) { a.part_rmse[2 * wave] = et2; a.part_rmse[2 * wave + 1] = ang2; }
+    }
+    if (a.telemetry && (a.ablate & 4) && lane == 0) {
+        // MIDAS_ABLATE=4: per-wave scan statistics and phase clocks, plain stores into the wave's own 16 slots
+        // behind the 16 cumulative counters (the caller sized the buffer 16 + 16 * waves)
+        tc[8] = clock64();
+        unsigned long long* w = a.telemetry + 16 + 16 * ((size_t)traj * nwaves + wave);
+        w[2] += (unsigned long long)__popcll(st_nn); w[4] += st_nn ? 1 : 0;
+        w[3] += (unsigned long long)__popcll(st_mesh); w[5] += st_mesh ? 1 : 0;
+        w[6] += st_scan;
+        w[7] += (unsigned long long)(wall_clock64() - wall0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[8 + i] += (unsigned long long)(tc[i + 1] - tc[i]);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a) {
+    __shared__ double s_cd[KD_MAX_LEVELS * 64];  // child-distance columns, reused by both searches
+    particle_update_wave(t6, t3, a, blockIdx.x, gridDim.x, blockIdx.y, s_cd);
+}
+
+// Front kernel of the fused single-trajectory step: the particle update (latency-bound: dependent scattered
+// fetches, ~1.5 waves per SIMD) and the codebook scoring (HBM-bound stream) have no dependency on each other -
+// the scores are only gathered in the tail - so they share ONE launch: workgroups [0, n_pu) run four
+// particle waves each and start first, workgroups [n_pu, ...) stream sixteen codebook rows each behind them
+// and fill the memory pipes the particle waves leave idle.
+template <typename T, int NJ>
+__global__ __launch_bounds__(256) void k_frame_front(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a,
+                                                     int n_pu, int nwaves, const T* __restrict__ emb,
+                                                     const double* __restrict__ norms, const double* __restrict__ code,
+                                                     double* __restrict__ scores, int64_t K) {
+    __shared__ double s_cd[4][KD_MAX_LEVELS * 64];
+    const int w = threadIdx.x >> 6;
+    if ((int)blockIdx.x < n_pu) {
+        const int64_t wave = (int64_t)blockIdx.x * 4 + w;
+        if (wave < nwaves) particle_update_wave(t6, t3, a, wave, nwaves, 0, s_cd[w]);
+    } else {
+        score_wave<T, NJ, 0>(emb, norms, code, scores, K, (int64_t)(blockIdx.x - n_pu) * 4 + w);
     }
 }
 
@@ -1162,6 +1282,35 @@ int launch_particle_update(midas_ctx* ctx, const midas_tree* t6, const midas_tre
     hipLaunchKernelGGL(k_particle_update, dim3((unsigned)particle_update_blocks(a.N), (unsigned)(a.batch > 1 ? a.batch : 1)), dim3(64), 0, ctx->stream,
                        view_of<Kd6>(t6), view_of<Kd3>(t3), a);
     MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    return MIDAS_OK;
+}
+
+// fused front: returns MIDAS_ERR_UNSUPPORTED-like 1 when the codebook layout has no fused instantiation
+int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t3, const ParticleUpdateArgs& a_in,
+                       const midas_codebook* cb, const double* code, double* scores, bool* launched) {
+    *launched = false;
+    if (a_in.N == 0 || a_in.batch > 1 || cb->dtype != MIDAS_F32) return MIDAS_OK;
+    if ((uintptr_t)cb->emb % 16 != 0 || (uintptr_t)code % 16 != 0) return MIDAS_OK;
+    if (cb->D != 512 && cb->D != 256 && cb->D != 128 && cb->D != 1024) return MIDAS_OK;
+    ParticleUpdateArgs a = a_in;
+    static const int ablate = getenv("MIDAS_ABLATE") ? atoi(getenv("MIDAS_ABLATE")) : 0;
+    a.ablate = ablate;
+    a.scores = nullptr;  // deferred: the tail gathers the scores
+    const int nwaves = particle_update_blocks(a.N), n_pu = (nwaves + 3) / 4;
+    const unsigned grid = (unsigned)(n_pu + ceil_div(cb->K, 16));
+    const float* emb = (const float*)cb->emb;
+#define MIDAS_FRONT(NJ)                                                                                              \
+    hipLaunchKernelGGL((k_frame_front<float, NJ>), dim3(grid), dim3(256), 0, ctx->stream, view_of<Kd6>(t6),         \
+                       view_of<Kd3>(t3), a, n_pu, nwaves, emb, cb->norms, code, scores, cb->K)
+    switch (cb->D) {
+        case 512: MIDAS_FRONT(8); break;
+        case 256: MIDAS_FRONT(4); break;
+        case 128: MIDAS_FRONT(2); break;
+        default: MIDAS_FRONT(16); break;
+    }
+#undef MIDAS_FRONT
+    MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    *launched = true;
     return MIDAS_OK;
 }
 

@@ -334,14 +334,23 @@ __global__ __launch_bounds__(256) void k_tail_a(int64_t N, const double* __restr
     double v[SCAN_CHUNK], vm[SCAN_CHUNK], l[SCAN_CHUNK];
     bool nan = false;
     int kept = 0;
+    // unconditional loads on clamped slots (conditional ones are issued one round trip at a time)
+    const double* __restrict__ src = apply ? e_io : x;
+    uint8_t okv[SCAN_CHUNK];
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) {
+        const int64_t i = base + j, ic = i < N ? i : N - 1;
+        v[j] = src[ic];
+        okv[j] = valid[ic];
+    }
 #pragma unroll
     for (int j = 0; j < SCAN_CHUNK; ++j) {
         const int64_t i = base + j;
         double e = 0.0, em = 0.0;
         if (i < N) {
-            if (apply) e = e_io[i];
-            else { e = x[i]; e_io[i] = e; }
-            const bool ok = valid[i] != 0;
+            e = v[j];
+            if (!apply) e_io[i] = e;
+            const bool ok = okv[j] != 0;
             em = e * (ok ? 1.0 : 0.0);
             kept += ok ? 1 : 0;
             nan |= em != em;
@@ -367,6 +376,135 @@ __global__ __launch_bounds__(256) void k_tail_a(int64_t N, const double* __restr
         atomicAdd(&status[1], kept);
         if (flags_out) atomicAdd(&flags_out[1], (double)kept);  // exact: integers far below 2^53
     }
+}
+
+// TA2 (fused single-GPU step, deferred mode): the particle update ran concurrently with the codebook scoring,
+// so this kernel gathers x = scores[nn_idx] itself, takes e = exp(x - 1) and produces what TA produces - with
+// the isclose guard (a GLOBAL property of x) deferred to TB:  the guard can only fire when every block's own
+// range is within the tolerance, so a block whose range is wider writes the softmax variant only; a block
+// whose range is within it (rare: all its particles share one score) writes the raw variant as well, and TB
+// picks one after reducing the per-block extrema.  Global traffic is coalesced (slot = k * 256 + thread); the
+// chunk-per-thread view the summation spec needs goes through LDS (one pad double per 16-slot chunk).
+MD int pad16(int i) { return i + (i >> 4); }
+
+MD void scan_variant(const double* val, const uint8_t* okm, int64_t base, int64_t N, double* s_a, double* s_m,
+                     double* s_gtot, double* __restrict__ lp_out, double& W_all, double& W_masked, bool& nan) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < SCAN_CHUNK; ++k) {
+        const int s = k * 256 + t;
+        const bool in = base + s < N;
+        const double v = in ? val[k] : 0.0;
+        const double m = in ? v * (okm[k] ? 1.0 : 0.0) : 0.0;
+        nan |= m != m;
+        s_a[pad16(s)] = v;
+        s_m[pad16(s)] = m;
+    }
+    __syncthreads();
+    double v[SCAN_CHUNK], vm[SCAN_CHUNK], l[SCAN_CHUNK];
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) { v[j] = s_a[t * 17 + j]; vm[j] = s_m[t * 17 + j]; }
+    W_all = block_scan(v, l, s_gtot);
+    __syncthreads();
+    W_masked = block_scan(vm, l, s_gtot);
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) s_m[t * 17 + j] = l[j];  // own chunk only
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SCAN_CHUNK; ++k) {
+        const int s = k * 256 + t;
+        if (base + s < N) lp_out[base + s] = s_m[pad16(s)];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_tail_a2(int64_t N, const double* __restrict__ scores,
+                                                 const int32_t* __restrict__ nn_idx, const uint8_t* __restrict__ valid,
+                                                 int32_t softmax, double* __restrict__ e_out, double* __restrict__ x_out,
+                                                 double* __restrict__ lp_soft, double* __restrict__ lp_raw,
+                                                 double* __restrict__ bsum_e, double* __restrict__ btot_soft,
+                                                 double* __restrict__ btot_raw, double* __restrict__ bmax,
+                                                 double* __restrict__ bmin, int32_t* __restrict__ status) {
+    __shared__ double s_a[SCAN_BLOCK + SCAN_BLOCK / 16];
+    __shared__ double s_m[SCAN_BLOCK + SCAN_BLOCK / 16];
+    __shared__ double s_gtot[16];
+    __shared__ double s_red[24];
+    const int t = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK;
+    // loads are unconditional on clamped slots (a conditional load per slot makes the compiler wait for each
+    // one before issuing the next); out-of-range slots are neutralised afterwards
+    int32_t nn[SCAN_CHUNK];
+    uint8_t okm[SCAN_CHUNK];
+    double x[SCAN_CHUNK];
+#pragma unroll
+    for (int k = 0; k < SCAN_CHUNK; ++k) {
+        const int64_t i = base + k * 256 + t, ic = i < N ? i : N - 1;
+        nn[k] = nn_idx[ic];
+        okm[k] = valid[ic];
+    }
+#pragma unroll
+    for (int k = 0; k < SCAN_CHUNK; ++k) x[k] = scores[nn[k]];
+    double mx = -INFINITY, mn = INFINITY;
+    bool xnan = false;
+    int kept = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_CHUNK; ++k) {
+        const bool in = base + k * 256 + t < N;
+        xnan |= in && x[k] != x[k];
+        mx = in && x[k] > mx ? x[k] : mx;
+        mn = in && x[k] < mn ? x[k] : mn;
+        kept += in && okm[k] ? 1 : 0;
+        if (!in) { x[k] = 0.0; okm[k] = 0; }
+    }
+    // block extrema (NaN propagates, as torch.max / torch.min do)
+    mx = wmax(mx);
+    mn = wmin(mn);
+    const bool wxnan = __any(xnan);
+    if ((t & 63) == 0) { s_red[t >> 6] = mx; s_red[8 + (t >> 6)] = mn; s_red[16 + (t >> 6)] = wxnan ? 1.0 : 0.0; }
+    __syncthreads();
+    mx = s_red[0]; mn = s_red[8];
+    double f = s_red[16];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        mx = s_red[w] > mx ? s_red[w] : mx;
+        mn = s_red[8 + w] < mn ? s_red[8 + w] : mn;
+        f += s_red[16 + w];
+    }
+    if (f != 0.0) { mx = NAN; mn = NAN; }
+    if (t == 0) { bmax[blockIdx.x] = mx; bmin[blockIdx.x] = mn; }
+    const bool close = __builtin_fabs(mx - mn) <= ISCLOSE_ATOL;  // false on NaN
+    const bool need_soft = softmax != 0, need_raw = !softmax || close;
+    bool nan = false;
+    double Wa = 0.0, Wm = 0.0;
+    if (need_soft) {
+        double e[SCAN_CHUNK];
+#pragma unroll
+        for (int k = 0; k < SCAN_CHUNK; ++k) {
+            e[k] = exp(x[k] - 1.0);
+            const int64_t i = base + k * 256 + t;
+            if (i < N) e_out[i] = e[k];
+        }
+        scan_variant(e, okm, base, N, s_a, s_m, s_gtot, lp_soft, Wa, Wm, nan);
+        if (t == 0) { bsum_e[blockIdx.x] = Wa; btot_soft[blockIdx.x] = Wm; }
+    }
+    if (need_raw) {
+#pragma unroll
+        for (int k = 0; k < SCAN_CHUNK; ++k) {
+            const int64_t i = base + k * 256 + t;
+            if (i < N) x_out[i] = x[k];
+        }
+        bool nan_raw = false;
+        scan_variant(x, okm, base, N, s_a, s_m, s_gtot, lp_raw, Wa, Wm, nan_raw);
+        if (t == 0) btot_raw[blockIdx.x] = Wm;
+        if (!need_soft) nan = nan_raw;  // with the softmax on, x NaN <=> e NaN: counted once
+    } else if (t == 0) {
+        btot_raw[blockIdx.x] = 0.0;
+    }
+    const bool wnan = __any(nan);
+    if (wnan && (t & 63) == 0) atomicOr(&status[0], 2);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
+    if ((t & 63) == 0 && kept) atomicAdd(&status[1], kept);
 }
 
 constexpr int TB_MAX_BLOCKS = 1024;  // 4 M particles (per GPU in the fused step, in total in the sharded step)
@@ -457,6 +595,13 @@ struct TailBArgs {
     int nrm;
     double* rmse_out;
     int64_t slot_base;     // Philox key offset of slot 0 (b * N for trajectory b of a batch)
+    // deferred mode (bmax != nullptr): the isclose guard is decided here from the per-block extrema of TA2
+    const double* bmax = nullptr;
+    const double* bmin = nullptr;
+    int32_t softmax = 1;
+    const double* x_raw = nullptr;            // raw variant of e
+    const double* lp_raw = nullptr;           // raw variant of lp
+    const double* block_totals_raw = nullptr; // raw variant of block_totals_em
 };
 
 __global__ __launch_bounds__(256) void k_tail_b(TailBArgs a) {
@@ -472,10 +617,36 @@ __global__ __launch_bounds__(256) void k_tail_b(TailBArgs a) {
         if (a.part_rmse) { a.part_rmse += 2 * b * a.nrm; a.rmse_out += 2 * b; }
         a.slot_base += o;
     }
-    const bool apply = a.flag[0] != 0;
+    bool apply;
+    if (a.bmax) {
+        // deferred guard: global extrema of x from the per-block ones (tiny: nb <= 1024 values, every thread
+        // reduces its share, NaN propagates), then pick the variant TA2 prepared
+        __shared__ double s_ex[12];
+        double mx = -INFINITY, mn = INFINITY;
+        bool nan = false;
+        for (int b = threadIdx.x; b < a.nb; b += 256) {
+            const double u = a.bmax[b], v = a.bmin[b];
+            nan |= (u != u) || (v != v);
+            mx = u > mx ? u : mx;
+            mn = v < mn ? v : mn;
+        }
+        mx = wmax(mx);
+        mn = wmin(mn);
+        const bool wn = __any(nan);
+        if ((threadIdx.x & 63) == 0) { s_ex[threadIdx.x >> 6] = mx; s_ex[4 + (threadIdx.x >> 6)] = mn; s_ex[8 + (threadIdx.x >> 6)] = wn ? 1.0 : 0.0; }
+        __syncthreads();
+        mx = s_ex[0]; mn = s_ex[4];
+        double f = s_ex[8];
+        for (int w = 1; w < 4; ++w) { mx = s_ex[w] > mx ? s_ex[w] : mx; mn = s_ex[4 + w] < mn ? s_ex[4 + w] : mn; f += s_ex[8 + w]; }
+        if (f != 0.0) { mx = NAN; mn = NAN; }
+        apply = a.softmax && !(__builtin_fabs(mx - mn) <= ISCLOSE_ATOL);
+        if (!apply) { a.e = a.x_raw; a.lp = a.lp_raw; a.block_totals_em = a.block_totals_raw; }
+    } else {
+        apply = a.flag[0] != 0;
+    }
     // fetch the block partials in parallel (s_bp <- totals of e*valid, s_end <- sums of e), then one thread
     // turns them into the sequential prefixes the spec asks for - no dependent global loads
-    for (int b = threadIdx.x; b < a.nb; b += 256) { s_bp[b] = a.block_totals_em[b]; s_end[b] = a.block_sums_e[b]; }
+    for (int b = threadIdx.x; b < a.nb; b += 256) { s_bp[b] = a.block_totals_em[b]; s_end[b] = apply ? a.block_sums_e[b] : 0.0; }
     __syncthreads();
     if (threadIdx.x == 0) {
         double acc = 0.0;
@@ -780,6 +951,29 @@ int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base) 
     double* pw = psum + (size_t)B * nb;
     double* e = a.e;
     int32_t* flag = (int32_t*)(pw + (size_t)B * nb);
+    if (!a.x) {  // deferred mode (single trajectory)
+        void* sc2;
+        if ((rc = midas_scratch(ctx, (size_t)nb * 3 * sizeof(double), &sc2))) return rc;
+        double* praw = (double*)sc2;
+        double* bmax = praw + nb;
+        double* bmin = bmax + nb;
+        hipLaunchKernelGGL(k_tail_a2, dim3((unsigned)nb), dim3(256), 0, ctx->stream, a.N, a.scores, a.nn_idx, a.valid, a.softmax,
+                           e, a.x_raw, a.cdf, a.lp_raw, psum, pw, praw, bmax, bmin, a.status);
+        LAUNCH_CHECK(ctx);
+        prof_mark(ctx, prof_slot_base + 1);
+        TailBArgs b;
+        b.N = a.N; b.nb = nb; b.e = e; b.valid = a.valid; b.lp = a.cdf; b.block_sums_e = psum; b.block_totals_em = pw;
+        b.flag = nullptr; b.status = a.status; b.weights = a.weights; b.mode = a.mode; b.u = a.u; b.u32 = a.u32;
+        b.seed = a.seed; b.step = a.step; b.ridx = a.ridx; b.poses_prop = a.poses_prop; b.poses_out = a.poses_out;
+        b.weights_out = a.weights_out; b.nn_idx = a.nn_idx; b.hint_out = a.hint_out;
+        b.part_rmse = a.part_rmse; b.nrm = a.part_rmse ? particle_update_blocks(a.N) : 0; b.rmse_out = a.rmse_out;
+        b.slot_base = 0;
+        b.bmax = bmax; b.bmin = bmin; b.softmax = a.softmax; b.x_raw = a.x_raw; b.lp_raw = a.lp_raw; b.block_totals_raw = praw;
+        hipLaunchKernelGGL(k_tail_b, dim3((unsigned)ceil_div(a.N, 256), 1u), dim3(256), 0, ctx->stream, b);
+        LAUNCH_CHECK(ctx);
+        prof_mark(ctx, prof_slot_base + 2);
+        return MIDAS_OK;
+    }
     if ((rc = launch_tail_a(ctx, a.N, a.x, a.valid, a.npart, 1, a.part_max, a.part_min, a.softmax, e, a.cdf, psum, pw, nullptr,
                             flag, a.status, B)))
         return rc;

@@ -134,7 +134,7 @@ class ShardState:
         self.flag = e((1,), torch.int32)
         self.status = e((2,), torch.int32)
         self.rmse = e((2,), torch.float64)
-        self.telemetry = e((2,), torch.int64)
+        self.telemetry = e((16,), torch.int64)
         self.telemetry.zero_()
         self.hint.fill_(-1)
         self.g1.zero_()

@@ -50,7 +50,11 @@ class FilterEngine:
         self.ridx = torch.zeros(N, dtype=torch.int32, device=self.device)
         self.status = torch.zeros(2, dtype=torch.int32, device=self.device)
         self.rmse = torch.zeros(2, dtype=torch.float64, device=self.device)
-        self.telemetry = torch.zeros(2, dtype=torch.int64, device=self.device)  # cumulative tree-search fallbacks
+        # 16 cumulative counters ([0], [1] = tree-search fallbacks); with MIDAS_ABLATE=4 (profiling) the kernel
+        # also keeps 16 statistics slots per wave behind them
+        import os
+        extra = 16 * ((N + 15) // 16) if int(os.environ.get("MIDAS_ABLATE", "0")) & 4 else 0
+        self.telemetry = torch.zeros(16 + extra, dtype=torch.int64, device=self.device)
         self.step_count = 0
         self.use_hint = True
 
@@ -148,7 +152,7 @@ class BatchFilterEngine:
         self.ridx = torch.zeros((B, N), dtype=torch.int32, device=d)
         self.status = torch.zeros((B, 2), dtype=torch.int32, device=d)
         self.rmse = torch.zeros((B, 2), dtype=torch.float64, device=d)
-        self.telemetry = torch.zeros(2, dtype=torch.int64, device=d)
+        self.telemetry = torch.zeros(16, dtype=torch.int64, device=d)
         self.step_count = 0
 
     def set_particles(self, poses):

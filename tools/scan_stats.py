@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Scan statistics of the particle update on the bench workload (run with MIDAS_ABLATE=4)."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from midastouch_amd.engine import FilterEngine
+from midastouch_amd.synthetic import make_codebook, make_trajectory
+
+dev = torch.device("cuda", 0)
+N, K, D = 100_000, 50_000, 512
+cb = make_codebook("004_sugar_box", K=K, D=D, seed=1001)
+T = 232
+traj = make_trajectory(cb, T=T, seed=2001)
+eng = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4000, device=dev)
+rng = np.random.default_rng(100)
+d0 = np.linalg.norm(cb.poses[:, :3, 3] - traj.gt_poses[0][:3, 3], axis=1)
+near = np.argsort(d0)[: max(64, K // 20)]
+eng.set_particles(torch.as_tensor(cb.poses[rng.choice(near, N)]))
+eng.project_to_codebook()
+odoms, codes, gts = (torch.as_tensor(x).to(dev) for x in (traj.odoms, traj.codes, traj.gt_poses))
+prev = np.zeros(16)
+for t in range(1, T):
+    eng.step(odoms[t], codes[t], gt=gts[t])
+    if t in (1, 2, 5, 10, 20, 50, 100, 150, 200, 230):
+        cur = eng.telemetry[16:].view(-1, 16).sum(0).cpu().numpy().astype(float)
+        uniq = int(torch.unique(eng.hint_next).numel())
+        print(t, "unique NN entries", uniq, "status", eng.status.cpu().tolist(), "d/frame", ((cur - prev)).round(0).tolist())
+        prev = cur
+per_wave = eng.telemetry[16:].view(-1, 16).cpu().numpy().astype(float)
+tot = per_wave.sum(0)
+print("fallbacks:", eng.telemetry[:2].tolist(), " per frame:", (tot / (T - 1)).round(1).tolist())
+tl = tot
+nw = (N + 63) // 64
+print("ticks per wave per frame [propagate+feature, nn solo, nn coop(+tree), mesh solo, mesh coop, tree3, gather+exp+rmse terms, reductions]:",
+      (tl[8:16] / (T - 1) / nw).round(0).tolist())
+print("mean wave lifetime us:", tl[7] / (T - 1) / nw / 100.0)
+print("[nn tree, prune tree, nn coop lanes, prune coop lanes, nn coop waves, prune coop waves, nn records scanned, -]")
