@@ -568,6 +568,10 @@ MIDAS_EXPORT int midas_tail_resample(midas_ctx* ctx, const midas_tail_resample_a
     return launch_tail_resample(ctx, *args);
 }
 
+#ifdef MIDAS_DEBUG_CLOCKS
+MIDAS_EXPORT int midas_debug_tb2_clocks(long long* out16) { return midas::debug_tb2_clocks(out16); }
+#endif
+
 // ---- profiling -----------------------------------------------------------------------------------
 MIDAS_EXPORT int midas_profile_enable(midas_ctx* ctx, int32_t on) {
     if (!ctx) return MIDAS_ERR_INVALID;

@@ -227,6 +227,7 @@ struct StepTailArgs {
     double* lp_raw = nullptr;  // [N] scratch: block-local prefix of x*valid, likewise
 };
 int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base);
+int debug_tb2_clocks(long long* out16);
 int launch_tail_a(midas_ctx* ctx, int64_t N, const double* x, const uint8_t* valid, int np, int pstride,
                   const double* pmax_all, const double* pmin_all, int32_t softmax, double* e_io, double* lp_out,
                   double* block_sums_e, double* block_totals_em, double* flags_out, int32_t* flag, int32_t* status,

@@ -388,7 +388,8 @@ __global__ __launch_bounds__(256) void k_tail_a(int64_t N, const double* __restr
 MD int pad16(int i) { return i + (i >> 4); }
 
 MD void scan_variant(const double* val, const uint8_t* okm, int64_t base, int64_t N, double* s_a, double* s_m,
-                     double* s_gtot, double* __restrict__ lp_out, double& W_all, double& W_masked, bool& nan) {
+                     double* s_gtot, double* __restrict__ lp_out, double* __restrict__ gend_out, double& W_all,
+                     double& W_masked, bool& nan) {
     const int t = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < SCAN_CHUNK; ++k) {
@@ -407,6 +408,7 @@ MD void scan_variant(const double* val, const uint8_t* okm, int64_t base, int64_
     W_all = block_scan(v, l, s_gtot);
     __syncthreads();
     W_masked = block_scan(vm, l, s_gtot);
+    if (base + (int64_t)t * SCAN_CHUNK < N) gend_out[(base >> 4) + t] = l[SCAN_CHUNK - 1];  // block-local prefix at the chunk end
 #pragma unroll
     for (int j = 0; j < SCAN_CHUNK; ++j) s_m[t * 17 + j] = l[j];  // own chunk only
     __syncthreads();
@@ -422,6 +424,7 @@ __global__ __launch_bounds__(256) void k_tail_a2(int64_t N, const double* __rest
                                                  const int32_t* __restrict__ nn_idx, const uint8_t* __restrict__ valid,
                                                  int32_t softmax, double* __restrict__ e_out, double* __restrict__ x_out,
                                                  double* __restrict__ lp_soft, double* __restrict__ lp_raw,
+                                                 double* __restrict__ gend_soft, double* __restrict__ gend_raw,
                                                  double* __restrict__ bsum_e, double* __restrict__ btot_soft,
                                                  double* __restrict__ btot_raw, double* __restrict__ bmax,
                                                  double* __restrict__ bmin, int32_t* __restrict__ status) {
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(256) void k_tail_a2(int64_t N, const double* __rest
             const int64_t i = base + k * 256 + t;
             if (i < N) e_out[i] = e[k];
         }
-        scan_variant(e, okm, base, N, s_a, s_m, s_gtot, lp_soft, Wa, Wm, nan);
+        scan_variant(e, okm, base, N, s_a, s_m, s_gtot, lp_soft, gend_soft, Wa, Wm, nan);
         if (t == 0) { bsum_e[blockIdx.x] = Wa; btot_soft[blockIdx.x] = Wm; }
     }
     if (need_raw) {
@@ -494,7 +497,7 @@ __global__ __launch_bounds__(256) void k_tail_a2(int64_t N, const double* __rest
             if (i < N) x_out[i] = x[k];
         }
         bool nan_raw = false;
-        scan_variant(x, okm, base, N, s_a, s_m, s_gtot, lp_raw, Wa, Wm, nan_raw);
+        scan_variant(x, okm, base, N, s_a, s_m, s_gtot, lp_raw, gend_raw, Wa, Wm, nan_raw);
         if (t == 0) btot_raw[blockIdx.x] = Wm;
         if (!need_soft) nan = nan_raw;  // with the softmax on, x NaN <=> e NaN: counted once
     } else if (t == 0) {
@@ -595,13 +598,6 @@ struct TailBArgs {
     int nrm;
     double* rmse_out;
     int64_t slot_base;     // Philox key offset of slot 0 (b * N for trajectory b of a batch)
-    // deferred mode (bmax != nullptr): the isclose guard is decided here from the per-block extrema of TA2
-    const double* bmax = nullptr;
-    const double* bmin = nullptr;
-    int32_t softmax = 1;
-    const double* x_raw = nullptr;            // raw variant of e
-    const double* lp_raw = nullptr;           // raw variant of lp
-    const double* block_totals_raw = nullptr; // raw variant of block_totals_em
 };
 
 __global__ __launch_bounds__(256) void k_tail_b(TailBArgs a) {
@@ -617,33 +613,7 @@ __global__ __launch_bounds__(256) void k_tail_b(TailBArgs a) {
         if (a.part_rmse) { a.part_rmse += 2 * b * a.nrm; a.rmse_out += 2 * b; }
         a.slot_base += o;
     }
-    bool apply;
-    if (a.bmax) {
-        // deferred guard: global extrema of x from the per-block ones (tiny: nb <= 1024 values, every thread
-        // reduces its share, NaN propagates), then pick the variant TA2 prepared
-        __shared__ double s_ex[12];
-        double mx = -INFINITY, mn = INFINITY;
-        bool nan = false;
-        for (int b = threadIdx.x; b < a.nb; b += 256) {
-            const double u = a.bmax[b], v = a.bmin[b];
-            nan |= (u != u) || (v != v);
-            mx = u > mx ? u : mx;
-            mn = v < mn ? v : mn;
-        }
-        mx = wmax(mx);
-        mn = wmin(mn);
-        const bool wn = __any(nan);
-        if ((threadIdx.x & 63) == 0) { s_ex[threadIdx.x >> 6] = mx; s_ex[4 + (threadIdx.x >> 6)] = mn; s_ex[8 + (threadIdx.x >> 6)] = wn ? 1.0 : 0.0; }
-        __syncthreads();
-        mx = s_ex[0]; mn = s_ex[4];
-        double f = s_ex[8];
-        for (int w = 1; w < 4; ++w) { mx = s_ex[w] > mx ? s_ex[w] : mx; mn = s_ex[4 + w] < mn ? s_ex[4 + w] : mn; f += s_ex[8 + w]; }
-        if (f != 0.0) { mx = NAN; mn = NAN; }
-        apply = a.softmax && !(__builtin_fabs(mx - mn) <= ISCLOSE_ATOL);
-        if (!apply) { a.e = a.x_raw; a.lp = a.lp_raw; a.block_totals_em = a.block_totals_raw; }
-    } else {
-        apply = a.flag[0] != 0;
-    }
+    const bool apply = a.flag[0] != 0;
     // fetch the block partials in parallel (s_bp <- totals of e*valid, s_end <- sums of e), then one thread
     // turns them into the sequential prefixes the spec asks for - no dependent global loads
     for (int b = threadIdx.x; b < a.nb; b += 256) { s_bp[b] = a.block_totals_em[b]; s_end[b] = apply ? a.block_sums_e[b] : 0.0; }
@@ -744,6 +714,278 @@ __global__ __launch_bounds__(256) void k_tail_b(TailBArgs a) {
         if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = p; sb[threadIdx.x >> 6] = q; }
         __syncthreads();
         if (threadIdx.x == 0) {
+            p = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+            q = (sb[0] + sb[1]) + (sb[2] + sb[3]);
+            a.rmse_out[0] = __builtin_sqrt(p / (double)N);
+            a.rmse_out[1] = __builtin_sqrt(q / (double)N);
+        }
+    }
+}
+
+// TB2 (fused single-trajectory step, after TA2): decides the isclose guard from TA2's per-block extrema, then
+// weights + resample + gather like TB, with the search restructured around round trips: the cumulative value
+// at the end of every 16-slot chunk (TA2's chunk-end table + block prefix) sits in LDS, so a draw is located
+// to its chunk without touching memory; four probes inside the chunk and the exact fix-up follow, and the
+// gathers of the winner's pose / weight / hint travel together.  Above TB2_TAB chunks per LDS table the table
+// holds every 2^cshift-th chunk end and the chunk is found with cshift probes of the global table.
+constexpr int TB2_TAB = 8192;
+#ifdef MIDAS_DEBUG_CLOCKS  // phase clocks of one workgroup (tools/variants.sh dbg "-DMIDAS_DEBUG_CLOCKS"; tools/tb2_clocks.py)
+__device__ long long g_tb2_clk[16];
+#define TB2_CLK(k) if (blockIdx.x == 97 && threadIdx.x == 64) g_tb2_clk[k] = clock64();
+#define TB2_WALL(k) if (threadIdx.x == 64) { if (blockIdx.x == 0) g_tb2_clk[8 + k] = wall_clock64(); if (blockIdx.x == 195) g_tb2_clk[10 + k] = wall_clock64(); if (blockIdx.x == 390) g_tb2_clk[12 + k] = wall_clock64(); }
+#else
+#define TB2_CLK(k)
+#define TB2_WALL(k)
+#endif
+
+struct TailB2Args {
+    int64_t N;
+    int nb, ng, nt, cshift;   // blocks, chunks, table entries, chunks per table entry (log2)
+    const double *e, *x_raw, *lp, *lp_raw, *gend, *gend_raw, *bsum_e, *btot, *btot_raw, *bmax, *bmin;
+    const uint8_t* valid;
+    int32_t softmax;
+    int32_t* status;
+    double* weights;
+    int32_t mode;
+    const double* u;
+    float u32;
+    uint64_t seed, step;
+    int32_t* ridx;
+    const float* poses_prop;
+    float* poses_out;
+    double* weights_out;
+    const int32_t* nn_idx;
+    int32_t* hint_out;
+    const double* part_rmse;
+    int nrm;
+    double* rmse_out;
+};
+
+__global__ __launch_bounds__(256) void k_tail_b2(TailB2Args a) {
+    // dynamic LDS sized to this launch (nt + 3 nb doubles) so that small N keeps several workgroups per CU
+    extern __shared__ double s_dyn[];
+    double* s_tab = s_dyn;            // [nt] block-local prefix at the chunk ends (TA2's table, every 2^cshift-th)
+    double* s_bp = s_tab + a.nt;      // [nb] exclusive prefix of the block totals of e*valid
+    double* s_w = s_bp + a.nb;        // [nb] block totals of e*valid
+    double* s_se = s_w + a.nb;        // [nb] block sums of e
+    __shared__ double s_ex[12];
+    __shared__ double s_tot[2];
+    __shared__ int s_apply;
+    const int t = threadIdx.x;
+    const int64_t N = a.N;
+    const int64_t i = (int64_t)blockIdx.x * 256 + t, ic = i < N ? i : N - 1;
+    TB2_CLK(0)
+    TB2_WALL(0)
+    // ---- round trip 1: everything that does not depend on the guard (the softmax variant is the common one).
+    // Loads sit in uniform branches only (a per-lane conditional load would be waited for one at a time).
+    constexpr int TPT = TB2_TAB / 256, BPT = TB_MAX_BLOCKS / 256;
+    const int nk = (a.nt + 255) >> 8, nbk = (a.nb + 255) >> 8;
+    const int ng1 = a.ng - 1, nb1 = a.nb - 1, cs = a.cshift;
+    double gv[TPT], bt[BPT], bs[BPT], bx[BPT], bn[BPT];
+#pragma unroll
+    for (int k = 0; k < TPT; ++k) {
+        gv[k] = 0.0;
+        if (k < nk) {
+            int c = ((k * 256 + t + 1) << cs) - 1;
+            c = c < ng1 ? c : ng1;
+            gv[k] = a.gend[c];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < BPT; ++k) {
+        bt[k] = 0.0; bs[k] = 0.0; bx[k] = 0.0; bn[k] = 0.0;
+        if (k < nbk) {
+            const int b = k * 256 + t, bc = b < nb1 ? b : nb1;
+            bt[k] = a.btot[bc];
+            bs[k] = a.bsum_e[bc];
+            bx[k] = a.bmax[bc];
+            bn[k] = a.bmin[bc];
+        }
+    }
+    double e_i = a.e[ic];
+    const bool ok_i = a.valid[ic] != 0;
+    const double u_i = a.u ? a.u[ic] : 0.0;
+    TB2_CLK(1)
+    // ---- guard: global extrema of x from TA2's per-block ones (NaN propagates)
+    double mx = -INFINITY, mn = INFINITY;
+    bool nan = false;
+#pragma unroll
+    for (int k = 0; k < BPT; ++k) {
+        const int b = k * 256 + t;
+        const bool in = b < a.nb;
+        nan |= in && ((bx[k] != bx[k]) || (bn[k] != bn[k]));
+        mx = in && bx[k] > mx ? bx[k] : mx;
+        mn = in && bn[k] < mn ? bn[k] : mn;
+        if (in) { s_w[b] = bt[k]; s_se[b] = bs[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < TPT; ++k) {
+        const int j = k * 256 + t;
+        if (j < a.nt) s_tab[j] = gv[k];
+    }
+    mx = wmax(mx);
+    mn = wmin(mn);
+    const bool wn = __any(nan);
+    if ((t & 63) == 0) { s_ex[t >> 6] = mx; s_ex[4 + (t >> 6)] = mn; s_ex[8 + (t >> 6)] = wn ? 1.0 : 0.0; }
+    __syncthreads();
+    if (t == 0) {
+        mx = s_ex[0]; mn = s_ex[4];
+        double f = s_ex[8];
+        for (int w = 1; w < 4; ++w) { mx = s_ex[w] > mx ? s_ex[w] : mx; mn = s_ex[4 + w] < mn ? s_ex[4 + w] : mn; f += s_ex[8 + w]; }
+        if (f != 0.0) { mx = NAN; mn = NAN; }
+        const bool apply = a.softmax && !(__builtin_fabs(mx - mn) <= ISCLOSE_ATOL);
+        s_apply = apply ? 1 : 0;
+        if (apply) {  // sequential sums in block order (the spec); reads and writes on different arrays so they pipeline
+            double acc = 0.0, S = 0.0;
+            for (int b = 0; b < a.nb; ++b) { s_bp[b] = acc; acc = acc + s_w[b]; S = S + s_se[b]; }
+            s_tot[0] = acc;
+            s_tot[1] = S;
+        }
+    }
+    __syncthreads();
+    const bool apply = s_apply != 0;
+    const double* __restrict__ lp = a.lp;
+    const double* __restrict__ esrc = a.e;
+    const double* __restrict__ gend = a.gend;
+    if (!apply) {
+        // rare: every particle has the same score (or the softmax is off) - switch to the raw variant TA2 wrote
+        lp = a.lp_raw; esrc = a.x_raw; gend = a.gend_raw;
+        for (int b = t; b < a.nb; b += 256) s_w[b] = a.btot_raw[b];
+        for (int j = t; j < a.nt; j += 256) {
+            int c = ((j + 1) << cs) - 1;
+            c = c < ng1 ? c : ng1;
+            s_tab[j] = gend[c];
+        }
+        e_i = esrc[ic];
+        __syncthreads();
+        if (t == 0) {
+            double acc = 0.0;
+            for (int b = 0; b < a.nb; ++b) { s_bp[b] = acc; acc = acc + s_w[b]; }
+            s_tot[0] = acc;
+            s_tot[1] = 1.0;
+        }
+        __syncthreads();
+    }
+    TB2_CLK(2)
+    const double total = s_tot[0], S = s_tot[1];
+    const bool bad_total = !(total == total) || total == 0.0;
+    const int st0 = a.status[0];
+    const bool usable = st0 == 0 && !bad_total;
+    if (blockIdx.x == 0 && t == 0 && bad_total) a.status[0] = st0 | ((total != total) ? 2 : 1);
+    TB2_CLK(3)
+    if (i < N) {
+        a.weights[i] = (e_i / S) * (ok_i ? 1.0 : 0.0);
+        int64_t src = i;
+        if (usable) {
+            double tq;
+            bool upper;
+            if (a.mode == MIDAS_RESAMPLE_MULTINOMIAL) {
+                tq = a.u ? u_i : philox_uniform53((uint64_t)i, a.seed, a.step);
+                upper = false;
+            } else {
+                const float r = a.u32 >= 0.0f ? a.u32 : philox_uniform24(a.seed, a.step);
+                const float off = r / (float)N;
+                tq = (double)i / (double)N + (double)off;
+                tq = tq >= 1.0 ? tq - 1.0 : tq;
+                upper = true;
+            }
+            const double tt = tq * total;
+            // "still left of the answer": cumulative value < tt (multinomial, lower bound) / <= tt (systematic, upper bound)
+            auto left = [&](double c) { return upper ? (c <= tt) : (c < tt); };
+            auto left_exact = [&](double c) { return upper ? (c <= tq) : (c < tq); };
+            // cumulative e*valid at the end of table entry j
+            auto tab = [&](int j) {
+                int c = ((j + 1) << cs) - 1;
+                c = c < ng1 ? c : ng1;
+                return s_bp[c >> 8] + s_tab[j];
+            };
+            // table entry: first j with !left(tab(j)); 4-ary rounds (three independent LDS probes each), then binary
+            int lo = 0, hi = a.nt;
+            while (hi - lo >= 4) {
+                const int q = (hi - lo) >> 2;
+                const int m1 = lo + q, m2 = m1 + q, m3 = m2 + q;
+                const bool p1 = left(tab(m1)), p2 = left(tab(m2)), p3 = left(tab(m3));
+                if (p3) lo = m3 + 1;
+                else if (p2) { lo = m2 + 1; hi = m3; }
+                else if (p1) { lo = m1 + 1; hi = m2; }
+                else hi = m1;
+            }
+            while (hi > lo) {
+                const int mid = lo + ((hi - lo) >> 1);
+                if (left(tab(mid))) lo = mid + 1; else hi = mid;
+            }
+            TB2_CLK(4)
+            if (lo >= a.nt) lo = a.nt - 1;
+            // chunk inside the entry (only when one entry spans several chunks)
+            int64_t c_lo = (int64_t)lo << cs, c_hi = c_lo + ((int64_t)1 << cs);
+            c_hi = c_hi < a.ng ? c_hi : a.ng;
+            while (c_hi - c_lo > 1) {
+                const int64_t mid = c_lo + ((c_hi - c_lo) >> 1);
+                const double c = s_bp[(mid - 1) >> 8] + gend[mid - 1];
+                if (left(c)) c_lo = mid; else c_hi = mid;
+            }
+            // the chunk's sixteen prefix values in one round trip; slot = number of them still left of the answer
+            const int64_t s0 = c_lo << 4;
+            const double bp = s_bp[c_lo >> 8];
+            double v[SCAN_CHUNK];
+#pragma unroll
+            for (int j = 0; j < SCAN_CHUNK; ++j) {
+                const int64_t sj = s0 + j;
+                v[j] = lp[sj < N ? sj : N - 1];
+            }
+            const double v_prev = lp[s0 > 0 ? s0 - 1 : 0];  // last slot of the previous chunk (its own block prefix)
+            const double bp_prev = s_bp[(s0 > 0 ? s0 - 1 : 0) >> 12];
+            int pos = 0;
+#pragma unroll
+            for (int j = 0; j < SCAN_CHUNK; ++j) pos += (s0 + j < N && left(bp + v[j])) ? 1 : 0;
+            int64_t l2 = s0 + pos;
+            // exact fix-up: the predicate on cdf_i = (BP + lp_i) / total is monotone in i over the whole array; the two
+            // neighbours of the boundary are normally inside the chunk just fetched
+            double vm = 0.0, vp = 0.0;
+#pragma unroll
+            for (int j = 0; j < SCAN_CHUNK; ++j) { vm = (j == pos - 1) ? v[j] : vm; vp = (j == pos) ? v[j] : vp; }
+            bool walk = false;
+            if (pos > 0) walk |= !left_exact((l2 - 1 == N - 1) ? 1.0 : (bp + vm) / total);
+            else if (l2 > 0) walk |= !left_exact((bp_prev + v_prev) / total);
+            if (pos < SCAN_CHUNK && l2 < N) walk |= left_exact((l2 == N - 1) ? 1.0 : (bp + vp) / total);
+            else walk = true;
+            TB2_CLK(5)
+            if (walk) {
+                if (l2 >= N) l2 = N - 1;
+                while (l2 > 0) {
+                    if (left_exact(cdf_at(lp, s_bp, total, l2 - 1, N))) break;
+                    --l2;
+                }
+                while (l2 < N - 1) {
+                    if (!left_exact(cdf_at(lp, s_bp, total, l2, N))) break;
+                    ++l2;
+                }
+            }
+            src = l2;
+        }
+        TB2_CLK(6)
+        a.ridx[i] = (int32_t)src;
+        const float4* ps = reinterpret_cast<const float4*>(a.poses_prop + src * 16);
+        const float4 r0 = ps[0], r1 = ps[1], r2 = ps[2], r3 = ps[3];
+        const double e_s = esrc[src];
+        const uint8_t ok_s = a.valid[src];
+        const int32_t nn_s = a.nn_idx[src];
+        float4* pd = reinterpret_cast<float4*>(a.poses_out + i * 16);
+        pd[0] = r0; pd[1] = r1; pd[2] = r2; pd[3] = r3;
+        a.weights_out[i] = (e_s / S) * (ok_s ? 1.0 : 0.0);
+        a.hint_out[i] = nn_s;
+        TB2_CLK(7)
+        TB2_WALL(1)
+    }
+    if (a.part_rmse && blockIdx.x == 0) {
+        __shared__ double sa[4], sb[4];
+        double p = 0.0, q = 0.0;
+        for (int k = t; k < a.nrm; k += 256) { p += a.part_rmse[2 * k]; q += a.part_rmse[2 * k + 1]; }
+        p = wsum(p);
+        q = wsum(q);
+        if ((t & 63) == 0) { sa[t >> 6] = p; sb[t >> 6] = q; }
+        __syncthreads();
+        if (t == 0) {
             p = (sa[0] + sa[1]) + (sa[2] + sa[3]);
             q = (sb[0] + sb[1]) + (sb[2] + sb[3]);
             a.rmse_out[0] = __builtin_sqrt(p / (double)N);
@@ -940,6 +1182,10 @@ int launch_tail_resample(midas_ctx* ctx, const midas_tail_resample_args& r) {
     return MIDAS_OK;
 }
 
+#ifdef MIDAS_DEBUG_CLOCKS
+int debug_tb2_clocks(long long* out16) { return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_tb2_clk), 16 * sizeof(long long)) == hipSuccess ? 0 : 1; }
+#endif
+
 int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base) {
     const int nb = (int)ceil_div(a.N, SCAN_BLOCK);
     if (nb > TB_MAX_BLOCKS) return midas_set_error(ctx, MIDAS_ERR_INVALID, "N", "more than 4 M particles per GPU: shard them");
@@ -952,24 +1198,31 @@ int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base) 
     double* e = a.e;
     int32_t* flag = (int32_t*)(pw + (size_t)B * nb);
     if (!a.x) {  // deferred mode (single trajectory)
+        const int ng = (int)ceil_div(a.N, SCAN_CHUNK);
+        int cshift = 0;
+        while (ceil_div((int64_t)ng, (int64_t)1 << cshift) > TB2_TAB) ++cshift;
+        const int nt = (int)ceil_div((int64_t)ng, (int64_t)1 << cshift);
         void* sc2;
-        if ((rc = midas_scratch(ctx, (size_t)nb * 3 * sizeof(double), &sc2))) return rc;
+        if ((rc = midas_scratch(ctx, ((size_t)nb * 3 + (size_t)ng * 2) * sizeof(double), &sc2))) return rc;
         double* praw = (double*)sc2;
         double* bmax = praw + nb;
         double* bmin = bmax + nb;
+        double* gend = bmin + nb;
+        double* gend_raw = gend + ng;
         hipLaunchKernelGGL(k_tail_a2, dim3((unsigned)nb), dim3(256), 0, ctx->stream, a.N, a.scores, a.nn_idx, a.valid, a.softmax,
-                           e, a.x_raw, a.cdf, a.lp_raw, psum, pw, praw, bmax, bmin, a.status);
+                           e, a.x_raw, a.cdf, a.lp_raw, gend, gend_raw, psum, pw, praw, bmax, bmin, a.status);
         LAUNCH_CHECK(ctx);
         prof_mark(ctx, prof_slot_base + 1);
-        TailBArgs b;
-        b.N = a.N; b.nb = nb; b.e = e; b.valid = a.valid; b.lp = a.cdf; b.block_sums_e = psum; b.block_totals_em = pw;
-        b.flag = nullptr; b.status = a.status; b.weights = a.weights; b.mode = a.mode; b.u = a.u; b.u32 = a.u32;
-        b.seed = a.seed; b.step = a.step; b.ridx = a.ridx; b.poses_prop = a.poses_prop; b.poses_out = a.poses_out;
-        b.weights_out = a.weights_out; b.nn_idx = a.nn_idx; b.hint_out = a.hint_out;
+        TailB2Args b;
+        b.N = a.N; b.nb = nb; b.ng = ng; b.nt = nt; b.cshift = cshift;
+        b.e = e; b.x_raw = a.x_raw; b.lp = a.cdf; b.lp_raw = a.lp_raw; b.gend = gend; b.gend_raw = gend_raw;
+        b.bsum_e = psum; b.btot = pw; b.btot_raw = praw; b.bmax = bmax; b.bmin = bmin;
+        b.valid = a.valid; b.softmax = a.softmax; b.status = a.status; b.weights = a.weights; b.mode = a.mode;
+        b.u = a.u; b.u32 = a.u32; b.seed = a.seed; b.step = a.step; b.ridx = a.ridx; b.poses_prop = a.poses_prop;
+        b.poses_out = a.poses_out; b.weights_out = a.weights_out; b.nn_idx = a.nn_idx; b.hint_out = a.hint_out;
         b.part_rmse = a.part_rmse; b.nrm = a.part_rmse ? particle_update_blocks(a.N) : 0; b.rmse_out = a.rmse_out;
-        b.slot_base = 0;
-        b.bmax = bmax; b.bmin = bmin; b.softmax = a.softmax; b.x_raw = a.x_raw; b.lp_raw = a.lp_raw; b.block_totals_raw = praw;
-        hipLaunchKernelGGL(k_tail_b, dim3((unsigned)ceil_div(a.N, 256), 1u), dim3(256), 0, ctx->stream, b);
+        hipLaunchKernelGGL(k_tail_b2, dim3((unsigned)ceil_div(a.N, 256)), dim3(256), (size_t)(nt + 3 * nb) * sizeof(double),
+                           ctx->stream, b);
         LAUNCH_CHECK(ctx);
         prof_mark(ctx, prof_slot_base + 2);
         return MIDAS_OK;

@@ -136,6 +136,59 @@ def test_step_all_drifted_and_guards(dev, oracle):
     assert float(eng.weights.abs().sum().item()) == 0.0
 
 
+@pytest.mark.parametrize("mode", ["weighted_random", "low_var"])
+def test_step_parity_many_particles_coarse_table(dev, oracle, mode):
+    """N above 8192 chunks: the resample search goes through the coarse chunk-end table plus probes of the
+    global one (k_tail_b2, cshift > 0); ragged last block; device Philox draws."""
+    from midastouch_amd.engine import FilterEngine
+    N, K, D = 140_003, 1500, 128
+    cb, traj, scale = _setup(N, K, D, seed=4)
+    ofl = oracle.OracleFilter(cb.poses, cb.embeddings, cb.mesh_vertices)
+    eng = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4100, resample=mode, device=dev)
+    rng = np.random.default_rng(9)
+    poses = cb.poses[rng.integers(0, K, N)]
+    eng.set_particles(torch.as_tensor(poses))
+    for t in range(1, 5):
+        tn, rot = oracle.philox_noise(N, 4100, t - 1, np.float32(2e-4), np.float32(0.5))
+        if mode == "weighted_random":
+            u, u32 = oracle.philox_uniform64(N, 4100, t - 1), None
+        else:
+            u, u32 = None, oracle.philox_uniform32(4100, t - 1)
+        ref = ofl.step(poses, traj.odoms[t], traj.codes[t], tn, rot, u=u, mode=mode, u32=u32)
+        eng.step(torch.as_tensor(traj.odoms[t]).to(dev), torch.as_tensor(traj.codes[t]).to(dev))
+        _compare_step(eng, ref, t)
+        poses = ref["poses"]
+
+
+@pytest.mark.parametrize("softmax", [True, False])
+def test_step_isclose_guard_and_raw_weights(dev, oracle, softmax):
+    """Identical codebook rows -> every particle has the same score -> get_similarity's isclose guard skips the
+    softmax (particle_filter.py:460-463) and the raw scores become the weights; softmax=False asks for that."""
+    from midastouch_amd.engine import FilterEngine
+    N, K, D = 9000, 800, 128
+    cb, traj, scale = _setup(N, K, D, seed=5)
+    emb = np.abs(cb.embeddings)  # non-negative scores: raw weights stay a valid distribution
+    if softmax:
+        emb[:] = emb[0]
+    ofl = oracle.OracleFilter(cb.poses, emb, cb.mesh_vertices)
+    eng = FilterEngine(cb.poses, emb, cb.mesh_vertices, N, seed=4200, softmax=softmax, device=dev)
+    rng = np.random.default_rng(10)
+    poses = cb.poses[rng.integers(0, K, N)]
+    eng.set_particles(torch.as_tensor(poses))
+    for t in range(1, 4):
+        code = np.abs(traj.codes[t])
+        tn, rot = oracle.philox_noise(N, 4200, t - 1, np.float32(2e-4), np.float32(0.5))
+        u = oracle.philox_uniform64(N, 4200, t - 1)
+        ref = ofl.step(poses, traj.odoms[t], code, tn, rot, u=u, softmax=softmax)
+        eng.step(torch.as_tensor(traj.odoms[t]).to(dev), torch.as_tensor(code).to(dev))
+        if softmax:
+            assert len(np.unique(ref["weights"][ref["weights"] != 0])) == 1  # raw, identical scores
+            assert ref["weights"].max() < 1.0 / N * 1e3 or ref["weights"].max() > 1e-3  # not softmax-normalised
+        assert ref["status"] == 0
+        _compare_step(eng, ref, t)
+        poses = ref["poses"]
+
+
 def test_step_full_size_properties(dev):
     """BASELINE config 2 sizes (N=100k, K=50k, D=512): size-independent properties."""
     from midastouch_amd.engine import FilterEngine

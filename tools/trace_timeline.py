@@ -4,6 +4,7 @@ import csv, sys, glob
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:40], r.get("Stream_Id", r.get("Queue_Id", "")))
         for r in csv.DictReader(open(f))]
+rows = [r for r in rows if 'midas' in r[2]]
 rows.sort()
 # take frames from the middle
 mid = len(rows) // 2
