@@ -572,37 +572,35 @@ constexpr int MESH_SOLO = MIDAS_MESH_SOLO;
 static_assert(NN_SOLO % NN_BATCH == 0 && NBR_M % NN_BATCH == 0 && MESH_SOLO % MESH_BATCH == 0 && MESH_M % MESH_BATCH == 0,
               "scan batches must tile the solo prefixes and the lists");
 
+// Scans records [0, NN_SOLO) of entry h's list (record 0 = the entry itself); the first batch is fetched
+// together with the entry so that r = |q - F_h| costs no round trip of its own.
 MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t h, float& best, int64_t& bi, int* n_scanned,
-                      int max_records = NBR_M, float* r_out = nullptr) {
+                      float* r_out = nullptr) {
     const Nbr6* nb = tv.nbrs + (size_t)h * NBR_REC;
-    {
-        const Nbr6 self = nb[0];
-        Point6 p;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) p.c[a] = self.c[a];
-        best = dist2(q, p);
-        bi = h;
-    }
-    const float r = __builtin_sqrtf(best);
-    if (r_out) *r_out = r;
-    const float rslack = -8e-7f * r;
+    float r = 0.f, rslack = 0.f;
     int scanned = 0;
     bool certified = false;
-    for (int s0 = 1; s0 <= max_records && !certified; s0 += NN_BATCH) {
+#pragma unroll 1
+    for (int s0 = 0; s0 < NN_SOLO && !certified; s0 += NN_BATCH) {
         Nbr6 e[NN_BATCH];
 #pragma unroll
         for (int j = 0; j < NN_BATCH; ++j) e[j] = nb[s0 + j];
 #pragma unroll
         for (int j = 0; j < NN_BATCH; ++j) {
-            if (!certified) {
+            Point6 p;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) p.c[a] = e[j].c[a];
+            if (s0 == 0 && j == 0) {  // the entry itself: the starting candidate (a NaN distance stays, as in a serial scan)
+                best = dist2(q, p);
+                bi = h;
+                r = __builtin_sqrtf(best);
+                rslack = -8e-7f * r;
+            } else if (!certified) {
                 // lower bound of |q - F| for this and every later record, with slack for the rounding of r and rho
                 const float g = fmaf_(e[j].rho - r, 0.9999996f, rslack);
                 if (g > 0.0f && g * g * 0.99997f > best) {
                     certified = true;
                 } else {
-                    Point6 p;
-#pragma unroll
-                    for (int a = 0; a < 6; ++a) p.c[a] = e[j].c[a];
                     const float d = dist2(q, p);
                     if (d < best || (d == best && (int64_t)e[j].idx < bi)) { best = d; bi = e[j].idx; }
                     ++scanned;
@@ -610,10 +608,7 @@ MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t h, float&
             }
         }
     }
-    if (!certified && max_records >= NBR_M) {
-        const float g = fmaf_(tv.rho_out[h] - r, 0.9999996f, rslack);
-        certified = g > 0.0f && g * g * 0.99997f > best;
-    }
+    if (r_out) *r_out = r;
     if (n_scanned) *n_scanned = scanned;
     return certified;
 }
@@ -680,7 +675,7 @@ MD bool coop_scan_list(const TreeView<Kd6>& tv, const float* qq, int h, int firs
 }
 
 // serve the lanes in `need`: continue their hint scan after the solo records, then try the twin entry.
-// Owners are taken COOP_G at a time so that their first chunks (records NN_SOLO+1 .. NN_SOLO+64, which decide
+// Owners are taken COOP_G at a time so that their first chunks (records NN_SOLO .. NN_SOLO+63, which decide
 // almost all of them) travel in one round trip; r = |q - F_h| comes from the owner lane (no header fetch).
 constexpr int COOP_G = 4;
 MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_lane, float& best, int64_t& bi, bool need,
@@ -696,7 +691,7 @@ MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_
             todo &= todo - 1;  // 0 & anything stays 0
             if (owner[g] >= 0) {
                 hh[g] = rl_i32(hint, owner[g]);
-                e[g] = tv.nbrs[(size_t)hh[g] * NBR_REC + (1 + NN_SOLO) + lane];
+                e[g] = tv.nbrs[(size_t)hh[g] * NBR_REC + NN_SOLO + lane];
             }
         }
 #pragma unroll
@@ -719,7 +714,7 @@ MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_
             const float gg = fmaf_(rl_f32(e[g].rho, 63) - rr, 0.9999996f, -8e-7f * rr);
             bool cert = gg > 0.0f && gg * gg * 0.99997f > bb;
             if (!cert) {
-                cert = coop_scan_list(tv, qq, hh[g], 1 + NN_SOLO + 64, rr, bb, b_i);
+                cert = coop_scan_list(tv, qq, hh[g], NN_SOLO + 64, rr, bb, b_i);
                 if (!cert) {
                     const int tw = tv.twin[hh[g]];
                     if (tw >= 0) {  // second chance from the entry across the angle-pi cut (record 0 = the twin itself)
@@ -840,7 +835,7 @@ MD bool nn6_wave(const TreeView<Kd6>& tv, const float* q, bool live, int32_t hin
     bool done = !live;
     const bool hinted = live && hint >= 0 && (int64_t)hint < tv.K;
     float r_lane = 0.f;
-    if (hinted) done = nn6_hint_scan(tv, q, hint, best, bi, n_scanned, NN_SOLO, &r_lane);  // first records, per lane
+    if (hinted) done = nn6_hint_scan(tv, q, hint, best, bi, n_scanned, &r_lane);  // records 0 .. NN_SOLO-1, per lane
     if (t_solo) *t_solo = clock64();
     nn6_coop(tv, q, hint, r_lane, best, bi, hinted && !done, done);                         // the rest, whole wave per lane
     wave_search<Kd6, false, STATS>(tv, q, best, bi, !done, cd, n_leaves, n_nodes);
@@ -1110,7 +1105,7 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
         const bool fb = nn6_wave(t6, f, live, hint, bi, bd, reinterpret_cast<float*>(s_cd), nullptr, nullptr, &nscan, &tc[2]);
         tc[3] = clock64();
         if (a.telemetry && (a.ablate & 4)) {  // MIDAS_ABLATE=4: scan statistics (profiling only), flushed at the end
-            st_nn = __ballot(live && nscan >= NN_SOLO);
+            st_nn = __ballot(live && nscan >= NN_SOLO - 1);
             st_scan = (unsigned long long)wave_sum((double)nscan);
         }
         if (a.telemetry) {

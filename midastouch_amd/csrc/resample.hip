@@ -1199,8 +1199,12 @@ int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base) 
     int32_t* flag = (int32_t*)(pw + (size_t)B * nb);
     if (!a.x) {  // deferred mode (single trajectory)
         const int ng = (int)ceil_div(a.N, SCAN_CHUNK);
+        // every workgroup of TB2 loads the table: keep it whole (one entry per chunk) while that is cheap, coarser
+        // for large N where (N / 256 workgroups) x table bytes would dominate
+        static const int tab_env = getenv("MIDAS_TB2_TAB") ? atoi(getenv("MIDAS_TB2_TAB")) : 0;
+        const int tab_cap = tab_env > 0 ? (tab_env < TB2_TAB ? tab_env : TB2_TAB) : (ng <= TB2_TAB ? TB2_TAB : (ng <= 4 * TB2_TAB ? 2048 : 1024));  // measured at N = 300k / 1M
         int cshift = 0;
-        while (ceil_div((int64_t)ng, (int64_t)1 << cshift) > TB2_TAB) ++cshift;
+        while (ceil_div((int64_t)ng, (int64_t)1 << cshift) > tab_cap) ++cshift;
         const int nt = (int)ceil_div((int64_t)ng, (int64_t)1 << cshift);
         void* sc2;
         if ((rc = midas_scratch(ctx, ((size_t)nb * 3 + (size_t)ng * 2) * sizeof(double), &sc2))) return rc;
