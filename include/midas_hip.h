@@ -185,49 +185,52 @@ int midas_filter_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree
  * global summation blocks [block_base, ...) (4096 slots per block; slot_base must be a multiple of 4096
  * on every rank but the last for results identical to a single-GPU run).  Arrays named *_all span all
  * shards in rank order and are assembled by the caller (torch.distributed all_gather over RCCL). */
-typedef struct midas_shard_update_args {
+typedef struct midas_shard_front_args {
     int64_t N;                  /* local particles */
     int64_t slot_base;          /* global index of local particle 0 (keys the Philox streams) */
     const float* poses_in_dev;  /* N x 16 */
     float* poses_prop_dev;      /* N x 16 out */
     const int32_t* hint_in_dev; /* N or NULL */
     int32_t* nn_idx_dev;        /* N out */
-    double* x_dev;              /* N out: score of the nearest codebook entry */
-    double* e_dev;              /* N out: exp(x - 1), the softmax numerator with the constant shift 1 */
     uint8_t* valid_dev;         /* N out: prune mask */
-    double* extrema_dev;        /* 2 out: max(x), min(x) over the local particles */
     const float* odom16_dev;
-    const double* code_dev;     /* D: tactile code (ignored when scores_dev is given) */
-    const double* scores_dev;   /* NULL, or K precomputed scores (codebook rows sharded across ranks and gathered) */
+    const double* code_dev;     /* D: tactile code (unused when scores_ready) */
+    double* scores_dev;         /* K: the frame's codebook scores - written here unless scores_ready (codebook rows
+                                 * sharded across ranks: the caller gathered the slices into it) */
+    int32_t scores_ready;
     const float* gt16_dev;      /* NULL or 16 */
-    double* rmse_sums_dev;      /* NULL or 2 out: sum |dt|^2, sum angle^2 over the local particles */
+    double* rmse_sums_dev;      /* NULL or 2 out: sum |dt|^2, sum angle^2 over the local particles (r1 + 5 nb + 2) */
     const float* tn_dev;        /* local host draws or NULL -> Philox */
     const float* rot_dev;
     float std_t, std_r;
     uint64_t seed, step;
     double prune_thr;
     uint64_t* telemetry_dev;    /* NULL or 16 cumulative counters (see midas_step_args) */
-    int32_t* status_dev;        /* 2: zeroed here, filled by midas_tail_a / midas_tail_fin */
-    double* flags_dev;          /* the last two doubles of this rank's g2 record (zeroed here, see midas_tail_a) */
-} midas_shard_update_args;
-/* score codebook + propagate + feature + NN + prune + score gather for the local particles */
-int midas_shard_update(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
-                       const midas_tree* tree3, const midas_shard_update_args* args);
-/* Exchange records (float64), one per rank, gathered by the caller in rank order:
- *   g1 = { max x, min x, sum |dt|^2, sum angle^2 }                       written by midas_shard_update
- *   g2 = { nb block sums of e | nb block totals of e*valid | NaN count | kept count },  nb = ceil(N / 4096)
- * midas_tail_a: e (in/out) = exp(x - 1) from midas_shard_update, replaced by x when the softmax is skipped
- * (softmax == 0 or |max - min| over g1_all <= 1e-8); lp = block-local prefix (fixed order) of e*valid; fills this
- * rank's g2 record; flag[0] = softmax applied; status[0] = 2 on NaN, status[1] = local particles kept. */
-int midas_tail_a(midas_ctx* ctx, int64_t N, const double* x_dev, const uint8_t* valid_dev, int32_t G,
-                 const double* g1_all_dev, int32_t softmax, double* e_dev, double* lp_dev, double* g2_dev,
-                 int32_t* flag_dev, int32_t* status_dev);
-/* midas_tail_fin: weights = e / S * valid; cdf = (BP + lp) / total in place, with S, BP, total summed
- * sequentially in global block order over g2_all; the globally last slot is forced to 1; status = global cdf
- * status + total kept count; rmse_dev (nullable, 2 doubles) from the sums in g1_all over N_total particles. */
-int midas_tail_fin(midas_ctx* ctx, int64_t N, const double* e_dev, const uint8_t* valid_dev, double* weights_dev,
-                   double* cdf_dev, int32_t G, const double* g2_all_dev, int32_t rank, const double* g1_all_dev,
-                   int64_t N_total, double* rmse_dev, const int32_t* flag_dev, int32_t* status_dev);
+    int32_t* status_dev;        /* 2: zeroed here, filled by midas_shard_tail_a / midas_shard_tail_fin */
+    double* flags_dev;          /* the NaN / kept counters of this rank's exchange record (r1 + 5 nb): zeroed here */
+} midas_shard_front_args;
+/* propagate + feature + NN + prune for the local particles and - in the same launch when the codebook is
+ * replicated - the codebook scores (particle_filter.py:359-403, tactile_tree.py:43-58) */
+int midas_shard_front(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
+                      const midas_shard_front_args* args);
+/* Exchange record (float64), ONE per rank and frame, gathered by the caller in rank order (nb = ceil(N / 4096)):
+ *   r1 = { nb block sums of e | nb block totals of e*valid | nb block totals of x*valid | nb block max x | nb block min x |
+ *          NaN count | kept count | sum |dt|^2 | sum angle^2 }
+ * midas_shard_tail_a: x = scores[nn_idx], e = exp(x - 1); lp / lp_raw = block-local prefix (fixed order) of e*valid /
+ * x*valid (the raw variant only where a block's own score range is within the isclose tolerance - the guard of
+ * get_similarity is global and decided in midas_shard_tail_fin); fills r1[0 .. 5 nb + 2); status[0] = 2 on NaN,
+ * status[1] = local particles kept. */
+int midas_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores_dev, const int32_t* nn_idx_dev,
+                       const uint8_t* valid_dev, int32_t softmax, double* e_dev, double* x_raw_dev, double* lp_dev,
+                       double* lp_raw_dev, double* r1_dev, int32_t* status_dev);
+/* midas_shard_tail_fin: softmax applied unless softmax == 0 or |max x - min x| over r1_all <= 1e-8 (then e := x);
+ * weights = e / S * valid; cdf (in place over lp) = (BP + lp) / total with S, BP, total summed sequentially in global
+ * block order over r1_all; the globally last slot is forced to 1; status = global cdf status + total kept count;
+ * rmse_dev (nullable, 2 doubles) from the sums in r1_all over N_total particles. */
+int midas_shard_tail_fin(midas_ctx* ctx, int64_t N, const double* e_dev, const double* x_raw_dev, const double* lp_raw_dev,
+                         const uint8_t* valid_dev, double* weights_dev, double* cdf_dev, int32_t G,
+                         const double* r1_all_dev, int32_t rank, int64_t N_total, int32_t softmax, double* rmse_dev,
+                         int32_t* status_dev);
 /* The cross-rank resample reads any shard's particles from ONE gathered buffer: every rank contributes a
  * record block of rank_stride bytes laid out as
  *     [ cdf: n x f64 | weights: n x f64 | propagated poses: n x 16 f32 | nn_idx: n x i32 ]   (n = n_per_rank,

@@ -58,14 +58,14 @@ class StepArgs(C.Structure):
     ]
 
 
-class ShardUpdateArgs(C.Structure):
-    """midas_shard_update_args (include/midas_hip.h)."""
+class ShardFrontArgs(C.Structure):
+    """midas_shard_front_args (include/midas_hip.h)."""
 
     _fields_ = [
         ("N", C.c_int64), ("slot_base", C.c_int64),
         ("poses_in", C.c_void_p), ("poses_prop", C.c_void_p), ("hint_in", C.c_void_p), ("nn_idx", C.c_void_p),
-        ("x", C.c_void_p), ("e", C.c_void_p), ("valid", C.c_void_p), ("extrema", C.c_void_p), ("odom16", C.c_void_p),
-        ("code", C.c_void_p), ("scores", C.c_void_p), ("gt16", C.c_void_p), ("rmse_sums", C.c_void_p),
+        ("valid", C.c_void_p), ("odom16", C.c_void_p), ("code", C.c_void_p), ("scores", C.c_void_p),
+        ("scores_ready", C.c_int32), ("gt16", C.c_void_p), ("rmse_sums", C.c_void_p),
         ("tn", C.c_void_p), ("rot", C.c_void_p),
         ("std_t", C.c_float), ("std_r", C.c_float), ("seed", C.c_uint64), ("step", C.c_uint64),
         ("prune_thr", C.c_double),
@@ -119,9 +119,9 @@ SIGNATURES = {
     "midas_rmse": (C.c_int, [_P, _I64, _P, _P, _P]),
     "midas_filter_step": (C.c_int, [_P, _P, _P, _P, C.POINTER(StepArgs)]),
     "midas_filter_step_batch": (C.c_int, [_P, _P, _P, _P, C.POINTER(StepArgs), _I32]),
-    "midas_shard_update": (C.c_int, [_P, _P, _P, _P, C.POINTER(ShardUpdateArgs)]),
-    "midas_tail_a": (C.c_int, [_P, _I64, _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _P]),
-    "midas_tail_fin": (C.c_int, [_P, _I64, _P, _P, _P, _P, _I32, _P, _I32, _P, _I64, _P, _P, _P]),
+    "midas_shard_front": (C.c_int, [_P, _P, _P, _P, C.POINTER(ShardFrontArgs)]),
+    "midas_shard_tail_a": (C.c_int, [_P, _I64, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _P]),
+    "midas_shard_tail_fin": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, _I32, _P, _I32, _I64, _I32, _P, _P]),
     "midas_tail_resample": (C.c_int, [_P, C.POINTER(TailResampleArgs)]),
     "midas_profile_enable": (C.c_int, [_P, _I32]),
     "midas_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64), _I32]),

@@ -479,29 +479,20 @@ static int filter_step_impl(midas_ctx* ctx, const midas_codebook* cb, const mida
 
 
 // ---- particle-sharded step pieces -------------------------------------------------------------------
-MIDAS_EXPORT int midas_shard_update(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
-                                    const midas_tree* tree3, const midas_shard_update_args* args) {
+MIDAS_EXPORT int midas_shard_front(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
+                                   const midas_tree* tree3, const midas_shard_front_args* args) {
     MIDAS_ENTER(ctx);
     MIDAS_REQUIRE(ctx, tree6 && tree3 && args && tree6->dim == 6 && tree3->dim == 3);
-    MIDAS_REQUIRE(ctx, args->scores_dev || (cb && tree6->K == cb->K));
-    const midas_shard_update_args& s = *args;
-    MIDAS_REQUIRE(ctx, s.N > 0 && s.poses_in_dev && s.poses_prop_dev && s.nn_idx_dev && s.x_dev && s.e_dev && s.valid_dev &&
-                           s.extrema_dev && s.odom16_dev && (s.code_dev || s.scores_dev) && s.poses_in_dev != s.poses_prop_dev);
+    const midas_shard_front_args& s = *args;
+    MIDAS_REQUIRE(ctx, s.scores_ready || (cb && tree6->K == cb->K && s.code_dev));
+    MIDAS_REQUIRE(ctx, s.N > 0 && s.poses_in_dev && s.poses_prop_dev && s.nn_idx_dev && s.valid_dev && s.scores_dev &&
+                           s.odom16_dev && s.status_dev && s.flags_dev && s.poses_in_dev != s.poses_prop_dev);
     MIDAS_REQUIRE(ctx, (s.tn_dev == nullptr) == (s.rot_dev == nullptr));
     const int npart = particle_update_blocks(s.N);
-    void *scores, *pmax, *pmin, *prm = nullptr;
+    void* prm = nullptr;
     int rc;
-    if (s.scores_dev) {
-        scores = const_cast<double*>(s.scores_dev);
-    } else {
-        if ((rc = midas_scratch(ctx, (size_t)cb->K * sizeof(double), &scores))) return rc;
-    }
-    if ((rc = midas_scratch(ctx, (size_t)npart * sizeof(double), &pmax))) return rc;
-    if ((rc = midas_scratch(ctx, (size_t)npart * sizeof(double), &pmin))) return rc;
     if (s.gt16_dev && s.rmse_sums_dev)
         if ((rc = midas_scratch(ctx, (size_t)npart * 2 * sizeof(double), &prm))) return rc;
-    if (!s.scores_dev)
-        if ((rc = launch_score(ctx, cb, 1, s.code_dev, (double*)scores))) return rc;
     ParticleUpdateArgs pa;
     pa.N = s.N;
     pa.poses_in = s.poses_in_dev;
@@ -516,9 +507,7 @@ MIDAS_EXPORT int midas_shard_update(midas_ctx* ctx, const midas_codebook* cb, co
     pa.slot_base = s.slot_base;
     pa.hint_in = s.hint_in_dev;
     pa.nn_idx = s.nn_idx_dev;
-    pa.scores = (const double*)scores;
-    pa.x = s.x_dev;
-    pa.e = s.e_dev;
+    pa.scores = nullptr;  // deferred: midas_shard_tail_a gathers the scores
     pa.valid = s.valid_dev;
     pa.t2 = squared_threshold(s.prune_thr);
     pa.thr = s.prune_thr;
@@ -526,35 +515,40 @@ MIDAS_EXPORT int midas_shard_update(midas_ctx* ctx, const midas_codebook* cb, co
     pa.telemetry = (unsigned long long*)s.telemetry_dev;
     pa.status_reset = s.status_dev;
     pa.flags_reset = s.flags_dev;
-    pa.part_max = (double*)pmax;
-    pa.part_min = (double*)pmin;
     pa.gt16 = prm ? s.gt16_dev : nullptr;
     pa.part_rmse = (double*)prm;
-    if ((rc = launch_particle_update(ctx, tree6, tree3, pa))) return rc;
-    return launch_reduce_partials(ctx, npart, (const double*)pmax, (const double*)pmin, (const double*)prm, s.extrema_dev,
-                                  prm ? s.rmse_sums_dev : nullptr);
+    bool fused = false;
+    if (!s.scores_ready && ctx->overlap)
+        if ((rc = launch_frame_front(ctx, tree6, tree3, pa, cb, s.code_dev, s.scores_dev, &fused))) return rc;
+    if (!fused) {
+        if (!s.scores_ready)
+            if ((rc = launch_score(ctx, cb, 1, s.code_dev, s.scores_dev))) return rc;
+        if ((rc = launch_particle_update(ctx, tree6, tree3, pa))) return rc;
+    }
+    if (prm) return launch_reduce_partials(ctx, npart, nullptr, nullptr, (const double*)prm, nullptr, s.rmse_sums_dev);
+    return MIDAS_OK;
 }
 
-MIDAS_EXPORT int midas_tail_a(midas_ctx* ctx, int64_t N, const double* x_dev, const uint8_t* valid_dev, int32_t G,
-                              const double* g1_all_dev, int32_t softmax, double* e_dev, double* lp_dev, double* g2_dev,
-                              int32_t* flag_dev, int32_t* status_dev) {
+MIDAS_EXPORT int midas_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores_dev, const int32_t* nn_idx_dev,
+                                    const uint8_t* valid_dev, int32_t softmax, double* e_dev, double* x_raw_dev,
+                                    double* lp_dev, double* lp_raw_dev, double* r1_dev, int32_t* status_dev) {
     MIDAS_ENTER(ctx);
-    MIDAS_REQUIRE(ctx, N > 0 && G > 0 && x_dev && valid_dev && g1_all_dev && e_dev && lp_dev && g2_dev && flag_dev && status_dev);
-    const int nb = (int)ceil_div(N, SCAN_BLOCK);
-    return launch_tail_a(ctx, N, x_dev, valid_dev, G, 4, g1_all_dev, g1_all_dev + 1, softmax, e_dev, lp_dev, g2_dev, g2_dev + nb,
-                         g2_dev + 2 * nb, flag_dev, status_dev);
+    MIDAS_REQUIRE(ctx, N > 0 && scores_dev && nn_idx_dev && valid_dev && e_dev && x_raw_dev && lp_dev && lp_raw_dev && r1_dev &&
+                           status_dev);
+    return launch_shard_tail_a(ctx, N, scores_dev, nn_idx_dev, valid_dev, softmax, e_dev, x_raw_dev, lp_dev, lp_raw_dev, r1_dev,
+                               status_dev);
 }
 
-MIDAS_EXPORT int midas_tail_fin(midas_ctx* ctx, int64_t N, const double* e_dev, const uint8_t* valid_dev, double* weights_dev,
-                                double* cdf_dev, int32_t G, const double* g2_all_dev, int32_t rank,
-                                const double* g1_all_dev, int64_t N_total, double* rmse_dev, const int32_t* flag_dev,
-                                int32_t* status_dev) {
+MIDAS_EXPORT int midas_shard_tail_fin(midas_ctx* ctx, int64_t N, const double* e_dev, const double* x_raw_dev,
+                                      const double* lp_raw_dev, const uint8_t* valid_dev, double* weights_dev,
+                                      double* cdf_dev, int32_t G, const double* r1_all_dev, int32_t rank, int64_t N_total,
+                                      int32_t softmax, double* rmse_dev, int32_t* status_dev) {
     MIDAS_ENTER(ctx);
-    MIDAS_REQUIRE(ctx, N > 0 && G > 0 && rank >= 0 && rank < G && e_dev && valid_dev && weights_dev && cdf_dev && g2_all_dev &&
-                           g1_all_dev && N_total >= N && flag_dev && status_dev);
+    MIDAS_REQUIRE(ctx, N > 0 && G > 0 && rank >= 0 && rank < G && e_dev && x_raw_dev && lp_raw_dev && valid_dev && weights_dev &&
+                           cdf_dev && r1_all_dev && N_total >= N && status_dev);
     const int nb = (int)ceil_div(N, SCAN_BLOCK);
-    return launch_tail_fin(ctx, N, e_dev, valid_dev, weights_dev, cdf_dev, G, nb, g2_all_dev, rank, g1_all_dev, (double)N_total,
-                           rmse_dev, flag_dev, status_dev);
+    return launch_tail_fin(ctx, N, e_dev, x_raw_dev, lp_raw_dev, valid_dev, weights_dev, cdf_dev, G, nb, r1_all_dev, rank,
+                           (double)N_total, softmax, rmse_dev, status_dev);
 }
 
 MIDAS_EXPORT int midas_tail_resample(midas_ctx* ctx, const midas_tail_resample_args* args) {

@@ -1317,10 +1317,12 @@ __global__ __launch_bounds__(256) void k_reduce_partials(int np, const double* _
     double a = -INFINITY, b = INFINITY, p = 0.0, q = 0.0;
     bool nan = false;
     for (int i = threadIdx.x; i < np; i += 256) {
-        double u = pmax[i], v = pmin[i];
-        nan |= (u != u) || (v != v);
-        a = u > a ? u : a;
-        b = v < b ? v : b;
+        if (pmax) {
+            double u = pmax[i], v = pmin[i];
+            nan |= (u != u) || (v != v);
+            a = u > a ? u : a;
+            b = v < b ? v : b;
+        }
         if (prm) { p += prm[2 * i]; q += prm[2 * i + 1]; }
     }
     a = wave_max(a);
@@ -1340,8 +1342,10 @@ __global__ __launch_bounds__(256) void k_reduce_partials(int np, const double* _
             a = s0[i] > a ? s0[i] : a;
             b = s1[i] < b ? s1[i] : b;
         }
-        extrema2[0] = bad ? NAN : a;
-        extrema2[1] = bad ? NAN : b;
+        if (extrema2) {
+            extrema2[0] = bad ? NAN : a;
+            extrema2[1] = bad ? NAN : b;
+        }
         if (rmse_sums2) {
             rmse_sums2[0] = (s2[0] + s2[1]) + (s2[2] + s2[3]);
             rmse_sums2[1] = (s3[0] + s3[1]) + (s3[2] + s3[3]);

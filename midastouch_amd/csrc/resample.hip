@@ -427,7 +427,8 @@ __global__ __launch_bounds__(256) void k_tail_a2(int64_t N, const double* __rest
                                                  double* __restrict__ gend_soft, double* __restrict__ gend_raw,
                                                  double* __restrict__ bsum_e, double* __restrict__ btot_soft,
                                                  double* __restrict__ btot_raw, double* __restrict__ bmax,
-                                                 double* __restrict__ bmin, int32_t* __restrict__ status) {
+                                                 double* __restrict__ bmin, int32_t* __restrict__ status,
+                                                 double* __restrict__ flags_out) {
     __shared__ double s_a[SCAN_BLOCK + SCAN_BLOCK / 16];
     __shared__ double s_m[SCAN_BLOCK + SCAN_BLOCK / 16];
     __shared__ double s_gtot[16];
@@ -504,46 +505,81 @@ __global__ __launch_bounds__(256) void k_tail_a2(int64_t N, const double* __rest
         btot_raw[blockIdx.x] = 0.0;
     }
     const bool wnan = __any(nan);
-    if (wnan && (t & 63) == 0) atomicOr(&status[0], 2);
+    if (wnan && (t & 63) == 0) {
+        atomicOr(&status[0], 2);
+        if (flags_out) atomicAdd(&flags_out[0], 1.0);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
-    if ((t & 63) == 0 && kept) atomicAdd(&status[1], kept);
+    if ((t & 63) == 0 && kept) {
+        atomicAdd(&status[1], kept);
+        if (flags_out) atomicAdd(&flags_out[1], (double)kept);  // exact: integers far below 2^53
+    }
 }
 
 constexpr int TB_MAX_BLOCKS = 1024;  // 4 M particles (per GPU in the fused step, in total in the sharded step)
 
-// TF (sharded path): weights = e / S * valid ; cdf = (BP + lp) / total with S, BP, total summed sequentially
-//     over ALL shards' block partials, read straight from the gathered exchange buffer g2_all
-//     (per rank: nb block sums of e | nb block totals of e*valid | NaN count | kept count) ; the globally last
-//     slot is forced to 1 ; status and (optionally) the rmse of all shards are finalised by block 0.
-__global__ __launch_bounds__(256) void k_tail_fin(int64_t N, const double* __restrict__ e, const uint8_t* __restrict__ valid,
+// TF (sharded path): every rank holds the gathered exchange records r1_all (one per rank, rec = 5 nb + 4 doubles:
+//     nb block sums of e | nb block totals of e*valid | nb block totals of x*valid | nb block max x | nb block min x |
+//     NaN count | kept count | sum |dt|^2 | sum angle^2 ) written by TA2 on each shard.  The isclose guard is decided
+//     from the gathered extrema (as TB2 does on one GPU) and picks the softmax or the raw variant; then
+//     weights = e / S * valid and cdf = (BP + lp) / total with S, BP, total summed sequentially over ALL shards'
+//     blocks in global block order; the globally last slot is forced to 1; block 0 finalises status and rmse.
+__global__ __launch_bounds__(256) void k_tail_fin(int64_t N, const double* __restrict__ e, const double* __restrict__ x_raw,
+                                                  const double* __restrict__ lp_raw, const uint8_t* __restrict__ valid,
                                                   double* __restrict__ weights, double* __restrict__ cdf_io, int G, int nb,
-                                                  const double* __restrict__ g2_all, int rank,
-                                                  const double* __restrict__ g1_all, double n_total,
-                                                  double* __restrict__ rmse_out, const int32_t* __restrict__ flag,
+                                                  const double* __restrict__ r1_all, int rank, double n_total,
+                                                  int32_t softmax, double* __restrict__ rmse_out,
                                                   int32_t* __restrict__ status) {
-    __shared__ double s_buf[TB_MAX_BLOCKS];
-    const int nb_all = G * nb, rec = 2 * nb + 2;
+    __shared__ double s_w[TB_MAX_BLOCKS];
+    __shared__ double s_se[TB_MAX_BLOCKS];
+    __shared__ double s_ex[12];
+    __shared__ double s_tot[3];
+    __shared__ int s_apply;
+    const int t = threadIdx.x;
+    const int nb_all = G * nb, rec = 5 * nb + 4;
     const int my = rank * nb + (int)blockIdx.x;
-    // totals of e*valid of every block, in global block order
-    for (int i = threadIdx.x; i < nb_all; i += 256) s_buf[i] = g2_all[(int64_t)(i / nb) * rec + nb + (i % nb)];
-    __syncthreads();
-    double bp = 0.0, total = 0.0;
-    for (int i = 0; i < nb_all; ++i) { if (i == my) bp = total; total = total + s_buf[i]; }
-    __syncthreads();
-    double S = 1.0;
-    if (flag[0]) {
-        for (int i = threadIdx.x; i < nb_all; i += 256) s_buf[i] = g2_all[(int64_t)(i / nb) * rec + (i % nb)];
-        __syncthreads();
-        S = 0.0;
-        for (int i = 0; i < nb_all; ++i) S = S + s_buf[i];
+    auto field = [&](int f, int i) { return r1_all[(int64_t)(i / nb) * rec + (int64_t)f * nb + (i % nb)]; };
+    double mx = -INFINITY, mn = INFINITY;
+    bool nan = false;
+    for (int i = t; i < nb_all; i += 256) {
+        const double u = field(3, i), v = field(4, i);
+        nan |= (u != u) || (v != v);
+        mx = u > mx ? u : mx;
+        mn = v < mn ? v : mn;
+        s_w[i] = field(1, i);
+        s_se[i] = field(0, i);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    mx = wmax(mx);
+    mn = wmin(mn);
+    const bool wn = __any(nan);
+    if ((t & 63) == 0) { s_ex[t >> 6] = mx; s_ex[4 + (t >> 6)] = mn; s_ex[8 + (t >> 6)] = wn ? 1.0 : 0.0; }
+    __syncthreads();
+    if (t == 0) {
+        mx = s_ex[0]; mn = s_ex[4];
+        double f = s_ex[8];
+        for (int w = 1; w < 4; ++w) { mx = s_ex[w] > mx ? s_ex[w] : mx; mn = s_ex[4 + w] < mn ? s_ex[4 + w] : mn; f += s_ex[8 + w]; }
+        if (f != 0.0) { mx = NAN; mn = NAN; }
+        s_apply = (softmax && !(__builtin_fabs(mx - mn) <= ISCLOSE_ATOL)) ? 1 : 0;
+    }
+    __syncthreads();
+    const bool apply = s_apply != 0;
+    if (!apply) {
+        for (int i = t; i < nb_all; i += 256) s_w[i] = field(2, i);
+        __syncthreads();
+    }
+    if (t == 0) {
+        double bp = 0.0, total = 0.0, S = 0.0;
+        for (int i = 0; i < nb_all; ++i) { if (i == my) bp = total; total = total + s_w[i]; S = S + s_se[i]; }
+        s_tot[0] = bp; s_tot[1] = total; s_tot[2] = apply ? S : 1.0;
+    }
+    __syncthreads();
+    const double bp = s_tot[0], total = s_tot[1], S = s_tot[2];
+    if (blockIdx.x == 0 && t == 0) {
         double nans = 0.0, kept = 0.0, st2 = 0.0, sr2 = 0.0;
         for (int r = 0; r < G; ++r) {
-            nans += g2_all[(int64_t)r * rec + 2 * nb];
-            kept += g2_all[(int64_t)r * rec + 2 * nb + 1];
-            if (rmse_out) { st2 += g1_all[4 * r + 2]; sr2 += g1_all[4 * r + 3]; }
+            const double* fl = r1_all + (int64_t)r * rec + 5 * nb;
+            nans += fl[0]; kept += fl[1]; st2 += fl[2]; sr2 += fl[3];
         }
         int st = nans != 0.0 ? 2 : 0;
         if (total != total) st |= 2;
@@ -552,14 +588,23 @@ __global__ __launch_bounds__(256) void k_tail_fin(int64_t N, const double* __res
         status[1] = (int32_t)kept;
         if (rmse_out) { rmse_out[0] = __builtin_sqrt(st2 / n_total); rmse_out[1] = __builtin_sqrt(sr2 / n_total); }
     }
+    const double* __restrict__ ev = apply ? e : x_raw;
+    const double* __restrict__ lpv = apply ? cdf_io : lp_raw;
     const bool is_last = rank == G - 1;
     const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK;
+    double ee[SCAN_CHUNK], ll[SCAN_CHUNK];
+    uint8_t ok[SCAN_CHUNK];
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) {  // unconditional loads on clamped slots
+        const int64_t i = base + (int64_t)j * 256 + t, ic = i < N ? i : N - 1;
+        ee[j] = ev[ic]; ll[j] = lpv[ic]; ok[j] = valid[ic];
+    }
 #pragma unroll
     for (int j = 0; j < SCAN_CHUNK; ++j) {
-        const int64_t i = base + (int64_t)j * 256 + threadIdx.x;
+        const int64_t i = base + (int64_t)j * 256 + t;
         if (i < N) {
-            weights[i] = (e[i] / S) * (valid[i] ? 1.0 : 0.0);
-            cdf_io[i] = (is_last && i == N - 1) ? 1.0 : (bp + cdf_io[i]) / total;
+            weights[i] = (ee[j] / S) * (ok[j] ? 1.0 : 0.0);
+            cdf_io[i] = (is_last && i == N - 1) ? 1.0 : (bp + ll[j]) / total;
         }
     }
 }
@@ -1159,13 +1204,27 @@ int launch_tail_a(midas_ctx* ctx, int64_t N, const double* x, const uint8_t* val
     return MIDAS_OK;
 }
 
-int launch_tail_fin(midas_ctx* ctx, int64_t N, const double* e, const uint8_t* valid, double* weights, double* cdf_io, int G,
-                    int nb, const double* g2_all, int rank, const double* g1_all, double n_total, double* rmse_out,
-                    const int32_t* flag, int32_t* status) {
+int launch_tail_fin(midas_ctx* ctx, int64_t N, const double* e, const double* x_raw, const double* lp_raw, const uint8_t* valid,
+                    double* weights, double* cdf_io, int G, int nb, const double* r1_all, int rank, double n_total,
+                    int32_t softmax, double* rmse_out, int32_t* status) {
     if ((int64_t)G * nb > TB_MAX_BLOCKS)
         return midas_set_error(ctx, MIDAS_ERR_INVALID, "G*nb", "more than 4 M particles in total in the sharded step");
-    hipLaunchKernelGGL(k_tail_fin, dim3((unsigned)ceil_div(N, SCAN_BLOCK)), dim3(256), 0, ctx->stream, N, e, valid, weights,
-                       cdf_io, G, nb, g2_all, rank, g1_all, n_total, rmse_out, flag, status);
+    hipLaunchKernelGGL(k_tail_fin, dim3((unsigned)ceil_div(N, SCAN_BLOCK)), dim3(256), 0, ctx->stream, N, e, x_raw, lp_raw, valid,
+                       weights, cdf_io, G, nb, r1_all, rank, n_total, softmax, rmse_out, status);
+    LAUNCH_CHECK(ctx);
+    return MIDAS_OK;
+}
+
+// TA2 of one shard: the exchange record r1 = [bsum_e | btot | btot_raw | bmax | bmin | NaN count, kept count | ...]
+int launch_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
+                        int32_t softmax, double* e, double* x_raw, double* lp, double* lp_raw, double* r1, int32_t* status) {
+    const int nb = (int)ceil_div(N, SCAN_BLOCK), ng = (int)ceil_div(N, SCAN_CHUNK);
+    void* sc;
+    int rc = midas_scratch(ctx, (size_t)ng * 2 * sizeof(double), &sc);  // chunk-end tables (only TB2 uses them)
+    if (rc) return rc;
+    double* gend = (double*)sc;
+    hipLaunchKernelGGL(k_tail_a2, dim3((unsigned)nb), dim3(256), 0, ctx->stream, N, scores, nn_idx, valid, softmax, e, x_raw, lp,
+                       lp_raw, gend, gend + ng, r1, r1 + nb, r1 + 2 * nb, r1 + 3 * nb, r1 + 4 * nb, status, r1 + 5 * nb);
     LAUNCH_CHECK(ctx);
     return MIDAS_OK;
 }
@@ -1214,7 +1273,7 @@ int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base) 
         double* gend = bmin + nb;
         double* gend_raw = gend + ng;
         hipLaunchKernelGGL(k_tail_a2, dim3((unsigned)nb), dim3(256), 0, ctx->stream, a.N, a.scores, a.nn_idx, a.valid, a.softmax,
-                           e, a.x_raw, a.cdf, a.lp_raw, gend, gend_raw, psum, pw, praw, bmax, bmin, a.status);
+                           e, a.x_raw, a.cdf, a.lp_raw, gend, gend_raw, psum, pw, praw, bmax, bmin, a.status, nullptr);
         LAUNCH_CHECK(ctx);
         prof_mark(ctx, prof_slot_base + 1);
         TailB2Args b;

@@ -4,11 +4,15 @@ SURVEY.md 8(e): rank r owns the global particle slots [r*N, (r+1)*N) and a full 
 the NN index and the mesh index.  One frame is the single-GPU frame (engine.FilterEngine.step) cut at
 its global reductions; between the local kernels the ranks exchange, with `all_gather`:
 
-  G1  4 doubles/rank   max x, min x (softmax shift + isclose guard), rmse partial sums
-  G2  2nb+2 doubles    block sums of exp(x - max) (softmax denominator), block totals of exp * mask
-                       (CDF offsets / total), NaN flag, kept count - all in the fixed summation order
-  G3  84 N bytes/rank  ONE packed record block [cdf | weights | propagated poses | NN indices]: the
+  R1  5nb+4 doubles    per 4096-slot block: sum of exp(x - 1) (softmax denominator), totals of exp * mask and of
+                       x * mask (CDF offsets / total of the softmax and of the raw variant), max x, min x (the
+                       isclose guard is global); then NaN count, kept count, rmse partial sums - all in the
+                       fixed summation order
+  R2  84 N bytes/rank  ONE packed record block [cdf | weights | propagated poses | NN indices]: the
                        cross-rank resample reads any rank's particle from the gathered blocks
+
+The local kernels are the single-GPU ones: the fused front (particle update + codebook scoring in one launch)
+and the deferred tail that gathers the scores itself.
 
 The float64 summation order is the single-GPU one (per-block totals are gathered and every rank adds
 them sequentially in global block order), so with N a multiple of 4096 the sharded run reproduces the
@@ -26,7 +30,7 @@ import ctypes as C
 import torch
 
 from . import _lib, ops
-from ._lib import MidasError, ShardUpdateArgs, TailResampleArgs, _ptr
+from ._lib import MidasError, ShardFrontArgs, TailResampleArgs, _ptr
 
 BLOCK = 4096  # summation block of the CDF spec (csrc/resample.hip)
 
@@ -56,6 +60,7 @@ class HipShardBackend:
         self.codebook = ops.Codebook(emb.to(self.device))
         self.tree3 = ops.Tree(torch.as_tensor(mesh_vertices).to(self.device, torch.float64))
         self.tree6.attach_mesh(self.tree3, self.cb_poses)
+        self.K = int(self.cb_poses.shape[0])
 
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.device)
@@ -68,31 +73,32 @@ class HipShardBackend:
         """This rank's slice of the frame's scores (row-sharded codebook)."""
         return self.codebook.score(code)[0]
 
-    def update(self, st, odom, code, gt, tn, rot, std_t, std_r, seed, step, prune_thr, use_hint=True, scores=None):
-        a = ShardUpdateArgs()
+    def front(self, st, odom, code, gt, tn, rot, std_t, std_r, seed, step, prune_thr, use_hint=True, scores_ready=False):
+        a = ShardFrontArgs()
         a.N, a.slot_base = st.N, st.slot_base
         a.poses_in, a.poses_prop = _ptr(st.poses), _ptr(st.poses_prop)
         a.hint_in = _ptr(st.hint) if use_hint else None
-        a.nn_idx, a.x, a.e, a.valid, a.extrema = _ptr(st.nn_idx), _ptr(st.x), _ptr(st.e), _ptr(st.valid), _ptr(st.g1[:2])
+        a.nn_idx, a.valid = _ptr(st.nn_idx), _ptr(st.valid)
         a.odom16, a.code, a.gt16 = _ptr(odom), _ptr(code), _ptr(gt)
-        a.scores = _ptr(scores)
-        a.rmse_sums = _ptr(st.g1[2:]) if gt is not None else None
+        a.scores, a.scores_ready = _ptr(st.scores), int(bool(scores_ready))
+        a.rmse_sums = _ptr(st.r1[5 * st.nb + 2:]) if gt is not None else None
         a.tn, a.rot = _ptr(tn), _ptr(rot)
         a.std_t, a.std_r, a.seed, a.step, a.prune_thr = std_t, std_r, seed, step, prune_thr
         a.telemetry = _ptr(st.telemetry)
         a.status = _ptr(st.status)
-        a.flags = _ptr(st.g2[2 * st.nb:])
+        a.flags = _ptr(st.r1[5 * st.nb:])
         self.ctx.bind_current_stream()
-        self.ctx.check(self.ctx.lib.midas_shard_update(self.ctx.h, None if scores is not None else self.codebook.h,
-                                                       self.tree6.h, self.tree3.h, C.byref(a)))
+        self.ctx.check(self.ctx.lib.midas_shard_front(self.ctx.h, None if scores_ready else self.codebook.h,
+                                                      self.tree6.h, self.tree3.h, C.byref(a)))
 
-    def tail_a(self, st, g1_all, softmax):
-        self.ctx.call("midas_tail_a", st.N, _ptr(st.x), _ptr(st.valid), g1_all.shape[0] // 4, _ptr(g1_all), int(softmax),
-                      _ptr(st.e), _ptr(st.cdf), _ptr(st.g2), _ptr(st.flag), _ptr(st.status))
+    def tail_a(self, st, softmax):
+        self.ctx.call("midas_shard_tail_a", st.N, _ptr(st.scores), _ptr(st.nn_idx), _ptr(st.valid), int(softmax), _ptr(st.e),
+                      _ptr(st.x), _ptr(st.cdf), _ptr(st.lp_raw), _ptr(st.r1), _ptr(st.status))
 
-    def tail_fin(self, st, g2_all, g1_all, rank, world, n_total, want_rmse):
-        self.ctx.call("midas_tail_fin", st.N, _ptr(st.e), _ptr(st.valid), _ptr(st.weights), _ptr(st.cdf), world, _ptr(g2_all),
-                      rank, _ptr(g1_all), n_total, _ptr(st.rmse) if want_rmse else None, _ptr(st.flag), _ptr(st.status))
+    def tail_fin(self, st, r1_all, rank, world, n_total, softmax, want_rmse):
+        self.ctx.call("midas_shard_tail_fin", st.N, _ptr(st.e), _ptr(st.x), _ptr(st.lp_raw), _ptr(st.valid), _ptr(st.weights),
+                      _ptr(st.cdf), world, _ptr(r1_all), rank, n_total, int(softmax),
+                      _ptr(st.rmse) if want_rmse else None, _ptr(st.status))
 
     def tail_resample(self, st, pack_all, n_all, mode, u, u32, seed, step):
         a = TailResampleArgs()
@@ -108,7 +114,7 @@ class HipShardBackend:
 class ShardState:
     """Per-shard tensors (allocated through the backend so tests can keep them on the CPU)."""
 
-    def __init__(self, backend, N, slot_base):
+    def __init__(self, backend, N, slot_base, K):
         e = backend.empty
         self.N, self.slot_base = int(N), int(slot_base)
         self.nb = (self.N + BLOCK - 1) // BLOCK
@@ -124,20 +130,20 @@ class ShardState:
         self.weights = self.pack[8 * N:16 * N].view(torch.float64)
         self.poses_prop = self.pack[16 * N:80 * N].view(torch.float32).view(N, 4, 4)
         self.nn_idx = self.pack[80 * N:84 * N].view(torch.int32)
-        self.x = e((N,), torch.float64)
+        self.x = e((N,), torch.float64)             # raw scores (written where the isclose guard may fire)
+        self.lp_raw = e((N,), torch.float64)        # block-local prefix of x * mask (likewise)
+        self.scores = e((int(K),), torch.float64)   # the frame's codebook scores
         self.valid = e((N,), torch.uint8)
         self.hint = e((N,), torch.int32)
         self.ridx = e((N,), torch.int32)
-        self.g1 = e((4,), torch.float64)            # max, min, rmse sums
         self.e = e((N,), torch.float64)
-        self.g2 = e((2 * self.nb + 2,), torch.float64)  # block sums of e, block totals of e*mask, NaN flag, kept
-        self.flag = e((1,), torch.int32)
+        self.r1 = e((5 * self.nb + 4,), torch.float64)  # exchange record (see the module docstring)
         self.status = e((2,), torch.int32)
         self.rmse = e((2,), torch.float64)
         self.telemetry = e((16,), torch.int64)
         self.telemetry.zero_()
         self.hint.fill_(-1)
-        self.g1.zero_()
+        self.r1.zero_()
 
 
 class TorchDistComm:
@@ -184,7 +190,7 @@ class ShardedFilterEngine:
         self.backend = backend
         self.N = int(num_particles)
         self.N_total = self.N * self.world
-        self.st = ShardState(self.backend, self.N, self.rank * self.N)
+        self.st = ShardState(self.backend, self.N, self.rank * self.N, self.backend.K)
         self.sig_t, self.sig_r, self.pen_max = float(sig_t), float(sig_r), float(pen_max)
         self.seed, self.softmax = int(seed), bool(softmax)
         self.mode = {"weighted_random": _lib.RESAMPLE_MULTINOMIAL, "low_var": _lib.RESAMPLE_SYSTEMATIC,
@@ -219,15 +225,15 @@ class ShardedFilterEngine:
     def step_gen(self, odom, code, gt=None, tn=None, rot=None, u=None, u32=-1.0, multiplier: float = 1.0):
         st, b, G = self.st, self.backend, self.world
         mul = max(float(multiplier), 1.0)
-        scores = None
+        ready = False
         if getattr(b, "row_shard", None) is not None:  # codebook rows sharded: gather the score slices first
-            scores = yield b.score_slice(code)
-        b.update(st, odom, code, gt, tn, rot, mul * self.sig_t, mul * self.sig_r, self.seed, self.step_count,
-                 self.pen_max, self.use_hint, scores=scores)
-        g1_all = yield st.g1
-        b.tail_a(st, g1_all, self.softmax)
-        g2_all = yield st.g2
-        b.tail_fin(st, g2_all, g1_all, self.rank, G, self.N_total, gt is not None)
+            st.scores.copy_((yield b.score_slice(code)))
+            ready = True
+        b.front(st, odom, code, gt, tn, rot, mul * self.sig_t, mul * self.sig_r, self.seed, self.step_count,
+                self.pen_max, self.use_hint, scores_ready=ready)
+        b.tail_a(st, self.softmax)
+        r1_all = yield st.r1
+        b.tail_fin(st, r1_all, self.rank, G, self.N_total, self.softmax, gt is not None)
         pack_all = yield st.pack
         b.tail_resample(st, pack_all, self.N_total, self.mode, u, u32, self.seed, self.step_count)
         self.step_count += 1
