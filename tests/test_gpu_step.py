@@ -189,6 +189,26 @@ def test_step_isclose_guard_and_raw_weights(dev, oracle, softmax):
         poses = ref["poses"]
 
 
+def test_step_unfused_path_odd_dimension(dev, oracle):
+    """D = 96 has no fused-front instantiation: separate scoring and particle-update launches, legacy tail
+    (midas_filter_step falls back by itself); same parity bar."""
+    from midastouch_amd.engine import FilterEngine
+    N, K, D = 5000, 2000, 96
+    cb, traj, scale = _setup(N, K, D, seed=6)
+    ofl = oracle.OracleFilter(cb.poses, cb.embeddings, cb.mesh_vertices)
+    eng = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4300, device=dev)
+    rng = np.random.default_rng(11)
+    poses = cb.poses[rng.integers(0, K, N)]
+    eng.set_particles(torch.as_tensor(poses))
+    for t in range(1, 6):
+        tn, rot = oracle.philox_noise(N, 4300, t - 1, np.float32(2e-4), np.float32(0.5))
+        u = oracle.philox_uniform64(N, 4300, t - 1)
+        ref = ofl.step(poses, traj.odoms[t], traj.codes[t], tn, rot, u=u)
+        eng.step(torch.as_tensor(traj.odoms[t]).to(dev), torch.as_tensor(traj.codes[t]).to(dev))
+        _compare_step(eng, ref, t)
+        poses = ref["poses"]
+
+
 def test_step_full_size_properties(dev):
     """BASELINE config 2 sizes (N=100k, K=50k, D=512): size-independent properties."""
     from midastouch_amd.engine import FilterEngine
