@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--sharded", action="store_true", help="use the particle-sharded engine even on one GPU (smoke test)")
+    ap.add_argument("--eager", action="store_true", help="materialise the resampled particles every frame (three launches per frame)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,7 +102,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from midastouch_amd.engine import FilterEngine
+    from midastouch_amd.engine import FilterEngine, PipelinedFilterEngine
     from midastouch_amd.synthetic import make_codebook, make_trajectory
 
     N, K, D = args.particles, args.codebook, args.dim
@@ -112,7 +113,10 @@ def main():
 
     sharded = world > 1 or args.sharded
     if not sharded:
-        eng = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4000, device=dev)
+        # pipelined: the resample of frame t runs inside the front kernel of frame t+1 (two launches per frame); the
+        # particle set is materialised when it is read - here once, after the timed region (eng.status below)
+        cls = FilterEngine if args.eager else PipelinedFilterEngine
+        eng = cls(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4000, device=dev)
     else:
         from midastouch_amd.dist import ShardedFilterEngine
         eng = ShardedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4000, device=dev)
@@ -163,6 +167,8 @@ def main():
                                "device Philox draws, multinomial resample" % (N, K, D),
                    "particles_per_gpu": N, "particles_total": N * world, "codebook_rows": K, "embedding_dim": D,
                    "parallelism": "particle-sharded x%d" % world if sharded else "single",
+                   "engine": "sharded" if sharded else ("eager: 3 launches/frame" if args.eager else
+                                                        "pipelined: resample of frame t folded into the front kernel of frame t+1, 2 launches/frame"),
                    "arith": "f32 poses/NN, f64 scores/weights/CDF", "last_status": status,
                    "tree_search_fallbacks_per_frame": {"nn": tele[0] / frames_run, "prune": tele[1] / frames_run}},
     }
@@ -187,7 +193,10 @@ def main():
         fused = per["score_codebook"] == 0.0  # the scoring shares the launch of the particle update (k_frame_front)
         if fused:
             per = {"frame_front": per["particle_update"], "tail_a": per["tail_a"], "tail_b": per["tail_b"]}
-            groups = {"frame_front": per["frame_front"], "tail": per["tail_a"] + per["tail_b"]}
+            if per["tail_b"] == 0.0:  # pipelined: no separate resample launch
+                per.pop("tail_b")
+            groups = {"frame_front": per["frame_front"], "tail": per["tail_a"] + per.get("tail_b", 0.0)}
+            # algorithmic bytes of the front: scoring + particle update (the folded resample's reads are not added)
             ab["frame_front"] = ab["score_codebook"] + ab["particle_update"]
             dom = "frame_front"
         else:
@@ -200,7 +209,8 @@ def main():
         traffic, traffic_src = None, None
         try:
             tj = json.load(open(os.path.join(REPO, "profiles", "r01_traffic.json")))
-            traffic, traffic_src = tj["kernels"][dom]["hbm_bytes"], "profiles/r01_traffic.json"
+            key = dom + ("" if args.eager or dom != "frame_front" else "_pipelined")
+            traffic, traffic_src = tj["kernels"][key]["hbm_bytes"], "profiles/r01_traffic.json"
         except Exception:
             pass
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

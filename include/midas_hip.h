@@ -179,6 +179,72 @@ int midas_filter_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree
                       const midas_tree* tree3, const midas_step_args* args);
 
 
+/* ---- pipelined single-trajectory step ------------------------------------------------------------------------
+ * Slot n of frame t+1 is particle src(n) of frame t: the resampler's search and gather (particle_filter.py:230-307)
+ * depend on nothing but the slot, so midas_lazy_step folds the resample of the PREVIOUS frame into the front kernel of
+ * this one - the resampled poses never travel through HBM and one launch per frame disappears.  A frame is then
+ *     midas_lazy_step  = [resample frame t-1 | propagate + NN + prune | score codebook] (one launch) + softmax/CDF tables
+ * and the resampled particle set of the last frame exists only implicitly until midas_lazy_flush materialises it
+ * (same kernel as the tail of midas_filter_step: identical indices, poses, weights).  After a flush the next
+ * midas_lazy_step starts from the materialised particles (resample_prev = 0).  The caller owns every buffer and
+ * alternates two sets of the per-frame state.  Requires a float32 codebook with D in {128, 256, 512, 1024} and
+ * N <= 1 M; MIDAS_ERR_INVALID otherwise (use midas_filter_step). */
+typedef struct midas_lazy_args {
+    int64_t N;
+    const float* poses_prop_prev_dev;  /* N x 16: propagated poses of the previous frame (resample_prev) */
+    const int32_t* nn_idx_prev_dev;    /* N */
+    const int32_t* status_prev_dev;    /* 2 */
+    float* poses_prop_dev;             /* N x 16 out */
+    int32_t* nn_idx_dev;               /* N out */
+    uint8_t* valid_dev;                /* N out */
+    int32_t* status_dev;               /* 2 out: [0] = 2 on NaN weights, [1] = particles kept by the prune */
+    double* tables_dev;                /* 4 N + 2 ceil(N/16) + 5 ceil(N/4096) doubles: on entry the previous frame's softmax /
+                                        * CDF tables (read when resample_prev), on exit this frame's */
+    double* scores_dev;                /* K: this frame's codebook scores */
+    double* part_rmse_dev;             /* NULL or 2 ceil(N/64): per-wave rmse sums of this frame (gt16_dev) */
+    int32_t resample_prev;             /* 1: particles = resample of the previous frame; 0: poses_in_dev / hint_in_dev */
+    const float* poses_in_dev;         /* N x 16 (resample_prev == 0) */
+    const int32_t* hint_in_dev;        /* N or NULL */
+    int32_t resample_mode;             /* draws of the previous frame's resample: */
+    const double* u_prev_dev;          /*   N uniforms or NULL -> Philox(seed, step_prev) */
+    float u32_prev;                    /*   systematic offset, < 0 -> Philox */
+    uint64_t step_prev;
+    int32_t* ridx_dev;                 /* NULL or N out: the previous frame's resample indices (resample_prev) */
+    const float* odom16_dev;
+    const double* code_dev;
+    const float* gt16_dev;             /* NULL or 16 */
+    const float* tn_dev;               /* host draws or NULL -> Philox(seed, step) */
+    const float* rot_dev;
+    float std_t, std_r;
+    uint64_t seed, step;
+    double prune_thr;
+    int32_t softmax;
+    uint64_t* telemetry_dev;           /* NULL or 16 cumulative counters (see midas_step_args) */
+} midas_lazy_args;
+int midas_lazy_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
+                    const midas_lazy_args* args);
+typedef struct midas_lazy_flush_args {
+    int64_t N;
+    const double* tables_dev;          /* the frame's tables, valid mask, NN indices, propagated poses (midas_lazy_step) */
+    const uint8_t* valid_dev;
+    const int32_t* nn_idx_dev;
+    const float* poses_prop_dev;
+    int32_t* status_dev;               /* [0] completed with the cdf status (see midas_cdf) */
+    const double* part_rmse_dev;       /* NULL or the frame's per-wave sums */
+    int32_t softmax, resample_mode;
+    const double* u_dev;               /* N uniforms or NULL -> Philox(seed, step) */
+    float u32;
+    uint64_t seed, step;
+    double* weights_dev;               /* N out: masked weights (pre-resample) */
+    int32_t* ridx_dev;                 /* N out */
+    float* poses_out_dev;              /* N x 16 out */
+    double* weights_out_dev;           /* N out */
+    int32_t* hint_out_dev;             /* N out */
+    double* rmse_dev;                  /* NULL or 2 out */
+} midas_lazy_flush_args;
+int midas_lazy_flush(midas_ctx* ctx, const midas_lazy_flush_args* args);
+
+
 /* ---- particle-sharded step (one process per GPU; the caller runs the collectives between the calls) ---- */
 /* The frame of midas_filter_step split at its three global reductions so that N_total particles can be
  * sharded across ranks: shard r owns the global slots [slot_base, slot_base + N) and the

@@ -75,6 +75,37 @@ class ShardFrontArgs(C.Structure):
     ]
 
 
+class LazyArgs(C.Structure):
+    """midas_lazy_args (include/midas_hip.h)."""
+
+    _fields_ = [
+        ("N", C.c_int64),
+        ("poses_prop_prev", C.c_void_p), ("nn_idx_prev", C.c_void_p), ("status_prev", C.c_void_p),
+        ("poses_prop", C.c_void_p), ("nn_idx", C.c_void_p), ("valid", C.c_void_p), ("status", C.c_void_p),
+        ("tables", C.c_void_p), ("scores", C.c_void_p), ("part_rmse", C.c_void_p),
+        ("resample_prev", C.c_int32), ("poses_in", C.c_void_p), ("hint_in", C.c_void_p),
+        ("resample_mode", C.c_int32), ("u_prev", C.c_void_p), ("u32_prev", C.c_float), ("step_prev", C.c_uint64),
+        ("ridx", C.c_void_p),
+        ("odom16", C.c_void_p), ("code", C.c_void_p), ("gt16", C.c_void_p), ("tn", C.c_void_p), ("rot", C.c_void_p),
+        ("std_t", C.c_float), ("std_r", C.c_float), ("seed", C.c_uint64), ("step", C.c_uint64),
+        ("prune_thr", C.c_double), ("softmax", C.c_int32), ("telemetry", C.c_void_p),
+    ]
+
+
+class LazyFlushArgs(C.Structure):
+    """midas_lazy_flush_args (include/midas_hip.h)."""
+
+    _fields_ = [
+        ("N", C.c_int64),
+        ("tables", C.c_void_p), ("valid", C.c_void_p), ("nn_idx", C.c_void_p), ("poses_prop", C.c_void_p),
+        ("status", C.c_void_p), ("part_rmse", C.c_void_p),
+        ("softmax", C.c_int32), ("resample_mode", C.c_int32), ("u", C.c_void_p), ("u32", C.c_float),
+        ("seed", C.c_uint64), ("step", C.c_uint64),
+        ("weights", C.c_void_p), ("ridx", C.c_void_p), ("poses_out", C.c_void_p), ("weights_out", C.c_void_p),
+        ("hint_out", C.c_void_p), ("rmse", C.c_void_p),
+    ]
+
+
 class TailResampleArgs(C.Structure):
     """midas_tail_resample_args (include/midas_hip.h)."""
 
@@ -119,6 +150,8 @@ SIGNATURES = {
     "midas_rmse": (C.c_int, [_P, _I64, _P, _P, _P]),
     "midas_filter_step": (C.c_int, [_P, _P, _P, _P, C.POINTER(StepArgs)]),
     "midas_filter_step_batch": (C.c_int, [_P, _P, _P, _P, C.POINTER(StepArgs), _I32]),
+    "midas_lazy_step": (C.c_int, [_P, _P, _P, _P, C.POINTER(LazyArgs)]),
+    "midas_lazy_flush": (C.c_int, [_P, C.POINTER(LazyFlushArgs)]),
     "midas_shard_front": (C.c_int, [_P, _P, _P, _P, C.POINTER(ShardFrontArgs)]),
     "midas_shard_tail_a": (C.c_int, [_P, _I64, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _P]),
     "midas_shard_tail_fin": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, _I32, _P, _I32, _I64, _I32, _P, _P]),

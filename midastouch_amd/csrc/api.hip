@@ -478,6 +478,130 @@ static int filter_step_impl(midas_ctx* ctx, const midas_codebook* cb, const mida
 }
 
 
+// ---- pipelined single-trajectory step ----------------------------------------------------------------
+static TailTables tables_of(double* t, int64_t N) {
+    const int64_t ng = ceil_div(N, SCAN_CHUNK), nb = ceil_div(N, SCAN_BLOCK);
+    TailTables tb;
+    tb.e = t; tb.x_raw = tb.e + N; tb.lp = tb.x_raw + N; tb.lp_raw = tb.lp + N;
+    tb.gend = tb.lp_raw + N; tb.gend_raw = tb.gend + ng;
+    tb.bsum_e = tb.gend_raw + ng; tb.btot = tb.bsum_e + nb; tb.btot_raw = tb.btot + nb; tb.bmax = tb.btot_raw + nb; tb.bmin = tb.bmax + nb;
+    return tb;
+}
+
+MIDAS_EXPORT int midas_lazy_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
+                                 const midas_lazy_args* args) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, cb && tree6 && tree3 && args && tree6->dim == 6 && tree3->dim == 3 && tree6->K == cb->K);
+    const midas_lazy_args& s = *args;
+    MIDAS_REQUIRE(ctx, s.N > 0 && ceil_div(s.N, SCAN_BLOCK) <= LAZY_MAX_BLOCKS && s.poses_prop_dev && s.nn_idx_dev && s.valid_dev &&
+                           s.status_dev && s.tables_dev && s.scores_dev && s.odom16_dev && s.code_dev);
+    MIDAS_REQUIRE(ctx, s.resample_prev ? (s.poses_prop_prev_dev && s.nn_idx_prev_dev && s.status_prev_dev &&
+                                          s.poses_prop_prev_dev != s.poses_prop_dev && s.nn_idx_prev_dev != s.nn_idx_dev &&
+                                          s.status_prev_dev != s.status_dev)
+                                       : (s.poses_in_dev && s.poses_in_dev != s.poses_prop_dev));
+    MIDAS_REQUIRE(ctx, (s.tn_dev == nullptr) == (s.rot_dev == nullptr));
+    MIDAS_REQUIRE(ctx, s.resample_mode == MIDAS_RESAMPLE_MULTINOMIAL || s.resample_mode == MIDAS_RESAMPLE_SYSTEMATIC);
+    const int64_t N = s.N;
+    const TailTables tb = tables_of(s.tables_dev, N);
+    ParticleUpdateArgs pa;
+    pa.N = N;
+    pa.poses_in = s.poses_in_dev;
+    pa.poses_prop = s.poses_prop_dev;
+    pa.odom16 = s.odom16_dev;
+    pa.tn = s.tn_dev;
+    pa.rot = s.rot_dev;
+    pa.std_t = s.std_t;
+    pa.std_r = s.std_r;
+    pa.seed = s.seed;
+    pa.step = s.step;
+    pa.hint_in = s.hint_in_dev;
+    pa.nn_idx = s.nn_idx_dev;
+    pa.scores = nullptr;
+    pa.valid = s.valid_dev;
+    pa.t2 = squared_threshold(s.prune_thr);
+    pa.thr = s.prune_thr;
+    pa.vlist = (tree6->vlist && tree6->vlist_mesh == tree3) ? (const MeshRec*)tree6->vlist : nullptr;
+    pa.telemetry = (unsigned long long*)s.telemetry_dev;
+    pa.status_reset = s.status_dev;
+    pa.gt16 = (s.gt16_dev && s.part_rmse_dev) ? s.gt16_dev : nullptr;
+    pa.part_rmse = s.part_rmse_dev;
+    if (s.resample_prev) {
+        LazyResample& r = pa.rs;
+        r.enabled = true;
+        r.e = tb.e; r.x_raw = tb.x_raw; r.lp = tb.lp; r.lp_raw = tb.lp_raw; r.gend = tb.gend; r.gend_raw = tb.gend_raw;
+        r.bsum_e = tb.bsum_e; r.btot = tb.btot; r.btot_raw = tb.btot_raw; r.bmax = tb.bmax; r.bmin = tb.bmin;
+        r.poses_prev = s.poses_prop_prev_dev; r.nn_prev = s.nn_idx_prev_dev; r.status_prev = s.status_prev_dev;
+        r.ridx_out = s.ridx_dev;
+        r.nb = (int)ceil_div(N, SCAN_BLOCK); r.ng = (int)ceil_div(N, SCAN_CHUNK);
+        r.softmax = s.softmax; r.mode = s.resample_mode; r.u = s.u_prev_dev; r.u32 = s.u32_prev;
+        r.seed = s.seed; r.step = s.step_prev;
+    }
+    if (ctx->prof && ctx->ev_ready) {
+        (void)hipEventRecord(ctx->ev[6], ctx->stream);
+        (void)hipEventRecord(ctx->ev[7], ctx->stream);
+    }
+    prof_mark(ctx, 1);
+    bool launched = false;
+    int rc;
+    if ((rc = launch_frame_front(ctx, tree6, tree3, pa, cb, s.code_dev, s.scores_dev, &launched))) return rc;
+    if (!launched)
+        return midas_set_error(ctx, MIDAS_ERR_INVALID, "codebook", "the pipelined step needs a float32 codebook with D in {128,256,512,1024}");
+    prof_mark(ctx, 2);
+    if ((rc = launch_tail_a2(ctx, N, s.scores_dev, s.nn_idx_dev, s.valid_dev, s.softmax, tb, s.status_dev))) return rc;
+    prof_mark(ctx, 3);
+    if (ctx->prof && ctx->ev_ready) {
+        const int lo = ctx->prof_only >= 0 ? ctx->prof_only : 1, hi = ctx->prof_only >= 0 ? ctx->prof_only + 1 : 3;
+        if (lo >= 1 && hi <= 3) {
+            MIDAS_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev[hi]));
+            for (int i = lo; i < hi; ++i) {
+                float ms = 0.f;
+                MIDAS_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
+                ctx->prof_ms[i] += (double)ms;
+            }
+        } else {
+            MIDAS_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev[7]));
+        }
+        float cal = 0.f;
+        MIDAS_HIP_CHECK(ctx, hipEventElapsedTime(&cal, ctx->ev[6], ctx->ev[7]));
+        ctx->prof_ms[7] += (double)cal;
+        ctx->prof_calls += 1;
+    }
+    return MIDAS_OK;
+}
+
+MIDAS_EXPORT int midas_lazy_flush(midas_ctx* ctx, const midas_lazy_flush_args* args) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, args != nullptr);
+    const midas_lazy_flush_args& s = *args;
+    MIDAS_REQUIRE(ctx, s.N > 0 && s.tables_dev && s.valid_dev && s.nn_idx_dev && s.poses_prop_dev && s.status_dev && s.weights_dev &&
+                           s.ridx_dev && s.poses_out_dev && s.weights_out_dev && s.hint_out_dev && s.poses_out_dev != s.poses_prop_dev);
+    MIDAS_REQUIRE(ctx, s.resample_mode == MIDAS_RESAMPLE_MULTINOMIAL || s.resample_mode == MIDAS_RESAMPLE_SYSTEMATIC);
+    const TailTables tb = tables_of(const_cast<double*>(s.tables_dev), s.N);
+    StepTailArgs ta;
+    ta.batch = 1;
+    ta.N = s.N;
+    ta.npart = 0;
+    ta.x = nullptr; ta.e = nullptr; ta.cdf = nullptr; ta.part_max = nullptr; ta.part_min = nullptr;
+    ta.valid = s.valid_dev;
+    ta.softmax = s.softmax;
+    ta.weights = s.weights_dev;
+    ta.status = s.status_dev;
+    ta.mode = s.resample_mode;
+    ta.u = s.u_dev;
+    ta.u32 = s.u32;
+    ta.seed = s.seed;
+    ta.step = s.step;
+    ta.ridx = s.ridx_dev;
+    ta.poses_prop = s.poses_prop_dev;
+    ta.poses_out = s.poses_out_dev;
+    ta.weights_out = s.weights_out_dev;
+    ta.nn_idx = s.nn_idx_dev;
+    ta.hint_out = s.hint_out_dev;
+    ta.part_rmse = (s.part_rmse_dev && s.rmse_dev) ? s.part_rmse_dev : nullptr;
+    ta.rmse_out = s.rmse_dev;
+    return launch_tail_b2(ctx, ta, tb);
+}
+
 // ---- particle-sharded step pieces -------------------------------------------------------------------
 MIDAS_EXPORT int midas_shard_front(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
                                    const midas_tree* tree3, const midas_shard_front_args* args) {

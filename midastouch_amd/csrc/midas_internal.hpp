@@ -151,6 +151,26 @@ int launch_nn3(midas_ctx* ctx, const midas_tree* t, int64_t N, const float* pose
 int launch_nn6_stats(midas_ctx* ctx, const midas_tree* t, int64_t N, const float* feat6, const int32_t* hint,
                      int32_t* leaves, int32_t* nodes);
 int launch_rmse(midas_ctx* ctx, int64_t N, const float* poses, const float* gt16, double* out2);
+// Resample of the PREVIOUS frame folded into the front kernel (k_frame_front): slot n of this frame is particle
+// src(n) of the previous one - a per-slot dependence - so the search and the gather of the resampler run as a
+// prologue of the particle update and the resampled poses never travel through HBM.  The tables are the ones
+// k_tail_a2 wrote for the previous frame; src is exactly what k_tail_b2 computes (same predicates).
+constexpr int LAZY_MAX_BLOCKS = 256;  // 1 M particles
+struct LazyResample {
+    bool enabled = false;
+    const double *e, *x_raw, *lp, *lp_raw, *gend, *gend_raw;       // [N] x4, [ng] x2
+    const double *bsum_e, *btot, *btot_raw, *bmax, *bmin;           // [nb] each
+    const float* poses_prev;                                         // [N x 16] propagated poses of the previous frame
+    const int32_t* nn_prev;                                          // [N]
+    const int32_t* status_prev;                                      // [2]
+    int32_t* ridx_out;                                               // nullable [N]
+    int nb, ng;
+    int32_t softmax, mode;
+    const double* u;                                                 // nullable: the previous frame's uniforms
+    float u32;
+    uint64_t seed, step;                                             // Philox key / counter of the previous frame's draws
+};
+
 struct ParticleUpdateArgs {
     int64_t N;
     const float* poses_in;
@@ -180,6 +200,7 @@ struct ParticleUpdateArgs {
     unsigned long long* telemetry = nullptr;  // nullable: cumulative [NN tree searches, mesh tree searches]
     int32_t* status_reset = nullptr;          // nullable: status[0..1] zeroed here for the tail kernels' atomics
     double* flags_reset = nullptr;            // nullable: two float64 counters zeroed here (sharded exchange record)
+    LazyResample rs;                          // fused front only
 };
 int particle_update_blocks(int64_t N);
 int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t3, const ParticleUpdateArgs& a,
@@ -227,6 +248,14 @@ struct StepTailArgs {
     double* lp_raw = nullptr;  // [N] scratch: block-local prefix of x*valid, likewise
 };
 int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base);
+// the deferred tail on explicit tables (what k_tail_a2 writes and k_tail_b2 / the lazy front read)
+struct TailTables {
+    double *e, *x_raw, *lp, *lp_raw, *gend, *gend_raw;       // [N] x4, [ceil(N/16)] x2
+    double *bsum_e, *btot, *btot_raw, *bmax, *bmin;           // [ceil(N/4096)] each
+};
+int launch_tail_a2(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
+                   int32_t softmax, const TailTables& tb, int32_t* status);
+int launch_tail_b2(midas_ctx* ctx, const StepTailArgs& a, const TailTables& tb);  // a.x, a.e, a.cdf, a.lp_raw unused
 int debug_tb2_clocks(long long* out16);
 int launch_tail_a(midas_ctx* ctx, int64_t N, const double* x, const uint8_t* valid, int np, int pstride,
                   const double* pmax_all, const double* pmin_all, int32_t softmax, double* e_io, double* lp_out,

@@ -1051,13 +1051,138 @@ __global__ __launch_bounds__(256) void k_rmse_final(int64_t N, int nb, const dou
     }
 }
 
+
+// ---- resample of the previous frame as a prologue of the particle update (LazyResample) -------------------------
+// Workgroup part: guard, sequential block prefix, exact cdf at the block ends into LDS (every thread of the
+// 256-thread workgroup takes part).  rs_lds: [0, nb) block prefix | [256, 256+nb) block ends | 512: total, 513: S,
+// 514: apply.  Same arithmetic as k_tail_b / k_tail_b2.
+constexpr double LAZY_ISCLOSE_ATOL = 1e-8;
+MD void lazy_tables(const LazyResample& rs, double* rs_lds) {
+    __shared__ double s_ex[12];
+    const int t = threadIdx.x;
+    const int b = t < rs.nb ? t : rs.nb - 1;  // nb <= 256: one block per thread, clamped loads
+    const double bt = rs.btot[b], btr = rs.btot_raw[b], bs = rs.bsum_e[b], bx = rs.bmax[b], bn = rs.bmin[b];
+    const bool in = t < rs.nb;
+    double mx = in ? bx : -INFINITY, mn = in ? bn : INFINITY;
+    const bool nan = in && ((bx != bx) || (bn != bn));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double a = __shfl_xor(mx, o), c = __shfl_xor(mn, o);
+        mx = a > mx ? a : mx;
+        mn = c < mn ? c : mn;
+    }
+    const bool wn = __any(nan);
+    if ((t & 63) == 0) { s_ex[t >> 6] = mx; s_ex[4 + (t >> 6)] = mn; s_ex[8 + (t >> 6)] = wn ? 1.0 : 0.0; }
+    __syncthreads();
+    mx = s_ex[0]; mn = s_ex[4];
+    double f = s_ex[8];
+    for (int w = 1; w < 4; ++w) { mx = s_ex[w] > mx ? s_ex[w] : mx; mn = s_ex[4 + w] < mn ? s_ex[4 + w] : mn; f += s_ex[8 + w]; }
+    if (f != 0.0) { mx = NAN; mn = NAN; }
+    const bool apply = rs.softmax && !(__builtin_fabs(mx - mn) <= LAZY_ISCLOSE_ATOL);
+    double* s_bp = rs_lds;
+    double* s_w = rs_lds + 256;
+    double* s_se = rs_lds + 516;
+    if (in) { s_w[t] = apply ? bt : btr; s_se[t] = bs; }
+    __syncthreads();
+    if (t == 0) {
+        double acc = 0.0, S = 0.0;
+        for (int i = 0; i < rs.nb; ++i) { s_bp[i] = acc; acc = acc + s_w[i]; S = S + s_se[i]; }
+        rs_lds[512] = acc;
+        rs_lds[513] = apply ? S : 1.0;
+        rs_lds[514] = apply ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    const double total = rs_lds[512];
+    // exact cdf at the last slot of every block: (BP_b + W_b) / total - the block total IS the block-local prefix at
+    // the block's last slot (same additions in the same order); the last block ends at N-1, forced to 1
+    const double wb = in ? s_w[t] : 0.0;
+    __syncthreads();
+    if (in) s_w[t] = (t == rs.nb - 1) ? 1.0 : (s_bp[t] + wb) / total;
+    __syncthreads();
+}
+
+// Per-lane part: the source particle of slot n (what k_tail_b2 writes to ridx[n]).
+MD int64_t lazy_source(const LazyResample& rs, const double* rs_lds, int64_t n, int64_t N) {
+    const double* s_bp = rs_lds;
+    const double* s_end = rs_lds + 256;
+    const double total = rs_lds[512];
+    const bool apply = rs_lds[514] != 0.0;
+    const bool bad_total = !(total == total) || total == 0.0;
+    if (rs.status_prev[0] != 0 || bad_total) return n;  // unusable weights: the resampler keeps the particles
+    const double* __restrict__ lp = apply ? rs.lp : rs.lp_raw;
+    const double* __restrict__ gend = apply ? rs.gend : rs.gend_raw;
+    double tq;
+    bool upper;
+    if (rs.mode == MIDAS_RESAMPLE_MULTINOMIAL) {
+        tq = rs.u ? rs.u[n] : philox_uniform53((uint64_t)n, rs.seed, rs.step);
+        upper = false;
+    } else {
+        const float r = rs.u32 >= 0.0f ? rs.u32 : philox_uniform24(rs.seed, rs.step);
+        const float off = r / (float)N;
+        tq = (double)n / (double)N + (double)off;
+        tq = tq >= 1.0 ? tq - 1.0 : tq;
+        upper = true;
+    }
+    const double tt = tq * total;
+    auto left = [&](double c) { return upper ? (c <= tt) : (c < tt); };
+    auto left_exact = [&](double c) { return upper ? (c <= tq) : (c < tq); };
+    // block: first b whose exact end value is not left of the draw
+    int lo = 0, hi = rs.nb;
+    while (hi > lo) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (left_exact(s_end[mid])) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= rs.nb) return N - 1;
+    const int64_t b_lo = (int64_t)lo << 12, b_hi = b_lo + SCAN_BLOCK < N ? b_lo + SCAN_BLOCK : N;
+    const double bp = s_bp[lo];
+    // chunk inside the block on the division-free comparison: 4-ary over the (at most 256) chunk ends
+    int64_t c_lo = b_lo >> 4, c_hi = (b_hi + SCAN_CHUNK - 1) >> 4;  // answer chunk in [c_lo, c_hi)
+    while (c_hi - c_lo >= 4) {
+        const int64_t q = (c_hi - c_lo) >> 2;
+        const int64_t m1 = c_lo + q, m2 = m1 + q, m3 = m2 + q;
+        const double g1 = gend[m1 - 1], g2 = gend[m2 - 1], g3 = gend[m3 - 1];  // end of the chunk BEFORE each pivot
+        const bool p1 = left(bp + g1), p2 = left(bp + g2), p3 = left(bp + g3);
+        if (p3) c_lo = m3;
+        else if (p2) { c_lo = m2; c_hi = m3; }
+        else if (p1) { c_lo = m1; c_hi = m2; }
+        else c_hi = m1;
+    }
+    while (c_hi - c_lo > 1) {
+        const int64_t mid = c_lo + ((c_hi - c_lo) >> 1);
+        if (left(bp + gend[mid - 1])) c_lo = mid; else c_hi = mid;
+    }
+    // the chunk's prefix values in one round trip; slot = number of them left of the draw; exact fix-up inside the block
+    const int64_t s0 = c_lo << 4;
+    double v[SCAN_CHUNK];
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) {
+        const int64_t sj = s0 + j;
+        v[j] = lp[sj < N ? sj : N - 1];
+    }
+    int pos = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) pos += (s0 + j < b_hi && left(bp + v[j])) ? 1 : 0;
+    int64_t l2 = s0 + pos;
+    if (l2 >= b_hi) l2 = b_hi - 1;
+    auto cdf = [&](int64_t i) { return (i == N - 1) ? 1.0 : (bp + lp[i]) / total; };
+    while (l2 > b_lo) {
+        if (left_exact(cdf(l2 - 1))) break;
+        --l2;
+    }
+    while (l2 < b_hi - 1) {
+        if (!left_exact(cdf(l2))) break;
+        ++l2;
+    }
+    return l2;
+}
+
 // =================================================================================================
 // fused particle update of the step
 // =================================================================================================
 // One wave = 64 consecutive particles of trajectory `traj`; `wave` counts the waves of that trajectory,
 // `nwaves` = waves per trajectory (strides of the per-wave partial arrays), s_cd = this wave's LDS columns.
 MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, ParticleUpdateArgs a, int64_t wave,
-                             int nwaves, int traj, double* s_cd) {
+                             int nwaves, int traj, double* s_cd, const double* rs_lds = nullptr) {
     const int lane = threadIdx.x & 63;
     if (traj) {  // batch of trajectories: every per-trajectory array is (B, ...) contiguous
         const int64_t b = traj, o = b * a.N;
@@ -1084,9 +1209,17 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
     float R[16], f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 16; ++i) R[i] = 0.f;
+    // source of the particle: its own slot, or - resample of the previous frame folded in - slot src of the previous
+    // frame's propagated poses
+    int64_t src = n;
+    if (rs_lds && live) {
+        src = lazy_source(a.rs, rs_lds, n, a.N);
+        if (a.rs.ridx_out) a.rs.ridx_out[n] = (int32_t)src;
+    }
+    const float* pose_src = rs_lds ? a.rs.poses_prev : a.poses_in;
     if (live) {
         float P[16], O[16];
-        load_pose(a.poses_in + n * 16, P);
+        load_pose(pose_src + src * 16, P);
 #pragma unroll
         for (int i = 0; i < 16; ++i) O[i] = a.odom16[i];
         propagate_one(n, n + a.slot_base, P, O, a.tn, a.rot, a.std_t, a.std_r, a.seed, a.step, R);
@@ -1097,7 +1230,7 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
     // nearest codebook entry
     int32_t bi = 0;
     float bd;
-    const int32_t hint = (live && a.hint_in) ? a.hint_in[n] : -1;
+    const int32_t hint = !live ? -1 : rs_lds ? a.rs.nn_prev[src] : a.hint_in ? a.hint_in[n] : -1;
     if (a.ablate & 1) {  // profiling only: trust the hint
         bi = hint < 0 ? 0 : hint;
     } else {
@@ -1191,10 +1324,12 @@ __global__ __launch_bounds__(256) void k_frame_front(TreeView<Kd6> t6, TreeView<
                                                      const double* __restrict__ norms, const double* __restrict__ code,
                                                      double* __restrict__ scores, int64_t K) {
     __shared__ double s_cd[4][KD_MAX_LEVELS * 64];
+    __shared__ double s_rs[3 * LAZY_MAX_BLOCKS + 8];
     const int w = threadIdx.x >> 6;
     if ((int)blockIdx.x < n_pu) {
+        if (a.rs.enabled) lazy_tables(a.rs, s_rs);  // uniform over the launch
         const int64_t wave = (int64_t)blockIdx.x * 4 + w;
-        if (wave < nwaves) particle_update_wave(t6, t3, a, wave, nwaves, 0, s_cd[w]);
+        if (wave < nwaves) particle_update_wave(t6, t3, a, wave, nwaves, 0, s_cd[w], a.rs.enabled ? s_rs : nullptr);
     } else {
         score_wave<T, NJ, 0>(emb, norms, code, scores, K, (int64_t)(blockIdx.x - n_pu) * 4 + w);
     }

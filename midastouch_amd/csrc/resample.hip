@@ -1245,6 +1245,39 @@ int launch_tail_resample(midas_ctx* ctx, const midas_tail_resample_args& r) {
 int debug_tb2_clocks(long long* out16) { return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_tb2_clk), 16 * sizeof(long long)) == hipSuccess ? 0 : 1; }
 #endif
 
+int launch_tail_a2(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
+                   int32_t softmax, const TailTables& tb, int32_t* status) {
+    const int nb = (int)ceil_div(N, SCAN_BLOCK);
+    hipLaunchKernelGGL(k_tail_a2, dim3((unsigned)nb), dim3(256), 0, ctx->stream, N, scores, nn_idx, valid, softmax, tb.e, tb.x_raw,
+                       tb.lp, tb.lp_raw, tb.gend, tb.gend_raw, tb.bsum_e, tb.btot, tb.btot_raw, tb.bmax, tb.bmin, status, nullptr);
+    LAUNCH_CHECK(ctx);
+    return MIDAS_OK;
+}
+
+int launch_tail_b2(midas_ctx* ctx, const StepTailArgs& a, const TailTables& tb) {
+    const int nb = (int)ceil_div(a.N, SCAN_BLOCK), ng = (int)ceil_div(a.N, SCAN_CHUNK);
+    if (nb > TB_MAX_BLOCKS) return midas_set_error(ctx, MIDAS_ERR_INVALID, "N", "more than 4 M particles per GPU: shard them");
+    // every workgroup of TB2 loads the table: keep it whole (one entry per chunk) while that is cheap, coarser
+    // for large N where (N / 256 workgroups) x table bytes would dominate
+    static const int tab_env = getenv("MIDAS_TB2_TAB") ? atoi(getenv("MIDAS_TB2_TAB")) : 0;
+    const int tab_cap = tab_env > 0 ? (tab_env < TB2_TAB ? tab_env : TB2_TAB) : (ng <= TB2_TAB ? TB2_TAB : (ng <= 4 * TB2_TAB ? 2048 : 1024));  // measured at N = 300k / 1M
+    int cshift = 0;
+    while (ceil_div((int64_t)ng, (int64_t)1 << cshift) > tab_cap) ++cshift;
+    const int nt = (int)ceil_div((int64_t)ng, (int64_t)1 << cshift);
+    TailB2Args b;
+    b.N = a.N; b.nb = nb; b.ng = ng; b.nt = nt; b.cshift = cshift;
+    b.e = tb.e; b.x_raw = tb.x_raw; b.lp = tb.lp; b.lp_raw = tb.lp_raw; b.gend = tb.gend; b.gend_raw = tb.gend_raw;
+    b.bsum_e = tb.bsum_e; b.btot = tb.btot; b.btot_raw = tb.btot_raw; b.bmax = tb.bmax; b.bmin = tb.bmin;
+    b.valid = a.valid; b.softmax = a.softmax; b.status = a.status; b.weights = a.weights; b.mode = a.mode;
+    b.u = a.u; b.u32 = a.u32; b.seed = a.seed; b.step = a.step; b.ridx = a.ridx; b.poses_prop = a.poses_prop;
+    b.poses_out = a.poses_out; b.weights_out = a.weights_out; b.nn_idx = a.nn_idx; b.hint_out = a.hint_out;
+    b.part_rmse = a.part_rmse; b.nrm = a.part_rmse ? particle_update_blocks(a.N) : 0; b.rmse_out = a.rmse_out;
+    hipLaunchKernelGGL(k_tail_b2, dim3((unsigned)ceil_div(a.N, 256)), dim3(256), (size_t)(nt + 3 * nb) * sizeof(double),
+                       ctx->stream, b);
+    LAUNCH_CHECK(ctx);
+    return MIDAS_OK;
+}
+
 int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base) {
     const int nb = (int)ceil_div(a.N, SCAN_BLOCK);
     if (nb > TB_MAX_BLOCKS) return midas_set_error(ctx, MIDAS_ERR_INVALID, "N", "more than 4 M particles per GPU: shard them");
@@ -1258,35 +1291,16 @@ int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base) 
     int32_t* flag = (int32_t*)(pw + (size_t)B * nb);
     if (!a.x) {  // deferred mode (single trajectory)
         const int ng = (int)ceil_div(a.N, SCAN_CHUNK);
-        // every workgroup of TB2 loads the table: keep it whole (one entry per chunk) while that is cheap, coarser
-        // for large N where (N / 256 workgroups) x table bytes would dominate
-        static const int tab_env = getenv("MIDAS_TB2_TAB") ? atoi(getenv("MIDAS_TB2_TAB")) : 0;
-        const int tab_cap = tab_env > 0 ? (tab_env < TB2_TAB ? tab_env : TB2_TAB) : (ng <= TB2_TAB ? TB2_TAB : (ng <= 4 * TB2_TAB ? 2048 : 1024));  // measured at N = 300k / 1M
-        int cshift = 0;
-        while (ceil_div((int64_t)ng, (int64_t)1 << cshift) > tab_cap) ++cshift;
-        const int nt = (int)ceil_div((int64_t)ng, (int64_t)1 << cshift);
         void* sc2;
         if ((rc = midas_scratch(ctx, ((size_t)nb * 3 + (size_t)ng * 2) * sizeof(double), &sc2))) return rc;
-        double* praw = (double*)sc2;
-        double* bmax = praw + nb;
-        double* bmin = bmax + nb;
-        double* gend = bmin + nb;
-        double* gend_raw = gend + ng;
-        hipLaunchKernelGGL(k_tail_a2, dim3((unsigned)nb), dim3(256), 0, ctx->stream, a.N, a.scores, a.nn_idx, a.valid, a.softmax,
-                           e, a.x_raw, a.cdf, a.lp_raw, gend, gend_raw, psum, pw, praw, bmax, bmin, a.status, nullptr);
-        LAUNCH_CHECK(ctx);
+        TailTables tb;
+        tb.e = e; tb.x_raw = a.x_raw; tb.lp = a.cdf; tb.lp_raw = a.lp_raw;
+        tb.bsum_e = psum; tb.btot = pw;
+        tb.btot_raw = (double*)sc2; tb.bmax = tb.btot_raw + nb; tb.bmin = tb.bmax + nb;
+        tb.gend = tb.bmin + nb; tb.gend_raw = tb.gend + ng;
+        if ((rc = launch_tail_a2(ctx, a.N, a.scores, a.nn_idx, a.valid, a.softmax, tb, a.status))) return rc;
         prof_mark(ctx, prof_slot_base + 1);
-        TailB2Args b;
-        b.N = a.N; b.nb = nb; b.ng = ng; b.nt = nt; b.cshift = cshift;
-        b.e = e; b.x_raw = a.x_raw; b.lp = a.cdf; b.lp_raw = a.lp_raw; b.gend = gend; b.gend_raw = gend_raw;
-        b.bsum_e = psum; b.btot = pw; b.btot_raw = praw; b.bmax = bmax; b.bmin = bmin;
-        b.valid = a.valid; b.softmax = a.softmax; b.status = a.status; b.weights = a.weights; b.mode = a.mode;
-        b.u = a.u; b.u32 = a.u32; b.seed = a.seed; b.step = a.step; b.ridx = a.ridx; b.poses_prop = a.poses_prop;
-        b.poses_out = a.poses_out; b.weights_out = a.weights_out; b.nn_idx = a.nn_idx; b.hint_out = a.hint_out;
-        b.part_rmse = a.part_rmse; b.nrm = a.part_rmse ? particle_update_blocks(a.N) : 0; b.rmse_out = a.rmse_out;
-        hipLaunchKernelGGL(k_tail_b2, dim3((unsigned)ceil_div(a.N, 256)), dim3(256), (size_t)(nt + 3 * nb) * sizeof(double),
-                           ctx->stream, b);
-        LAUNCH_CHECK(ctx);
+        if ((rc = launch_tail_b2(ctx, a, tb))) return rc;
         prof_mark(ctx, prof_slot_base + 2);
         return MIDAS_OK;
     }

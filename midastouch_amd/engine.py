@@ -17,7 +17,7 @@ import ctypes as C
 import torch
 
 from . import _lib, ops
-from ._lib import MidasError, StepArgs, _ptr
+from ._lib import LazyArgs, LazyFlushArgs, MidasError, StepArgs, _ptr
 
 
 class FilterEngine:
@@ -112,6 +112,145 @@ class FilterEngine:
         self.ctx.call("midas_profile_read", ms, C.byref(calls), int(reset))
         names = [self.ctx.lib.midas_profile_slot_name(i).decode() for i in range(_lib.PROF_SLOTS)]
         return {n: ms[i] for i, n in enumerate(names) if n}, calls.value
+
+
+def _materialised(name):
+    """Attribute that belongs to the resampled particle set: reading it materialises a pending resample first."""
+
+    def get(self):
+        self.flush()
+        return getattr(self, "_" + name)
+
+    def put(self, value):
+        setattr(self, "_" + name, value)
+
+    return property(get, put)
+
+
+class PipelinedFilterEngine(FilterEngine):
+    """FilterEngine with the resample of frame t folded into the front kernel of frame t+1 (midas_lazy_step).
+
+    Slot n of the next frame is particle src(n) of this one, a per-slot dependence: the resampler's search and
+    gather run as a prologue of the next particle update, the resampled poses never travel through HBM and a
+    frame is two launches instead of three.  The resampled particle set of the latest frame therefore exists only
+    implicitly (tables + draws) until somebody reads it: `poses`, `weights`, `weights_res`, `hint`, `ridx`, `status`
+    and `rmse` materialise it on access (`flush()`, the same kernel as the eager engine's tail - bit-identical
+    results); `nn_idx` and `poses_prop` of the latest frame are always there.  A caller that looks at the particles
+    every frame gets the eager engine's launches; one that only steps gets the pipelined ones.
+    Needs a float32 codebook with D in {128, 256, 512, 1024} and N <= 1 M (MidasError otherwise: use FilterEngine).
+    """
+
+    poses = _materialised("poses")
+    weights = _materialised("weights")
+    weights_res = _materialised("weights_res")
+    hint = _materialised("hint")
+    ridx = _materialised("ridx")
+    rmse = _materialised("rmse")
+
+    def __init__(self, *args, **kw):
+        self._pending = False
+        self._flushed = True
+        super().__init__(*args, **kw)
+        N, dev = self.N, self.device
+        if self.codebook.emb.dtype != torch.float32 or self.D not in (128, 256, 512, 1024) or N > (1 << 20):
+            raise MidasError("PipelinedFilterEngine needs a float32 codebook with D in {128,256,512,1024} and N <= 2^20")
+        f64 = dict(dtype=torch.float64, device=dev)
+        self._prop = [self.poses_prop, torch.zeros_like(self.poses_prop)]
+        self._nn = [self.nn_idx, torch.zeros_like(self.nn_idx)]
+        self._st = [torch.zeros(2, dtype=torch.int32, device=dev) for _ in range(2)]
+        self._valid = torch.zeros(N, dtype=torch.uint8, device=dev)
+        ng, nb = (N + 15) // 16, (N + 4095) // 4096
+        self._tables = torch.zeros(4 * N + 2 * ng + 5 * nb, **f64)
+        self._scores = torch.zeros(self.K, **f64)
+        self._part_rmse = torch.zeros(2 * ((N + 63) // 64), **f64)
+        self._cur = 0
+        self._draw = (None, -1.0, 0)
+        self._had_gt = False
+
+    # the latest frame's own outputs
+    @property
+    def status(self):
+        self.flush()
+        return self._st[self._cur]
+
+    @status.setter
+    def status(self, v):
+        pass  # the base constructor's tensor is not used
+
+    @property
+    def nn_idx(self):
+        return self._nn[self._cur] if hasattr(self, "_nn") else self._nn0
+
+    @nn_idx.setter
+    def nn_idx(self, v):
+        self._nn0 = v
+
+    @property
+    def poses_prop(self):
+        return self._prop[self._cur] if hasattr(self, "_prop") else self._prop0
+
+    @poses_prop.setter
+    def poses_prop(self, v):
+        self._prop0 = v
+
+    def set_particles(self, poses):
+        self._pending, self._flushed = False, True
+        super().set_particles(poses)
+
+    def project_to_codebook(self):
+        self.flush()
+        return super().project_to_codebook()
+
+    def step(self, odom, code, gt=None, tn=None, rot=None, u=None, u32=-1.0, multiplier: float = 1.0):
+        cur, nxt = self._cur, self._cur ^ 1
+        fold = self._pending and not self._flushed
+        a = LazyArgs()
+        a.N = self.N
+        a.poses_prop_prev, a.nn_idx_prev, a.status_prev = _ptr(self._prop[cur]), _ptr(self._nn[cur]), _ptr(self._st[cur])
+        a.poses_prop, a.nn_idx, a.valid, a.status = _ptr(self._prop[nxt]), _ptr(self._nn[nxt]), _ptr(self._valid), _ptr(self._st[nxt])
+        a.tables, a.scores = _ptr(self._tables), _ptr(self._scores)
+        a.part_rmse = _ptr(self._part_rmse) if gt is not None else None
+        a.resample_prev = int(fold)
+        a.poses_in = _ptr(self._poses)
+        a.hint_in = _ptr(self._hint) if self.use_hint else None
+        pu, pu32, pstep = self._draw
+        a.resample_mode, a.u_prev, a.u32_prev, a.step_prev = self.mode, _ptr(pu), float(pu32), int(pstep)
+        a.ridx = _ptr(self._ridx) if fold else None
+        a.odom16, a.code, a.gt16 = _ptr(odom), _ptr(code), _ptr(gt)
+        a.tn, a.rot = _ptr(tn), _ptr(rot)
+        mul = max(float(multiplier), 1.0)
+        a.std_t, a.std_r = mul * self.sig_t, mul * self.sig_r
+        a.seed, a.step = self.seed, self.step_count
+        a.prune_thr, a.softmax = self.pen_max, int(self.softmax)
+        a.telemetry = _ptr(self.telemetry)
+        self._keep = (odom, code, gt, tn, rot, pu)
+        self.ctx.bind_current_stream()
+        self.ctx.check(self.ctx.lib.midas_lazy_step(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h, C.byref(a)))
+        # this frame's resample draws, consumed by the next step or by flush()
+        self._draw = (None if u is None else u.to(self.device, torch.float64).clone(), float(u32), self.step_count)
+        self._had_gt = gt is not None
+        self._pending, self._flushed, self._cur = True, False, nxt
+        self.step_count += 1
+
+    def flush(self):
+        """Materialise the latest frame's resample (poses, weights, weights_res, hint, ridx, status, rmse)."""
+        if not self._pending or self._flushed:
+            return
+        cur = self._cur
+        u, u32, stp = self._draw
+        a = LazyFlushArgs()
+        a.N = self.N
+        a.tables, a.valid, a.nn_idx, a.poses_prop = _ptr(self._tables), _ptr(self._valid), _ptr(self._nn[cur]), _ptr(self._prop[cur])
+        a.status = _ptr(self._st[cur])
+        a.part_rmse = _ptr(self._part_rmse) if self._had_gt else None
+        a.softmax, a.resample_mode, a.u, a.u32 = int(self.softmax), self.mode, _ptr(u), float(u32)
+        a.seed, a.step = self.seed, int(stp)
+        a.weights, a.ridx, a.poses_out = _ptr(self._weights), _ptr(self._ridx), _ptr(self._poses)
+        a.weights_out, a.hint_out = _ptr(self._weights_res), _ptr(self._hint)
+        a.rmse = _ptr(self._rmse) if self._had_gt else None
+        self.ctx.bind_current_stream()
+        self.ctx.check(self.ctx.lib.midas_lazy_flush(self.ctx.h, C.byref(a)))
+        self._flushed = True
 
 
 class BatchFilterEngine:

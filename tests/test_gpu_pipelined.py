@@ -1,0 +1,123 @@
+"""PipelinedFilterEngine (midas_lazy_step / midas_lazy_flush): the resample of frame t runs inside the front kernel of
+frame t+1.  Same parity bar as the eager step: NN indices, propagated poses, resample indices and resampled poses
+bit-identical to the oracle, weights within 1e-12 relative - whether or not the particle set is materialised
+(read) between frames.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda", 0)
+
+
+def _setup(N, K, D, seed):
+    from midastouch_amd.synthetic import make_codebook, make_trajectory
+    cb = make_codebook("004_sugar_box", K=K, D=D, seed=1000 + seed)
+    traj = make_trajectory(cb, T=24, seed=2000 + seed)
+    return cb, traj
+
+
+@pytest.mark.parametrize("mode", ["weighted_random", "low_var"])
+@pytest.mark.parametrize("read_every", [1, 4, 100])
+def test_pipelined_parity_device_draws(dev, oracle, mode, read_every):
+    from midastouch_amd.engine import PipelinedFilterEngine
+    N, K, D = 9000, 3000, 256   # three summation blocks, ragged
+    cb, traj = _setup(N, K, D, 7)
+    ofl = oracle.OracleFilter(cb.poses, cb.embeddings, cb.mesh_vertices)
+    eng = PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4400, resample=mode, device=dev)
+    rng = np.random.default_rng(12)
+    poses = cb.poses[rng.integers(0, K, N)]
+    eng.set_particles(torch.as_tensor(poses))
+    prev = None
+    for t in range(1, 14):
+        tn, rot = oracle.philox_noise(N, 4400, t - 1, np.float32(2e-4), np.float32(0.5))
+        if mode == "weighted_random":
+            ref = ofl.step(poses, traj.odoms[t], traj.codes[t], tn, rot, u=oracle.philox_uniform64(N, 4400, t - 1))
+        else:
+            ref = ofl.step(poses, traj.odoms[t], traj.codes[t], tn, rot, mode="low_var", u32=oracle.philox_uniform32(4400, t - 1))
+        folded = eng._pending and not eng._flushed
+        eng.step(torch.as_tensor(traj.odoms[t]).to(dev), torch.as_tensor(traj.codes[t]).to(dev),
+                 gt=torch.as_tensor(traj.gt_poses[t]).to(dev))
+        # always there, no materialisation
+        assert np.array_equal(eng.poses_prop.cpu().numpy(), ref["poses_prop"]), f"frame {t}: propagated poses"
+        assert np.array_equal(eng.nn_idx.cpu().numpy(), ref["nn_idx"]), f"frame {t}: NN index"
+        assert not eng._flushed
+        if folded:  # the folded resample reports the previous frame's indices
+            assert np.array_equal(eng._ridx.cpu().numpy(), prev["ridx"]), f"frame {t}: folded resample indices"
+        if t % read_every == 0:
+            assert np.array_equal(eng.ridx.cpu().numpy(), ref["ridx"]), f"frame {t}: resample indices"
+            assert eng._flushed
+            assert np.array_equal(eng.poses.cpu().numpy(), ref["poses"]), f"frame {t}: resampled poses"
+            w = eng.weights.cpu().numpy()
+            assert np.array_equal(w == 0, ref["weights"] == 0)
+            np.testing.assert_allclose(w, ref["weights"], rtol=1e-12, atol=0)
+            np.testing.assert_allclose(eng.weights_res.cpu().numpy(), ref["weights_res"], rtol=1e-12)
+            assert np.array_equal(eng.hint.cpu().numpy(), ref["nn_idx_res"])
+            st = eng.status.cpu().numpy()
+            assert st[0] == ref["status"] and st[1] == int(ref["mask"].sum())
+            rt, rr = oracle.particle_rmse(ref["poses_prop"], traj.gt_poses[t])
+            rm = eng.rmse.cpu().numpy()
+            assert rm[0] == pytest.approx(rt, rel=1e-9) and rm[1] == pytest.approx(rr, rel=1e-4, abs=0.03)
+        poses, prev = ref["poses"], ref
+    assert np.array_equal(eng.poses.cpu().numpy(), poses)  # final materialisation
+
+
+def test_pipelined_parity_host_draws(dev, oracle):
+    """Parity mode: the reference's host draws; the uniforms of frame t are consumed by the NEXT call."""
+    from midastouch_amd.engine import PipelinedFilterEngine
+    N, K, D = 5000, 2500, 128
+    cb, traj = _setup(N, K, D, 8)
+    ofl = oracle.OracleFilter(cb.poses, cb.embeddings, cb.mesh_vertices)
+    eng = PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, device=dev)
+    rng = np.random.default_rng(13)
+    poses = cb.poses[rng.integers(0, K, N)]
+    eng.set_particles(torch.as_tensor(poses))
+    for t in range(1, 9):
+        torch.manual_seed(3100 + t)
+        tn = torch.normal(mean=0.0, std=2e-4, size=(N, 3))
+        rot = torch.normal(mean=0.0, std=0.5, size=(N, 3))
+        u = torch.rand(N, dtype=torch.float64)
+        ref = ofl.step(poses, traj.odoms[t], traj.codes[t], tn.numpy(), rot.numpy(), u=u.numpy())
+        ud = u.to(dev)
+        eng.step(torch.as_tensor(traj.odoms[t]).to(dev), torch.as_tensor(traj.codes[t]).to(dev), tn=tn.to(dev), rot=rot.to(dev), u=ud)
+        ud.zero_()  # the engine must have kept its own copy
+        assert np.array_equal(eng.nn_idx.cpu().numpy(), ref["nn_idx"]), f"frame {t}"
+        poses = ref["poses"]
+    assert np.array_equal(eng.ridx.cpu().numpy(), ref["ridx"])
+    assert np.array_equal(eng.poses.cpu().numpy(), poses)
+
+
+def test_pipelined_equals_eager_full_size(dev):
+    """c2 sizes: twelve frames, pipelined without reads vs eager - identical particles at the end."""
+    from midastouch_amd.engine import FilterEngine, PipelinedFilterEngine
+    N, K, D = 100_000, 50_000, 512
+    cb, traj = _setup(N, K, D, 9)
+    rng = np.random.default_rng(14)
+    d0 = np.linalg.norm(cb.poses[:, :3, 3] - traj.gt_poses[0][:3, 3], axis=1)
+    start = torch.as_tensor(cb.poses[rng.choice(np.argsort(d0)[:2500], N)])
+    od, co = torch.as_tensor(traj.odoms).to(dev), torch.as_tensor(traj.codes).to(dev)
+    outs = []
+    for cls in (FilterEngine, PipelinedFilterEngine):
+        eng = cls(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4500, device=dev)
+        eng.set_particles(start)
+        eng.project_to_codebook()
+        for t in range(1, 13):
+            eng.step(od[t], co[t])
+        outs.append((eng.poses.cpu().numpy(), eng.ridx.cpu().numpy(), eng.weights.cpu().numpy(), eng.status.cpu().numpy()))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
+def test_pipelined_rejects_unsupported_layout(dev):
+    from midastouch_amd._lib import MidasError
+    from midastouch_amd.engine import PipelinedFilterEngine
+    cb, traj = _setup(512, 600, 96, 10)
+    with pytest.raises(MidasError):
+        PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, 512, device=dev)
