@@ -198,7 +198,8 @@ typedef struct midas_lazy_args {
     int32_t* nn_idx_dev;               /* N out */
     uint8_t* valid_dev;                /* N out */
     int32_t* status_dev;               /* 2 out: [0] = 2 on NaN weights, [1] = particles kept by the prune */
-    double* tables_dev;                /* 4 N + 2 ceil(N/16) + 5 ceil(N/4096) doubles: on entry the previous frame's softmax /
+    double* tables_dev;                /* 128-byte aligned, 4 N16 + 2 G16 + 37 ceil(N/4096) doubles with N16 = N and G16 = ceil(N/16),
+                                        * each rounded up to a multiple of 16: on entry the previous frame's softmax /
                                         * CDF tables (read when resample_prev), on exit this frame's */
     double* scores_dev;                /* K: this frame's codebook scores */
     double* part_rmse_dev;             /* NULL or 2 ceil(N/64): per-wave rmse sums of this frame (gt16_dev) */

@@ -479,12 +479,16 @@ static int filter_step_impl(midas_ctx* ctx, const midas_codebook* cb, const mida
 
 
 // ---- pipelined single-trajectory step ----------------------------------------------------------------
+// Layout of the caller's table block (doubles).  The per-slot and per-chunk arrays are padded to multiples of 16 so
+// that the lazy front may fetch whole 16-value lines with aligned 16-byte loads (values past the data are ignored).
 static TailTables tables_of(double* t, int64_t N) {
     const int64_t ng = ceil_div(N, SCAN_CHUNK), nb = ceil_div(N, SCAN_BLOCK);
+    const int64_t Np = ceil_div(N, 16) * 16, ngp = ceil_div(ng, 16) * 16;
     TailTables tb;
-    tb.e = t; tb.x_raw = tb.e + N; tb.lp = tb.x_raw + N; tb.lp_raw = tb.lp + N;
-    tb.gend = tb.lp_raw + N; tb.gend_raw = tb.gend + ng;
-    tb.bsum_e = tb.gend_raw + ng; tb.btot = tb.bsum_e + nb; tb.btot_raw = tb.btot + nb; tb.bmax = tb.btot_raw + nb; tb.bmin = tb.bmax + nb;
+    tb.e = t; tb.x_raw = tb.e + Np; tb.lp = tb.x_raw + Np; tb.lp_raw = tb.lp + Np;
+    tb.gend = tb.lp_raw + Np; tb.gend_raw = tb.gend + ngp;
+    tb.ggend = tb.gend_raw + ngp; tb.ggend_raw = tb.ggend + 16 * nb;
+    tb.bsum_e = tb.ggend_raw + 16 * nb; tb.btot = tb.bsum_e + nb; tb.btot_raw = tb.btot + nb; tb.bmax = tb.btot_raw + nb; tb.bmin = tb.bmax + nb;
     return tb;
 }
 
@@ -494,7 +498,7 @@ MIDAS_EXPORT int midas_lazy_step(midas_ctx* ctx, const midas_codebook* cb, const
     MIDAS_REQUIRE(ctx, cb && tree6 && tree3 && args && tree6->dim == 6 && tree3->dim == 3 && tree6->K == cb->K);
     const midas_lazy_args& s = *args;
     MIDAS_REQUIRE(ctx, s.N > 0 && ceil_div(s.N, SCAN_BLOCK) <= LAZY_MAX_BLOCKS && s.poses_prop_dev && s.nn_idx_dev && s.valid_dev &&
-                           s.status_dev && s.tables_dev && s.scores_dev && s.odom16_dev && s.code_dev);
+                           s.status_dev && s.tables_dev && (uintptr_t)s.tables_dev % 128 == 0 && s.scores_dev && s.odom16_dev && s.code_dev);
     MIDAS_REQUIRE(ctx, s.resample_prev ? (s.poses_prop_prev_dev && s.nn_idx_prev_dev && s.status_prev_dev &&
                                           s.poses_prop_prev_dev != s.poses_prop_dev && s.nn_idx_prev_dev != s.nn_idx_dev &&
                                           s.status_prev_dev != s.status_dev)
@@ -529,6 +533,7 @@ MIDAS_EXPORT int midas_lazy_step(midas_ctx* ctx, const midas_codebook* cb, const
         LazyResample& r = pa.rs;
         r.enabled = true;
         r.e = tb.e; r.x_raw = tb.x_raw; r.lp = tb.lp; r.lp_raw = tb.lp_raw; r.gend = tb.gend; r.gend_raw = tb.gend_raw;
+        r.ggend = tb.ggend; r.ggend_raw = tb.ggend_raw;
         r.bsum_e = tb.bsum_e; r.btot = tb.btot; r.btot_raw = tb.btot_raw; r.bmax = tb.bmax; r.bmin = tb.bmin;
         r.poses_prev = s.poses_prop_prev_dev; r.nn_prev = s.nn_idx_prev_dev; r.status_prev = s.status_prev_dev;
         r.ridx_out = s.ridx_dev;

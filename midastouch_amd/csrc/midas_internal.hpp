@@ -159,6 +159,7 @@ constexpr int LAZY_MAX_BLOCKS = 256;  // 1 M particles
 struct LazyResample {
     bool enabled = false;
     const double *e, *x_raw, *lp, *lp_raw, *gend, *gend_raw;       // [N] x4, [ng] x2
+    const double *ggend, *ggend_raw;                                // [16 nb] x2
     const double *bsum_e, *btot, *btot_raw, *bmax, *bmin;           // [nb] each
     const float* poses_prev;                                         // [N x 16] propagated poses of the previous frame
     const int32_t* nn_prev;                                          // [N]
@@ -252,6 +253,7 @@ int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base);
 struct TailTables {
     double *e, *x_raw, *lp, *lp_raw, *gend, *gend_raw;       // [N] x4, [ceil(N/16)] x2
     double *bsum_e, *btot, *btot_raw, *bmax, *bmin;           // [ceil(N/4096)] each
+    double *ggend, *ggend_raw;                                // [16 ceil(N/4096)]: block-local prefix at the end of each 256-slot group
 };
 int launch_tail_a2(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
                    int32_t softmax, const TailTables& tb, int32_t* status);

@@ -675,59 +675,97 @@ MD bool coop_scan_list(const TreeView<Kd6>& tv, const float* qq, int h, int firs
 }
 
 // serve the lanes in `need`: continue their hint scan after the solo records, then try the twin entry.
-// Owners are taken COOP_G at a time so that their first chunks (records NN_SOLO .. NN_SOLO+63, which decide
-// almost all of them) travel in one round trip; r = |q - F_h| comes from the owner lane (no header fetch).
-constexpr int COOP_G = 4;
+// minimum over a 16-lane row of (d, idx), ties to the smaller idx; every lane of the row gets the result
+MD void row_best(float& d, int& i) {
+#define MIDAS_STEP(CTRL)                                                              \
+    {                                                                                 \
+        const float od = __uint_as_float(dpp_u32<CTRL>(__float_as_uint(d)));          \
+        const int oi = (int)dpp_u32<CTRL>((uint32_t)i);                                \
+        if (od < d || (od == d && oi < i)) { d = od; i = oi; }                         \
+    }
+    MIDAS_STEP(DPP_XOR1) MIDAS_STEP(DPP_XOR2) MIDAS_STEP(DPP_HALF_MIRROR) MIDAS_STEP(0x140 /* row_mirror */)
+#undef MIDAS_STEP
+}
+
+// Four owners at a time, one per 16-lane row: the row walks records NN_SOLO .. NN_SOLO+63 of its owner's list in four
+// steps of 16 (all eight loads per lane in flight together) and reduces inside the row with DPP - the four owners are
+// evaluated by the same instructions, where the whole-wave form spent them once per owner.  The certificate is the
+// one of the 64-record chunk (its last record's rho against the final best); an owner it does not settle continues
+// with the whole-wave chunks and the twin entry.
 MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_lane, float& best, int64_t& bi, bool need,
                  bool& done) {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, row = lane >> 4, j = lane & 15;
     unsigned long long todo = __ballot(need);
+    const int my_rank = (int)__builtin_popcountll(todo & ((1ull << lane) - 1ull));  // rank of this lane among the owners
+    int served = 0;                                                                  // owners handled so far
     while (todo) {
-        int owner[COOP_G], hh[COOP_G];
-        Nbr6 e[COOP_G];
+        int owner[4];
 #pragma unroll
-        for (int g = 0; g < COOP_G; ++g) {
-            owner[g] = todo ? (int)__builtin_ctzll(todo) : -1;
+        for (int k = 0; k < 4; ++k) {
+            owner[k] = todo ? (int)__builtin_ctzll(todo) : -1;
             todo &= todo - 1;  // 0 & anything stays 0
-            if (owner[g] >= 0) {
-                hh[g] = rl_i32(hint, owner[g]);
-                e[g] = tv.nbrs[(size_t)hh[g] * NBR_REC + NN_SOLO + lane];
-            }
         }
+        const int mine = row == 0 ? owner[0] : row == 1 ? owner[1] : row == 2 ? owner[2] : owner[3];
+        const int src = mine >= 0 ? mine : lane;
+        float qq[6];
 #pragma unroll
-        for (int g = 0; g < COOP_G; ++g) {
-            if (owner[g] < 0) continue;
-            float qq[6];
+        for (int d = 0; d < 6; ++d) qq[d] = __shfl(q[d], src);
+        const float rr = __shfl(r_lane, src);
+        float bb = __shfl(best, src);
+        int b_i = __shfl((int)bi, src);
+        const int hh = __shfl(hint, src);
+        const Nbr6* nb = tv.nbrs + (size_t)(mine >= 0 ? hh : 0) * NBR_REC + NN_SOLO + j;
+        Nbr6 e[4];
 #pragma unroll
-            for (int d = 0; d < 6; ++d) qq[d] = rl_f32(q[d], owner[g]);
-            const float rr = rl_f32(r_lane, owner[g]);
-            float bb = rl_f32(best, owner[g]);
-            int b_i = rl_i32((int)bi, owner[g]);
+        for (int m = 0; m < 4; ++m) e[m] = nb[16 * m];
+        float d = INFINITY;
+        int id = 0x7fffffff;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
             Point6 p;
 #pragma unroll
-            for (int a = 0; a < 6; ++a) p.c[a] = e[g].c[a];
-            float d = dist2(qq, p);
-            if (!(d == d)) d = INFINITY;
-            int id = e[g].idx;
-            wave_best(d, id);
-            if (d < bb || (d == bb && id < b_i)) { bb = d; b_i = id; }
-            const float gg = fmaf_(rl_f32(e[g].rho, 63) - rr, 0.9999996f, -8e-7f * rr);
-            bool cert = gg > 0.0f && gg * gg * 0.99997f > bb;
-            if (!cert) {
-                cert = coop_scan_list(tv, qq, hh[g], NN_SOLO + 64, rr, bb, b_i);
-                if (!cert) {
-                    const int tw = tv.twin[hh[g]];
-                    if (tw >= 0) {  // second chance from the entry across the angle-pi cut (record 0 = the twin itself)
-                        const Nbr6 ts = tv.nbrs[(size_t)tw * NBR_REC];
-                        Point6 pt;
+            for (int a = 0; a < 6; ++a) p.c[a] = e[m].c[a];
+            const float dm = dist2(qq, p);
+            if (dm < d || (dm == d && e[m].idx < id)) { d = dm; id = e[m].idx; }  // NaN never wins
+        }
+        row_best(d, id);
+        if (d < bb || (d == bb && id < b_i)) { bb = d; b_i = id; }
+        const float rho_last = __shfl(e[3].rho, lane | 15);  // record NN_SOLO+63 of the row's owner
+        const float gg = fmaf_(rho_last - rr, 0.9999996f, -8e-7f * rr);
+        const bool cert = gg > 0.0f && gg * gg * 0.99997f > bb;
+        // hand the rows' results to the owners: owner with rank r among this group sits in row r - served
+        const int from = 16 * ((my_rank - served) & 3);
+        const float rb = __shfl(bb, from);
+        const int ri = __shfl(b_i, from);
+        const int rc = __shfl((int)cert, from);
+        const bool in_group = need && my_rank >= served && my_rank < served + 4;
+        if (in_group) { best = rb; bi = ri; done = rc != 0; }
+        served += 4;
+        // owners the chunk did not settle: whole-wave continuation, one at a time (rare)
+        unsigned long long open = __ballot(in_group && !done);
+        while (open) {
+            const int o = (int)__builtin_ctzll(open);
+            open &= open - 1;
+            float q1[6];
 #pragma unroll
-                        for (int a = 0; a < 6; ++a) pt.c[a] = ts.c[a];
-                        const float r2 = __builtin_sqrtf(dist2(qq, pt));
-                        cert = coop_scan_list(tv, qq, tw, 0, r2, bb, b_i);
-                    }
+            for (int dd = 0; dd < 6; ++dd) q1[dd] = rl_f32(q[dd], o);
+            const float r1 = rl_f32(r_lane, o);
+            float b1 = rl_f32(best, o);
+            int i1 = rl_i32((int)bi, o);
+            const int h1 = rl_i32(hint, o);
+            bool c1 = coop_scan_list(tv, q1, h1, NN_SOLO + 64, r1, b1, i1);
+            if (!c1) {
+                const int tw = tv.twin[h1];
+                if (tw >= 0) {  // second chance from the entry across the angle-pi cut (record 0 = the twin itself)
+                    const Nbr6 ts = tv.nbrs[(size_t)tw * NBR_REC];
+                    Point6 pt;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) pt.c[a] = ts.c[a];
+                    const float r2 = __builtin_sqrtf(dist2(q1, pt));
+                    c1 = coop_scan_list(tv, q1, tw, 0, r2, b1, i1);
                 }
             }
-            if (lane == owner[g]) { best = bb; bi = b_i; done = cert; }
+            if (lane == o) { best = b1; bi = i1; done = c1; }
         }
     }
 }
@@ -740,50 +778,89 @@ MD double rl_f64(double v, int lane) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+MD double shfl_f64(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__shfl((int)(unsigned)b, src), hi = (unsigned)__shfl((int)(unsigned)(b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// Four owners at a time, one per 16-lane row, records MESH_SOLO+1 .. MESH_SOLO+64 of each owner's vertex list in four
+// steps of 16 (loads in flight together).  Serial semantics inside a row: records in order, the first event decides
+// ("provably too far" before "hit" on the same record).  An owner the 64 records do not settle continues with the
+// whole wave, 64 records per step.
 MD void mesh_coop(const MeshRec* __restrict__ vlist, int32_t h, const double* tq, double t2, double lim_lane, bool need, int& mv) {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, row = lane >> 4, j = lane & 15;
     unsigned long long todo = __ballot(need);
+    const int my_rank = (int)__builtin_popcountll(todo & ((1ull << lane) - 1ull));
+    int served = 0;
     while (todo) {
-        int owner[COOP_G], hh[COOP_G];
-        MeshRec e[COOP_G];
+        int owner[4];
 #pragma unroll
-        for (int g = 0; g < COOP_G; ++g) {
-            owner[g] = todo ? (int)__builtin_ctzll(todo) : -1;
+        for (int k = 0; k < 4; ++k) {
+            owner[k] = todo ? (int)__builtin_ctzll(todo) : -1;
             todo &= todo - 1;
-            if (owner[g] >= 0) {
-                hh[g] = rl_i32(h, owner[g]);
-                e[g] = vlist[(size_t)hh[g] * MESH_REC + (1 + MESH_SOLO) + lane];
+        }
+        const int mine = row == 0 ? owner[0] : row == 1 ? owner[1] : row == 2 ? owner[2] : owner[3];
+        const int src = mine >= 0 ? mine : lane;
+        double q3[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) q3[d] = shfl_f64(tq[d], src);
+        const double lim = shfl_f64(lim_lane, src);
+        const int hh = __shfl(h, src);
+        const MeshRec* vl = vlist + (size_t)(mine >= 0 ? hh : 0) * MESH_REC + (1 + MESH_SOLO) + j;
+        MeshRec e[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) e[m] = vl[16 * m];
+        int res = -1;  // row-uniform
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            Point3 p;
+            p.c[0] = e[m].c[0]; p.c[1] = e[m].c[1]; p.c[2] = e[m].c[2];
+            const bool hit = dist2(q3, p) <= t2;
+            const bool stop = (double)e[m].rho * (1.0 - 1e-7) > lim;
+            const unsigned hits = (unsigned)(__ballot(hit) >> (16 * row)) & 0xffffu;
+            const unsigned stops = (unsigned)(__ballot(stop) >> (16 * row)) & 0xffffu;
+            const int fh = hits ? __builtin_ctz(hits) : 16, fs = stops ? __builtin_ctz(stops) : 16;
+            if (res < 0) {
+                if (fh < 16 && fh < fs) res = 1;
+                else if (fs < 16) res = 0;
             }
         }
+        const int from = 16 * ((my_rank - served) & 3);
+        const int rres = __shfl(res, from);
+        const bool in_group = need && my_rank >= served && my_rank < served + 4;
+        if (in_group) mv = rres;
+        served += 4;
+        // owners the 64 records did not settle (rare): the rest of the list with the whole wave, then the list's outer radius
+        unsigned long long open = __ballot(in_group && mv < 0);
+        while (open) {
+            const int o = (int)__builtin_ctzll(open);
+            open &= open - 1;
+            double q1[3];
 #pragma unroll
-        for (int g = 0; g < COOP_G; ++g) {
-            if (owner[g] < 0) continue;
-            double q3[3];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) q3[d] = rl_f64(tq[d], owner[g]);
-            const double lim = rl_f64(lim_lane, owner[g]);
-            const MeshRec* vl = vlist + (size_t)hh[g] * MESH_REC;
-            int res = -1;
-            for (int c0 = 1 + MESH_SOLO; c0 <= MESH_M && res < 0; c0 += 64) {
+            for (int d = 0; d < 3; ++d) q1[d] = rl_f64(tq[d], o);
+            const double lim1 = rl_f64(lim_lane, o);
+            const MeshRec* v1 = vlist + (size_t)rl_i32(h, o) * MESH_REC;
+            int r1 = -1;
+            for (int c0 = 1 + MESH_SOLO + 64; c0 <= MESH_M && r1 < 0; c0 += 64) {
                 const int s = c0 + lane;
                 bool hit = false;
                 float rho = INFINITY;
                 if (s <= MESH_M) {
-                    const MeshRec r = (c0 == 1 + MESH_SOLO) ? e[g] : vl[s];
+                    const MeshRec r = v1[s];
                     Point3 p;
                     p.c[0] = r.c[0]; p.c[1] = r.c[1]; p.c[2] = r.c[2];
                     rho = r.rho;
-                    hit = dist2(q3, p) <= t2;
+                    hit = dist2(q1, p) <= t2;
                 }
                 const unsigned long long hits = __ballot(hit);
-                const unsigned long long stops = __ballot((double)rho * (1.0 - 1e-7) > lim);
-                // serial semantics: walk the records in order; the first event decides
+                const unsigned long long stops = __ballot((double)rho * (1.0 - 1e-7) > lim1);
                 const int fh = hits ? (int)__builtin_ctzll(hits) : 64, fs = stops ? (int)__builtin_ctzll(stops) : 64;
-                if (fh < 64 && fh < fs) res = 1;
-                else if (fs < 64) res = 0;
+                if (fh < 64 && fh < fs) r1 = 1;
+                else if (fs < 64) r1 = 0;
             }
-            if (res < 0) res = ((double)vl[0].rho * (1.0 - 1e-7) > lim) ? 0 : -1;
-            if (lane == owner[g]) mv = res;
+            if (r1 < 0) r1 = ((double)v1[0].rho * (1.0 - 1e-7) > lim1) ? 0 : -1;
+            if (lane == o) mv = r1;
         }
     }
 }
@@ -1135,43 +1212,58 @@ MD int64_t lazy_source(const LazyResample& rs, const double* rs_lds, int64_t n, 
     if (lo >= rs.nb) return N - 1;
     const int64_t b_lo = (int64_t)lo << 12, b_hi = b_lo + SCAN_BLOCK < N ? b_lo + SCAN_BLOCK : N;
     const double bp = s_bp[lo];
-    // chunk inside the block on the division-free comparison: 4-ary over the (at most 256) chunk ends
-    int64_t c_lo = b_lo >> 4, c_hi = (b_hi + SCAN_CHUNK - 1) >> 4;  // answer chunk in [c_lo, c_hi)
-    while (c_hi - c_lo >= 4) {
-        const int64_t q = (c_hi - c_lo) >> 2;
-        const int64_t m1 = c_lo + q, m2 = m1 + q, m3 = m2 + q;
-        const double g1 = gend[m1 - 1], g2 = gend[m2 - 1], g3 = gend[m3 - 1];  // end of the chunk BEFORE each pivot
-        const bool p1 = left(bp + g1), p2 = left(bp + g2), p3 = left(bp + g3);
-        if (p3) c_lo = m3;
-        else if (p2) { c_lo = m2; c_hi = m3; }
-        else if (p1) { c_lo = m1; c_hi = m2; }
-        else c_hi = m1;
-    }
-    while (c_hi - c_lo > 1) {
-        const int64_t mid = c_lo + ((c_hi - c_lo) >> 1);
-        if (left(bp + gend[mid - 1])) c_lo = mid; else c_hi = mid;
-    }
-    // the chunk's prefix values in one round trip; slot = number of them left of the draw; exact fix-up inside the block
-    const int64_t s0 = c_lo << 4;
+    const double* __restrict__ ggend = apply ? rs.ggend : rs.ggend_raw;
+    // Three levels, one 128-byte line each (16 prefix values fetched together, position = how many are left of the
+    // draw on the division-free comparison): 256-slot group ends of the block, chunk ends of the group, slots of the
+    // chunk.  Values past the end of the data are not counted.
+    // (the caller's tables are padded to whole lines, so every line is fetched with eight aligned 16-byte loads)
     double v[SCAN_CHUNK];
+    auto fetch16 = [&](const double* __restrict__ p) {
+        const double2* p2 = reinterpret_cast<const double2*>(p);
 #pragma unroll
-    for (int j = 0; j < SCAN_CHUNK; ++j) {
-        const int64_t sj = s0 + j;
-        v[j] = lp[sj < N ? sj : N - 1];
-    }
+        for (int j = 0; j < 8; ++j) { const double2 w = p2[j]; v[2 * j] = w.x; v[2 * j + 1] = w.y; }
+    };
+    const int n_chunks = (int)((b_hi - b_lo + SCAN_CHUNK - 1) >> 4), n_groups = (n_chunks + 15) >> 4;
+    fetch16(ggend + (int64_t)lo * 16);
+    int g = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) g += (j < n_groups && left(bp + v[j])) ? 1 : 0;
+    g = g < n_groups ? g : n_groups - 1;
+    const int64_t c0 = (b_lo >> 4) + 16 * g;
+    fetch16(gend + c0);
+    const int n_in_group = n_chunks - 16 * g < 16 ? n_chunks - 16 * g : 16;
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) c += (j < n_in_group && left(bp + v[j])) ? 1 : 0;
+    c = c < n_in_group ? c : n_in_group - 1;
+    const int64_t s0 = (c0 + c) << 4;
+    const double v_prev = lp[s0 > b_lo ? s0 - 1 : b_lo];  // the slot before the chunk (same block)
+    fetch16(lp + s0);
     int pos = 0;
 #pragma unroll
     for (int j = 0; j < SCAN_CHUNK; ++j) pos += (s0 + j < b_hi && left(bp + v[j])) ? 1 : 0;
     int64_t l2 = s0 + pos;
-    if (l2 >= b_hi) l2 = b_hi - 1;
-    auto cdf = [&](int64_t i) { return (i == N - 1) ? 1.0 : (bp + lp[i]) / total; };
-    while (l2 > b_lo) {
-        if (left_exact(cdf(l2 - 1))) break;
-        --l2;
+    // exact fix-up: the predicate on cdf_i = (BP + lp_i) / total is monotone in i; the two neighbours of the boundary are
+    // normally in registers, otherwise walk (inside the block: its end is exact)
+    double vm = v_prev, vp = 0.0;
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) { vm = (j == pos - 1) ? v[j] : vm; vp = (j == pos) ? v[j] : vp; }
+    auto cdfv = [&](int64_t i, double lpv) { return (i == N - 1) ? 1.0 : (bp + lpv) / total; };
+    bool walk = l2 >= b_hi;
+    if (!walk) {
+        if (l2 > b_lo) walk |= !left_exact(cdfv(l2 - 1, vm));
+        walk |= pos >= SCAN_CHUNK || left_exact(cdfv(l2, vp));
     }
-    while (l2 < b_hi - 1) {
-        if (!left_exact(cdf(l2))) break;
-        ++l2;
+    if (walk) {
+        if (l2 >= b_hi) l2 = b_hi - 1;
+        while (l2 > b_lo) {
+            if (left_exact(cdfv(l2 - 1, lp[l2 - 1]))) break;
+            --l2;
+        }
+        while (l2 < b_hi - 1) {
+            if (!left_exact(cdfv(l2, lp[l2]))) break;
+            ++l2;
+        }
     }
     return l2;
 }

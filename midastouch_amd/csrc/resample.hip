@@ -388,8 +388,8 @@ __global__ __launch_bounds__(256) void k_tail_a(int64_t N, const double* __restr
 MD int pad16(int i) { return i + (i >> 4); }
 
 MD void scan_variant(const double* val, const uint8_t* okm, int64_t base, int64_t N, double* s_a, double* s_m,
-                     double* s_gtot, double* __restrict__ lp_out, double* __restrict__ gend_out, double& W_all,
-                     double& W_masked, bool& nan) {
+                     double* s_gtot, double* __restrict__ lp_out, double* __restrict__ gend_out,
+                     double* __restrict__ ggend_out, double& W_all, double& W_masked, bool& nan) {
     const int t = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < SCAN_CHUNK; ++k) {
@@ -409,6 +409,7 @@ MD void scan_variant(const double* val, const uint8_t* okm, int64_t base, int64_
     __syncthreads();
     W_masked = block_scan(vm, l, s_gtot);
     if (base + (int64_t)t * SCAN_CHUNK < N) gend_out[(base >> 4) + t] = l[SCAN_CHUNK - 1];  // block-local prefix at the chunk end
+    if ((t & 15) == 15) ggend_out[(base >> 8) + (t >> 4)] = l[SCAN_CHUNK - 1];               // ... at the end of each 256-slot group
 #pragma unroll
     for (int j = 0; j < SCAN_CHUNK; ++j) s_m[t * 17 + j] = l[j];  // own chunk only
     __syncthreads();
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(256) void k_tail_a2(int64_t N, const double* __rest
                                                  int32_t softmax, double* __restrict__ e_out, double* __restrict__ x_out,
                                                  double* __restrict__ lp_soft, double* __restrict__ lp_raw,
                                                  double* __restrict__ gend_soft, double* __restrict__ gend_raw,
+                                                 double* __restrict__ ggend_soft, double* __restrict__ ggend_raw,
                                                  double* __restrict__ bsum_e, double* __restrict__ btot_soft,
                                                  double* __restrict__ btot_raw, double* __restrict__ bmax,
                                                  double* __restrict__ bmin, int32_t* __restrict__ status,
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(256) void k_tail_a2(int64_t N, const double* __rest
             const int64_t i = base + k * 256 + t;
             if (i < N) e_out[i] = e[k];
         }
-        scan_variant(e, okm, base, N, s_a, s_m, s_gtot, lp_soft, gend_soft, Wa, Wm, nan);
+        scan_variant(e, okm, base, N, s_a, s_m, s_gtot, lp_soft, gend_soft, ggend_soft, Wa, Wm, nan);
         if (t == 0) { bsum_e[blockIdx.x] = Wa; btot_soft[blockIdx.x] = Wm; }
     }
     if (need_raw) {
@@ -498,7 +500,7 @@ __global__ __launch_bounds__(256) void k_tail_a2(int64_t N, const double* __rest
             if (i < N) x_out[i] = x[k];
         }
         bool nan_raw = false;
-        scan_variant(x, okm, base, N, s_a, s_m, s_gtot, lp_raw, gend_raw, Wa, Wm, nan_raw);
+        scan_variant(x, okm, base, N, s_a, s_m, s_gtot, lp_raw, gend_raw, ggend_raw, Wa, Wm, nan_raw);
         if (t == 0) btot_raw[blockIdx.x] = Wm;
         if (!need_soft) nan = nan_raw;  // with the softmax on, x NaN <=> e NaN: counted once
     } else if (t == 0) {
@@ -1220,11 +1222,12 @@ int launch_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores, const i
                         int32_t softmax, double* e, double* x_raw, double* lp, double* lp_raw, double* r1, int32_t* status) {
     const int nb = (int)ceil_div(N, SCAN_BLOCK), ng = (int)ceil_div(N, SCAN_CHUNK);
     void* sc;
-    int rc = midas_scratch(ctx, (size_t)ng * 2 * sizeof(double), &sc);  // chunk-end tables (only TB2 uses them)
+    int rc = midas_scratch(ctx, ((size_t)ng * 2 + (size_t)nb * 32) * sizeof(double), &sc);  // chunk / group-end tables (unused here)
     if (rc) return rc;
     double* gend = (double*)sc;
     hipLaunchKernelGGL(k_tail_a2, dim3((unsigned)nb), dim3(256), 0, ctx->stream, N, scores, nn_idx, valid, softmax, e, x_raw, lp,
-                       lp_raw, gend, gend + ng, r1, r1 + nb, r1 + 2 * nb, r1 + 3 * nb, r1 + 4 * nb, status, r1 + 5 * nb);
+                       lp_raw, gend, gend + ng, gend + 2 * ng, gend + 2 * ng + 16 * nb, r1, r1 + nb, r1 + 2 * nb, r1 + 3 * nb, r1 + 4 * nb,
+                       status, r1 + 5 * nb);
     LAUNCH_CHECK(ctx);
     return MIDAS_OK;
 }
@@ -1249,7 +1252,8 @@ int launch_tail_a2(midas_ctx* ctx, int64_t N, const double* scores, const int32_
                    int32_t softmax, const TailTables& tb, int32_t* status) {
     const int nb = (int)ceil_div(N, SCAN_BLOCK);
     hipLaunchKernelGGL(k_tail_a2, dim3((unsigned)nb), dim3(256), 0, ctx->stream, N, scores, nn_idx, valid, softmax, tb.e, tb.x_raw,
-                       tb.lp, tb.lp_raw, tb.gend, tb.gend_raw, tb.bsum_e, tb.btot, tb.btot_raw, tb.bmax, tb.bmin, status, nullptr);
+                       tb.lp, tb.lp_raw, tb.gend, tb.gend_raw, tb.ggend, tb.ggend_raw, tb.bsum_e, tb.btot, tb.btot_raw, tb.bmax, tb.bmin,
+                       status, nullptr);
     LAUNCH_CHECK(ctx);
     return MIDAS_OK;
 }
@@ -1292,12 +1296,13 @@ int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base) 
     if (!a.x) {  // deferred mode (single trajectory)
         const int ng = (int)ceil_div(a.N, SCAN_CHUNK);
         void* sc2;
-        if ((rc = midas_scratch(ctx, ((size_t)nb * 3 + (size_t)ng * 2) * sizeof(double), &sc2))) return rc;
+        if ((rc = midas_scratch(ctx, ((size_t)nb * 35 + (size_t)ng * 2) * sizeof(double), &sc2))) return rc;
         TailTables tb;
         tb.e = e; tb.x_raw = a.x_raw; tb.lp = a.cdf; tb.lp_raw = a.lp_raw;
         tb.bsum_e = psum; tb.btot = pw;
         tb.btot_raw = (double*)sc2; tb.bmax = tb.btot_raw + nb; tb.bmin = tb.bmax + nb;
         tb.gend = tb.bmin + nb; tb.gend_raw = tb.gend + ng;
+        tb.ggend = tb.gend_raw + ng; tb.ggend_raw = tb.ggend + 16 * nb;
         if ((rc = launch_tail_a2(ctx, a.N, a.scores, a.nn_idx, a.valid, a.softmax, tb, a.status))) return rc;
         prof_mark(ctx, prof_slot_base + 1);
         if ((rc = launch_tail_b2(ctx, a, tb))) return rc;

@@ -160,7 +160,7 @@ class PipelinedFilterEngine(FilterEngine):
         self._st = [torch.zeros(2, dtype=torch.int32, device=dev) for _ in range(2)]
         self._valid = torch.zeros(N, dtype=torch.uint8, device=dev)
         ng, nb = (N + 15) // 16, (N + 4095) // 4096
-        self._tables = torch.zeros(4 * N + 2 * ng + 5 * nb, **f64)
+        self._tables = torch.zeros(4 * (-(-N // 16) * 16) + 2 * (-(-ng // 16) * 16) + 37 * nb, **f64)
         self._scores = torch.zeros(self.K, **f64)
         self._part_rmse = torch.zeros(2 * ((N + 63) // 64), **f64)
         self._cur = 0

@@ -3,7 +3,7 @@
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from midastouch_amd.engine import FilterEngine
+from midastouch_amd.engine import FilterEngine, PipelinedFilterEngine
 from midastouch_amd.synthetic import make_codebook, make_trajectory
 
 dev = torch.device("cuda", 0)
@@ -11,7 +11,7 @@ N, K, D = 100_000, 50_000, 512
 cb = make_codebook("004_sugar_box", K=K, D=D, seed=1001)
 T = 232
 traj = make_trajectory(cb, T=T, seed=2001)
-eng = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4000, device=dev)
+eng = (PipelinedFilterEngine if os.environ.get("MIDAS_PIPELINED") else FilterEngine)(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4000, device=dev)
 rng = np.random.default_rng(100)
 d0 = np.linalg.norm(cb.poses[:, :3, 3] - traj.gt_poses[0][:3, 3], axis=1)
 near = np.argsort(d0)[: max(64, K // 20)]
@@ -23,8 +23,8 @@ for t in range(1, T):
     eng.step(odoms[t], codes[t], gt=gts[t])
     if t in (1, 2, 5, 10, 20, 50, 100, 150, 200, 230):
         cur = eng.telemetry[16:].view(-1, 16).sum(0).cpu().numpy().astype(float)
-        uniq = int(torch.unique(eng.hint_next).numel())
-        print(t, "unique NN entries", uniq, "status", eng.status.cpu().tolist(), "d/frame", ((cur - prev)).round(0).tolist())
+        uniq = int(torch.unique(eng.nn_idx).numel())
+        print(t, "unique NN entries", uniq, "d/frame", ((cur - prev)).round(0).tolist())
         prev = cur
 per_wave = eng.telemetry[16:].view(-1, 16).cpu().numpy().astype(float)
 tot = per_wave.sum(0)
@@ -34,4 +34,18 @@ nw = (N + 63) // 64
 print("ticks per wave per frame [propagate+feature, nn solo, nn coop(+tree), mesh solo, mesh coop, tree3, gather+exp+rmse terms, reductions]:",
       (tl[8:16] / (T - 1) / nw).round(0).tolist())
 print("mean wave lifetime us:", tl[7] / (T - 1) / nw / 100.0)
+# distribution over waves of the LAST frame's lifetime (slot 7 is cumulative: difference of two reads)
+before_all = eng.telemetry[16:].view(-1, 16).clone()
+before = before_all[:, 7].clone()
+eng.step(odoms[1], codes[1], gt=gts[1])
+torch.cuda.synchronize()
+life = (eng.telemetry[16:].view(-1, 16)[:, 7] - before).cpu().numpy()[:nw] / 100.0
+dd = (eng.telemetry[16:].view(-1, 16) - before_all).cpu().numpy()[:nw].astype(float)
+order = np.argsort(life)
+names = "nn_coop_lanes mesh_coop_lanes scanned | ticks: prop nn_solo nn_coop mesh_solo mesh_coop tree3 gather reduce"
+print(names)
+for tag, sel in (("slowest", order[-6:]), ("median", order[nw // 2 - 3: nw // 2 + 3]), ("fastest", order[:3])):
+    for w in sel:
+        print(f"  {tag} wave {w}: life {life[w]:.1f} us | {int(dd[w,2])} {int(dd[w,3])} {int(dd[w,6])} | " + " ".join(str(int(x)) for x in dd[w, 8:16]))
+print("last frame, wave lifetime us: p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(life, [10, 50, 90, 99, 100])))
 print("[nn tree, prune tree, nn coop lanes, prune coop lanes, nn coop waves, prune coop waves, nn records scanned, -]")
