@@ -1410,7 +1410,8 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
 // the scores are only gathered in the tail - so they share ONE launch: workgroups [0, n_pu) run four
 // particle waves each and start first, workgroups [n_pu, ...) stream sixteen codebook rows each behind them
 // and fill the memory pipes the particle waves leave idle.
-template <typename T, int NJ>
+// LAZY: the resample of the previous frame runs as a prologue of the particle waves (midas_lazy_step).
+template <typename T, int NJ, bool LAZY>
 __global__ __launch_bounds__(256) void k_frame_front(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a,
                                                      int n_pu, int nwaves, const T* __restrict__ emb,
                                                      const double* __restrict__ norms, const double* __restrict__ code,
@@ -1419,9 +1420,9 @@ __global__ __launch_bounds__(256) void k_frame_front(TreeView<Kd6> t6, TreeView<
     __shared__ double s_rs[3 * LAZY_MAX_BLOCKS + 8];
     const int w = threadIdx.x >> 6;
     if ((int)blockIdx.x < n_pu) {
-        if (a.rs.enabled) lazy_tables(a.rs, s_rs);  // uniform over the launch
+        if (LAZY) lazy_tables(a.rs, s_rs);
         const int64_t wave = (int64_t)blockIdx.x * 4 + w;
-        if (wave < nwaves) particle_update_wave(t6, t3, a, wave, nwaves, 0, s_cd[w], a.rs.enabled ? s_rs : nullptr);
+        if (wave < nwaves) particle_update_wave(t6, t3, a, wave, nwaves, 0, s_cd[w], LAZY ? s_rs : nullptr);
     } else {
         score_wave<T, NJ, 0>(emb, norms, code, scores, K, (int64_t)(blockIdx.x - n_pu) * 4 + w);
     }
@@ -1522,8 +1523,12 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
     const unsigned grid = (unsigned)(n_pu + ceil_div(cb->K, 16));
     const float* emb = (const float*)cb->emb;
 #define MIDAS_FRONT(NJ)                                                                                              \
-    hipLaunchKernelGGL((k_frame_front<float, NJ>), dim3(grid), dim3(256), 0, ctx->stream, view_of<Kd6>(t6),         \
-                       view_of<Kd3>(t3), a, n_pu, nwaves, emb, cb->norms, code, scores, cb->K)
+    if (a.rs.enabled)                                                                                                \
+        hipLaunchKernelGGL((k_frame_front<float, NJ, true>), dim3(grid), dim3(256), 0, ctx->stream, view_of<Kd6>(t6), \
+                           view_of<Kd3>(t3), a, n_pu, nwaves, emb, cb->norms, code, scores, cb->K);                  \
+    else                                                                                                             \
+        hipLaunchKernelGGL((k_frame_front<float, NJ, false>), dim3(grid), dim3(256), 0, ctx->stream, view_of<Kd6>(t6), \
+                           view_of<Kd3>(t3), a, n_pu, nwaves, emb, cb->norms, code, scores, cb->K)
     switch (cb->D) {
         case 512: MIDAS_FRONT(8); break;
         case 256: MIDAS_FRONT(4); break;
