@@ -39,6 +39,9 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec peak (6.3 TB/s achievable)
 PER_PARTICLE_UPDATE = 140  # bytes, SURVEY.md section 8(d): propagate 128 + idx w 4 + score gather 4 + dist w 4
 PER_PARTICLE_TAIL = 200    # the remaining 200 of the 340 B/particle
+# of which the pipelined front performs, for the previous frame: CDF read 8, resample index write 4, pose gather read 64,
+# label (hint) gather read 4 - the 64-byte write of the gathered pose and the weight gather are what the fusion removes
+PER_PARTICLE_FOLDED = 80
 
 
 def algorithmic_bytes(N, K, D, B=1):
@@ -214,8 +217,8 @@ def main():
             if per["tail_b"] == 0.0:  # pipelined: no separate resample launch
                 per.pop("tail_b")
             groups = {"frame_front": per["frame_front"], "tail": per["tail_a"] + per.get("tail_b", 0.0)}
-            # algorithmic bytes of the front: scoring + particle update (the folded resample's reads are not added)
-            ab["frame_front"] = ab["score_codebook"] + ab["particle_update"]
+            # algorithmic bytes of the front: scoring + particle update (+ the folded resample's share when pipelined)
+            ab["frame_front"] = ab["score_codebook"] + ab["particle_update"] + (0 if "tail_b" in per else N * PER_PARTICLE_FOLDED)
             dom = "frame_front"
         else:
             groups = {"score_codebook": per["score_codebook"], "particle_update": per["particle_update"],
