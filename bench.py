@@ -19,8 +19,9 @@ resampled poses never written to HBM.  The last frame's particle set is material
 after every frame (three launches per frame, what a caller that looks at the particles each frame gets).
 
 Multi-GPU (N>1): one filter whose particles are sharded across the ranks (N_total = gpus x 100k,
-weak scaling); per frame the ranks exchange (max, sum-exp, weight-total) and the resampled particles
-over RCCL.  `value` = frames processed by all ranks / wall time = gpus x steps / t.
+weak scaling); per frame the ranks all_gather one small record of per-block sums / extrema and exchange the
+resampled particles over RCCL (all_to_all of the rows each rank needs, resolved by the owners of the sources).
+`value` = frames processed by all ranks / wall time = gpus x steps / t.
 
 Prints ONE JSON line on rank 0.
 """
@@ -90,6 +91,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--sharded", action="store_true", help="use the particle-sharded engine even on one GPU (smoke test)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "a2a", "allgather"], help="sharded engine: form of the resample exchange")
     ap.add_argument("--eager", action="store_true", help="materialise the resampled particles every frame (three launches per frame)")
     args = ap.parse_args()
 
@@ -129,7 +131,7 @@ def main():
         eng = cls(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4000, device=dev)
     else:
         from midastouch_amd.dist import ShardedFilterEngine
-        eng = ShardedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4000, device=dev)
+        eng = ShardedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4000, device=dev, exchange=args.exchange)
     rng = np.random.default_rng(100 + rank)
     # particles start on codebook poses within ~2 cm of the first ground-truth pose
     d0 = np.linalg.norm(cb.poses[:, :3, 3] - traj.gt_poses[0][:3, 3], axis=1)
@@ -187,7 +189,7 @@ def main():
                                "device Philox draws, multinomial resample" % (N, K, D),
                    "particles_per_gpu": N, "particles_total": N * world, "codebook_rows": K, "embedding_dim": D,
                    "parallelism": "particle-sharded x%d" % world if sharded else "single",
-                   "engine": "sharded" if sharded else ("eager: 3 launches/frame" if args.eager else
+                   "engine": ("sharded, exchange=" + eng.exchange) if sharded else ("eager: 3 launches/frame" if args.eager else
                                                         "pipelined: resample of frame t folded into the front kernel of frame t+1, 2 launches/frame"),
                    "arith": "f32 poses/NN, f64 scores/weights/CDF", "last_status": status,
                    "steps_per_sec_materialised_every_frame": eager_rate,

@@ -283,19 +283,54 @@ int midas_shard_front(midas_ctx* ctx, const midas_codebook* cb, const midas_tree
 /* Exchange record (float64), ONE per rank and frame, gathered by the caller in rank order (nb = ceil(N / 4096)):
  *   r1 = { nb block sums of e | nb block totals of e*valid | nb block totals of x*valid | nb block max x | nb block min x |
  *          NaN count | kept count | sum |dt|^2 | sum angle^2 }
- * midas_shard_tail_a: x = scores[nn_idx], e = exp(x - 1); lp / lp_raw = block-local prefix (fixed order) of e*valid /
- * x*valid (the raw variant only where a block's own score range is within the isclose tolerance - the guard of
- * get_similarity is global and decided in midas_shard_tail_fin); fills r1[0 .. 5 nb + 2); status[0] = 2 on NaN,
- * status[1] = local particles kept. */
+ * midas_shard_tail_a: x = scores[nn_idx], e = exp(x - 1); fills this rank's softmax / CDF tables (tables_dev: the layout
+ * of midas_lazy_args.tables_dev minus its 5 nb block records, i.e. 4 N16 + 2 G16 + 32 nb doubles, 128-byte aligned: e | x |
+ * lp | lp_raw | chunk ends x2 | group ends x2; the raw variants only where a block's own score range is within the isclose
+ * tolerance - the guard of get_similarity is global and decided after the exchange) and r1[0 .. 5 nb + 2);
+ * status[0] = 2 on NaN, status[1] = local particles kept. */
 int midas_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores_dev, const int32_t* nn_idx_dev,
-                       const uint8_t* valid_dev, int32_t softmax, double* e_dev, double* x_raw_dev, double* lp_dev,
-                       double* lp_raw_dev, double* r1_dev, int32_t* status_dev);
+                       const uint8_t* valid_dev, int32_t softmax, double* tables_dev, double* r1_dev, int32_t* status_dev);
+/* Owner-side resample.  The draw of a slot is a pure function of the slot (Philox keyed by the global slot, replicated host
+ * uniforms, or the systematic comb) and the gathered records give every rank the global block prefix, so every rank can
+ * tell for EVERY slot of the filter which rank owns its source particle; the owner resolves the source inside its own
+ * tables and sends that one row to the rank holding the slot.  Per frame:
+ *   midas_shard_route_count  -> counts_dev[0 .. G) rows this rank sends to each rank, [G .. 2G) rows it receives from each
+ *                               (the caller reads them back: split sizes of the all_to_all); finalises status / rmse
+ *   midas_shard_route_pack   -> send_dev: sum(send counts) records of 88 bytes, segment of rank d at the exclusive prefix
+ *                               of the send counts; weights_dev: this rank's masked weights
+ *   all_to_all (caller), then midas_shard_unpack scatters the N received records to their slots.
+ * Record: int32 slot (local at the destination) | int32 global source index | int32 NN index | int32 0 | f64 weight |
+ * 16 x f32 pose.  N must be the same on every rank and >= 256. */
+typedef struct midas_shard_route_args {
+    int64_t N;
+    int32_t G, rank;
+    const double* r1_all_dev;       /* G x (5 nb + 4) */
+    const double* tables_dev;       /* this rank's tables (midas_shard_tail_a) */
+    const uint8_t* valid_dev;
+    const int32_t* nn_idx_dev;
+    const float* poses_prop_dev;
+    int32_t* status_dev;            /* 2 out: global cdf status, total particles kept */
+    double* rmse_dev;               /* NULL or 2 out */
+    int32_t softmax, resample_mode;
+    const double* u_all_dev;        /* NULL -> Philox, or G * N uniforms (the same on every rank) */
+    float u32;
+    uint64_t seed, step;
+    int32_t* counts_dev;            /* 3 G ints: send counts | receive counts | scratch */
+    void* send_dev;                 /* pack: sum(send counts) x 88 bytes */
+    double* weights_dev;            /* pack: N out */
+} midas_shard_route_args;
+int midas_shard_route_count(midas_ctx* ctx, const midas_shard_route_args* args);
+int midas_shard_route_pack(midas_ctx* ctx, const midas_shard_route_args* args);
+int midas_shard_unpack(midas_ctx* ctx, int64_t N, const void* recv_dev, int32_t* ridx_dev, float* poses_out_dev,
+                       double* weights_out_dev, int32_t* hint_out_dev);
+/* ---- the all_gather form of the exchange (every rank materialises its slice of the global CDF and gathers every
+ * shard's packed block; G-1 times the bytes of the owner-side form, no read-back of counts) ---- */
 /* midas_shard_tail_fin: softmax applied unless softmax == 0 or |max x - min x| over r1_all <= 1e-8 (then e := x);
- * weights = e / S * valid; cdf (in place over lp) = (BP + lp) / total with S, BP, total summed sequentially in global
+ * weights = e / S * valid; cdf_dev = (BP + lp) / total with S, BP, total summed sequentially in global
  * block order over r1_all; the globally last slot is forced to 1; status = global cdf status + total kept count;
  * rmse_dev (nullable, 2 doubles) from the sums in r1_all over N_total particles. */
-int midas_shard_tail_fin(midas_ctx* ctx, int64_t N, const double* e_dev, const double* x_raw_dev, const double* lp_raw_dev,
-                         const uint8_t* valid_dev, double* weights_dev, double* cdf_dev, int32_t G,
+int midas_shard_tail_fin(midas_ctx* ctx, int64_t N, const double* tables_dev, const uint8_t* valid_dev,
+                         double* weights_dev, double* cdf_dev, int32_t G,
                          const double* r1_all_dev, int32_t rank, int64_t N_total, int32_t softmax, double* rmse_dev,
                          int32_t* status_dev);
 /* The cross-rank resample reads any shard's particles from ONE gathered buffer: every rank contributes a

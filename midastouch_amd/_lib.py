@@ -106,6 +106,19 @@ class LazyFlushArgs(C.Structure):
     ]
 
 
+class ShardRouteArgs(C.Structure):
+    """midas_shard_route_args (include/midas_hip.h)."""
+
+    _fields_ = [
+        ("N", C.c_int64), ("G", C.c_int32), ("rank", C.c_int32),
+        ("r1_all", C.c_void_p), ("tables", C.c_void_p), ("valid", C.c_void_p), ("nn_idx", C.c_void_p),
+        ("poses_prop", C.c_void_p), ("status", C.c_void_p), ("rmse", C.c_void_p),
+        ("softmax", C.c_int32), ("resample_mode", C.c_int32), ("u_all", C.c_void_p), ("u32", C.c_float),
+        ("seed", C.c_uint64), ("step", C.c_uint64),
+        ("counts", C.c_void_p), ("send", C.c_void_p), ("weights", C.c_void_p),
+    ]
+
+
 class TailResampleArgs(C.Structure):
     """midas_tail_resample_args (include/midas_hip.h)."""
 
@@ -153,8 +166,11 @@ SIGNATURES = {
     "midas_lazy_step": (C.c_int, [_P, _P, _P, _P, C.POINTER(LazyArgs)]),
     "midas_lazy_flush": (C.c_int, [_P, C.POINTER(LazyFlushArgs)]),
     "midas_shard_front": (C.c_int, [_P, _P, _P, _P, C.POINTER(ShardFrontArgs)]),
-    "midas_shard_tail_a": (C.c_int, [_P, _I64, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _P]),
-    "midas_shard_tail_fin": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, _I32, _P, _I32, _I64, _I32, _P, _P]),
+    "midas_shard_tail_a": (C.c_int, [_P, _I64, _P, _P, _P, _I32, _P, _P, _P]),
+    "midas_shard_tail_fin": (C.c_int, [_P, _I64, _P, _P, _P, _P, _I32, _P, _I32, _I64, _I32, _P, _P]),
+    "midas_shard_route_count": (C.c_int, [_P, C.POINTER(ShardRouteArgs)]),
+    "midas_shard_route_pack": (C.c_int, [_P, C.POINTER(ShardRouteArgs)]),
+    "midas_shard_unpack": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P]),
     "midas_tail_resample": (C.c_int, [_P, C.POINTER(TailResampleArgs)]),
     "midas_profile_enable": (C.c_int, [_P, _I32]),
     "midas_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64), _I32]),

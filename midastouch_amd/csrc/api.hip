@@ -658,26 +658,65 @@ MIDAS_EXPORT int midas_shard_front(midas_ctx* ctx, const midas_codebook* cb, con
     return MIDAS_OK;
 }
 
-MIDAS_EXPORT int midas_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores_dev, const int32_t* nn_idx_dev,
-                                    const uint8_t* valid_dev, int32_t softmax, double* e_dev, double* x_raw_dev,
-                                    double* lp_dev, double* lp_raw_dev, double* r1_dev, int32_t* status_dev) {
-    MIDAS_ENTER(ctx);
-    MIDAS_REQUIRE(ctx, N > 0 && scores_dev && nn_idx_dev && valid_dev && e_dev && x_raw_dev && lp_dev && lp_raw_dev && r1_dev &&
-                           status_dev);
-    return launch_shard_tail_a(ctx, N, scores_dev, nn_idx_dev, valid_dev, softmax, e_dev, x_raw_dev, lp_dev, lp_raw_dev, r1_dev,
-                               status_dev);
+// tables block of one shard: the lazy layout without the per-block records (those live in the exchange record r1)
+static TailTables shard_tables_of(double* t, int64_t N) {
+    const int64_t ng = ceil_div(N, SCAN_CHUNK), nb = ceil_div(N, SCAN_BLOCK);
+    const int64_t Np = ceil_div(N, 16) * 16, ngp = ceil_div(ng, 16) * 16;
+    TailTables tb;
+    tb.e = t; tb.x_raw = tb.e + Np; tb.lp = tb.x_raw + Np; tb.lp_raw = tb.lp + Np;
+    tb.gend = tb.lp_raw + Np; tb.gend_raw = tb.gend + ngp;
+    tb.ggend = tb.gend_raw + ngp; tb.ggend_raw = tb.ggend + 16 * nb;
+    tb.bsum_e = tb.btot = tb.btot_raw = tb.bmax = tb.bmin = nullptr;
+    return tb;
 }
 
-MIDAS_EXPORT int midas_shard_tail_fin(midas_ctx* ctx, int64_t N, const double* e_dev, const double* x_raw_dev,
-                                      const double* lp_raw_dev, const uint8_t* valid_dev, double* weights_dev,
-                                      double* cdf_dev, int32_t G, const double* r1_all_dev, int32_t rank, int64_t N_total,
-                                      int32_t softmax, double* rmse_dev, int32_t* status_dev) {
+MIDAS_EXPORT int midas_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores_dev, const int32_t* nn_idx_dev,
+                                    const uint8_t* valid_dev, int32_t softmax, double* tables_dev, double* r1_dev,
+                                    int32_t* status_dev) {
     MIDAS_ENTER(ctx);
-    MIDAS_REQUIRE(ctx, N > 0 && G > 0 && rank >= 0 && rank < G && e_dev && x_raw_dev && lp_raw_dev && valid_dev && weights_dev &&
-                           cdf_dev && r1_all_dev && N_total >= N && status_dev);
+    MIDAS_REQUIRE(ctx, N > 0 && scores_dev && nn_idx_dev && valid_dev && tables_dev && (uintptr_t)tables_dev % 128 == 0 && r1_dev &&
+                           status_dev);
+    return launch_shard_tail_a(ctx, N, scores_dev, nn_idx_dev, valid_dev, softmax, shard_tables_of(tables_dev, N), r1_dev, status_dev);
+}
+
+MIDAS_EXPORT int midas_shard_tail_fin(midas_ctx* ctx, int64_t N, const double* tables_dev, const uint8_t* valid_dev,
+                                      double* weights_dev, double* cdf_dev, int32_t G, const double* r1_all_dev, int32_t rank,
+                                      int64_t N_total, int32_t softmax, double* rmse_dev, int32_t* status_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, N > 0 && G > 0 && rank >= 0 && rank < G && tables_dev && valid_dev && weights_dev && cdf_dev && r1_all_dev &&
+                           N_total >= N && status_dev);
     const int nb = (int)ceil_div(N, SCAN_BLOCK);
-    return launch_tail_fin(ctx, N, e_dev, x_raw_dev, lp_raw_dev, valid_dev, weights_dev, cdf_dev, G, nb, r1_all_dev, rank,
+    const TailTables tb = shard_tables_of(const_cast<double*>(tables_dev), N);
+    return launch_tail_fin(ctx, N, tb.e, tb.x_raw, tb.lp, tb.lp_raw, valid_dev, weights_dev, cdf_dev, G, nb, r1_all_dev, rank,
                            (double)N_total, softmax, rmse_dev, status_dev);
+}
+
+static int shard_route(midas_ctx* ctx, const midas_shard_route_args* args, bool pack) {
+    MIDAS_REQUIRE(ctx, args != nullptr);
+    const midas_shard_route_args& s = *args;
+    MIDAS_REQUIRE(ctx, s.N >= 256 && s.G > 0 && s.G <= 64 && s.rank >= 0 && s.rank < s.G && s.r1_all_dev && s.tables_dev &&
+                           (uintptr_t)s.tables_dev % 128 == 0 && s.valid_dev && s.nn_idx_dev && s.poses_prop_dev && s.status_dev &&
+                           s.counts_dev);
+    MIDAS_REQUIRE(ctx, !pack || (s.send_dev && s.weights_dev && (uintptr_t)s.send_dev % 8 == 0));
+    MIDAS_REQUIRE(ctx, s.resample_mode == MIDAS_RESAMPLE_MULTINOMIAL || s.resample_mode == MIDAS_RESAMPLE_SYSTEMATIC);
+    return launch_shard_route(ctx, s, shard_tables_of(const_cast<double*>(s.tables_dev), s.N), pack);
+}
+
+MIDAS_EXPORT int midas_shard_route_count(midas_ctx* ctx, const midas_shard_route_args* args) {
+    MIDAS_ENTER(ctx);
+    return shard_route(ctx, args, false);
+}
+
+MIDAS_EXPORT int midas_shard_route_pack(midas_ctx* ctx, const midas_shard_route_args* args) {
+    MIDAS_ENTER(ctx);
+    return shard_route(ctx, args, true);
+}
+
+MIDAS_EXPORT int midas_shard_unpack(midas_ctx* ctx, int64_t N, const void* recv_dev, int32_t* ridx_dev, float* poses_out_dev,
+                                    double* weights_out_dev, int32_t* hint_out_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, N > 0 && recv_dev && (uintptr_t)recv_dev % 8 == 0 && ridx_dev && poses_out_dev && weights_out_dev && hint_out_dev);
+    return launch_shard_unpack(ctx, N, recv_dev, ridx_dev, poses_out_dev, weights_out_dev, hint_out_dev);
 }
 
 MIDAS_EXPORT int midas_tail_resample(midas_ctx* ctx, const midas_tail_resample_args* args) {

@@ -258,16 +258,19 @@ struct TailTables {
 int launch_tail_a2(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
                    int32_t softmax, const TailTables& tb, int32_t* status);
 int launch_tail_b2(midas_ctx* ctx, const StepTailArgs& a, const TailTables& tb);  // a.x, a.e, a.cdf, a.lp_raw unused
+int launch_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
+                        int32_t softmax, const TailTables& tb, double* r1, int32_t* status);
+int launch_shard_route(midas_ctx* ctx, const midas_shard_route_args& r, const TailTables& tb, bool pack);
+int launch_shard_unpack(midas_ctx* ctx, int64_t N, const void* recv, int32_t* ridx, float* poses_out, double* weights_out,
+                        int32_t* hint_out);
 int debug_tb2_clocks(long long* out16);
 int launch_tail_a(midas_ctx* ctx, int64_t N, const double* x, const uint8_t* valid, int np, int pstride,
                   const double* pmax_all, const double* pmin_all, int32_t softmax, double* e_io, double* lp_out,
                   double* block_sums_e, double* block_totals_em, double* flags_out, int32_t* flag, int32_t* status,
                   int batch = 1);
-int launch_tail_fin(midas_ctx* ctx, int64_t N, const double* e, const double* x_raw, const double* lp_raw, const uint8_t* valid,
-                    double* weights, double* cdf_io, int G, int nb, const double* r1_all, int rank, double n_total,
-                    int32_t softmax, double* rmse_out, int32_t* status);
-int launch_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
-                        int32_t softmax, double* e, double* x_raw, double* lp, double* lp_raw, double* r1, int32_t* status);
+int launch_tail_fin(midas_ctx* ctx, int64_t N, const double* e, const double* x_raw, const double* lp, const double* lp_raw,
+                    const uint8_t* valid, double* weights, double* cdf_io, int G, int nb, const double* r1_all, int rank,
+                    double n_total, int32_t softmax, double* rmse_out, int32_t* status);
 int launch_tail_resample(midas_ctx* ctx, const midas_tail_resample_args& r);
 int launch_reduce_partials(midas_ctx* ctx, int np, const double* pmax, const double* pmin, const double* prm,
                            double* extrema2, double* rmse_sums2);

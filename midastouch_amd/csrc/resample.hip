@@ -6,6 +6,7 @@
 // 4096 values); every level is a sequential float64 sum in index order starting from +0.0.
 #include "midas_internal.hpp"
 #include "midas_math.hpp"
+#include "resample_search.hpp"
 
 namespace midas {
 
@@ -528,7 +529,8 @@ constexpr int TB_MAX_BLOCKS = 1024;  // 4 M particles (per GPU in the fused step
 //     weights = e / S * valid and cdf = (BP + lp) / total with S, BP, total summed sequentially over ALL shards'
 //     blocks in global block order; the globally last slot is forced to 1; block 0 finalises status and rmse.
 __global__ __launch_bounds__(256) void k_tail_fin(int64_t N, const double* __restrict__ e, const double* __restrict__ x_raw,
-                                                  const double* __restrict__ lp_raw, const uint8_t* __restrict__ valid,
+                                                  const double* __restrict__ lp, const double* __restrict__ lp_raw,
+                                                  const uint8_t* __restrict__ valid,
                                                   double* __restrict__ weights, double* __restrict__ cdf_io, int G, int nb,
                                                   const double* __restrict__ r1_all, int rank, double n_total,
                                                   int32_t softmax, double* __restrict__ rmse_out,
@@ -591,7 +593,7 @@ __global__ __launch_bounds__(256) void k_tail_fin(int64_t N, const double* __res
         if (rmse_out) { rmse_out[0] = __builtin_sqrt(st2 / n_total); rmse_out[1] = __builtin_sqrt(sr2 / n_total); }
     }
     const double* __restrict__ ev = apply ? e : x_raw;
-    const double* __restrict__ lpv = apply ? cdf_io : lp_raw;
+    const double* __restrict__ lpv = apply ? lp : lp_raw;
     const bool is_last = rank == G - 1;
     const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK;
     double ee[SCAN_CHUNK], ll[SCAN_CHUNK];
@@ -1113,6 +1115,226 @@ __global__ __launch_bounds__(256) void k_tail_resample(TailResampleArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// sharded step, owner-side resample: rows travel instead of whole shards
+// ------------------------------------------------------------------------------------------------
+// After the exchange of the per-block records (r1_all) every rank knows the GLOBAL block prefix, and the draw of
+// a slot is a pure function of the slot (Philox keyed by the global slot, the replicated host uniforms, or the
+// systematic comb) - so every rank can tell, for every slot of the whole filter, which rank OWNS the source particle
+// (the block the draw falls in, on the exact predicate).  The owner then resolves the exact source inside its own
+// tables and sends that one row (pose, weight, NN index) to the rank holding the slot: an all_to_all of N rows per
+// rank in total, where gathering every shard's packed block moved G-1 times as much.
+//   pass COUNT: for every global slot: owner o, destination d  ->  counts[d] += (o == me), counts[G + o] += (d == me)
+//               (the split sizes of the all_to_all; the caller reads them back) ; status / rmse finalised
+//   pass PACK : the slots this rank owns: source slot (search_in_block), record -> send buffer, segment d at the
+//               exclusive prefix of the send counts ; the rank's own masked weights
+// Record (88 bytes): int32 slot (local at the destination) | int32 global source | int32 NN index | pad | f64 weight |
+// 16 x f32 pose.
+constexpr int ROUTE_REC = 88;
+struct ShardRouteArgs {
+    int64_t N;        // particles per rank
+    int G, rank, nb;  // ranks, this rank, blocks per rank
+    const double* r1_all;
+    const double *e, *x_raw, *lp, *lp_raw, *gend, *gend_raw, *ggend, *ggend_raw;
+    const uint8_t* valid;
+    const int32_t* nn_idx;
+    const float* poses_prop;
+    int32_t* status;
+    double* rmse_out;
+    double n_total;
+    int32_t softmax, mode;
+    const double* u_all;
+    float u32;
+    uint64_t seed, step;
+    int32_t* counts;  // [2 G]
+    int32_t* cursor;  // [G]
+    char* send;
+    double* weights;
+};
+
+template <bool PACK>
+__global__ __launch_bounds__(256) void k_shard_route(ShardRouteArgs a) {
+    __shared__ double s_bp[TB_MAX_BLOCKS];
+    __shared__ double s_end[TB_MAX_BLOCKS];
+    __shared__ double s_se[TB_MAX_BLOCKS];
+    __shared__ double s_ex[12];
+    __shared__ double s_tot[3];
+    __shared__ int s_apply, s_cnt[2], s_base[2];
+    __shared__ int s_hist[128], s_soff[64];
+    const int t = threadIdx.x;
+    const int nb_all = a.G * a.nb, rec = 5 * a.nb + 4;
+    auto field = [&](int f, int i) { return a.r1_all[(int64_t)(i / a.nb) * rec + (int64_t)f * a.nb + (i % a.nb)]; };
+    // ---- tables (as k_tail_fin): guard, sequential prefix over all blocks, exact cdf at the block ends
+    double mx = -INFINITY, mn = INFINITY;
+    bool nan = false;
+    for (int i = t; i < nb_all; i += 256) {
+        const double u = field(3, i), v = field(4, i);
+        nan |= (u != u) || (v != v);
+        mx = u > mx ? u : mx;
+        mn = v < mn ? v : mn;
+        s_end[i] = field(1, i);
+        s_se[i] = field(0, i);
+    }
+    mx = wmax(mx);
+    mn = wmin(mn);
+    const bool wn = __any(nan);
+    if ((t & 63) == 0) { s_ex[t >> 6] = mx; s_ex[4 + (t >> 6)] = mn; s_ex[8 + (t >> 6)] = wn ? 1.0 : 0.0; }
+    if (t < 128) s_hist[t] = 0;
+    if (t < 2) s_cnt[t] = 0;
+    __syncthreads();
+    if (t == 0) {
+        mx = s_ex[0]; mn = s_ex[4];
+        double f = s_ex[8];
+        for (int w = 1; w < 4; ++w) { mx = s_ex[w] > mx ? s_ex[w] : mx; mn = s_ex[4 + w] < mn ? s_ex[4 + w] : mn; f += s_ex[8 + w]; }
+        if (f != 0.0) { mx = NAN; mn = NAN; }
+        s_apply = (a.softmax && !(__builtin_fabs(mx - mn) <= ISCLOSE_ATOL)) ? 1 : 0;
+    }
+    __syncthreads();
+    const bool apply = s_apply != 0;
+    if (!apply) {
+        for (int i = t; i < nb_all; i += 256) s_end[i] = field(2, i);
+        __syncthreads();
+    }
+    if (t == 0) {
+        double acc = 0.0, S = 0.0;
+        for (int i = 0; i < nb_all; ++i) { s_bp[i] = acc; acc = acc + s_end[i]; S = S + s_se[i]; }
+        s_tot[0] = acc; s_tot[1] = apply ? S : 1.0;
+        double nans = 0.0;
+        for (int r = 0; r < a.G; ++r) nans += a.r1_all[(int64_t)r * rec + 5 * a.nb];
+        s_tot[2] = nans;
+        if (PACK) {  // segment offsets of the send buffer = exclusive prefix of the send counts
+            int o = 0;
+            for (int g = 0; g < a.G; ++g) { s_soff[g] = o; o += a.counts[g]; }
+        }
+    }
+    __syncthreads();
+    const double total = s_tot[0], S = s_tot[1];
+    {   // exact cdf at the last slot of every block: (BP_b + W_b) / total (the block total is the block-local prefix at
+        // the block's last slot); the globally last block ends at the last particle, forced to 1
+        double wv[TB_MAX_BLOCKS / 256];
+#pragma unroll
+        for (int k = 0; k < TB_MAX_BLOCKS / 256; ++k) wv[k] = (k * 256 + t < nb_all) ? s_end[k * 256 + t] : 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TB_MAX_BLOCKS / 256; ++k) {
+            const int b = k * 256 + t;
+            if (b < nb_all) s_end[b] = (b == nb_all - 1) ? 1.0 : (s_bp[b] + wv[k]) / total;
+        }
+        __syncthreads();
+    }
+    const bool bad_total = !(total == total) || total == 0.0;
+    const bool usable = s_tot[2] == 0.0 && !bad_total;
+    if (!PACK && blockIdx.x == 0 && t == 0) {
+        double kept = 0.0, st2 = 0.0, sr2 = 0.0;
+        for (int r = 0; r < a.G; ++r) {
+            const double* fl = a.r1_all + (int64_t)r * rec + 5 * a.nb;
+            kept += fl[1]; st2 += fl[2]; sr2 += fl[3];
+        }
+        int st = s_tot[2] != 0.0 ? 2 : 0;
+        if (total != total) st |= 2;
+        else if (total == 0.0) st |= 1;
+        a.status[0] = st;
+        a.status[1] = (int32_t)kept;
+        if (a.rmse_out) { a.rmse_out[0] = __builtin_sqrt(st2 / a.n_total); a.rmse_out[1] = __builtin_sqrt(sr2 / a.n_total); }
+    }
+    // ---- per global slot
+    const int64_t N = a.N, N_all = (int64_t)a.G * N;
+    const int64_t i = (int64_t)blockIdx.x * 256 + t;
+    const bool live = i < N_all;
+    const int d = live ? (int)(i / N) : 0;
+    int o = d, b = 0;
+    double tq = 0.0;
+    bool upper = false, past = false;
+    if (live && usable) {
+        if (a.mode == MIDAS_RESAMPLE_MULTINOMIAL) {
+            tq = a.u_all ? a.u_all[i] : philox_uniform53((uint64_t)i, a.seed, a.step);
+        } else {
+            const float r = a.u32 >= 0.0f ? a.u32 : philox_uniform24(a.seed, a.step);
+            const float off = r / (float)N_all;
+            tq = (double)i / (double)N_all + (double)off;
+            tq = tq >= 1.0 ? tq - 1.0 : tq;
+            upper = true;
+        }
+        int lo = 0, hi = nb_all;
+        while (hi > lo) {
+            const int mid = lo + ((hi - lo) >> 1);
+            const double c = s_end[mid];
+            if (upper ? (c <= tq) : (c < tq)) lo = mid + 1; else hi = mid;
+        }
+        past = lo >= nb_all;  // beyond every block end: the last particle
+        b = past ? nb_all - 1 : lo;
+        o = b / a.nb;
+    }
+    if (!PACK) {
+        if (live) {
+            if (o == a.rank) atomicAdd(&s_hist[d], 1);
+            if (d == a.rank) atomicAdd(&s_hist[64 + o], 1);
+        }
+        __syncthreads();
+        if (t < a.G) {
+            if (s_hist[t]) atomicAdd(&a.counts[t], s_hist[t]);
+            if (s_hist[64 + t]) atomicAdd(&a.counts[a.G + t], s_hist[64 + t]);
+        }
+        return;
+    }
+    // ---- PACK: this rank's own masked weights, then the rows it owns
+    const double* __restrict__ ev = apply ? a.e : a.x_raw;
+    if (live && d == a.rank) {
+        const int64_t il = i - (int64_t)a.rank * N;
+        a.weights[il] = (ev[il] / S) * (a.valid[il] ? 1.0 : 0.0);
+    }
+    const bool mine = live && o == a.rank;
+    const int d0 = (int)(((int64_t)blockIdx.x * 256) / N);  // a workgroup spans at most two destinations (N >= 256)
+    int pos = 0;
+    if (mine) pos = atomicAdd(&s_cnt[d - d0], 1);
+    __syncthreads();
+    if (t < 2 && s_cnt[t]) s_base[t] = atomicAdd(&a.cursor[d0 + t], s_cnt[t]);
+    __syncthreads();
+    if (mine) {
+        int64_t src;
+        if (!usable) src = i - (int64_t)a.rank * N;  // the resampler keeps the particles
+        else if (past) src = N - 1;
+        else
+            src = search_in_block(apply ? a.lp : a.lp_raw, apply ? a.gend : a.gend_raw, apply ? a.ggend : a.ggend_raw,
+                                  b - a.rank * a.nb, N, a.rank == a.G - 1 ? N - 1 : -1, s_bp[b], total, tq, upper);
+        char* rp = a.send + (size_t)(s_soff[d] + s_base[d - d0] + pos) * ROUTE_REC;
+        const float4* ps = reinterpret_cast<const float4*>(a.poses_prop + src * 16);
+        const float4 r0 = ps[0], r1 = ps[1], r2 = ps[2], r3 = ps[3];
+        const double w = (ev[src] / S) * (a.valid[src] ? 1.0 : 0.0);
+        const int32_t nn = a.nn_idx[src];
+        // records are 8-byte aligned (88 = 8 x 11): everything goes out as 8-byte pieces
+        reinterpret_cast<int2*>(rp)[0] = make_int2((int)(i - (int64_t)d * N), (int)((int64_t)a.rank * N + src));
+        reinterpret_cast<int2*>(rp)[1] = make_int2(nn, 0);
+        *reinterpret_cast<double*>(rp + 16) = w;
+        float2* p2 = reinterpret_cast<float2*>(rp + 24);
+        p2[0] = make_float2(r0.x, r0.y); p2[1] = make_float2(r0.z, r0.w);
+        p2[2] = make_float2(r1.x, r1.y); p2[3] = make_float2(r1.z, r1.w);
+        p2[4] = make_float2(r2.x, r2.y); p2[5] = make_float2(r2.z, r2.w);
+        p2[6] = make_float2(r3.x, r3.y); p2[7] = make_float2(r3.z, r3.w);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_shard_unpack(int64_t N, const char* __restrict__ recv, int32_t* __restrict__ ridx,
+                                                      float* __restrict__ poses_out, double* __restrict__ weights_out,
+                                                      int32_t* __restrict__ hint_out) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    const char* rp = recv + (size_t)r * ROUTE_REC;
+    const int2 h0 = *reinterpret_cast<const int2*>(rp), h1 = *reinterpret_cast<const int2*>(rp + 8);
+    const double w = *reinterpret_cast<const double*>(rp + 16);
+    const float2* p2 = reinterpret_cast<const float2*>(rp + 24);
+    float2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = p2[k];
+    const int64_t slot = h0.x;
+    ridx[slot] = h0.y;
+    hint_out[slot] = h1.x;
+    weights_out[slot] = w;
+    float2* pd = reinterpret_cast<float2*>(poses_out + slot * 16);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pd[k] = v[k];
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 #define LAUNCH_CHECK(ctx) MIDAS_HIP_CHECK(ctx, hipGetLastError())
@@ -1206,12 +1428,12 @@ int launch_tail_a(midas_ctx* ctx, int64_t N, const double* x, const uint8_t* val
     return MIDAS_OK;
 }
 
-int launch_tail_fin(midas_ctx* ctx, int64_t N, const double* e, const double* x_raw, const double* lp_raw, const uint8_t* valid,
-                    double* weights, double* cdf_io, int G, int nb, const double* r1_all, int rank, double n_total,
-                    int32_t softmax, double* rmse_out, int32_t* status) {
+int launch_tail_fin(midas_ctx* ctx, int64_t N, const double* e, const double* x_raw, const double* lp, const double* lp_raw,
+                    const uint8_t* valid, double* weights, double* cdf_io, int G, int nb, const double* r1_all, int rank,
+                    double n_total, int32_t softmax, double* rmse_out, int32_t* status) {
     if ((int64_t)G * nb > TB_MAX_BLOCKS)
         return midas_set_error(ctx, MIDAS_ERR_INVALID, "G*nb", "more than 4 M particles in total in the sharded step");
-    hipLaunchKernelGGL(k_tail_fin, dim3((unsigned)ceil_div(N, SCAN_BLOCK)), dim3(256), 0, ctx->stream, N, e, x_raw, lp_raw, valid,
+    hipLaunchKernelGGL(k_tail_fin, dim3((unsigned)ceil_div(N, SCAN_BLOCK)), dim3(256), 0, ctx->stream, N, e, x_raw, lp, lp_raw, valid,
                        weights, cdf_io, G, nb, r1_all, rank, n_total, softmax, rmse_out, status);
     LAUNCH_CHECK(ctx);
     return MIDAS_OK;
@@ -1219,14 +1441,10 @@ int launch_tail_fin(midas_ctx* ctx, int64_t N, const double* e, const double* x_
 
 // TA2 of one shard: the exchange record r1 = [bsum_e | btot | btot_raw | bmax | bmin | NaN count, kept count | ...]
 int launch_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
-                        int32_t softmax, double* e, double* x_raw, double* lp, double* lp_raw, double* r1, int32_t* status) {
-    const int nb = (int)ceil_div(N, SCAN_BLOCK), ng = (int)ceil_div(N, SCAN_CHUNK);
-    void* sc;
-    int rc = midas_scratch(ctx, ((size_t)ng * 2 + (size_t)nb * 32) * sizeof(double), &sc);  // chunk / group-end tables (unused here)
-    if (rc) return rc;
-    double* gend = (double*)sc;
-    hipLaunchKernelGGL(k_tail_a2, dim3((unsigned)nb), dim3(256), 0, ctx->stream, N, scores, nn_idx, valid, softmax, e, x_raw, lp,
-                       lp_raw, gend, gend + ng, gend + 2 * ng, gend + 2 * ng + 16 * nb, r1, r1 + nb, r1 + 2 * nb, r1 + 3 * nb, r1 + 4 * nb,
+                        int32_t softmax, const TailTables& tb, double* r1, int32_t* status) {
+    const int nb = (int)ceil_div(N, SCAN_BLOCK);
+    hipLaunchKernelGGL(k_tail_a2, dim3((unsigned)nb), dim3(256), 0, ctx->stream, N, scores, nn_idx, valid, softmax, tb.e, tb.x_raw,
+                       tb.lp, tb.lp_raw, tb.gend, tb.gend_raw, tb.ggend, tb.ggend_raw, r1, r1 + nb, r1 + 2 * nb, r1 + 3 * nb, r1 + 4 * nb,
                        status, r1 + 5 * nb);
     LAUNCH_CHECK(ctx);
     return MIDAS_OK;
@@ -1278,6 +1496,37 @@ int launch_tail_b2(midas_ctx* ctx, const StepTailArgs& a, const TailTables& tb) 
     b.part_rmse = a.part_rmse; b.nrm = a.part_rmse ? particle_update_blocks(a.N) : 0; b.rmse_out = a.rmse_out;
     hipLaunchKernelGGL(k_tail_b2, dim3((unsigned)ceil_div(a.N, 256)), dim3(256), (size_t)(nt + 3 * nb) * sizeof(double),
                        ctx->stream, b);
+    LAUNCH_CHECK(ctx);
+    return MIDAS_OK;
+}
+
+int launch_shard_route(midas_ctx* ctx, const midas_shard_route_args& r, const TailTables& tb, bool pack) {
+    const int nb = (int)ceil_div(r.N, SCAN_BLOCK);
+    if ((int64_t)r.G * nb > TB_MAX_BLOCKS)
+        return midas_set_error(ctx, MIDAS_ERR_INVALID, "G*nb", "more than 4 M particles in total in the sharded step");
+    ShardRouteArgs a;
+    a.N = r.N; a.G = r.G; a.rank = r.rank; a.nb = nb; a.r1_all = r.r1_all_dev;
+    a.e = tb.e; a.x_raw = tb.x_raw; a.lp = tb.lp; a.lp_raw = tb.lp_raw; a.gend = tb.gend; a.gend_raw = tb.gend_raw;
+    a.ggend = tb.ggend; a.ggend_raw = tb.ggend_raw;
+    a.valid = r.valid_dev; a.nn_idx = r.nn_idx_dev; a.poses_prop = r.poses_prop_dev;
+    a.status = r.status_dev; a.rmse_out = r.rmse_dev; a.n_total = (double)r.G * (double)r.N;
+    a.softmax = r.softmax; a.mode = r.resample_mode; a.u_all = r.u_all_dev; a.u32 = r.u32; a.seed = r.seed; a.step = r.step;
+    a.counts = r.counts_dev; a.cursor = r.counts_dev + 2 * r.G; a.send = (char*)r.send_dev; a.weights = r.weights_dev;
+    const unsigned grid = (unsigned)ceil_div((int64_t)r.G * r.N, 256);
+    if (pack) {
+        hipLaunchKernelGGL(k_shard_route<true>, dim3(grid), dim3(256), 0, ctx->stream, a);
+    } else {
+        MIDAS_HIP_CHECK(ctx, hipMemsetAsync(r.counts_dev, 0, (size_t)3 * r.G * sizeof(int32_t), ctx->stream));
+        hipLaunchKernelGGL(k_shard_route<false>, dim3(grid), dim3(256), 0, ctx->stream, a);
+    }
+    LAUNCH_CHECK(ctx);
+    return MIDAS_OK;
+}
+
+int launch_shard_unpack(midas_ctx* ctx, int64_t N, const void* recv, int32_t* ridx, float* poses_out, double* weights_out,
+                        int32_t* hint_out) {
+    hipLaunchKernelGGL(k_shard_unpack, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, N, (const char*)recv, ridx,
+                       poses_out, weights_out, hint_out);
     LAUNCH_CHECK(ctx);
     return MIDAS_OK;
 }

@@ -1,0 +1,75 @@
+// resample_search.hpp - the slot of a draw inside a 4096-slot summation block, shared by the pipelined front
+// (particles.hip, lazy_source) and the owner-side routing of the sharded step (resample.hip, k_shard_route_*).
+#pragma once
+#include "midas_internal.hpp"
+
+namespace midas {
+
+// lp / gend / ggend: block-local prefix of e*valid per slot / at the chunk ends / at the 256-slot group ends (k_tail_a2's
+// tables of this GPU's particles, padded to whole 16-value lines).  b = block index in those arrays, N = their particle
+// count, one_slot = index of the slot whose cdf is forced to 1 (the globally last particle) or -1; bp = exclusive
+// prefix of the block totals before block b in GLOBAL block order, total = sum of all block totals.  The block was
+// chosen on the exact predicate (its end value is not left of the draw, the previous block's is), so the answer lies
+// inside it.  Returns the first slot i of the block with not left(cdf_i), cdf_i = (bp + lp_i) / total, where
+// left(c) = c < tq (multinomial, lower bound) or c <= tq (systematic, upper bound).
+MD int64_t search_in_block(const double* __restrict__ lp, const double* __restrict__ gend, const double* __restrict__ ggend,
+                           int b, int64_t N, int64_t one_slot, double bp, double total, double tq, bool upper) {
+    const double tt = tq * total;
+    auto left = [&](double c) { return upper ? (c <= tt) : (c < tt); };
+    auto left_exact = [&](double c) { return upper ? (c <= tq) : (c < tq); };
+    const int64_t b_lo = (int64_t)b << 12, b_hi = b_lo + SCAN_BLOCK < N ? b_lo + SCAN_BLOCK : N;
+    // Three levels, one 128-byte line each (16 prefix values fetched together with eight aligned 16-byte loads,
+    // position = how many are left of the draw on the division-free comparison): 256-slot group ends of the block,
+    // chunk ends of the group, slots of the chunk.  Values past the end of the data are not counted.
+    double v[SCAN_CHUNK];
+    auto fetch16 = [&](const double* __restrict__ p) {
+        const double2* p2 = reinterpret_cast<const double2*>(p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const double2 w = p2[j]; v[2 * j] = w.x; v[2 * j + 1] = w.y; }
+    };
+    const int n_chunks = (int)((b_hi - b_lo + SCAN_CHUNK - 1) >> 4), n_groups = (n_chunks + 15) >> 4;
+    fetch16(ggend + (int64_t)b * 16);
+    int g = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) g += (j < n_groups && left(bp + v[j])) ? 1 : 0;
+    g = g < n_groups ? g : n_groups - 1;
+    const int64_t c0 = (b_lo >> 4) + 16 * g;
+    fetch16(gend + c0);
+    const int n_in_group = n_chunks - 16 * g < 16 ? n_chunks - 16 * g : 16;
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) c += (j < n_in_group && left(bp + v[j])) ? 1 : 0;
+    c = c < n_in_group ? c : n_in_group - 1;
+    const int64_t s0 = (c0 + c) << 4;
+    const double v_prev = lp[s0 > b_lo ? s0 - 1 : b_lo];  // the slot before the chunk (same block)
+    fetch16(lp + s0);
+    int pos = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) pos += (s0 + j < b_hi && left(bp + v[j])) ? 1 : 0;
+    int64_t l2 = s0 + pos;
+    // exact fix-up: the predicate on cdf_i is monotone in i; the two neighbours of the boundary are normally in
+    // registers, otherwise walk (inside the block: its end is exact)
+    double vm = v_prev, vp = 0.0;
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) { vm = (j == pos - 1) ? v[j] : vm; vp = (j == pos) ? v[j] : vp; }
+    auto cdfv = [&](int64_t i, double lpv) { return (i == one_slot) ? 1.0 : (bp + lpv) / total; };
+    bool walk = l2 >= b_hi;
+    if (!walk) {
+        if (l2 > b_lo) walk |= !left_exact(cdfv(l2 - 1, vm));
+        walk |= pos >= SCAN_CHUNK || left_exact(cdfv(l2, vp));
+    }
+    if (walk) {
+        if (l2 >= b_hi) l2 = b_hi - 1;
+        while (l2 > b_lo) {
+            if (left_exact(cdfv(l2 - 1, lp[l2 - 1]))) break;
+            --l2;
+        }
+        while (l2 < b_hi - 1) {
+            if (!left_exact(cdfv(l2, lp[l2]))) break;
+            ++l2;
+        }
+    }
+    return l2;
+}
+
+}  // namespace midas

@@ -2,14 +2,17 @@
 
 SURVEY.md 8(e): rank r owns the global particle slots [r*N, (r+1)*N) and a full replica of the codebook,
 the NN index and the mesh index.  One frame is the single-GPU frame (engine.FilterEngine.step) cut at
-its global reductions; between the local kernels the ranks exchange, with `all_gather`:
+its global reductions; between the local kernels the ranks exchange:
 
-  R1  5nb+4 doubles    per 4096-slot block: sum of exp(x - 1) (softmax denominator), totals of exp * mask and of
-                       x * mask (CDF offsets / total of the softmax and of the raw variant), max x, min x (the
-                       isclose guard is global); then NaN count, kept count, rmse partial sums - all in the
-                       fixed summation order
-  R2  84 N bytes/rank  ONE packed record block [cdf | weights | propagated poses | NN indices]: the
-                       cross-rank resample reads any rank's particle from the gathered blocks
+  R1  all_gather, 5nb+4 doubles/rank: per 4096-slot block the sum of exp(x - 1) (softmax denominator), the totals of
+      exp * mask and of x * mask (CDF offsets / total of the softmax and of the raw variant), max x, min x (the isclose
+      guard is global); then NaN count, kept count, rmse partial sums - all in the fixed summation order
+  R2  the resampled particles.  exchange="a2a" (default): the draw of a slot is a pure function of the slot, so after
+      R1 every rank can tell for every slot of the filter which rank owns its source; the OWNER resolves the source in
+      its own tables and sends that one 88-byte row to the rank holding the slot - an all_to_all of N rows per rank in
+      total (the split sizes are read back from the device, one small synchronisation per frame).
+      exchange="allgather": every rank materialises its slice of the global CDF and all ranks gather ONE packed block
+      [cdf | weights | propagated poses | NN indices] (84 N bytes per rank, G-1 times the bytes, no read-back).
 
 The local kernels are the single-GPU ones: the fused front (particle update + codebook scoring in one launch)
 and the deferred tail that gathers the scores itself.
@@ -30,9 +33,10 @@ import ctypes as C
 import torch
 
 from . import _lib, ops
-from ._lib import MidasError, ShardFrontArgs, TailResampleArgs, _ptr
+from ._lib import MidasError, ShardFrontArgs, ShardRouteArgs, TailResampleArgs, _ptr
 
 BLOCK = 4096  # summation block of the CDF spec (csrc/resample.hip)
+ROUTE_REC = 88  # bytes per routed particle row (include/midas_hip.h)
 
 
 class HipShardBackend:
@@ -92,13 +96,40 @@ class HipShardBackend:
                                                       self.tree6.h, self.tree3.h, C.byref(a)))
 
     def tail_a(self, st, softmax):
-        self.ctx.call("midas_shard_tail_a", st.N, _ptr(st.scores), _ptr(st.nn_idx), _ptr(st.valid), int(softmax), _ptr(st.e),
-                      _ptr(st.x), _ptr(st.cdf), _ptr(st.lp_raw), _ptr(st.r1), _ptr(st.status))
+        self.ctx.call("midas_shard_tail_a", st.N, _ptr(st.scores), _ptr(st.nn_idx), _ptr(st.valid), int(softmax), _ptr(st.tables),
+                      _ptr(st.r1), _ptr(st.status))
 
     def tail_fin(self, st, r1_all, rank, world, n_total, softmax, want_rmse):
-        self.ctx.call("midas_shard_tail_fin", st.N, _ptr(st.e), _ptr(st.x), _ptr(st.lp_raw), _ptr(st.valid), _ptr(st.weights),
-                      _ptr(st.cdf), world, _ptr(r1_all), rank, n_total, int(softmax),
-                      _ptr(st.rmse) if want_rmse else None, _ptr(st.status))
+        self.ctx.call("midas_shard_tail_fin", st.N, _ptr(st.tables), _ptr(st.valid), _ptr(st.weights), _ptr(st.cdf), world,
+                      _ptr(r1_all), rank, n_total, int(softmax), _ptr(st.rmse) if want_rmse else None, _ptr(st.status))
+
+    # ---- owner-side resample ---------------------------------------------------------------------------------
+    def _route_args(self, st, r1_all, rank, world, softmax, mode, u_all, u32, seed, step, want_rmse):
+        a = ShardRouteArgs()
+        a.N, a.G, a.rank = st.N, world, rank
+        a.r1_all, a.tables, a.valid, a.nn_idx, a.poses_prop = _ptr(r1_all), _ptr(st.tables), _ptr(st.valid), _ptr(st.nn_idx), _ptr(st.poses_prop)
+        a.status, a.rmse = _ptr(st.status), (_ptr(st.rmse) if want_rmse else None)
+        a.softmax, a.resample_mode, a.u_all, a.u32, a.seed, a.step = int(softmax), mode, _ptr(u_all), float(u32), seed, step
+        a.counts, a.weights = _ptr(st.counts), _ptr(st.weights)
+        return a
+
+    def route(self, st, r1_all, rank, world, softmax, mode, u_all, u32, seed, step, want_rmse):
+        """-> (send buffer, rows sent to each rank, rows received from each rank)."""
+        a = self._route_args(st, r1_all, rank, world, softmax, mode, u_all, u32, seed, step, want_rmse)
+        self.ctx.bind_current_stream()
+        self.ctx.check(self.ctx.lib.midas_shard_route_count(self.ctx.h, C.byref(a)))
+        counts = st.counts[:2 * world].tolist()  # the split sizes: the one host read-back of the frame
+        sends, recvs = counts[:world], counts[world:]
+        rows = max(sum(sends), 1)
+        send = getattr(st, "_send", None)
+        if send is None or send.numel() < rows * ROUTE_REC:  # kept across frames; a rank owns ~N sources, up to G*N
+            send = st._send = torch.empty((max(rows, 2 * st.N) * ROUTE_REC,), dtype=torch.uint8, device=self.device)
+        a.send = _ptr(send)
+        self.ctx.check(self.ctx.lib.midas_shard_route_pack(self.ctx.h, C.byref(a)))
+        return send[:sum(sends) * ROUTE_REC], sends, recvs
+
+    def unpack(self, st, recv):
+        self.ctx.call("midas_shard_unpack", st.N, _ptr(recv), _ptr(st.ridx), _ptr(st.poses), _ptr(st.weights_res), _ptr(st.hint))
 
     def tail_resample(self, st, pack_all, n_all, mode, u, u32, seed, step):
         a = TailResampleArgs()
@@ -130,13 +161,16 @@ class ShardState:
         self.weights = self.pack[8 * N:16 * N].view(torch.float64)
         self.poses_prop = self.pack[16 * N:80 * N].view(torch.float32).view(N, 4, 4)
         self.nn_idx = self.pack[80 * N:84 * N].view(torch.int32)
-        self.x = e((N,), torch.float64)             # raw scores (written where the isclose guard may fire)
-        self.lp_raw = e((N,), torch.float64)        # block-local prefix of x * mask (likewise)
+        # softmax / CDF tables of the shard (include/midas_hip.h midas_shard_tail_a): e | x | lp | lp_raw | chunk ends x2 |
+        # group ends x2, per-slot and per-chunk arrays padded to multiples of 16
+        ng = (N + 15) // 16
+        self.tables = e((4 * (-(-N // 16) * 16) + 2 * (-(-ng // 16) * 16) + 32 * self.nb,), torch.float64)
+        self.tables.zero_()
+        self.counts = e((3 * 64,), torch.int32)     # send counts | receive counts | scratch of the owner-side resample
         self.scores = e((int(K),), torch.float64)   # the frame's codebook scores
         self.valid = e((N,), torch.uint8)
         self.hint = e((N,), torch.int32)
         self.ridx = e((N,), torch.int32)
-        self.e = e((N,), torch.float64)
         self.r1 = e((5 * self.nb + 4,), torch.float64)  # exchange record (see the module docstring)
         self.status = e((2,), torch.int32)
         self.rmse = e((2,), torch.float64)
@@ -166,17 +200,26 @@ class TorchDistComm:
         return out
 
 
+    def all_to_all(self, send: torch.Tensor, in_splits, out_splits) -> torch.Tensor:
+        out = torch.empty((sum(out_splits),), dtype=send.dtype, device=send.device)
+        self.dist.all_to_all_single(out, send.contiguous(), list(out_splits), list(in_splits), group=self.group)
+        return out
+
+
 class SingleComm:
     rank, world = 0, 1
 
     def all_gather(self, t):
         return t
 
+    def all_to_all(self, send, in_splits, out_splits):
+        return send
+
 
 class ShardedFilterEngine:
     def __init__(self, cb_poses=None, cb_embeddings=None, mesh_vertices=None, num_particles: int = 0, *, sig_t=2e-4,
                  sig_r=0.5, pen_max=0.002, seed=4000, softmax=True, resample="weighted_random", device=None,
-                 comm=None, backend=None, rank=None, world=None, shard_codebook_rows=False):
+                 comm=None, backend=None, rank=None, world=None, shard_codebook_rows=False, exchange="auto"):
         if comm is None:
             import torch.distributed as dist
 
@@ -197,6 +240,11 @@ class ShardedFilterEngine:
                      "low_var_batch": _lib.RESAMPLE_SYSTEMATIC}[resample]
         self.step_count = 0
         self.use_hint = True
+        if exchange not in ("auto", "a2a", "allgather"):
+            raise MidasError("exchange must be 'auto', 'a2a' or 'allgather'")
+        # the owner-side form moves 1/(G-1) of the bytes but reads the split sizes back once per frame: it pays off
+        # from four ranks on
+        self.exchange = ("a2a" if self.world >= 4 else "allgather") if exchange == "auto" else exchange
 
     # convenience views used by bench.py / tests (same names as FilterEngine)
     poses = property(lambda self: self.st.poses)
@@ -233,31 +281,52 @@ class ShardedFilterEngine:
                 self.pen_max, self.use_hint, scores_ready=ready)
         b.tail_a(st, self.softmax)
         r1_all = yield st.r1
-        b.tail_fin(st, r1_all, self.rank, G, self.N_total, self.softmax, gt is not None)
-        pack_all = yield st.pack
-        b.tail_resample(st, pack_all, self.N_total, self.mode, u, u32, self.seed, self.step_count)
+        if self.exchange == "a2a":
+            # u (parity mode) must hold the uniforms of ALL slots of the filter here, the same on every rank
+            send, sends, recvs = b.route(st, r1_all, self.rank, G, self.softmax, self.mode, u, u32, self.seed, self.step_count,
+                                         gt is not None)
+            recv = yield ("a2a", send, [n * ROUTE_REC for n in sends], [n * ROUTE_REC for n in recvs])
+            b.unpack(st, recv)
+        else:
+            b.tail_fin(st, r1_all, self.rank, G, self.N_total, self.softmax, gt is not None)
+            pack_all = yield st.pack
+            b.tail_resample(st, pack_all, self.N_total, self.mode, u, u32, self.seed, self.step_count)
         self.step_count += 1
+
+    def _exchange(self, msg):
+        if isinstance(msg, tuple):
+            return self.comm.all_to_all(msg[1], msg[2], msg[3])
+        return self.comm.all_gather(msg)
 
     def step(self, odom, code, gt=None, **draws):
         gen = self.step_gen(odom, code, gt, **draws)
         try:
             msg = next(gen)
             while True:
-                msg = gen.send(self.comm.all_gather(msg))
+                msg = gen.send(self._exchange(msg))
         except StopIteration:
             pass
 
 
 def run_lockstep(engines, per_rank_args):
-    """Step several shards of ONE process in lock-step (tests): gathers are concatenations in rank order."""
+    """Step several shards of ONE process in lock-step (tests): gathers are concatenations in rank order, the
+    all_to_all hands every shard the segments the others addressed to it."""
     gens = [e.step_gen(*a[0], **a[1]) for e, a in zip(engines, per_rank_args)]
     msgs = [next(g) for g in gens]
     while True:
-        gathered = torch.cat([m.reshape((m.shape[0],) + tuple(m.shape[1:])) for m in msgs], dim=0)
+        if isinstance(msgs[0], tuple):
+            G = len(msgs)
+            offs = [[sum(m[2][:d]) for d in range(G)] for m in msgs]
+            replies = [torch.cat([msgs[s_][1][offs[s_][d]:offs[s_][d] + msgs[s_][2][d]] for s_ in range(G)]) for d in range(G)]
+            for d in range(G):
+                assert [msgs[s_][2][d] for s_ in range(G)] == list(msgs[d][3]), "send / receive counts disagree"
+        else:
+            gathered = torch.cat([m.reshape((m.shape[0],) + tuple(m.shape[1:])) for m in msgs], dim=0)
+            replies = [gathered] * len(gens)
         nxt, done = [], 0
-        for g in gens:
+        for g, r in zip(gens, replies):
             try:
-                nxt.append(g.send(gathered))
+                nxt.append(g.send(r))
             except StopIteration:
                 done += 1
         if done:

@@ -25,7 +25,7 @@ def _data():
     return cb, traj, start
 
 
-def _worker(rank, world, port, mode, out_dir):
+def _worker(rank, world, port, mode, exchange, out_dir):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -33,7 +33,7 @@ def _worker(rank, world, port, mode, out_dir):
     from tests._oracle_shard_backend import OracleShardBackend
     cb, traj, start = _data()
     eng = ShardedFilterEngine(num_particles=N_LOC, backend=OracleShardBackend(cb.poses, cb.embeddings, cb.mesh_vertices),
-                              resample=mode, seed=4000)
+                              resample=mode, seed=4000, exchange=exchange)
     assert eng.world == world and eng.rank == rank
     eng.set_particles(torch.as_tensor(start[rank * N_LOC:(rank + 1) * N_LOC]))
     res = []
@@ -54,10 +54,11 @@ def _free_port():
     return p
 
 
+@pytest.mark.parametrize("exchange", ["a2a", "allgather"])
 @pytest.mark.parametrize("mode", ["weighted_random", "low_var"])
-def test_two_rank_gloo_equals_single_process(tmp_path, oracle, mode):
+def test_two_rank_gloo_equals_single_process(tmp_path, oracle, mode, exchange):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), mode, exchange, str(tmp_path)), nprocs=world, join=True)
     parts = [torch.load(os.path.join(tmp_path, f"r{r}.pt"), weights_only=False) for r in range(world)]
     cb, traj, start = _data()
     ofl = oracle.OracleFilter(cb.poses, cb.embeddings, cb.mesh_vertices)

@@ -22,9 +22,12 @@ class FakeComm:
     def all_gather(self, t):
         raise AssertionError("lock-step test never calls the communicator")
 
+    all_to_all = all_gather
 
+
+@pytest.mark.parametrize("exchange", ["a2a", "allgather"])
 @pytest.mark.parametrize("shards,mode", [(2, "weighted_random"), (3, "low_var"), (1, "weighted_random")])
-def test_sharded_hip_equals_fused_engine(dev, shards, mode):
+def test_sharded_hip_equals_fused_engine(dev, shards, mode, exchange):
     from midastouch_amd.dist import HipShardBackend, ShardedFilterEngine, run_lockstep
     from midastouch_amd.engine import FilterEngine
     from midastouch_amd.synthetic import make_codebook, make_trajectory
@@ -38,7 +41,8 @@ def test_sharded_hip_equals_fused_engine(dev, shards, mode):
     single.set_particles(torch.as_tensor(start))
     single.project_to_codebook()
     be = HipShardBackend(cb.poses, cb.embeddings, cb.mesh_vertices, dev)
-    engs = [ShardedFilterEngine(num_particles=n_loc, backend=be, comm=FakeComm(r, shards), resample=mode) for r in range(shards)]
+    engs = [ShardedFilterEngine(num_particles=n_loc, backend=be, comm=FakeComm(r, shards), resample=mode, exchange=exchange)
+            for r in range(shards)]
     for r, e in enumerate(engs):
         e.set_particles(torch.as_tensor(start[r * n_loc:(r + 1) * n_loc]))
         e.project_to_codebook()
@@ -87,7 +91,35 @@ def test_codebook_row_sharding_equals_replicated(dev):
         assert np.array_equal(cat("poses"), single.poses.cpu().numpy()), t
 
 
-def test_single_rank_process_group_nccl(dev):
+def test_sharded_host_uniforms_replicated(dev):
+    """Parity mode of the owner-side exchange: the uniforms of ALL slots are given to every shard."""
+    from midastouch_amd.dist import HipShardBackend, ShardedFilterEngine, run_lockstep
+    from midastouch_amd.engine import FilterEngine
+    from midastouch_amd.synthetic import make_codebook, make_trajectory
+    shards, n_loc, K, D = 2, 4096, 3000, 128
+    N = shards * n_loc
+    cb = make_codebook(K=K, D=D, seed=1000)
+    traj = make_trajectory(cb, T=6, seed=2000)
+    start = cb.poses[np.random.default_rng(3).integers(0, K, N)]
+    single = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, device=dev)
+    single.set_particles(torch.as_tensor(start))
+    be = HipShardBackend(cb.poses, cb.embeddings, cb.mesh_vertices, dev)
+    engs = [ShardedFilterEngine(num_particles=n_loc, backend=be, comm=FakeComm(r, shards)) for r in range(shards)]
+    for r, e in enumerate(engs):
+        e.set_particles(torch.as_tensor(start[r * n_loc:(r + 1) * n_loc]))
+    for t in range(1, 5):
+        od, code = torch.as_tensor(traj.odoms[t]).to(dev), torch.as_tensor(traj.codes[t]).to(dev)
+        torch.manual_seed(77 + t)
+        u = torch.rand(N, dtype=torch.float64).to(dev)
+        single.step(od, code, u=u)
+        run_lockstep(engs, [((od, code), {"u": u}) for _ in engs])
+        cat = lambda name: torch.cat([getattr(e, name) for e in engs]).cpu().numpy()
+        assert np.array_equal(cat("ridx"), single.ridx.cpu().numpy()), t
+        assert np.array_equal(cat("poses"), single.poses.cpu().numpy()), t
+
+
+@pytest.mark.parametrize("exchange", ["a2a", "allgather"])
+def test_single_rank_process_group_nccl(dev, exchange):
     """world_size 1 through torch.distributed's nccl (= RCCL) backend: the real communicator path."""
     import os
     import torch.distributed as dist
@@ -103,7 +135,7 @@ def test_single_rank_process_group_nccl(dev):
         traj = make_trajectory(cb, T=6, seed=2000)
         start = cb.poses[np.random.default_rng(0).integers(0, K, n)]
         a = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, n, device=dev)
-        b = ShardedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, n, device=dev)
+        b = ShardedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, n, device=dev, exchange=exchange)
         assert b.world == 1
         for e in (a, b):
             e.set_particles(torch.as_tensor(start))
