@@ -84,6 +84,45 @@ def test_two_rank_gloo_equals_single_process(tmp_path, oracle, mode, exchange):
         poses = ref["poses"]
 
 
+def test_four_rank_gloo_auto_exchange(tmp_path, oracle):
+    """Four ranks: exchange='auto' picks the owner-side all_to_all; same bar (bit-identical to one process)."""
+    global N_LOC
+    world = 4
+    mp.spawn(_worker4, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(tmp_path, f"r{r}.pt"), weights_only=False) for r in range(world)]
+    assert all(p["exchange"] == "a2a" for p in parts)
+    cb, traj, _ = _data()
+    start = cb.poses[np.random.default_rng(5).integers(0, K, world * N_LOC)]
+    ofl = oracle.OracleFilter(cb.poses, cb.embeddings, cb.mesh_vertices)
+    poses, N = start, world * N_LOC
+    for t in range(1, 3):
+        tn, rot = oracle.philox_noise(N, 4000, t - 1, np.float32(2e-4), np.float32(0.5))
+        ref = ofl.step(poses, traj.odoms[t], traj.codes[t], tn, rot, u=oracle.philox_uniform64(N, 4000, t - 1))
+        assert np.array_equal(np.concatenate([p["res"][t - 1]["ridx"] for p in parts]), ref["ridx"]), f"frame {t}"
+        assert np.array_equal(np.concatenate([p["res"][t - 1]["poses"] for p in parts]), ref["poses"]), f"frame {t}"
+        assert np.array_equal(np.concatenate([p["res"][t - 1]["weights"] for p in parts]), ref["weights"]), f"frame {t}"
+        poses = ref["poses"]
+
+
+def _worker4(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from midastouch_amd.dist import ShardedFilterEngine
+    from tests._oracle_shard_backend import OracleShardBackend
+    cb, traj, _ = _data()
+    start = cb.poses[np.random.default_rng(5).integers(0, K, world * N_LOC)]
+    eng = ShardedFilterEngine(num_particles=N_LOC, backend=OracleShardBackend(cb.poses, cb.embeddings, cb.mesh_vertices), seed=4000)
+    eng.set_particles(torch.as_tensor(start[rank * N_LOC:(rank + 1) * N_LOC]))
+    res = []
+    for t in range(1, 3):
+        eng.step(torch.as_tensor(traj.odoms[t]), torch.as_tensor(traj.codes[t]))
+        res.append({"ridx": eng.ridx.numpy().copy(), "weights": eng.weights.numpy().copy(), "poses": eng.poses.numpy().copy()})
+    torch.save({"exchange": eng.exchange, "res": res}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def test_lockstep_three_shards_equal_single(oracle):
     """Same check without any collective library: three shards of one process stepped in lock-step."""
     from midastouch_amd.dist import ShardedFilterEngine, run_lockstep
