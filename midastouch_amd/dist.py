@@ -281,8 +281,8 @@ class ShardedFilterEngine:
                 self.pen_max, self.use_hint, scores_ready=ready)
         b.tail_a(st, self.softmax)
         r1_all = yield st.r1
+        # u (parity mode): the uniforms of ALL slots of the filter, the same tensor on every rank
         if self.exchange == "a2a":
-            # u (parity mode) must hold the uniforms of ALL slots of the filter here, the same on every rank
             send, sends, recvs = b.route(st, r1_all, self.rank, G, self.softmax, self.mode, u, u32, self.seed, self.step_count,
                                          gt is not None)
             recv = yield ("a2a", send, [n * ROUTE_REC for n in sends], [n * ROUTE_REC for n in recvs])
@@ -290,7 +290,8 @@ class ShardedFilterEngine:
         else:
             b.tail_fin(st, r1_all, self.rank, G, self.N_total, self.softmax, gt is not None)
             pack_all = yield st.pack
-            b.tail_resample(st, pack_all, self.N_total, self.mode, u, u32, self.seed, self.step_count)
+            u_loc = None if u is None else u[self.rank * self.N:(self.rank + 1) * self.N]
+            b.tail_resample(st, pack_all, self.N_total, self.mode, u_loc, u32, self.seed, self.step_count)
         self.step_count += 1
 
     def _exchange(self, msg):

@@ -91,8 +91,9 @@ def test_codebook_row_sharding_equals_replicated(dev):
         assert np.array_equal(cat("poses"), single.poses.cpu().numpy()), t
 
 
-def test_sharded_host_uniforms_replicated(dev):
-    """Parity mode of the owner-side exchange: the uniforms of ALL slots are given to every shard."""
+@pytest.mark.parametrize("exchange", ["a2a", "allgather"])
+def test_sharded_host_uniforms_replicated(dev, exchange):
+    """Parity mode: the uniforms of ALL slots are given to every shard (both exchange forms)."""
     from midastouch_amd.dist import HipShardBackend, ShardedFilterEngine, run_lockstep
     from midastouch_amd.engine import FilterEngine
     from midastouch_amd.synthetic import make_codebook, make_trajectory
@@ -104,7 +105,7 @@ def test_sharded_host_uniforms_replicated(dev):
     single = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, device=dev)
     single.set_particles(torch.as_tensor(start))
     be = HipShardBackend(cb.poses, cb.embeddings, cb.mesh_vertices, dev)
-    engs = [ShardedFilterEngine(num_particles=n_loc, backend=be, comm=FakeComm(r, shards)) for r in range(shards)]
+    engs = [ShardedFilterEngine(num_particles=n_loc, backend=be, comm=FakeComm(r, shards), exchange=exchange) for r in range(shards)]
     for r, e in enumerate(engs):
         e.set_particles(torch.as_tensor(start[r * n_loc:(r + 1) * n_loc]))
     for t in range(1, 5):
