@@ -4,7 +4,7 @@
 import json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from midastouch_amd.engine import BatchFilterEngine, FilterEngine
+from midastouch_amd.engine import BatchFilterEngine, FilterEngine, PipelinedFilterEngine
 from midastouch_amd.synthetic import make_codebook, make_trajectory
 dev = torch.device("cuda", 0)
 
@@ -19,11 +19,12 @@ def run(eng, step, n=100, warm=10):
 
 res = {}
 cb = make_codebook(K=5000, D=256, seed=1000); tr = make_trajectory(cb, T=130, seed=2000)
-eng = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, 1000, device=dev)
-eng.set_particles(torch.as_tensor(cb.poses[np.random.default_rng(0).integers(0, 5000, 1000)])); eng.project_to_codebook()
 od, co = torch.as_tensor(tr.odoms).to(dev), torch.as_tensor(tr.codes).to(dev)
-us = run(eng, lambda i: eng.step(od[1 + i % 128], co[1 + i % 128]))
-res["c1_N1k_K5k_D256"] = {"us_per_step": round(us, 1), "steps_per_s": round(1e6 / us)}
+for tag, cls in (("eager", FilterEngine), ("pipelined", PipelinedFilterEngine)):
+    eng = cls(cb.poses, cb.embeddings, cb.mesh_vertices, 1000, device=dev)
+    eng.set_particles(torch.as_tensor(cb.poses[np.random.default_rng(0).integers(0, 5000, 1000)])); eng.project_to_codebook()
+    us = run(eng, lambda i: eng.step(od[1 + i % 128], co[1 + i % 128]))
+    res["c1_N1k_K5k_D256_" + tag] = {"us_per_step": round(us, 1), "steps_per_s": round(1e6 / us)}
 
 cb = make_codebook("cotter-pin", K=50000, D=512, seed=1005)
 B, N = 64, 10000
@@ -38,9 +39,11 @@ res["c5_B64_N10k_K50k_D512"] = {"us_per_batch_step": round(us, 1), "trajectory_s
 
 cb = make_codebook("035_power_drill", K=50000, D=512, seed=1003); tr = make_trajectory(cb, T=70, seed=2003)
 N = 1_000_000
-eng = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, device=dev)
-eng.set_particles(torch.as_tensor(cb.poses[np.random.default_rng(2).integers(0, 50000, N)])); eng.project_to_codebook()
 od, co = torch.as_tensor(tr.odoms).to(dev), torch.as_tensor(tr.codes).to(dev)
-us = run(eng, lambda i: eng.step(od[1 + i % 68], co[1 + i % 68]), n=40)
-res["c3total_N1M_K50k_D512_single_gpu"] = {"us_per_step": round(us, 1), "steps_per_s": round(1e6 / us)}
+for tag, cls in (("eager", FilterEngine), ("pipelined", PipelinedFilterEngine)):
+    eng = cls(cb.poses, cb.embeddings, cb.mesh_vertices, N, device=dev)
+    eng.set_particles(torch.as_tensor(cb.poses[np.random.default_rng(2).integers(0, 50000, N)])); eng.project_to_codebook()
+    us = run(eng, lambda i: eng.step(od[1 + i % 68], co[1 + i % 68]), n=40)
+    res["c3total_N1M_K50k_D512_single_gpu_" + tag] = {"us_per_step": round(us, 1), "steps_per_s": round(1e6 / us)}
+    del eng
 print(json.dumps(res))
