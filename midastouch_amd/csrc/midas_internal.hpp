@@ -40,7 +40,10 @@ constexpr int KD_MAX_LEVELS = 10; // 8-ary levels (8^10 leaves x 16 slots is far
 // distance rho from F_k to that neighbour (rounded down), coordinates inlined so that one 32-byte
 // read is one candidate.  Unused records are sentinels (+inf coordinates, rho = +inf).
 struct alignas(16) Nbr6 { float c[6]; int32_t idx; float rho; };
-constexpr int NBR_M = 256;
+#ifndef MIDAS_NBR_M
+#define MIDAS_NBR_M 512
+#endif
+constexpr int NBR_M = MIDAS_NBR_M;
 constexpr int NBR_REC = NBR_M + 1;  // record 0 = the entry itself
 
 // Mesh-vertex record of the prune fast path: the vertices nearest to a codebook entry's translation.
