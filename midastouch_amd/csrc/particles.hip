@@ -688,86 +688,98 @@ MD void row_best(float& d, int& i) {
 #undef MIDAS_STEP
 }
 
-// Four owners at a time, one per 16-lane row: the row walks records NN_SOLO .. NN_SOLO+63 of its owner's list in four
-// steps of 16 (all eight loads per lane in flight together) and reduces inside the row with DPP - the four owners are
+// Four owners at a time, one per 16-lane row: the row walks the next 64 records of its owner's list in four steps of
+// 16 (all eight loads per lane in flight together) and reduces inside the row with DPP - the four owners are
 // evaluated by the same instructions, where the whole-wave form spent them once per owner.  The certificate is the
-// one of the 64-record chunk (its last record's rho against the final best); an owner it does not settle continues
-// with the whole-wave chunks and the twin entry.
+// one of the 64-record chunk (its last record's rho against the final best); an owner it does not settle comes back
+// in the next pass with its next 64 records, until its list is exhausted (then: the list's outer radius, the twin).
 MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_lane, float& best, int64_t& bi, bool need,
                  bool& done) {
     const int lane = threadIdx.x & 63, row = lane >> 4, j = lane & 15;
-    unsigned long long todo = __ballot(need);
-    const int my_rank = (int)__builtin_popcountll(todo & ((1ull << lane) - 1ull));  // rank of this lane among the owners
-    int served = 0;                                                                  // owners handled so far
-    while (todo) {
-        int owner[4];
+    int nrec = NN_SOLO;  // next record of this lane's list (owners only)
+    // pass after pass: every open owner gets its next 64 records, four owners per instruction stream
+    for (;;) {
+        const bool open_lane = need && !done && nrec <= NBR_M;
+        unsigned long long todo = __ballot(open_lane);
+        if (!todo) break;
+        const int my_rank = (int)__builtin_popcountll(todo & ((1ull << lane) - 1ull));  // rank among this pass's owners
+        int served = 0;
+        while (todo) {
+            int owner[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            owner[k] = todo ? (int)__builtin_ctzll(todo) : -1;
-            todo &= todo - 1;  // 0 & anything stays 0
-        }
-        const int mine = row == 0 ? owner[0] : row == 1 ? owner[1] : row == 2 ? owner[2] : owner[3];
-        const int src = mine >= 0 ? mine : lane;
-        float qq[6];
-#pragma unroll
-        for (int d = 0; d < 6; ++d) qq[d] = __shfl(q[d], src);
-        const float rr = __shfl(r_lane, src);
-        float bb = __shfl(best, src);
-        int b_i = __shfl((int)bi, src);
-        const int hh = __shfl(hint, src);
-        const Nbr6* nb = tv.nbrs + (size_t)(mine >= 0 ? hh : 0) * NBR_REC + NN_SOLO + j;
-        Nbr6 e[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) e[m] = nb[16 * m];
-        float d = INFINITY;
-        int id = 0x7fffffff;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            Point6 p;
-#pragma unroll
-            for (int a = 0; a < 6; ++a) p.c[a] = e[m].c[a];
-            const float dm = dist2(qq, p);
-            if (dm < d || (dm == d && e[m].idx < id)) { d = dm; id = e[m].idx; }  // NaN never wins
-        }
-        row_best(d, id);
-        if (d < bb || (d == bb && id < b_i)) { bb = d; b_i = id; }
-        const float rho_last = __shfl(e[3].rho, lane | 15);  // record NN_SOLO+63 of the row's owner
-        const float gg = fmaf_(rho_last - rr, 0.9999996f, -8e-7f * rr);
-        const bool cert = gg > 0.0f && gg * gg * 0.99997f > bb;
-        // hand the rows' results to the owners: owner with rank r among this group sits in row r - served
-        const int from = 16 * ((my_rank - served) & 3);
-        const float rb = __shfl(bb, from);
-        const int ri = __shfl(b_i, from);
-        const int rc = __shfl((int)cert, from);
-        const bool in_group = need && my_rank >= served && my_rank < served + 4;
-        if (in_group) { best = rb; bi = ri; done = rc != 0; }
-        served += 4;
-        // owners the chunk did not settle: whole-wave continuation, one at a time (rare)
-        unsigned long long open = __ballot(in_group && !done);
-        while (open) {
-            const int o = (int)__builtin_ctzll(open);
-            open &= open - 1;
-            float q1[6];
-#pragma unroll
-            for (int dd = 0; dd < 6; ++dd) q1[dd] = rl_f32(q[dd], o);
-            const float r1 = rl_f32(r_lane, o);
-            float b1 = rl_f32(best, o);
-            int i1 = rl_i32((int)bi, o);
-            const int h1 = rl_i32(hint, o);
-            bool c1 = coop_scan_list(tv, q1, h1, NN_SOLO + 64, r1, b1, i1);
-            if (!c1) {
-                const int tw = tv.twin[h1];
-                if (tw >= 0) {  // second chance from the entry across the angle-pi cut (record 0 = the twin itself)
-                    const Nbr6 ts = tv.nbrs[(size_t)tw * NBR_REC];
-                    Point6 pt;
-#pragma unroll
-                    for (int a = 0; a < 6; ++a) pt.c[a] = ts.c[a];
-                    const float r2 = __builtin_sqrtf(dist2(q1, pt));
-                    c1 = coop_scan_list(tv, q1, tw, 0, r2, b1, i1);
-                }
+            for (int k = 0; k < 4; ++k) {
+                owner[k] = todo ? (int)__builtin_ctzll(todo) : -1;
+                todo &= todo - 1;  // 0 & anything stays 0
             }
-            if (lane == o) { best = b1; bi = i1; done = c1; }
+            const int mine = row == 0 ? owner[0] : row == 1 ? owner[1] : row == 2 ? owner[2] : owner[3];
+            const int src = mine >= 0 ? mine : lane;
+            float qq[6];
+#pragma unroll
+            for (int d = 0; d < 6; ++d) qq[d] = __shfl(q[d], src);
+            const float rr = __shfl(r_lane, src);
+            float bb = __shfl(best, src);
+            int b_i = __shfl((int)bi, src);
+            // (shuffles stay unconditional: a lane outside the branch could not serve as a source)
+            const int hh_s = __shfl(hint, src), first_s = __shfl(nrec, src);
+            const int hh = mine >= 0 ? hh_s : 0;
+            const int first = mine >= 0 ? first_s : 0;  // records first .. first+63, clamped to the list
+            const Nbr6* nb = tv.nbrs + (size_t)hh * NBR_REC;
+            Nbr6 e[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int s = first + 16 * m + j;
+                e[m] = nb[s <= NBR_M ? s : NBR_M];
+            }
+            float d = INFINITY, rho_last = 0.f;
+            int id = 0x7fffffff;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                Point6 p;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) p.c[a] = e[m].c[a];
+                const float dm = dist2(qq, p);
+                const bool in = first + 16 * m + j <= NBR_M;
+                if (in && (dm < d || (dm == d && e[m].idx < id))) { d = dm; id = e[m].idx; }  // NaN never wins
+                rho_last = in ? e[m].rho : rho_last;
+            }
+            row_best(d, id);
+            if (d < bb || (d == bb && id < b_i)) { bb = d; b_i = id; }
+            // largest rho scanned = the last valid record of the chunk (clamped loads repeat the list's last record);
+            // once the list is exhausted the bound is the distance of the first entry NOT in it
+            rho_last = __shfl(rho_last, lane | 15);
+            const bool at_end = first + 63 >= NBR_M;
+            const float bound = at_end ? tv.rho_out[hh] : rho_last;
+            const float gg = fmaf_(bound - rr, 0.9999996f, -8e-7f * rr);
+            const bool cert = gg > 0.0f && gg * gg * 0.99997f > bb;
+            // hand the rows' results to the owners: owner with rank r among this group sits in row r - served
+            const int from = 16 * ((my_rank - served) & 3);
+            const float rb = __shfl(bb, from);
+            const int ri = __shfl(b_i, from);
+            const int rc = __shfl((int)cert, from);
+            if (open_lane && my_rank >= served && my_rank < served + 4) { best = rb; bi = ri; done = rc != 0; nrec += 64; }
+            served += 4;
         }
+    }
+    // lists exhausted without a certificate: second chance from the entry across the angle-pi cut, whole wave (rare)
+    unsigned long long open = __ballot(need && !done);
+    while (open) {
+        const int o = (int)__builtin_ctzll(open);
+        open &= open - 1;
+        const int h1 = rl_i32(hint, o);
+        const int tw = tv.twin[h1];
+        if (tw < 0) continue;
+        float q1[6];
+#pragma unroll
+        for (int dd = 0; dd < 6; ++dd) q1[dd] = rl_f32(q[dd], o);
+        float b1 = rl_f32(best, o);
+        int i1 = rl_i32((int)bi, o);
+        const Nbr6 ts = tv.nbrs[(size_t)tw * NBR_REC];  // record 0 = the twin itself
+        Point6 pt;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) pt.c[a] = ts.c[a];
+        const float r2 = __builtin_sqrtf(dist2(q1, pt));
+        const bool c1 = coop_scan_list(tv, q1, tw, 0, r2, b1, i1);
+        if (lane == o) { best = b1; bi = i1; done = c1; }
     }
 }
 
