@@ -115,7 +115,8 @@ MIDAS_EXPORT int midas_ctx_create(int device, void* hip_stream, midas_ctx** out)
     ctx->device = device;
     ctx->scratch = new (std::nothrow) ScratchState();
     // NULL selects the device's default (null) stream - torch's default stream on ROCm - so that
-    // kernels stay ordered with the caller's other work; the library never creates a stream.
+    // kernels stay ordered with the caller's other work.  The only stream the library creates is the side stream of
+    // the batch step, forked from and joined back into this stream by events inside midas_filter_step_batch.
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
     if (const char* ov = getenv("MIDAS_OVERLAP")) ctx->overlap = atoi(ov) != 0;
@@ -133,6 +134,12 @@ MIDAS_EXPORT int midas_ctx_destroy(midas_ctx* ctx) {
     if (ctx->ev_ready)
         for (auto& e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->side) {
+        (void)hipStreamSynchronize(ctx->side);
+        (void)hipEventDestroy(ctx->ev_fork);
+        (void)hipEventDestroy(ctx->ev_join);
+        (void)hipStreamDestroy(ctx->side);
+    }
     delete ctx;
     return MIDAS_OK;
 }
@@ -377,8 +384,19 @@ static int filter_step_impl(midas_ctx* ctx, const midas_codebook* cb, const mida
     // Single trajectory: the codebook scoring and the particle update share one launch (k_frame_front); the
     // tail then gathers the scores.  Other layouts / batches: scoring, then the particle update with the scores.
     void* lp_raw = nullptr;
-    if (B == 1 && ctx->overlap)
-        if ((rc = midas_scratch(ctx, N * sizeof(double), &lp_raw))) return rc;
+    // a batch scores all its codes in one pass over the codebook on the matrix cores when the layout allows it
+    const bool mfma = B > 1 && cb->dtype == MIDAS_F32 && cb->D % 16 == 0 && (uintptr_t)cb->emb % 16 == 0;
+    // Batch: that pass (a separate kernel shape: 1024-thread workgroups, 132 KB of LDS) runs on a side stream
+    // concurrently with the particle update, which does not need the scores; the fork / join events cost ~8 us,
+    // the overlap saves the ~60 us of the scoring.
+    const bool defer_batch = mfma && ctx->overlap;
+    if ((B == 1 && ctx->overlap) || defer_batch)
+        if ((rc = midas_scratch(ctx, Bz * N * sizeof(double), &lp_raw))) return rc;
+    if (defer_batch && !ctx->side) {
+        MIDAS_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        MIDAS_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        MIDAS_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
 
     if (ctx->prof && ctx->ev_ready) {  // calibration: an empty event pair measures the bracket overhead itself
         (void)hipEventRecord(ctx->ev[6], ctx->stream);
@@ -417,10 +435,22 @@ static int filter_step_impl(midas_ctx* ctx, const midas_codebook* cb, const mida
         prof_mark(ctx, 1);  // fused front: reported in the particle_update slot, the score slot stays empty
         if ((rc = launch_frame_front(ctx, tree6, tree3, pa, cb, s.code_dev, (double*)scores, &defer))) return rc;
     }
-    if (!defer) {
+    if (defer_batch) {
+        hipStream_t main_stream = ctx->stream;
+        MIDAS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, main_stream));  // the codes, and last frame's readers of `scores`
+        MIDAS_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+        ctx->stream = ctx->side;
+        rc = launch_score_batch(ctx, cb, B, s.code_dev, (double*)scores);
+        ctx->stream = main_stream;
+        if (rc) return rc;
+        MIDAS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join, ctx->side));
+        prof_mark(ctx, 1);
+        pa.scores = nullptr;  // deferred: the tail gathers the scores
+        if ((rc = launch_particle_update(ctx, tree6, tree3, pa))) return rc;
+        MIDAS_HIP_CHECK(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
+        defer = true;
+    } else if (!defer) {
         prof_mark(ctx, 0);
-        // a batch scores all its codes in one pass over the codebook on the matrix cores when the layout allows it
-        const bool mfma = B > 1 && cb->dtype == MIDAS_F32 && cb->D % 16 == 0 && (uintptr_t)cb->emb % 16 == 0;
         if ((rc = mfma ? launch_score_batch(ctx, cb, B, s.code_dev, (double*)scores)
                        : launch_score(ctx, cb, B, s.code_dev, (double*)scores)))
             return rc;
@@ -435,6 +465,7 @@ static int filter_step_impl(midas_ctx* ctx, const midas_codebook* cb, const mida
     ta.npart = npart;
     ta.x = defer ? nullptr : (const double*)x;
     ta.scores = (const double*)scores;
+    ta.score_stride = cb->K;
     ta.x_raw = (double*)x;
     ta.lp_raw = (double*)lp_raw;
     ta.e = (double*)e;

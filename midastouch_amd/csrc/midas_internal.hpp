@@ -84,6 +84,10 @@ struct midas_ctx {
     double prof_ms[MIDAS_PROF_SLOTS] = {};
     int64_t prof_calls = 0;
     bool overlap = true;  // MIDAS_OVERLAP=0: separate scoring and particle-update launches (the pre-fusion path)
+    // side stream of the batch step: the matrix-core scoring of the B codes runs there, concurrently with the particle
+    // update (created on first use, non-blocking, forked from / joined into `stream` by the two events)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 struct midas_codebook {
@@ -250,6 +254,7 @@ struct StepTailArgs {
     const double* scores = nullptr;
     double* x_raw = nullptr;   // [N] scratch: raw scores, written only where the guard may fire
     double* lp_raw = nullptr;  // [N] scratch: block-local prefix of x*valid, likewise
+    int64_t score_stride = 0;  // K: scores are (batch, K)
 };
 int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base);
 // the deferred tail on explicit tables (what k_tail_a2 writes and k_tail_b2 / the lazy front read)
@@ -259,7 +264,7 @@ struct TailTables {
     double *ggend, *ggend_raw;                                // [16 ceil(N/4096)]: block-local prefix at the end of each 256-slot group
 };
 int launch_tail_a2(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
-                   int32_t softmax, const TailTables& tb, int32_t* status);
+                   int32_t softmax, const TailTables& tb, int32_t* status, int batch = 1, int64_t score_stride = 0);
 int launch_tail_b2(midas_ctx* ctx, const StepTailArgs& a, const TailTables& tb);  // a.x, a.e, a.cdf, a.lp_raw unused
 int launch_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
                         int32_t softmax, const TailTables& tb, double* r1, int32_t* status);

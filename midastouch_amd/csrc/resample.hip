@@ -431,7 +431,14 @@ __global__ __launch_bounds__(256) void k_tail_a2(int64_t N, const double* __rest
                                                  double* __restrict__ bsum_e, double* __restrict__ btot_soft,
                                                  double* __restrict__ btot_raw, double* __restrict__ bmax,
                                                  double* __restrict__ bmin, int32_t* __restrict__ status,
-                                                 double* __restrict__ flags_out) {
+                                                 double* __restrict__ flags_out, int64_t score_stride) {
+    if (blockIdx.y) {  // batch of trajectories: every per-trajectory array is (B, ...) contiguous, plain strides
+        const int64_t b = blockIdx.y, o = b * N, ng = (N + SCAN_CHUNK - 1) / SCAN_CHUNK, nb = gridDim.x;
+        scores += b * score_stride; nn_idx += o; valid += o; e_out += o; x_out += o; lp_soft += o; lp_raw += o;
+        gend_soft += b * ng; gend_raw += b * ng; ggend_soft += b * 16 * nb; ggend_raw += b * 16 * nb;
+        bsum_e += b * nb; btot_soft += b * nb; btot_raw += b * nb; bmax += b * nb; bmin += b * nb;
+        status += 2 * b;
+    }
     __shared__ double s_a[SCAN_BLOCK + SCAN_BLOCK / 16];
     __shared__ double s_m[SCAN_BLOCK + SCAN_BLOCK / 16];
     __shared__ double s_gtot[16];
@@ -820,6 +827,16 @@ __global__ __launch_bounds__(256) void k_tail_b2(TailB2Args a) {
     __shared__ double s_ex[12];
     __shared__ double s_tot[2];
     __shared__ int s_apply;
+    if (blockIdx.y) {  // batch of trajectories (plain strides)
+        const int64_t b = blockIdx.y, o = b * a.N;
+        a.e += o; a.x_raw += o; a.lp += o; a.lp_raw += o; a.gend += b * a.ng; a.gend_raw += b * a.ng;
+        a.bsum_e += b * a.nb; a.btot += b * a.nb; a.btot_raw += b * a.nb; a.bmax += b * a.nb; a.bmin += b * a.nb;
+        a.valid += o; a.status += 2 * b; a.weights += o;
+        if (a.u) a.u += o;
+        a.ridx += o; a.poses_prop += o * 16; a.poses_out += o * 16; a.weights_out += o; a.nn_idx += o; a.hint_out += o;
+        if (a.part_rmse) { a.part_rmse += 2 * b * a.nrm; a.rmse_out += 2 * b; }
+    }
+    const int64_t slot_base = (int64_t)blockIdx.y * a.N;  // Philox key offset of slot 0
     const int t = threadIdx.x;
     const int64_t N = a.N;
     const int64_t i = (int64_t)blockIdx.x * 256 + t, ic = i < N ? i : N - 1;
@@ -929,10 +946,10 @@ __global__ __launch_bounds__(256) void k_tail_b2(TailB2Args a) {
             double tq;
             bool upper;
             if (a.mode == MIDAS_RESAMPLE_MULTINOMIAL) {
-                tq = a.u ? u_i : philox_uniform53((uint64_t)i, a.seed, a.step);
+                tq = a.u ? u_i : philox_uniform53((uint64_t)(slot_base + i), a.seed, a.step);
                 upper = false;
             } else {
-                const float r = a.u32 >= 0.0f ? a.u32 : philox_uniform24(a.seed, a.step);
+                const float r = a.u32 >= 0.0f ? a.u32 : philox_uniform24(a.seed + (uint64_t)blockIdx.y, a.step);
                 const float off = r / (float)N;
                 tq = (double)i / (double)N + (double)off;
                 tq = tq >= 1.0 ? tq - 1.0 : tq;
@@ -1445,7 +1462,7 @@ int launch_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores, const i
     const int nb = (int)ceil_div(N, SCAN_BLOCK);
     hipLaunchKernelGGL(k_tail_a2, dim3((unsigned)nb), dim3(256), 0, ctx->stream, N, scores, nn_idx, valid, softmax, tb.e, tb.x_raw,
                        tb.lp, tb.lp_raw, tb.gend, tb.gend_raw, tb.ggend, tb.ggend_raw, r1, r1 + nb, r1 + 2 * nb, r1 + 3 * nb, r1 + 4 * nb,
-                       status, r1 + 5 * nb);
+                       status, r1 + 5 * nb, 0);
     LAUNCH_CHECK(ctx);
     return MIDAS_OK;
 }
@@ -1467,11 +1484,11 @@ int debug_tb2_clocks(long long* out16) { return hipMemcpyFromSymbol(out16, HIP_S
 #endif
 
 int launch_tail_a2(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
-                   int32_t softmax, const TailTables& tb, int32_t* status) {
+                   int32_t softmax, const TailTables& tb, int32_t* status, int batch, int64_t score_stride) {
     const int nb = (int)ceil_div(N, SCAN_BLOCK);
-    hipLaunchKernelGGL(k_tail_a2, dim3((unsigned)nb), dim3(256), 0, ctx->stream, N, scores, nn_idx, valid, softmax, tb.e, tb.x_raw,
+    hipLaunchKernelGGL(k_tail_a2, dim3((unsigned)nb, (unsigned)(batch > 1 ? batch : 1)), dim3(256), 0, ctx->stream, N, scores, nn_idx, valid, softmax, tb.e, tb.x_raw,
                        tb.lp, tb.lp_raw, tb.gend, tb.gend_raw, tb.ggend, tb.ggend_raw, tb.bsum_e, tb.btot, tb.btot_raw, tb.bmax, tb.bmin,
-                       status, nullptr);
+                       status, nullptr, score_stride);
     LAUNCH_CHECK(ctx);
     return MIDAS_OK;
 }
@@ -1494,8 +1511,8 @@ int launch_tail_b2(midas_ctx* ctx, const StepTailArgs& a, const TailTables& tb) 
     b.u = a.u; b.u32 = a.u32; b.seed = a.seed; b.step = a.step; b.ridx = a.ridx; b.poses_prop = a.poses_prop;
     b.poses_out = a.poses_out; b.weights_out = a.weights_out; b.nn_idx = a.nn_idx; b.hint_out = a.hint_out;
     b.part_rmse = a.part_rmse; b.nrm = a.part_rmse ? particle_update_blocks(a.N) : 0; b.rmse_out = a.rmse_out;
-    hipLaunchKernelGGL(k_tail_b2, dim3((unsigned)ceil_div(a.N, 256)), dim3(256), (size_t)(nt + 3 * nb) * sizeof(double),
-                       ctx->stream, b);
+    hipLaunchKernelGGL(k_tail_b2, dim3((unsigned)ceil_div(a.N, 256), (unsigned)(a.batch > 1 ? a.batch : 1)), dim3(256),
+                       (size_t)(nt + 3 * nb) * sizeof(double), ctx->stream, b);
     LAUNCH_CHECK(ctx);
     return MIDAS_OK;
 }
@@ -1542,17 +1559,17 @@ int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base) 
     double* pw = psum + (size_t)B * nb;
     double* e = a.e;
     int32_t* flag = (int32_t*)(pw + (size_t)B * nb);
-    if (!a.x) {  // deferred mode (single trajectory)
+    if (!a.x) {  // deferred mode: the tail gathers the scores (B trajectories as grid.y, plain strides)
         const int ng = (int)ceil_div(a.N, SCAN_CHUNK);
         void* sc2;
-        if ((rc = midas_scratch(ctx, ((size_t)nb * 35 + (size_t)ng * 2) * sizeof(double), &sc2))) return rc;
+        if ((rc = midas_scratch(ctx, (size_t)B * ((size_t)nb * 35 + (size_t)ng * 2) * sizeof(double), &sc2))) return rc;
         TailTables tb;
         tb.e = e; tb.x_raw = a.x_raw; tb.lp = a.cdf; tb.lp_raw = a.lp_raw;
         tb.bsum_e = psum; tb.btot = pw;
-        tb.btot_raw = (double*)sc2; tb.bmax = tb.btot_raw + nb; tb.bmin = tb.bmax + nb;
-        tb.gend = tb.bmin + nb; tb.gend_raw = tb.gend + ng;
-        tb.ggend = tb.gend_raw + ng; tb.ggend_raw = tb.ggend + 16 * nb;
-        if ((rc = launch_tail_a2(ctx, a.N, a.scores, a.nn_idx, a.valid, a.softmax, tb, a.status))) return rc;
+        tb.btot_raw = (double*)sc2; tb.bmax = tb.btot_raw + (size_t)B * nb; tb.bmin = tb.bmax + (size_t)B * nb;
+        tb.gend = tb.bmin + (size_t)B * nb; tb.gend_raw = tb.gend + (size_t)B * ng;
+        tb.ggend = tb.gend_raw + (size_t)B * ng; tb.ggend_raw = tb.ggend + (size_t)B * 16 * nb;
+        if ((rc = launch_tail_a2(ctx, a.N, a.scores, a.nn_idx, a.valid, a.softmax, tb, a.status, B, a.score_stride))) return rc;
         prof_mark(ctx, prof_slot_base + 1);
         if ((rc = launch_tail_b2(ctx, a, tb))) return rc;
         prof_mark(ctx, prof_slot_base + 2);

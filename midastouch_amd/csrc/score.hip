@@ -117,14 +117,36 @@ constexpr int MF_PAD = 4;      // floats of padding per staged code row (bank sp
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-// codes (B x D float64) -> float32 rows padded to a multiple of 64 codes (zeros), row stride D
-__global__ __launch_bounds__(256) void k_codes_to_f32(const double* __restrict__ codes, float* __restrict__ out, int B,
-                                                      int Bpad, int D) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx < (int64_t)Bpad * D) {
-        const int b = (int)(idx / D);
-        out[idx] = b < B ? (float)codes[idx] : 0.0f;
+// codes (B x D float64) -> float32 rows padded to a multiple of 64 codes (zeros), row stride D, and max(|e_b|, eps) of
+// every code in float64 (sequential fma chain per quarter-wave lane, as in the single-code kernel).  One quarter-wave
+// per code; the loads of a lane are issued eight at a time (a rolled loop would wait for each one).
+__global__ __launch_bounds__(256) void k_codes_prepare(const double* __restrict__ codes, float* __restrict__ out,
+                                                       double* __restrict__ norms, int B, int Bpad, int D) {
+    const int lane = threadIdx.x & 63, s = lane & 15;
+    const int b = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    if (b >= Bpad) return;
+    const bool real = b < B;
+    const double* c = codes + (int64_t)(real ? b : 0) * D;
+    float* o = out + (int64_t)b * D;
+    double acc = 0.0;
+    for (int j0 = s; j0 < D; j0 += 16 * 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = j0 + 16 * k;
+            v[k] = c[j < D ? j : D - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = j0 + 16 * k;
+            if (j < D) {
+                o[j] = real ? (float)v[k] : 0.0f;
+                acc = fma_(v[k], v[k], acc);
+            }
+        }
     }
+    acc = quarter_reduce(acc);
+    if (real && s == 0) { const double n = __builtin_sqrt(acc); norms[b] = n < COS_EPS ? COS_EPS : n; }
 }
 
 __global__ __launch_bounds__(1024) void k_score_mfma(const float* __restrict__ emb, const double* __restrict__ norms,
@@ -180,17 +202,6 @@ __global__ __launch_bounds__(1024) void k_score_mfma(const float* __restrict__ e
     }
 }
 
-// max(|e_b|, eps) of every code, float64, one quarter-wave per code
-__global__ __launch_bounds__(256) void k_code_norms(const double* __restrict__ codes, double* __restrict__ out, int B, int D) {
-    const int lane = threadIdx.x & 63, s = lane & 15;
-    const int b = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
-    double acc = 0.0;
-    if (b < B)
-        for (int j = s; j < D; j += 16) { const double v = codes[(int64_t)b * D + j]; acc = fma_(v, v, acc); }
-    acc = quarter_reduce(acc);
-    if (b < B && s == 0) { const double n = __builtin_sqrt(acc); out[b] = n < COS_EPS ? COS_EPS : n; }
-}
-
 int launch_score_batch(midas_ctx* ctx, const midas_codebook* cb, int32_t B, const double* codes, double* scores) {
     if (cb->dtype != MIDAS_F32 || cb->D % 16 != 0 || (uintptr_t)cb->emb % 16 != 0)
         return midas_set_error(ctx, MIDAS_ERR_INVALID, "midas_score_batch", "needs float32 embeddings with D % 16 == 0");
@@ -200,9 +211,8 @@ int launch_score_batch(midas_ctx* ctx, const midas_codebook* cb, int32_t B, cons
     int rc = midas_scratch(ctx, (size_t)B * sizeof(double), &cn);
     if (rc) return rc;
     if ((rc = midas_scratch(ctx, (size_t)Bpad * D * sizeof(float), &c32))) return rc;
-    hipLaunchKernelGGL(k_code_norms, dim3((unsigned)ceil_div(B, 16)), dim3(256), 0, ctx->stream, codes, (double*)cn, B, D);
-    hipLaunchKernelGGL(k_codes_to_f32, dim3((unsigned)ceil_div((int64_t)Bpad * D, 256)), dim3(256), 0, ctx->stream, codes,
-                       (float*)c32, B, Bpad, D);
+    hipLaunchKernelGGL(k_codes_prepare, dim3((unsigned)ceil_div(Bpad, 16)), dim3(256), 0, ctx->stream, codes, (float*)c32,
+                       (double*)cn, B, Bpad, D);
     const int dc = D < MF_DC ? D : MF_DC;
     const size_t lds = (size_t)MF_CODES * (dc + MF_PAD) * sizeof(float);
     static bool attr_set = false;
