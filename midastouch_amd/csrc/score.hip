@@ -110,9 +110,15 @@ int launch_score(midas_ctx* ctx, const midas_codebook* cb, int32_t B, const doub
 // 0..3: acc = fmaf(C[k][16c+4g+s], E[b][16c+4g+s], acc).  Epilogue: float64 division by the norms.
 // HBM: K*D*4 bytes once (102 MB at c2) vs B times for the GEMV loop; MFMA: 2*K*D*B flop.
 constexpr int MF_ROWS_PER_WAVE = 16;
-constexpr int MF_WAVES = 16;   // 1024-thread workgroups: four waves per SIMD share one staged copy of the codes
+#ifndef MIDAS_MF_WAVES
+#define MIDAS_MF_WAVES 16
+#endif
+#ifndef MIDAS_MF_DC
+#define MIDAS_MF_DC 512
+#endif
+constexpr int MF_WAVES = MIDAS_MF_WAVES;   // waves per workgroup: they share one staged copy of the codes
 constexpr int MF_CODES = 64;   // codes per pass (4 N-tiles)
-constexpr int MF_DC = 512;     // D-chunk staged in LDS
+constexpr int MF_DC = MIDAS_MF_DC;         // D-chunk staged in LDS
 constexpr int MF_PAD = 4;      // floats of padding per staged code row (bank spread)
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(256) void k_codes_prepare(const double* __restrict_
     if (real && s == 0) { const double n = __builtin_sqrt(acc); norms[b] = n < COS_EPS ? COS_EPS : n; }
 }
 
-__global__ __launch_bounds__(1024) void k_score_mfma(const float* __restrict__ emb, const double* __restrict__ norms,
+__global__ __launch_bounds__(64 * MF_WAVES) void k_score_mfma(const float* __restrict__ emb, const double* __restrict__ norms,
                                                      const float* __restrict__ codes32, const double* __restrict__ code_norms,
                                                      double* __restrict__ out, int64_t K, int D, int B, int b0) {
     extern __shared__ __attribute__((aligned(16))) float s_e[];  // [MF_CODES][dc + MF_PAD]
@@ -166,14 +172,17 @@ __global__ __launch_bounds__(1024) void k_score_mfma(const float* __restrict__ e
         const int dc = D - d0 < MF_DC ? D - d0 : MF_DC;
         const int ld = dc + MF_PAD;
         __syncthreads();
-        for (int idx = threadIdx.x; idx < MF_CODES * (dc / 4); idx += 1024) {  // stage this D-chunk of the 64 codes
+        for (int idx = threadIdx.x; idx < MF_CODES * (dc / 4); idx += 64 * MF_WAVES) {  // stage this D-chunk of the 64 codes
             const int b = idx / (dc / 4), d = (idx - b * (dc / 4)) * 4;
             *reinterpret_cast<float4*>(&s_e[b * ld + d]) =
                 *reinterpret_cast<const float4*>(&codes32[(int64_t)(b0 + b) * D + d0 + d]);
         }
         __syncthreads();
+        float4 a_next = *reinterpret_cast<const float4*>(arow + d0 + 4 * g);
         for (int c = 0; c < dc; c += 16) {
-            const float4 a = *reinterpret_cast<const float4*>(arow + d0 + c + 4 * g);
+            const float4 a = a_next;
+            const int cn = c + 16 < dc ? c + 16 : c;  // the next step's row piece travels while this step computes
+            a_next = *reinterpret_cast<const float4*>(arow + d0 + cn + 4 * g);
             float4 e[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) e[t] = *reinterpret_cast<const float4*>(&s_e[(16 * t + i) * ld + c + 4 * g]);
@@ -222,7 +231,7 @@ int launch_score_batch(midas_ctx* ctx, const midas_codebook* cb, int32_t B, cons
     }
     const unsigned grid = (unsigned)ceil_div(cb->K, MF_ROWS_PER_WAVE * MF_WAVES);
     for (int b0 = 0; b0 < B; b0 += MF_CODES) {
-        hipLaunchKernelGGL(k_score_mfma, dim3(grid), dim3(1024), lds, ctx->stream, (const float*)cb->emb, cb->norms,
+        hipLaunchKernelGGL(k_score_mfma, dim3(grid), dim3(64 * MF_WAVES), lds, ctx->stream, (const float*)cb->emb, cb->norms,
                            (const float*)c32, (const double*)cn, scores, cb->K, D, B, b0);
     }
     MIDAS_HIP_CHECK(ctx, hipGetLastError());
