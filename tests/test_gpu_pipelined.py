@@ -121,3 +121,28 @@ def test_pipelined_rejects_unsupported_layout(dev):
     cb, traj = _setup(512, 600, 96, 10)
     with pytest.raises(MidasError):
         PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, 512, device=dev)
+
+
+@pytest.mark.parametrize("N", [1, 2, 17, 255, 257, 4095, 4097, 8193])
+@pytest.mark.parametrize("cls_name", ["FilterEngine", "PipelinedFilterEngine"])
+def test_edge_particle_counts(dev, oracle, N, cls_name):
+    """Ragged sizes: below a wave, across chunk / workgroup / summation-block boundaries - both engines."""
+    import midastouch_amd.engine as E
+    K, D = 700, 128
+    cb, traj = _setup(N, K, D, 20)
+    ofl = oracle.OracleFilter(cb.poses, cb.embeddings, cb.mesh_vertices)
+    eng = getattr(E, cls_name)(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4600, device=dev)
+    rng = np.random.default_rng(N)
+    poses = cb.poses[rng.integers(0, K, N)]
+    eng.set_particles(torch.as_tensor(poses))
+    for t in range(1, 6):
+        tn, rot = oracle.philox_noise(N, 4600, t - 1, np.float32(2e-4), np.float32(0.5))
+        ref = ofl.step(poses, traj.odoms[t], traj.codes[t], tn, rot, u=oracle.philox_uniform64(N, 4600, t - 1))
+        eng.step(torch.as_tensor(traj.odoms[t]).to(dev), torch.as_tensor(traj.codes[t]).to(dev))
+        assert np.array_equal(eng.nn_idx.cpu().numpy(), ref["nn_idx"]), f"frame {t}"
+        if t % 2 == 0 or t == 5:
+            assert eng.status.cpu().numpy()[0] == ref["status"], f"frame {t}"
+            assert np.array_equal(eng.ridx.cpu().numpy(), ref["ridx"]), f"frame {t}"
+            assert np.array_equal(eng.poses.cpu().numpy(), ref["poses"]), f"frame {t}"
+            np.testing.assert_allclose(eng.weights.cpu().numpy(), ref["weights"], rtol=1e-12, atol=0)
+        poses = ref["poses"]
