@@ -201,6 +201,11 @@ def load():
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback."
         )
+    # torch first: the library shares the process's HIP runtime with torch (device memory and streams come from
+    # torch).  torch ships its own libamdhip64; if this library were loaded before it, the loader would bind
+    # /opt/rocm's copy instead and the two runtimes would not see each other's devices and streams.
+    import torch  # noqa: F401
+
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
