@@ -52,6 +52,23 @@ def synthetic_sequence(cfg, device, T: int = 100, D: Optional[int] = None, seed:
                     torch.as_tensor(traj.codes).to(device), tree, cb.mesh_vertices, obj)
 
 
+def load_sequence(sequence_npz: str, codebook_path: str, device, obj_model: str = "object", check_logmap: bool = False) -> Sequence:
+    """A recorded sequence: `codebook_path` is a `codebook.npz` or a reference `codebook.pkl` (codebook_io.py);
+    `sequence_npz` holds `gt_poses (T,4,4)`, `meas_poses (T,4,4)`, `codes (T,D)` (the TCN outputs, upstream of this
+    path) and `mesh_vertices (M,3)` (the decimated STL vertices of `particle_filter.__init__`, :108-110)."""
+    tree = tactile_tree.load(codebook_path, device=device, check_logmap=check_logmap)
+    with np.load(sequence_npz) as z:
+        need = ("gt_poses", "meas_poses", "codes", "mesh_vertices")
+        missing = [k for k in need if k not in z.files]
+        if missing:
+            raise ValueError(f"{sequence_npz}: arrays {missing} missing")
+        gt, meas, codes, verts = (np.asarray(z[k]) for k in need)
+    if codes.shape[1] != tree.embeddings.shape[1]:
+        raise ValueError(f"tactile codes are {codes.shape[1]}-d, the codebook's embeddings {tree.embeddings.shape[1]}-d")
+    return Sequence(torch.as_tensor(gt, dtype=torch.float32).to(device), torch.as_tensor(meas, dtype=torch.float32).to(device),
+                    torch.as_tensor(codes, dtype=torch.float64).to(device), tree, verts, obj_model)
+
+
 # ---- north-star aliases ---------------------------------------------------------------------------
 def update_weights(pf: particle_filter, codebook: tactile_tree, particles: Particles, tactile_code: torch.Tensor,
                    softmax: bool = True) -> Particles:

@@ -167,15 +167,50 @@ class tactile_tree:
     def get_embedding(self, idx):
         return self.embeddings[idx, :].double()
 
-    # -- on-disk container (next-1: replaces the dill pickle of build_codebook.py:136-137) ------------
+    # -- on-disk container (replaces the dill pickle of build_codebook.py:136-137) --------
     def save(self, path: str):
-        np.savez_compressed(path, poses=self.poses.cpu().numpy(), cam_poses=self.cam_poses.cpu().numpy(),
-                            embeddings=self.embeddings.cpu().numpy())
+        """Write `codebook.npz` (midastouch_amd/codebook_io.py)."""
+        from . import codebook_io
+
+        codebook_io.save_codebook(path, self.poses, self.cam_poses, self.embeddings, self.reference_logmap)
 
     @classmethod
-    def load(cls, path: str) -> "tactile_tree":
-        z = np.load(path)
-        return cls(torch.as_tensor(z["poses"]), torch.as_tensor(z["cam_poses"]), torch.as_tensor(z["embeddings"]))
+    def load(cls, path: str, device=None, check_logmap: bool = False) -> "tactile_tree":
+        """Open a `codebook.npz`, or a reference `codebook.pkl` (read without the reference package or pynanoflann).
+
+        check_logmap: after `to_device`, compare the kernels' 6-d features with the ones the reference stored in the
+        file (theseus log-map) and raise when they differ by more than 1e-5 - the two log-maps are unpinned against
+        each other otherwise."""
+        from . import codebook_io
+
+        z = codebook_io.load_codebook(path)
+        t = cls(z["poses"], z["cam_poses"], z["embeddings"])
+        t.reference_logmap = z.get("logmap_pose")
+        if device is not None:
+            t.to_device(device)
+            if check_logmap:
+                t.check_reference_logmap()
+        elif check_logmap:
+            raise MidasError("check_logmap needs a HIP device: pass device=")
+        return t
+
+    reference_logmap = None
+
+    def check_reference_logmap(self, atol: float = 1e-5) -> float:
+        """max |R3_SE3(poses) - stored reference features| (rotation part compared modulo the sign at angle pi)."""
+        self._require_tree()
+        if self.reference_logmap is None:
+            raise MidasError("the codebook file holds no reference logmap_pose")
+        ref = self.reference_logmap.to(self.logmap_pose.device, torch.float32)
+        d = (self.logmap_pose - ref).abs()
+        # at |log R| = pi the axis sign is a convention: accept the mirrored rotation vector there
+        flip = (self.logmap_pose[:, 3:] + ref[:, 3:]).abs()
+        near_pi = self.logmap_pose[:, 3:].norm(dim=1) > 0.01 * 3.13
+        d[:, 3:] = torch.where(near_pi[:, None], torch.minimum(d[:, 3:], flip), d[:, 3:])
+        err = float(d.max())
+        if not err <= atol:
+            raise MidasError(f"6-d features differ from the reference's stored logmap_pose by {err:.3e} (> {atol})")
+        return err
 
     def __getstate__(self):  # handles are rebuilt after unpickling + to_device
         st = dict(self.__dict__)
