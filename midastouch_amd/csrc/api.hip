@@ -583,7 +583,7 @@ MIDAS_EXPORT int midas_lazy_step(midas_ctx* ctx, const midas_codebook* cb, const
     if (!launched)
         return midas_set_error(ctx, MIDAS_ERR_INVALID, "codebook", "the pipelined step needs a float32 codebook with D in {128,256,512,1024}");
     prof_mark(ctx, 2);
-    if ((rc = launch_tail_a2(ctx, N, s.scores_dev, s.nn_idx_dev, s.valid_dev, s.softmax, tb, s.status_dev))) return rc;
+    if ((rc = launch_tail_a2(ctx, N, s.scores_dev, s.nn_idx_dev, s.valid_dev, s.softmax, tb, s.status_dev, 1, 0, true))) return rc;
     prof_mark(ctx, 3);
     if (ctx->prof && ctx->ev_ready) {
         const int lo = ctx->prof_only >= 0 ? ctx->prof_only : 1, hi = ctx->prof_only >= 0 ? ctx->prof_only + 1 : 3;

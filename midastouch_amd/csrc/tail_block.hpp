@@ -1,0 +1,197 @@
+// tail_block.hpp - the blocked scan of the summation spec and the per-block part of the step tail (score gather,
+// softmax numerators, masked prefix sums) in the chunk-per-thread view, without LDS staging.
+#pragma once
+#include "midas_internal.hpp"
+#include "midas_math.hpp"
+
+namespace midas {
+
+constexpr double TAIL_ISCLOSE_ATOL = 1e-8;  // torch.isclose default atol (particle_filter.py:460-463)
+
+// Block-local part of the spec scan.  v[16] = this lane's chunk (absent values = +0.0).
+// l[j] = GP_g + (TP_c + local_j) (l may be v itself); returns the block total W (identical in every thread).
+// Needs 16 doubles of LDS (s_gtot) and contains one __syncthreads().
+MD double block_scan(const double* v, double* l, double* s_gtot) {
+    __builtin_amdgcn_sched_barrier(0);  // phase walls: work hoisted across them only adds live registers
+    double run = 0.0;
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) { run = run + v[j]; l[j] = run; }
+    const double T = run;
+    const int lane = threadIdx.x & 63, c = threadIdx.x & 15, gbase = lane & ~15;
+    double TP = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double t = __shfl(T, gbase + j);
+        if (j < c) TP = TP + t;
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four exchanges in flight, not sixteen (registers)
+    }
+    if (c == 15) s_gtot[threadIdx.x >> 4] = TP + T;
+    __syncthreads();
+    const int g = threadIdx.x >> 4;
+    double GP = 0.0, W = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double t = s_gtot[j];
+        if (j < g) GP = GP + t;
+        W = W + t;
+    }
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) l[j] = GP + (TP + l[j]);
+    __builtin_amdgcn_sched_barrier(0);
+    return W;
+}
+
+// The block total of block_scan alone (same additions in the same order), for sums whose prefixes nobody reads.
+MD double block_total(const double* v, double* s_gtot) {
+    __builtin_amdgcn_sched_barrier(0);
+    double T = 0.0;
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) T = T + v[j];
+    const int lane = threadIdx.x & 63, c = threadIdx.x & 15, gbase = lane & ~15;
+    double TP = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double t = __shfl(T, gbase + j);
+        if (j < c) TP = TP + t;
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four exchanges in flight, not sixteen (registers)
+    }
+    if (c == 15) s_gtot[threadIdx.x >> 4] = TP + T;
+    __syncthreads();
+    double W = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) W = W + s_gtot[j];
+    __builtin_amdgcn_sched_barrier(0);
+    return W;
+}
+
+// One 4096-slot block by one 256-thread workgroup, thread t owning the chunk of slots [16 t, 16 t + 16) - the view the
+// summation spec is written in, so nothing is transposed: x = scores[nn_idx], e = exp(x - 1), e*valid, block sums,
+// block-local prefix, chunk-end and group-end tables, block extrema of x; the raw-score variant only when the block's own
+// range is within the isclose tolerance (see k_tail_a2).  Outputs are identical to k_tail_a2's; the per-slot tables are
+// written in whole 16-value chunks (the layouts are padded to multiples of 16, values past N are never read).
+// padded: the per-slot tables hold a multiple of 16 values, so the chunk that straddles N is stored whole too.  Needs N >= 16.
+// s_gtot: 16 doubles, s_red: 24 doubles of LDS.  kept_out (every thread): valid slots of the block; nan_out: some masked
+// weight of the block is NaN.
+MD void tail_a_direct(int64_t N, int blk, const double* __restrict__ scores, const int32_t* __restrict__ nn_idx,
+                      const uint8_t* __restrict__ valid, int32_t softmax, const TailTables& tb, bool padded, double* s_gtot,
+                      double* s_red, int& kept_out, bool& nan_out) {
+    const int t = threadIdx.x;
+    const int64_t bbase = (int64_t)blk * SCAN_BLOCK, base = bbase + (int64_t)t * SCAN_CHUNK;
+    // Sixteen contiguous slots from ONE address (the loads share it and travel together; a clamped index per slot would
+    // cost an address register pair each).  A chunk that would run past N starts at N - 16 instead and is shifted below.
+    const int64_t cs = base + SCAN_CHUNK <= N ? base : N - SCAN_CHUNK;
+    const int32_t* pn = nn_idx + cs;
+    const uint8_t* pv = valid + cs;
+    int32_t nn[SCAN_CHUNK];
+    unsigned okbits = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) {
+        nn[j] = pn[j];
+        okbits |= pv[j] != 0 ? (1u << j) : 0u;
+    }
+    if (cs != base) {  // at most one straddling chunk per block (chunks wholly past N keep neutral values)
+        const int shift = base < N ? (int)(base - cs) : SCAN_CHUNK;
+        for (int s = 0; s < shift; ++s) {
+#pragma unroll
+            for (int j = 0; j + 1 < SCAN_CHUNK; ++j) nn[j] = nn[j + 1];
+            okbits >>= 1;
+        }
+    }
+    double v[SCAN_CHUNK];
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) v[j] = scores[nn[j]];
+    double mx = -INFINITY, mn = INFINITY;
+    bool xnan = false;
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) {
+        const bool in = base + j < N;
+        xnan |= in && v[j] != v[j];
+        mx = in && v[j] > mx ? v[j] : mx;
+        mn = in && v[j] < mn ? v[j] : mn;
+    }
+    int kept = __popc(okbits);
+    // block extrema (NaN propagates, as torch.max / torch.min do)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double a = __shfl_xor(mx, o), c = __shfl_xor(mn, o);
+        mx = a > mx ? a : mx;
+        mn = c < mn ? c : mn;
+        kept += __shfl_xor(kept, o);
+    }
+    const bool wxnan = __any(xnan);
+    if ((t & 63) == 0) { s_red[t >> 6] = mx; s_red[4 + (t >> 6)] = mn; s_red[8 + (t >> 6)] = wxnan ? 1.0 : 0.0; s_red[12 + (t >> 6)] = (double)kept; }
+    __syncthreads();
+    mx = s_red[0]; mn = s_red[4];
+    double f = s_red[8], kd = s_red[12];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        mx = s_red[w] > mx ? s_red[w] : mx;
+        mn = s_red[4 + w] < mn ? s_red[4 + w] : mn;
+        f += s_red[8 + w];
+        kd += s_red[12 + w];
+    }
+    kept_out = (int)kd;
+    if (f != 0.0) { mx = NAN; mn = NAN; }
+    if (t == 0) { tb.bmax[blk] = mx; tb.bmin[blk] = mn; }
+    const bool close = __builtin_fabs(mx - mn) <= TAIL_ISCLOSE_ATOL;  // false on NaN
+    const bool need_soft = softmax != 0, need_raw = !softmax || close;
+    bool nan = false;
+    __syncthreads();
+    // the own chunk of a per-slot table, as eight 16-byte stores from one address (padded layout: see above)
+    auto store_chunk = [&](double* __restrict__ out, const double* val) {
+        if (base + SCAN_CHUNK <= N || (padded && base < N)) {
+            double2* o2 = reinterpret_cast<double2*>(out + base);
+#pragma unroll
+            for (int j = 0; j < SCAN_CHUNK / 2; ++j) o2[j] = make_double2(val[2 * j], val[2 * j + 1]);
+        } else if (base < N) {
+#pragma unroll
+            for (int j = 0; j < SCAN_CHUNK; ++j)
+                if (base + j < N) out[base + j] = val[j];
+        }
+    };
+    // one variant, in place: val[j] of the own chunk -> sums, prefix, tables (val is consumed)
+    auto variant = [&](double* val, double* __restrict__ lp_out, double* __restrict__ gend_out,
+                       double* __restrict__ ggend_out, double& W_all, double& W_masked, bool& vnan) {
+#pragma unroll
+        for (int j = 0; j < SCAN_CHUNK; ++j) val[j] = base + j < N ? val[j] : 0.0;
+        W_all = block_total(val, s_gtot);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SCAN_CHUNK; ++j) {
+            val[j] = val[j] * ((okbits >> j) & 1u ? 1.0 : 0.0);  // okbits is clear on out-of-range slots
+            vnan |= val[j] != val[j];
+        }
+        W_masked = block_scan(val, val, s_gtot);
+        if (base < N) gend_out[(bbase >> 4) + t] = val[SCAN_CHUNK - 1];              // block-local prefix at the chunk end
+        if ((t & 15) == 15) ggend_out[(bbase >> 8) + (t >> 4)] = val[SCAN_CHUNK - 1];  // ... at the end of each 256-slot group
+        store_chunk(lp_out, val);
+        __syncthreads();
+    };
+    double Wa = 0.0, Wm = 0.0;
+    if (need_soft) {
+#pragma unroll
+        for (int j = 0; j < SCAN_CHUNK; ++j) {
+            v[j] = exp(v[j] - 1.0);
+            __builtin_amdgcn_sched_barrier(0);  // one exponential at a time: sixteen interleaved ones cost ~80 registers
+        }
+        store_chunk(tb.e, v);
+        variant(v, tb.lp, tb.gend, tb.ggend, Wa, Wm, nan);
+        if (t == 0) { tb.bsum_e[blk] = Wa; tb.btot[blk] = Wm; }
+    }
+    if (need_raw) {  // rare (every particle of the block shares one score) or the softmax is off
+        if (need_soft) {  // the scores were consumed in place: gather them again
+#pragma unroll
+            for (int j = 0; j < SCAN_CHUNK; ++j) v[j] = scores[nn[j]];
+        }
+        store_chunk(tb.x_raw, v);
+        bool nan_raw = false;
+        variant(v, tb.lp_raw, tb.gend_raw, tb.ggend_raw, Wa, Wm, nan_raw);
+        if (t == 0) tb.btot_raw[blk] = Wm;
+        if (!need_soft) nan = nan_raw;  // with the softmax on, x NaN <=> e NaN: counted once
+    } else if (t == 0) {
+        tb.btot_raw[blk] = 0.0;
+    }
+    nan_out = __syncthreads_or(nan ? 1 : 0) != 0;
+}
+
+}  // namespace midas
