@@ -143,6 +143,19 @@ int midas_gather_rows(midas_ctx* ctx, int64_t M, const int32_t* idx_dev, const v
 int midas_rmse(midas_ctx* ctx, int64_t N, const float* poses_dev, const float* gt16_dev,
                double* out2_dev);
 
+/* ---- cluster centres (K9) -------------------------------------------------------------------- */
+/* particle_filter.get_cluster_centers(method="quat_avg") (modules/particle_filter.py:153-206) with pose.xyz_quat_averaged
+ * (modules/pose.py:112-147; its removed Tensor.eig is a symmetric 4x4 eigenproblem, solved here by Jacobi in float64).
+ * For each of the C label values: members = particles carrying it; weights taken as float32 (:161) and flattened to 1
+ * when isclose(max - min, 0) (:178-184); centre rotation = principal eigenvector of sum w q q^T / sum w over sign-fixed
+ * unit quaternions, centre translation = weighted mean; std = sqrt(sum w (t - centre)^2 / sum w) per axis.
+ * weights: float64 (weights64_dev) or float32 (weights32_dev), exactly one non-NULL.  centers_dev: C x 16 float32,
+ * stds_dev: C x 3 float32, counts_dev: NULL or C int64 (members per label; a label nobody carries gives NaN rows).
+ * 1 <= C <= 64. */
+int midas_cluster_centers(midas_ctx* ctx, int64_t N, const float* poses_dev, const double* weights64_dev,
+                          const float* weights32_dev, const int64_t* labels_dev, int32_t C, const int64_t* label_values_dev,
+                          float* centers_dev, float* stds_dev, int64_t* counts_dev);
+
 /* ---- the fused per-frame step ---------------------------------------------------------------- */
 /* One call = filter/filter.py:150-190 minus clustering/annealing:
  *   score codebook -> propagate -> feature -> NN -> x = s[idx] -> softmax -> prune -> cdf ->

@@ -344,6 +344,18 @@ static double squared_threshold(double thr) {
 static int filter_step_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
                             const midas_step_args* args, int32_t B);
 
+MIDAS_EXPORT int midas_cluster_centers(midas_ctx* ctx, int64_t N, const float* poses_dev, const double* weights64_dev,
+                                       const float* weights32_dev, const int64_t* labels_dev, int32_t C,
+                                       const int64_t* label_values_dev, float* centers_dev, float* stds_dev,
+                                       int64_t* counts_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, N > 0 && poses_dev && labels_dev && label_values_dev && centers_dev && stds_dev && C >= 1 && C <= 64);
+    MIDAS_REQUIRE(ctx, (weights64_dev == nullptr) != (weights32_dev == nullptr));
+    MIDAS_REQUIRE(ctx, (uintptr_t)poses_dev % 16 == 0);
+    return launch_cluster_centers(ctx, N, poses_dev, weights64_dev, weights32_dev, labels_dev, C, label_values_dev, centers_dev,
+                                  stds_dev, counts_dev);
+}
+
 MIDAS_EXPORT int midas_filter_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
                                    const midas_tree* tree3, const midas_step_args* args) {
     MIDAS_ENTER(ctx);

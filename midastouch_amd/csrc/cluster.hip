@@ -1,0 +1,236 @@
+// cluster.hip - K9: cluster centres of the labelled particle set.
+//
+// particle_filter.get_cluster_centers(method="quat_avg") (modules/particle_filter.py:153-206) with
+// pose.xyz_quat_averaged (modules/pose.py:112-147): per cluster label the weights (float32) are flattened to 1 when
+// isclose(max - min, 0); the rotation is Markley's quaternion mean = principal eigenvector of sum w q q^T / sum w over
+// sign-fixed quaternions (qw >= 0), the translation the weighted mean, the spread sqrt(sum w (t - mean)^2 / sum w).
+// The reference walks the clusters in a Python loop of ~25 small torch ops each; here one pass over the particles
+// accumulates every cluster's moments (both the weighted and the flattened set, the choice needs the cluster's
+// extrema) and one small kernel finishes each cluster (4x4 symmetric eigenproblem by cyclic Jacobi in float64).
+//
+// Summation order (deterministic): per particle wave a shuffle tree, per 256-thread block the four waves in order,
+// then the blocks in order.
+#include "midas_internal.hpp"
+#include "midas_math.hpp"
+
+namespace midas {
+
+constexpr int CL_MOM = 36;  // moments per cluster, see the enum
+enum : int {
+    M_SW = 0,      // sum w
+    M_CNT = 1,     // members
+    M_WMAX = 2,    // max w (float32 values)
+    M_WMIN = 3,    // min w
+    M_QQW = 4,     // 10: upper triangle of sum w q q^T, q = (x, y, z, w)
+    M_QQ1 = 14,    // 10: the same with w = 1
+    M_TW = 24,     // 3: sum w t
+    M_T1 = 27,     // 3: sum t
+    M_TTW = 30,    // 3: sum w t^2
+    M_TT1 = 33,    // 3: sum t^2
+};
+
+// unit quaternion (x, y, z, w) of a rotation matrix, float64, branch on the largest diagonal term (Shepperd)
+MD void quat_of(const float* P, double* q) {
+    const double r00 = P[0], r01 = P[1], r02 = P[2], r10 = P[4], r11 = P[5], r12 = P[6], r20 = P[8], r21 = P[9], r22 = P[10];
+    const double tr = r00 + r11 + r22;
+    double x, y, z, w;
+    if (tr > 0.0) {
+        const double s = __builtin_sqrt(tr + 1.0) * 2.0;
+        w = 0.25 * s; x = (r21 - r12) / s; y = (r02 - r20) / s; z = (r10 - r01) / s;
+    } else if (r00 > r11 && r00 > r22) {
+        const double s = __builtin_sqrt(1.0 + r00 - r11 - r22) * 2.0;
+        w = (r21 - r12) / s; x = 0.25 * s; y = (r01 + r10) / s; z = (r02 + r20) / s;
+    } else if (r11 > r22) {
+        const double s = __builtin_sqrt(1.0 + r11 - r00 - r22) * 2.0;
+        w = (r02 - r20) / s; x = (r01 + r10) / s; y = 0.25 * s; z = (r12 + r21) / s;
+    } else {
+        const double s = __builtin_sqrt(1.0 + r22 - r00 - r11) * 2.0;
+        w = (r10 - r01) / s; x = (r02 + r20) / s; y = (r12 + r21) / s; z = 0.25 * s;
+    }
+    const double n = __builtin_sqrt(x * x + y * y + z * z + w * w);
+    const double sg = w < 0.0 ? -1.0 : 1.0;  // antipodal fix (pose.py:126)
+    q[0] = sg * x / n; q[1] = sg * y / n; q[2] = sg * z / n; q[3] = sg * w / n;
+}
+
+MD double cl_wsum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+MD double cl_wmax(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v, o); v = t > v ? t : v; }
+    return v;
+}
+MD double cl_wmin(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v, o); v = t < v ? t : v; }
+    return v;
+}
+
+// part[(block * C + c) * CL_MOM + m]
+__global__ __launch_bounds__(256) void k_cluster_moments(int64_t N, const float* __restrict__ poses, const double* __restrict__ w64,
+                                                         const float* __restrict__ w32, const int64_t* __restrict__ labels, int C,
+                                                         const int64_t* __restrict__ label_values, double* __restrict__ part) {
+    __shared__ double s_w[4][CL_MOM];
+    const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
+    const int64_t n = (int64_t)blockIdx.x * 256 + t;
+    const bool live = n < N;
+    const int64_t nc = live ? n : N - 1;
+    float P[16];
+    const float4* p4 = reinterpret_cast<const float4*>(poses + nc * 16);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const float4 r = p4[i]; P[4 * i] = r.x; P[4 * i + 1] = r.y; P[4 * i + 2] = r.z; P[4 * i + 3] = r.w; }
+    const int64_t lab = labels[nc];
+    // particles.weights.float() (:161): the reference averages with float32 weights
+    const double w = w64 ? (double)(float)w64[nc] : (double)w32[nc];
+    double q[4];
+    quat_of(P, q);
+    const double tx = P[3], ty = P[7], tz = P[11];
+    double v[CL_MOM];
+    for (int c = 0; c < C; ++c) {
+        const bool mine = live && lab == label_values[c];
+        const double a = mine ? w : 0.0, b = mine ? 1.0 : 0.0;
+        v[M_SW] = a; v[M_CNT] = b; v[M_WMAX] = 0.0; v[M_WMIN] = 0.0;
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = i; j < 4; ++j) {
+                const double qq = q[i] * q[j];
+                v[M_QQW + k] = a * qq; v[M_QQ1 + k] = b * qq;
+                ++k;
+            }
+        v[M_TW] = a * tx; v[M_TW + 1] = a * ty; v[M_TW + 2] = a * tz;
+        v[M_T1] = b * tx; v[M_T1 + 1] = b * ty; v[M_T1 + 2] = b * tz;
+        v[M_TTW] = a * tx * tx; v[M_TTW + 1] = a * ty * ty; v[M_TTW + 2] = a * tz * tz;
+        v[M_TT1] = b * tx * tx; v[M_TT1 + 1] = b * ty * ty; v[M_TT1 + 2] = b * tz * tz;
+        const double mx = cl_wmax(mine ? w : -INFINITY), mn = cl_wmin(mine ? w : INFINITY);
+#pragma unroll
+        for (int m = 0; m < CL_MOM; ++m)
+            if (m != M_WMAX && m != M_WMIN) v[m] = cl_wsum(v[m]);
+        __syncthreads();  // the previous cluster's LDS values have been read
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < CL_MOM; ++m) s_w[wv][m] = v[m];
+            s_w[wv][M_WMAX] = mx; s_w[wv][M_WMIN] = mn;
+        }
+        __syncthreads();
+        if (t < CL_MOM) {
+            double r;
+            if (t == M_WMAX) { r = s_w[0][t]; for (int i = 1; i < 4; ++i) r = s_w[i][t] > r ? s_w[i][t] : r; }
+            else if (t == M_WMIN) { r = s_w[0][t]; for (int i = 1; i < 4; ++i) r = s_w[i][t] < r ? s_w[i][t] : r; }
+            else r = ((s_w[0][t] + s_w[1][t]) + s_w[2][t]) + s_w[3][t];
+            part[((size_t)blockIdx.x * C + c) * CL_MOM + t] = r;
+        }
+    }
+}
+
+// cyclic Jacobi on a symmetric 4x4 (float64): A -> diag, V = eigenvectors (columns)
+MD void jacobi4(double A[4][4], double V[4][4]) {
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 32; ++sweep) {
+        double off = 0.0;
+        for (int i = 0; i < 4; ++i)
+            for (int j = i + 1; j < 4; ++j) off += A[i][j] * A[i][j];
+        if (off < 1e-40) break;
+        for (int p = 0; p < 3; ++p)
+            for (int q = p + 1; q < 4; ++q) {
+                if (__builtin_fabs(A[p][q]) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (__builtin_fabs(theta) + __builtin_sqrt(theta * theta + 1.0));
+                const double c = 1.0 / __builtin_sqrt(tt * tt + 1.0), s = tt * c;
+                for (int k = 0; k < 4; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq;
+                    A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 4; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk;
+                    A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 4; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+}
+
+// one 64-thread workgroup per cluster: blocks summed in order, then the closed forms
+__global__ __launch_bounds__(64) void k_cluster_finish(int nblocks, int C, const double* __restrict__ part,
+                                                       float* __restrict__ centers, float* __restrict__ stds,
+                                                       int64_t* __restrict__ counts) {
+    __shared__ double s_m[CL_MOM];
+    const int c = blockIdx.x, t = threadIdx.x;
+    if (t < CL_MOM) {
+        double r = part[(size_t)c * CL_MOM + t];
+        for (int b = 1; b < nblocks; ++b) {
+            const double x = part[((size_t)b * C + c) * CL_MOM + t];
+            if (t == M_WMAX) r = x > r ? x : r;
+            else if (t == M_WMIN) r = x < r ? x : r;
+            else r = r + x;
+        }
+        s_m[t] = r;
+    }
+    __syncthreads();
+    if (t != 0) return;
+    if (counts) counts[c] = (int64_t)s_m[M_CNT];
+    float* out = centers + (size_t)c * 16;
+    float* sd = stds + (size_t)c * 3;
+    if (s_m[M_CNT] == 0.0) {  // empty cluster (the caller passed a label nobody carries): NaN like a 0/0 mean
+        for (int i = 0; i < 16; ++i) out[i] = NAN;
+        for (int i = 0; i < 3; ++i) sd[i] = NAN;
+        return;
+    }
+    // torch.isclose(max - min, 0): |d| <= atol (1e-8), in the float32 arithmetic of the reference
+    const float d = (float)s_m[M_WMAX] - (float)s_m[M_WMIN];
+    const bool flat = __builtin_fabsf(d) <= 1e-8f;
+    const int oq = flat ? M_QQ1 : M_QQW, ot = flat ? M_T1 : M_TW, ott = flat ? M_TT1 : M_TTW;
+    const double sw = flat ? s_m[M_CNT] : s_m[M_SW];
+    double A[4][4], V[4][4];
+    int k = 0;
+    for (int i = 0; i < 4; ++i)
+        for (int j = i; j < 4; ++j) { A[i][j] = A[j][i] = s_m[oq + k] / sw; ++k; }
+    jacobi4(A, V);
+    int best = 0;
+    for (int i = 1; i < 4; ++i)
+        if (A[i][i] > A[best][best]) best = i;
+    double qx = V[0][best], qy = V[1][best], qz = V[2][best], qw = V[3][best];
+    if (qw < 0.0) { qx = -qx; qy = -qy; qz = -qz; qw = -qw; }  // :139
+    const double n = __builtin_sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
+    qx /= n; qy /= n; qz /= n; qw /= n;
+    float mean[3];
+    for (int i = 0; i < 3; ++i) mean[i] = (float)(s_m[ot + i] / sw);
+    out[0] = (float)(1.0 - 2.0 * (qy * qy + qz * qz)); out[1] = (float)(2.0 * (qx * qy - qz * qw)); out[2] = (float)(2.0 * (qx * qz + qy * qw)); out[3] = mean[0];
+    out[4] = (float)(2.0 * (qx * qy + qz * qw)); out[5] = (float)(1.0 - 2.0 * (qx * qx + qz * qz)); out[6] = (float)(2.0 * (qy * qz - qx * qw)); out[7] = mean[1];
+    out[8] = (float)(2.0 * (qx * qz - qy * qw)); out[9] = (float)(2.0 * (qy * qz + qx * qw)); out[10] = (float)(1.0 - 2.0 * (qx * qx + qy * qy)); out[11] = mean[2];
+    out[12] = 0.f; out[13] = 0.f; out[14] = 0.f; out[15] = 1.f;
+    // sum w (t - m)^2 / sum w with m the float32 centre, from the moments
+    for (int i = 0; i < 3; ++i) {
+        const double m = (double)mean[i];
+        double var = (s_m[ott + i] - 2.0 * m * s_m[ot + i] + m * m * sw) / sw;
+        var = var < 0.0 ? 0.0 : var;
+        sd[i] = (float)__builtin_sqrt(var);
+    }
+}
+
+int launch_cluster_centers(midas_ctx* ctx, int64_t N, const float* poses, const double* w64, const float* w32,
+                           const int64_t* labels, int32_t C, const int64_t* label_values, float* centers, float* stds,
+                           int64_t* counts) {
+    const int nb = (int)ceil_div(N, 256);
+    void* part;
+    int rc = midas_scratch(ctx, (size_t)nb * C * CL_MOM * sizeof(double), &part);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_cluster_moments, dim3((unsigned)nb), dim3(256), 0, ctx->stream, N, poses, w64, w32, labels, (int)C,
+                       label_values, (double*)part);
+    hipLaunchKernelGGL(k_cluster_finish, dim3((unsigned)C), dim3(64), 0, ctx->stream, nb, (int)C, (const double*)part, centers,
+                       stds, counts);
+    MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    return MIDAS_OK;
+}
+
+}  // namespace midas

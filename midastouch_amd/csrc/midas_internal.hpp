@@ -284,6 +284,11 @@ int launch_tail_resample(midas_ctx* ctx, const midas_tail_resample_args& r);
 int launch_reduce_partials(midas_ctx* ctx, int np, const double* pmax, const double* pmin, const double* prm,
                            double* extrema2, double* rmse_sums2);
 
+// cluster.hip
+int launch_cluster_centers(midas_ctx* ctx, int64_t N, const float* poses, const double* w64, const float* w32,
+                           const int64_t* labels, int32_t C, const int64_t* label_values, float* centers, float* stds,
+                           int64_t* counts);
+
 // profiling hook used by the step: record event `slot` on the stream when profiling is on
 void prof_mark(midas_ctx* ctx, int slot);
 

@@ -230,3 +230,23 @@ def rmse(poses: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
     out = torch.empty(2, dtype=torch.float64, device=poses.device)
     _ctx(poses).call("midas_rmse", poses.shape[0], _ptr(poses), _ptr(gt), _ptr(out))
     return out
+
+
+def cluster_centers(poses: torch.Tensor, weights: torch.Tensor, labels: torch.Tensor, label_values: torch.Tensor):
+    """K9: (centres (C,4,4) f32, stds (C,3) f32, members (C,) i64) of the clusters `label_values` (midas_cluster_centers)."""
+    poses = _poses(poses)
+    dev = poses.device
+    labels = labels.to(dev, torch.int64).contiguous()
+    label_values = label_values.to(dev, torch.int64).contiguous()
+    weights = weights.to(dev).contiguous()
+    if weights.dtype not in (torch.float32, torch.float64):
+        weights = weights.double()
+    C = int(label_values.shape[0])
+    centers = torch.empty((C, 4, 4), dtype=torch.float32, device=dev)
+    stds = torch.empty((C, 3), dtype=torch.float32, device=dev)
+    counts = torch.empty((C,), dtype=torch.int64, device=dev)
+    w64 = _ptr(weights) if weights.dtype == torch.float64 else None
+    w32 = _ptr(weights) if weights.dtype == torch.float32 else None
+    _ctx(poses).call("midas_cluster_centers", poses.shape[0], _ptr(poses), w64, w32, _ptr(labels), C, _ptr(label_values),
+                     _ptr(centers), _ptr(stds), _ptr(counts))
+    return centers, stds, counts

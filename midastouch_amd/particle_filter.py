@@ -210,14 +210,20 @@ class particle_filter:
     def get_cluster_centers(self, _particles: Particles, method: str = "logmap") -> Tuple[torch.Tensor, torch.Tensor]:
         """Weighted pose mean + translation std per cluster label (:153-206).
 
-        "quat_avg" is Markley's quaternion mean (modules/pose.py:112-147; the symmetric 4x4 goes through
-        torch.linalg.eigh because Tensor.eig no longer exists); "logmap" averages rotation vectors.
+        "quat_avg" (what filter.py:185 asks for) is Markley's quaternion mean (modules/pose.py:112-147) on the device:
+        one pass over the particles accumulates every cluster's moments, a small kernel solves the symmetric 4x4
+        eigenproblem the reference handed to the removed Tensor.eig (midas_cluster_centers, csrc/cluster.hip).
+        "logmap" averages rotation vectors with torch ops.
         """
-        from .pose import quat_average_pose, logmap_average_pose
-
         particles = copy.copy(_particles)
-        poses, weights, labels = particles.poses, particles.weights.float(), particles.labels
+        poses, labels = particles.poses, particles.labels
         uniq = torch.unique(labels)
+        if method == "quat_avg":  # K9: every cluster in one pass over the particles (ops.cluster_centers)
+            cluster_poses, cluster_stds, _ = ops.cluster_centers(poses, particles.weights, labels, uniq)
+            return cluster_poses, cluster_stds
+        from .pose import logmap_average_pose
+
+        weights = particles.weights.float()
         cluster_stds = torch.zeros((uniq.shape[0], 3), device=uniq.device)
         cluster_poses = torch.zeros((uniq.shape[0], 4, 4), device=uniq.device)
         for i, label in enumerate(uniq):
@@ -225,7 +231,7 @@ class particle_filter:
             tp, tw = poses[sel, :, :], weights[sel]
             if torch.isclose(tw.max() - tw.min(), torch.tensor([0.0], device=tw.device, dtype=tw.dtype)):
                 tw = torch.ones_like(tw)
-            cluster_poses[i] = logmap_average_pose(tp, tw) if method == "logmap" else quat_average_pose(tp, tw)
+            cluster_poses[i] = logmap_average_pose(tp, tw)
             cluster_stds[i, :] = torch.sqrt(torch.sum(((tp[:, :3, 3] - cluster_poses[i, :3, 3]) ** 2 * tw[:, None]) / tw.sum(), dim=0))
         return cluster_poses, cluster_stds
 

@@ -302,6 +302,40 @@ def init_filter_compose(gt, tn, rot_deg):
     return (np.asarray(gt, dtype=np.float32)[None] @ Tn).astype(np.float32)
 
 
+def cluster_centers(poses, weights, labels):
+    """particle_filter.get_cluster_centers(method="quat_avg") (particle_filter.py:153-206) + pose.xyz_quat_averaged
+    (pose.py:112-147) in numpy float64: per unique label, float32 weights flattened to 1 when isclose(max - min, 0);
+    Markley mean = principal eigenvector of sum w q q^T / sum w over quaternions with qw >= 0 (numpy eigh stands in for the
+    removed Tensor.eig: the matrix is symmetric); weighted mean translation; std about the float32 centre.
+    -> (label values (C,), centres (C,4,4) f32, stds (C,3) f32)."""
+    from scipy.spatial.transform import Rotation
+    poses = np.asarray(poses, dtype=np.float32).reshape(-1, 4, 4)
+    w32 = np.asarray(weights).astype(np.float32)
+    labels = np.asarray(labels)
+    uniq = np.unique(labels)
+    centers = np.zeros((len(uniq), 4, 4), dtype=np.float32)
+    stds = np.zeros((len(uniq), 3), dtype=np.float32)
+    for i, lab in enumerate(uniq):
+        sel = labels == lab
+        tp, tw = poses[sel].astype(np.float64), w32[sel]
+        if abs(np.float32(tw.max() - tw.min())) <= 1e-8:
+            tw = np.ones_like(tw)
+        tw = tw.astype(np.float64)
+        q = Rotation.from_matrix(tp[:, :3, :3]).as_quat()  # x, y, z, w
+        q[q[:, 3] < 0] *= -1.0
+        M = np.einsum("n,ni,nj->ij", tw, q, q) / tw.sum()
+        evals, evecs = np.linalg.eigh(M)
+        aq = evecs[:, np.argmax(evals)]
+        if aq[3] < 0:
+            aq = -aq
+        centers[i, :3, :3] = Rotation.from_quat(aq).as_matrix()
+        centers[i, :3, 3] = (tp[:, :3, 3] * tw[:, None]).sum(axis=0) / tw.sum()
+        centers[i, 3, 3] = 1.0
+        d = tp[:, :3, 3] - centers[i, :3, 3].astype(np.float64)
+        stds[i] = np.sqrt((d * d * tw[:, None]).sum(axis=0) / tw.sum())
+    return uniq, centers, stds
+
+
 class Annealer:
     """particle_filter.annealing (particle_filter.py:405-447) on index sets.
 
