@@ -91,11 +91,15 @@ def step(engine: FilterEngine, odom: torch.Tensor, tactile_code: torch.Tensor, g
 
 # ---- the reference loop -----------------------------------------------------------------------------
 def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str = "fixed", max_frames: int = None,
-           cluster: bool = True, progress: bool = False) -> dict:
+           cluster: bool = True, progress: bool = False, softmax: bool = True, update_freq: int = 1, floor: int = 1000,
+           results_path: Optional[str] = None) -> dict:
     """Run the filter over a sequence; returns the reference's `filter_stats` dict (filter.py:99-116).
 
     pace="fixed" steps one frame per iteration (deterministic); pace="wallclock" reproduces
     `idx = int(frame_rate * total_time)` (:134-135): slow iterations skip frames, fast ones repeat.
+    The defaults are `filter/filter.py`'s; `filter_real(...)` below presets the real-data script's variations
+    (`filter/filter_real.py`: raw scores :208-210, measurement update every `update_freq`-th frame with unit weights
+    in between :205-212, annealing floor 10000 :228).  results_path: directory `filter_stats.npy` is written to (:252).
     """
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     expt_cfg = cfg.expt
@@ -148,8 +152,11 @@ def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str
         filter_stats["rmse_r"].append(rmse_r.item())
 
         start = time.time()
-        _, _, nn_tactile_codes = codebook.SE3_NN(particles.poses)
-        particles.weights = pf.get_similarity(tactile_code, nn_tactile_codes, softmax=True)
+        if count % max(int(update_freq), 1) == 0:
+            _, _, nn_tactile_codes = codebook.SE3_NN(particles.poses)
+            particles.weights = pf.get_similarity(tactile_code, nn_tactile_codes, softmax=softmax)
+        else:  # filter_real.py:211-212 (float32 ones there; float64 here so that the in-place prune keeps its dtype)
+            particles.weights = torch.ones(len(particles), device=device, dtype=torch.float64)
         particles, drifted = pf.remove_invalid_particles(particles)
         if drifted:
             particles.poses, _, _ = codebook.SE3_NN(particles.poses)
@@ -157,7 +164,7 @@ def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str
             if count % 50 == 0:
                 particles = pf.cluster_particles(particles)
             cluster_poses, cluster_stds = pf.get_cluster_centers(particles, method="quat_avg")
-            particles = pf.annealing(particles, torch.mean(cluster_stds).cpu())
+            particles = pf.annealing(particles, torch.mean(cluster_stds).cpu(), floor=floor)
         else:
             cluster_poses = torch.zeros((0, 4, 4), device=device)
             cluster_stds = torch.zeros((0, 3), device=device)
@@ -184,7 +191,29 @@ def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str
         filter_stats["total_time"] = sum(filter_stats["time"])
     filter_stats["avg_time"] = sum(filter_stats["time"]) / max(len(filter_stats["time"]), 1)
     filter_stats["avg_timer"] = {k: float(np.average(v)) if v else 0.0 for k, v in avg_timer.items()}
+    if results_path is not None:
+        save_filter_stats(filter_stats, results_path)
     return filter_stats
+
+
+def save_filter_stats(filter_stats: dict, results_path: str) -> str:
+    """`np.save(results_path/filter_stats.npy, filter_stats)` (filter.py:252) - a pickled dict, read back with
+    `np.load(..., allow_pickle=True).item()`; device tensors are moved to the host first."""
+    import os
+
+    os.makedirs(results_path, exist_ok=True)
+    host = {k: ([t.cpu() if torch.is_tensor(t) else t for t in v] if isinstance(v, list) else
+                (v.cpu() if torch.is_tensor(v) else v)) for k, v in filter_stats.items()}
+    path = os.path.join(results_path, "filter_stats.npy")
+    np.save(path, host)
+    return path
+
+
+def filter_real(cfg, seq: Optional[Sequence] = None, **kw) -> dict:
+    """The loop with `filter/filter_real.py`'s settings: raw similarity scores as weights, annealing floor 10000."""
+    kw.setdefault("softmax", False)
+    kw.setdefault("floor", 10000)
+    return filter(cfg, seq, **kw)
 
 
 def main(argv=None):
@@ -193,9 +222,10 @@ def main(argv=None):
     from .config import load_config
 
     cfg = load_config(list(sys.argv[1:] if argv is None else argv))
-    stats = filter(cfg, progress=True)
+    stats = filter(cfg, progress=True, results_path=".")
     print(f"Total time: {stats['total_time']:.3f}, Per iteration time: {stats['avg_time']:.4f}")
-    np.save("filter_stats.npy", {k: v for k, v in stats.items() if k not in ("cluster_poses", "cluster_stds")})
+    t = stats["avg_timer"]
+    print(f'Avg time: tactile: {t["tactile"]:.2f}, motion : {t["motion"]:.2f}, meas : {t["meas"]:.2f} ')
 
 
 if __name__ == "__main__":

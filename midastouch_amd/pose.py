@@ -1,8 +1,7 @@
 """SE(3) helpers used by the low-rate parts of the filter (cluster centres), torch ops on the device.
 
-Counterparts of `midastouch/modules/pose.py`: `xyz_quat_averaged` (:112-147), `log_map_averaged`
-(:101-109), `tf_to_xyzquat` (:26-34).  These run once per frame over a handful of clusters; they are
-not on the accelerated per-particle path.
+Counterparts of `midastouch/modules/pose.py`: `log_map_averaged` (:101-109), `tf_to_xyzquat` (:26-34).
+`xyz_quat_averaged` (:112-147), the one the filter loop uses, is the K9 kernel (`ops.cluster_centers`).
 """
 from __future__ import annotations
 
@@ -25,33 +24,6 @@ def tf_to_xyzquat(poses: torch.Tensor) -> torch.Tensor:
     k = torch.where(th > 1e-8, torch.sin(half) / th.clamp_min(1e-30), 0.5 - th * th / 48.0)
     q = torch.cat((torch.cos(half), w * k), dim=1)
     return torch.cat((poses[:, :3, 3].double(), q), dim=1)
-
-
-def _quat_to_matrix(q: torch.Tensor) -> torch.Tensor:
-    w, x, y, z = (q / q.norm()).unbind()
-    return torch.stack([
-        torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)]),
-        torch.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)]),
-        torch.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]),
-    ])
-
-
-def quat_average_pose(T: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    """Markley weighted quaternion mean + weighted mean translation -> (4,4) float32."""
-    xq = tf_to_xyzquat(T)
-    q = xq[:, 3:]
-    q = torch.where(q[:, :1] < 0, -q, q)  # antipodal fix (pose.py:126)
-    wd = w.double()
-    M = (q[:, :, None] * q[:, None, :] * wd[:, None, None]).sum(dim=0) / wd.sum()
-    evals, evecs = torch.linalg.eigh(M.cpu())
-    avg_q = evecs[:, -1].to(T.device)
-    if avg_q[0] < 0:
-        avg_q = -avg_q
-    avg_t = (xq[:, :3] * wd[:, None]).sum(dim=0) / wd.sum()
-    out = torch.eye(4, dtype=torch.float64, device=T.device)
-    out[:3, :3] = _quat_to_matrix(avg_q)
-    out[:3, 3] = avg_t
-    return out.float()
 
 
 def _hat(v: torch.Tensor) -> torch.Tensor:

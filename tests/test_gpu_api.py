@@ -184,3 +184,19 @@ def test_reference_loop_runs_and_tracks(dev):
     # converged: the particle cloud ends within a few mm of the ground truth
     assert stats["rmse_t"][-1] < 0.02
     assert min(stats["num_particles"]) >= 1000
+
+
+def test_filter_real_settings_and_stats_file(dev, tmp_path):
+    """filter_real(): raw scores as weights, measurement update every other frame, floor 10000; filter_stats.npy (:252)."""
+    from midastouch_amd.config import load_config
+    from midastouch_amd.filter import filter_real, synthetic_sequence
+    cfg = load_config(["expt.params.num_particles=3000", "expt.codebook_size=4000"])
+    seq = synthetic_sequence(cfg, dev, T=24)
+    torch.manual_seed(0)
+    stats = filter_real(cfg, seq=seq, device=dev, update_freq=2, results_path=str(tmp_path))
+    assert len(stats["rmse_t"]) == 24 and np.isfinite(stats["rmse_t"]).all()
+    # floor=10000 > 3000 particles: abs(N - floor) never limits the removal, N//3 does; the count stays positive
+    assert min(stats["num_particles"]) >= 1
+    back = np.load(str(tmp_path / "filter_stats.npy"), allow_pickle=True).item()
+    assert back["traj_size"] == 24 and len(back["cluster_poses"]) == 24 and not back["cluster_poses"][0].is_cuda
+    assert back["rmse_t"] == stats["rmse_t"]
