@@ -156,6 +156,15 @@ int midas_cluster_centers(midas_ctx* ctx, int64_t N, const float* poses_dev, con
                           const float* weights32_dev, const int64_t* labels_dev, int32_t C, const int64_t* label_values_dev,
                           float* centers_dev, float* stds_dev, int64_t* counts_dev);
 
+/* ---- single-touch evaluation: top-n of similarity rows + best pose error (next-3) ------------- */
+/* eval/single_touch_test.py:35-73 top_n_error: for each of the B query rows of scores_dev (B x K float64, row b = the
+ * similarities of codebook entry row0 + b to every entry, e.g. from midas_score / midas_score_batch) the diagonal entry is
+ * set to 0 (:64), the n best-scoring entries are selected (value descending, smaller index first on ties; np.argpartition
+ * leaves ties unspecified) and err_dev[b] = min over them of |feat[j] - feat[row0 + b]|_2 (feat_dev: K x d float64, d <= 16).
+ * idx_dev: NULL or B x n int32, the selected entries best first (-1 padded when K < n).  1 <= n <= 256. */
+int midas_topn_pose_error(midas_ctx* ctx, int32_t B, int64_t K, const double* scores_dev, int64_t row0, int32_t n,
+                          const double* feat_dev, int32_t d, double* err_dev, int32_t* idx_dev);
+
 /* ---- the fused per-frame step ---------------------------------------------------------------- */
 /* One call = filter/filter.py:150-190 minus clustering/annealing:
  *   score codebook -> propagate -> feature -> NN -> x = s[idx] -> softmax -> prune -> cdf ->

@@ -356,6 +356,14 @@ MIDAS_EXPORT int midas_cluster_centers(midas_ctx* ctx, int64_t N, const float* p
                                   stds_dev, counts_dev);
 }
 
+MIDAS_EXPORT int midas_topn_pose_error(midas_ctx* ctx, int32_t B, int64_t K, const double* scores_dev, int64_t row0, int32_t n,
+                                       const double* feat_dev, int32_t d, double* err_dev, int32_t* idx_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, B >= 1 && K >= 1 && scores_dev && feat_dev && err_dev && n >= 1 && n <= 256 && d >= 1 && d <= 16);
+    MIDAS_REQUIRE(ctx, row0 >= 0 && row0 + B <= K);
+    return launch_topn_pose_error(ctx, B, K, scores_dev, row0, n, feat_dev, d, err_dev, idx_dev);
+}
+
 MIDAS_EXPORT int midas_filter_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
                                    const midas_tree* tree3, const midas_step_args* args) {
     MIDAS_ENTER(ctx);

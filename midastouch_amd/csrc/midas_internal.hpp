@@ -289,6 +289,10 @@ int launch_cluster_centers(midas_ctx* ctx, int64_t N, const float* poses, const 
                            const int64_t* labels, int32_t C, const int64_t* label_values, float* centers, float* stds,
                            int64_t* counts);
 
+// topn.hip
+int launch_topn_pose_error(midas_ctx* ctx, int32_t B, int64_t K, const double* scores, int64_t row0, int32_t n,
+                           const double* feat, int32_t d, double* err_out, int32_t* idx_out);
+
 // profiling hook used by the step: record event `slot` on the stream when profiling is on
 void prof_mark(midas_ctx* ctx, int slot);
 

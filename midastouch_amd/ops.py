@@ -250,3 +250,16 @@ def cluster_centers(poses: torch.Tensor, weights: torch.Tensor, labels: torch.Te
     _ctx(poses).call("midas_cluster_centers", poses.shape[0], _ptr(poses), w64, w32, _ptr(labels), C, _ptr(label_values),
                      _ptr(centers), _ptr(stds), _ptr(counts))
     return centers, stds, counts
+
+
+def topn_pose_error(scores: torch.Tensor, row0: int, n: int, feat: torch.Tensor, want_idx: bool = False):
+    """Per row of `scores` (B, K) f64 - row b = similarities of entry row0 + b - the best pose error among its n
+    best-scoring entries, diagonal zeroed (midas_topn_pose_error; eval/single_touch_test.py:35-73)."""
+    scores = scores.to(torch.float64).contiguous()
+    feat = feat.to(scores.device, torch.float64).contiguous()
+    B, K = scores.shape
+    err = torch.empty((B,), dtype=torch.float64, device=scores.device)
+    idx = torch.empty((B, n), dtype=torch.int32, device=scores.device) if want_idx else None
+    _ctx(scores).call("midas_topn_pose_error", B, K, _ptr(scores), int(row0), int(n), _ptr(feat), int(feat.shape[1]), _ptr(err),
+                      _ptr(idx))
+    return (err, idx) if want_idx else err
