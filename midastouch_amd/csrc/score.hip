@@ -120,6 +120,10 @@ constexpr int MF_WAVES = MIDAS_MF_WAVES;   // waves per workgroup: they share on
 constexpr int MF_CODES = 64;   // codes per pass (4 N-tiles)
 constexpr int MF_DC = MIDAS_MF_DC;         // D-chunk staged in LDS
 constexpr int MF_PAD = 4;      // floats of padding per staged code row (bank spread)
+#ifndef MIDAS_MF_PF
+#define MIDAS_MF_PF 2
+#endif
+constexpr int MF_PF = MIDAS_MF_PF;         // row pieces in flight per lane and queue
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
@@ -172,20 +176,37 @@ __global__ __launch_bounds__(64 * MF_WAVES) void k_score_mfma(const float* __res
         const int dc = D - d0 < MF_DC ? D - d0 : MF_DC;
         const int ld = dc + MF_PAD;
         __syncthreads();
-        for (int idx = threadIdx.x; idx < MF_CODES * (dc / 4); idx += 64 * MF_WAVES) {  // stage this D-chunk of the 64 codes
-            const int b = idx / (dc / 4), d = (idx - b * (dc / 4)) * 4;
-            *reinterpret_cast<float4*>(&s_e[b * ld + d]) =
-                *reinterpret_cast<const float4*>(&codes32[(int64_t)(b0 + b) * D + d0 + d]);
+        // stage this D-chunk of the 64 codes: eight 16-byte pieces per thread and round trip (a rolled copy loop waits
+        // for every load before it issues the next one)
+        const int q4 = dc / 4, total = MF_CODES * q4;
+        for (int base = 0; base < total; base += 8 * 64 * MF_WAVES) {
+            float4 v[8];
+            int off[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int idx = base + k * 64 * MF_WAVES + (int)threadIdx.x;
+                const int ic = idx < total ? idx : total - 1;
+                const int b = ic / q4, d = (ic - b * q4) * 4;
+                off[k] = idx < total ? b * ld + d : -1;
+                v[k] = *reinterpret_cast<const float4*>(&codes32[(int64_t)(b0 + b) * D + d0 + d]);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (off[k] >= 0) *reinterpret_cast<float4*>(&s_e[off[k]]) = v[k];
         }
         __syncthreads();
-        float4 a_next = *reinterpret_cast<const float4*>(arow + d0 + 4 * g);
-        for (int c = 0; c < dc; c += 16) {
-            const float4 a = a_next;
-            const int cn = c + 16 < dc ? c + 16 : c;  // the next step's row piece travels while this step computes
-            a_next = *reinterpret_cast<const float4*>(arow + d0 + cn + 4 * g);
+        // The row pieces travel MF_PF steps ahead of the multiplies.  Two register queues alternate: a piece is fetched
+        // into the queue that is NOT being multiplied from - fetched into the registers the MFMAs of the step still read,
+        // the compiler parks it in a temporary and waits for it on the spot (s_waitcnt vmcnt(0) in every step).
+        auto piece = [&](int c) {
+            const int cc = c < dc ? c : dc - 16;
+            return *reinterpret_cast<const float4*>(arow + d0 + cc + 4 * g);
+        };
+        auto step = [&](const float4& a, int c) {
+            const float* eb = reinterpret_cast<const float*>(__builtin_assume_aligned(s_e, 16));
             float4 e[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) e[t] = *reinterpret_cast<const float4*>(&s_e[(16 * t + i) * ld + c + 4 * g]);
+            for (int t = 0; t < 4; ++t) e[t] = *reinterpret_cast<const float4*>(&eb[(16 * t + i) * ld + c + 4 * g]);
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, e[t].x, acc[t], 0, 0, 0);
 #pragma unroll
@@ -194,6 +215,23 @@ __global__ __launch_bounds__(64 * MF_WAVES) void k_score_mfma(const float* __res
             for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, e[t].z, acc[t], 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, e[t].w, acc[t], 0, 0, 0);
+        };
+        float4 qa[MF_PF], qb[MF_PF];
+#pragma unroll
+        for (int p = 0; p < MF_PF; ++p) qa[p] = piece(16 * p);
+        for (int c0 = 0; c0 < dc; c0 += 32 * MF_PF) {
+#pragma unroll
+            for (int p = 0; p < MF_PF; ++p) {
+                const int c = c0 + 16 * p;
+                qb[p] = piece(c + 16 * MF_PF);
+                if (c < dc) step(qa[p], c);  // wave-uniform
+            }
+#pragma unroll
+            for (int p = 0; p < MF_PF; ++p) {
+                const int c = c0 + 16 * (MF_PF + p);
+                qa[p] = piece(c + 16 * MF_PF);
+                if (c < dc) step(qb[p], c);
+            }
         }
     }
     // D[row = 4g + r][code = i] in register r of lane (g, i)
@@ -202,10 +240,18 @@ __global__ __launch_bounds__(64 * MF_WAVES) void k_score_mfma(const float* __res
         const int b = 16 * t + i;
         if (b < nb) {
             const double ne = code_norms[b0 + b];
+            const int64_t k0 = row0 + 4 * g;  // the lane's four rows are consecutive: one 32-byte run of the code's scores
+            double* o = out + (int64_t)(b0 + b) * K + k0;
+            if (k0 + 3 < K && ((uintptr_t)o & 15) == 0) {
+                double2 lo, hi;
+                lo.x = (double)acc[t][0] / (ne * norms[k0]); lo.y = (double)acc[t][1] / (ne * norms[k0 + 1]);
+                hi.x = (double)acc[t][2] / (ne * norms[k0 + 2]); hi.y = (double)acc[t][3] / (ne * norms[k0 + 3]);
+                reinterpret_cast<double2*>(o)[0] = lo;
+                reinterpret_cast<double2*>(o)[1] = hi;
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t k = row0 + 4 * g + r;
-                if (k < K) out[(int64_t)(b0 + b) * K + k] = (double)acc[t][r] / (ne * norms[k]);
+                for (int r = 0; r < 4; ++r)
+                    if (k0 + r < K) o[r] = (double)acc[t][r] / (ne * norms[k0 + r]);
             }
         }
     }

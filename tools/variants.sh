@@ -8,11 +8,12 @@ mkdir -p build/variants
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wall -Wno-unused-function"
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
-  ( /opt/rocm/bin/hipcc $F $flags -c score.hip -o build/variants/$name.score.o &&
-    /opt/rocm/bin/hipcc $F $flags -c particles.hip -o build/variants/$name.particles.o &&
-    /opt/rocm/bin/hipcc $F $flags -c resample.hip -o build/variants/$name.resample.o &&
-    /opt/rocm/bin/hipcc $F $flags -c api.hip -o build/variants/$name.api.o &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/$name.so build/variants/$name.score.o build/variants/$name.particles.o build/variants/$name.resample.o build/variants/$name.api.o &&
+  ( objs=""
+    for f in score particles resample cluster topn api; do
+      /opt/rocm/bin/hipcc $F $flags -c $f.hip -o build/variants/$name.$f.o || exit 1
+      objs="$objs build/variants/$name.$f.o"
+    done
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/$name.so $objs &&
     echo built $name ) &
 done
 wait
