@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--sharded", action="store_true", help="use the particle-sharded engine even on one GPU (smoke test)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "a2a", "allgather"], help="sharded engine: form of the resample exchange")
     ap.add_argument("--eager", action="store_true", help="materialise the resampled particles every frame (three launches per frame)")
+    ap.add_argument("--resample", default="weighted_random", choices=["weighted_random", "low_var"],
+                    help="resampler mode (particle_filter.py:230-307): the reference's default multinomial draws, or systematic")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,10 +130,11 @@ def main():
         # pipelined: the resample of frame t runs inside the front kernel of frame t+1 (two launches per frame); the
         # particle set is materialised when it is read - here once, after the timed region (eng.status below)
         cls = FilterEngine if args.eager else PipelinedFilterEngine
-        eng = cls(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4000, device=dev)
+        eng = cls(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4000, device=dev, resample=args.resample)
     else:
         from midastouch_amd.dist import ShardedFilterEngine
-        eng = ShardedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4000, device=dev, exchange=args.exchange)
+        eng = ShardedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4000, device=dev, exchange=args.exchange,
+                                  resample=args.resample)
     rng = np.random.default_rng(100 + rank)
     # particles start on codebook poses within ~2 cm of the first ground-truth pose
     d0 = np.linalg.norm(cb.poses[:, :3, 3] - traj.gt_poses[0][:3, 3], axis=1)
@@ -186,7 +189,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "c2: 004_sugar_box synthetic trajectory, N=%d particles/GPU x K=%d x D=%d codebook, "
-                               "device Philox draws, multinomial resample" % (N, K, D),
+                               "device Philox draws, %s resample" % (N, K, D, "multinomial" if args.resample == "weighted_random" else "systematic"),
                    "particles_per_gpu": N, "particles_total": N * world, "codebook_rows": K, "embedding_dim": D,
                    "parallelism": "particle-sharded x%d" % world if sharded else "single",
                    "engine": ("sharded, exchange=" + eng.exchange) if sharded else ("eager: 3 launches/frame" if args.eager else
