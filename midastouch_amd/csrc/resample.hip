@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void k_tail_a2(int64_t N, const double* __rest
 // trips fewer on a latency-bound kernel).  Single trajectory, N >= 16; MIDAS_TAIL_DIRECT=0 selects k_tail_a2.
 __global__ __launch_bounds__(256) void k_tail_a2d(int64_t N, const double* __restrict__ scores, const int32_t* __restrict__ nn_idx,
                                                   const uint8_t* __restrict__ valid, int32_t softmax, TailTables tb, bool padded,
-                                                  int32_t* __restrict__ status) {
+                                                  int32_t* __restrict__ status, double* __restrict__ flags_out) {
     __shared__ double s_gtot[16];
     __shared__ double s_red[24];
     int kept = 0;
@@ -511,6 +511,10 @@ __global__ __launch_bounds__(256) void k_tail_a2d(int64_t N, const double* __res
     if (threadIdx.x == 0) {
         if (nan) atomicOr(&status[0], 2);
         if (kept) atomicAdd(&status[1], kept);
+        if (flags_out) {  // sharded exchange record: NaN marker (any non-zero) and kept count (exact: integers far below 2^53)
+            if (nan) atomicAdd(&flags_out[0], 1.0);
+            if (kept) atomicAdd(&flags_out[1], (double)kept);
+        }
     }
 }
 
@@ -1447,6 +1451,15 @@ int launch_tail_fin(midas_ctx* ctx, int64_t N, const double* e, const double* x_
 int launch_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
                         int32_t softmax, const TailTables& tb, double* r1, int32_t* status) {
     const int nb = (int)ceil_div(N, SCAN_BLOCK);
+    static const bool direct = !(getenv("MIDAS_TAIL_DIRECT") && atoi(getenv("MIDAS_TAIL_DIRECT")) == 0);
+    if (direct && N >= SCAN_CHUNK) {  // the shard's per-slot tables are padded (shard_tables_of, api.hip)
+        TailTables t = tb;
+        t.bsum_e = r1; t.btot = r1 + nb; t.btot_raw = r1 + 2 * nb; t.bmax = r1 + 3 * nb; t.bmin = r1 + 4 * nb;
+        hipLaunchKernelGGL(k_tail_a2d, dim3((unsigned)nb), dim3(256), 0, ctx->stream, N, scores, nn_idx, valid, softmax, t, true,
+                           status, r1 + 5 * nb);
+        LAUNCH_CHECK(ctx);
+        return MIDAS_OK;
+    }
     hipLaunchKernelGGL(k_tail_a2, dim3((unsigned)nb), dim3(256), 0, ctx->stream, N, scores, nn_idx, valid, softmax, tb.e, tb.x_raw,
                        tb.lp, tb.lp_raw, tb.gend, tb.gend_raw, tb.ggend, tb.ggend_raw, r1, r1 + nb, r1 + 2 * nb, r1 + 3 * nb, r1 + 4 * nb,
                        status, r1 + 5 * nb, 0);
@@ -1476,7 +1489,7 @@ int launch_tail_a2(midas_ctx* ctx, int64_t N, const double* scores, const int32_
     static const bool direct = !(getenv("MIDAS_TAIL_DIRECT") && atoi(getenv("MIDAS_TAIL_DIRECT")) == 0);
     if (direct && batch <= 1 && N >= SCAN_CHUNK) {
         hipLaunchKernelGGL(k_tail_a2d, dim3((unsigned)nb), dim3(256), 0, ctx->stream, N, scores, nn_idx, valid, softmax, tb,
-                           padded_tables, status);
+                           padded_tables, status, (double*)nullptr);
         LAUNCH_CHECK(ctx);
         return MIDAS_OK;
     }
