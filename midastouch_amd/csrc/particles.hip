@@ -1385,6 +1385,195 @@ __global__ __launch_bounds__(256) void k_frame_front(TreeView<Kd6> t6, TreeView<
 }
 
 // =================================================================================================
+// two-kernel form of the front: (A) resample prologue + propagate + feature, beside the codebook scoring;
+// (B) nearest neighbour + prune with FOUR lanes per particle
+// =================================================================================================
+// At N = 100k the particle waves of the single front kernel are 1.5 per SIMD and every one of them walks its whole chain
+// of dependent fetches alone.  The chain's second half - list scans - parallelises over records:
+// a quad of lanes fetches the 32 solo records of the neighbour list (then the 16 of the vertex list) in ONE round trip
+// instead of four (two).  That needs four times the waves, which do not fit beside the 127-register front and the
+// scoring stream; as a kernel of its own (no propagate state, no scoring) they do.  The hand-over is 32 bytes per
+// particle (6-d feature + hint); the results are the ones of the single-kernel form bit for bit (exact NN with the same
+// tie rule, the same "first event in record order" of the prune list).
+struct alignas(16) PuFeat { float f[6]; int32_t hint; int32_t pad; };
+static_assert(sizeof(PuFeat) == 32, "two 16-byte pieces per particle");
+
+// part A of a particle wave: what particle_update_wave does before the nearest-neighbour search, plus its rmse epilogue
+MD void particle_front_wave(ParticleUpdateArgs a, int64_t wave, const double* rs_lds, PuFeat* __restrict__ feat) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = wave * 64 + lane;
+    const bool live = n < a.N;
+    if (wave == 0 && lane == 0) {
+        if (a.status_reset) { a.status_reset[0] = 0; a.status_reset[1] = 0; }
+        if (a.flags_reset) { a.flags_reset[0] = 0.0; a.flags_reset[1] = 0.0; }
+    }
+    double et2 = 0.0, ang2 = 0.0;
+    int64_t src = n;
+    if (rs_lds && live) {
+        src = lazy_source(a.rs, rs_lds, n, a.N);
+        if (a.rs.ridx_out) a.rs.ridx_out[n] = (int32_t)src;
+    }
+    const float* pose_src = rs_lds ? a.rs.poses_prev : a.poses_in;
+    if (live) {
+        float P[16], O[16], R[16], f[6];
+        load_pose(pose_src + src * 16, P);
+        const int32_t hint = rs_lds ? a.rs.nn_prev[src] : a.hint_in ? a.hint_in[n] : -1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) O[i] = a.odom16[i];
+        propagate_one(n, n + a.slot_base, P, O, a.tn, a.rot, a.std_t, a.std_r, a.seed, a.step, R);
+        store_pose(a.poses_prop + n * 16, R);
+        se3_feature(R, 0.99f, 0.01f, f);
+        float4* o = reinterpret_cast<float4*>(feat + n);
+        o[0] = make_float4(f[0], f[1], f[2], f[3]);
+        o[1] = make_float4(f[4], f[5], __int_as_float(hint), 0.f);
+        if (a.gt16) {
+            float G[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) G[i] = a.gt16[i];
+            rmse_terms(R, G, et2, ang2);
+        }
+    }
+    if (a.gt16) {
+        et2 = wave_sum(et2);
+        ang2 = wave_sum(ang2);
+        if (lane == 0) { a.part_rmse[2 * wave] = et2; a.part_rmse[2 * wave + 1] = ang2; }
+    }
+}
+
+template <typename T, int NJ, bool LAZY>
+__global__ __launch_bounds__(256) void k_frame_front_a(ParticleUpdateArgs a, int n_pu, int nwaves, PuFeat* __restrict__ feat,
+                                                       const T* __restrict__ emb, const double* __restrict__ norms,
+                                                       const double* __restrict__ code, double* __restrict__ scores, int64_t K) {
+    __shared__ double s_rs[LAZY ? 3 * LAZY_MAX_BLOCKS + 8 : 8];
+    const int w = threadIdx.x >> 6;
+    if ((int)blockIdx.x < n_pu) {
+        if (LAZY) lazy_tables(a.rs, s_rs);
+        const int64_t wave = (int64_t)blockIdx.x * 4 + w;
+        if (wave < nwaves) particle_front_wave(a, wave, LAZY ? s_rs : nullptr, feat);
+    } else {
+        score_wave<T, NJ, 0>(emb, norms, code, scores, K, (int64_t)(blockIdx.x - n_pu) * 4 + w);
+    }
+}
+
+template <int CTRL>
+MD float dpp_f32(float v) { return __uint_as_float(dpp_u32<CTRL>(__float_as_uint(v))); }
+constexpr int DPP_QUAD_LANE0 = 0x00, DPP_QUAD_LANE3 = 0xFF;  // quad_perm broadcasts
+
+// part B: a wave = 16 particles x 4 lanes; lane q4 of a quad takes records q4, q4 + 4, ... of its particle's lists
+static_assert(NN_SOLO == 32 && MESH_SOLO == 16, "the quad scans fetch 8 + 4 records per lane");
+#ifndef MIDAS_NNP_OCC
+#define MIDAS_NNP_OCC 4
+#endif
+__global__ __launch_bounds__(256, MIDAS_NNP_OCC) void k_particle_nn_prune(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a,
+                                                           const PuFeat* __restrict__ feat) {
+    __shared__ double s_cd[4][KD_MAX_LEVELS * 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, q4 = lane & 3;
+    const int64_t p = ((int64_t)blockIdx.x * 4 + w) * 16 + (lane >> 2);
+    const bool live = p < a.N, owner = q4 == 0;
+    const int64_t pc = live ? p : a.N - 1;
+    const float4* fp = reinterpret_cast<const float4*>(feat + pc);
+    const float4 f0 = fp[0], f1 = fp[1];
+    const float q[6] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y};
+    const int32_t hint = live ? __float_as_int(f1.z) : -1;
+    // ---- nearest codebook entry: records 0 .. 31 of the hinted entry's list in one round trip ----
+    float best = INFINITY, r_lane = 0.f;
+    int64_t bi = 0;
+    bool done = !live;
+    const bool hinted = live && hint >= 0 && (int64_t)hint < t6.K;
+    {
+        const Nbr6* nb = t6.nbrs + (size_t)(hinted ? hint : 0) * NBR_REC;
+        Nbr6 e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = nb[4 * j + q4];
+        float d0 = 0.f, ld = INFINITY;
+        int li = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            Point6 pt;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) pt.c[c] = e[j].c[c];
+            const float d = dist2(q, pt);
+            if (j == 0) d0 = d;  // record 0 (lane 0 of the quad) is the entry itself: the starting candidate, handled below
+            const bool cand = !(j == 0 && q4 == 0);
+            if (cand && (d < ld || (d == ld && e[j].idx < li))) { ld = d; li = e[j].idx; }  // NaN never wins
+        }
+#define MIDAS_QSTEP(CTRL)                                                          \
+        {                                                                          \
+            const float od = dpp_f32<CTRL>(ld);                                    \
+            const int oi = (int)dpp_u32<CTRL>((uint32_t)li);                        \
+            if (od < ld || (od == ld && oi < li)) { ld = od; li = oi; }            \
+        }
+        MIDAS_QSTEP(DPP_XOR1) MIDAS_QSTEP(DPP_XOR2)
+#undef MIDAS_QSTEP
+        d0 = dpp_f32<DPP_QUAD_LANE0>(d0);
+        const float rho_last = dpp_f32<DPP_QUAD_LANE3>(e[7].rho);  // record 31: the largest rho fetched
+        if (hinted) {
+            best = d0;  // a NaN distance stays, as in the serial scan
+            bi = hint;
+            r_lane = __builtin_sqrtf(d0);
+            if (ld < best || (ld == best && (int64_t)li < bi)) { best = ld; bi = li; }
+            // every record behind the last one fetched is at least this far (lower bound with slack for the rounding
+            // of r and rho, as in nn6_hint_scan): nothing unseen can beat or tie the best
+            const float g = fmaf_(rho_last - r_lane, 0.9999996f, -8e-7f * r_lane);
+            done = g > 0.0f && g * g * 0.99997f > best;
+        }
+    }
+    nn6_coop(t6, q, hint, r_lane, best, bi, owner && hinted && !done, done);  // the rest of the list, owners = lane 0 of a quad
+    const bool fb = owner && live && !done;
+    wave_search<Kd6, false>(t6, q, best, bi, fb, reinterpret_cast<float*>(s_cd[w]));
+    if (a.telemetry) {
+        const unsigned long long m = __ballot(fb);
+        if (lane == 0 && m) atomicAdd(&a.telemetry[0], (unsigned long long)__popcll(m));
+    }
+    const int32_t nn = (int32_t)dpp_u32<DPP_QUAD_LANE0>((uint32_t)(int32_t)bi);
+    // ---- prune: header + records 1 .. 16 of the entry's vertex list in one round trip ----
+    const float* pr = a.poses_prop + pc * 16;
+    const double q3[3] = {(double)pr[3], (double)pr[7], (double)pr[11]};
+    int mv = -1;  // 1 valid, 0 invalid, -1 undecided
+    double lim = 0.0;
+    if (a.vlist) {
+        const MeshRec* vl = a.vlist + (size_t)(live ? nn : 0) * MESH_REC;
+        const MeshRec hd = vl[0];
+        MeshRec e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = vl[1 + 4 * j + q4];
+        Point3 ph;
+        ph.c[0] = hd.c[0]; ph.c[1] = hd.c[1]; ph.c[2] = hd.c[2];
+        const double delta = __builtin_sqrt(dist2(q3, ph)) * (1.0 + 1e-12);
+        lim = a.thr * (1.0 + 1e-9) + delta + 1e-12;  // as mesh_list_check
+        unsigned hits = 0, stops = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Point3 pt;
+            pt.c[0] = e[j].c[0]; pt.c[1] = e[j].c[1]; pt.c[2] = e[j].c[2];
+            const int pos = 4 * j + q4;  // record 1 + pos
+            stops |= ((double)e[j].rho * (1.0 - 1e-7) > lim ? 1u : 0u) << pos;
+            hits |= (dist2(q3, pt) <= a.t2 ? 1u : 0u) << pos;
+        }
+        hits |= dpp_u32<DPP_XOR1>(hits); hits |= dpp_u32<DPP_XOR2>(hits);
+        stops |= dpp_u32<DPP_XOR1>(stops); stops |= dpp_u32<DPP_XOR2>(stops);
+        if (live && (hits | stops)) {  // the first event in record order decides, "provably too far" before "hit"
+            const int fh = hits ? __builtin_ctz(hits) : 32, fs = stops ? __builtin_ctz(stops) : 32;
+            mv = fh < fs ? 1 : 0;
+        }
+        mesh_coop(a.vlist, nn, q3, a.t2, lim, owner && live && mv < 0, mv);
+    }
+    double bestd = a.t2;
+    int64_t vi = 0;
+    const bool fb3 = owner && live && mv < 0;
+    bool ok = wave_search<Kd3, true>(t3, q3, bestd, vi, fb3, s_cd[w]);
+    if (a.telemetry) {
+        const unsigned long long m = __ballot(fb3);
+        if (lane == 0 && m) atomicAdd(&a.telemetry[1], (unsigned long long)__popcll(m));
+    }
+    if (mv >= 0) ok = mv == 1;
+    if (owner && live) {
+        a.nn_idx[p] = nn;
+        a.valid[p] = ok ? 1 : 0;
+    }
+}
+
+// =================================================================================================
 // launchers
 // =================================================================================================
 int launch_se3_feature(midas_ctx* ctx, int64_t N, const float* poses, float w, float* feat6) {
@@ -1478,6 +1667,36 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
     const int nwaves = particle_update_blocks(a.N), n_pu = (nwaves + 3) / 4;
     const unsigned grid = (unsigned)(n_pu + ceil_div(cb->K, 16));
     const float* emb = (const float*)cb->emb;
+    // Two-kernel form (quad-parallel list scans, see k_particle_nn_prune) while its N/16 waves fit the chip at once
+    // (4 waves per SIMD at 112 registers = 65536 particles): measured at K = 50k, D = 512 the pipelined frame gains 6 - 15 %
+    // for N = 4k .. 40k and loses 4 % at N = 100k, 7 % at N = 1M; when the particle set is materialised every frame the
+    // extra launch boundary only pays off for the smallest sets.  MIDAS_SPLIT_FRONT = 0 never, 2 always.
+    static const int split_env = getenv("MIDAS_SPLIT_FRONT") ? atoi(getenv("MIDAS_SPLIT_FRONT")) : 1;
+    const bool split_front = split_env == 2 || (split_env == 1 && ((a.rs.enabled && a.N <= 65536) || a.N <= 2048));
+    if (split_front && !(a.ablate & 7)) {
+        void* feat;
+        int rc = midas_scratch(ctx, (size_t)a.N * sizeof(PuFeat), &feat);
+        if (rc) return rc;
+#define MIDAS_FRONT_A(NJ)                                                                                            \
+    if (a.rs.enabled)                                                                                                \
+        hipLaunchKernelGGL((k_frame_front_a<float, NJ, true>), dim3(grid), dim3(256), 0, ctx->stream, a, n_pu, nwaves,  \
+                           (PuFeat*)feat, emb, cb->norms, code, scores, cb->K);                                      \
+    else                                                                                                             \
+        hipLaunchKernelGGL((k_frame_front_a<float, NJ, false>), dim3(grid), dim3(256), 0, ctx->stream, a, n_pu, nwaves, \
+                           (PuFeat*)feat, emb, cb->norms, code, scores, cb->K)
+        switch (cb->D) {
+            case 512: MIDAS_FRONT_A(8); break;
+            case 256: MIDAS_FRONT_A(4); break;
+            case 128: MIDAS_FRONT_A(2); break;
+            default: MIDAS_FRONT_A(16); break;
+        }
+#undef MIDAS_FRONT_A
+        hipLaunchKernelGGL(k_particle_nn_prune, dim3((unsigned)ceil_div(a.N, 64)), dim3(256), 0, ctx->stream, view_of<Kd6>(t6),
+                           view_of<Kd3>(t3), a, (const PuFeat*)feat);
+        MIDAS_HIP_CHECK(ctx, hipGetLastError());
+        *launched = true;
+        return MIDAS_OK;
+    }
 #define MIDAS_FRONT(NJ)                                                                                              \
     if (a.rs.enabled)                                                                                                \
         hipLaunchKernelGGL((k_frame_front<float, NJ, true>), dim3(grid), dim3(256), 0, ctx->stream, view_of<Kd6>(t6), \
