@@ -1457,34 +1457,44 @@ __global__ __launch_bounds__(256) void k_frame_front_a(ParticleUpdateArgs a, int
 
 template <int CTRL>
 MD float dpp_f32(float v) { return __uint_as_float(dpp_u32<CTRL>(__float_as_uint(v))); }
-constexpr int DPP_QUAD_LANE0 = 0x00, DPP_QUAD_LANE3 = 0xFF;  // quad_perm broadcasts
 
-// part B: a wave = 16 particles x 4 lanes; lane q4 of a quad takes records q4, q4 + 4, ... of its particle's lists
-static_assert(NN_SOLO == 32 && MESH_SOLO == 16, "the quad scans fetch 8 + 4 records per lane");
+// part B: a wave = 64/LPP particles x LPP lanes (4 or 2); lane g of a group takes records g, g + LPP, ... of its
+// particle's lists: with four lanes the 32 solo records of the neighbour list are one round trip of eight records per
+// lane, with two lanes two; header + 16 records of the vertex list are one round trip either way.
+static_assert(NN_SOLO == 32 && MESH_SOLO == 16, "the group scans fetch 32 / 16 records");
 #ifndef MIDAS_NNP_OCC
 #define MIDAS_NNP_OCC 4
 #endif
+template <int LPP>
 __global__ __launch_bounds__(256, MIDAS_NNP_OCC) void k_particle_nn_prune(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a,
-                                                           const PuFeat* __restrict__ feat) {
+                                                                          const PuFeat* __restrict__ feat) {
+    static_assert(LPP == 4 || LPP == 2, "lanes per particle");
+    // quad_perm selectors inside a group of LPP lanes: broadcast of its first / last lane
+    constexpr int BC_FIRST = LPP == 4 ? 0x00 : 0xA0, BC_LAST = LPP == 4 ? 0xFF : 0xF5;
+    constexpr int PPW = 64 / LPP;          // particles per wave
+    constexpr int NN_PASSES = 32 / (8 * LPP);  // round trips of eight records per lane
+    constexpr int MESH_PER_LANE = 16 / LPP;
     __shared__ double s_cd[4][KD_MAX_LEVELS * 64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, q4 = lane & 3;
-    const int64_t p = ((int64_t)blockIdx.x * 4 + w) * 16 + (lane >> 2);
-    const bool live = p < a.N, owner = q4 == 0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane & (LPP - 1);
+    const int64_t p = ((int64_t)blockIdx.x * 4 + w) * PPW + lane / LPP;
+    const bool live = p < a.N, owner = g == 0;
     const int64_t pc = live ? p : a.N - 1;
     const float4* fp = reinterpret_cast<const float4*>(feat + pc);
     const float4 f0 = fp[0], f1 = fp[1];
     const float q[6] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y};
     const int32_t hint = live ? __float_as_int(f1.z) : -1;
-    // ---- nearest codebook entry: records 0 .. 31 of the hinted entry's list in one round trip ----
+    // ---- nearest codebook entry: the solo records of the hinted entry's list ----
     float best = INFINITY, r_lane = 0.f;
     int64_t bi = 0;
     bool done = !live;
     const bool hinted = live && hint >= 0 && (int64_t)hint < t6.K;
-    {
-        const Nbr6* nb = t6.nbrs + (size_t)(hinted ? hint : 0) * NBR_REC;
+    const Nbr6* nb = t6.nbrs + (size_t)(hinted ? hint : 0) * NBR_REC;
+#pragma unroll 1
+    for (int pass = 0; pass < NN_PASSES; ++pass) {
+        if (pass > 0 && !__any(hinted && !done)) break;
         Nbr6 e[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = nb[4 * j + q4];
+        for (int j = 0; j < 8; ++j) e[j] = nb[pass * 8 * LPP + LPP * j + g];
         float d0 = 0.f, ld = INFINITY;
         int li = 0x7fffffff;
 #pragma unroll
@@ -1493,39 +1503,42 @@ __global__ __launch_bounds__(256, MIDAS_NNP_OCC) void k_particle_nn_prune(TreeVi
 #pragma unroll
             for (int c = 0; c < 6; ++c) pt.c[c] = e[j].c[c];
             const float d = dist2(q, pt);
-            if (j == 0) d0 = d;  // record 0 (lane 0 of the quad) is the entry itself: the starting candidate, handled below
-            const bool cand = !(j == 0 && q4 == 0);
+            if (j == 0) d0 = d;  // record 0 (first lane, first pass) is the entry itself: the starting candidate, below
+            const bool cand = !(pass == 0 && j == 0 && g == 0);
             if (cand && (d < ld || (d == ld && e[j].idx < li))) { ld = d; li = e[j].idx; }  // NaN never wins
         }
-#define MIDAS_QSTEP(CTRL)                                                          \
+#define MIDAS_GSTEP(CTRL)                                                          \
         {                                                                          \
             const float od = dpp_f32<CTRL>(ld);                                    \
             const int oi = (int)dpp_u32<CTRL>((uint32_t)li);                        \
             if (od < ld || (od == ld && oi < li)) { ld = od; li = oi; }            \
         }
-        MIDAS_QSTEP(DPP_XOR1) MIDAS_QSTEP(DPP_XOR2)
-#undef MIDAS_QSTEP
-        d0 = dpp_f32<DPP_QUAD_LANE0>(d0);
-        const float rho_last = dpp_f32<DPP_QUAD_LANE3>(e[7].rho);  // record 31: the largest rho fetched
-        if (hinted) {
-            best = d0;  // a NaN distance stays, as in the serial scan
-            bi = hint;
-            r_lane = __builtin_sqrtf(d0);
+        MIDAS_GSTEP(DPP_XOR1)
+        if (LPP == 4) MIDAS_GSTEP(DPP_XOR2)
+#undef MIDAS_GSTEP
+        d0 = dpp_f32<BC_FIRST>(d0);
+        const float rho_last = dpp_f32<BC_LAST>(e[7].rho);  // the largest rho fetched so far
+        if (hinted && !done) {
+            if (pass == 0) {
+                best = d0;  // a NaN distance stays, as in the serial scan
+                bi = hint;
+                r_lane = __builtin_sqrtf(d0);
+            }
             if (ld < best || (ld == best && (int64_t)li < bi)) { best = ld; bi = li; }
             // every record behind the last one fetched is at least this far (lower bound with slack for the rounding
             // of r and rho, as in nn6_hint_scan): nothing unseen can beat or tie the best
-            const float g = fmaf_(rho_last - r_lane, 0.9999996f, -8e-7f * r_lane);
-            done = g > 0.0f && g * g * 0.99997f > best;
+            const float gg = fmaf_(rho_last - r_lane, 0.9999996f, -8e-7f * r_lane);
+            done = gg > 0.0f && gg * gg * 0.99997f > best;
         }
     }
-    nn6_coop(t6, q, hint, r_lane, best, bi, owner && hinted && !done, done);  // the rest of the list, owners = lane 0 of a quad
+    nn6_coop(t6, q, hint, r_lane, best, bi, owner && hinted && !done, done);  // the rest of the list, owners = first lanes
     const bool fb = owner && live && !done;
     wave_search<Kd6, false>(t6, q, best, bi, fb, reinterpret_cast<float*>(s_cd[w]));
     if (a.telemetry) {
         const unsigned long long m = __ballot(fb);
         if (lane == 0 && m) atomicAdd(&a.telemetry[0], (unsigned long long)__popcll(m));
     }
-    const int32_t nn = (int32_t)dpp_u32<DPP_QUAD_LANE0>((uint32_t)(int32_t)bi);
+    const int32_t nn = (int32_t)dpp_u32<BC_FIRST>((uint32_t)(int32_t)bi);
     // ---- prune: header + records 1 .. 16 of the entry's vertex list in one round trip ----
     const float* pr = a.poses_prop + pc * 16;
     const double q3[3] = {(double)pr[3], (double)pr[7], (double)pr[11]};
@@ -1534,24 +1547,24 @@ __global__ __launch_bounds__(256, MIDAS_NNP_OCC) void k_particle_nn_prune(TreeVi
     if (a.vlist) {
         const MeshRec* vl = a.vlist + (size_t)(live ? nn : 0) * MESH_REC;
         const MeshRec hd = vl[0];
-        MeshRec e[4];
+        MeshRec e[MESH_PER_LANE];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) e[j] = vl[1 + 4 * j + q4];
+        for (int j = 0; j < MESH_PER_LANE; ++j) e[j] = vl[1 + LPP * j + g];
         Point3 ph;
         ph.c[0] = hd.c[0]; ph.c[1] = hd.c[1]; ph.c[2] = hd.c[2];
         const double delta = __builtin_sqrt(dist2(q3, ph)) * (1.0 + 1e-12);
         lim = a.thr * (1.0 + 1e-9) + delta + 1e-12;  // as mesh_list_check
         unsigned hits = 0, stops = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < MESH_PER_LANE; ++j) {
             Point3 pt;
             pt.c[0] = e[j].c[0]; pt.c[1] = e[j].c[1]; pt.c[2] = e[j].c[2];
-            const int pos = 4 * j + q4;  // record 1 + pos
+            const int pos = LPP * j + g;  // record 1 + pos
             stops |= ((double)e[j].rho * (1.0 - 1e-7) > lim ? 1u : 0u) << pos;
             hits |= (dist2(q3, pt) <= a.t2 ? 1u : 0u) << pos;
         }
-        hits |= dpp_u32<DPP_XOR1>(hits); hits |= dpp_u32<DPP_XOR2>(hits);
-        stops |= dpp_u32<DPP_XOR1>(stops); stops |= dpp_u32<DPP_XOR2>(stops);
+        hits |= dpp_u32<DPP_XOR1>(hits); stops |= dpp_u32<DPP_XOR1>(stops);
+        if (LPP == 4) { hits |= dpp_u32<DPP_XOR2>(hits); stops |= dpp_u32<DPP_XOR2>(stops); }
         if (live && (hits | stops)) {  // the first event in record order decides, "provably too far" before "hit"
             const int fh = hits ? __builtin_ctz(hits) : 32, fs = stops ? __builtin_ctz(stops) : 32;
             mv = fh < fs ? 1 : 0;
@@ -1667,12 +1680,15 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
     const int nwaves = particle_update_blocks(a.N), n_pu = (nwaves + 3) / 4;
     const unsigned grid = (unsigned)(n_pu + ceil_div(cb->K, 16));
     const float* emb = (const float*)cb->emb;
-    // Two-kernel form (quad-parallel list scans, see k_particle_nn_prune) while its N/16 waves fit the chip at once
-    // (4 waves per SIMD at 112 registers = 65536 particles): measured at K = 50k, D = 512 the pipelined frame gains 6 - 15 %
-    // for N = 4k .. 40k and loses 4 % at N = 100k, 7 % at N = 1M; when the particle set is materialised every frame the
-    // extra launch boundary only pays off for the smallest sets.  MIDAS_SPLIT_FRONT = 0 never, 2 always.
+    // Two-kernel form (group-parallel list scans, see k_particle_nn_prune) while its N/16 waves fit the chip at once (4 waves
+    // per SIMD at 112 registers = 65536 particles with four lanes each).  Measured at K = 50k, D = 512 the pipelined frame
+    // gains 6 - 15 % for N = 4k .. 40k; when the particle set is materialised every frame the extra launch boundary only pays
+    // off for the smallest sets; at N = 100k the four-lane form (two rounds of waves) loses 4 %, the two-lane form (one
+    // round, two trips) 8 %, at N = 1M 7 %: there the single kernel stays.
+    // MIDAS_SPLIT_FRONT = 0 never, 2 always with 4 lanes per particle, 3 always with 2.
     static const int split_env = getenv("MIDAS_SPLIT_FRONT") ? atoi(getenv("MIDAS_SPLIT_FRONT")) : 1;
-    const bool split_front = split_env == 2 || (split_env == 1 && ((a.rs.enabled && a.N <= 65536) || a.N <= 2048));
+    const bool split_front = split_env >= 2 || (split_env == 1 && ((a.rs.enabled && a.N <= 65536) || a.N <= 2048));
+    const int lpp = split_env == 3 ? 2 : 4;
     if (split_front && !(a.ablate & 7)) {
         void* feat;
         int rc = midas_scratch(ctx, (size_t)a.N * sizeof(PuFeat), &feat);
@@ -1691,8 +1707,12 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
             default: MIDAS_FRONT_A(16); break;
         }
 #undef MIDAS_FRONT_A
-        hipLaunchKernelGGL(k_particle_nn_prune, dim3((unsigned)ceil_div(a.N, 64)), dim3(256), 0, ctx->stream, view_of<Kd6>(t6),
-                           view_of<Kd3>(t3), a, (const PuFeat*)feat);
+        if (lpp == 4)
+            hipLaunchKernelGGL(k_particle_nn_prune<4>, dim3((unsigned)ceil_div(a.N, 64)), dim3(256), 0, ctx->stream,
+                               view_of<Kd6>(t6), view_of<Kd3>(t3), a, (const PuFeat*)feat);
+        else
+            hipLaunchKernelGGL(k_particle_nn_prune<2>, dim3((unsigned)ceil_div(a.N, 128)), dim3(256), 0, ctx->stream,
+                               view_of<Kd6>(t6), view_of<Kd3>(t3), a, (const PuFeat*)feat);
         MIDAS_HIP_CHECK(ctx, hipGetLastError());
         *launched = true;
         return MIDAS_OK;
