@@ -112,6 +112,10 @@ def main():
     if world > 1 or args.sharded:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RCCL prints its version banner on STDOUT (NCCL_DEBUG=VERSION is exported on the GPU boxes) and libc flushes it at
+        # exit, i.e. AFTER the JSON line: keep stdout to the one line the driver parses
+        if os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", "INFO"):
+            del os.environ["NCCL_DEBUG"]
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -247,7 +251,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cb, traj, N)
     if rank == 0:
-        print(json.dumps(out))
+        try:  # anything native libraries left in the C stdio buffer goes out first: the JSON line is the last line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
