@@ -11,9 +11,10 @@ Here the container is a plain `codebook.npz`:
     logmap_pose (K,6)   float32   optional: the reference's own 6-d features (theseus log-map), kept only as a
                                   cross-check for the kernels' log-map (`tactile_tree.load(check_logmap=True)`)
 
-`read_reference_pickle` opens the reference's pickle WITHOUT its classes: an unpickler whose `find_class` hands out
-inert placeholder classes for everything outside torch / numpy / the standard containers, so the module object and
-the KD-tree come back as attribute bags and only the tensors are used.
+`read_reference_pickle` opens the reference's pickle WITHOUT its classes: an unpickler whose `find_class` resolves an
+explicit list of (module, name) pairs (container / ndarray / tensor constructors; `_SAFE_GLOBALS`), refuses every other
+name of torch / numpy / dill / os-like modules and hands out inert placeholder classes for the rest, so the module
+object and the KD-tree come back as attribute bags and only the tensors are used.
 
     python -m midastouch_amd.codebook_io convert <codebook.pkl> <codebook.npz>
     python -m midastouch_amd.codebook_io info <codebook.npz | codebook.pkl>
@@ -31,9 +32,43 @@ import torch
 from ._lib import MidasError
 
 FORMAT_VERSION = 1
-_SAFE_PREFIXES = ("torch", "numpy", "collections", "copyreg", "_codecs", "dill")
+# The ONLY globals a codebook pickle may resolve to real objects, as exact (module, name) pairs: constructors that
+# build containers, arrays and tensors and run nothing else.  Deliberately absent: every module attribute reachable
+# through re-exports (torch.os, numpy.os, ...), builtins.getattr / type / eval, numpy's `scalar` (unpickles object
+# payloads), torch.load and torch.storage._load_from_bytes (an unrestricted torch.load; replaced below by a
+# weights-only one), dill's type / function / code constructors.  Anything else becomes an inert placeholder.
 _SAFE_BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray",
-                  "complex", "slice", "range", "object", "getattr", "type"}
+                  "complex", "slice", "range", "object"}
+_SAFE_GLOBALS = {
+    ("collections", "OrderedDict"), ("collections", "defaultdict"),
+    ("copyreg", "_reconstructor"), ("copyreg", "__newobj__"), ("_codecs", "encode"),
+    ("numpy", "dtype"), ("numpy", "ndarray"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch", "Size"), ("torch", "device"),
+} | {("torch", n + "Storage") for n in ("Float", "Double", "Half", "BFloat16", "Long", "Int", "Short", "Char", "Byte", "Bool")}
+
+
+def _storage_from_bytes(b):
+    """What torch.storage._load_from_bytes does, minus its unrestricted unpickler: the nested stream is read with
+    torch's weights-only loader, which builds storages and tensors and nothing else."""
+    if not isinstance(b, (bytes, bytearray)):
+        raise pickle.UnpicklingError("storage payload is not bytes")
+    return torch.load(io.BytesIO(bytes(b)), weights_only=True)
+
+
+def _create_array(f, args, state, npdict=None):
+    """dill._dill._create_array for plain ndarrays: `f` came through find_class, so it is numpy's `_reconstruct`."""
+    if getattr(f, "__name__", "") != "_reconstruct" or not getattr(f, "__module__", "").startswith("numpy"):
+        raise pickle.UnpicklingError("array reconstructor is not numpy's")
+    array = f(*args)
+    array.__setstate__(state)
+    if array.dtype.hasobject:
+        raise pickle.UnpicklingError("object arrays are not codebook data")
+    return array
+
+
+_REPLACED_GLOBALS = {("torch.storage", "_load_from_bytes"): _storage_from_bytes,
+                     ("dill._dill", "_create_array"): _create_array}
 
 
 class _Placeholder:
@@ -63,13 +98,21 @@ def _placeholder_class(module: str, name: str):
 def _make_unpickler(base):
     class _CodebookUnpickler(base):
         def find_class(self, module, name):
-            root = module.split(".")[0]
-            if root == "builtins" or root == "__builtin__":
+            if (module, name) in _REPLACED_GLOBALS:
+                return _REPLACED_GLOBALS[(module, name)]
+            if module in ("builtins", "__builtin__"):
                 if name in _SAFE_BUILTINS:
-                    return super().find_class(module, name)
+                    return getattr(__import__("builtins"), name)
                 raise pickle.UnpicklingError(f"refusing builtins.{name} in a codebook pickle")
-            if root in _SAFE_PREFIXES:
-                return super().find_class(module, name)
+            if (module, name) in _SAFE_GLOBALS:
+                obj = pickle.Unpickler.find_class(self, module, name)  # plain attribute lookup, no dill by-value extras
+                if isinstance(obj, type(pickle)):
+                    raise pickle.UnpicklingError(f"{module}.{name} is a module")
+                return obj
+            if module.split(".")[0] in ("torch", "numpy", "dill", "os", "posix", "nt", "subprocess", "sys", "importlib",
+                                        "pickle", "shutil", "socket", "ctypes", "runpy", "code", "pty"):
+                # a name of these packages that is not on the list is never a codebook's data: refuse loudly
+                raise pickle.UnpicklingError(f"refusing {module}.{name} in a codebook pickle")
             return _placeholder_class(module, name)
 
     return _CodebookUnpickler
@@ -77,11 +120,9 @@ def _make_unpickler(base):
 
 def read_reference_pickle(path: str) -> dict:
     """{poses, cam_poses, embeddings[, logmap_pose]} (CPU tensors) from a reference `codebook.pkl`."""
-    try:  # the reference writes with dill (build_codebook.py:12); plain pickle reads the same stream unless the class
-        import dill  # was pickled by value, which dill's own Unpickler understands
-        base = dill.Unpickler
-    except ImportError:  # pragma: no cover
-        base = pickle.Unpickler
+    # the reference writes with dill (build_codebook.py:12): a standard pickle stream whose dill-specific globals
+    # (dill._dill._create_array) are answered by find_class above; dill's own Unpickler is not needed and not used
+    base = pickle.Unpickler
     with open(path, "rb") as f:
         data = f.read()
     try:

@@ -65,6 +65,7 @@ class HipShardBackend:
         self.tree3 = ops.Tree(torch.as_tensor(mesh_vertices).to(self.device, torch.float64))
         self.tree6.attach_mesh(self.tree3, self.cb_poses)
         self.K = int(self.cb_poses.shape[0])
+        self.D = int(emb.shape[1])
 
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.device)
@@ -273,6 +274,16 @@ class ShardedFilterEngine:
     def step_gen(self, odom, code, gt=None, tn=None, rot=None, u=None, u32=-1.0, multiplier: float = 1.0):
         st, b, G = self.st, self.backend, self.world
         mul = max(float(multiplier), 1.0)
+        # the kernels read raw pointers: operands on the shard's device, in the ABI's dtypes, contiguous, right sizes
+        from .engine import operand
+        d, D = st.poses.device, int(getattr(b, "D", torch.as_tensor(code).numel()))
+        if (tn is None) != (rot is None):
+            raise MidasError("tn and rot (the motion model's host draws) come together or not at all")
+        odom, gt = operand(odom, "odom", torch.float32, (4, 4), d), operand(gt, "gt pose", torch.float32, (4, 4), d)
+        code = operand(code, "tactile code", torch.float64, (D,), d)
+        tn, rot = operand(tn, "tn", torch.float32, (self.N, 3), d), operand(rot, "rot", torch.float32, (self.N, 3), d)
+        u = operand(u, "u (the uniforms of all slots of the filter)", torch.float64, (self.N_total,), d)
+        self._keep = (odom, code, gt, tn, rot, u)
         ready = False
         if getattr(b, "row_shard", None) is not None:  # codebook rows sharded: gather the score slices first
             st.scores.copy_((yield b.score_slice(code)))

@@ -20,6 +20,23 @@ from . import _lib, ops
 from ._lib import LazyArgs, LazyFlushArgs, MidasError, StepArgs, _ptr
 
 
+def operand(t, name: str, dtype, shape, device):
+    """A frame operand as the C ABI reads it: on `device`, `dtype`, contiguous, exactly `shape` elements (the kernels
+    take raw pointers and check nothing).  Host tensors (the reference's CPU-generator draws), float32 tactile codes
+    (what the TCN emits before its .double()) and strided views are converted; a wrong element count raises."""
+    if t is None:
+        return None
+    t = torch.as_tensor(t)
+    n = 1
+    for s_ in shape:
+        n *= int(s_)
+    if t.numel() != n:
+        raise MidasError(f"{name}: expected shape {tuple(shape)} ({n} values), got {tuple(t.shape)}")
+    if t.device != device or t.dtype != dtype:
+        t = t.to(device=device, dtype=dtype)
+    return t.contiguous().reshape(shape)
+
+
 class FilterEngine:
     def __init__(self, cb_poses, cb_embeddings, mesh_vertices, num_particles: int, *, sig_t=2e-4, sig_r=0.5,
                  pen_max=0.002, seed=4000, softmax=True, resample="weighted_random", device=None):
@@ -76,6 +93,7 @@ class FilterEngine:
     # ---- one frame ------------------------------------------------------------------------------
     def step(self, odom, code, gt=None, tn=None, rot=None, u=None, u32=-1.0, multiplier: float = 1.0):
         """Runs one frame; results stay on the device (self.poses, self.weights, self.ridx ...)."""
+        odom, code, gt, tn, rot, u = self._operands(odom, code, gt, tn, rot, u)
         a = StepArgs()
         a.N = self.N
         a.poses_in, a.poses_prop, a.poses_out = _ptr(self.poses), _ptr(self.poses_prop), _ptr(self.poses)
@@ -100,6 +118,14 @@ class FilterEngine:
                                                       C.byref(a)))
         self.hint, self.hint_next = self.hint_next, self.hint
         self.step_count += 1
+
+    def _operands(self, odom, code, gt, tn, rot, u):
+        d, N = self.device, self.N
+        if (tn is None) != (rot is None):
+            raise MidasError("tn and rot (the motion model's host draws) come together or not at all")
+        return (operand(odom, "odom", torch.float32, (4, 4), d), operand(code, "tactile code", torch.float64, (self.D,), d),
+                operand(gt, "gt pose", torch.float32, (4, 4), d), operand(tn, "tn", torch.float32, (N, 3), d),
+                operand(rot, "rot", torch.float32, (N, 3), d), operand(u, "u", torch.float64, (N,), d))
 
     # ---- profiling --------------------------------------------------------------------------------
     def profile(self, on, only_slot: int = None):
@@ -202,6 +228,7 @@ class PipelinedFilterEngine(FilterEngine):
         return super().project_to_codebook()
 
     def step(self, odom, code, gt=None, tn=None, rot=None, u=None, u32=-1.0, multiplier: float = 1.0):
+        odom, code, gt, tn, rot, u = self._operands(odom, code, gt, tn, rot, u)
         cur, nxt = self._cur, self._cur ^ 1
         fold = self._pending and not self._flushed
         a = LazyArgs()
@@ -227,7 +254,7 @@ class PipelinedFilterEngine(FilterEngine):
         self.ctx.bind_current_stream()
         self.ctx.check(self.ctx.lib.midas_lazy_step(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h, C.byref(a)))
         # this frame's resample draws, consumed by the next step or by flush()
-        self._draw = (None if u is None else u.to(self.device, torch.float64).clone(), float(u32), self.step_count)
+        self._draw = (None if u is None else u.clone(), float(u32), self.step_count)
         self._had_gt = gt is not None
         self._pending, self._flushed, self._cur = True, False, nxt
         self.step_count += 1
@@ -309,6 +336,13 @@ class BatchFilterEngine:
 
     def step(self, odoms, codes, gts=None, tn=None, rot=None, u=None, u32=-1.0):
         """odoms (B,4,4) f32, codes (B,D) f64, gts (B,4,4) f32 or None; optional host draws tn/rot (B,N,3), u (B,N)."""
+        d, B, N = self.device, self.B, self.N
+        if (tn is None) != (rot is None):
+            raise MidasError("tn and rot (the motion model's host draws) come together or not at all")
+        odoms, gts = operand(odoms, "odoms", torch.float32, (B, 4, 4), d), operand(gts, "gt poses", torch.float32, (B, 4, 4), d)
+        codes = operand(codes, "tactile codes", torch.float64, (B, self.codebook.D), d)
+        tn, rot = operand(tn, "tn", torch.float32, (B, N, 3), d), operand(rot, "rot", torch.float32, (B, N, 3), d)
+        u = operand(u, "u", torch.float64, (B, N), d)
         a = StepArgs()
         a.N = self.N
         a.poses_in, a.poses_prop, a.poses_out = _ptr(self.poses), _ptr(self.poses_prop), _ptr(self.poses)

@@ -200,7 +200,9 @@ class particle_filter:
         if method == "euclidean":
             data = particles.poses[:, :3, 3].cpu().numpy()
         elif method == "logmap":
-            data = torch.cat((particles.poses[:, :3, 3], ops.se3_feature(particles.poses, 1.0)[:, 3:]), dim=1).cpu().numpy()
+            from .pose import se3_log
+
+            data = se3_log(particles.poses).cpu().numpy()  # [V^-1 t, omega], the embedding th.SE3.log_map gives (:219-220)
         else:
             raise ValueError(method)
         clustering = DBSCAN(eps=eps, min_samples=min_samples).fit(data)

@@ -31,9 +31,10 @@ def _hat(v: torch.Tensor) -> torch.Tensor:
     return torch.stack([torch.stack([z, -v[2], v[1]]), torch.stack([v[2], z, -v[0]]), torch.stack([-v[1], v[0], z])])
 
 
-def logmap_average_pose(T: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    """Weighted mean in the se(3) tangent space, mapped back with exp (pose.py:101-109)."""
-    wd = w.double()
+def se3_log(T: torch.Tensor) -> torch.Tensor:
+    """(N,4,4) -> (N,6) float64 tangent vectors [V^-1 t, omega] - theseus `SE3.log_map` (used at pose.py:105-106 and
+    by `cluster_particles(method="logmap")`, particle_filter.py:218-223)."""
+    T = T[None] if T.dim() == 2 else T
     om = rotvec(T).double()
     th = om.norm(dim=1)
     t = T[:, :3, 3].double()
@@ -42,7 +43,13 @@ def logmap_average_pose(T: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
                     torch.full_like(th, 1.0 / 12.0))
     wxt = torch.cross(om, t, dim=1)
     u = t - 0.5 * wxt + c[:, None] * torch.cross(om, wxt, dim=1)
-    xi = (torch.cat((u, om), dim=1) * wd[:, None]).sum(dim=0) / wd.sum()
+    return torch.cat((u, om), dim=1)
+
+
+def logmap_average_pose(T: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """Weighted mean in the se(3) tangent space, mapped back with exp (pose.py:101-109)."""
+    wd = w.double()
+    xi = (se3_log(T) * wd[:, None]).sum(dim=0) / wd.sum()
     u_m, w_m = xi[:3], xi[3:]
     thm = w_m.norm()
     W = _hat(w_m)

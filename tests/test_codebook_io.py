@@ -67,6 +67,25 @@ def test_rejects_garbage_and_hostile_pickles(tmp_path):
     h2.write_bytes(pickle.dumps(_OsCall()))
     with pytest.raises(MidasError):  # posix.system becomes an inert placeholder: no poses in the result
         codebook_io.read_reference_pickle(str(h2))
+    # re-export gadgets: torch and numpy expose os / sys as attributes, so a prefix allow-list would hand out
+    # torch.os.getcwd / numpy.os.system; the loader resolves exact (module, name) pairs only
+    for mod, name in (("torch", "os"), ("numpy", "os"), ("torch", "load"), ("numpy", "load"), ("builtins", "getattr"),
+                      ("builtins", "type"), ("dill._dill", "_load_type"), ("numpy._core.multiarray", "scalar"),
+                      ("torch.serialization", "load"), ("os", "system")):
+        g = tmp_path / "gadget.pkl"
+        g.write_bytes(b"\x80\x02c" + mod.encode() + b"\n" + name.encode() + b"\n.")
+        with pytest.raises(MidasError, match="refusing"):
+            codebook_io.read_reference_pickle(str(g))
+    # getattr(torch.os, "getcwd")() as a stream: GLOBAL getattr, GLOBAL torch.os, "getcwd", TUPLE2, REDUCE, EMPTY_TUPLE, REDUCE
+    g.write_bytes(b"\x80\x02cbuiltins\ngetattr\nctorch\nos\nX\x06\x00\x00\x00getcwd\x86R)R.")
+    with pytest.raises(MidasError, match="refusing"):
+        codebook_io.read_reference_pickle(str(g))
+    # a storage payload is read by torch's weights-only loader, not by the unrestricted torch.load the real
+    # torch.storage._load_from_bytes wraps: a hostile nested stream is refused, an honest one still loads
+    nested = pickle.dumps(_OsCall())
+    g.write_bytes(b"\x80\x02ctorch.storage\n_load_from_bytes\n" + pickle.dumps(nested)[2:-1] + b"\x85R.")
+    with pytest.raises(MidasError):
+        codebook_io.read_reference_pickle(str(g))
     empty = tmp_path / "e.npz"
     np.savez(str(empty), poses=np.zeros((3, 4, 4), np.float32))
     with pytest.raises(MidasError):
