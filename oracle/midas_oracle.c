@@ -19,6 +19,8 @@
  *   mo_cdf / searches   modules/particle_filter.py:237-261,295-303 (normalise, multinomial == inverse-CDF
  *                       lower_bound on float64; low_var two-pointer loop == upper_bound)
  *   mo_rmse             modules/particle_filter.py:472-496, modules/pose.py:178-208
+ *   mo_dbscan           modules/particle_filter.py:208-217 (sklearn DBSCAN on the translations - third-party,
+ *                       pinned by fixture G9 written by the reference's own cluster_particles)
  *
  * Pinning: oracle/oracle.py wraps these functions; tests/test_oracle_golden.py checks them against
  * the golden fixtures in tests/golden/ that tools/gen_goldens.py produced by running the real
@@ -588,4 +590,79 @@ MO_API void mo_rmse(int64_t N, const float* poses, const float* gt16, double* ou
 MO_API void mo_gather_rows(int64_t M, const int32_t* idx, const void* src, void* dst, int64_t row_bytes) {
     for (int64_t i = 0; i < M; ++i)
         memcpy((char*)dst + i * row_bytes, (const char*)src + (int64_t)idx[i] * row_bytes, (size_t)row_bytes);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* cluster_particles: DBSCAN labels                                                           */
+/* ------------------------------------------------------------------------------------------ */
+/* modules/particle_filter.py:208-217: sklearn.cluster.DBSCAN(eps, min_samples).fit(X).labels_ on the particle
+ * translations X (N,3) float32 (scikit-learn is third-party; its published algorithm, sklearn/cluster/_dbscan.py +
+ * _dbscan_inner.pyx, restated):
+ *   - neighbourhood of i = { j : |x_i - x_j|^2 <= eps^2 }, i included; the KD-tree sklearn builds works on float64
+ *     copies and compares the reduced distance d = ((dx*dx) + dy*dy) + dz*dz (accumulated in that order) with eps*eps;
+ *   - core <=> |neighbourhood| >= min_samples;
+ *   - clusters = connected components of the core points under "within eps", numbered in the order the scan over
+ *     i = 0, 1, ... meets their first core point; a non-core point within eps of core points takes the number of the
+ *     first cluster that reaches it = the smallest number among them (cluster c is expanded completely before
+ *     c + 1 starts); everything else is noise (-1).
+ * O(N^2): meant for the sizes the parity tests use. */
+static int64_t uf_find(int64_t* p, int64_t i) {
+    while (p[i] != i) { p[i] = p[p[i]]; i = p[i]; }
+    return i;
+}
+
+MO_API int32_t mo_dbscan(int64_t N, const float* X, double eps, int64_t min_samples, int32_t* labels) {
+    const double r2 = eps * eps;
+    int64_t* parent = (int64_t*)malloc((size_t)(N > 0 ? N : 1) * sizeof(int64_t));
+    int32_t* number = (int32_t*)malloc((size_t)(N > 0 ? N : 1) * sizeof(int32_t));
+    uint8_t* core = (uint8_t*)calloc((size_t)(N > 0 ? N : 1), 1);
+    for (int64_t i = 0; i < N; ++i) {
+        int64_t cnt = 0;
+        const double xi = X[3 * i], yi = X[3 * i + 1], zi = X[3 * i + 2];
+        for (int64_t j = 0; j < N; ++j) {
+            const double dx = xi - (double)X[3 * j], dy = yi - (double)X[3 * j + 1], dz = zi - (double)X[3 * j + 2];
+            double d = dx * dx;
+            d += dy * dy;
+            d += dz * dz;
+            cnt += d <= r2;
+        }
+        core[i] = cnt >= min_samples;
+        parent[i] = i;
+    }
+    for (int64_t i = 0; i < N; ++i) {
+        if (!core[i]) continue;
+        const double xi = X[3 * i], yi = X[3 * i + 1], zi = X[3 * i + 2];
+        for (int64_t j = i + 1; j < N; ++j) {
+            if (!core[j]) continue;
+            const double dx = xi - (double)X[3 * j], dy = yi - (double)X[3 * j + 1], dz = zi - (double)X[3 * j + 2];
+            double d = dx * dx;
+            d += dy * dy;
+            d += dz * dz;
+            if (d <= r2) {
+                int64_t a = uf_find(parent, i), b = uf_find(parent, j);
+                if (a != b) { if (a < b) parent[b] = a; else parent[a] = b; }  /* root = smallest index */
+            }
+        }
+    }
+    int32_t ncl = 0;
+    for (int64_t i = 0; i < N; ++i) number[i] = (core[i] && uf_find(parent, i) == i) ? ncl++ : -1;
+    for (int64_t i = 0; i < N; ++i) {
+        if (core[i]) { labels[i] = number[uf_find(parent, i)]; continue; }
+        int32_t best = -1;
+        const double xi = X[3 * i], yi = X[3 * i + 1], zi = X[3 * i + 2];
+        for (int64_t j = 0; j < N; ++j) {
+            if (!core[j]) continue;
+            const double dx = xi - (double)X[3 * j], dy = yi - (double)X[3 * j + 1], dz = zi - (double)X[3 * j + 2];
+            double d = dx * dx;
+            d += dy * dy;
+            d += dz * dz;
+            if (d <= r2) {
+                const int32_t c = number[uf_find(parent, j)];
+                if (best < 0 || c < best) best = c;
+            }
+        }
+        labels[i] = best;
+    }
+    free(parent); free(number); free(core);
+    return ncl;
 }

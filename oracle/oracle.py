@@ -336,6 +336,27 @@ def cluster_centers(poses, weights, labels):
     return uniq, centers, stds
 
 
+def dbscan(points, eps: float = 1e-2, min_samples: int = 1):
+    """particle_filter.cluster_particles(method="euclidean") labels (particle_filter.py:208-217): sklearn DBSCAN on the
+    (N,3) float32 translations, restated in C (mo_dbscan).  Returns (labels int32 (N,), number of clusters)."""
+    X = _f32(points).reshape(-1, 3)
+    labels = np.empty(X.shape[0], dtype=np.int32)
+    L = lib()
+    L.mo_dbscan.restype = C.c_int32
+    ncl = L.mo_dbscan(C.c_int64(X.shape[0]), _p(X), C.c_double(float(eps)), C.c_int64(int(min_samples)), _p(labels))
+    return labels, int(ncl)
+
+
+def cluster_var(stds):
+    """`torch.mean(cluster_stds)` (filter/filter.py:189) of the float32 (C,3) spreads as the spec states it: float32
+    running sum in row-major order divided by the float32 count."""
+    s = np.float32(0.0)
+    flat = np.asarray(stds, dtype=np.float32).ravel()
+    for v in flat:
+        s = np.float32(s + v)
+    return np.float32(s / np.float32(flat.shape[0]))
+
+
 class Annealer:
     """particle_filter.annealing (particle_filter.py:405-447) on index sets.
 
@@ -384,6 +405,69 @@ class Annealer:
 # ------------------------------------------------------------------------------------------
 # the per-frame loop body as one object
 # ------------------------------------------------------------------------------------------
+class OracleLoop:
+    """The whole loop body filter/filter.py:150-190 - motion, rmse, weights, prune (+ re-projection when every particle
+    drifted, :176-179), DBSCAN every 50th frame (:182-183), cluster centres (:184-186), annealing (:189), resampling
+    (:190) - as one `step()` over a particle set whose size changes from frame to frame.  The spec of the device loop
+    engine (midas_loop_step): same arithmetic as OracleFilter.step plus
+      labels   = dbscan(translations, eps, N // 5) on frames with count % 50 == 0, carried through the resample otherwise;
+      var      = cluster_var(stds of the clusters present), annealing on it (Annealer; ties in the top-k by index);
+      resample = N' draws over the blocked CDF of (e * mask)[keep], N' = size of the annealed set; the weights that
+                 travel on are e / S * mask with S the blocked sum of e over the N particles BEFORE annealing."""
+
+    def __init__(self, cb_poses, cb_embeddings, mesh_verts, pen_max=0.002, floor=1000, eps=1e-2, softmax=True, cluster=True):
+        self.f = OracleFilter(cb_poses, cb_embeddings, mesh_verts, pen_max)
+        self.annealer = Annealer()
+        self.floor, self.eps, self.softmax, self.cluster = int(floor), float(eps), bool(softmax), bool(cluster)
+        self.count = 0
+
+    def step(self, poses, labels, odom, code, tn, rot_deg, u=None, gt=None, mode="weighted_random", u32=None,
+             keep_override=None, draws=None):
+        """`u`: uniforms for the N' draws (only the first N' are used) or `draws(N')` -> uniforms, called once N' is known
+        (the reference draws them after annealing).  keep_override: teacher-forced annealed index list (tests of tie frames)."""
+        f, out = self.f, {}
+        N = poses.shape[0]
+        p1 = propagate(poses, odom, tn, rot_deg)
+        if gt is not None:
+            out["rmse"] = particle_rmse(p1, gt)
+        idx = nn6(R3_SE3(p1), f.cb_feat)[0]
+        scores = score_codebook(f.emb, code)
+        x = scores[idx]
+        mask = ~(nn3_dist(p1, f.verts) > f.pen_max)
+        e, applied = softmax_numerators(x, self.softmax, shift=1.0)
+        S = blocked_scan(e)[1] if applied else 1.0
+        w = e / S * mask
+        out.update(poses_prop=p1, nn_idx=idx, mask=mask, weights=w, drifted=bool(mask.sum() == 0))
+        if out["drifted"]:  # every particle is off the surface: back onto the codebook (:176-179)
+            p1 = f.cb_poses[idx].copy()
+            out["poses_prop"] = p1
+        if self.cluster:
+            if self.count % 50 == 0:
+                labels = dbscan(p1[:, :3, 3], self.eps, N // 5)[0]
+            uniq, centers, stds = cluster_centers(p1, w, labels)
+            var = cluster_var(stds)
+            keep = self.annealer.step(w, var, self.floor) if keep_override is None else np.asarray(keep_override)
+            if keep_override is not None:  # keep the annealer's state in step with the forced decision
+                self.annealer.step(w, var, self.floor)
+            out.update(labels_frame=labels, cluster_labels=uniq, cluster_poses=centers, cluster_stds=stds, var=var)
+        else:
+            keep = np.arange(N)
+        out["keep"] = keep.astype(np.int32)
+        n2 = keep.shape[0]
+        em = (e * mask)[keep]
+        if u is None and draws is not None:
+            u = draws(n2)
+        ridx, status = resample_indices(em, mode, u=None if u is None else np.asarray(u)[:n2], u32=u32)
+        out["status"] = status
+        if status:
+            ridx = np.arange(n2, dtype=np.int32)
+        src = keep[ridx]
+        out.update(ridx=ridx.astype(np.int32), src=src.astype(np.int32), poses=p1[src], weights_res=w[src],
+                   nn_idx_res=idx[src], labels=np.asarray(labels)[src], N=n2)
+        self.count += 1
+        return out
+
+
 class OracleFilter:
     """filter/filter.py:150-190 without clustering/annealing (the fixed-N headline step).
 
@@ -401,10 +485,12 @@ class OracleFilter:
     def SE3_NN_idx(self, poses):
         return nn6(R3_SE3(poses), self.cb_feat)[0]
 
-    def step(self, poses, odom, code, tn, rot_deg, u=None, mode="weighted_random", u32=None, softmax=True, scores=None):
-        """Returns dict with every intermediate the parity tests compare."""
+    def step(self, poses, odom, code, tn, rot_deg, u=None, mode="weighted_random", u32=None, softmax=True, scores=None,
+             prop_override=None):
+        """Returns dict with every intermediate the parity tests compare.  prop_override: continue from these propagated
+        poses instead of the step's own (teacher forcing against a trace of the reference)."""
         out = {}
-        p1 = propagate(poses, odom, tn, rot_deg)
+        p1 = propagate(poses, odom, tn, rot_deg) if prop_override is None else _f32(prop_override)
         out["poses_prop"] = p1
         feat = R3_SE3(p1)
         idx, d2 = nn6(feat, self.cb_feat)

@@ -127,3 +127,29 @@ def test_g8_init_filter(golden, oracle):
     g = golden("g8_init")
     poses = oracle.init_filter_compose(g["gt"], g["tn"], g["rot"])
     np.testing.assert_allclose(poses, g["poses"], rtol=0, atol=2e-6)
+
+
+def test_g2b_resampler_100k_hashed(golden, oracle):
+    """The reference's resampler at N = 100 000 (12 weight sets x 2 modes, fixture G2b holds digests of its index
+    arrays): the oracle's blocked-order CDF + inverse search reproduces every index."""
+    import torch
+    from _recipes import g2b_cases, sha
+    for ci, w, mode, seed, ref_sha, head, tail in g2b_cases(golden("g2b_resampler_100k")):
+        torch.manual_seed(seed)
+        if mode == "weighted_random":
+            idx, status = oracle.resample_indices(w, mode, u=torch.rand(len(w), dtype=torch.float64).numpy())
+        else:
+            idx, status = oracle.resample_indices(w, mode, u32=float(torch.rand(1).item()))
+        assert status == 0
+        assert np.array_equal(idx[:64], head) and np.array_equal(idx[-64:], tail), (ci, mode)
+        assert sha(idx.astype(np.int32)) == ref_sha, (ci, mode)
+
+
+def test_g9_dbscan(golden, oracle):
+    """cluster_particles (sklearn DBSCAN, min_samples = N // 5) labels written by the reference: restated exactly."""
+    g = golden("g9_dbscan")
+    for tag in ("two", "one", "noise", "three", "lattice", "eps2"):
+        X, ref = g[f"{tag}_X"], g[f"{tag}_labels"]
+        lab, ncl = oracle.dbscan(X, float(g[f"{tag}_eps"]), len(X) // 5)
+        assert np.array_equal(lab, ref), tag
+        assert ncl == ref.max() + 1
