@@ -375,6 +375,104 @@ typedef struct midas_tail_resample_args {
 } midas_tail_resample_args;
 int midas_tail_resample(midas_ctx* ctx, const midas_tail_resample_args* args);
 
+/* ---- the whole loop body on a variable-size particle set ------------------------------------------------------
+ * One call = filter/filter.py:150-190 INCLUDING clustering and annealing: motion model (particle_filter.py:359-377), rmse
+ * (:472-496), SE3_NN + get_similarity (:449-469, tactile_tree.py:43-58), remove_invalid_particles (:379-403) with the
+ * re-projection when every particle drifted (filter.py:176-179), cluster_particles (DBSCAN, :208-228) on the frames the
+ * caller asks for, get_cluster_centers("quat_avg") (:153-206), annealing (:405-447: device-side top-k selection, compaction
+ * or duplication) and resampler (:230-307) - with the particle count in device memory, so that nothing is read back
+ * between frames.  Every per-particle array holds `cap` entries (the initial particle count: annealing never grows the set
+ * beyond it, :439-440); the live count is ctl_i[MIDAS_LOOP_I_N].
+ *
+ * phases (bit mask, executed in this order; a frame is all of them, possibly split over several calls when the host
+ * wants to look at or replace something in between - e.g. draw the resampler's uniforms once the annealed size is known):
+ *   MIDAS_LOOP_FRONT     propagate + NN + prune + codebook scores; x, e, masked weights w, S, guard, drift re-projection, rmse
+ *   MIDAS_LOOP_DBSCAN    labels_dev <- DBSCAN(translations of the propagated poses, eps, n / 5); ctl_i[NCL]
+ *   MIDAS_LOOP_ANNEAL    cluster centres of labels_dev, var = mean(stds), annealing decision, src_dev = annealed set
+ *                        (without this phase the annealed set is the identity: n_set = n)
+ *   MIDAS_LOOP_RESAMPLE  blocked CDF of (e * valid)[src], n_set draws, gathers into poses_dev / weights_out_dev /
+ *                        hint_dev / labels_out_dev; ctl_i[N] <- n_set; the frame's log row
+ * Summation order, draws and guards as in midas_filter_step; ties in the annealing's top-k go to the smaller index
+ * (what torch.topk does on CUDA; its CPU kernel makes another, equally arbitrary choice). */
+#define MIDAS_LOOP_FRONT 1
+#define MIDAS_LOOP_DBSCAN 2
+#define MIDAS_LOOP_ANNEAL 4
+#define MIDAS_LOOP_RESAMPLE 8
+#define MIDAS_LOOP_MAX_CLUSTERS 64
+/* ctl_i (32 x int32) */
+#define MIDAS_LOOP_I_N 0       /* live particle count (set by the caller before the first frame) */
+#define MIDAS_LOOP_I_NSET 1    /* size of the annealed set of this frame = draws of its resample */
+#define MIDAS_LOOP_I_MODE 2    /* annealing of this frame: 0 none, 1 removed K particles, 2 duplicated K */
+#define MIDAS_LOOP_I_K 3
+#define MIDAS_LOOP_I_INIT 4    /* init_particles (particle_filter.py:416) */
+#define MIDAS_LOOP_I_VARSET 5  /* 0 until the first annealing call stored its variance (:413-417) */
+#define MIDAS_LOOP_I_KEPT 6    /* particles kept by the prune */
+#define MIDAS_LOOP_I_DRIFT 7   /* 1: every particle was pruned, poses re-projected onto the codebook */
+#define MIDAS_LOOP_I_STATUS 8  /* cdf status of the resample (see midas_cdf): != 0 -> the annealed set went on unresampled */
+#define MIDAS_LOOP_I_RAW 9     /* 1: the weights are raw scores (softmax off or skipped by the isclose guard) */
+#define MIDAS_LOOP_I_NCL 10    /* labels are in [-1, NCL) (DBSCAN phase, or set by the caller with its own labels) */
+#define MIDAS_LOOP_I_NPRES 11  /* rows of cluster_poses_dev / cluster_stds_dev: labels present, ascending */
+#define MIDAS_LOOP_I_FRAME 12  /* frames completed */
+#define MIDAS_LOOP_I_NAN 13    /* NaN among the scores */
+#define MIDAS_LOOP_I_ERR 14    /* bit 0: more than MIDAS_LOOP_MAX_CLUSTERS - 1 clusters, bit 1: DBSCAN grid limit */
+/* ctl_d (16 x float64) */
+#define MIDAS_LOOP_D_S 0        /* softmax denominator (1 when raw) */
+#define MIDAS_LOOP_D_VARPREV 1  /* particle_var (float32 value) */
+#define MIDAS_LOOP_D_VAR 2      /* this frame's mean cluster spread */
+#define MIDAS_LOOP_D_RMSE_T 3
+#define MIDAS_LOOP_D_RMSE_R 4
+#define MIDAS_LOOP_D_XMAX 5
+#define MIDAS_LOOP_D_XMIN 6
+#define MIDAS_LOOP_D_TOTAL 7    /* total of the resample's CDF */
+#define MIDAS_LOOP_LOG_DOUBLES 168 /* log row: 16 scalars {frame, n, n_set, rmse_t, rmse_r, kept, drifted, status, mode, k,
+                                    * npres, var, S, raw, ncl, err} + 8 x (16 pose + 3 std) of the first clusters present */
+typedef struct midas_loop_args {
+    int64_t cap;
+    int32_t* ctl_i_dev;            /* 32 */
+    double* ctl_d_dev;             /* 16 */
+    float* poses_dev;              /* cap x 16: particle set at the frame start; the resampled set on return */
+    float* poses_prop_dev;         /* cap x 16: propagated (and possibly re-projected) poses of the frame */
+    int32_t* hint_dev;             /* cap: NN index of each particle's ancestor, in / out (-1 = none) */
+    int32_t* nn_idx_dev;           /* cap */
+    uint8_t* valid_dev;            /* cap: prune mask */
+    double* x_dev;                 /* cap: scores[nn] */
+    double* e_dev;                 /* cap: exp(x - 1), or x when the softmax is off */
+    double* weights_dev;           /* cap: masked weights before annealing / resampling */
+    double* weights_out_dev;       /* cap: the same gathered by the resample */
+    int32_t* labels_dev;           /* cap: cluster labels of the particles of this frame (in, or written by the DBSCAN phase) */
+    int32_t* labels_out_dev;       /* cap: labels gathered by the resample (the caller swaps the two) */
+    int32_t* src_dev;              /* cap: annealed set -> index into the frame's particles */
+    int32_t* ridx_dev;             /* cap: resample indices into the annealed set */
+    double* scores_dev;            /* K */
+    double* part_rmse_dev;         /* NULL or 2 ceil(cap / 64) */
+    const float* cb_poses_dev;     /* K x 16: codebook poses (drift re-projection, filter.py:176-179) */
+    float* cluster_poses_dev;      /* MIDAS_LOOP_MAX_CLUSTERS x 16 out */
+    float* cluster_stds_dev;       /* MIDAS_LOOP_MAX_CLUSTERS x 3 out */
+    double* log_dev;               /* NULL or MIDAS_LOOP_LOG_DOUBLES: this frame's log row */
+    const float* odom16_dev;
+    const double* code_dev;
+    const float* gt16_dev;         /* NULL or 16 */
+    const float* tn_dev;           /* host draws for the live particles or NULL -> Philox(seed, step) */
+    const float* rot_dev;
+    const double* u_dev;           /* NULL -> Philox, or >= n_set uniforms */
+    float u32;
+    float std_t, std_r;
+    uint64_t seed, step;
+    double prune_thr;
+    int32_t softmax, resample_mode;
+    int32_t floor;                 /* annealing floor (particle_filter.py:406) */
+    double eps;                    /* DBSCAN radius (particle_filter.py:209) */
+    uint64_t* telemetry_dev;       /* NULL or 16 counters (see midas_step_args) */
+} midas_loop_args;
+int midas_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
+                    const midas_loop_args* args, int32_t phases);
+/* cluster_particles(method="euclidean") alone (particle_filter.py:208-217): labels_dev[i] = DBSCAN label of pose i's
+ * translation, eps as given, min_samples < 0 -> N / 5.  Exact float64 predicate |dx|^2 <= eps^2, clusters numbered by their
+ * first core point, border points to the smallest adjacent cluster - what sklearn's DBSCAN returns.
+ * ncl_dev: 2 x int32 out {number of clusters, limit flag}. */
+int midas_dbscan(midas_ctx* ctx, int64_t N, const float* poses_dev, double eps, int64_t min_samples, int32_t* labels_dev,
+                 int32_t* ncl_dev);
+
 /* B concurrent trajectories against one codebook (BASELINE config 5, "throughput mode"): every per-trajectory
  * array of `args` carries a leading batch dimension, contiguous - poses (B,N,16), weights (B,N), hints (B,N),
  * odom16 (B,16), code (B,D), gt16 (B,16), rmse (B,2), status (B,2), tn/rot (B,N,3), u (B,N); scalars are shared.

@@ -68,11 +68,11 @@ MD double cl_wmin(double v) {
     return v;
 }
 
-// part[(block * C + c) * CL_MOM + m]
-__global__ __launch_bounds__(256) void k_cluster_moments(int64_t N, const float* __restrict__ poses, const double* __restrict__ w64,
-                                                         const float* __restrict__ w32, const int64_t* __restrict__ labels, int C,
-                                                         const int64_t* __restrict__ label_values, double* __restrict__ part) {
-    __shared__ double s_w[4][CL_MOM];
+// part[(block * C + c) * CL_MOM + m]; label_value(c) = the label cluster slot c stands for
+template <typename LabelT, typename LV>
+MD void cluster_moments_body(int64_t N, const float* __restrict__ poses, const double* __restrict__ w64,
+                             const float* __restrict__ w32, const LabelT* __restrict__ labels, int C, LV label_value,
+                             double* __restrict__ part, double (*s_w)[CL_MOM]) {
     const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
     const int64_t n = (int64_t)blockIdx.x * 256 + t;
     const bool live = n < N;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_cluster_moments(int64_t N, const float*
     const float4* p4 = reinterpret_cast<const float4*>(poses + nc * 16);
 #pragma unroll
     for (int i = 0; i < 3; ++i) { const float4 r = p4[i]; P[4 * i] = r.x; P[4 * i + 1] = r.y; P[4 * i + 2] = r.z; P[4 * i + 3] = r.w; }
-    const int64_t lab = labels[nc];
+    const int64_t lab = (int64_t)labels[nc];
     // particles.weights.float() (:161): the reference averages with float32 weights
     const double w = w64 ? (double)(float)w64[nc] : (double)w32[nc];
     double q[4];
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void k_cluster_moments(int64_t N, const float*
     const double tx = P[3], ty = P[7], tz = P[11];
     double v[CL_MOM];
     for (int c = 0; c < C; ++c) {
-        const bool mine = live && lab == label_values[c];
+        const bool mine = live && lab == label_value(c);
         const double a = mine ? w : 0.0, b = mine ? 1.0 : 0.0;
         v[M_SW] = a; v[M_CNT] = b; v[M_WMAX] = 0.0; v[M_WMIN] = 0.0;
         int k = 0;
@@ -124,6 +124,26 @@ __global__ __launch_bounds__(256) void k_cluster_moments(int64_t N, const float*
             part[((size_t)blockIdx.x * C + c) * CL_MOM + t] = r;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_cluster_moments(int64_t N, const float* __restrict__ poses, const double* __restrict__ w64,
+                                                         const float* __restrict__ w32, const int64_t* __restrict__ labels, int C,
+                                                         const int64_t* __restrict__ label_values, double* __restrict__ part) {
+    __shared__ double s_w[4][CL_MOM];
+    cluster_moments_body(N, poses, w64, w32, labels, C, [&](int c) { return label_values[c]; }, part, s_w);
+}
+
+// loop engine: labels are DBSCAN's int32 values in [-1, ncl), cluster slot c stands for label c - 1; the particle count
+// and ncl come from the control block (midas_loop_step)
+__global__ __launch_bounds__(256) void k_loop_cluster_moments(const int32_t* __restrict__ ctl_i, const float* __restrict__ poses,
+                                                              const double* __restrict__ w64, const int32_t* __restrict__ labels,
+                                                              double* __restrict__ part) {
+    __shared__ double s_w[4][CL_MOM];
+    const int64_t n = ctl_i[LOOP_I_N];
+    int C = ctl_i[LOOP_I_NCL] + 1;
+    C = C > LOOP_MAX_CLUSTERS ? LOOP_MAX_CLUSTERS : C;
+    if ((int64_t)blockIdx.x * 256 >= n) return;
+    cluster_moments_body(n, poses, w64, (const float*)nullptr, labels, C, [](int c) { return (int64_t)(c - 1); }, part, s_w);
 }
 
 // cyclic Jacobi on a symmetric 4x4 (float64): A -> diag, V = eigenvectors (columns)
@@ -161,11 +181,9 @@ MD void jacobi4(double A[4][4], double V[4][4]) {
 }
 
 // one 64-thread workgroup per cluster: blocks summed in order, then the closed forms
-__global__ __launch_bounds__(64) void k_cluster_finish(int nblocks, int C, const double* __restrict__ part,
-                                                       float* __restrict__ centers, float* __restrict__ stds,
-                                                       int64_t* __restrict__ counts) {
-    __shared__ double s_m[CL_MOM];
-    const int c = blockIdx.x, t = threadIdx.x;
+MD void cluster_finish_body(int nblocks, int C, int c, const double* __restrict__ part, float* __restrict__ centers,
+                            float* __restrict__ stds, int64_t* __restrict__ counts, double* s_m) {
+    const int t = threadIdx.x;
     if (t < CL_MOM) {
         double r = part[(size_t)c * CL_MOM + t];
         for (int b = 1; b < nblocks; ++b) {
@@ -216,6 +234,35 @@ __global__ __launch_bounds__(64) void k_cluster_finish(int nblocks, int C, const
         var = var < 0.0 ? 0.0 : var;
         sd[i] = (float)__builtin_sqrt(var);
     }
+}
+
+__global__ __launch_bounds__(64) void k_cluster_finish(int nblocks, int C, const double* __restrict__ part,
+                                                       float* __restrict__ centers, float* __restrict__ stds,
+                                                       int64_t* __restrict__ counts) {
+    __shared__ double s_m[CL_MOM];
+    cluster_finish_body(nblocks, C, blockIdx.x, part, centers, stds, counts, s_m);
+}
+
+// loop engine: cluster slot c = blockIdx.x of the LOOP_MAX_CLUSTERS launched; rows of label c - 1
+__global__ __launch_bounds__(64) void k_loop_cluster_finish(const int32_t* __restrict__ ctl_i, const double* __restrict__ part,
+                                                            float* __restrict__ centers, float* __restrict__ stds,
+                                                            int64_t* __restrict__ counts) {
+    __shared__ double s_m[CL_MOM];
+    const int64_t n = ctl_i[LOOP_I_N];
+    int C = ctl_i[LOOP_I_NCL] + 1;
+    C = C > LOOP_MAX_CLUSTERS ? LOOP_MAX_CLUSTERS : C;
+    if ((int)blockIdx.x >= C) return;
+    cluster_finish_body((int)((n + 255) / 256), C, blockIdx.x, part, centers, stds, counts, s_m);
+}
+
+int launch_loop_cluster(midas_ctx* ctx, int64_t cap, const int32_t* ctl_i, const float* poses, const double* w64,
+                        const int32_t* labels, double* part, float* centers, float* stds, int64_t* counts) {
+    hipLaunchKernelGGL(k_loop_cluster_moments, dim3((unsigned)ceil_div(cap, 256)), dim3(256), 0, ctx->stream, ctl_i, poses, w64,
+                       labels, part);
+    hipLaunchKernelGGL(k_loop_cluster_finish, dim3(LOOP_MAX_CLUSTERS), dim3(64), 0, ctx->stream, ctl_i, (const double*)part, centers,
+                       stds, counts);
+    MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    return MIDAS_OK;
 }
 
 int launch_cluster_centers(midas_ctx* ctx, int64_t N, const float* poses, const double* w64, const float* w32,

@@ -134,6 +134,19 @@ int midas_scratch(midas_ctx* ctx, size_t bytes, void** out);
 
 namespace midas {
 
+// control block of the loop engine (midas_loop_args.ctl_i_dev / ctl_d_dev; include/midas_hip.h MIDAS_LOOP_*)
+enum : int {
+    LOOP_I_N = MIDAS_LOOP_I_N, LOOP_I_NSET = MIDAS_LOOP_I_NSET, LOOP_I_MODE = MIDAS_LOOP_I_MODE, LOOP_I_K = MIDAS_LOOP_I_K,
+    LOOP_I_INIT = MIDAS_LOOP_I_INIT, LOOP_I_VARSET = MIDAS_LOOP_I_VARSET, LOOP_I_KEPT = MIDAS_LOOP_I_KEPT,
+    LOOP_I_DRIFT = MIDAS_LOOP_I_DRIFT, LOOP_I_STATUS = MIDAS_LOOP_I_STATUS, LOOP_I_RAW = MIDAS_LOOP_I_RAW,
+    LOOP_I_NCL = MIDAS_LOOP_I_NCL, LOOP_I_NPRES = MIDAS_LOOP_I_NPRES, LOOP_I_FRAME = MIDAS_LOOP_I_FRAME,
+    LOOP_I_NAN = MIDAS_LOOP_I_NAN, LOOP_I_ERR = MIDAS_LOOP_I_ERR,
+    LOOP_D_S = MIDAS_LOOP_D_S, LOOP_D_VARPREV = MIDAS_LOOP_D_VARPREV, LOOP_D_VAR = MIDAS_LOOP_D_VAR,
+    LOOP_D_RMSE_T = MIDAS_LOOP_D_RMSE_T, LOOP_D_RMSE_R = MIDAS_LOOP_D_RMSE_R, LOOP_D_XMAX = MIDAS_LOOP_D_XMAX,
+    LOOP_D_XMIN = MIDAS_LOOP_D_XMIN, LOOP_D_TOTAL = MIDAS_LOOP_D_TOTAL,
+    LOOP_MAX_CLUSTERS = MIDAS_LOOP_MAX_CLUSTERS,
+};
+
 // blocked-scan spec constants (DESIGN.md "Summation order")
 constexpr int SCAN_CHUNK = 16;
 constexpr int SCAN_TPB = 256;
@@ -188,6 +201,8 @@ struct ParticleUpdateArgs {
     const float* rot;
     float std_t, std_r;
     uint64_t seed, step;
+    const int32_t* n_live = nullptr;  // nullable: the live particle count in device memory (loop engine); N is then
+                                      // the capacity the grid was sized for and slots >= *n_live are skipped
     int64_t slot_base = 0;  // global index of local particle 0 (Philox key)
     int32_t batch = 1;      // trajectories (grid.y); per-trajectory arrays are (batch, ...) contiguous
     int64_t score_stride = 0;  // K: scores are (batch, K)
@@ -288,6 +303,17 @@ int launch_reduce_partials(midas_ctx* ctx, int np, const double* pmax, const dou
 int launch_cluster_centers(midas_ctx* ctx, int64_t N, const float* poses, const double* w64, const float* w32,
                            const int64_t* labels, int32_t C, const int64_t* label_values, float* centers, float* stds,
                            int64_t* counts);
+
+int launch_loop_cluster(midas_ctx* ctx, int64_t cap, const int32_t* ctl_i, const float* poses, const double* w64,
+                        const int32_t* labels, double* part, float* centers, float* stds, int64_t* counts);
+
+// loop.hip / dbscan.hip - the reference's whole loop body on a variable-size particle set (midas_loop_step)
+int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* t6, const midas_tree* t3,
+                     const midas_loop_args& a, int32_t phases);
+// labels_out[i] in [-1, ncl) for the n = *n_dev (or N when n_dev is null) poses; min_samples < 0 -> n / 5 (cluster_particles);
+// ncl_out[0] = number of clusters, ncl_out[1] = 1 when the grid / cluster limits were exceeded
+int launch_dbscan(midas_ctx* ctx, int64_t cap, const int32_t* n_dev, const float* poses, double eps, int64_t min_samples,
+                  int32_t* labels_out, int32_t* ncl_out);
 
 // topn.hip
 int launch_topn_pose_error(midas_ctx* ctx, int32_t B, int64_t K, const double* scores, int64_t row0, int32_t n,

@@ -1232,6 +1232,11 @@ MD int64_t lazy_source(const LazyResample& rs, const double* rs_lds, int64_t n, 
 MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, ParticleUpdateArgs a, int64_t wave,
                              int nwaves, int traj, double* s_cd, const double* rs_lds = nullptr) {
     const int lane = threadIdx.x & 63;
+    if (a.n_live) {  // variable particle count: the grid covers the capacity, the waves past the live set leave
+        const int64_t nl = *a.n_live;
+        a.N = nl < a.N ? nl : a.N;
+        if (wave * 64 >= a.N && wave != 0) return;
+    }
     if (traj) {  // batch of trajectories: every per-trajectory array is (B, ...) contiguous
         const int64_t b = traj, o = b * a.N;
         a.poses_in += o * 16; a.poses_prop += o * 16; a.odom16 += b * 16;
@@ -1401,6 +1406,11 @@ static_assert(sizeof(PuFeat) == 32, "two 16-byte pieces per particle");
 // part A of a particle wave: what particle_update_wave does before the nearest-neighbour search, plus its rmse epilogue
 MD void particle_front_wave(ParticleUpdateArgs a, int64_t wave, const double* rs_lds, PuFeat* __restrict__ feat) {
     const int lane = threadIdx.x & 63;
+    if (a.n_live) {
+        const int64_t nl = *a.n_live;
+        a.N = nl < a.N ? nl : a.N;
+        if (wave * 64 >= a.N && wave != 0) return;
+    }
     const int64_t n = wave * 64 + lane;
     const bool live = n < a.N;
     if (wave == 0 && lane == 0) {
@@ -1476,9 +1486,14 @@ __global__ __launch_bounds__(256, MIDAS_NNP_OCC) void k_particle_nn_prune(TreeVi
     constexpr int MESH_PER_LANE = 16 / LPP;
     __shared__ double s_cd[4][KD_MAX_LEVELS * 64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane & (LPP - 1);
+    if (a.n_live) {
+        const int64_t nl = *a.n_live;
+        a.N = nl < a.N ? nl : a.N;
+        if ((int64_t)blockIdx.x * 4 * PPW >= a.N) return;  // whole workgroup past the live set
+    }
     const int64_t p = ((int64_t)blockIdx.x * 4 + w) * PPW + lane / LPP;
     const bool live = p < a.N, owner = g == 0;
-    const int64_t pc = live ? p : a.N - 1;
+    const int64_t pc = live ? p : (a.N > 0 ? a.N - 1 : 0);
     const float4* fp = reinterpret_cast<const float4*>(feat + pc);
     const float4 f0 = fp[0], f1 = fp[1];
     const float q[6] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y};
