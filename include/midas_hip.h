@@ -462,6 +462,8 @@ typedef struct midas_loop_args {
     int32_t softmax, resample_mode;
     int32_t floor;                 /* annealing floor (particle_filter.py:406) */
     double eps;                    /* DBSCAN radius (particle_filter.py:209) */
+    int32_t unit_weights;          /* 1: a frame without measurement update - every particle scores 1, so the weights are the
+                                    * prune mask (filter/filter_real.py:205-212, `update_freq`) */
     uint64_t* telemetry_dev;       /* NULL or 16 counters (see midas_step_args) */
 } midas_loop_args;
 int midas_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
@@ -472,6 +474,12 @@ int midas_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* 
  * ncl_dev: 2 x int32 out {number of clusters, limit flag}. */
 int midas_dbscan(midas_ctx* ctx, int64_t N, const float* poses_dev, double eps, int64_t min_samples, int32_t* labels_dev,
                  int32_t* ncl_dev);
+
+/* The selection step of particle_filter.annealing alone (modules/particle_filter.py:421-446, torch.topk + Particles.remove /
+ * add): src_dev[0 .. n_set) = the annealed set as indices into the N particles.  mode 1: the N particles minus the k of
+ * smallest weight, in their order (n_set = N - k); mode 2: all N followed by the k of largest weight, largest first
+ * (n_set = N + k; src_dev holds N + k entries).  Ties go to the smaller index.  0 <= k <= N / 3.  weights_dev: N float64. */
+int midas_anneal_select(midas_ctx* ctx, int64_t N, const double* weights_dev, int32_t mode, int64_t k, int32_t* src_dev);
 
 /* B concurrent trajectories against one codebook (BASELINE config 5, "throughput mode"): every per-trajectory
  * array of `args` carries a leading batch dimension, contiguous - poses (B,N,16), weights (B,N), hints (B,N),

@@ -131,6 +131,31 @@ class TailResampleArgs(C.Structure):
     ]
 
 
+class LoopArgs(C.Structure):
+    """midas_loop_args (include/midas_hip.h)."""
+
+    _fields_ = [
+        ("cap", C.c_int64), ("ctl_i", C.c_void_p), ("ctl_d", C.c_void_p),
+        ("poses", C.c_void_p), ("poses_prop", C.c_void_p), ("hint", C.c_void_p), ("nn_idx", C.c_void_p), ("valid", C.c_void_p),
+        ("x", C.c_void_p), ("e", C.c_void_p), ("weights", C.c_void_p), ("weights_out", C.c_void_p),
+        ("labels", C.c_void_p), ("labels_out", C.c_void_p), ("src", C.c_void_p), ("ridx", C.c_void_p),
+        ("scores", C.c_void_p), ("part_rmse", C.c_void_p), ("cb_poses", C.c_void_p),
+        ("cluster_poses", C.c_void_p), ("cluster_stds", C.c_void_p), ("log", C.c_void_p),
+        ("odom16", C.c_void_p), ("code", C.c_void_p), ("gt16", C.c_void_p), ("tn", C.c_void_p), ("rot", C.c_void_p),
+        ("u", C.c_void_p), ("u32", C.c_float), ("std_t", C.c_float), ("std_r", C.c_float),
+        ("seed", C.c_uint64), ("step", C.c_uint64), ("prune_thr", C.c_double),
+        ("softmax", C.c_int32), ("resample_mode", C.c_int32), ("floor", C.c_int32), ("eps", C.c_double),
+        ("unit_weights", C.c_int32), ("telemetry", C.c_void_p),
+    ]
+
+
+# phases of midas_loop_step and the control-block indices (include/midas_hip.h MIDAS_LOOP_*)
+LOOP_FRONT, LOOP_DBSCAN, LOOP_ANNEAL, LOOP_RESAMPLE = 1, 2, 4, 8
+LOOP_MAX_CLUSTERS, LOOP_LOG_DOUBLES = 64, 168
+(LOOP_I_N, LOOP_I_NSET, LOOP_I_MODE, LOOP_I_K, LOOP_I_INIT, LOOP_I_VARSET, LOOP_I_KEPT, LOOP_I_DRIFT, LOOP_I_STATUS,
+ LOOP_I_RAW, LOOP_I_NCL, LOOP_I_NPRES, LOOP_I_FRAME, LOOP_I_NAN, LOOP_I_ERR) = range(15)
+(LOOP_D_S, LOOP_D_VARPREV, LOOP_D_VAR, LOOP_D_RMSE_T, LOOP_D_RMSE_R, LOOP_D_XMAX, LOOP_D_XMIN, LOOP_D_TOTAL) = range(8)
+
 # name -> (restype, argtypes); must list every symbol include/midas_hip.h declares
 _P, _I32, _I64, _U64, _F, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
 SIGNATURES = {
@@ -167,6 +192,9 @@ SIGNATURES = {
     "midas_filter_step_batch": (C.c_int, [_P, _P, _P, _P, C.POINTER(StepArgs), _I32]),
     "midas_lazy_step": (C.c_int, [_P, _P, _P, _P, C.POINTER(LazyArgs)]),
     "midas_lazy_flush": (C.c_int, [_P, C.POINTER(LazyFlushArgs)]),
+    "midas_loop_step": (C.c_int, [_P, _P, _P, _P, C.POINTER(LoopArgs), _I32]),
+    "midas_dbscan": (C.c_int, [_P, _I64, _P, _D, _I64, _P, _P]),
+    "midas_anneal_select": (C.c_int, [_P, _I64, _P, _I32, _I64, _P]),
     "midas_shard_front": (C.c_int, [_P, _P, _P, _P, C.POINTER(ShardFrontArgs)]),
     "midas_shard_tail_a": (C.c_int, [_P, _I64, _P, _P, _P, _I32, _P, _P, _P]),
     "midas_shard_tail_fin": (C.c_int, [_P, _I64, _P, _P, _P, _P, _I32, _P, _I32, _I64, _I32, _P, _P]),

@@ -781,6 +781,45 @@ MIDAS_EXPORT int midas_tail_resample(midas_ctx* ctx, const midas_tail_resample_a
     return launch_tail_resample(ctx, *args);
 }
 
+// ---- the whole loop body on a variable-size particle set ----------------------------------------------
+MIDAS_EXPORT int midas_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
+                                 const midas_loop_args* args, int32_t phases) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, args != nullptr && phases != 0 && (phases & ~15) == 0);
+    const midas_loop_args& s = *args;
+    MIDAS_REQUIRE(ctx, s.cap > 0 && ceil_div(s.cap, SCAN_BLOCK) <= LAZY_MAX_BLOCKS && s.ctl_i_dev && s.ctl_d_dev);
+    MIDAS_REQUIRE(ctx, s.poses_dev && s.poses_prop_dev && s.poses_dev != s.poses_prop_dev && s.hint_dev && s.nn_idx_dev && s.valid_dev &&
+                           s.x_dev && s.e_dev && s.weights_dev && s.weights_out_dev && s.labels_dev && s.labels_out_dev &&
+                           s.labels_dev != s.labels_out_dev && s.src_dev && s.ridx_dev && s.scores_dev && s.cluster_poses_dev &&
+                           s.cluster_stds_dev);
+    MIDAS_REQUIRE(ctx, (uintptr_t)s.poses_dev % 16 == 0 && (uintptr_t)s.poses_prop_dev % 16 == 0);
+    if (phases & MIDAS_LOOP_FRONT) {
+        MIDAS_REQUIRE(ctx, cb && tree6 && tree3 && tree6->dim == 6 && tree3->dim == 3 && tree6->K == cb->K);
+        MIDAS_REQUIRE(ctx, s.odom16_dev && s.code_dev && s.cb_poses_dev && (uintptr_t)s.cb_poses_dev % 16 == 0);
+        MIDAS_REQUIRE(ctx, (s.tn_dev == nullptr) == (s.rot_dev == nullptr));
+    }
+    if (phases & MIDAS_LOOP_DBSCAN) MIDAS_REQUIRE(ctx, s.eps > 0.0);
+    if (phases & MIDAS_LOOP_RESAMPLE)
+        MIDAS_REQUIRE(ctx, s.resample_mode == MIDAS_RESAMPLE_MULTINOMIAL || s.resample_mode == MIDAS_RESAMPLE_SYSTEMATIC);
+    return launch_loop_step(ctx, cb, tree6, tree3, s, phases);
+}
+
+MIDAS_EXPORT int midas_anneal_select(midas_ctx* ctx, int64_t N, const double* weights_dev, int32_t mode, int64_t k,
+                                     int32_t* src_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, N > 0 && ceil_div(N, SCAN_BLOCK) <= LAZY_MAX_BLOCKS && weights_dev && src_dev && (mode == 1 || mode == 2) &&
+                           k >= 0 && k <= N / 3);
+    return launch_anneal_select(ctx, N, weights_dev, k == 0 ? 0 : mode, k, src_dev);
+}
+
+MIDAS_EXPORT int midas_dbscan(midas_ctx* ctx, int64_t N, const float* poses_dev, double eps, int64_t min_samples,
+                              int32_t* labels_dev, int32_t* ncl_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, N > 0 && N < ((int64_t)1 << 31) && poses_dev && labels_dev && ncl_dev && eps > 0.0);
+    MIDAS_HIP_CHECK(ctx, hipMemsetAsync(ncl_dev, 0, 2 * sizeof(int32_t), ctx->stream));
+    return launch_dbscan(ctx, N, nullptr, poses_dev, eps, min_samples, labels_dev, ncl_dev, ncl_dev + 1);
+}
+
 #ifdef MIDAS_DEBUG_CLOCKS
 MIDAS_EXPORT int midas_debug_tb2_clocks(long long* out16) { return midas::debug_tb2_clocks(out16); }
 #endif

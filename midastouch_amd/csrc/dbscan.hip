@@ -1,0 +1,414 @@
+// dbscan.hip - particle_filter.cluster_particles(method="euclidean") on the device (modules/particle_filter.py:208-217):
+// sklearn.cluster.DBSCAN(eps, min_samples = N / 5).fit(translations).labels_.
+//
+// The reference runs it on the host every 50th frame; at N = 100 000 that is seconds (neighbour lists of a spread
+// cloud) to minutes (a converged one: N^2 / 2 list entries), i.e. the one step that would keep the loop from ever running
+// at sensor rate.  min_samples is huge (N / 5), which shapes the algorithm:
+//   * uniform grid of side h = 0.577 eps (cube diagonal < eps): all points of a cell are mutual neighbours, candidates
+//     live in the 5 x 5 x 5 cells around a point (two cells away is already > eps apart in that axis);
+//   * core test: cell population first (no distance at all), then the population of the 125 cells as an upper bound,
+//     then exact tests with an early exit at min_samples;
+//   * components: the core points of a cell form a clique -> one representative per cell; a core point only needs ONE
+//     partner within eps per neighbouring cell to join that cell's component (lock-free union-find, larger root under
+//     smaller, so a root is the smallest particle index of its cluster);
+//   * numbering as sklearn's scan does: clusters in the order of their first core point; a border point takes the
+//     smallest number among the clusters whose core points reach it.
+// Predicate (sklearn's KD-tree on float64 copies): ((dx*dx) + dy*dy) + dz*dz <= eps*eps, accumulated in that order.
+// Pinned by fixture G9 (labels written by the reference's own cluster_particles) through the oracle's O(N^2) restatement.
+#include <cmath>
+
+#include "midas_internal.hpp"
+
+namespace midas {
+
+#define DB_LAUNCH_CHECK(ctx) MIDAS_HIP_CHECK(ctx, hipGetLastError())
+
+constexpr int DB_MAXDIM = 128;                     // cells per axis
+constexpr int DB_MAXCELLS = DB_MAXDIM * DB_MAXDIM * DB_MAXDIM;
+constexpr int DB_MAXROOTS = LOOP_MAX_CLUSTERS - 1;  // labels -1 .. 62
+constexpr double DB_CELL = 0.577;                   // cell side / eps, below 1 / sqrt(3)
+
+struct DbGrid {         // written by k_db_setup
+    double ox, oy, oz;  // origin
+    double h;           // cell side
+    int32_t dx, dy, dz; // cells per axis
+    int32_t ncells;
+    int32_t n;          // points
+    int32_t ms;         // min_samples
+    int32_t nroots;
+    int32_t err;
+};
+
+struct DbArgs {
+    int64_t N;              // capacity / host count
+    const int32_t* n_dev;   // nullable: live count
+    const float* poses;     // x 16
+    double eps, r2;
+    int64_t min_samples;    // < 0 -> n / 5
+    DbGrid* grid;
+    float* part;            // [blocks x 6] bounds partials
+    int32_t* cell_count;    // [DB_MAXCELLS] population, then cursor
+    int32_t* cell_start;    // [DB_MAXCELLS + 1]
+    int32_t* cell_rep;      // [DB_MAXCELLS] smallest particle index among the cell's core points (INT_MAX: none)
+    int32_t* cell_num;      // [DB_MAXCELLS] cluster number of the cell's core points (-1: none)
+    int32_t* cid;           // [N] cell of particle i
+    int32_t* s_orig;        // [N] sorted position -> particle
+    float4* s_pt;           // [N] sorted position -> (x, y, z, cell id as int bits)
+    uint8_t* s_core;        // [N] by sorted position
+    int32_t* parent;        // [N] by particle (core points only)
+    int32_t* roots;         // [DB_MAXROOTS + 1]
+    int32_t* labels;        // [N] out
+    int32_t* ncl_out;       // out: number of clusters
+    int32_t* err_out;       // nullable: |= 2 on a limit
+};
+
+__device__ __forceinline__ int64_t db_n(const DbArgs& a) {
+    if (!a.n_dev) return a.N;
+    const int64_t n = *a.n_dev;
+    return n < a.N ? n : a.N;
+}
+
+__global__ __launch_bounds__(256) void k_db_bounds(DbArgs a) {
+    __shared__ float s[6][4];
+    const int64_t n = db_n(a);
+    const int t = threadIdx.x;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + t; i < n; i += (int64_t)gridDim.x * 256) {
+        const float* P = a.poses + i * 16;
+        const float c[3] = {P[3], P[7], P[11]};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { lo[d] = c[d] < lo[d] ? c[d] : lo[d]; hi[d] = c[d] > hi[d] ? c[d] : hi[d]; }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float x = __shfl_xor(lo[d], o), y = __shfl_xor(hi[d], o);
+            lo[d] = x < lo[d] ? x : lo[d];
+            hi[d] = y > hi[d] ? y : hi[d];
+        }
+    if ((t & 63) == 0)
+        for (int d = 0; d < 3; ++d) { s[d][t >> 6] = lo[d]; s[3 + d][t >> 6] = hi[d]; }
+    __syncthreads();
+    if (t < 6) {
+        float v = s[t][0];
+        for (int w = 1; w < 4; ++w) v = t < 3 ? (s[t][w] < v ? s[t][w] : v) : (s[t][w] > v ? s[t][w] : v);
+        a.part[blockIdx.x * 6 + t] = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_db_setup(DbArgs a, int nblocks) {
+    if (threadIdx.x != 0) return;
+    const int64_t n = db_n(a);
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int b = 0; b < nblocks; ++b)
+        for (int d = 0; d < 3; ++d) {
+            const float x = a.part[b * 6 + d], y = a.part[b * 6 + 3 + d];
+            lo[d] = x < lo[d] ? x : lo[d];
+            hi[d] = y > hi[d] ? y : hi[d];
+        }
+    DbGrid g;
+    g.h = a.eps * DB_CELL;
+    g.ox = lo[0]; g.oy = lo[1]; g.oz = lo[2];
+    int dims[3];
+    int err = 0;
+    for (int d = 0; d < 3; ++d) {
+        const double ext = (double)hi[d] - (double)lo[d];
+        double c = n > 0 ? floor(ext / g.h) + 1.0 : 1.0;
+        if (!(c >= 1.0)) c = 1.0;                      // NaN extents
+        if (c > (double)DB_MAXDIM) { c = DB_MAXDIM; err = 1; }
+        dims[d] = (int)c;
+    }
+    g.dx = dims[0]; g.dy = dims[1]; g.dz = dims[2];
+    g.ncells = g.dx * g.dy * g.dz;
+    g.n = (int32_t)n;
+    g.ms = a.min_samples < 0 ? (int32_t)(n / 5) : (int32_t)a.min_samples;
+    g.nroots = 0;
+    g.err = err;
+    *a.grid = g;
+}
+
+__device__ __forceinline__ int db_cell_of(const DbGrid& g, float x, float y, float z, int& cx, int& cy, int& cz) {
+    cx = (int)floor(((double)x - g.ox) / g.h);
+    cy = (int)floor(((double)y - g.oy) / g.h);
+    cz = (int)floor(((double)z - g.oz) / g.h);
+    cx = cx < 0 ? 0 : cx >= g.dx ? g.dx - 1 : cx;
+    cy = cy < 0 ? 0 : cy >= g.dy ? g.dy - 1 : cy;
+    cz = cz < 0 ? 0 : cz >= g.dz ? g.dz - 1 : cz;
+    return (cz * g.dy + cy) * g.dx + cx;
+}
+
+__global__ __launch_bounds__(256) void k_db_count(DbArgs a) {
+    const DbGrid g = *a.grid;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.n) return;
+    const float* P = a.poses + i * 16;
+    int cx, cy, cz;
+    const int c = db_cell_of(g, P[3], P[7], P[11], cx, cy, cz);
+    a.cid[i] = c;
+    atomicAdd(&a.cell_count[c], 1);
+}
+
+// exclusive scan of the cell populations (one workgroup); the counters become the scatter cursors
+__global__ __launch_bounds__(1024) void k_db_scan(DbArgs a) {
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    const DbGrid g = *a.grid;
+    const int t = threadIdx.x;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < g.ncells; base += 1024 * 8) {
+        int v[8], mine = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = base + t * 8 + j;
+            v[j] = c < g.ncells ? a.cell_count[c] : 0;
+            mine += v[j];
+        }
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int x = __shfl_up(incl, o);
+            if ((t & 63) >= o) incl += x;
+        }
+        if ((t & 63) == 63) s_w[t >> 6] = incl;
+        __syncthreads();
+        int before = s_carry + incl - mine;
+        for (int w = 0; w < (t >> 6); ++w) before += s_w[w];
+        int run = before;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = base + t * 8 + j;
+            if (c < g.ncells) { a.cell_start[c] = run; a.cell_count[c] = run; a.cell_rep[c] = 0x7fffffff; a.cell_num[c] = -1; }
+            run += v[j];
+        }
+        __syncthreads();
+        if (t == 1023) s_carry = run;
+        __syncthreads();
+    }
+    if (t == 0) a.cell_start[g.ncells] = s_carry;
+}
+
+__global__ __launch_bounds__(256) void k_db_scatter(DbArgs a) {
+    const DbGrid g = *a.grid;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.n) return;
+    const float* P = a.poses + i * 16;
+    const int c = a.cid[i];
+    const int p = atomicAdd(&a.cell_count[c], 1);
+    a.s_orig[p] = (int32_t)i;
+    a.s_pt[p] = make_float4(P[3], P[7], P[11], __int_as_float(c));
+}
+
+__device__ __forceinline__ bool db_within(const float4& p, const float4& q, double r2) {
+    const double dx = (double)p.x - (double)q.x, dy = (double)p.y - (double)q.y, dz = (double)p.z - (double)q.z;
+    double d = dx * dx;
+    d += dy * dy;
+    d += dz * dz;
+    return d <= r2;
+}
+
+// walks the 5 x 5 x 5 cells around cell c (own cell included when `own`); f(cell) returns true to stop
+template <typename F>
+__device__ __forceinline__ void db_for_cells(const DbGrid& g, int c, bool own, F f) {
+    const int cx = c % g.dx, cy = (c / g.dx) % g.dy, cz = c / (g.dx * g.dy);
+    for (int z = cz - 2 < 0 ? 0 : cz - 2; z <= (cz + 2 >= g.dz ? g.dz - 1 : cz + 2); ++z)
+        for (int y = cy - 2 < 0 ? 0 : cy - 2; y <= (cy + 2 >= g.dy ? g.dy - 1 : cy + 2); ++y)
+            for (int x = cx - 2 < 0 ? 0 : cx - 2; x <= (cx + 2 >= g.dx ? g.dx - 1 : cx + 2); ++x) {
+                const int c2 = (z * g.dy + y) * g.dx + x;
+                if (c2 == c && !own) continue;
+                if (f(c2)) return;
+            }
+}
+
+// core <=> at least min_samples points within eps (itself included)
+__global__ __launch_bounds__(256) void k_db_core(DbArgs a) {
+    const DbGrid g = *a.grid;
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= g.n) return;
+    const float4 me = a.s_pt[p];
+    const int c = __float_as_int(me.w);
+    int cnt = a.cell_start[c + 1] - a.cell_start[c];  // the own cell: all within eps
+    bool core = cnt >= g.ms;
+    if (!core) {
+        int upper = cnt;
+        db_for_cells(g, c, false, [&](int c2) { upper += a.cell_start[c2 + 1] - a.cell_start[c2]; return false; });
+        if (upper >= g.ms) {
+            db_for_cells(g, c, false, [&](int c2) {
+                const int e = a.cell_start[c2 + 1];
+                for (int q = a.cell_start[c2]; q < e; ++q) {
+                    cnt += db_within(me, a.s_pt[q], a.r2) ? 1 : 0;
+                    if (cnt >= g.ms) return true;
+                }
+                return false;
+            });
+            core = cnt >= g.ms;
+        }
+    }
+    a.s_core[p] = core ? 1 : 0;
+    const int32_t orig = a.s_orig[p];
+    if (core) atomicMin(&a.cell_rep[c], orig);
+    a.parent[orig] = orig;
+}
+
+__device__ __forceinline__ int32_t db_find(int32_t* parent, int32_t i) {
+    int32_t r = i;
+    while (true) {
+        const int32_t pr = __atomic_load_n(&parent[r], __ATOMIC_RELAXED);
+        if (pr == r) break;
+        r = pr;
+    }
+    return r;
+}
+
+// lock-free union: the larger root is hooked under the smaller one, so a root is its component's smallest index
+__device__ __forceinline__ void db_union(int32_t* parent, int32_t x, int32_t y) {
+    while (true) {
+        x = db_find(parent, x);
+        y = db_find(parent, y);
+        if (x == y) return;
+        if (x > y) { const int32_t t = x; x = y; y = t; }
+        if (atomicCAS(&parent[y], y, x) == y) return;
+    }
+}
+
+// the core points of a cell are a clique: hang each under the cell's representative
+__global__ __launch_bounds__(256) void k_db_clique(DbArgs a) {
+    const DbGrid g = *a.grid;
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= g.n || !a.s_core[p]) return;
+    const int c = __float_as_int(a.s_pt[p].w);
+    const int32_t orig = a.s_orig[p], rep = a.cell_rep[c];
+    if (orig != rep) a.parent[orig] = rep;
+}
+
+// one partner within eps in a neighbouring cell joins that cell's component
+__global__ __launch_bounds__(256) void k_db_link(DbArgs a) {
+    const DbGrid g = *a.grid;
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= g.n || !a.s_core[p]) return;
+    const float4 me = a.s_pt[p];
+    const int c = __float_as_int(me.w);
+    const int32_t orig = a.s_orig[p];
+    db_for_cells(g, c, false, [&](int c2) {
+        const int32_t rep2 = a.cell_rep[c2];
+        if (rep2 == 0x7fffffff) return false;  // no core point there
+        if (db_find(a.parent, rep2) == db_find(a.parent, orig)) return false;
+        const int e = a.cell_start[c2 + 1];
+        for (int q = a.cell_start[c2]; q < e; ++q)
+            if (a.s_core[q] && db_within(me, a.s_pt[q], a.r2)) { db_union(a.parent, orig, rep2); break; }
+        return false;
+    });
+}
+
+// flatten; the roots (a cluster's first core point in index order) are collected
+__global__ __launch_bounds__(256) void k_db_roots(DbArgs a) {
+    DbGrid* gp = a.grid;
+    const DbGrid g = *gp;
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= g.n || !a.s_core[p]) return;
+    const int32_t orig = a.s_orig[p];
+    const int32_t r = db_find(a.parent, orig);
+    a.parent[orig] = r;  // the unions are complete: values only ever move towards the root, a plain store is safe
+    if (r == orig) {
+        const int slot = atomicAdd(&gp->nroots, 1);
+        if (slot < DB_MAXROOTS) a.roots[slot] = orig;
+    }
+}
+
+// cluster number of a root = its rank among the roots; per cell the number of its core points' cluster
+__global__ __launch_bounds__(256) void k_db_number(DbArgs a) {
+    __shared__ int32_t s_roots[DB_MAXROOTS + 1];
+    DbGrid* gp = a.grid;
+    const DbGrid g = *gp;
+    int nr = g.nroots;
+    const bool over = nr > DB_MAXROOTS;
+    nr = over ? DB_MAXROOTS : nr;
+    const int t = threadIdx.x;
+    if (t < nr) {  // rank sort of the few roots
+        const int32_t v = a.roots[t];
+        int rank = 0;
+        for (int j = 0; j < nr; ++j) rank += a.roots[j] < v ? 1 : 0;
+        s_roots[rank] = v;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && t == 0) {
+        *a.ncl_out = nr;
+        if (a.err_out && (over || g.err)) *a.err_out |= 2;
+    }
+    for (int64_t p = (int64_t)blockIdx.x * 256 + t; p < g.n; p += (int64_t)gridDim.x * 256) {
+        if (!a.s_core[p]) continue;
+        const int32_t orig = a.s_orig[p];
+        const int32_t r = db_find(a.parent, orig);
+        int num = -1;
+        for (int j = 0; j < nr; ++j) num = s_roots[j] == r ? j : num;
+        a.labels[orig] = num;
+        const int c = __float_as_int(a.s_pt[p].w);
+        if (a.cell_rep[c] == orig) a.cell_num[c] = num;
+    }
+}
+
+// border points: the smallest cluster number among the core points within eps; noise otherwise
+__global__ __launch_bounds__(256) void k_db_border(DbArgs a) {
+    const DbGrid g = *a.grid;
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= g.n || a.s_core[p]) return;
+    const float4 me = a.s_pt[p];
+    const int c = __float_as_int(me.w);
+    int best = 0x7fffffff;
+    db_for_cells(g, c, true, [&](int c2) {
+        const int num = a.cell_num[c2];
+        if (num < 0 || num >= best) return false;
+        if (c2 == c) { best = num; return false; }  // a core point of the own cell is within eps
+        const int e = a.cell_start[c2 + 1];
+        for (int q = a.cell_start[c2]; q < e; ++q)
+            if (a.s_core[q] && db_within(me, a.s_pt[q], a.r2)) { best = num; break; }
+        return false;
+    });
+    a.labels[a.s_orig[p]] = best == 0x7fffffff ? -1 : best;
+}
+
+int launch_dbscan(midas_ctx* ctx, int64_t cap, const int32_t* n_dev, const float* poses, double eps, int64_t min_samples,
+                  int32_t* labels_out, int32_t* ncl_out, int32_t* err_out) {
+    if (cap <= 0) return MIDAS_OK;
+    hipStream_t st = ctx->stream;
+    DbArgs a;
+    a.N = cap; a.n_dev = n_dev; a.poses = poses; a.eps = eps; a.r2 = eps * eps; a.min_samples = min_samples;
+    a.labels = labels_out; a.ncl_out = ncl_out; a.err_out = err_out;
+    const int nbb = (int)(ceil_div(cap, 256) < 256 ? ceil_div(cap, 256) : 256);
+    int rc;
+    void* p;
+#define DB_SCRATCH(field, type, count)                                        \
+    if ((rc = midas_scratch(ctx, (size_t)(count) * sizeof(type), &p))) return rc; \
+    a.field = (type*)p
+    DB_SCRATCH(grid, DbGrid, 1);
+    DB_SCRATCH(part, float, nbb * 6);
+    DB_SCRATCH(cell_count, int32_t, DB_MAXCELLS);
+    DB_SCRATCH(cell_start, int32_t, DB_MAXCELLS + 1);
+    DB_SCRATCH(cell_rep, int32_t, DB_MAXCELLS);
+    DB_SCRATCH(cell_num, int32_t, DB_MAXCELLS);
+    DB_SCRATCH(cid, int32_t, cap);
+    DB_SCRATCH(s_orig, int32_t, cap);
+    DB_SCRATCH(s_pt, float4, cap);
+    DB_SCRATCH(s_core, uint8_t, cap);
+    DB_SCRATCH(parent, int32_t, cap);
+    DB_SCRATCH(roots, int32_t, DB_MAXROOTS + 1);
+#undef DB_SCRATCH
+    const unsigned gp = (unsigned)ceil_div(cap, 256);
+    MIDAS_HIP_CHECK(ctx, hipMemsetAsync(a.cell_count, 0, (size_t)DB_MAXCELLS * sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_db_bounds, dim3(nbb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_db_setup, dim3(1), dim3(64), 0, st, a, nbb);
+    hipLaunchKernelGGL(k_db_count, dim3(gp), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_db_scan, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(k_db_scatter, dim3(gp), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_db_core, dim3(gp), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_db_clique, dim3(gp), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_db_link, dim3(gp), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_db_roots, dim3(gp), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_db_number, dim3(gp < 1024 ? gp : 1024), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_db_border, dim3(gp), dim3(256), 0, st, a);
+    DB_LAUNCH_CHECK(ctx);
+    return MIDAS_OK;
+}
+
+}  // namespace midas

@@ -1,0 +1,842 @@
+// loop.hip - the reference's whole loop body on a variable-size particle set (midas_loop_step).
+//
+// filter/filter.py:150-190 changes the particle count every frame between the measurement update and the resample
+// (particle_filter.annealing, modules/particle_filter.py:405-447).  Here the count lives in device memory
+// (ctl_i[LOOP_I_N]); every kernel is launched over the capacity of the arrays and reads the live count itself, so a frame
+// needs no host round trip:
+//
+//   FRONT     k_frame_front (particles.hip, live count from the control block) -> k_loop_xe (scores gathered, softmax
+//             numerators, per-block sums in the spec order) -> k_loop_weights (S, isclose guard, masked weights, drift
+//             re-projection, rmse)
+//   DBSCAN    dbscan.hip
+//   ANNEAL    k_loop_cluster_* (cluster.hip) -> k_loop_decide (labels present, var = mean(stds), the annealing rule in
+//             float32 as torch evaluates it) -> k_loop_select x 6 (radix select of the k-th smallest / largest weight,
+//             11-bit digits of the order-preserving 64-bit key) -> k_loop_compact_count / k_loop_compact (the annealed set
+//             as an index list: survivors in their order, or everybody + the k best) -> k_loop_sort_chunks /
+//             k_loop_sort_rank (the duplicates in topk's output order: weight descending, index ascending)
+//   RESAMPLE  k_loop_scan (blocked prefix sums of (e * valid)[src]) -> k_loop_resample (n_set draws, exact inverse
+//             search on cdf_i = (BP_b + lp_i) / total, gathers through src)
+//
+// Spec (oracle/oracle.py OracleLoop): identical to midas_filter_step where the two overlap; ties of the top-k selection go
+// to the smaller index.
+#include "midas_internal.hpp"
+#include "midas_math.hpp"
+#include "tail_block.hpp"
+
+namespace midas {
+
+#define LAUNCH_CHECK(ctx) MIDAS_HIP_CHECK(ctx, hipGetLastError())
+
+constexpr double LOOP_ISCLOSE_ATOL = 1e-8;  // torch.isclose default atol (particle_filter.py:460-463)
+constexpr int SEL_PASSES = 6;
+constexpr int SEL_BINS = 2048;
+constexpr int SORT_CHUNK = 2048;  // (key, index) pairs sorted per workgroup in LDS
+__device__ const int kSelShift[SEL_PASSES] = {53, 42, 31, 20, 9, 0};
+__device__ const int kSelWidth[SEL_PASSES] = {11, 11, 11, 11, 11, 9};
+
+MD double lw_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+MD int lw_isum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Order-preserving 64-bit key of a weight: a < b <=> key(a) < key(b); -0.0 == +0.0; NaN above everything (torch.topk
+// treats NaN as the largest value).
+MD uint64_t weight_key(double w) {
+    if (w == 0.0) w = 0.0;  // -0.0 -> +0.0
+    if (w != w) return ~0ull;
+    const uint64_t b = (uint64_t)__double_as_longlong(w);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// ---- FRONT, second half ---------------------------------------------------------------------------------------------
+// x = scores[nn], e = exp(x - 1) (or x when the softmax is off); per 4096-slot block the sum of e in the spec order,
+// the extrema of x, the particles the prune kept, NaN among the scores.
+__global__ __launch_bounds__(256) void k_loop_xe(const int32_t* __restrict__ ctl_i, const double* __restrict__ scores,
+                                                 const int32_t* __restrict__ nn_idx, const uint8_t* __restrict__ valid,
+                                                 int32_t softmax, int32_t unit, double* __restrict__ x_out, double* __restrict__ e_out,
+                                                 double* __restrict__ bsum, double* __restrict__ bmax, double* __restrict__ bmin,
+                                                 int32_t* __restrict__ bkept, int32_t* __restrict__ bnan) {
+    __shared__ double s_gtot[16];
+    __shared__ double s_mx[4], s_mn[4];
+    __shared__ int s_k[4], s_f[4];
+    const int64_t n = ctl_i[LOOP_I_N];
+    const int blk = blockIdx.x, t = threadIdx.x;
+    const int64_t bbase = (int64_t)blk * SCAN_BLOCK;
+    if (bbase >= n) return;
+    const int64_t base = bbase + (int64_t)t * SCAN_CHUNK;
+    double v[SCAN_CHUNK];
+    double mx = -INFINITY, mn = INFINITY;
+    int kept = 0;
+    bool nan = false;
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) {
+        const int64_t i = base + j;
+        const bool in = i < n;
+        const int64_t ic = in ? i : n - 1;
+        const double xv = unit ? 1.0 : scores[nn_idx[ic]];
+        const bool ok = valid[ic] != 0;
+        const double ev = softmax ? exp(xv - 1.0) : xv;
+        if (in) { x_out[i] = xv; e_out[i] = ev; }
+        v[j] = in ? ev : 0.0;
+        mx = in && xv > mx ? xv : mx;
+        mn = in && xv < mn ? xv : mn;
+        kept += in && ok ? 1 : 0;
+        nan |= in && xv != xv;
+    }
+    const double W = block_total(v, s_gtot);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double a = __shfl_xor(mx, o), c = __shfl_xor(mn, o);
+        mx = a > mx ? a : mx;
+        mn = c < mn ? c : mn;
+    }
+    kept = lw_isum(kept);
+    const bool wnan = __any(nan);
+    if ((t & 63) == 0) { s_mx[t >> 6] = mx; s_mn[t >> 6] = mn; s_k[t >> 6] = kept; s_f[t >> 6] = wnan ? 1 : 0; }
+    __syncthreads();
+    if (t == 0) {
+        for (int w = 1; w < 4; ++w) {
+            mx = s_mx[w] > mx ? s_mx[w] : mx;
+            mn = s_mn[w] < mn ? s_mn[w] : mn;
+            kept += s_k[w];
+        }
+        const int f = s_f[0] | s_f[1] | s_f[2] | s_f[3];
+        bsum[blk] = W;
+        bmax[blk] = f ? NAN : mx;  // NaN propagates, as torch.max / torch.min do
+        bmin[blk] = f ? NAN : mn;
+        bkept[blk] = kept;
+        bnan[blk] = f;
+    }
+}
+
+// S = blocks summed in order; guard; w = (e or x) / S * valid; every particle back onto its codebook pose when all of them
+// were pruned (filter.py:176-179); block 0 finalises the control block and the rmse.
+__global__ __launch_bounds__(256) void k_loop_weights(int32_t* __restrict__ ctl_i, double* __restrict__ ctl_d,
+                                                      const double* __restrict__ bsum, const double* __restrict__ bmax,
+                                                      const double* __restrict__ bmin, const int32_t* __restrict__ bkept,
+                                                      const int32_t* __restrict__ bnan, const double* __restrict__ x,
+                                                      const double* __restrict__ e, const uint8_t* __restrict__ valid,
+                                                      const int32_t* __restrict__ nn_idx, const float* __restrict__ cb_poses,
+                                                      float* __restrict__ poses_prop, double* __restrict__ w_out,
+                                                      int32_t* __restrict__ src, const double* __restrict__ part_rmse,
+                                                      int32_t softmax) {
+    __shared__ double s_sum[LAZY_MAX_BLOCKS];
+    __shared__ double s_mx[4], s_mn[4], sa[4], sb[4];
+    __shared__ int s_k[4], s_f[4];
+    const int64_t n = ctl_i[LOOP_I_N];
+    const int blk = blockIdx.x, t = threadIdx.x;
+    const int64_t bbase = (int64_t)blk * SCAN_BLOCK;
+    if (bbase >= n && blk != 0) return;
+    const int nb = (int)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    double mx = -INFINITY, mn = INFINITY;
+    int kept = 0, f = 0;
+    bool anynan = false;
+    for (int i = t; i < nb; i += 256) {
+        s_sum[i] = bsum[i];
+        const double a = bmax[i], c = bmin[i];
+        anynan |= a != a;
+        mx = a > mx ? a : mx;
+        mn = c < mn ? c : mn;
+        kept += bkept[i];
+        f |= bnan[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double a = __shfl_xor(mx, o), c = __shfl_xor(mn, o);
+        mx = a > mx ? a : mx;
+        mn = c < mn ? c : mn;
+    }
+    kept = lw_isum(kept);
+    f = __any(f != 0 || anynan) ? 1 : 0;
+    if ((t & 63) == 0) { s_mx[t >> 6] = mx; s_mn[t >> 6] = mn; s_k[t >> 6] = kept; s_f[t >> 6] = f; }
+    __syncthreads();
+    mx = s_mx[0]; mn = s_mn[0]; kept = s_k[0]; f = s_f[0];
+    for (int w = 1; w < 4; ++w) {
+        mx = s_mx[w] > mx ? s_mx[w] : mx;
+        mn = s_mn[w] < mn ? s_mn[w] : mn;
+        kept += s_k[w];
+        f |= s_f[w];
+    }
+    if (f) { mx = NAN; mn = NAN; }
+    double S = 0.0;
+    for (int i = 0; i < nb; ++i) S = S + s_sum[i];
+    const bool close = __builtin_fabs(mx - mn) <= LOOP_ISCLOSE_ATOL;  // false on NaN
+    const bool applied = softmax != 0 && !close;
+    const double Sd = applied ? S : 1.0;
+    const bool drifted = kept == 0 && n > 0;
+#pragma unroll 4
+    for (int j = 0; j < SCAN_CHUNK; ++j) {
+        const int64_t i = bbase + (int64_t)j * 256 + t;
+        if (i < n) {
+            const double num = applied ? e[i] : x[i];
+            w_out[i] = num / Sd * (valid[i] ? 1.0 : 0.0);
+            src[i] = (int32_t)i;  // until an ANNEAL phase says otherwise the annealed set is the particle set itself
+            if (drifted) {
+                const float4* s4 = reinterpret_cast<const float4*>(cb_poses + (size_t)nn_idx[i] * 16);
+                float4* d4 = reinterpret_cast<float4*>(poses_prop + (size_t)i * 16);
+                d4[0] = s4[0]; d4[1] = s4[1]; d4[2] = s4[2]; d4[3] = s4[3];
+            }
+        }
+    }
+    if (blk != 0) return;
+    double p = 0.0, q = 0.0;
+    if (part_rmse) {
+        const int nw = (int)((n + 63) / 64);
+        for (int k = t; k < nw; k += 256) { p += part_rmse[2 * k]; q += part_rmse[2 * k + 1]; }
+        p = lw_sum(p);
+        q = lw_sum(q);
+        if ((t & 63) == 0) { sa[t >> 6] = p; sb[t >> 6] = q; }
+    }
+    __syncthreads();
+    if (t == 0) {
+        if (part_rmse) {
+            p = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+            q = (sb[0] + sb[1]) + (sb[2] + sb[3]);
+            ctl_d[LOOP_D_RMSE_T] = __builtin_sqrt(p / (double)n);
+            ctl_d[LOOP_D_RMSE_R] = __builtin_sqrt(q / (double)n);
+        }
+        ctl_d[LOOP_D_S] = Sd;
+        ctl_d[LOOP_D_XMAX] = mx;
+        ctl_d[LOOP_D_XMIN] = mn;
+        ctl_i[LOOP_I_KEPT] = kept;
+        ctl_i[LOOP_I_DRIFT] = drifted ? 1 : 0;
+        ctl_i[LOOP_I_RAW] = applied ? 0 : 1;
+        ctl_i[LOOP_I_NAN] = f;
+        ctl_i[LOOP_I_NSET] = (int32_t)n;
+        ctl_i[LOOP_I_MODE] = 0;
+        ctl_i[LOOP_I_K] = 0;
+    }
+}
+
+// ---- ANNEAL ---------------------------------------------------------------------------------------------------------
+// One workgroup: the clusters present (labels ascending) -> compact rows, var = float32 running sum of their stds / count
+// (torch.mean(cluster_stds), filter.py:189), then particle_filter.annealing's rule (:413-447) in the float32 arithmetic torch
+// uses for `var / self.particle_var`, `1.0 - ratio` and `* N`.  Also clears the select histograms.
+__global__ __launch_bounds__(256) void k_loop_decide(int32_t* __restrict__ ctl_i, double* __restrict__ ctl_d,
+                                                     const float* __restrict__ centers_all, const float* __restrict__ stds_all,
+                                                     const int64_t* __restrict__ counts_all, float* __restrict__ centers_out,
+                                                     float* __restrict__ stds_out, uint32_t* __restrict__ hist,
+                                                     int32_t* __restrict__ sel_state, int32_t floor_n) {
+    const int t = threadIdx.x;
+    for (int i = t; i < SEL_PASSES * SEL_BINS; i += 256) hist[i] = 0u;
+    for (int i = t; i < 4 * (SEL_PASSES + 2); i += 256) sel_state[i] = 0;
+    if (t != 0) return;
+    const int32_t n = ctl_i[LOOP_I_N];
+    int C = ctl_i[LOOP_I_NCL] + 1;
+    if (C > LOOP_MAX_CLUSTERS) { C = LOOP_MAX_CLUSTERS; ctl_i[LOOP_I_ERR] |= 1; }
+    int np = 0;
+    float sum = 0.f;
+    for (int c = 0; c < C; ++c) {
+        if (counts_all[c] == 0) continue;
+        for (int i = 0; i < 16; ++i) centers_out[np * 16 + i] = centers_all[c * 16 + i];
+        for (int i = 0; i < 3; ++i) {
+            const float s = stds_all[c * 3 + i];
+            stds_out[np * 3 + i] = s;
+            sum = sum + s;
+        }
+        ++np;
+    }
+    const float var = sum / (float)(3 * np);
+    ctl_i[LOOP_I_NPRES] = np;
+    ctl_d[LOOP_D_VAR] = (double)var;
+    int mode = 0, k = 0;
+    if (!ctl_i[LOOP_I_VARSET]) {  // first call: remember the variance and the particle count (:413-417)
+        ctl_d[LOOP_D_VARPREV] = (double)var;
+        ctl_i[LOOP_I_INIT] = n;
+        ctl_i[LOOP_I_VARSET] = 1;
+    } else if (var == 0.0f) {     // converged to a single pose (:418-420)
+    } else {
+        const float prev = (float)ctl_d[LOOP_D_VARPREV];
+        const float ratio = var / prev;
+        ctl_d[LOOP_D_VARPREV] = (double)var;
+        if (ratio < 1.0f) {
+            const int a = (int)((1.0f - ratio) * (float)n);
+            const int b = n - floor_n < 0 ? floor_n - n : n - floor_n;
+            k = a < b ? a : b;
+            k = k < n / 3 ? k : n / 3;
+            mode = k > 0 ? 1 : 0;
+        } else if (ratio > 1.0f) {
+            const int a = (int)((ratio - 1.0f) * (float)n);
+            k = a < n / 3 ? a : n / 3;
+            mode = (k + n > ctl_i[LOOP_I_INIT] || k <= 0) ? 0 : 2;
+        }
+        if (!mode) k = 0;
+    }
+    ctl_i[LOOP_I_MODE] = mode;
+    ctl_i[LOOP_I_K] = k;
+    ctl_i[LOOP_I_NSET] = mode == 1 ? n - k : mode == 2 ? n + k : n;
+    sel_state[0] = 0; sel_state[1] = 0; sel_state[2] = k;  // pass 0: empty prefix, rank k
+}
+
+// the selection key of particle i: ascending for a removal (k smallest weights), complemented for a duplication (k largest)
+MD uint64_t select_key(const double* __restrict__ w, int64_t i, int mode) {
+    const uint64_t key = weight_key(w[i]);
+    return mode == 2 ? ~key : key;
+}
+
+// (prefix, rank) of pass p from the histogram of pass p - 1 and its own (prefix, rank); every workgroup computes it for
+// itself, workgroup 0 also publishes it for the next pass.  state[4 * p + {0, 1, 2}] = prefix hi, prefix lo, rank.
+MD void select_advance(const uint32_t* __restrict__ hist, int32_t* __restrict__ state, int p, uint64_t& prefix, int& krem,
+                       int* s_scan) {
+    const int t = threadIdx.x;
+    prefix = ((uint64_t)(uint32_t)state[4 * (p - 1)] << 32) | (uint32_t)state[4 * (p - 1) + 1];
+    krem = state[4 * (p - 1) + 2];
+    const uint32_t* h = hist + (size_t)(p - 1) * SEL_BINS;
+    // 2048 bins, 8 per thread: the bin in which the running count reaches the rank
+    uint32_t c[8];
+    int mine = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { c[j] = h[t * 8 + j]; mine += (int)c[j]; }
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if ((t & 63) >= o) incl += v;
+    }
+    if ((t & 63) == 63) s_scan[t >> 6] = incl;
+    __syncthreads();
+    int before = incl - mine;
+    for (int w = 0; w < (t >> 6); ++w) before += s_scan[w];
+    __syncthreads();
+    if (krem > before && krem <= before + mine) {  // exactly one thread
+        int run = before, d = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (krem > run && krem <= run + (int)c[j]) { d = j; break; }
+            run += (int)c[j];
+        }
+        s_scan[4] = t * 8 + d;
+        s_scan[5] = krem - run;
+    }
+    __syncthreads();
+    const int digit = s_scan[4];
+    krem = s_scan[5];
+    prefix = (prefix << kSelWidth[p - 1]) | (uint64_t)digit;
+    __syncthreads();
+    if (blockIdx.x == 0 && t == 0) {
+        state[4 * p] = (int32_t)(uint32_t)(prefix >> 32);
+        state[4 * p + 1] = (int32_t)(uint32_t)prefix;
+        state[4 * p + 2] = krem;
+    }
+}
+
+// pass P of the radix select: histogram of digit P over the particles whose key starts with the prefix found so far
+template <int P>
+__global__ __launch_bounds__(256) void k_loop_select(const int32_t* __restrict__ ctl_i, const double* __restrict__ w,
+                                                     uint32_t* __restrict__ hist, int32_t* __restrict__ state) {
+    __shared__ uint32_t s_h[SEL_BINS];
+    __shared__ int s_scan[8];
+    const int mode = ctl_i[LOOP_I_MODE];
+    if (!mode) return;
+    const int64_t n = ctl_i[LOOP_I_N];
+    const int64_t bbase = (int64_t)blockIdx.x * SCAN_BLOCK;
+    if (bbase >= n && blockIdx.x != 0) return;
+    const int t = threadIdx.x;
+    uint64_t prefix = 0;
+    int krem = 0;
+    if (P > 0) select_advance(hist, state, P, prefix, krem, s_scan);
+    if (bbase >= n) return;
+    for (int i = t; i < SEL_BINS; i += 256) s_h[i] = 0u;
+    __syncthreads();
+    const int shift = kSelShift[P], width = kSelWidth[P];
+#pragma unroll 4
+    for (int j = 0; j < SCAN_CHUNK; ++j) {
+        const int64_t i = bbase + (int64_t)j * 256 + t;
+        if (i < n) {
+            const uint64_t key = select_key(w, i, mode);
+            const bool match = P == 0 || (key >> (shift + width)) == prefix;
+            if (match) atomicAdd(&s_h[(uint32_t)(key >> shift) & ((1u << width) - 1u)], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* h = hist + (size_t)P * SEL_BINS;
+    for (int i = t; i < SEL_BINS; i += 256)
+        if (s_h[i]) atomicAdd(&h[i], s_h[i]);
+}
+
+// per 4096-slot block: particles whose key is below the threshold key, and equal to it
+__global__ __launch_bounds__(256) void k_loop_compact_count(const int32_t* __restrict__ ctl_i, const double* __restrict__ w,
+                                                            const uint32_t* __restrict__ hist, int32_t* __restrict__ state,
+                                                            int32_t* __restrict__ c_less, int32_t* __restrict__ c_eq) {
+    __shared__ int s_scan[8];
+    __shared__ int s_a[4], s_b[4];
+    const int mode = ctl_i[LOOP_I_MODE];
+    if (!mode) return;
+    const int64_t n = ctl_i[LOOP_I_N];
+    const int64_t bbase = (int64_t)blockIdx.x * SCAN_BLOCK;
+    if (bbase >= n && blockIdx.x != 0) return;
+    const int t = threadIdx.x;
+    uint64_t T;
+    int r;
+    select_advance(hist, state, SEL_PASSES, T, r, s_scan);
+    if (bbase >= n) return;
+    int less = 0, eq = 0;
+#pragma unroll 4
+    for (int j = 0; j < SCAN_CHUNK; ++j) {
+        const int64_t i = bbase + (int64_t)j * 256 + t;
+        if (i < n) {
+            const uint64_t key = select_key(w, i, mode);
+            less += key < T ? 1 : 0;
+            eq += key == T ? 1 : 0;
+        }
+    }
+    less = lw_isum(less);
+    eq = lw_isum(eq);
+    if ((t & 63) == 0) { s_a[t >> 6] = less; s_b[t >> 6] = eq; }
+    __syncthreads();
+    if (t == 0) {
+        c_less[blockIdx.x] = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]);
+        c_eq[blockIdx.x] = (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]);
+    }
+}
+
+// The annealed set as an index list.  Selected = key < T, or key == T among the first r such particles in index order.
+// Removal: src = the unselected particles in their order.  Duplication: src[0, n) = identity, the selected particles go to
+// (sel_key, sel_idx) in index order and are put into topk's output order by the two sort kernels.
+__global__ __launch_bounds__(256) void k_loop_compact(const int32_t* __restrict__ ctl_i, const double* __restrict__ w,
+                                                      const int32_t* __restrict__ state, const int32_t* __restrict__ c_less,
+                                                      const int32_t* __restrict__ c_eq, int32_t* __restrict__ src,
+                                                      uint64_t* __restrict__ sel_key, int32_t* __restrict__ sel_idx) {
+    __shared__ int s_l[LAZY_MAX_BLOCKS], s_e[LAZY_MAX_BLOCKS];
+    __shared__ int s_wl[4], s_we[4];
+    const int mode = ctl_i[LOOP_I_MODE];
+    const int64_t n = ctl_i[LOOP_I_N];
+    const int blk = blockIdx.x, t = threadIdx.x;
+    const int64_t bbase = (int64_t)blk * SCAN_BLOCK;
+    if (bbase >= n) return;
+    const int64_t base = bbase + (int64_t)t * SCAN_CHUNK;
+    if (!mode) {  // no annealing this frame: the identity
+#pragma unroll 4
+        for (int j = 0; j < SCAN_CHUNK; ++j) {
+            const int64_t i = bbase + (int64_t)j * 256 + t;
+            if (i < n) src[i] = (int32_t)i;
+        }
+        return;
+    }
+    const uint64_t T = ((uint64_t)(uint32_t)state[4 * SEL_PASSES] << 32) | (uint32_t)state[4 * SEL_PASSES + 1];
+    const int r = state[4 * SEL_PASSES + 2];
+    for (int i = t; i < blk; i += 256) { s_l[i] = c_less[i]; s_e[i] = c_eq[i]; }
+    __syncthreads();
+    int less_before = 0, eq_before = 0;
+    for (int i = 0; i < blk; ++i) { less_before += s_l[i]; eq_before += s_e[i]; }
+    // chunk-per-thread view: flags of the own 16 slots, exclusive counts inside the block
+    unsigned lbits = 0, ebits = 0;
+    uint64_t keys[SCAN_CHUNK];
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) {
+        const int64_t i = base + j;
+        const bool in = i < n;
+        keys[j] = select_key(w, in ? i : n - 1, mode);
+        lbits |= (in && keys[j] < T) ? (1u << j) : 0u;
+        ebits |= (in && keys[j] == T) ? (1u << j) : 0u;
+    }
+    const int ml = __popc(lbits), me = __popc(ebits);
+    int il = ml, ie = me;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int a = __shfl_up(il, o), b = __shfl_up(ie, o);
+        if ((t & 63) >= o) { il += a; ie += b; }
+    }
+    if ((t & 63) == 63) { s_wl[t >> 6] = il; s_we[t >> 6] = ie; }
+    __syncthreads();
+    int lb = less_before + il - ml, eb = eq_before + ie - me;
+    for (int wv = 0; wv < (t >> 6); ++wv) { lb += s_wl[wv]; eb += s_we[wv]; }
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) {
+        const int64_t i = base + j;
+        if (i >= n) break;
+        const bool isl = (lbits >> j) & 1u, ise = (ebits >> j) & 1u;
+        const int taken_eq = eb < r ? eb : r;          // equal keys before i that were selected
+        const bool selected = isl || (ise && eb < r);
+        const int sel_before = lb + taken_eq;
+        if (mode == 1) {
+            if (!selected) src[i - sel_before] = (int32_t)i;
+        } else {
+            src[i] = (int32_t)i;
+            if (selected) { sel_key[sel_before] = keys[j]; sel_idx[sel_before] = (int32_t)i; }
+        }
+        lb += isl ? 1 : 0;
+        eb += ise ? 1 : 0;
+    }
+}
+
+// Duplication only: the k selected (key, index) pairs, key = ~weight_key (ascending = weight descending), are sorted by
+// (key, index) - torch.topk's sorted output with ties by index.  Chunks of 2048 pairs by a bitonic network in LDS ...
+MD bool pair_less(uint64_t ka, int32_t ia, uint64_t kb, int32_t ib) { return ka < kb || (ka == kb && ia < ib); }
+
+__global__ __launch_bounds__(256) void k_loop_sort_chunks(const int32_t* __restrict__ ctl_i, const uint64_t* __restrict__ key_in,
+                                                          const int32_t* __restrict__ idx_in, uint64_t* __restrict__ key_out,
+                                                          int32_t* __restrict__ idx_out) {
+    __shared__ uint64_t s_k[SORT_CHUNK];
+    __shared__ int32_t s_i[SORT_CHUNK];
+    if (ctl_i[LOOP_I_MODE] != 2) return;
+    const int k = ctl_i[LOOP_I_K];
+    const int c0 = blockIdx.x * SORT_CHUNK;
+    if (c0 >= k) return;
+    const int t = threadIdx.x;
+    for (int i = t; i < SORT_CHUNK; i += 256) {
+        const bool in = c0 + i < k;
+        s_k[i] = in ? key_in[c0 + i] : ~0ull;
+        s_i[i] = in ? idx_in[c0 + i] : 0x7fffffff;  // padding sorts behind every real pair
+    }
+    __syncthreads();
+    for (int size = 2; size <= SORT_CHUNK; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int p = t; p < SORT_CHUNK / 2; p += 256) {
+                const int lo = 2 * p - (p & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint64_t ka = s_k[lo], kb = s_k[hi];
+                const int32_t ia = s_i[lo], ib = s_i[hi];
+                const bool swap = up ? pair_less(kb, ib, ka, ia) : pair_less(ka, ia, kb, ib);
+                if (swap) { s_k[lo] = kb; s_k[hi] = ka; s_i[lo] = ib; s_i[hi] = ia; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = t; i < SORT_CHUNK; i += 256)
+        if (c0 + i < k) { key_out[c0 + i] = s_k[i]; idx_out[c0 + i] = s_i[i]; }
+}
+
+// ... then every pair finds its rank: its place in its own chunk plus, by binary search, the pairs of every other chunk
+// that precede it (all pairs are distinct).  src[n + rank] = index.
+__global__ __launch_bounds__(256) void k_loop_sort_rank(const int32_t* __restrict__ ctl_i, const uint64_t* __restrict__ key_s,
+                                                        const int32_t* __restrict__ idx_s, int32_t* __restrict__ src) {
+    if (ctl_i[LOOP_I_MODE] != 2) return;
+    const int k = ctl_i[LOOP_I_K];
+    const int64_t n = ctl_i[LOOP_I_N];
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= k) return;
+    const uint64_t key = key_s[q];
+    const int32_t idx = idx_s[q];
+    const int own = q / SORT_CHUNK, nch = (k + SORT_CHUNK - 1) / SORT_CHUNK;
+    int rank = q - own * SORT_CHUNK;
+    for (int c = 0; c < nch; ++c) {
+        if (c == own) continue;
+        int lo = c * SORT_CHUNK, hi = lo + SORT_CHUNK < k ? lo + SORT_CHUNK : k;
+        const int c0 = lo;
+        while (hi > lo) {
+            const int mid = lo + ((hi - lo) >> 1);
+            if (pair_less(key_s[mid], idx_s[mid], key, idx)) lo = mid + 1; else hi = mid;
+        }
+        rank += lo - c0;
+    }
+    src[n + rank] = idx;
+}
+
+// ---- RESAMPLE -------------------------------------------------------------------------------------------------------
+// block-local prefix of (e * valid)[src] (or x * valid when the weights are raw scores) in the spec order
+__global__ __launch_bounds__(256) void k_loop_scan(const int32_t* __restrict__ ctl_i, const double* __restrict__ x,
+                                                   const double* __restrict__ e, const uint8_t* __restrict__ valid,
+                                                   const int32_t* __restrict__ src, double* __restrict__ lp,
+                                                   double* __restrict__ btot, int32_t* __restrict__ bnan) {
+    __shared__ double s_gtot[16];
+    const int64_t n2 = ctl_i[LOOP_I_NSET];
+    const int raw = ctl_i[LOOP_I_RAW];
+    const int blk = blockIdx.x, t = threadIdx.x;
+    const int64_t base = (int64_t)blk * SCAN_BLOCK + (int64_t)t * SCAN_CHUNK;
+    if ((int64_t)blk * SCAN_BLOCK >= n2) return;
+    double v[SCAN_CHUNK];
+    bool nan = false;
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) {
+        const int64_t i = base + j;
+        const bool in = i < n2;
+        const int32_t s = src[in ? i : n2 - 1];
+        const double num = raw ? x[s] : e[s];
+        const double m = num * (valid[s] ? 1.0 : 0.0);
+        v[j] = in ? m : 0.0;
+        nan |= in && m != m;
+    }
+    const double W = block_scan(v, v, s_gtot);
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j)
+        if (base + j < n2) lp[base + j] = v[j];
+    const int f = __syncthreads_or(nan ? 1 : 0);
+    if (t == 0) { btot[blk] = W; bnan[blk] = f; }
+}
+
+struct LoopResampleArgs {
+    int32_t* ctl_i;
+    double* ctl_d;
+    const double* lp;
+    const double* btot;
+    const int32_t* bnan;
+    const int32_t* src;
+    const float* poses_prop;
+    const double* w;
+    const int32_t* nn_idx;
+    const int32_t* labels;
+    float* poses_out;
+    double* weights_out;
+    int32_t* hint_out;
+    int32_t* labels_out;
+    int32_t* ridx;
+    int32_t mode;
+    const double* u;
+    float u32;
+    uint64_t seed, step;
+    double* log;
+    const float* cluster_poses;
+    const float* cluster_stds;
+};
+
+// n_set draws over cdf_i = (BP_b + lp_i) / total (last slot 1): lower bound (multinomial) / upper bound (systematic) by
+// bisection on the exact values; the drawn particle's rows are fetched through src.  All-zero or NaN weights: the annealed
+// set goes on unresampled (particle_filter.py:240-241).
+__global__ __launch_bounds__(256) void k_loop_resample(LoopResampleArgs a) {
+    __shared__ double s_bp[LAZY_MAX_BLOCKS + 1];
+    __shared__ int s_flag;
+    const int64_t n2 = a.ctl_i[LOOP_I_NSET];
+    const int t = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * 256 + t;
+    if ((int64_t)blockIdx.x * 256 >= n2 && blockIdx.x != 0) return;
+    const int nb = (int)((n2 + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    for (int b = t; b < nb; b += 256) s_bp[b + 1] = a.btot[b];
+    if (t == 0) s_flag = 0;
+    __syncthreads();
+    int f = 0;
+    for (int b = t; b < nb; b += 256) f |= a.bnan[b];
+    if (f) s_flag = 1;
+    if (t == 0) {
+        double acc = 0.0;
+        s_bp[0] = 0.0;
+        for (int b = 0; b < nb; ++b) { const double w = s_bp[b + 1]; acc = acc + w; s_bp[b + 1] = acc; }
+    }
+    __syncthreads();
+    const double total = s_bp[nb];
+    const int status = (s_flag || total != total) ? 2 : (total == 0.0 ? 1 : 0);
+    if (i < n2) {
+        int64_t pick = i;
+        if (!status) {
+            const bool upper = a.mode == MIDAS_RESAMPLE_SYSTEMATIC;
+            double uq;
+            if (!upper) {
+                uq = a.u ? a.u[i] : philox_uniform53((uint64_t)i, a.seed, a.step);
+            } else {
+                const float r = a.u32 >= 0.0f ? a.u32 : philox_uniform24(a.seed, a.step);
+                const float off = r / (float)n2;
+                uq = (double)i / (double)n2 + (double)off;
+                uq = uq >= 1.0 ? uq - 1.0 : uq;
+            }
+            int64_t lo = 0, hi = n2;
+            while (hi > lo) {
+                const int64_t mid = lo + ((hi - lo) >> 1);
+                const double c = mid == n2 - 1 ? 1.0 : (s_bp[mid >> 12] + a.lp[mid]) / total;
+                const bool left = upper ? c <= uq : c < uq;
+                if (left) lo = mid + 1; else hi = mid;
+            }
+            pick = lo < n2 ? lo : n2 - 1;
+        }
+        a.ridx[i] = (int32_t)pick;
+        const int32_t s = a.src[pick];
+        const float4* s4 = reinterpret_cast<const float4*>(a.poses_prop + (size_t)s * 16);
+        float4* d4 = reinterpret_cast<float4*>(a.poses_out + (size_t)i * 16);
+        const float4 r0 = s4[0], r1 = s4[1], r2 = s4[2], r3 = s4[3];
+        d4[0] = r0; d4[1] = r1; d4[2] = r2; d4[3] = r3;
+        a.weights_out[i] = a.w[s];
+        a.hint_out[i] = a.nn_idx[s];
+        a.labels_out[i] = a.labels[s];
+    }
+    if (blockIdx.x == 0 && t == 0) {
+        const int32_t n = a.ctl_i[LOOP_I_N];
+        a.ctl_i[LOOP_I_STATUS] = status;
+        a.ctl_d[LOOP_D_TOTAL] = total;
+        if (a.log) {
+            double* L = a.log;
+            L[0] = (double)a.ctl_i[LOOP_I_FRAME]; L[1] = (double)n; L[2] = (double)n2;
+            L[3] = a.ctl_d[LOOP_D_RMSE_T]; L[4] = a.ctl_d[LOOP_D_RMSE_R];
+            L[5] = (double)a.ctl_i[LOOP_I_KEPT]; L[6] = (double)a.ctl_i[LOOP_I_DRIFT]; L[7] = (double)status;
+            L[8] = (double)a.ctl_i[LOOP_I_MODE]; L[9] = (double)a.ctl_i[LOOP_I_K];
+            const int np = a.ctl_i[LOOP_I_NPRES];
+            L[10] = (double)np; L[11] = a.ctl_d[LOOP_D_VAR]; L[12] = a.ctl_d[LOOP_D_S]; L[13] = (double)a.ctl_i[LOOP_I_RAW];
+            L[14] = (double)a.ctl_i[LOOP_I_NCL]; L[15] = (double)a.ctl_i[LOOP_I_ERR];
+            for (int c = 0; c < 8 && c < np; ++c) {
+                for (int k = 0; k < 16; ++k) L[16 + c * 19 + k] = (double)a.cluster_poses[c * 16 + k];
+                for (int k = 0; k < 3; ++k) L[16 + c * 19 + 16 + k] = (double)a.cluster_stds[c * 3 + k];
+            }
+        }
+        a.ctl_i[LOOP_I_FRAME] += 1;
+        a.ctl_i[LOOP_I_N] = (int32_t)n2;  // the other workgroups read LOOP_I_NSET only
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+// largest float64 t2 with sqrt(t2) <= thr (see api.hip)
+static double loop_squared_threshold(double thr) {
+    if (!(thr >= 0.0)) return -1.0;
+    if (std::isinf(thr)) return INFINITY;
+    double t = thr * thr;
+    while (std::sqrt(t) > thr) t = std::nextafter(t, 0.0);
+    while (std::sqrt(std::nextafter(t, INFINITY)) <= thr) t = std::nextafter(t, INFINITY);
+    return t;
+}
+
+struct SelectScratch {
+    uint32_t* hist;
+    int32_t *state, *c_less, *c_eq, *sel_idx, *srt_idx;
+    uint64_t *sel_key, *srt_key;
+    size_t ksel;
+};
+
+static int select_scratch(midas_ctx* ctx, int64_t cap, SelectScratch& ss) {
+    const unsigned nbcap = (unsigned)ceil_div(cap, SCAN_BLOCK);
+    ss.ksel = (size_t)cap / 3 + 1;
+    void* p;
+    int rc;
+#define SEL_SCRATCH(field, type, count)                                           \
+    if ((rc = midas_scratch(ctx, (size_t)(count) * sizeof(type), &p))) return rc; \
+    ss.field = (type*)p
+    SEL_SCRATCH(hist, uint32_t, SEL_PASSES * SEL_BINS);
+    SEL_SCRATCH(state, int32_t, 4 * (SEL_PASSES + 2));
+    SEL_SCRATCH(c_less, int32_t, nbcap);
+    SEL_SCRATCH(c_eq, int32_t, nbcap);
+    SEL_SCRATCH(sel_key, uint64_t, ss.ksel);
+    SEL_SCRATCH(sel_idx, int32_t, ss.ksel);
+    SEL_SCRATCH(srt_key, uint64_t, ss.ksel);
+    SEL_SCRATCH(srt_idx, int32_t, ss.ksel);
+#undef SEL_SCRATCH
+    return MIDAS_OK;
+}
+
+// ctl_i[N, MODE, K] and the cleared histograms / pass-0 state are in place: select, compact, order the duplicates
+static int launch_select(midas_ctx* ctx, int64_t cap, const int32_t* ci, const double* w, int32_t* src, const SelectScratch& ss) {
+    hipStream_t st = ctx->stream;
+    const unsigned nbcap = (unsigned)ceil_div(cap, SCAN_BLOCK);
+    hipLaunchKernelGGL(k_loop_select<0>, dim3(nbcap), dim3(256), 0, st, ci, w, ss.hist, ss.state);
+    hipLaunchKernelGGL(k_loop_select<1>, dim3(nbcap), dim3(256), 0, st, ci, w, ss.hist, ss.state);
+    hipLaunchKernelGGL(k_loop_select<2>, dim3(nbcap), dim3(256), 0, st, ci, w, ss.hist, ss.state);
+    hipLaunchKernelGGL(k_loop_select<3>, dim3(nbcap), dim3(256), 0, st, ci, w, ss.hist, ss.state);
+    hipLaunchKernelGGL(k_loop_select<4>, dim3(nbcap), dim3(256), 0, st, ci, w, ss.hist, ss.state);
+    hipLaunchKernelGGL(k_loop_select<5>, dim3(nbcap), dim3(256), 0, st, ci, w, ss.hist, ss.state);
+    hipLaunchKernelGGL(k_loop_compact_count, dim3(nbcap), dim3(256), 0, st, ci, w, (const uint32_t*)ss.hist, ss.state, ss.c_less,
+                       ss.c_eq);
+    hipLaunchKernelGGL(k_loop_compact, dim3(nbcap), dim3(256), 0, st, ci, w, (const int32_t*)ss.state, (const int32_t*)ss.c_less,
+                       (const int32_t*)ss.c_eq, src, ss.sel_key, ss.sel_idx);
+    hipLaunchKernelGGL(k_loop_sort_chunks, dim3((unsigned)ceil_div((int64_t)ss.ksel, SORT_CHUNK)), dim3(256), 0, st, ci,
+                       (const uint64_t*)ss.sel_key, (const int32_t*)ss.sel_idx, ss.srt_key, ss.srt_idx);
+    hipLaunchKernelGGL(k_loop_sort_rank, dim3((unsigned)ceil_div((int64_t)ss.ksel, 256)), dim3(256), 0, st, ci,
+                       (const uint64_t*)ss.srt_key, (const int32_t*)ss.srt_idx, src);
+    LAUNCH_CHECK(ctx);
+    return MIDAS_OK;
+}
+
+// a plan made by the host (the op-by-op annealing of the class surface): control block + cleared select state
+__global__ __launch_bounds__(256) void k_anneal_plan(int32_t* __restrict__ ctl_i, uint32_t* __restrict__ hist,
+                                                     int32_t* __restrict__ state, int32_t n, int32_t mode, int32_t k) {
+    const int t = threadIdx.x;
+    for (int i = t; i < SEL_PASSES * SEL_BINS; i += 256) hist[i] = 0u;
+    for (int i = t; i < 4 * (SEL_PASSES + 2); i += 256) state[i] = (i == 2) ? k : 0;
+    if (t < 32) ctl_i[t] = t == LOOP_I_N ? n : t == LOOP_I_MODE ? mode : t == LOOP_I_K ? k : 0;
+}
+
+int launch_anneal_select(midas_ctx* ctx, int64_t N, const double* w, int32_t mode, int64_t k, int32_t* src) {
+    void* ctl;
+    int rc;
+    if ((rc = midas_scratch(ctx, 32 * sizeof(int32_t), &ctl))) return rc;
+    SelectScratch ss;
+    if ((rc = select_scratch(ctx, N, ss))) return rc;
+    hipLaunchKernelGGL(k_anneal_plan, dim3(1), dim3(256), 0, ctx->stream, (int32_t*)ctl, ss.hist, ss.state, (int32_t)N, mode, (int32_t)k);
+    return launch_select(ctx, N, (const int32_t*)ctl, w, src, ss);
+}
+
+int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* t6, const midas_tree* t3,
+                     const midas_loop_args& s, int32_t phases) {
+    const int64_t cap = s.cap;
+    const unsigned nbcap = (unsigned)ceil_div(cap, SCAN_BLOCK);
+    int rc;
+    hipStream_t st = ctx->stream;
+    if (phases & MIDAS_LOOP_FRONT) {
+        ParticleUpdateArgs pa;
+        pa.N = cap;
+        pa.n_live = s.ctl_i_dev + LOOP_I_N;
+        pa.poses_in = s.poses_dev;
+        pa.poses_prop = s.poses_prop_dev;
+        pa.odom16 = s.odom16_dev;
+        pa.tn = s.tn_dev;
+        pa.rot = s.rot_dev;
+        pa.std_t = s.std_t;
+        pa.std_r = s.std_r;
+        pa.seed = s.seed;
+        pa.step = s.step;
+        pa.hint_in = s.hint_dev;
+        pa.nn_idx = s.nn_idx_dev;
+        pa.scores = nullptr;  // deferred: k_loop_xe gathers the scores
+        pa.valid = s.valid_dev;
+        pa.t2 = loop_squared_threshold(s.prune_thr);
+        pa.thr = s.prune_thr;
+        pa.vlist = (t6->vlist && t6->vlist_mesh == t3) ? (const MeshRec*)t6->vlist : nullptr;
+        pa.telemetry = (unsigned long long*)s.telemetry_dev;
+        pa.gt16 = (s.gt16_dev && s.part_rmse_dev) ? s.gt16_dev : nullptr;
+        pa.part_rmse = s.part_rmse_dev;
+        bool fused = false;
+        if (ctx->overlap)
+            if ((rc = launch_frame_front(ctx, t6, t3, pa, cb, s.code_dev, s.scores_dev, &fused))) return rc;
+        if (!fused) {
+            if ((rc = launch_score(ctx, cb, 1, s.code_dev, s.scores_dev))) return rc;
+            if ((rc = launch_particle_update(ctx, t6, t3, pa))) return rc;
+        }
+        void* p;
+        if ((rc = midas_scratch(ctx, (size_t)nbcap * (3 * sizeof(double) + 2 * sizeof(int32_t)), &p))) return rc;
+        double* bsum = (double*)p;
+        double *bmax = bsum + nbcap, *bmin = bmax + nbcap;
+        int32_t* bkept = (int32_t*)(bmin + nbcap);
+        int32_t* bnan = bkept + nbcap;
+        hipLaunchKernelGGL(k_loop_xe, dim3(nbcap), dim3(256), 0, st, (const int32_t*)s.ctl_i_dev, (const double*)s.scores_dev,
+                           (const int32_t*)s.nn_idx_dev, (const uint8_t*)s.valid_dev, s.softmax, s.unit_weights, s.x_dev, s.e_dev, bsum, bmax, bmin,
+                           bkept, bnan);
+        hipLaunchKernelGGL(k_loop_weights, dim3(nbcap), dim3(256), 0, st, s.ctl_i_dev, s.ctl_d_dev, (const double*)bsum,
+                           (const double*)bmax, (const double*)bmin, (const int32_t*)bkept, (const int32_t*)bnan,
+                           (const double*)s.x_dev, (const double*)s.e_dev, (const uint8_t*)s.valid_dev,
+                           (const int32_t*)s.nn_idx_dev, s.cb_poses_dev, s.poses_prop_dev, s.weights_dev, s.src_dev,
+                           (const double*)(pa.gt16 ? s.part_rmse_dev : nullptr), s.softmax);
+        LAUNCH_CHECK(ctx);
+    }
+    if (phases & MIDAS_LOOP_DBSCAN) {
+        if ((rc = launch_dbscan(ctx, cap, s.ctl_i_dev + LOOP_I_N, s.poses_prop_dev, s.eps, -1, s.labels_dev,
+                                s.ctl_i_dev + LOOP_I_NCL, s.ctl_i_dev + LOOP_I_ERR)))
+            return rc;
+    }
+    if (phases & MIDAS_LOOP_ANNEAL) {
+        void *part, *cen, *sd, *cnt;
+        if ((rc = midas_scratch(ctx, (size_t)ceil_div(cap, 256) * LOOP_MAX_CLUSTERS * 36 * sizeof(double), &part))) return rc;
+        if ((rc = midas_scratch(ctx, LOOP_MAX_CLUSTERS * 16 * sizeof(float), &cen))) return rc;
+        if ((rc = midas_scratch(ctx, LOOP_MAX_CLUSTERS * 3 * sizeof(float), &sd))) return rc;
+        if ((rc = midas_scratch(ctx, LOOP_MAX_CLUSTERS * sizeof(int64_t), &cnt))) return rc;
+        SelectScratch ss;
+        if ((rc = select_scratch(ctx, cap, ss))) return rc;
+        if ((rc = launch_loop_cluster(ctx, cap, s.ctl_i_dev, s.poses_prop_dev, s.weights_dev, s.labels_dev, (double*)part, (float*)cen,
+                                      (float*)sd, (int64_t*)cnt)))
+            return rc;
+        hipLaunchKernelGGL(k_loop_decide, dim3(1), dim3(256), 0, st, s.ctl_i_dev, s.ctl_d_dev, (const float*)cen, (const float*)sd,
+                           (const int64_t*)cnt, s.cluster_poses_dev, s.cluster_stds_dev, ss.hist, ss.state, s.floor);
+        if ((rc = launch_select(ctx, cap, s.ctl_i_dev, s.weights_dev, s.src_dev, ss))) return rc;
+    }
+    if (phases & MIDAS_LOOP_RESAMPLE) {
+        void *lp, *bt, *bn, *ident = nullptr;
+        if ((rc = midas_scratch(ctx, (size_t)cap * sizeof(double), &lp))) return rc;
+        if ((rc = midas_scratch(ctx, (size_t)nbcap * sizeof(double), &bt))) return rc;
+        if ((rc = midas_scratch(ctx, (size_t)nbcap * sizeof(int32_t), &bn))) return rc;
+        (void)ident;
+        hipLaunchKernelGGL(k_loop_scan, dim3(nbcap), dim3(256), 0, st, (const int32_t*)s.ctl_i_dev, (const double*)s.x_dev,
+                           (const double*)s.e_dev, (const uint8_t*)s.valid_dev, (const int32_t*)s.src_dev, (double*)lp, (double*)bt,
+                           (int32_t*)bn);
+        LoopResampleArgs r;
+        r.ctl_i = s.ctl_i_dev; r.ctl_d = s.ctl_d_dev;
+        r.lp = (const double*)lp; r.btot = (const double*)bt; r.bnan = (const int32_t*)bn;
+        r.src = s.src_dev; r.poses_prop = s.poses_prop_dev; r.w = s.weights_dev; r.nn_idx = s.nn_idx_dev; r.labels = s.labels_dev;
+        r.poses_out = s.poses_dev; r.weights_out = s.weights_out_dev; r.hint_out = s.hint_dev; r.labels_out = s.labels_out_dev;
+        r.ridx = s.ridx_dev; r.mode = s.resample_mode; r.u = s.u_dev; r.u32 = s.u32; r.seed = s.seed; r.step = s.step;
+        r.log = s.log_dev; r.cluster_poses = s.cluster_poses_dev; r.cluster_stds = s.cluster_stds_dev;
+        hipLaunchKernelGGL(k_loop_resample, dim3((unsigned)ceil_div(cap, 256)), dim3(256), 0, st, r);
+        LAUNCH_CHECK(ctx);
+    }
+    return MIDAS_OK;
+}
+
+}  // namespace midas

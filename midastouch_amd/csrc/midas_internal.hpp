@@ -310,10 +310,13 @@ int launch_loop_cluster(midas_ctx* ctx, int64_t cap, const int32_t* ctl_i, const
 // loop.hip / dbscan.hip - the reference's whole loop body on a variable-size particle set (midas_loop_step)
 int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* t6, const midas_tree* t3,
                      const midas_loop_args& a, int32_t phases);
+// src[0 .. n_set): the annealed particle set as indices - mode 1: the N particles minus the k of smallest weight, in
+// order; mode 2: all N followed by the k of largest weight, best first; ties to the smaller index
+int launch_anneal_select(midas_ctx* ctx, int64_t N, const double* w, int32_t mode, int64_t k, int32_t* src);
 // labels_out[i] in [-1, ncl) for the n = *n_dev (or N when n_dev is null) poses; min_samples < 0 -> n / 5 (cluster_particles);
-// ncl_out[0] = number of clusters, ncl_out[1] = 1 when the grid / cluster limits were exceeded
+// ncl_out[0] = number of clusters; err_out (nullable) |= 2 when the grid / cluster limits were exceeded
 int launch_dbscan(midas_ctx* ctx, int64_t cap, const int32_t* n_dev, const float* poses, double eps, int64_t min_samples,
-                  int32_t* labels_out, int32_t* ncl_out);
+                  int32_t* labels_out, int32_t* ncl_out, int32_t* err_out);
 
 // topn.hip
 int launch_topn_pose_error(midas_ctx* ctx, int32_t B, int64_t K, const double* scores, int64_t row0, int32_t n,

@@ -92,16 +92,30 @@ def step(engine: FilterEngine, odom: torch.Tensor, tactile_code: torch.Tensor, g
 # ---- the reference loop -----------------------------------------------------------------------------
 def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str = "fixed", max_frames: int = None,
            cluster: bool = True, progress: bool = False, softmax: bool = True, update_freq: int = 1, floor: int = 1000,
-           results_path: Optional[str] = None) -> dict:
+           results_path: Optional[str] = None, draws: str = "device", seed: int = 4000) -> dict:
     """Run the filter over a sequence; returns the reference's `filter_stats` dict (filter.py:99-116).
 
-    pace="fixed" steps one frame per iteration (deterministic); pace="wallclock" reproduces
-    `idx = int(frame_rate * total_time)` (:134-135): slow iterations skip frames, fast ones repeat.
-    The defaults are `filter/filter.py`'s; `filter_real(...)` below presets the real-data script's variations
-    (`filter/filter_real.py`: raw scores :208-210, measurement update every `update_freq`-th frame with unit weights
-    in between :205-212, annealing floor 10000 :228).  results_path: directory `filter_stats.npy` is written to (:252).
+    The loop body (filter.py:150-190: motionModel -> particle_rmse -> SE3_NN + get_similarity -> remove_invalid_particles
+    [-> re-projection] -> cluster_particles every 50th frame -> get_cluster_centers -> annealing -> resampler) is one
+    `LoopEngine.step` per frame: same order of operations, same guards, the particle count on the device, nothing read back
+    between frames; rmse, particle counts and cluster centres come out of the engine's frame log after the last frame.
+
+    draws="device" (default): Philox streams on the device, frames are enqueued back to back.  draws="host": the
+    reference's own random streams - torch.normal tn, rot and the resampler's torch.rand on the CPU generator, in its
+    order - which needs the particle count on the host twice per frame (bit-parity with the reference under
+    torch.manual_seed, at the price of those read-backs and of the host generator).
+    pace="fixed" steps one frame per iteration; pace="wallclock" reproduces `idx = int(frame_rate * total_time)`
+    (:134-135: slow iterations skip frames, fast ones repeat) and therefore waits for every frame.
+    The defaults are `filter/filter.py`'s; `filter_real(...)` presets the real-data script's variations
+    (`filter/filter_real.py`: raw scores :208-210, measurement update every `update_freq`-th frame with unit weights in
+    between :205-212, annealing floor 10000 :228).  results_path: directory `filter_stats.npy` is written to (:252).
     """
+    from . import _lib
+    from .loop_engine import LoopEngine
+
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if draws not in ("device", "host"):
+        raise ValueError("draws must be 'device' or 'host'")
     expt_cfg = cfg.expt
     init_particles = int(expt_cfg.params.num_particles)
     noise_ratio = expt_cfg.params.noise_ratio
@@ -113,84 +127,91 @@ def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str
     if max_frames is not None:
         traj_size = min(traj_size, max_frames)
     pf = particle_filter(cfg, seq.mesh_vertices, noise_ratio, downsample=1, device=device)
+    eng = LoopEngine(codebook, None, pf.mesh_kdtree, init_particles, sig_t=pf.motion_noise["sig_t"], sig_r=pf.motion_noise["sig_r"],
+                     pen_max=pf.pen_max, seed=seed, softmax=softmax, floor=floor, cluster=cluster, log_frames=max(traj_size + 8, 64),
+                     device=device)
+    inv_meas = torch.linalg.inv(meas_p)  # odom = inv(meas[prev]) @ meas[idx] (:154): all inverses in one call
+    eye = torch.eye(4, device=device)
     heatmap_poses, _ = codebook.get_poses()
     heatmap_embeddings = codebook.get_embeddings()
+    every_frame = pace == "wallclock" or viz is not None or progress  # somebody looks at every frame: wait for it
 
-    timer = dict.fromkeys(["tactile", "motion", "meas"], 0.0)
-    avg_timer = {"tactile": [], "motion": [], "meas": []}
     filter_stats = {
         "rmse_t": [], "rmse_r": [], "time": [], "traj_size": traj_size, "avg_time": None, "total_time": 0,
         "cluster_poses": [], "cluster_stds": [], "obj_name": seq.obj_model, "tree_size": len(codebook),
         "noise_ratio": noise_ratio, "init_noise": pf.init_noise, "init_particles": init_particles,
         "num_particles": [], "log_id": str(expt_cfg.log_id).zfill(2), "trial_id": 0,
     }
-    prev_idx, count, fixed_idx = 0, 0, 0
-    particles = None
+    motion_time = []
+    events = [torch.cuda.Event(enable_timing=True)]
+    events[0].record()
+    prev_idx, count, fixed_idx, total_time = 0, 0, 0, 0.0
     while True:
         if pace == "wallclock":
-            idx = int(frame_rate * filter_stats["total_time"])
+            idx = int(frame_rate * total_time)
         else:
             idx = fixed_idx
             fixed_idx += 1
         if idx >= traj_size:
             break
-        tactile_code = seq.codes[idx][None]
-        timer["tactile"] = 0.0  # perception is upstream of this path
-
         start = time.time()
-        if prev_idx > 0:  # (filter.py:152) - like the reference, frames seen while prev_idx == 0 re-initialise
-            odom = torch.inverse(meas_p[prev_idx, :]) @ meas_p[idx, :]
-            particles = pf.motionModel(particles, odom, multiplier=1.0)
-        else:
+        moving = prev_idx > 0
+        if not moving:  # (filter.py:152,156-160) - like the reference, frames seen while prev_idx == 0 re-initialise
             particles = pf.init_filter(gt_p[idx, :], init_particles)
-            particles.poses, _, _ = codebook.SE3_NN(particles.poses)
-        torch.cuda.synchronize(device)
-        timer["motion"] = time.time() - start
-
-        rmse_t, rmse_r = particle_rmse(particles, gt_p[idx, :])
-        filter_stats["rmse_t"].append(rmse_t.item())
-        filter_stats["rmse_r"].append(rmse_r.item())
-
-        start = time.time()
-        if count % max(int(update_freq), 1) == 0:
-            _, _, nn_tactile_codes = codebook.SE3_NN(particles.poses)
-            particles.weights = pf.get_similarity(tactile_code, nn_tactile_codes, softmax=softmax)
-        else:  # filter_real.py:211-212 (float32 ones there; float64 here so that the in-place prune keeps its dtype)
-            particles.weights = torch.ones(len(particles), device=device, dtype=torch.float64)
-        particles, drifted = pf.remove_invalid_particles(particles)
-        if drifted:
-            particles.poses, _, _ = codebook.SE3_NN(particles.poses)
-        if cluster:
-            if count % 50 == 0:
-                particles = pf.cluster_particles(particles)
-            cluster_poses, cluster_stds = pf.get_cluster_centers(particles, method="quat_avg")
-            particles = pf.annealing(particles, torch.mean(cluster_stds).cpu(), floor=floor)
+            eng.set_particles(particles.poses, reset_annealing=count == 0)
+            eng.project_to_codebook()
+            odom = eye
         else:
-            cluster_poses = torch.zeros((0, 4, 4), device=device)
-            cluster_stds = torch.zeros((0, 3), device=device)
-        particles = pf.resampler(particles)
-        torch.cuda.synchronize(device)
-        timer["meas"] = time.time() - start
-
-        filter_stats["cluster_poses"].append(cluster_poses)
-        filter_stats["cluster_stds"].append(cluster_stds)
-        filter_stats["num_particles"].append(len(particles))
-        filter_stats["time"].append(sum(timer.values()))
-        for k in timer:
-            avg_timer[k].append(timer[k])
+            odom = inv_meas[prev_idx] @ meas_p[idx, :]
+        unit = count % max(int(update_freq), 1) != 0  # filter_real.py:205-212: no measurement update on this frame
+        kw = dict(gt=gt_p[idx, :], dbscan=cluster and count % 50 == 0, unit_weights=unit, std_override=None if moving else (0.0, 0.0))
+        if draws == "host":
+            n = eng.n
+            std_t, std_r = (pf.motion_noise["sig_t"], pf.motion_noise["sig_r"]) if moving else (0.0, 0.0)
+            if moving:  # add_noise_to_odom's draws, its order (:326-335); the initial frames draw inside init_filter
+                kw["tn"] = torch.normal(mean=pf.motion_noise["mu"], std=std_t, size=(n, 3))
+                kw["rot"] = torch.normal(mean=pf.motion_noise["mu"], std=std_r, size=(n, 3))
+            else:
+                kw["tn"], kw["rot"] = torch.zeros((n, 3)), torch.zeros((n, 3))
+            eng.step(odom, seq.codes[idx], phases=_lib.LOOP_FRONT | _lib.LOOP_DBSCAN | _lib.LOOP_ANNEAL, **kw)
+            n_set = int(eng.ctl_i[_lib.LOOP_I_NSET].item())
+            eng.step(None, None, u=torch.rand(n_set, dtype=torch.float64), phases=_lib.LOOP_RESAMPLE)  # multinomial's stream
+        else:
+            eng.step(odom, seq.codes[idx], **kw)
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        events.append(ev)
+        if every_frame:
+            ev.synchronize()
+            total_time += events[-2].elapsed_time(ev) * 1e-3 if pace != "wallclock" else time.time() - start
         if viz is not None:
-            heatmap_weights = pf.get_similarity(tactile_code, heatmap_embeddings, softmax=False)
+            heatmap_weights = pf.get_similarity(seq.codes[idx][None], heatmap_embeddings, softmax=False)
+            rec = eng.frame_view()
             # the visualiser reads particles.poses asynchronously (viz/visualizer.py:329-361): hand it a snapshot
-            snap = Particles(particles.poses.clone(), particles.weights.clone(), particles.labels.clone())
-            viz.update(snap, cluster_poses, cluster_stds, gt_p[idx, :], heatmap_poses, heatmap_weights, None, None, None, idx)
+            snap = Particles(rec["poses"].clone(), rec["weights_res"].clone(), rec["labels"].clone())
+            viz.update(snap, torch.as_tensor(rec["cluster_poses"]), torch.as_tensor(rec["cluster_stds"]), gt_p[idx, :], heatmap_poses,
+                       heatmap_weights, None, None, None, idx)
         if progress:
-            print(f"[{idx}] RMSE {1000 * filter_stats['rmse_t'][-1]:.1f} mm {filter_stats['rmse_r'][-1]:.0f} deg "
-                  f"P {len(particles)} rate {1.0 / max(filter_stats['time'][-1], 1e-9):.1f} Hz")
+            rec = eng.read_log(count, count + 1)[0]
+            print(f"[{idx}] RMSE {1000 * rec['rmse_t']:.1f} mm {rec['rmse_r']:.0f} deg P {rec['n_after']} "
+                  f"rate {1.0 / max(events[-2].elapsed_time(ev) * 1e-3, 1e-9):.1f} Hz")
+        motion_time.append(time.time() - start)
         prev_idx = idx
         count += 1
-        filter_stats["total_time"] = sum(filter_stats["time"])
-    filter_stats["avg_time"] = sum(filter_stats["time"]) / max(len(filter_stats["time"]), 1)
-    filter_stats["avg_timer"] = {k: float(np.average(v)) if v else 0.0 for k, v in avg_timer.items()}
+    torch.cuda.synchronize(device)
+    for rec, e0, e1 in zip(eng.read_log(0, count), events, events[1:]):
+        filter_stats["rmse_t"].append(rec["rmse_t"])
+        filter_stats["rmse_r"].append(rec["rmse_r"])
+        filter_stats["cluster_poses"].append(torch.as_tensor(rec["cluster_poses"]))
+        filter_stats["cluster_stds"].append(torch.as_tensor(rec["cluster_stds"]))
+        filter_stats["num_particles"].append(rec["n_after"])
+        filter_stats["time"].append(e0.elapsed_time(e1) * 1e-3)  # frame to frame on the device's clock
+    filter_stats["total_time"] = sum(filter_stats["time"])
+    filter_stats["avg_time"] = filter_stats["total_time"] / max(len(filter_stats["time"]), 1)
+    # the reference's three timers: perception is upstream of this path; motion and measurement share one launch here
+    filter_stats["avg_timer"] = {"tactile": 0.0, "motion": 0.0, "meas": filter_stats["avg_time"],
+                                 "host_enqueue": float(np.average(motion_time)) if motion_time else 0.0}
+    filter_stats["frames"] = eng.read_log(0, count)
     if results_path is not None:
         save_filter_stats(filter_stats, results_path)
     return filter_stats

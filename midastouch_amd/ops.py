@@ -252,6 +252,26 @@ def cluster_centers(poses: torch.Tensor, weights: torch.Tensor, labels: torch.Te
     return centers, stds, counts
 
 
+def dbscan(poses: torch.Tensor, eps: float = 1e-2, min_samples: int = -1):
+    """cluster_particles(method="euclidean") labels (particle_filter.py:208-217): DBSCAN of the translations on the device.
+    min_samples < 0 -> N // 5.  Returns (labels int32 (N,), info int32 (2,) = [clusters, limit flag])."""
+    poses = _poses(poses)
+    labels = torch.empty(poses.shape[0], dtype=torch.int32, device=poses.device)
+    info = torch.zeros(2, dtype=torch.int32, device=poses.device)
+    _ctx(poses).call("midas_dbscan", poses.shape[0], _ptr(poses), float(eps), int(min_samples), _ptr(labels), _ptr(info))
+    return labels, info
+
+
+def anneal_select(weights: torch.Tensor, mode: int, k: int) -> torch.Tensor:
+    """Index list of the annealed particle set (particle_filter.py:421-446): mode 1 = without the k smallest weights (order
+    kept), mode 2 = everybody followed by the k largest (largest first); ties to the smaller index."""
+    w = weights.double().contiguous()
+    n = w.shape[0]
+    src = torch.empty(n + (k if mode == 2 else 0), dtype=torch.int32, device=w.device)
+    _ctx(w).call("midas_anneal_select", n, _ptr(w), int(mode), int(k), _ptr(src))
+    return src[:n - k] if mode == 1 else src
+
+
 def topn_pose_error(scores: torch.Tensor, row0: int, n: int, feat: torch.Tensor, want_idx: bool = False):
     """Per row of `scores` (B, K) f64 - row b = similarities of entry row0 + b - the best pose error among its n
     best-scoring entries, diagonal zeroed (midas_topn_pose_error; eval/single_touch_test.py:35-73)."""

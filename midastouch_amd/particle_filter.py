@@ -4,7 +4,7 @@ Same class and method names, argument meaning, return types and guard behaviour 
 `midastouch/modules/particle_filter.py` (citations below are to that file unless stated), so the
 Hydra-driven runner can import these instead.  Every arithmetic step runs in libmidas_hip.so; host
 code only draws the random numbers the reference draws (torch CPU generator, same order) and does the
-low-rate bookkeeping (DBSCAN every 50 frames, annealing counts).  No CPU fallback.
+annealing rule's three lines of scalar arithmetic.  No CPU fallback.
 """
 from __future__ import annotations
 
@@ -192,20 +192,23 @@ class particle_filter:
 
     # ---------------------------------------------------------------------------------------------
     def cluster_particles(self, _particles: Particles, method: str = "euclidean", eps: float = 1e-2) -> Particles:
-        """DBSCAN on the host every 50th frame, labels only (:208-228)."""
+        """DBSCAN labels of the particles, min_samples = N / 5 (:208-228).  "euclidean" (what the loop uses, filter.py:183)
+        runs on the device (midas_dbscan: exact float64 predicate on a uniform grid, clusters numbered by their first core
+        point like sklearn's scan) - the reference's host call takes seconds to minutes at 100k particles; "logmap" clusters
+        the 6-d SE(3) logarithms on the host through sklearn like the reference."""
+        particles = copy.copy(_particles)
+        if method == "euclidean":
+            labels, _ = ops.dbscan(particles.poses, eps)
+            particles.labels = labels.to(torch.int64)
+            return particles
+        if method != "logmap":
+            raise ValueError(method)
         from sklearn.cluster import DBSCAN
 
-        particles = copy.copy(_particles)
-        min_samples = int(len(particles) / 5)
-        if method == "euclidean":
-            data = particles.poses[:, :3, 3].cpu().numpy()
-        elif method == "logmap":
-            from .pose import se3_log
+        from .pose import se3_log
 
-            data = se3_log(particles.poses).cpu().numpy()  # [V^-1 t, omega], the embedding th.SE3.log_map gives (:219-220)
-        else:
-            raise ValueError(method)
-        clustering = DBSCAN(eps=eps, min_samples=min_samples).fit(data)
+        data = se3_log(particles.poses).cpu().numpy()  # [V^-1 t, omega], the embedding th.SE3.log_map gives (:219-220)
+        clustering = DBSCAN(eps=eps, min_samples=int(len(particles) / 5)).fit(data)
         particles.labels = torch.tensor(clustering.labels_, device=particles.labels.device)
         return particles
 
@@ -237,31 +240,39 @@ class particle_filter:
             cluster_stds[i, :] = torch.sqrt(torch.sum(((tp[:, :3, 3] - cluster_poses[i, :3, 3]) ** 2 * tw[:, None]) / tw.sum(), dim=0))
         return cluster_poses, cluster_stds
 
-    def annealing(self, _particles: Particles, var, floor: int = 1000) -> Particles:
-        """Adapt the particle count to the cluster variance (:405-447)."""
-        particles = copy.copy(_particles)
-        if torch.isinf(torch.as_tensor(self.particle_var)).all():
-            self.particle_var = var
-            self.init_particles = len(particles.weights)
-            return particles
-        if var == 0.0:
-            return particles
+    def _anneal_plan(self, n: int, var, floor: int):
+        """The rule of :413-447 as a plan (mode, k): 1 = drop the k particles of smallest weight, 2 = duplicate the k of
+        largest weight, None = leave the set alone.  `var` and `particle_var` keep whatever scalar type the caller works in
+        (the loop hands in float32 tensors, so the ratio and the counts are float32 arithmetic there)."""
+        if torch.isinf(torch.as_tensor(self.particle_var)).all():  # first frame: remember spread and size
+            self.particle_var, self.init_particles = var, n
+            return None
+        if var == 0.0:  # converged to a single pose
+            return None
         ratio = var / self.particle_var
         self.particle_var = var
-        n_particles = len(particles.weights)
-        N = particles.poses.shape[0]
         if ratio < 1:
-            num_remove = min(int((1.0 - ratio) * N), abs(n_particles - floor), n_particles // 3)
-            if not num_remove:
-                return particles
-            remove_idxs = torch.topk(particles.weights, num_remove, largest=False).indices
-            particles.remove(remove_idxs)
-        elif ratio > 1:
-            num_increase = min(int((ratio - 1.0) * N), n_particles // 3)
-            if num_increase + n_particles > self.init_particles:
-                return particles
-            add_idxs = torch.topk(particles.weights, num_increase, largest=True).indices
-            particles.add(particles.poses[add_idxs, :], particles.weights[add_idxs], particles.labels[add_idxs])
+            k = min(int((1.0 - ratio) * n), abs(n - floor), n // 3)
+            return (1, k) if k > 0 else None
+        if ratio > 1:
+            k = min(int((ratio - 1.0) * n), n // 3)
+            return (2, k) if k > 0 and k + n <= self.init_particles else None
+        return None
+
+    def annealing(self, _particles: Particles, var, floor: int = 1000) -> Particles:
+        """Adapt the particle count to the cluster spread (:405-447).  The selection runs on the device
+        (midas_anneal_select: radix select of the k-th weight, compaction of the survivors in their order or the k best
+        appended best-first; ties to the smaller index, as torch.topk resolves them on CUDA) and comes back as one index
+        list the three arrays are gathered through."""
+        particles = copy.copy(_particles)
+        plan = self._anneal_plan(len(particles.weights), var, floor)
+        if plan is None:
+            return particles
+        src = ops.anneal_select(particles.weights, *plan)
+        self.last_anneal_indices = src
+        particles.poses = ops.gather_rows(particles.poses, src)
+        particles.weights = ops.gather_rows(particles.weights, src)
+        particles.labels = ops.gather_rows(particles.labels, src)
         return particles
 
     # ---------------------------------------------------------------------------------------------

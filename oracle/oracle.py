@@ -415,10 +415,12 @@ class OracleLoop:
       resample = N' draws over the blocked CDF of (e * mask)[keep], N' = size of the annealed set; the weights that
                  travel on are e / S * mask with S the blocked sum of e over the N particles BEFORE annealing."""
 
-    def __init__(self, cb_poses, cb_embeddings, mesh_verts, pen_max=0.002, floor=1000, eps=1e-2, softmax=True, cluster=True):
+    def __init__(self, cb_poses, cb_embeddings, mesh_verts, pen_max=0.002, floor=1000, eps=1e-2, softmax=True, cluster=True,
+                 cluster_every=50):
         self.f = OracleFilter(cb_poses, cb_embeddings, mesh_verts, pen_max)
         self.annealer = Annealer()
         self.floor, self.eps, self.softmax, self.cluster = int(floor), float(eps), bool(softmax), bool(cluster)
+        self.cluster_every = int(cluster_every)
         self.count = 0
 
     def step(self, poses, labels, odom, code, tn, rot_deg, u=None, gt=None, mode="weighted_random", u32=None,
@@ -442,7 +444,7 @@ class OracleLoop:
             p1 = f.cb_poses[idx].copy()
             out["poses_prop"] = p1
         if self.cluster:
-            if self.count % 50 == 0:
+            if self.count % self.cluster_every == 0:
                 labels = dbscan(p1[:, :3, 3], self.eps, N // 5)[0]
             uniq, centers, stds = cluster_centers(p1, w, labels)
             var = cluster_var(stds)

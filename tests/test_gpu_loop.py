@@ -1,0 +1,277 @@
+"""The loop engine (midas_loop_step: the reference's whole loop body with clustering and annealing on a device-side
+particle count), device DBSCAN and the annealing selection against the oracle and the reference's fixtures."""
+import copy
+
+import numpy as np
+import pytest
+
+from _recipes import recipe_weights, sha
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda", 0)
+
+
+def _poses_of(X, dev):
+    P = torch.eye(4)[None].repeat(len(X), 1, 1).clone()
+    P[:, :3, 3] = torch.as_tensor(np.asarray(X, dtype=np.float32))
+    return P.to(dev)
+
+
+# ---- DBSCAN ---------------------------------------------------------------------------------------------------------
+def test_dbscan_matches_reference_fixture(dev, golden):
+    """cluster_particles labels written by the reference (sklearn DBSCAN, min_samples = N // 5): exact."""
+    from midastouch_amd import ops
+    g = golden("g9_dbscan")
+    for tag in ("two", "one", "noise", "three", "lattice", "eps2"):
+        X, ref = g[f"{tag}_X"], g[f"{tag}_labels"]
+        lab, info = ops.dbscan(_poses_of(X, dev), float(g[f"{tag}_eps"]))
+        assert np.array_equal(lab.cpu().numpy(), ref), tag
+        assert info.cpu().tolist() == [int(ref.max()) + 1, 0]
+
+
+@pytest.mark.parametrize("case", ["blobs_small_ms", "many_clusters", "chain", "spread20k", "dense", "single"])
+def test_dbscan_matches_oracle(dev, oracle, case):
+    from midastouch_amd import ops
+    rng = np.random.default_rng(hash(case) % 1000)
+    eps, ms = 1e-2, -1
+    if case == "blobs_small_ms":
+        X = np.concatenate([rng.normal(c, 0.004, (400, 3)) for c in ([0, 0, 0], [0.03, 0, 0], [0, 0.04, 0.01])] +
+                           [rng.uniform(-0.03, 0.07, (300, 3))])
+        ms = 25
+    elif case == "many_clusters":  # 40 tight clusters + noise: numbering by first core point, border assignment
+        cen = rng.uniform(-0.2, 0.2, (40, 3))
+        X = np.concatenate([rng.normal(c, 0.002, (60, 3)) for c in cen] + [rng.uniform(-0.25, 0.25, (400, 3))])
+        X = X[rng.permutation(len(X))]
+        ms = 12
+    elif case == "chain":  # a long thin cluster: many cells, deep union chains
+        t = rng.uniform(0, 0.5, 6000)
+        X = np.stack([t, 0.01 * np.sin(40 * t), rng.normal(0, 0.001, 6000)], axis=1)
+        ms = 30
+    elif case == "spread20k":
+        X = rng.uniform(-0.5, 0.5, (20000, 3)) * np.array([0.038, 0.089, 0.175])
+    elif case == "dense":  # everything inside a couple of cells
+        X = rng.normal(0, 0.0015, (5000, 3))
+    else:
+        X = np.zeros((1, 3))
+    X = X.astype(np.float32)
+    ref, ncl = oracle.dbscan(X, eps, len(X) // 5 if ms < 0 else ms)
+    lab, info = ops.dbscan(_poses_of(X, dev), eps, ms)
+    assert info.cpu().tolist() == [ncl, 0]
+    assert np.array_equal(lab.cpu().numpy(), ref), case
+
+
+# ---- annealing selection ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [5, 100, 4096, 4097, 10000, 100000])
+def test_anneal_select_matches_stable_argsort(dev, n):
+    from midastouch_amd import ops
+    rng = np.random.default_rng(n)
+    sets = {
+        "distinct": rng.permutation(n).astype(np.float64) + 1.0,
+        "dupes": recipe_weights(n, "dupes", 7),
+        "masked": recipe_weights(n, "masked", 9),
+        "raw": rng.uniform(-1, 1, n) * (rng.uniform(size=n) > 0.3),   # negative scores, -0.0 among the zeros
+    }
+    for tag, w in sets.items():
+        wd = torch.as_tensor(w).to(dev)
+        for k in sorted({0, 1, 2, n // 7, n // 3}):
+            if k > n // 3:
+                continue
+            rem = np.argsort(w, kind="stable")[:k]
+            keep = np.ones(n, bool)
+            keep[rem] = False
+            got = ops.anneal_select(wd, 1, k).cpu().numpy()
+            assert np.array_equal(got, np.nonzero(keep)[0]), (tag, k, "remove")
+            add = np.argsort(-w, kind="stable")[:k]
+            got = ops.anneal_select(wd, 2, k).cpu().numpy()
+            assert np.array_equal(got, np.concatenate([np.arange(n), add])), (tag, k, "add")
+
+
+def test_annealing_api_matches_reference_golden(dev, golden):
+    """particle_filter.annealing on the device selection: kept / duplicated ids of the reference's own runs (G5)."""
+    from midastouch_amd.config import load_config
+    from midastouch_amd.particle_filter import Particles, particle_filter
+    g = golden("g5_anneal")
+    for tag in ("shrink", "grow", "floor"):
+        pf = particle_filter(load_config(), np.zeros((8, 3)), 1.0, downsample=1, device=dev)
+        w = torch.as_tensor(g[f"{tag}_w0"]).to(dev)
+        n = w.shape[0]
+        ids = torch.arange(n, dtype=torch.float32, device=dev)
+        P = torch.eye(4, device=dev)[None].repeat(n, 1, 1).contiguous()
+        P[:, 0, 3] = ids
+        parts = Particles(P, w, ids.clone())
+        for i, v in enumerate(g[f"{tag}_vars"]):
+            parts = pf.annealing(parts, torch.tensor(float(v)), floor=int(g[f"{tag}_floor"]))  # float32 scalar, as the generator passed it
+            assert np.array_equal(parts.labels.cpu().numpy().astype(np.int32), g[f"{tag}_ids_{i}"]), (tag, i)
+            assert np.array_equal(parts.poses[:, 0, 3].cpu().numpy().astype(np.int32), g[f"{tag}_ids_{i}"])
+
+
+# ---- the loop engine --------------------------------------------------------------------------------------------------
+def _compare_frame(fv, ref, t, dbscan_frame):
+    n = ref["poses_prop"].shape[0]
+    assert fv["n"] == n, f"frame {t}: particle count"
+    assert np.array_equal(fv["poses_prop"].cpu().numpy(), ref["poses_prop"]), f"frame {t}: propagated poses"
+    assert np.array_equal(fv["nn_idx"].cpu().numpy(), ref["nn_idx"]), f"frame {t}: NN"
+    assert np.array_equal(fv["valid"].cpu().numpy().astype(bool), ref["mask"]), f"frame {t}: prune mask"
+    np.testing.assert_allclose(fv["weights"].cpu().numpy(), ref["weights"], rtol=1e-12, atol=0, err_msg=f"frame {t}")
+    assert fv["drifted"] == ref["drifted"]
+    if "var" in ref:
+        if dbscan_frame:
+            assert np.array_equal(fv["labels_frame"].cpu().numpy(), ref["labels_frame"]), f"frame {t}: DBSCAN labels"
+        assert fv["clusters"] == len(ref["cluster_labels"]), f"frame {t}: clusters present"
+        assert np.float32(fv["var"]) == ref["var"], f"frame {t}: mean cluster spread {fv['var']} vs {ref['var']}"
+        np.testing.assert_allclose(fv["cluster_poses"], ref["cluster_poses"][:8], atol=2e-6)
+        np.testing.assert_allclose(fv["cluster_stds"], ref["cluster_stds"][:8], rtol=1e-5, atol=1e-9)
+    assert fv["n_after"] == ref["N"], f"frame {t}: annealed size {fv['n_after']} vs {ref['N']}"
+    assert np.array_equal(fv["src"].cpu().numpy(), ref["keep"]), f"frame {t}: annealed set"
+    assert fv["status"] == ref["status"]
+    assert np.array_equal(fv["ridx"].cpu().numpy(), ref["ridx"]), f"frame {t}: resample indices"
+    assert np.array_equal(fv["poses"].cpu().numpy(), ref["poses"]), f"frame {t}: resampled poses"
+    np.testing.assert_allclose(fv["weights_res"].cpu().numpy(), ref["weights_res"], rtol=1e-12)
+    assert np.array_equal(fv["hint"].cpu().numpy(), ref["nn_idx_res"])
+    assert np.array_equal(fv["labels"].cpu().numpy(), ref["labels"]), f"frame {t}: labels carried"
+    if "rmse" in ref:
+        assert fv["rmse_t"] == pytest.approx(ref["rmse"][0], rel=1e-9)
+        assert fv["rmse_r"] == pytest.approx(ref["rmse"][1], rel=1e-6, abs=1e-6)
+
+
+@pytest.mark.parametrize("N0,mode,cluster", [(6000, "weighted_random", True), (9000, "low_var", True), (3000, "weighted_random", False)])
+def test_loop_engine_free_running_vs_oracle(dev, oracle, N0, mode, cluster):
+    """Device Philox draws, 40 frames, DBSCAN every 5th: N, annealed sets, labels, resample indices and poses identical to
+    the oracle's loop body frame after frame (nothing is teacher-forced)."""
+    from midastouch_amd.loop_engine import LoopEngine
+    from midastouch_amd.synthetic import make_codebook, make_trajectory, mesh_scale
+    K, D, T, seed = 3000, 256, 40, 4100
+    cb = make_codebook(K=K, D=D, seed=1013, mesh_points=20000)
+    traj = make_trajectory(cb, T=T + 1, seed=2013)
+    g = torch.Generator().manual_seed(11)
+    sc = mesh_scale(cb.extents)
+    tn0 = torch.normal(0.0, sc / 3.0 * 0.15, size=(N0, 3), generator=g).numpy()
+    rot0 = torch.normal(0.0, 60.0 * 0.15, size=(N0, 3), generator=g).numpy()
+    poses = oracle.init_filter_compose(traj.gt_poses[0], tn0, rot0)
+    loop = oracle.OracleLoop(cb.poses, cb.embeddings, cb.mesh_vertices, cluster=cluster, cluster_every=5)
+    poses = cb.poses[loop.f.SE3_NN_idx(poses)]
+    eng = LoopEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N0, seed=seed, resample=mode, cluster=cluster, cluster_every=5, device=dev)
+    eng.set_particles(torch.as_tensor(poses))
+    labels = np.zeros(N0, dtype=np.int64)
+    sizes = []
+    for t in range(T):
+        n = poses.shape[0]
+        tn, rot = oracle.philox_noise(n, seed, t, np.float32(2e-4), np.float32(0.5))
+        u32 = oracle.philox_uniform32(seed, t) if mode == "low_var" else None
+        ref = loop.step(poses, labels, traj.odoms[t + 1], traj.codes[t + 1], tn, rot, gt=traj.gt_poses[t + 1], mode=mode, u32=u32,
+                        draws=(lambda n2: oracle.philox_uniform64(n2, seed, t)) if mode == "weighted_random" else None)
+        eng.step(torch.as_tensor(traj.odoms[t + 1]), torch.as_tensor(traj.codes[t + 1]), gt=torch.as_tensor(traj.gt_poses[t + 1]))
+        _compare_frame(eng.frame_view(), ref, t, cluster and t % 5 == 0)
+        poses, labels = ref["poses"], ref["labels"]
+        sizes.append(ref["N"])
+    if cluster:
+        assert min(sizes) < N0 and any(b > a for a, b in zip(sizes, sizes[1:])), sizes  # removed and duplicated
+    log = eng.read_log()
+    assert [r["n_after"] for r in log] == sizes and eng.n == sizes[-1]
+
+
+def test_loop_engine_replays_reference_loop_trace(dev, golden, oracle):
+    """G13 (the reference's loop body with DBSCAN + annealing, N0 = 4096, 64 frames) with the reference's host draws in
+    its order - tn, rot, then, once the annealed size is known, the resampler's uniforms (the frame is split there).  Every
+    frame starts from the trace's own state; frames whose top-k the reference decided inside a tie follow the index
+    rule and are compared with the oracle under that rule, all others with the reference's digests too."""
+    from midastouch_amd import _lib
+    from midastouch_amd.loop_engine import LoopEngine
+    from midastouch_amd.synthetic import make_codebook, make_trajectory
+    g = golden("g13_loop_trace")
+    cb = make_codebook(K=int(g["K"]), D=int(g["D"]), seed=int(g["cb_seed"]), mesh_points=20000)
+    T, N0 = int(g["T"]), int(g["N0"])
+    traj = make_trajectory(cb, T=T + 1, seed=int(g["traj_seed"]))
+    loop = oracle.OracleLoop(cb.poses, cb.embeddings, cb.mesh_vertices)
+    eng = LoopEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N0, device=dev)
+    poses, labels = g["poses0"], np.zeros(N0, dtype=np.int64)
+    exact_frames = 0
+    for t in range(1, T + 1):
+        n = poses.shape[0]
+        eng.set_particles(torch.as_tensor(poses), torch.as_tensor(labels), reset_annealing=False)
+        eng.set_annealing_state(float(loop.annealer.particle_var), loop.annealer.init_particles or 0)
+        eng.step_count = t - 1
+        torch.manual_seed(3000 + t)
+        tn = torch.normal(mean=0.0, std=2e-4, size=(n, 3))
+        rot = torch.normal(mean=0.0, std=0.5, size=(n, 3))
+        dbs = (t - 1) % 50 == 0
+        eng.step(torch.as_tensor(traj.odoms[t]), torch.as_tensor(traj.codes[t]), gt=torch.as_tensor(traj.gt_poses[t]), tn=tn, rot=rot,
+                 dbscan=dbs, phases=_lib.LOOP_FRONT | _lib.LOOP_DBSCAN | _lib.LOOP_ANNEAL)
+        n2 = int(eng.ctl_i[_lib.LOOP_I_NSET].item())
+        u = torch.rand(n2, dtype=torch.float64)
+        eng.step(None, None, u=u, phases=_lib.LOOP_RESAMPLE)
+        tie = bool(g[f"tie_{t}"])
+        by_index = copy.deepcopy(loop)
+        ref_idx = by_index.step(poses, labels, traj.odoms[t], traj.codes[t], tn.numpy(), rot.numpy(), gt=traj.gt_poses[t], u=u.numpy())
+        assert ref_idx["N"] == n2 == int(g[f"N2_{t}"])
+        fv = eng.frame_view()
+        _compare_frame(fv, ref_idx, t, dbs)
+        if not tie:  # no tie: the reference's own digests
+            assert sha(fv["src"].cpu().numpy().astype(np.int32)) == str(g[f"keep_{t}_sha"])
+            assert sha(fv["ridx"].cpu().numpy().astype(np.int32)) == str(g[f"ridx_{t}_sha"])
+            exact_frames += 1
+        # carry on from the reference's own choice
+        ref = loop.step(poses, labels, traj.odoms[t], traj.codes[t], tn.numpy(), rot.numpy(), gt=traj.gt_poses[t], u=u.numpy(),
+                        keep_override=g[f"keep_{t}"] if tie else None)
+        assert sha(ref["ridx"].astype(np.int32)) == str(g[f"ridx_{t}_sha"])
+        poses, labels = ref["poses"], ref["labels"]
+    assert exact_frames >= 3
+
+
+def test_filter_runner_host_draws_matches_oracle_loop(dev, oracle):
+    """filter(draws="host"): the runner's orchestration (initial frames, the re-initialisation quirk of filter.py:152, odometry,
+    DBSCAN cadence, draw order on the torch CPU generator) against the oracle's loop body fed with the same draws."""
+    from midastouch_amd.config import load_config
+    from midastouch_amd.filter import filter as run_filter, synthetic_sequence
+    from midastouch_amd.particle_filter import particle_filter
+    N, T = 1500, 14
+    cfg = load_config([f"expt.params.num_particles={N}", "expt.codebook_size=2500"])
+    seq = synthetic_sequence(cfg, dev, T=T)
+    torch.manual_seed(5)
+    stats = run_filter(cfg, seq=seq, device=dev, draws="host", floor=300)
+    # the same frames on the CPU
+    cb_poses, emb = seq.codebook.poses.cpu().numpy(), seq.codebook.embeddings.cpu().numpy()
+    gt, meas, codes = seq.gt_p.cpu().numpy(), seq.meas_p.cpu().numpy(), seq.codes.cpu().numpy()
+    pf = particle_filter(cfg, seq.mesh_vertices, cfg.expt.params.noise_ratio, downsample=1, device=dev)
+    loop = oracle.OracleLoop(cb_poses, emb, seq.mesh_vertices, floor=300)
+    inv = torch.linalg.inv(seq.meas_p).cpu().numpy()
+    torch.manual_seed(5)
+    prev, poses, labels = 0, None, None
+    for idx in range(T):
+        if prev > 0:
+            n = poses.shape[0]
+            odom = (torch.as_tensor(inv[prev]).to(dev) @ seq.meas_p[idx]).cpu().numpy()
+            tn = torch.normal(mean=0.0, std=pf.motion_noise["sig_t"], size=(n, 3)).numpy()
+            rot = torch.normal(mean=0.0, std=pf.motion_noise["sig_r"], size=(n, 3)).numpy()
+        else:
+            p0 = pf.init_filter(seq.gt_p[idx], N).poses.cpu().numpy()
+            poses, labels = cb_poses[loop.f.SE3_NN_idx(p0)], np.zeros(N, dtype=np.int64)
+            odom, tn, rot = np.eye(4, dtype=np.float32), np.zeros((N, 3), np.float32), np.zeros((N, 3), np.float32)
+        r = loop.step(poses, labels, odom, codes[idx], tn, rot, gt=gt[idx], draws=lambda n2: torch.rand(n2, dtype=torch.float64).numpy())
+        assert stats["num_particles"][idx] == r["N"], idx
+        assert stats["rmse_t"][idx] == pytest.approx(r["rmse"][0], rel=1e-9), idx
+        assert len(stats["cluster_stds"][idx]) == len(r["cluster_labels"])
+        poses, labels, prev = r["poses"], r["labels"], idx
+    assert stats["frames"][-1]["n_after"] == poses.shape[0]
+
+
+def test_filter_runner_device_draws_tracks_and_anneals(dev):
+    """filter() with its default device draws: frames are enqueued back to back, the log is read once at the end."""
+    from midastouch_amd.config import load_config
+    from midastouch_amd.filter import filter as run_filter, synthetic_sequence
+    cfg = load_config(["expt.params.num_particles=20000", "expt.codebook_size=5000"])
+    seq = synthetic_sequence(cfg, dev, T=80)
+    stats = run_filter(cfg, seq=seq, device=dev)
+    assert len(stats["rmse_t"]) == 80 and np.isfinite(stats["rmse_t"]).all()
+    assert stats["rmse_t"][-1] < 0.02
+    assert min(stats["num_particles"]) >= 1000 and min(stats["num_particles"]) < 20000  # annealed
+    assert all(f["err"] == 0 for f in stats["frames"])
+    assert stats["frames"][0]["mode"] == 0 and any(f["mode"] == 1 for f in stats["frames"])
