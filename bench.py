@@ -11,12 +11,20 @@ per GPU, 50 000 x 512-d codebook.  A step = one frame of the filter loop body
 rmse epilogue), inputs (codebook, trajectory, particles) resident in HBM, random draws from the
 on-device Philox streams (real work inside the timed region).
 
+Protocol: particles start from `init_filter(gt_0, N)` (sigma_t = mesh scale / 3, sigma_r = 60 deg,
+particle_filter.py:124-145) projected onto the codebook (filter.py:159-160); the first 20 frames after that wide start are
+timed on their own (`config.diffuse_regime`: stale hints, tree-search fallbacks), then W warm-up steps, then exactly K
+timed steps enqueued by ONE C-ABI call (midas_lazy_run) between barrier + synchronize; a second pass of K steps with one
+HIP event per step gives `config.ms_per_step_median / _p95`.
+
 Single GPU: the pipelined engine - the resample + gather of frame t runs as a prologue of frame t+1's front kernel
 (a per-slot dependence), so every timed step performs one resample (the previous frame's), one propagate / NN /
-prune, one codebook scoring and one softmax / CDF pass: the same work per step, two launches instead of three, the
-resampled poses never written to HBM.  The last frame's particle set is materialised after the timed region
-(`eng.status`).  `config.steps_per_sec_materialised_every_frame` is the same engine with the particle set read
-after every frame (three launches per frame, what a caller that looks at the particles each frame gets).
+prune, one codebook scoring and one softmax / CDF pass and leaves its rmse: the same work per step, two launches instead
+of three, the resampled poses never written to HBM.  The last frame's particle set is materialised after the timed region
+(`eng.status`).  Beside the headline (the fixed-N step of SURVEY.md 8(d)) `config` carries the rates a caller sees who
+wants more per frame: `steps_per_sec_materialised_every_frame` (the particle set read after every frame, three launches)
+and `reference_loop_frames_per_sec` (midastouch_amd.filter.filter: the reference's loop with DBSCAN every 50th frame,
+cluster centres and annealing every frame on the device-side particle count, N0 = N).
 
 Multi-GPU (N>1): one filter whose particles are sharded across the ranks (N_total = gpus x 100k,
 weak scaling); per frame the ranks all_gather one small record of per-block sums / extrema and exchange the
@@ -74,10 +82,54 @@ def cpu_baseline(cb, traj, N, budget_s=12.0, max_steps=40):
         poses, _ = flt.step(poses, odoms[t], codes[t][None])
         done += 1
     dt = time.perf_counter() - t0
+    # "restructured" mode: the same frame with the data movement of this implementation - the
+    # codebook scored once per frame (K x D GEMV), one score gathered per particle - on the same threads
+    emb64 = torch.as_tensor(cb.embeddings).double()
+    nrm = emb64.norm(dim=1).clamp_min(1e-8)
+    from scipy.spatial import cKDTree
+    from oracle import oracle as orc
+    tree, mtree = flt.tree, flt.mesh_tree
+    p = poses.numpy() if torch.is_tensor(poses) else np.asarray(poses)
+    t1 = time.perf_counter()
+    done2 = 0
+    while done2 < max_steps and (time.perf_counter() - t1) < budget_s / 2:
+        t = 2 + done2 % (len(odoms) - 2)
+        tn = torch.normal(0.0, 2e-4, size=(N, 3)).numpy()
+        rot = torch.normal(0.0, 0.5, size=(N, 3)).numpy()
+        p1 = orc.propagate(p, traj.odoms[t], tn, rot)
+        idx = tree.query(orc.R3_SE3(p1), workers=-1)[1]
+        c = codes[t].double()
+        scores = (emb64 @ c) / (nrm * c.norm().clamp_min(1e-8))
+        w = torch.softmax(scores[torch.as_tensor(idx)], dim=0)
+        w = w * torch.as_tensor(mtree.query(p1[:, :3, 3].astype(np.float64), workers=-1)[0] <= 0.002)
+        p = p1[torch.multinomial(w, N, replacement=True).numpy()]
+        done2 += 1
+    dt2 = time.perf_counter() - t1
     return {"value": done / dt, "unit": "steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
             "sample": f"{done} frames of the same workload (N={N}, K={cb.K}, D={cb.D}) through the reference-shaped "
                       f"torch-CPU path (gather (N,D) f64 + cosine + softmax + multinomial; scipy cKDTree workers=-1 "
-                      f"stands in for pynanoflann n_jobs=16), {dt:.1f} s"}
+                      f"stands in for pynanoflann n_jobs=16), {dt:.1f} s",
+            "restructured_value": done2 / dt2,
+            "restructured_sample": f"{done2} frames with the codebook scored once per frame and one score gathered per "
+                                   f"particle (K x D GEMV instead of the (N,D) gather), same threads, {dt2:.1f} s"}
+
+
+def reference_loop_rate(cb, traj, N, dev, tree, mesh_tree, T=200):
+    """midastouch_amd.filter.filter - the reference's loop body with DBSCAN every 50th frame, cluster centres and annealing
+    every frame (filter/filter.py:150-190), N0 = N, device draws - over T frames of the same trajectory: frames / s after the
+    two initial frames (whose init_filter runs on the host like the reference's)."""
+    from midastouch_amd.config import load_config
+    from midastouch_amd.filter import Sequence, filter as run_filter
+
+    cfg = load_config([f"expt.params.num_particles={N}", f"expt.codebook_size={cb.K}", f"tcn.model.output_dim={cb.D}"])
+    T = min(T, traj.gt_poses.shape[0])
+    seq = Sequence(torch.as_tensor(traj.gt_poses[:T]).to(dev), torch.as_tensor(traj.meas_poses[:T]).to(dev),
+                   torch.as_tensor(traj.codes[:T]).to(dev), tree, cb.mesh_vertices, "004_sugar_box", mesh_tree=mesh_tree)
+    st = run_filter(cfg, seq, device=dev)
+    steady = st["time"][2:]
+    return {"frames_per_sec": len(steady) / sum(steady), "ms_per_frame": 1e3 * sum(steady) / len(steady), "frames": len(steady),
+            "N0": N, "N_final": st["num_particles"][-1], "N_min": min(st["num_particles"]),
+            "ms_frame_max": 1e3 * max(steady), "rmse_t_mm_final": 1e3 * st["rmse_t"][-1]}
 
 
 def main():
@@ -90,6 +142,7 @@ def main():
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-loop", action="store_true", help="skip the reference-named loop (filter() with clustering + annealing)")
     ap.add_argument("--sharded", action="store_true", help="use the particle-sharded engine even on one GPU (smoke test)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "a2a", "allgather"], help="sharded engine: form of the resample exchange")
     ap.add_argument("--eager", action="store_true", help="materialise the resampled particles every frame (three launches per frame)")
@@ -126,25 +179,23 @@ def main():
     N, K, D = args.particles, args.codebook, args.dim
     cb = make_codebook("004_sugar_box", K=K, D=D, seed=1001)
     NPROF = 50  # frames per kernel of the per-kernel timing passes; they continue the trajectory
-    T = min(args.warmup + 2 * args.steps + 4 * NPROF + 2, 1024)
+    T = min(max(args.warmup + 3 * args.steps + 4 * NPROF + 2, 202), 1024)
     traj = make_trajectory(cb, T=T, seed=2001)
 
     sharded = world > 1 or args.sharded
+    tree = None
     if not sharded:
         # pipelined: the resample of frame t runs inside the front kernel of frame t+1 (two launches per frame); the
         # particle set is materialised when it is read - here once, after the timed region (eng.status below)
+        from midastouch_amd.tactile_tree import tactile_tree
+        tree = tactile_tree(torch.as_tensor(cb.poses), torch.as_tensor(cb.cam_poses), torch.as_tensor(cb.embeddings))
+        tree.to_device(dev)  # one codebook index, shared by the engine and by the reference-named loop below
         cls = FilterEngine if args.eager else PipelinedFilterEngine
-        eng = cls(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4000, device=dev, resample=args.resample)
+        eng = cls(tree, None, cb.mesh_vertices, N, seed=4000, device=dev, resample=args.resample)
     else:
         from midastouch_amd.dist import ShardedFilterEngine
         eng = ShardedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4000, device=dev, exchange=args.exchange,
                                   resample=args.resample)
-    rng = np.random.default_rng(100 + rank)
-    # particles start on codebook poses within ~2 cm of the first ground-truth pose
-    d0 = np.linalg.norm(cb.poses[:, :3, 3] - traj.gt_poses[0][:3, 3], axis=1)
-    near = np.argsort(d0)[: max(64, K // 20)]
-    eng.set_particles(torch.as_tensor(cb.poses[rng.choice(near, N)]))
-    eng.project_to_codebook()
     odoms = torch.as_tensor(traj.odoms).to(dev)
     codes = torch.as_tensor(traj.codes).to(dev)
     gts = torch.as_tensor(traj.gt_poses).to(dev)
@@ -153,15 +204,58 @@ def main():
         t = 1 + i % (T - 1)
         eng.step(odoms[t], codes[t], gt=gts[t])
 
-    for i in range(args.warmup):
-        frame(i)
+    def frames(i0, n):
+        """n consecutive frames starting at trajectory position i0; one C-ABI call where the engine has one"""
+        t0_ = 1 + i0 % (T - 1)
+        if hasattr(eng, "run") and not args.eager and t0_ + n <= T:
+            return eng.run(odoms[t0_:t0_ + n], codes[t0_:t0_ + n], gts[t0_:t0_ + n])
+        for i in range(n):
+            frame(i0 + i)
+        return None
+
+    # start: init_filter(gt_0, N) - sigma_t = mesh scale / 3, sigma_r = 60 deg (particle_filter.py:124-145) - projected onto
+    # the codebook (filter.py:159-160); sharded runs draw every rank's slice from its own seed
+    from midastouch_amd.synthetic import mesh_scale
+    from scipy.spatial.transform import Rotation
+
+    def wide_init(seed):
+        g = torch.Generator().manual_seed(seed)
+        tn0 = torch.normal(0.0, mesh_scale(cb.extents) / 3.0, size=(N, 3), generator=g)
+        rn0 = torch.normal(0.0, 60.0, size=(N, 3), generator=g)
+        Tn = torch.zeros((N, 4, 4))
+        Tn[:, :3, :3] = torch.as_tensor(Rotation.from_euler("zyx", rn0.numpy(), degrees=True).as_matrix()).float()
+        Tn[:, :3, 3], Tn[:, 3, 3] = tn0, 1.0
+        eng.set_particles(torch.as_tensor(traj.gt_poses[0])[None] @ Tn)
+        eng.project_to_codebook()
+
+    wide_init(100 + rank)
+    frames(0, 2)  # library load, allocator, first-touch: not part of any figure
+    torch.cuda.synchronize()
+    diffuse = None
+    if not sharded:  # the first frames after a wide start: hints are stale, the cloud covers the whole object
+        wide_init(200 + rank)
+        tele0 = eng.telemetry.cpu().numpy().copy()
+        ND = 20
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(ND + 1)]
+        evs[0].record()
+        for i in range(ND):
+            frame(i)
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        dms = [evs[i].elapsed_time(evs[i + 1]) for i in range(ND)]
+        tele1 = eng.telemetry.cpu().numpy()
+        diffuse = {"frames": ND, "ms_per_step_mean": float(np.mean(dms)), "ms_first_frame": dms[0], "ms_per_step_max": float(np.max(dms)),
+                   "steps_per_sec": 1e3 / float(np.mean(dms)),
+                   "tree_search_fallbacks_per_frame": {"nn": float(tele1[0] - tele0[0]) / ND, "prune": float(tele1[1] - tele0[1]) / ND},
+                   "note": "per-step HIP events (one step per call), frames 1..20 after init_filter(gt_0, N) + projection"}
+        wide_init(100 + rank)
+    frames(0, args.warmup)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        frame(args.warmup + i)
+    run_log = frames(args.warmup, args.steps)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -183,8 +277,32 @@ def main():
             eng.flush()
         torch.cuda.synchronize()
         eager_rate = args.steps / (time.perf_counter() - t1)
+    # per-step distribution inside the timed call, from the device clock each frame leaves in the run's log
+    run_stats = None
+    if run_log is not None and args.steps > 1:
+        ts = run_log[:, 2].cpu().numpy()
+        d = np.diff(ts) * 1e-3
+        run_stats = {"ms_per_step_median": float(np.median(d)), "ms_per_step_p95": float(np.percentile(d, 95)), "ms_per_step_max": float(d.max()),
+                     "slowest_step": int(d.argmax()) + 1, "device_span_ms": float(ts[-1] - ts[0]) * 1e-3,
+                     "note": "device wall clock at the end of each frame of the timed midas_lazy_run call"}
+    # per-step distribution: the same K steps again, one HIP event after each (one step per call)
+    step_stats = None
+    if not sharded:
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        evs[0].record()
+        for i in range(args.steps):
+            frame(args.warmup + 2 * args.steps + i)
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        per_step = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)])
+        step_stats = {"ms_per_step_median": float(np.median(per_step)), "ms_per_step_p95": float(np.percentile(per_step, 95)),
+                      "ms_per_step_min": float(per_step.min()), "ms_per_step_max": float(per_step.max())}
+    # the reference-named loop (clustering + annealing every frame, device-side particle count) on the same workload
+    loop_rate = None
+    if not sharded and not args.no_loop:
+        loop_rate = reference_loop_rate(cb, traj, N, dev, tree, eng.tree3)
     tele = (eng.st.telemetry if sharded else eng.telemetry).cpu().numpy().tolist()
-    frames_run = args.warmup + args.steps * (2 if eager_rate else 1)
+    frames_run = 2 + (40 if diffuse else 0) + args.warmup + args.steps * (3 if eager_rate else 1)
 
     ab = algorithmic_bytes(N, K, D)
     out = {
@@ -199,7 +317,11 @@ def main():
                    "engine": ("sharded, exchange=" + eng.exchange) if sharded else ("eager: 3 launches/frame" if args.eager else
                                                         "pipelined: resample of frame t folded into the front kernel of frame t+1, 2 launches/frame"),
                    "arith": "f32 poses/NN, f64 scores/weights/CDF", "last_status": status,
+                   "init": "init_filter(gt_0, N) (sigma_t = mesh scale / 3, sigma_r = 60 deg) projected onto the codebook",
+                   "timed_region": "K steps by one midas_lazy_run call" if hasattr(eng, "run") and not args.eager else "K step() calls",
                    "steps_per_sec_materialised_every_frame": eager_rate,
+                   "reference_loop_frames_per_sec": loop_rate,
+                   "per_step": step_stats, "per_step_in_timed_call": run_stats, "diffuse_regime": diffuse,
                    "tree_search_fallbacks_per_frame": {"nn": tele[0] / frames_run, "prune": tele[1] / frames_run}},
     }
 
@@ -207,7 +329,7 @@ def main():
     if not sharded and not args.no_profile:
         # one kernel bracketed at a time (two events per frame) so the others run back to back
         names = ["score_codebook", "particle_update", "tail_a", "tail_b"]
-        per, fi = {}, args.warmup + 2 * args.steps
+        per, fi = {}, args.warmup + 3 * args.steps
         for slot, name in enumerate(names):
             eng.profile(True, only_slot=slot)
             eng.profile_read(reset=True)

@@ -246,6 +246,15 @@ typedef struct midas_lazy_args {
 } midas_lazy_args;
 int midas_lazy_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
                     const midas_lazy_args* args);
+/* T consecutive frames of midas_lazy_step enqueued by one call (device Philox draws): frame f takes odom16_dev + 16 f,
+ * code_dev + D f and (when given) gt16_dev + 16 f, alternates the two buffer sets of `first` (frame 0 uses first's own
+ * assignment, frame 1 the swapped one, ...) and folds the resample of the frame before it; rmse_log_dev (NULL or 3 T
+ * doubles) receives every frame's {rmse_t, rmse_r, device wall clock in us at the end of the frame}.  The reference's loop body is called once per sensor frame
+ * (filter/filter.py:131-233); replaying a recorded sequence needs no host turn-around between frames.  After the call the
+ * latest frame's buffers are first's (poses_prop, nn_idx, status) when T is even, its *_prev ones when T is odd. */
+int midas_lazy_run(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
+                   const midas_lazy_args* first, int32_t T, double* rmse_log_dev);
+
 typedef struct midas_lazy_flush_args {
     int64_t N;
     const double* tables_dev;          /* the frame's tables, valid mask, NN indices, propagated poses (midas_lazy_step) */

@@ -191,6 +191,7 @@ SIGNATURES = {
     "midas_filter_step": (C.c_int, [_P, _P, _P, _P, C.POINTER(StepArgs)]),
     "midas_filter_step_batch": (C.c_int, [_P, _P, _P, _P, C.POINTER(StepArgs), _I32]),
     "midas_lazy_step": (C.c_int, [_P, _P, _P, _P, C.POINTER(LazyArgs)]),
+    "midas_lazy_run": (C.c_int, [_P, _P, _P, _P, C.POINTER(LazyArgs), _I32, _P]),
     "midas_lazy_flush": (C.c_int, [_P, C.POINTER(LazyFlushArgs)]),
     "midas_loop_step": (C.c_int, [_P, _P, _P, _P, C.POINTER(LoopArgs), _I32]),
     "midas_dbscan": (C.c_int, [_P, _I64, _P, _D, _I64, _P, _P]),

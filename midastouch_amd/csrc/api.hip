@@ -543,11 +543,48 @@ static TailTables tables_of(double* t, int64_t N) {
     return tb;
 }
 
+static int lazy_step_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
+                          const midas_lazy_args& s, double* rmse_out);
+
 MIDAS_EXPORT int midas_lazy_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
                                  const midas_lazy_args* args) {
     MIDAS_ENTER(ctx);
     MIDAS_REQUIRE(ctx, cb && tree6 && tree3 && args && tree6->dim == 6 && tree3->dim == 3 && tree6->K == cb->K);
-    const midas_lazy_args& s = *args;
+    return lazy_step_impl(ctx, cb, tree6, tree3, *args, nullptr);
+}
+
+MIDAS_EXPORT int midas_lazy_run(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
+                                const midas_lazy_args* first, int32_t T, double* rmse_log_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, cb && tree6 && tree3 && first && tree6->dim == 6 && tree3->dim == 3 && tree6->K == cb->K && T >= 1);
+    MIDAS_REQUIRE(ctx, first->poses_prop_prev_dev && first->nn_idx_prev_dev && first->status_prev_dev && !first->tn_dev &&
+                           !first->rot_dev && !first->u_prev_dev);
+    MIDAS_REQUIRE(ctx, !rmse_log_dev || (first->gt16_dev && first->part_rmse_dev));
+    midas_lazy_args a = *first;
+    for (int32_t f = 0; f < T; ++f) {
+        int rc = f ? scratch_reset(ctx) : MIDAS_OK;  // frames are ordered on the stream: each may reuse the scratch
+        if (rc) return rc;
+        rc = lazy_step_impl(ctx, cb, tree6, tree3, a, rmse_log_dev ? rmse_log_dev + 3 * f : nullptr);
+        if (rc) return rc;
+        // next frame: the buffer sets swap, the resample of this frame is folded in, the inputs advance
+        float* pp = const_cast<float*>(a.poses_prop_prev_dev);
+        int32_t* np = const_cast<int32_t*>(a.nn_idx_prev_dev);
+        int32_t* sp = const_cast<int32_t*>(a.status_prev_dev);
+        a.poses_prop_prev_dev = a.poses_prop_dev; a.nn_idx_prev_dev = a.nn_idx_dev; a.status_prev_dev = a.status_dev;
+        a.poses_prop_dev = pp; a.nn_idx_dev = np; a.status_dev = sp;
+        a.resample_prev = 1;
+        a.u32_prev = -1.0f;
+        a.step_prev = a.step;
+        a.step += 1;
+        a.odom16_dev += 16;
+        a.code_dev += cb->D;
+        if (a.gt16_dev) a.gt16_dev += 16;
+    }
+    return MIDAS_OK;
+}
+
+static int lazy_step_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
+                          const midas_lazy_args& s, double* rmse_out) {
     MIDAS_REQUIRE(ctx, s.N > 0 && ceil_div(s.N, SCAN_BLOCK) <= LAZY_MAX_BLOCKS && s.poses_prop_dev && s.nn_idx_dev && s.valid_dev &&
                            s.status_dev && s.tables_dev && (uintptr_t)s.tables_dev % 128 == 0 && s.scores_dev && s.odom16_dev && s.code_dev);
     MIDAS_REQUIRE(ctx, s.resample_prev ? (s.poses_prop_prev_dev && s.nn_idx_prev_dev && s.status_prev_dev &&
@@ -603,7 +640,9 @@ MIDAS_EXPORT int midas_lazy_step(midas_ctx* ctx, const midas_codebook* cb, const
     if (!launched)
         return midas_set_error(ctx, MIDAS_ERR_INVALID, "codebook", "the pipelined step needs a float32 codebook with D in {128,256,512,1024}");
     prof_mark(ctx, 2);
-    if ((rc = launch_tail_a2(ctx, N, s.scores_dev, s.nn_idx_dev, s.valid_dev, s.softmax, tb, s.status_dev, 1, 0, true))) return rc;
+    if ((rc = launch_tail_a2(ctx, N, s.scores_dev, s.nn_idx_dev, s.valid_dev, s.softmax, tb, s.status_dev, 1, 0, true,
+                             pa.gt16 ? s.part_rmse_dev : nullptr, rmse_out)))
+        return rc;
     prof_mark(ctx, 3);
     if (ctx->prof && ctx->ev_ready) {
         const int lo = ctx->prof_only >= 0 ? ctx->prof_only : 1, hi = ctx->prof_only >= 0 ? ctx->prof_only + 1 : 3;

@@ -185,12 +185,22 @@ MD void cluster_finish_body(int nblocks, int C, int c, const double* __restrict_
                             float* __restrict__ stds, int64_t* __restrict__ counts, double* s_m) {
     const int t = threadIdx.x;
     if (t < CL_MOM) {
+        // blocks in order; eight partials are fetched together (independent loads), then added one after the other
         double r = part[(size_t)c * CL_MOM + t];
-        for (int b = 1; b < nblocks; ++b) {
-            const double x = part[((size_t)b * C + c) * CL_MOM + t];
-            if (t == M_WMAX) r = x > r ? x : r;
-            else if (t == M_WMIN) r = x < r ? x : r;
-            else r = r + x;
+        for (int b0 = 1; b0 < nblocks; b0 += 8) {
+            double x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int b = b0 + j < nblocks ? b0 + j : nblocks - 1;
+                x[j] = part[((size_t)b * C + c) * CL_MOM + t];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (b0 + j >= nblocks) break;
+                if (t == M_WMAX) r = x[j] > r ? x[j] : r;
+                else if (t == M_WMIN) r = x[j] < r ? x[j] : r;
+                else r = r + x[j];
+            }
         }
         s_m[t] = r;
     }

@@ -37,6 +37,7 @@ struct DbGrid {         // written by k_db_setup
     int32_t ms;         // min_samples
     int32_t nroots;
     int32_t err;
+    int32_t nwork;      // points whose core test needs distances
 };
 
 struct DbArgs {
@@ -57,6 +58,7 @@ struct DbArgs {
     uint8_t* s_core;        // [N] by sorted position
     int32_t* parent;        // [N] by particle (core points only)
     int32_t* roots;         // [DB_MAXROOTS + 1]
+    int32_t* work;          // [N] sorted positions whose core test needs distances
     int32_t* labels;        // [N] out
     int32_t* ncl_out;       // out: number of clusters
     int32_t* err_out;       // nullable: |= 2 on a limit
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(64) void k_db_setup(DbArgs a, int nblocks) {
     g.ms = a.min_samples < 0 ? (int32_t)(n / 5) : (int32_t)a.min_samples;
     g.nroots = 0;
     g.err = err;
+    g.nwork = 0;
     *a.grid = g;
 }
 
@@ -221,34 +224,60 @@ __device__ __forceinline__ void db_for_cells(const DbGrid& g, int c, bool own, F
             }
 }
 
-// core <=> at least min_samples points within eps (itself included)
+// core <=> at least min_samples points within eps (itself included).  Pass 1, one thread per point, decides what needs no
+// distance: the own cell alone reaches min_samples (all of it is within eps), or the 125 cells together cannot.  The rest
+// goes to a worklist.
 __global__ __launch_bounds__(256) void k_db_core(DbArgs a) {
-    const DbGrid g = *a.grid;
+    DbGrid* gp = a.grid;
+    const DbGrid g = *gp;
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= g.n) return;
     const float4 me = a.s_pt[p];
     const int c = __float_as_int(me.w);
-    int cnt = a.cell_start[c + 1] - a.cell_start[c];  // the own cell: all within eps
-    bool core = cnt >= g.ms;
-    if (!core) {
+    const int cnt = a.cell_start[c + 1] - a.cell_start[c];
+    int state = cnt >= g.ms ? 1 : 0;  // 1 core, 0 not core, 2 undecided
+    if (!state) {
         int upper = cnt;
         db_for_cells(g, c, false, [&](int c2) { upper += a.cell_start[c2 + 1] - a.cell_start[c2]; return false; });
-        if (upper >= g.ms) {
-            db_for_cells(g, c, false, [&](int c2) {
-                const int e = a.cell_start[c2 + 1];
-                for (int q = a.cell_start[c2]; q < e; ++q) {
-                    cnt += db_within(me, a.s_pt[q], a.r2) ? 1 : 0;
-                    if (cnt >= g.ms) return true;
-                }
-                return false;
-            });
-            core = cnt >= g.ms;
+        if (upper >= g.ms) state = 2;
+    }
+    const int32_t orig = a.s_orig[p];
+    a.parent[orig] = orig;
+    if (state == 2) {
+        a.work[atomicAdd(&gp->nwork, 1)] = (int32_t)p;
+        return;
+    }
+    a.s_core[p] = (uint8_t)state;
+    if (state) atomicMin(&a.cell_rep[c], orig);
+}
+
+// Pass 2, one wave per undecided point: the lanes share the candidates of each cell (coalesced), the count stops at
+// min_samples.
+__global__ __launch_bounds__(256) void k_db_core_count(DbArgs a) {
+    const DbGrid g = *a.grid;
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * 256) >> 6);
+    for (int wi = wave; wi < g.nwork; wi += nwaves) {
+        const int32_t p = a.work[wi];
+        const float4 me = a.s_pt[p];
+        const int c = __float_as_int(me.w);
+        int cnt = a.cell_start[c + 1] - a.cell_start[c];
+        db_for_cells(g, c, false, [&](int c2) {
+            const int e = a.cell_start[c2 + 1];
+            for (int q0 = a.cell_start[c2]; q0 < e; q0 += 64) {
+                const int q = q0 + lane;
+                const bool in = q < e && db_within(me, a.s_pt[q < e ? q : e - 1], a.r2);
+                cnt += __popcll(__ballot(in));
+                if (cnt >= g.ms) return true;
+            }
+            return false;
+        });
+        if (lane == 0) {
+            const bool core = cnt >= g.ms;
+            a.s_core[p] = core ? 1 : 0;
+            if (core) atomicMin(&a.cell_rep[c], a.s_orig[p]);
         }
     }
-    a.s_core[p] = core ? 1 : 0;
-    const int32_t orig = a.s_orig[p];
-    if (core) atomicMin(&a.cell_rep[c], orig);
-    a.parent[orig] = orig;
 }
 
 __device__ __forceinline__ int32_t db_find(int32_t* parent, int32_t i) {
@@ -393,6 +422,7 @@ int launch_dbscan(midas_ctx* ctx, int64_t cap, const int32_t* n_dev, const float
     DB_SCRATCH(s_core, uint8_t, cap);
     DB_SCRATCH(parent, int32_t, cap);
     DB_SCRATCH(roots, int32_t, DB_MAXROOTS + 1);
+    DB_SCRATCH(work, int32_t, cap);
 #undef DB_SCRATCH
     const unsigned gp = (unsigned)ceil_div(cap, 256);
     MIDAS_HIP_CHECK(ctx, hipMemsetAsync(a.cell_count, 0, (size_t)DB_MAXCELLS * sizeof(int32_t), st));
@@ -402,6 +432,7 @@ int launch_dbscan(midas_ctx* ctx, int64_t cap, const int32_t* n_dev, const float
     hipLaunchKernelGGL(k_db_scan, dim3(1), dim3(1024), 0, st, a);
     hipLaunchKernelGGL(k_db_scatter, dim3(gp), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_db_core, dim3(gp), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_db_core_count, dim3(gp < 2048 ? gp : 2048), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_db_clique, dim3(gp), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_db_link, dim3(gp), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_db_roots, dim3(gp), dim3(256), 0, st, a);

@@ -70,25 +70,57 @@ __global__ __launch_bounds__(256) void k_loop_xe(const int32_t* __restrict__ ctl
     const int64_t bbase = (int64_t)blk * SCAN_BLOCK;
     if (bbase >= n) return;
     const int64_t base = bbase + (int64_t)t * SCAN_CHUNK;
+    // batched, unconditional loads on clamped indices (a branch around a load makes hipcc wait for each one in turn)
     double v[SCAN_CHUNK];
+    int32_t nn[SCAN_CHUNK];
+    unsigned okbits = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) {
+        const int64_t ic = base + j < n ? base + j : n - 1;
+        nn[j] = nn_idx[ic];
+        okbits |= valid[ic] != 0 ? (1u << j) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) v[j] = unit ? 1.0 : scores[nn[j]];
     double mx = -INFINITY, mn = INFINITY;
     int kept = 0;
     bool nan = false;
 #pragma unroll
     for (int j = 0; j < SCAN_CHUNK; ++j) {
-        const int64_t i = base + j;
-        const bool in = i < n;
-        const int64_t ic = in ? i : n - 1;
-        const double xv = unit ? 1.0 : scores[nn_idx[ic]];
-        const bool ok = valid[ic] != 0;
-        const double ev = softmax ? exp(xv - 1.0) : xv;
-        if (in) { x_out[i] = xv; e_out[i] = ev; }
-        v[j] = in ? ev : 0.0;
+        const bool in = base + j < n;
+        const double xv = v[j];
         mx = in && xv > mx ? xv : mx;
         mn = in && xv < mn ? xv : mn;
-        kept += in && ok ? 1 : 0;
+        kept += in && ((okbits >> j) & 1u) ? 1 : 0;
         nan |= in && xv != xv;
     }
+    if (base + SCAN_CHUNK <= n) {
+        double2* o2 = reinterpret_cast<double2*>(x_out + base);
+#pragma unroll
+        for (int j = 0; j < SCAN_CHUNK / 2; ++j) o2[j] = make_double2(v[2 * j], v[2 * j + 1]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < SCAN_CHUNK; ++j)
+            if (base + j < n) x_out[base + j] = v[j];
+    }
+    if (softmax) {
+#pragma unroll
+        for (int j = 0; j < SCAN_CHUNK; ++j) {
+            v[j] = exp(v[j] - 1.0);
+            __builtin_amdgcn_sched_barrier(0);  // one exponential at a time (registers)
+        }
+    }
+    if (base + SCAN_CHUNK <= n) {
+        double2* o2 = reinterpret_cast<double2*>(e_out + base);
+#pragma unroll
+        for (int j = 0; j < SCAN_CHUNK / 2; ++j) o2[j] = make_double2(v[2 * j], v[2 * j + 1]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < SCAN_CHUNK; ++j)
+            if (base + j < n) e_out[base + j] = v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) v[j] = base + j < n ? v[j] : 0.0;
     const double W = block_total(v, s_gtot);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -470,7 +502,7 @@ __global__ __launch_bounds__(256) void k_loop_compact(const int32_t* __restrict_
 // (key, index) - torch.topk's sorted output with ties by index.  Chunks of 2048 pairs by a bitonic network in LDS ...
 MD bool pair_less(uint64_t ka, int32_t ia, uint64_t kb, int32_t ib) { return ka < kb || (ka == kb && ia < ib); }
 
-__global__ __launch_bounds__(256) void k_loop_sort_chunks(const int32_t* __restrict__ ctl_i, const uint64_t* __restrict__ key_in,
+__global__ __launch_bounds__(1024) void k_loop_sort_chunks(const int32_t* __restrict__ ctl_i, const uint64_t* __restrict__ key_in,
                                                           const int32_t* __restrict__ idx_in, uint64_t* __restrict__ key_out,
                                                           int32_t* __restrict__ idx_out) {
     __shared__ uint64_t s_k[SORT_CHUNK];
@@ -480,7 +512,7 @@ __global__ __launch_bounds__(256) void k_loop_sort_chunks(const int32_t* __restr
     const int c0 = blockIdx.x * SORT_CHUNK;
     if (c0 >= k) return;
     const int t = threadIdx.x;
-    for (int i = t; i < SORT_CHUNK; i += 256) {
+    for (int i = t; i < SORT_CHUNK; i += 1024) {
         const bool in = c0 + i < k;
         s_k[i] = in ? key_in[c0 + i] : ~0ull;
         s_i[i] = in ? idx_in[c0 + i] : 0x7fffffff;  // padding sorts behind every real pair
@@ -488,7 +520,7 @@ __global__ __launch_bounds__(256) void k_loop_sort_chunks(const int32_t* __restr
     __syncthreads();
     for (int size = 2; size <= SORT_CHUNK; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int p = t; p < SORT_CHUNK / 2; p += 256) {
+            for (int p = t; p < SORT_CHUNK / 2; p += 1024) {
                 const int lo = 2 * p - (p & (stride - 1)), hi = lo + stride;
                 const bool up = (lo & size) == 0;
                 const uint64_t ka = s_k[lo], kb = s_k[hi];
@@ -499,7 +531,7 @@ __global__ __launch_bounds__(256) void k_loop_sort_chunks(const int32_t* __restr
             __syncthreads();
         }
     }
-    for (int i = t; i < SORT_CHUNK; i += 256)
+    for (int i = t; i < SORT_CHUNK; i += 1024)
         if (c0 + i < k) { key_out[c0 + i] = s_k[i]; idx_out[c0 + i] = s_i[i]; }
 }
 
@@ -718,7 +750,7 @@ static int launch_select(midas_ctx* ctx, int64_t cap, const int32_t* ci, const d
                        ss.c_eq);
     hipLaunchKernelGGL(k_loop_compact, dim3(nbcap), dim3(256), 0, st, ci, w, (const int32_t*)ss.state, (const int32_t*)ss.c_less,
                        (const int32_t*)ss.c_eq, src, ss.sel_key, ss.sel_idx);
-    hipLaunchKernelGGL(k_loop_sort_chunks, dim3((unsigned)ceil_div((int64_t)ss.ksel, SORT_CHUNK)), dim3(256), 0, st, ci,
+    hipLaunchKernelGGL(k_loop_sort_chunks, dim3((unsigned)ceil_div((int64_t)ss.ksel, SORT_CHUNK)), dim3(1024), 0, st, ci,
                        (const uint64_t*)ss.sel_key, (const int32_t*)ss.sel_idx, ss.srt_key, ss.srt_idx);
     hipLaunchKernelGGL(k_loop_sort_rank, dim3((unsigned)ceil_div((int64_t)ss.ksel, 256)), dim3(256), 0, st, ci,
                        (const uint64_t*)ss.srt_key, (const int32_t*)ss.srt_idx, src);

@@ -1702,7 +1702,9 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
     // round, two trips) 8 %, at N = 1M 7 %: there the single kernel stays.
     // MIDAS_SPLIT_FRONT = 0 never, 2 always with 4 lanes per particle, 3 always with 2.
     static const int split_env = getenv("MIDAS_SPLIT_FRONT") ? atoi(getenv("MIDAS_SPLIT_FRONT")) : 1;
-    const bool split_front = split_env >= 2 || (split_env == 1 && ((a.rs.enabled && a.N <= 65536) || a.N <= 2048));
+    // a live count in device memory (loop engine): the set shrinks within a few frames of annealing, so the two-kernel form
+    // whatever the capacity
+    const bool split_front = split_env >= 2 || (split_env == 1 && ((a.rs.enabled && a.N <= 65536) || a.N <= 2048 || a.n_live));
     const int lpp = split_env == 3 ? 2 : 4;
     if (split_front && !(a.ablate & 7)) {
         void* feat;

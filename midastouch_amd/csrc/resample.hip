@@ -502,18 +502,36 @@ __global__ __launch_bounds__(256) void k_tail_a2(int64_t N, const double* __rest
 // trips fewer on a latency-bound kernel).  Single trajectory, N >= 16; MIDAS_TAIL_DIRECT=0 selects k_tail_a2.
 __global__ __launch_bounds__(256) void k_tail_a2d(int64_t N, const double* __restrict__ scores, const int32_t* __restrict__ nn_idx,
                                                   const uint8_t* __restrict__ valid, int32_t softmax, TailTables tb, bool padded,
-                                                  int32_t* __restrict__ status, double* __restrict__ flags_out) {
+                                                  int32_t* __restrict__ status, double* __restrict__ flags_out,
+                                                  const double* __restrict__ part_rmse, int nrm, double* __restrict__ rmse_out) {
     __shared__ double s_gtot[16];
     __shared__ double s_red[24];
     int kept = 0;
     bool nan = false;
     tail_a_direct(N, (int)blockIdx.x, scores, nn_idx, valid, softmax, tb, padded, s_gtot, s_red, kept, nan);
-    if (threadIdx.x == 0) {
+    const int t = threadIdx.x;
+    if (t == 0) {
         if (nan) atomicOr(&status[0], 2);
         if (kept) atomicAdd(&status[1], kept);
         if (flags_out) {  // sharded exchange record: NaN marker (any non-zero) and kept count (exact: integers far below 2^53)
             if (nan) atomicAdd(&flags_out[0], 1.0);
             if (kept) atomicAdd(&flags_out[1], (double)kept);
+        }
+    }
+    if (rmse_out && blockIdx.x == 0) {  // the frame's rmse from the front kernel's per-wave sums (same order as k_tail_b2)
+        double p = 0.0, q = 0.0;
+        for (int k = t; k < nrm; k += 256) { p += part_rmse[2 * k]; q += part_rmse[2 * k + 1]; }
+        p = wsum(p);
+        q = wsum(q);
+        __syncthreads();
+        if ((t & 63) == 0) { s_red[t >> 6] = p; s_red[4 + (t >> 6)] = q; }
+        __syncthreads();
+        if (t == 0) {
+            p = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+            q = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+            rmse_out[0] = __builtin_sqrt(p / (double)N);
+            rmse_out[1] = __builtin_sqrt(q / (double)N);
+            rmse_out[2] = (double)wall_clock64() * 0.01;  // device wall clock (100 MHz) in us: where this frame ended
         }
     }
 }
@@ -1456,7 +1474,7 @@ int launch_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores, const i
         TailTables t = tb;
         t.bsum_e = r1; t.btot = r1 + nb; t.btot_raw = r1 + 2 * nb; t.bmax = r1 + 3 * nb; t.bmin = r1 + 4 * nb;
         hipLaunchKernelGGL(k_tail_a2d, dim3((unsigned)nb), dim3(256), 0, ctx->stream, N, scores, nn_idx, valid, softmax, t, true,
-                           status, r1 + 5 * nb);
+                           status, r1 + 5 * nb, (const double*)nullptr, 0, (double*)nullptr);
         LAUNCH_CHECK(ctx);
         return MIDAS_OK;
     }
@@ -1484,12 +1502,14 @@ int debug_tb2_clocks(long long* out16) { return hipMemcpyFromSymbol(out16, HIP_S
 #endif
 
 int launch_tail_a2(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
-                   int32_t softmax, const TailTables& tb, int32_t* status, int batch, int64_t score_stride, bool padded_tables) {
+                   int32_t softmax, const TailTables& tb, int32_t* status, int batch, int64_t score_stride, bool padded_tables,
+                   const double* part_rmse, double* rmse_out) {
     const int nb = (int)ceil_div(N, SCAN_BLOCK);
     static const bool direct = !(getenv("MIDAS_TAIL_DIRECT") && atoi(getenv("MIDAS_TAIL_DIRECT")) == 0);
     if (direct && batch <= 1 && N >= SCAN_CHUNK) {
         hipLaunchKernelGGL(k_tail_a2d, dim3((unsigned)nb), dim3(256), 0, ctx->stream, N, scores, nn_idx, valid, softmax, tb,
-                           padded_tables, status, (double*)nullptr);
+                           padded_tables, status, (double*)nullptr, part_rmse, particle_update_blocks(N),
+                           part_rmse ? rmse_out : (double*)nullptr);
         LAUNCH_CHECK(ctx);
         return MIDAS_OK;
     }

@@ -44,12 +44,17 @@ class FilterEngine:
         self.ctx = _lib.context(dev)
         self.device = self.ctx.device
         f32 = dict(dtype=torch.float32, device=self.device)
-        self.cb_poses = torch.as_tensor(cb_poses).to(**f32).contiguous()
-        self.cb_feat = ops.se3_feature(self.cb_poses)
-        self.tree6 = ops.Tree(self.cb_feat)
-        self.codebook = ops.Codebook(torch.as_tensor(cb_embeddings).to(self.device))
-        self.tree3 = ops.Tree(torch.as_tensor(mesh_vertices).to(self.device, torch.float64))
-        self.tree6.attach_mesh(self.tree3, self.cb_poses)
+        if hasattr(cb_poses, "SE3_NN") and cb_embeddings is None:  # a tactile_tree already on the device: share its index
+            tt = cb_poses
+            self.cb_poses, self.cb_feat, self.tree6, self.codebook = tt.poses, tt.logmap_pose, tt.tree, tt.codebook
+        else:
+            self.cb_poses = torch.as_tensor(cb_poses).to(**f32).contiguous()
+            self.cb_feat = ops.se3_feature(self.cb_poses)
+            self.tree6 = ops.Tree(self.cb_feat)
+            self.codebook = ops.Codebook(torch.as_tensor(cb_embeddings).to(self.device))
+        self.tree3 = mesh_vertices if isinstance(mesh_vertices, ops.Tree) else ops.Tree(torch.as_tensor(mesh_vertices).to(self.device, torch.float64))
+        if getattr(self.tree6, "_mesh", None) is not self.tree3:
+            self.tree6.attach_mesh(self.tree3, self.cb_poses)
         self.K, self.D = self.codebook.K, self.codebook.D
         self.sig_t, self.sig_r, self.pen_max = float(sig_t), float(sig_r), float(pen_max)
         self.seed, self.softmax = int(seed), bool(softmax)
@@ -258,6 +263,48 @@ class PipelinedFilterEngine(FilterEngine):
         self._had_gt = gt is not None
         self._pending, self._flushed, self._cur = True, False, nxt
         self.step_count += 1
+
+    def run(self, odoms, codes, gts=None):
+        """T frames by ONE C-ABI call (midas_lazy_run; device draws): odoms (T,4,4) f32, codes (T,D) f64, gts (T,4,4) f32 or
+        None.  Returns the (T,3) float64 device tensor of per-frame {rmse_t, rmse_r, device clock in us at the frame's end}
+        when gts is given.  Equivalent to T
+        calls of step() - same kernels, same results - without the per-frame turn-around through Python."""
+        d = self.device
+        T = int(torch.as_tensor(odoms).shape[0])
+        odoms = operand(odoms, "odoms", torch.float32, (T, 4, 4), d)
+        codes = operand(codes, "tactile codes", torch.float64, (T, self.D), d)
+        gts = operand(gts, "gt poses", torch.float32, (T, 4, 4), d)
+        cur, nxt = self._cur, self._cur ^ 1
+        fold = self._pending and not self._flushed
+        a = LazyArgs()
+        a.N = self.N
+        a.poses_prop_prev, a.nn_idx_prev, a.status_prev = _ptr(self._prop[cur]), _ptr(self._nn[cur]), _ptr(self._st[cur])
+        a.poses_prop, a.nn_idx, a.valid, a.status = _ptr(self._prop[nxt]), _ptr(self._nn[nxt]), _ptr(self._valid), _ptr(self._st[nxt])
+        a.tables, a.scores = _ptr(self._tables), _ptr(self._scores)
+        a.part_rmse = _ptr(self._part_rmse) if gts is not None else None
+        a.resample_prev = int(fold)
+        a.poses_in = _ptr(self._poses)
+        a.hint_in = _ptr(self._hint) if self.use_hint else None
+        pu, pu32, pstep = self._draw
+        if pu is not None:
+            raise MidasError("run() continues with device draws: the pending frame was stepped with host uniforms - flush() first")
+        a.resample_mode, a.u_prev, a.u32_prev, a.step_prev = self.mode, None, float(pu32), int(pstep)
+        a.ridx = None
+        a.odom16, a.code, a.gt16 = _ptr(odoms), _ptr(codes), _ptr(gts)
+        a.std_t, a.std_r = self.sig_t, self.sig_r
+        a.seed, a.step = self.seed, self.step_count
+        a.prune_thr, a.softmax = self.pen_max, int(self.softmax)
+        a.telemetry = _ptr(self.telemetry)
+        log = torch.zeros((T, 3), dtype=torch.float64, device=d) if gts is not None else None
+        self._keep = (odoms, codes, gts, log)
+        self.ctx.bind_current_stream()
+        self.ctx.check(self.ctx.lib.midas_lazy_run(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h, C.byref(a), T, _ptr(log)))
+        self.step_count += T
+        self._draw = (None, -1.0, self.step_count - 1)
+        self._had_gt = gts is not None
+        self._pending, self._flushed = True, False
+        self._cur = nxt if T % 2 else cur
+        return log
 
     def flush(self):
         """Materialise the latest frame's resample (poses, weights, weights_res, hint, ridx, status, rmse)."""

@@ -38,6 +38,7 @@ class Sequence:
     codebook: tactile_tree
     mesh_vertices: np.ndarray
     obj_model: str
+    mesh_tree: Optional[object] = None  # an ops.Tree over mesh_vertices already on the device (shared with other engines)
 
 
 def synthetic_sequence(cfg, device, T: int = 100, D: Optional[int] = None, seed: int = 0) -> Sequence:
@@ -127,10 +128,15 @@ def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str
     if max_frames is not None:
         traj_size = min(traj_size, max_frames)
     pf = particle_filter(cfg, seq.mesh_vertices, noise_ratio, downsample=1, device=device)
+    if seq.mesh_tree is not None:
+        pf._mesh_tree = seq.mesh_tree
     eng = LoopEngine(codebook, None, pf.mesh_kdtree, init_particles, sig_t=pf.motion_noise["sig_t"], sig_r=pf.motion_noise["sig_r"],
                      pen_max=pf.pen_max, seed=seed, softmax=softmax, floor=floor, cluster=cluster, log_frames=max(traj_size + 8, 64),
                      device=device)
-    inv_meas = torch.linalg.inv(meas_p)  # odom = inv(meas[prev]) @ meas[idx] (:154): all inverses in one call
+    # odom = inv(meas[prev]) @ meas[idx] (:154): the inverses in one call, and - frame after frame in fixed pace - the
+    # products too (a 4x4 product per frame through the BLAS library costs more device time than the whole frame's kernels)
+    inv_meas = torch.linalg.inv(meas_p)
+    step_odoms = torch.matmul(inv_meas[:-1], meas_p[1:]).contiguous() if meas_p.shape[0] > 1 else None
     eye = torch.eye(4, device=device)
     heatmap_poses, _ = codebook.get_poses()
     heatmap_embeddings = codebook.get_embeddings()
@@ -162,7 +168,7 @@ def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str
             eng.project_to_codebook()
             odom = eye
         else:
-            odom = inv_meas[prev_idx] @ meas_p[idx, :]
+            odom = step_odoms[prev_idx] if idx == prev_idx + 1 else inv_meas[prev_idx] @ meas_p[idx, :]
         unit = count % max(int(update_freq), 1) != 0  # filter_real.py:205-212: no measurement update on this frame
         kw = dict(gt=gt_p[idx, :], dbscan=cluster and count % 50 == 0, unit_weights=unit, std_override=None if moving else (0.0, 0.0))
         if draws == "host":

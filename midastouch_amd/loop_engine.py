@@ -44,7 +44,8 @@ class LoopEngine:
             self.tree6 = ops.Tree(self.cb_feat)
             self.codebook = ops.Codebook(torch.as_tensor(cb_embeddings).to(d))
         self.tree3 = mesh_vertices if isinstance(mesh_vertices, ops.Tree) else ops.Tree(torch.as_tensor(mesh_vertices).to(d, torch.float64))
-        self.tree6.attach_mesh(self.tree3, self.cb_poses)
+        if getattr(self.tree6, "_mesh", None) is not self.tree3:  # vertex lists of this mesh not yet on the codebook index
+            self.tree6.attach_mesh(self.tree3, self.cb_poses)
         self.K, self.D = self.codebook.K, self.codebook.D
         self.sig_t, self.sig_r, self.pen_max = float(sig_t), float(sig_r), float(pen_max)
         self.seed, self.softmax, self.floor, self.eps = int(seed), bool(softmax), int(floor), float(eps)

@@ -146,3 +146,38 @@ def test_edge_particle_counts(dev, oracle, N, cls_name):
             assert np.array_equal(eng.poses.cpu().numpy(), ref["poses"]), f"frame {t}"
             np.testing.assert_allclose(eng.weights.cpu().numpy(), ref["weights"], rtol=1e-12, atol=0)
         poses = ref["poses"]
+
+
+def test_run_equals_stepping(dev):
+    """midas_lazy_run (T frames by one call) == T calls of midas_lazy_step: bit-identical particle set, per-frame rmse."""
+    from midastouch_amd.engine import PipelinedFilterEngine
+    from midastouch_amd.synthetic import make_codebook, make_trajectory
+    N, K, D, T = 5000, 4000, 256, 23
+    cb = make_codebook(K=K, D=D, seed=1000)
+    traj = make_trajectory(cb, T=T + 6, seed=2000)
+    rng = np.random.default_rng(3)
+    p0 = torch.as_tensor(cb.poses[rng.integers(0, K, N)])
+    odoms, codes, gts = (torch.as_tensor(x).to(dev) for x in (traj.odoms, traj.codes, traj.gt_poses))
+    a = PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4000, device=dev)
+    b = PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4000, device=dev)
+    a.set_particles(p0)
+    b.set_particles(p0)
+    rm = []
+    for t in range(1, 1 + T + 4):
+        a.step(odoms[t], codes[t], gt=gts[t])
+        if t in (3, 10):
+            rm.append(a.rmse.clone())  # materialises: the next frame starts unfolded, as run() must handle too
+    # b: three frames stepped, a flush, then runs of odd and even length, then single steps again
+    for t in (1, 2, 3):
+        b.step(odoms[t], codes[t], gt=gts[t])
+    assert torch.equal(b.rmse, rm[0])
+    log1 = b.run(odoms[4:11], codes[4:11], gts[4:11])          # 7 frames (odd)
+    assert torch.equal(b.rmse, rm[1]) and torch.equal(log1[-1, :2], rm[1])
+    assert (log1[1:, 2] > log1[:-1, 2]).all()  # device clock at the end of each frame
+    log2 = b.run(odoms[11:1 + T], codes[11:1 + T], gts[11:1 + T])  # even
+    for t in range(1 + T, 1 + T + 4):
+        b.step(odoms[t], codes[t], gt=gts[t])
+    assert b.step_count == a.step_count
+    for name in ("poses", "weights", "weights_res", "ridx", "hint", "rmse"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert torch.isfinite(log2).all() and log2.shape == (T - 10, 3)
