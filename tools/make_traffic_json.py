@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r01_traffic.json from a tools/pmc_traffic.sh output directory.
+"""profiles/r02_traffic.json from a tools/pmc_traffic.sh output directory.
 
 usage: tools/make_traffic_json.py gpurun_out/pmc_<tag> [out.json]
 HBM bytes per launch: fetch = FETCH_SIZE (KiB) * 1024 * 2 (gfx950's rocprofv3 tallies 128-B requests at 64 B,
@@ -9,7 +9,7 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 d = sys.argv[1]
-out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_traffic.json")
+out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_traffic.json")
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
