@@ -324,6 +324,9 @@ def main():
                    "engine": ("sharded, exchange=" + eng.exchange) if sharded else ("eager: 3 launches/frame" if args.eager else
                                                         "pipelined: resample of frame t folded into the front kernel of frame t+1, 2 launches/frame"),
                    "arith": "f32 poses/NN, f64 scores/weights/CDF", "last_status": status,
+                   "scoring": ("sparse: the particle kernels score only the codebook rows that are some particle's nearest entry "
+                               "(same arithmetic, same scores); %d distinct rows in the last frame" % int(torch.unique(eng.nn_idx).numel()))
+                   if getattr(eng, "sparse_scores", False) else "dense: all K rows every frame",
                    "init": "init_filter(gt_0, N) (sigma_t = mesh scale / 3, sigma_r = 60 deg) projected onto the codebook",
                    "timed_region": "K steps by one midas_lazy_run call" if hasattr(eng, "run") and not args.eager else "K step() calls",
                    "steps_per_sec_materialised_every_frame": eager_rate,
@@ -378,7 +381,11 @@ def main():
                            "algorithmic_bytes_per_launch": ab[dom], "kernel_ms": groups[dom],
                            "per_kernel_ms": per, "event_pair_overhead_ms": overhead,
                            "step_bytes": ab["step"],
-                           "step_frac": ab["step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                           "step_frac": ab["step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "note": "achieved = SURVEY.md 8(d) algorithmic bytes (which charge all K rows of the codebook to every "
+                                   "step) / kernel time; with sparse scoring the kernel touches only the rows in use, so `traffic` "
+                                   "(PMC) is BELOW the algorithmic bytes and the kernel is bound by the dependent-fetch chain of a "
+                                   "particle wave, not by bandwidth (DESIGN.md section 4)"}
     if sharded:
         # no per-kernel event passes in the sharded frame: the step-level figure per GPU (each rank moves the algorithmic
         # bytes of its own N particles and of the whole replicated codebook every frame)

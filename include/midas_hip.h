@@ -195,6 +195,11 @@ typedef struct midas_step_args {
     int32_t resample_mode;
     int32_t* status_dev;         /* [0] cdf status (see midas_cdf), [1] particles kept by the prune */
     uint64_t* telemetry_dev;     /* NULL or 16 cumulative counters: [0],[1] particles whose NN / prune needed the tree search; [2..15] scan statistics and phase clocks (MIDAS_ABLATE=4) */
+    uint32_t* score_stamps_dev;  /* NULL: every codebook row is scored every frame.  Else K uint32 stamps, zeroed once by the caller, together with
+                                    * score_epoch (non-zero, different on every frame that uses these stamps): only the rows that are
+                                    * some particle's nearest entry are scored - by the particle kernels themselves, same arithmetic,
+                                    * same scores; scores_dev then holds the frame's scores at those rows only */
+    uint32_t score_epoch;
 } midas_step_args;
 
 int midas_filter_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
@@ -243,6 +248,8 @@ typedef struct midas_lazy_args {
     double prune_thr;
     int32_t softmax;
     uint64_t* telemetry_dev;           /* NULL or 16 cumulative counters (see midas_step_args) */
+    uint32_t* score_stamps_dev;        /* sparse scoring, see midas_step_args (midas_lazy_run advances the epoch by one per frame) */
+    uint32_t score_epoch;
 } midas_lazy_args;
 int midas_lazy_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
                     const midas_lazy_args* args);
@@ -474,6 +481,8 @@ typedef struct midas_loop_args {
     int32_t unit_weights;          /* 1: a frame without measurement update - every particle scores 1, so the weights are the
                                     * prune mask (filter/filter_real.py:205-212, `update_freq`) */
     uint64_t* telemetry_dev;       /* NULL or 16 counters (see midas_step_args) */
+    uint32_t* score_stamps_dev;    /* sparse scoring, see midas_step_args */
+    uint32_t score_epoch;
 } midas_loop_args;
 int midas_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
                     const midas_loop_args* args, int32_t phases);

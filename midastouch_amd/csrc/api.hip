@@ -450,6 +450,7 @@ static int filter_step_impl(midas_ctx* ctx, const midas_codebook* cb, const mida
     pa.part_min = (double*)pmin;
     pa.gt16 = prm ? s.gt16_dev : nullptr;
     pa.part_rmse = (double*)prm;
+    if (B == 1 && s.score_stamps_dev && s.score_epoch) { pa.sp.stamps = s.score_stamps_dev; pa.sp.epoch = s.score_epoch; }
     bool defer = false;
     if (B == 1 && ctx->overlap) {
         prof_mark(ctx, 1);  // fused front: reported in the particle_update slot, the score slot stays empty
@@ -475,6 +476,7 @@ static int filter_step_impl(midas_ctx* ctx, const midas_codebook* cb, const mida
                        : launch_score(ctx, cb, B, s.code_dev, (double*)scores)))
             return rc;
         prof_mark(ctx, 1);
+        pa.sp.stamps = nullptr;  // scored densely just above
         if ((rc = launch_particle_update(ctx, tree6, tree3, pa))) return rc;
     }
     prof_mark(ctx, 2);
@@ -576,6 +578,7 @@ MIDAS_EXPORT int midas_lazy_run(midas_ctx* ctx, const midas_codebook* cb, const 
         a.u32_prev = -1.0f;
         a.step_prev = a.step;
         a.step += 1;
+        if (a.score_stamps_dev) a.score_epoch = a.score_epoch + 1 ? a.score_epoch + 1 : 1;  // never 0
         a.odom16_dev += 16;
         a.code_dev += cb->D;
         if (a.gt16_dev) a.gt16_dev += 16;
@@ -617,6 +620,7 @@ static int lazy_step_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_
     pa.status_reset = s.status_dev;
     pa.gt16 = (s.gt16_dev && s.part_rmse_dev) ? s.gt16_dev : nullptr;
     pa.part_rmse = s.part_rmse_dev;
+    if (s.score_stamps_dev && s.score_epoch) { pa.sp.stamps = s.score_stamps_dev; pa.sp.epoch = s.score_epoch; }
     if (s.resample_prev) {
         LazyResample& r = pa.rs;
         r.enabled = true;

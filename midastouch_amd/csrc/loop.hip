@@ -806,11 +806,13 @@ int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree*
         pa.telemetry = (unsigned long long*)s.telemetry_dev;
         pa.gt16 = (s.gt16_dev && s.part_rmse_dev) ? s.gt16_dev : nullptr;
         pa.part_rmse = s.part_rmse_dev;
+        if (s.score_stamps_dev && s.score_epoch) { pa.sp.stamps = s.score_stamps_dev; pa.sp.epoch = s.score_epoch; }
         bool fused = false;
         if (ctx->overlap)
             if ((rc = launch_frame_front(ctx, t6, t3, pa, cb, s.code_dev, s.scores_dev, &fused))) return rc;
         if (!fused) {
             if ((rc = launch_score(ctx, cb, 1, s.code_dev, s.scores_dev))) return rc;
+            pa.sp.stamps = nullptr;  // scored densely just above
             if ((rc = launch_particle_update(ctx, t6, t3, pa))) return rc;
         }
         void* p;

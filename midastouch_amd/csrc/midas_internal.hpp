@@ -192,6 +192,17 @@ struct LazyResample {
     uint64_t seed, step;                                             // Philox key / counter of the previous frame's draws
 };
 
+// sparse scoring inside the particle kernels (score_body.hpp score_claimed_rows)
+struct SparseScore {
+    uint32_t* stamps = nullptr;   // [K] epoch of the last frame that scored row k (nullptr: dense scoring)
+    uint32_t epoch = 0;
+    const float* emb = nullptr;
+    const double* norms = nullptr;
+    const double* code = nullptr;
+    double* scores = nullptr;
+    int nj = 0;                   // D / 64
+};
+
 struct ParticleUpdateArgs {
     int64_t N;
     const float* poses_in;
@@ -224,6 +235,7 @@ struct ParticleUpdateArgs {
     int32_t* status_reset = nullptr;          // nullable: status[0..1] zeroed here for the tail kernels' atomics
     double* flags_reset = nullptr;            // nullable: two float64 counters zeroed here (sharded exchange record)
     LazyResample rs;                          // fused front only
+    SparseScore sp;                           // stamps != nullptr: only the rows that are some particle's nearest entry are scored
 };
 int particle_update_blocks(int64_t N);
 int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t3, const ParticleUpdateArgs& a,

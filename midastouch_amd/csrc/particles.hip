@@ -1299,6 +1299,7 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
             if (lane == 0 && m) atomicAdd(&a.telemetry[0], (unsigned long long)__popcll(m));
         }
     }
+    if (a.sp.stamps) score_claimed_rows_nj(a.sp, live, bi);  // the first particle of the frame on an entry has it scored
     // prune: valid <=> some mesh vertex within sqrt(t2) of the particle
     double q3[3] = {(double)R[3], (double)R[7], (double)R[11]};
     double best = a.t2;
@@ -1554,6 +1555,7 @@ __global__ __launch_bounds__(256, MIDAS_NNP_OCC) void k_particle_nn_prune(TreeVi
         if (lane == 0 && m) atomicAdd(&a.telemetry[0], (unsigned long long)__popcll(m));
     }
     const int32_t nn = (int32_t)dpp_u32<BC_FIRST>((uint32_t)(int32_t)bi);
+    if (a.sp.stamps) score_claimed_rows_nj(a.sp, owner && live, nn);
     // ---- prune: header + records 1 .. 16 of the entry's vertex list in one round trip ----
     const float* pr = a.poses_prop + pc * 16;
     const double q3[3] = {(double)pr[3], (double)pr[7], (double)pr[11]};
@@ -1693,7 +1695,10 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
     a.ablate = ablate;
     a.scores = nullptr;  // deferred: the tail gathers the scores
     const int nwaves = particle_update_blocks(a.N), n_pu = (nwaves + 3) / 4;
-    const unsigned grid = (unsigned)(n_pu + ceil_div(cb->K, 16));
+    if (a.sp.stamps) {  // sparse scoring: the particle waves score the rows they need, no streaming workgroups
+        a.sp.emb = (const float*)cb->emb; a.sp.norms = cb->norms; a.sp.code = code; a.sp.scores = scores; a.sp.nj = cb->D / 64;
+    }
+    const unsigned grid = (unsigned)(n_pu + (a.sp.stamps ? 0 : ceil_div(cb->K, 16)));
     const float* emb = (const float*)cb->emb;
     // Two-kernel form (group-parallel list scans, see k_particle_nn_prune) while its N/16 waves fit the chip at once (4 waves
     // per SIMD at 112 registers = 65536 particles with four lanes each).  Measured at K = 50k, D = 512 the pipelined frame

@@ -79,4 +79,76 @@ MD void score_wave(const T* __restrict__ emb, const double* __restrict__ norms, 
     }
 }
 
+// ---- sparse scoring inside the particle kernels ----------------------------------------------------------------
+// cos(code, C_k) is only ever read at k = nearest entry of some particle (modules/particle_filter.py:449-457 scores the
+// gathered rows; the dense pass over all K rows is this implementation's restructuring of it).  Once the cloud has
+// gathered, a few hundred of the K rows are anybody's nearest entry: scoring exactly those reads 10^5 bytes instead of
+// 10^8.  `want` = this lane holds a live particle whose nearest entry is `row`.  One lane per distinct row of the wave
+// exchanges the row's stamp with the frame's epoch; whoever finds an older stamp is the first of the whole frame to need
+// the row and has the wave score it - four rows at a time in score_wave's layout (quarter-wave per row, lane s owns floats
+// [64 j + 4 s, + 4) for ascending j, xor butterfly), so every score is bit-identical to the dense kernel's.
+template <int NJ>
+MD void score_claimed_rows(const SparseScore& sp, bool want, int32_t row) {
+    constexpr int D = NJ * 64;
+    const int lane = threadIdx.x & 63, s = lane & 15, qd = lane >> 4;
+    // leaders: the first lane of each distinct row among the wanting lanes
+    bool leader = false;
+    unsigned long long todo = __ballot(want);
+    while (todo) {
+        const int l = __builtin_ctzll(todo);
+        const int32_t r = __shfl(row, l);
+        const unsigned long long same = __ballot(want && row == r);
+        leader |= lane == l;
+        todo &= ~same;
+    }
+    // a cheap look first (after the first frames nearly every needed row carries the epoch already), then the exchange
+    bool claim = false;
+    if (leader && sp.stamps[row] != sp.epoch) claim = atomicExch(&sp.stamps[row], sp.epoch) != sp.epoch;
+    unsigned long long m = __ballot(claim);
+    while (m) {
+        int32_t mine = -1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (m) {
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                const int32_t r = __shfl(row, l);
+                mine = qd == q ? r : mine;
+            }
+        }
+        const bool have = mine >= 0;
+        const float* rp = sp.emb + (size_t)(have ? mine : 0) * D + s * 4;
+        float4 v[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) v[j] = *reinterpret_cast<const float4*>(rp + j * 64);
+        double acc = 0.0, ne2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const double2* p = reinterpret_cast<const double2*>(sp.code + j * 64 + s * 4);
+            const double2 a = p[0], b = p[1];
+            ne2 = fma_(a.x, a.x, ne2); ne2 = fma_(a.y, a.y, ne2); ne2 = fma_(b.x, b.x, ne2); ne2 = fma_(b.y, b.y, ne2);
+            acc = fma_((double)v[j].x, a.x, acc);
+            acc = fma_((double)v[j].y, a.y, acc);
+            acc = fma_((double)v[j].z, b.x, acc);
+            acc = fma_((double)v[j].w, b.y, acc);
+        }
+        ne2 = quarter_reduce(ne2);
+        acc = quarter_reduce(acc);
+        if (have && s == 0) {
+            double ne = __builtin_sqrt(ne2);
+            ne = ne < COS_EPS ? COS_EPS : ne;
+            sp.scores[mine] = acc / (ne * sp.norms[mine]);
+        }
+    }
+}
+
+MD void score_claimed_rows_nj(const SparseScore& sp, bool want, int32_t row) {
+    switch (sp.nj) {
+        case 8: score_claimed_rows<8>(sp, want, row); break;
+        case 4: score_claimed_rows<4>(sp, want, row); break;
+        case 2: score_claimed_rows<2>(sp, want, row); break;
+        default: score_claimed_rows<16>(sp, want, row); break;
+    }
+}
+
 }  // namespace midas

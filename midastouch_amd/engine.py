@@ -79,6 +79,19 @@ class FilterEngine:
         self.telemetry = torch.zeros(16 + extra, dtype=torch.int64, device=self.device)
         self.step_count = 0
         self.use_hint = True
+        # sparse scoring: only the rows that are some particle's nearest entry are scored, by the particle kernels
+        # themselves (stamps of the frame that last scored a row; include/midas_hip.h score_stamps_dev).  Same scores.
+        import os as _os
+        self.sparse_scores = self.codebook.emb.dtype == torch.float32 and self.D in (128, 256, 512, 1024) and \
+            _os.environ.get("MIDAS_DENSE_SCORES", "0") != "1"
+        self._stamps = torch.zeros(self.K, dtype=torch.int32, device=self.device)
+        self._epoch = 0
+
+    def _next_epoch(self, n: int = 1) -> int:
+        """First of n consecutive score epochs (non-zero, never reused while the stamps live)."""
+        first = self._epoch + 1
+        self._epoch += n
+        return first
 
     # ---- state ----------------------------------------------------------------------------------
     def set_particles(self, poses: torch.Tensor):
@@ -117,6 +130,8 @@ class FilterEngine:
         a.softmax, a.resample_mode = int(self.softmax), self.mode
         a.status = _ptr(self.status)
         a.telemetry = _ptr(self.telemetry)
+        if self.sparse_scores:
+            a.score_stamps, a.score_epoch = _ptr(self._stamps), self._next_epoch()
         self._keep = (odom, code, gt, tn, rot, u)  # keep operands alive until the stream has consumed them
         self.ctx.bind_current_stream()
         self.ctx.check(self.ctx.lib.midas_filter_step(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h,
@@ -255,6 +270,8 @@ class PipelinedFilterEngine(FilterEngine):
         a.seed, a.step = self.seed, self.step_count
         a.prune_thr, a.softmax = self.pen_max, int(self.softmax)
         a.telemetry = _ptr(self.telemetry)
+        if self.sparse_scores:
+            a.score_stamps, a.score_epoch = _ptr(self._stamps), self._next_epoch()
         self._keep = (odom, code, gt, tn, rot, pu)
         self.ctx.bind_current_stream()
         self.ctx.check(self.ctx.lib.midas_lazy_step(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h, C.byref(a)))
@@ -295,6 +312,8 @@ class PipelinedFilterEngine(FilterEngine):
         a.seed, a.step = self.seed, self.step_count
         a.prune_thr, a.softmax = self.pen_max, int(self.softmax)
         a.telemetry = _ptr(self.telemetry)
+        if self.sparse_scores:
+            a.score_stamps, a.score_epoch = _ptr(self._stamps), self._next_epoch(T)
         log = torch.zeros((T, 3), dtype=torch.float64, device=d) if gts is not None else None
         self._keep = (odoms, codes, gts, log)
         self.ctx.bind_current_stream()

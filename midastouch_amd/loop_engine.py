@@ -69,6 +69,10 @@ class LoopEngine:
         self.log_frames = int(log_frames)
         self._log = z((self.log_frames, _lib.LOOP_LOG_DOUBLES), torch.float64)
         self.telemetry = z(16, torch.int64)
+        import os as _os
+        self.sparse_scores = self.codebook.emb.dtype == torch.float32 and self.D in (128, 256, 512, 1024) and \
+            _os.environ.get("MIDAS_DENSE_SCORES", "0") != "1"
+        self._stamps, self._epoch = z(self.K, torch.int32), 0  # sparse scoring (include/midas_hip.h score_stamps_dev)
         self.step_count = 0        # frames enqueued (Philox counter, log row)
         self._n_host = None        # particle count as last known by the host (None: ask the device)
         self._pending_phases = 0
@@ -200,6 +204,9 @@ class LoopEngine:
         a.floor, a.eps = self.floor, self.eps
         a.unit_weights = int(bool(unit_weights))
         a.telemetry = _ptr(self.telemetry)
+        if self.sparse_scores and phases & _lib.LOOP_FRONT:
+            self._epoch += 1
+            a.score_stamps, a.score_epoch = _ptr(self._stamps), self._epoch
         self._keep = keep
         self.ctx.bind_current_stream()
         self.ctx.check(self.ctx.lib.midas_loop_step(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h, C.byref(a), int(phases)))
