@@ -353,14 +353,27 @@ typedef struct midas_shard_route_args {
     const double* u_all_dev;        /* NULL -> Philox, or G * N uniforms (the same on every rank) */
     float u32;
     uint64_t seed, step;
-    int32_t* counts_dev;            /* 3 G ints: send counts | receive counts | scratch */
-    void* send_dev;                 /* pack: sum(send counts) x 88 bytes */
+    int32_t* counts_dev;            /* 3 G + 1 ints: send counts | receive counts | scratch */
+    void* send_dev;                 /* pack: sum(send counts) x 88 bytes (fixed_cap > 0: G x fixed_cap x 88) */
     double* weights_dev;            /* pack: N out */
+    /* Fixed-capacity form of midas_shard_route_pack - no count pass, nothing read back: the rows for rank d go to rows
+     * [d * fixed_cap, (d + 1) * fixed_cap) of send_dev (unused rows keep slot = -1), the all_to_all has equal splits; rows
+     * that do not fit a segment go to ovf_dev (ovf_cap rows, gathered by every rank, destination rank in the record's
+     * fourth int); counts_dev[3 G] = rows sent there (> ovf_cap: rows were lost, the frame is invalid).  The receiver scans all G x fixed_cap + G x ovf_cap rows
+     * (midas_shard_unpack_rows).  0: the counted form above. */
+    int64_t fixed_cap, ovf_cap;
+    void* ovf_dev;
+    void* self_dev;                 /* fixed form: N x 88 bytes - the rows whose slot and source both live on this rank stay
+                                     * here instead of travelling (unpacked like the others) */
 } midas_shard_route_args;
 int midas_shard_route_count(midas_ctx* ctx, const midas_shard_route_args* args);
 int midas_shard_route_pack(midas_ctx* ctx, const midas_shard_route_args* args);
 int midas_shard_unpack(midas_ctx* ctx, int64_t N, const void* recv_dev, int32_t* ridx_dev, float* poses_out_dev,
                        double* weights_out_dev, int32_t* hint_out_dev);
+/* the same over `rows` records of which some are padding (slot -1); dest >= 0: only the records whose destination rank is
+ * dest (the gathered overflow blocks) */
+int midas_shard_unpack_rows(midas_ctx* ctx, int64_t rows, const void* recv_dev, int32_t dest, int32_t* ridx_dev,
+                            float* poses_out_dev, double* weights_out_dev, int32_t* hint_out_dev);
 /* ---- the all_gather form of the exchange (every rank materialises its slice of the global CDF and gathers every
  * shard's packed block; G-1 times the bytes of the owner-side form, no read-back of counts) ---- */
 /* midas_shard_tail_fin: softmax applied unless softmax == 0 or |max x - min x| over r1_all <= 1e-8 (then e := x);

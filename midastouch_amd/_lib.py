@@ -119,6 +119,7 @@ class ShardRouteArgs(C.Structure):
         ("softmax", C.c_int32), ("resample_mode", C.c_int32), ("u_all", C.c_void_p), ("u32", C.c_float),
         ("seed", C.c_uint64), ("step", C.c_uint64),
         ("counts", C.c_void_p), ("send", C.c_void_p), ("weights", C.c_void_p),
+        ("fixed_cap", C.c_int64), ("ovf_cap", C.c_int64), ("ovf", C.c_void_p), ("self_rows", C.c_void_p),
     ]
 
 
@@ -206,6 +207,7 @@ SIGNATURES = {
     "midas_shard_route_count": (C.c_int, [_P, C.POINTER(ShardRouteArgs)]),
     "midas_shard_route_pack": (C.c_int, [_P, C.POINTER(ShardRouteArgs)]),
     "midas_shard_unpack": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P]),
+    "midas_shard_unpack_rows": (C.c_int, [_P, _I64, _P, _I32, _P, _P, _P, _P]),
     "midas_tail_resample": (C.c_int, [_P, C.POINTER(TailResampleArgs)]),
     "midas_profile_enable": (C.c_int, [_P, _I32]),
     "midas_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64), _I32]),

@@ -792,6 +792,8 @@ static int shard_route(midas_ctx* ctx, const midas_shard_route_args* args, bool 
                            (uintptr_t)s.tables_dev % 128 == 0 && s.valid_dev && s.nn_idx_dev && s.poses_prop_dev && s.status_dev &&
                            s.counts_dev);
     MIDAS_REQUIRE(ctx, !pack || (s.send_dev && s.weights_dev && (uintptr_t)s.send_dev % 8 == 0));
+    MIDAS_REQUIRE(ctx, !pack || s.fixed_cap == 0 || (s.fixed_cap > 0 && s.ovf_cap > 0 && s.ovf_dev && (uintptr_t)s.ovf_dev % 8 == 0 && s.self_dev && (uintptr_t)s.self_dev % 8 == 0 &&
+                                                     s.G * s.fixed_cap < ((int64_t)1 << 31)));
     MIDAS_REQUIRE(ctx, s.resample_mode == MIDAS_RESAMPLE_MULTINOMIAL || s.resample_mode == MIDAS_RESAMPLE_SYSTEMATIC);
     return launch_shard_route(ctx, s, shard_tables_of(const_cast<double*>(s.tables_dev), s.N), pack);
 }
@@ -811,6 +813,13 @@ MIDAS_EXPORT int midas_shard_unpack(midas_ctx* ctx, int64_t N, const void* recv_
     MIDAS_ENTER(ctx);
     MIDAS_REQUIRE(ctx, N > 0 && recv_dev && (uintptr_t)recv_dev % 8 == 0 && ridx_dev && poses_out_dev && weights_out_dev && hint_out_dev);
     return launch_shard_unpack(ctx, N, recv_dev, ridx_dev, poses_out_dev, weights_out_dev, hint_out_dev);
+}
+
+MIDAS_EXPORT int midas_shard_unpack_rows(midas_ctx* ctx, int64_t rows, const void* recv_dev, int32_t dest, int32_t* ridx_dev,
+                                         float* poses_out_dev, double* weights_out_dev, int32_t* hint_out_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, rows > 0 && recv_dev && (uintptr_t)recv_dev % 8 == 0 && ridx_dev && poses_out_dev && weights_out_dev && hint_out_dev);
+    return launch_shard_unpack(ctx, rows, recv_dev, ridx_dev, poses_out_dev, weights_out_dev, hint_out_dev, dest);
 }
 
 MIDAS_EXPORT int midas_tail_resample(midas_ctx* ctx, const midas_tail_resample_args* args) {

@@ -1175,6 +1175,12 @@ struct ShardRouteArgs {
     int32_t* cursor;  // [G]
     char* send;
     double* weights;
+    // fixed-capacity form (no count pass, no read-back): segment of destination d = rows [d * fixed_cap, + fixed_cap) of
+    // `send`, unused rows keep slot -1 (the buffers were set to 0xFF); rows that do not fit go to `ovf` (gathered by all)
+    int64_t fixed_cap = 0, ovf_cap = 0;
+    char* ovf = nullptr;
+    int32_t* ovf_count = nullptr;
+    char* self_rows = nullptr;  // [N] the rows this rank owns AND needs (they never travel)
 };
 
 template <bool PACK>
@@ -1227,9 +1233,9 @@ __global__ __launch_bounds__(256) void k_shard_route(ShardRouteArgs a) {
         double nans = 0.0;
         for (int r = 0; r < a.G; ++r) nans += a.r1_all[(int64_t)r * rec + 5 * a.nb];
         s_tot[2] = nans;
-        if (PACK) {  // segment offsets of the send buffer = exclusive prefix of the send counts
+        if (PACK) {  // segment offsets of the send buffer = exclusive prefix of the send counts (or fixed segments)
             int o = 0;
-            for (int g = 0; g < a.G; ++g) { s_soff[g] = o; o += a.counts[g]; }
+            for (int g = 0; g < a.G; ++g) { s_soff[g] = a.fixed_cap ? (int)(g * a.fixed_cap) : o; o += a.fixed_cap ? 0 : a.counts[g]; }
         }
     }
     __syncthreads();
@@ -1249,7 +1255,7 @@ __global__ __launch_bounds__(256) void k_shard_route(ShardRouteArgs a) {
     }
     const bool bad_total = !(total == total) || total == 0.0;
     const bool usable = s_tot[2] == 0.0 && !bad_total;
-    if (!PACK && blockIdx.x == 0 && t == 0) {
+    if ((!PACK || a.fixed_cap) && blockIdx.x == 0 && t == 0) {
         double kept = 0.0, st2 = 0.0, sr2 = 0.0;
         for (int r = 0; r < a.G; ++r) {
             const double* fl = a.r1_all + (int64_t)r * rec + 5 * a.nb;
@@ -1323,29 +1329,40 @@ __global__ __launch_bounds__(256) void k_shard_route(ShardRouteArgs a) {
             src = search_in_block(apply ? a.lp : a.lp_raw, apply ? a.gend : a.gend_raw, apply ? a.ggend : a.ggend_raw,
                                   b - a.rank * a.nb, N, a.rank == a.G - 1 ? N - 1 : -1, s_bp[b], total, tq, upper);
         char* rp = a.send + (size_t)(s_soff[d] + s_base[d - d0] + pos) * ROUTE_REC;
+        if (a.fixed_cap && d == a.rank) {  // own slot, own source: stays here (systematic draws are mostly of this kind)
+            rp = a.self_rows + (size_t)(s_base[d - d0] + pos) * ROUTE_REC;
+        } else if (a.fixed_cap && s_base[d - d0] + pos >= a.fixed_cap) {  // segment full: the row travels in the overflow block
+            const int q = atomicAdd(a.ovf_count, 1);
+            if (q >= a.ovf_cap) rp = nullptr;  // lost: the caller sees ovf_count > ovf_cap (counts_dev[3 G])
+            else rp = a.ovf + (size_t)q * ROUTE_REC;
+        }
+        if (rp) {
         const float4* ps = reinterpret_cast<const float4*>(a.poses_prop + src * 16);
         const float4 r0 = ps[0], r1 = ps[1], r2 = ps[2], r3 = ps[3];
         const double w = (ev[src] / S) * (a.valid[src] ? 1.0 : 0.0);
         const int32_t nn = a.nn_idx[src];
         // records are 8-byte aligned (88 = 8 x 11): everything goes out as 8-byte pieces
         reinterpret_cast<int2*>(rp)[0] = make_int2((int)(i - (int64_t)d * N), (int)((int64_t)a.rank * N + src));
-        reinterpret_cast<int2*>(rp)[1] = make_int2(nn, 0);
+        reinterpret_cast<int2*>(rp)[1] = make_int2(nn, d);  // d: the destination rank (read from overflow rows)
         *reinterpret_cast<double*>(rp + 16) = w;
         float2* p2 = reinterpret_cast<float2*>(rp + 24);
         p2[0] = make_float2(r0.x, r0.y); p2[1] = make_float2(r0.z, r0.w);
         p2[2] = make_float2(r1.x, r1.y); p2[3] = make_float2(r1.z, r1.w);
         p2[4] = make_float2(r2.x, r2.y); p2[5] = make_float2(r2.z, r2.w);
         p2[6] = make_float2(r3.x, r3.y); p2[7] = make_float2(r3.z, r3.w);
+        }
     }
 }
 
+// rows: records to look at; dest >= 0: only rows addressed to that rank (overflow block), rows with slot -1 are padding
 __global__ __launch_bounds__(256) void k_shard_unpack(int64_t N, const char* __restrict__ recv, int32_t* __restrict__ ridx,
                                                       float* __restrict__ poses_out, double* __restrict__ weights_out,
-                                                      int32_t* __restrict__ hint_out) {
+                                                      int32_t* __restrict__ hint_out, int32_t dest) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= N) return;
     const char* rp = recv + (size_t)r * ROUTE_REC;
     const int2 h0 = *reinterpret_cast<const int2*>(rp), h1 = *reinterpret_cast<const int2*>(rp + 8);
+    if (h0.x < 0 || (dest >= 0 && h1.y != dest)) return;
     const double w = *reinterpret_cast<const double*>(rp + 16);
     const float2* p2 = reinterpret_cast<const float2*>(rp + 24);
     float2 v[8];
@@ -1557,7 +1574,15 @@ int launch_shard_route(midas_ctx* ctx, const midas_shard_route_args& r, const Ta
     a.softmax = r.softmax; a.mode = r.resample_mode; a.u_all = r.u_all_dev; a.u32 = r.u32; a.seed = r.seed; a.step = r.step;
     a.counts = r.counts_dev; a.cursor = r.counts_dev + 2 * r.G; a.send = (char*)r.send_dev; a.weights = r.weights_dev;
     const unsigned grid = (unsigned)ceil_div((int64_t)r.G * r.N, 256);
-    if (pack) {
+    if (pack && r.fixed_cap > 0) {  // one pass, no counts: padded segments + overflow block
+        a.fixed_cap = r.fixed_cap; a.ovf_cap = r.ovf_cap; a.ovf = (char*)r.ovf_dev; a.ovf_count = r.counts_dev + 2 * r.G + r.G;
+        a.self_rows = (char*)r.self_dev;
+        MIDAS_HIP_CHECK(ctx, hipMemsetAsync(r.self_dev, 0xFF, (size_t)r.N * ROUTE_REC, ctx->stream));
+        MIDAS_HIP_CHECK(ctx, hipMemsetAsync(r.counts_dev, 0, (size_t)(3 * r.G + 1) * sizeof(int32_t), ctx->stream));
+        MIDAS_HIP_CHECK(ctx, hipMemsetAsync(r.send_dev, 0xFF, (size_t)r.G * r.fixed_cap * ROUTE_REC, ctx->stream));
+        MIDAS_HIP_CHECK(ctx, hipMemsetAsync(r.ovf_dev, 0xFF, (size_t)r.ovf_cap * ROUTE_REC, ctx->stream));
+        hipLaunchKernelGGL(k_shard_route<true>, dim3(grid), dim3(256), 0, ctx->stream, a);
+    } else if (pack) {
         hipLaunchKernelGGL(k_shard_route<true>, dim3(grid), dim3(256), 0, ctx->stream, a);
     } else {
         MIDAS_HIP_CHECK(ctx, hipMemsetAsync(r.counts_dev, 0, (size_t)3 * r.G * sizeof(int32_t), ctx->stream));
@@ -1568,9 +1593,9 @@ int launch_shard_route(midas_ctx* ctx, const midas_shard_route_args& r, const Ta
 }
 
 int launch_shard_unpack(midas_ctx* ctx, int64_t N, const void* recv, int32_t* ridx, float* poses_out, double* weights_out,
-                        int32_t* hint_out) {
+                        int32_t* hint_out, int32_t dest) {
     hipLaunchKernelGGL(k_shard_unpack, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, N, (const char*)recv, ridx,
-                       poses_out, weights_out, hint_out);
+                       poses_out, weights_out, hint_out, dest);
     LAUNCH_CHECK(ctx);
     return MIDAS_OK;
 }

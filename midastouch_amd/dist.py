@@ -132,6 +132,29 @@ class HipShardBackend:
     def unpack(self, st, recv):
         self.ctx.call("midas_shard_unpack", st.N, _ptr(recv), _ptr(st.ridx), _ptr(st.poses), _ptr(st.weights_res), _ptr(st.hint))
 
+    # ---- the same without the count pass and its read-back: padded segments of fixed capacity + an overflow block ----
+    def route_fixed(self, st, r1_all, rank, world, softmax, mode, u_all, u32, seed, step, want_rmse, cap, ovf_cap):
+        """-> (send buffer of world x cap rows, overflow block of ovf_cap rows); unused rows carry slot -1."""
+        a = self._route_args(st, r1_all, rank, world, softmax, mode, u_all, u32, seed, step, want_rmse)
+        send = getattr(st, "_send_fixed", None)
+        if send is None or send.numel() != world * cap * ROUTE_REC:
+            send = st._send_fixed = torch.empty((world * cap * ROUTE_REC,), dtype=torch.uint8, device=self.device)
+            st._ovf = torch.empty((ovf_cap * ROUTE_REC,), dtype=torch.uint8, device=self.device)
+            st._self = torch.empty((st.N * ROUTE_REC,), dtype=torch.uint8, device=self.device)
+        a.send, a.fixed_cap, a.ovf_cap, a.ovf, a.self_rows = _ptr(send), int(cap), int(ovf_cap), _ptr(st._ovf), _ptr(st._self)
+        self.ctx.bind_current_stream()
+        self.ctx.check(self.ctx.lib.midas_shard_route_pack(self.ctx.h, C.byref(a)))
+        return send, st._ovf
+
+    def unpack_fixed(self, st, recv, ovf_all, rank):
+        for buf, dest in ((recv, -1), (ovf_all, rank), (st._self, -1)):
+            self.ctx.call("midas_shard_unpack_rows", buf.numel() // ROUTE_REC, _ptr(buf), int(dest), _ptr(st.ridx), _ptr(st.poses),
+                          _ptr(st.weights_res), _ptr(st.hint))
+
+    def overflow_rows(self, st, world):
+        """Rows the last fixed-capacity frame put into its overflow block (more than its capacity: rows were lost)."""
+        return int(st.counts[3 * world].item())
+
     def tail_resample(self, st, pack_all, n_all, mode, u, u32, seed, step):
         a = TailResampleArgs()
         a.N, a.N_all, a.slot_base = st.N, n_all, st.slot_base
@@ -241,11 +264,19 @@ class ShardedFilterEngine:
                      "low_var_batch": _lib.RESAMPLE_SYSTEMATIC}[resample]
         self.step_count = 0
         self.use_hint = True
-        if exchange not in ("auto", "a2a", "allgather"):
-            raise MidasError("exchange must be 'auto', 'a2a' or 'allgather'")
-        # the owner-side form moves 1/(G-1) of the bytes but reads the split sizes back once per frame: it pays off
-        # from four ranks on
-        self.exchange = ("a2a" if self.world >= 4 else "allgather") if exchange == "auto" else exchange
+        if exchange not in ("auto", "a2a", "a2a_fixed", "allgather"):
+            raise MidasError("exchange must be 'auto', 'a2a', 'a2a_fixed' or 'allgather'")
+        # a2a_fixed: per destination a segment of 1.5 x the expected N / G rows (after a resample every rank owns ~1 / G of
+        # the weight mass), the rest through an overflow block of N / 4 rows that every rank gathers
+        self.seg_cap = -(-int(1.5 * self.N / self.world + 64) // 8) * 8
+        self.ovf_cap = max(self.N // 4, 256)
+        # the owner-side forms move a fraction of the bytes of the all_gather form: from four ranks on.  "a2a_fixed" has no
+        # host read-back inside the frame (fixed-capacity segments + overflow block); "a2a" sends exactly the rows needed
+        # but reads the split sizes back
+        # (multinomial draws: every rank needs ~N / G rows of every other; systematic draws walk the CDF in slot order, their
+        # traffic is whatever the weight distribution makes it - counted exchange there)
+        auto = "allgather" if self.world < 4 else ("a2a_fixed" if self.mode == _lib.RESAMPLE_MULTINOMIAL else "a2a")
+        self.exchange = auto if exchange == "auto" else exchange
 
     # convenience views used by bench.py / tests (same names as FilterEngine)
     poses = property(lambda self: self.st.poses)
@@ -298,6 +329,13 @@ class ShardedFilterEngine:
                                          gt is not None)
             recv = yield ("a2a", send, [n * ROUTE_REC for n in sends], [n * ROUTE_REC for n in recvs])
             b.unpack(st, recv)
+        elif self.exchange == "a2a_fixed":
+            send, ovf = b.route_fixed(st, r1_all, self.rank, G, self.softmax, self.mode, u, u32, self.seed, self.step_count, gt is not None,
+                                      self.seg_cap, self.ovf_cap)
+            eq = [self.seg_cap * ROUTE_REC] * G
+            recv = yield ("a2a", send, eq, eq)
+            ovf_all = yield ovf
+            b.unpack_fixed(st, recv, ovf_all, self.rank)
         else:
             b.tail_fin(st, r1_all, self.rank, G, self.N_total, self.softmax, gt is not None)
             pack_all = yield st.pack

@@ -172,6 +172,40 @@ class OracleShardBackend:
         rec[:, 24:88] = st.poses_prop.numpy().reshape(N, 16)[sr].astype(np.float32).view(np.uint8).reshape(-1, 64)
         return torch.as_tensor(rec.reshape(-1)), sends, recvs
 
+    def route_fixed(self, st, r1_all, rank, world, softmax, mode, u_all, u32, seed, step, want_rmse, cap, ovf_cap):
+        """The fixed-capacity form: the rows of `route`, destination by destination, into padded segments; what does not
+        fit goes to the overflow block with the destination rank in the fourth int."""
+        rec, sends, _ = self.route(st, r1_all, rank, world, softmax, mode, u_all, u32, seed, step, want_rmse)
+        rec = rec.numpy().reshape(-1, ROUTE_REC)
+        send = np.full((world * cap, ROUTE_REC), 0xFF, dtype=np.uint8)
+        ovf = np.full((ovf_cap, ROUTE_REC), 0xFF, dtype=np.uint8)
+        o, q = 0, 0
+        for d, n in enumerate(sends):
+            rows = rec[o:o + n].copy()
+            rows[:, 12:16] = np.array([d], dtype=np.int32).view(np.uint8)
+            if d == rank:  # own slot, own source: never travels
+                st._self_rows = rows
+                o += n
+                continue
+            fit = min(n, cap)
+            send[d * cap:d * cap + fit] = rows[:fit]
+            extra = rows[fit:]
+            assert q + len(extra) <= ovf_cap, "overflow block too small"
+            ovf[q:q + len(extra)] = extra
+            q += len(extra)
+            o += n
+        st.overflow_rows = q
+        return torch.as_tensor(send.reshape(-1)), torch.as_tensor(ovf.reshape(-1))
+
+    def unpack_fixed(self, st, recv, ovf_all, rank):
+        rows = [recv.numpy().reshape(-1, ROUTE_REC)]
+        o = ovf_all.numpy().reshape(-1, ROUTE_REC)
+        rows.append(o[o[:, 12:16].copy().view(np.int32).reshape(-1) == rank])
+        rows.append(st._self_rows)
+        rec = np.concatenate(rows)
+        rec = rec[rec[:, 0:4].copy().view(np.int32).reshape(-1) >= 0]
+        self.unpack(st, torch.as_tensor(rec.reshape(-1)))
+
     def unpack(self, st, recv):
         rec = recv.numpy().reshape(-1, ROUTE_REC)
         assert rec.shape[0] == st.N

@@ -32,8 +32,11 @@ def _worker(rank, world, port, mode, exchange, out_dir):
     from midastouch_amd.dist import ShardedFilterEngine
     from tests._oracle_shard_backend import OracleShardBackend
     cb, traj, start = _data()
+    tight = exchange == "a2a_fixed_tight"  # segments smaller than the expected row count: the overflow block is in use
     eng = ShardedFilterEngine(num_particles=N_LOC, backend=OracleShardBackend(cb.poses, cb.embeddings, cb.mesh_vertices),
-                              resample=mode, seed=4000, exchange=exchange)
+                              resample=mode, seed=4000, exchange="a2a_fixed" if tight else exchange)
+    if tight:
+        eng.seg_cap = (N_LOC // world) * 7 // 8 // 8 * 8
     assert eng.world == world and eng.rank == rank
     eng.set_particles(torch.as_tensor(start[rank * N_LOC:(rank + 1) * N_LOC]))
     res = []
@@ -54,7 +57,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("exchange", ["a2a", "allgather"])
+@pytest.mark.parametrize("exchange", ["a2a", "allgather", "a2a_fixed", "a2a_fixed_tight"])
 @pytest.mark.parametrize("mode", ["weighted_random", "low_var"])
 def test_two_rank_gloo_equals_single_process(tmp_path, oracle, mode, exchange):
     world = 2
@@ -85,12 +88,12 @@ def test_two_rank_gloo_equals_single_process(tmp_path, oracle, mode, exchange):
 
 
 def test_four_rank_gloo_auto_exchange(tmp_path, oracle):
-    """Four ranks: exchange='auto' picks the owner-side all_to_all; same bar (bit-identical to one process)."""
+    """Four ranks: exchange='auto' picks the owner-side all_to_all without read-back; same bar (bit-identical to one process)."""
     global N_LOC
     world = 4
     mp.spawn(_worker4, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     parts = [torch.load(os.path.join(tmp_path, f"r{r}.pt"), weights_only=False) for r in range(world)]
-    assert all(p["exchange"] == "a2a" for p in parts)
+    assert all(p["exchange"] == "a2a_fixed" for p in parts)
     cb, traj, _ = _data()
     start = cb.poses[np.random.default_rng(5).integers(0, K, world * N_LOC)]
     ofl = oracle.OracleFilter(cb.poses, cb.embeddings, cb.mesh_vertices)

@@ -25,7 +25,7 @@ class FakeComm:
     all_to_all = all_gather
 
 
-@pytest.mark.parametrize("exchange", ["a2a", "allgather"])
+@pytest.mark.parametrize("exchange", ["a2a", "allgather", "a2a_fixed", "a2a_fixed_tight"])
 @pytest.mark.parametrize("shards,mode", [(2, "weighted_random"), (3, "low_var"), (1, "weighted_random")])
 def test_sharded_hip_equals_fused_engine(dev, shards, mode, exchange):
     from midastouch_amd.dist import HipShardBackend, ShardedFilterEngine, run_lockstep
@@ -41,8 +41,12 @@ def test_sharded_hip_equals_fused_engine(dev, shards, mode, exchange):
     single.set_particles(torch.as_tensor(start))
     single.project_to_codebook()
     be = HipShardBackend(cb.poses, cb.embeddings, cb.mesh_vertices, dev)
-    engs = [ShardedFilterEngine(num_particles=n_loc, backend=be, comm=FakeComm(r, shards), resample=mode, exchange=exchange)
-            for r in range(shards)]
+    tight = exchange == "a2a_fixed_tight"  # segments below the expected row count: the overflow block carries the rest
+    engs = [ShardedFilterEngine(num_particles=n_loc, backend=be, comm=FakeComm(r, shards), resample=mode,
+                                exchange="a2a_fixed" if tight else exchange) for r in range(shards)]
+    if tight:
+        for e in engs:
+            e.seg_cap = (n_loc // shards) * 7 // 8 // 8 * 8
     for r, e in enumerate(engs):
         e.set_particles(torch.as_tensor(start[r * n_loc:(r + 1) * n_loc]))
         e.project_to_codebook()

@@ -98,7 +98,7 @@ def test_sharded_engine_vs_oracle(dev, oracle):
     rng = np.random.default_rng(1)
     start = cb.poses[rng.integers(0, K, G * n)]
     be = HipShardBackend(cb.poses, cb.embeddings, cb.mesh_vertices, dev)
-    for exchange in ("allgather", "a2a"):
+    for exchange in ("allgather", "a2a", "a2a_fixed"):
         engs = [ShardedFilterEngine(num_particles=n, backend=be, comm=FakeComm(r, G), seed=seed, exchange=exchange) for r in range(G)]
         for r, e in enumerate(engs):
             e.set_particles(torch.as_tensor(start[r * n:(r + 1) * n]))
