@@ -144,7 +144,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-loop", action="store_true", help="skip the reference-named loop (filter() with clustering + annealing)")
     ap.add_argument("--sharded", action="store_true", help="use the particle-sharded engine even on one GPU (smoke test)")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "a2a", "allgather"], help="sharded engine: form of the resample exchange")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "a2a", "a2a_fixed", "allgather"], help="sharded engine: form of the resample exchange")
     ap.add_argument("--eager", action="store_true", help="materialise the resampled particles every frame (three launches per frame)")
     ap.add_argument("--resample", default="weighted_random", choices=["weighted_random", "low_var"],
                     help="resampler mode (particle_filter.py:230-307): the reference's default multinomial draws, or systematic")
@@ -308,6 +308,13 @@ def main():
     loop_rate = None
     if not sharded and not args.no_loop:
         loop_rate = reference_loop_rate(cb, traj, N, dev, tree, eng.tree3)
+    exchange_info = None
+    if sharded:
+        exchange_info = {"form": eng.exchange}
+        if eng.exchange == "a2a_fixed":  # rows beyond the overflow block's capacity would have been lost: must not happen
+            ov = eng.backend.overflow_rows(eng.st, world)
+            exchange_info.update(segment_rows=eng.seg_cap, overflow_capacity=eng.ovf_cap, overflow_rows_last_frame=ov,
+                                 valid=bool(ov <= eng.ovf_cap))
     tele = (eng.st.telemetry if sharded else eng.telemetry).cpu().numpy().tolist()
     frames_run = 2 + (40 if diffuse else 0) + args.warmup + args.steps * (3 if eager_rate else 1)
 
@@ -331,7 +338,7 @@ def main():
                    "timed_region": "K steps by one midas_lazy_run call" if hasattr(eng, "run") and not args.eager else "K step() calls",
                    "steps_per_sec_materialised_every_frame": eager_rate,
                    "reference_loop_frames_per_sec": loop_rate,
-                   "per_step": step_stats, "per_step_in_timed_call": run_stats, "diffuse_regime": diffuse,
+                   "per_step": step_stats, "per_step_in_timed_call": run_stats, "diffuse_regime": diffuse, "exchange": exchange_info,
                    "tree_search_fallbacks_per_frame": {"nn": tele[0] / frames_run, "prune": tele[1] / frames_run}},
     }
 

@@ -91,7 +91,8 @@ template <int NJ>
 MD void score_claimed_rows(const SparseScore& sp, bool want, int32_t row) {
     constexpr int D = NJ * 64;
     const int lane = threadIdx.x & 63, s = lane & 15, qd = lane >> 4;
-    // leaders: the first lane of each distinct row among the wanting lanes
+    // leaders: the first lane of each distinct row among the wanting lanes (a per-lane look at the stamps first was
+    // measured: 64 scattered 4-byte loads per wave cost more than the election they save - 17.7k vs 20.5k steps/s)
     bool leader = false;
     unsigned long long todo = __ballot(want);
     while (todo) {
@@ -101,7 +102,7 @@ MD void score_claimed_rows(const SparseScore& sp, bool want, int32_t row) {
         leader |= lane == l;
         todo &= ~same;
     }
-    // a cheap look first (after the first frames nearly every needed row carries the epoch already), then the exchange
+    // only the leaders look (after the first waves of a frame nearly every needed row carries the epoch already), then exchange
     bool claim = false;
     if (leader && sp.stamps[row] != sp.epoch) claim = atomicExch(&sp.stamps[row], sp.epoch) != sp.epoch;
     unsigned long long m = __ballot(claim);
