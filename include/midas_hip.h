@@ -496,6 +496,13 @@ typedef struct midas_loop_args {
     uint64_t* telemetry_dev;       /* NULL or 16 counters (see midas_step_args) */
     uint32_t* score_stamps_dev;    /* sparse scoring, see midas_step_args */
     uint32_t score_epoch;
+    /* What lets the caller size the launches to the live set without reading anything back: */
+    int32_t* host_mirror;          /* NULL or 2 int32 in PINNED HOST memory: the RESAMPLE phase stores {frames completed, live
+                                    * count} there when the frame is done; the host may look at it whenever it likes */
+    int64_t grid_n;                /* 0 (= cap) or an UPPER BOUND of the live count at the start of this frame: the grids cover
+                                    * grid_n particles (annealing grows the set by at most n / 3 per frame, so a count seen L frames
+                                    * ago bounds today's by (4/3)^L); ctl_i[ERR] |= 4 if the bound was wrong */
+    int32_t anneal_small;          /* 1: grid_n <= 16384 - one workgroup runs decide + select + compaction + sort (same results) */
 } midas_loop_args;
 int midas_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
                     const midas_loop_args* args, int32_t phases);

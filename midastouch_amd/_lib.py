@@ -151,6 +151,7 @@ class LoopArgs(C.Structure):
         ("softmax", C.c_int32), ("resample_mode", C.c_int32), ("floor", C.c_int32), ("eps", C.c_double),
         ("unit_weights", C.c_int32), ("telemetry", C.c_void_p),
         ("score_stamps", C.c_void_p), ("score_epoch", C.c_uint32),
+        ("host_mirror", C.c_void_p), ("grid_n", C.c_int64), ("anneal_small", C.c_int32),
     ]
 
 

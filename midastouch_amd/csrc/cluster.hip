@@ -151,13 +151,17 @@ MD void jacobi4(double A[4][4], double V[4][4]) {
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) V[i][j] = i == j ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 32; ++sweep) {
-        double off = 0.0;
-        for (int i = 0; i < 4; ++i)
+        double off = 0.0, dia = 0.0;
+        for (int i = 0; i < 4; ++i) {
+            dia += A[i][i] * A[i][i];
             for (int j = i + 1; j < 4; ++j) off += A[i][j] * A[i][j];
-        if (off < 1e-40) break;
+        }
+        // converged when the off-diagonal mass is below rounding of the diagonal (the eigenvector error is of the order
+        // sqrt(off) / gap: 1e-15 here, far below the float32 the result is rounded to)
+        if (off < 1e-40 || off < 1e-30 * dia) break;
         for (int p = 0; p < 3; ++p)
             for (int q = p + 1; q < 4; ++q) {
-                if (__builtin_fabs(A[p][q]) < 1e-300) continue;
+                if (__builtin_fabs(A[p][q]) < 1e-300 || A[p][q] * A[p][q] < 1e-34 * dia) continue;
                 const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
                 const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (__builtin_fabs(theta) + __builtin_sqrt(theta * theta + 1.0));
                 const double c = 1.0 / __builtin_sqrt(tt * tt + 1.0), s = tt * c;

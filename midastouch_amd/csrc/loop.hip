@@ -19,6 +19,8 @@
 //
 // Spec (oracle/oracle.py OracleLoop): identical to midas_filter_step where the two overlap; ties of the top-k selection go
 // to the smaller index.
+#include <cstdlib>
+
 #include "midas_internal.hpp"
 #include "midas_math.hpp"
 #include "tail_block.hpp"
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void k_loop_xe(const int32_t* __restrict__ ctl
 
 // S = blocks summed in order; guard; w = (e or x) / S * valid; every particle back onto its codebook pose when all of them
 // were pruned (filter.py:176-179); block 0 finalises the control block and the rmse.
-__global__ __launch_bounds__(256) void k_loop_weights(int32_t* __restrict__ ctl_i, double* __restrict__ ctl_d,
+__global__ __launch_bounds__(256) void k_loop_weights(int32_t* __restrict__ ctl_i, double* __restrict__ ctl_d, int32_t grid_n,
                                                       const double* __restrict__ bsum, const double* __restrict__ bmax,
                                                       const double* __restrict__ bmin, const int32_t* __restrict__ bkept,
                                                       const int32_t* __restrict__ bnan, const double* __restrict__ x,
@@ -240,6 +242,7 @@ __global__ __launch_bounds__(256) void k_loop_weights(int32_t* __restrict__ ctl_
         ctl_i[LOOP_I_DRIFT] = drifted ? 1 : 0;
         ctl_i[LOOP_I_RAW] = applied ? 0 : 1;
         ctl_i[LOOP_I_NAN] = f;
+        if (n > grid_n) ctl_i[LOOP_I_ERR] |= 4;  // the launches were sized for fewer particles than are alive
         ctl_i[LOOP_I_NSET] = (int32_t)n;
         ctl_i[LOOP_I_MODE] = 0;
         ctl_i[LOOP_I_K] = 0;
@@ -250,15 +253,10 @@ __global__ __launch_bounds__(256) void k_loop_weights(int32_t* __restrict__ ctl_
 // One workgroup: the clusters present (labels ascending) -> compact rows, var = float32 running sum of their stds / count
 // (torch.mean(cluster_stds), filter.py:189), then particle_filter.annealing's rule (:413-447) in the float32 arithmetic torch
 // uses for `var / self.particle_var`, `1.0 - ratio` and `* N`.  Also clears the select histograms.
-__global__ __launch_bounds__(256) void k_loop_decide(int32_t* __restrict__ ctl_i, double* __restrict__ ctl_d,
-                                                     const float* __restrict__ centers_all, const float* __restrict__ stds_all,
-                                                     const int64_t* __restrict__ counts_all, float* __restrict__ centers_out,
-                                                     float* __restrict__ stds_out, uint32_t* __restrict__ hist,
-                                                     int32_t* __restrict__ sel_state, int32_t floor_n) {
-    const int t = threadIdx.x;
-    for (int i = t; i < SEL_PASSES * SEL_BINS; i += 256) hist[i] = 0u;
-    for (int i = t; i < 4 * (SEL_PASSES + 2); i += 256) sel_state[i] = 0;
-    if (t != 0) return;
+// (one thread) -> {mode, k}
+MD void loop_decide(int32_t* __restrict__ ctl_i, double* __restrict__ ctl_d, const float* __restrict__ centers_all,
+                    const float* __restrict__ stds_all, const int64_t* __restrict__ counts_all, float* __restrict__ centers_out,
+                    float* __restrict__ stds_out, int32_t floor_n, int& mode_out, int& k_out) {
     const int32_t n = ctl_i[LOOP_I_N];
     int C = ctl_i[LOOP_I_NCL] + 1;
     if (C > LOOP_MAX_CLUSTERS) { C = LOOP_MAX_CLUSTERS; ctl_i[LOOP_I_ERR] |= 1; }
@@ -303,6 +301,22 @@ __global__ __launch_bounds__(256) void k_loop_decide(int32_t* __restrict__ ctl_i
     ctl_i[LOOP_I_MODE] = mode;
     ctl_i[LOOP_I_K] = k;
     ctl_i[LOOP_I_NSET] = mode == 1 ? n - k : mode == 2 ? n + k : n;
+    mode_out = mode;
+    k_out = k;
+}
+
+__global__ __launch_bounds__(256) void k_loop_decide(int32_t* __restrict__ ctl_i, double* __restrict__ ctl_d,
+                                                     const float* __restrict__ centers_all, const float* __restrict__ stds_all,
+                                                     const int64_t* __restrict__ counts_all, float* __restrict__ centers_out,
+                                                     float* __restrict__ stds_out, uint32_t* __restrict__ hist,
+                                                     int32_t* __restrict__ sel_state, int32_t floor_n) {
+    const int t = threadIdx.x;
+    for (int i = t; i < SEL_PASSES * SEL_BINS; i += 256) hist[i] = 0u;
+    for (int i = t; i < 4 * (SEL_PASSES + 2); i += 256) sel_state[i] = 0;
+    __syncthreads();
+    if (t != 0) return;
+    int mode, k;
+    loop_decide(ctl_i, ctl_d, centers_all, stds_all, counts_all, centers_out, stds_out, floor_n, mode, k);
     sel_state[0] = 0; sel_state[1] = 0; sel_state[2] = k;  // pass 0: empty prefix, rank k
 }
 
@@ -561,6 +575,148 @@ __global__ __launch_bounds__(256) void k_loop_sort_rank(const int32_t* __restric
     src[n + rank] = idx;
 }
 
+// ---- ANNEAL for a small set: decide + radix select + compaction + sort by ONE workgroup -----------------------------------
+// After a few frames of annealing the set holds ~10^4 particles and the eleven launches above do a few microseconds of work
+// each behind ~4.5 us of launch floor.  When the caller knows that n <= LOOP_SMALL_MAX (LoopEngine bounds the count it saw
+// last by the largest growth annealing allows per frame) one 1024-thread workgroup does the same steps - sixteen keys per
+// thread in registers, LDS histograms, the k duplicates sorted in LDS - with identical results.
+constexpr int LOOP_SMALL_MAX = 16384, LOOP_SMALL_PAIRS = 8192;
+
+// exclusive prefix over the 1024 threads of (a, b); totals returned in ta / tb.  s_w: 32 ints of LDS.
+MD void small_scan2(int a, int b, int& ea, int& eb, int& ta, int& tb, int* s_w) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    int ia = a, ib = b;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int x = __shfl_up(ia, o), y = __shfl_up(ib, o);
+        if (lane >= o) { ia += x; ib += y; }
+    }
+    __syncthreads();
+    if (lane == 63) { s_w[wv] = ia; s_w[16 + wv] = ib; }
+    __syncthreads();
+    int pa = 0, pb = 0;
+    ta = 0; tb = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int x = s_w[w], y = s_w[16 + w];
+        if (w < wv) { pa += x; pb += y; }
+        ta += x; tb += y;
+    }
+    ea = pa + ia - a;
+    eb = pb + ib - b;
+}
+
+template <bool DECIDE>
+__global__ __launch_bounds__(1024) void k_loop_anneal_small(int32_t* __restrict__ ctl_i, double* __restrict__ ctl_d,
+                                                            const float* __restrict__ centers_all, const float* __restrict__ stds_all,
+                                                            const int64_t* __restrict__ counts_all, float* __restrict__ centers_out,
+                                                            float* __restrict__ stds_out, int32_t floor_n,
+                                                            const double* __restrict__ w, int32_t* __restrict__ src) {
+    __shared__ uint32_t s_h[SEL_BINS];
+    __shared__ int s_w[40];
+    __shared__ uint64_t s_key[LOOP_SMALL_PAIRS];
+    __shared__ int32_t s_idx[LOOP_SMALL_PAIRS];
+    const int t = threadIdx.x;
+    if (t == 0) {
+        int mode = ctl_i[LOOP_I_MODE], k = ctl_i[LOOP_I_K];  // !DECIDE: a plan made by the host (midas_anneal_select)
+        if (DECIDE) loop_decide(ctl_i, ctl_d, centers_all, stds_all, counts_all, centers_out, stds_out, floor_n, mode, k);
+        const int n0 = ctl_i[LOOP_I_N];
+        if (n0 > LOOP_SMALL_MAX) { ctl_i[LOOP_I_ERR] |= 4; mode = 0; }  // the caller's bound was wrong: no annealing, flagged
+        s_w[36] = mode; s_w[37] = k; s_w[38] = n0;
+    }
+    __syncthreads();
+    const int mode = s_w[36], k = s_w[37], n = s_w[38];
+    if (!mode) {
+        if (n > LOOP_SMALL_MAX && t == 0) { ctl_i[LOOP_I_MODE] = 0; ctl_i[LOOP_I_K] = 0; ctl_i[LOOP_I_NSET] = n; }
+        return;  // identity index list: written by k_loop_weights
+    }
+    // thread t owns the sixteen consecutive particles [16 t, 16 t + 16): index order = thread order, one block scan compacts
+    uint64_t key[16];
+    const int base = 16 * t;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int i = base + j;
+        key[j] = select_key(w, i < n ? i : n - 1, mode);
+    }
+    const int mine_n = n - base < 0 ? 0 : n - base > 16 ? 16 : n - base;  // how many of them exist
+    // ---- radix select: the k-th smallest key T and how many of its equals to take (r)
+    uint64_t prefix = 0;
+    int krem = k;
+#pragma unroll 1
+    for (int p = 0; p < SEL_PASSES; ++p) {
+        s_h[t] = 0u; s_h[t + 1024] = 0u;
+        __syncthreads();
+        const int shift = kSelShift[p], width = kSelWidth[p];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const bool match = p == 0 || (key[j] >> (shift + width)) == prefix;
+            if (j < mine_n && match) atomicAdd(&s_h[(uint32_t)(key[j] >> shift) & ((1u << width) - 1u)], 1u);
+        }
+        __syncthreads();
+        const int c0 = (int)s_h[2 * t], c1 = (int)s_h[2 * t + 1];
+        int e0, e1, t0, t1;
+        small_scan2(c0 + c1, 0, e0, e1, t0, t1, s_w);
+        if (krem > e0 && krem <= e0 + c0 + c1) {  // exactly one thread
+            const bool first = krem <= e0 + c0;
+            s_w[32] = 2 * t + (first ? 0 : 1);
+            s_w[33] = krem - e0 - (first ? 0 : c0);
+        }
+        __syncthreads();
+        prefix = (prefix << width) | (uint64_t)s_w[32];
+        krem = s_w[33];
+        __syncthreads();
+    }
+    const uint64_t T = prefix;
+    const int r = krem;
+    // ---- compaction in index order
+    unsigned lbits = 0, ebits = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        lbits |= (j < mine_n && key[j] < T) ? (1u << j) : 0u;
+        ebits |= (j < mine_n && key[j] == T) ? (1u << j) : 0u;
+    }
+    int lb, eb, tl, te;
+    small_scan2(__popc(lbits), __popc(ebits), lb, eb, tl, te, s_w);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j < mine_n) {
+            const int i = base + j;
+            const bool isl = (lbits >> j) & 1u, ise = (ebits >> j) & 1u;
+            const bool selected = isl || (ise && eb < r);
+            const int sel_before = lb + (eb < r ? eb : r);
+            if (mode == 1) {
+                if (!selected) src[i - sel_before] = i;
+            } else if (selected) {
+                s_key[sel_before] = key[j];
+                s_idx[sel_before] = i;
+            }
+            lb += isl ? 1 : 0;
+            eb += ise ? 1 : 0;
+        }
+    }
+    if (mode != 2) return;
+    // ---- the k duplicates in topk's order: (key, index) ascending, bitonic network over the next power of two
+    int P = 2;
+    while (P < k) P <<= 1;
+    __syncthreads();
+    for (int i = k + t; i < P; i += 1024) { s_key[i] = ~0ull; s_idx[i] = 0x7fffffff; }
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int q = t; q < P / 2; q += 1024) {
+                const int lo = 2 * q - (q & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint64_t ka = s_key[lo], kb = s_key[hi];
+                const int32_t ia = s_idx[lo], ib = s_idx[hi];
+                const bool swap = up ? pair_less(kb, ib, ka, ia) : pair_less(ka, ia, kb, ib);
+                if (swap) { s_key[lo] = kb; s_key[hi] = ka; s_idx[lo] = ib; s_idx[hi] = ia; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int q = t; q < k; q += 1024) src[n + q] = s_idx[q];
+}
+
 // ---- RESAMPLE -------------------------------------------------------------------------------------------------------
 // block-local prefix of (e * valid)[src] (or x * valid when the weights are raw scores) in the spec order
 __global__ __launch_bounds__(256) void k_loop_scan(const int32_t* __restrict__ ctl_i, const double* __restrict__ x,
@@ -616,6 +772,7 @@ struct LoopResampleArgs {
     double* log;
     const float* cluster_poses;
     const float* cluster_stds;
+    int32_t* host_mirror;
 };
 
 // n_set draws over cdf_i = (BP_b + lp_i) / total (last slot 1): lower bound (multinomial) / upper bound (systematic) by
@@ -695,6 +852,10 @@ __global__ __launch_bounds__(256) void k_loop_resample(LoopResampleArgs a) {
         }
         a.ctl_i[LOOP_I_FRAME] += 1;
         a.ctl_i[LOOP_I_N] = (int32_t)n2;  // the other workgroups read LOOP_I_NSET only
+        if (a.host_mirror) {  // pinned host memory: the count first, then the frame number that says it is there
+            __hip_atomic_store(&a.host_mirror[1], (int32_t)n2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&a.host_mirror[0], a.ctl_i[LOOP_I_FRAME], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -767,6 +928,11 @@ __global__ __launch_bounds__(256) void k_anneal_plan(int32_t* __restrict__ ctl_i
     if (t < 32) ctl_i[t] = t == LOOP_I_N ? n : t == LOOP_I_MODE ? mode : t == LOOP_I_K ? k : 0;
 }
 
+__global__ __launch_bounds__(256) void k_loop_identity(int32_t n, int32_t* __restrict__ src) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) src[i] = i;
+}
+
 int launch_anneal_select(midas_ctx* ctx, int64_t N, const double* w, int32_t mode, int64_t k, int32_t* src) {
     void* ctl;
     int rc;
@@ -774,12 +940,21 @@ int launch_anneal_select(midas_ctx* ctx, int64_t N, const double* w, int32_t mod
     SelectScratch ss;
     if ((rc = select_scratch(ctx, N, ss))) return rc;
     hipLaunchKernelGGL(k_anneal_plan, dim3(1), dim3(256), 0, ctx->stream, (int32_t*)ctl, ss.hist, ss.state, (int32_t)N, mode, (int32_t)k);
+    const char* small = getenv("MIDAS_ANNEAL_SMALL");  // tests: the single-workgroup path on the same plan
+    if (N <= LOOP_SMALL_MAX && small && atoi(small)) {
+        hipLaunchKernelGGL(k_loop_identity, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, (int32_t)N, src);
+        hipLaunchKernelGGL(k_loop_anneal_small<false>, dim3(1), dim3(1024), 0, ctx->stream, (int32_t*)ctl, (double*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, (const int64_t*)nullptr, (float*)nullptr, (float*)nullptr, 0, w, src);
+        LAUNCH_CHECK(ctx);
+        return MIDAS_OK;
+    }
     return launch_select(ctx, N, (const int32_t*)ctl, w, src, ss);
 }
 
 int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* t6, const midas_tree* t3,
                      const midas_loop_args& s, int32_t phases) {
-    const int64_t cap = s.cap;
+    // the grids cover `cap` particles: the capacity, or the caller's upper bound of the live count
+    const int64_t cap = (s.grid_n > 0 && s.grid_n < s.cap) ? s.grid_n : s.cap;
     const unsigned nbcap = (unsigned)ceil_div(cap, SCAN_BLOCK);
     int rc;
     hipStream_t st = ctx->stream;
@@ -824,7 +999,7 @@ int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree*
         hipLaunchKernelGGL(k_loop_xe, dim3(nbcap), dim3(256), 0, st, (const int32_t*)s.ctl_i_dev, (const double*)s.scores_dev,
                            (const int32_t*)s.nn_idx_dev, (const uint8_t*)s.valid_dev, s.softmax, s.unit_weights, s.x_dev, s.e_dev, bsum, bmax, bmin,
                            bkept, bnan);
-        hipLaunchKernelGGL(k_loop_weights, dim3(nbcap), dim3(256), 0, st, s.ctl_i_dev, s.ctl_d_dev, (const double*)bsum,
+        hipLaunchKernelGGL(k_loop_weights, dim3(nbcap), dim3(256), 0, st, s.ctl_i_dev, s.ctl_d_dev, (int32_t)(cap < (1 << 30) ? cap : (1 << 30)), (const double*)bsum,
                            (const double*)bmax, (const double*)bmin, (const int32_t*)bkept, (const int32_t*)bnan,
                            (const double*)s.x_dev, (const double*)s.e_dev, (const uint8_t*)s.valid_dev,
                            (const int32_t*)s.nn_idx_dev, s.cb_poses_dev, s.poses_prop_dev, s.weights_dev, s.src_dev,
@@ -847,17 +1022,25 @@ int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree*
         if ((rc = launch_loop_cluster(ctx, cap, s.ctl_i_dev, s.poses_prop_dev, s.weights_dev, s.labels_dev, (double*)part, (float*)cen,
                                       (float*)sd, (int64_t*)cnt)))
             return rc;
-        hipLaunchKernelGGL(k_loop_decide, dim3(1), dim3(256), 0, st, s.ctl_i_dev, s.ctl_d_dev, (const float*)cen, (const float*)sd,
-                           (const int64_t*)cnt, s.cluster_poses_dev, s.cluster_stds_dev, ss.hist, ss.state, s.floor);
-        if ((rc = launch_select(ctx, cap, s.ctl_i_dev, s.weights_dev, s.src_dev, ss))) return rc;
+        if (s.anneal_small && cap <= LOOP_SMALL_MAX) {
+            hipLaunchKernelGGL(k_loop_anneal_small<true>, dim3(1), dim3(1024), 0, st, s.ctl_i_dev, s.ctl_d_dev, (const float*)cen, (const float*)sd,
+                               (const int64_t*)cnt, s.cluster_poses_dev, s.cluster_stds_dev, s.floor, (const double*)s.weights_dev, s.src_dev);
+            LAUNCH_CHECK(ctx);
+        } else {
+            hipLaunchKernelGGL(k_loop_decide, dim3(1), dim3(256), 0, st, s.ctl_i_dev, s.ctl_d_dev, (const float*)cen, (const float*)sd,
+                               (const int64_t*)cnt, s.cluster_poses_dev, s.cluster_stds_dev, ss.hist, ss.state, s.floor);
+            if ((rc = launch_select(ctx, cap, s.ctl_i_dev, s.weights_dev, s.src_dev, ss))) return rc;
+        }
     }
     if (phases & MIDAS_LOOP_RESAMPLE) {
-        void *lp, *bt, *bn, *ident = nullptr;
-        if ((rc = midas_scratch(ctx, (size_t)cap * sizeof(double), &lp))) return rc;
-        if ((rc = midas_scratch(ctx, (size_t)nbcap * sizeof(double), &bt))) return rc;
-        if ((rc = midas_scratch(ctx, (size_t)nbcap * sizeof(int32_t), &bn))) return rc;
-        (void)ident;
-        hipLaunchKernelGGL(k_loop_scan, dim3(nbcap), dim3(256), 0, st, (const int32_t*)s.ctl_i_dev, (const double*)s.x_dev,
+        // the annealed set may be a third larger than the particle set the bound was given for
+        const int64_t cap2 = cap + cap / 3 + 1 < s.cap ? cap + cap / 3 + 1 : s.cap;
+        const unsigned nb2 = (unsigned)ceil_div(cap2, SCAN_BLOCK);
+        void *lp, *bt, *bn;
+        if ((rc = midas_scratch(ctx, (size_t)cap2 * sizeof(double), &lp))) return rc;
+        if ((rc = midas_scratch(ctx, (size_t)nb2 * sizeof(double), &bt))) return rc;
+        if ((rc = midas_scratch(ctx, (size_t)nb2 * sizeof(int32_t), &bn))) return rc;
+        hipLaunchKernelGGL(k_loop_scan, dim3(nb2), dim3(256), 0, st, (const int32_t*)s.ctl_i_dev, (const double*)s.x_dev,
                            (const double*)s.e_dev, (const uint8_t*)s.valid_dev, (const int32_t*)s.src_dev, (double*)lp, (double*)bt,
                            (int32_t*)bn);
         LoopResampleArgs r;
@@ -867,7 +1050,8 @@ int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree*
         r.poses_out = s.poses_dev; r.weights_out = s.weights_out_dev; r.hint_out = s.hint_dev; r.labels_out = s.labels_out_dev;
         r.ridx = s.ridx_dev; r.mode = s.resample_mode; r.u = s.u_dev; r.u32 = s.u32; r.seed = s.seed; r.step = s.step;
         r.log = s.log_dev; r.cluster_poses = s.cluster_poses_dev; r.cluster_stds = s.cluster_stds_dev;
-        hipLaunchKernelGGL(k_loop_resample, dim3((unsigned)ceil_div(cap, 256)), dim3(256), 0, st, r);
+        r.host_mirror = s.host_mirror;
+        hipLaunchKernelGGL(k_loop_resample, dim3((unsigned)ceil_div(cap2, 256)), dim3(256), 0, st, r);
         LAUNCH_CHECK(ctx);
     }
     return MIDAS_OK;

@@ -73,6 +73,11 @@ class LoopEngine:
         self.sparse_scores = self.codebook.emb.dtype == torch.float32 and self.D in (128, 256, 512, 1024) and \
             _os.environ.get("MIDAS_DENSE_SCORES", "0") != "1"
         self._stamps, self._epoch = z(self.K, torch.int32), 0  # sparse scoring (include/midas_hip.h score_stamps_dev)
+        # {frames completed, live count} as the device last reported them, in pinned host memory: lets step() size its launches
+        # to the live set without waiting for anything (an upper bound is all it needs, see _count_bound)
+        self._mirror = torch.zeros(2, dtype=torch.int32).pin_memory()
+        self._frames_at_reset, self._n_at_reset, self._steps_at_reset, self._grid_n = 0, cap, 0, cap
+        self.max_ahead = 1         # frames the host may enqueue ahead of the device's last report (None: no limit)
         self.step_count = 0        # frames enqueued (Philox counter, log row)
         self._n_host = None        # particle count as last known by the host (None: ask the device)
         self._pending_phases = 0
@@ -107,6 +112,33 @@ class LoopEngine:
         self.ctl_i.copy_(ci)
         self._n_host = n
         self._pending_phases = 0
+        torch.cuda.current_stream(self.device).synchronize()  # the control block is in place, nothing older is in flight
+        self._mirror[0], self._mirror[1] = int(ci[_lib.LOOP_I_FRAME]), n
+        self._frames_at_reset, self._n_at_reset, self._steps_at_reset = int(ci[_lib.LOOP_I_FRAME]), n, self.step_count
+
+    def _count_bound(self) -> int:
+        """An upper bound of the live count at the start of the frame about to be enqueued, from what the device reported
+        last: annealing adds at most n // 3 particles per frame (particle_filter.py:437) and never exceeds the capacity."""
+        if not self.cluster:
+            return self._n_at_reset
+        enq = self.step_count - self._steps_at_reset
+        # stay at most `max_ahead` frames in front of the device: the bound below grows by 4/3 per unreported frame, and a
+        # host that runs dozens of frames ahead could only ever assume the full capacity.  One frame in the queue while the
+        # next is being enqueued keeps the device busy (enqueueing a frame takes less than running it); the wait is a look
+        # at pinned memory.
+        if self.max_ahead is not None and enq - (int(self._mirror[0]) - self._frames_at_reset) > self.max_ahead:
+            import time
+            t0 = time.perf_counter()
+            while enq - (int(self._mirror[0]) - self._frames_at_reset) > self.max_ahead and time.perf_counter() - t0 < 0.05:
+                pass
+        done = int(self._mirror[0]) - self._frames_at_reset   # frames of this run the device has finished
+        n = int(self._mirror[1]) if done > 0 else self._n_at_reset
+        lag = (self.step_count - self._steps_at_reset) - max(done, 0)  # frames enqueued since that report
+        for _ in range(max(lag, 0)):
+            n += n // 3
+            if n >= self.cap:
+                return self.cap
+        return min(n, self.cap)
 
     def set_annealing_state(self, particle_var: float, init_particles: int):
         """particle_filter.particle_var / init_particles (particle_filter.py:413-417) - for restarts and tests."""
@@ -203,6 +235,11 @@ class LoopEngine:
         a.prune_thr, a.softmax, a.resample_mode = self.pen_max, int(self.softmax), self.mode
         a.floor, a.eps = self.floor, self.eps
         a.unit_weights = int(bool(unit_weights))
+        if frame_start:
+            self._grid_n = self._count_bound()
+        a.host_mirror = C.c_void_p(self._mirror.data_ptr())
+        a.grid_n = self._grid_n
+        a.anneal_small = int(self._grid_n <= 16384)
         a.telemetry = _ptr(self.telemetry)
         if self.sparse_scores and phases & _lib.LOOP_FRONT:
             self._epoch += 1

@@ -69,9 +69,14 @@ def test_dbscan_matches_oracle(dev, oracle, case):
 
 
 # ---- annealing selection ----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n", [5, 100, 4096, 4097, 10000, 100000])
-def test_anneal_select_matches_stable_argsort(dev, n):
+@pytest.mark.parametrize("small", [0, 1])
+@pytest.mark.parametrize("n", [5, 100, 1024, 1025, 4096, 4097, 10000, 16384, 100000])
+def test_anneal_select_matches_stable_argsort(dev, n, small, monkeypatch):
+    """small = 1: the single-workgroup path of the loop engine (n <= 16384) on the same plans."""
     from midastouch_amd import ops
+    if small and n > 16384:
+        pytest.skip("single-workgroup path holds 16384 particles")
+    monkeypatch.setenv("MIDAS_ANNEAL_SMALL", str(small))
     rng = np.random.default_rng(n)
     sets = {
         "distinct": rng.permutation(n).astype(np.float64) + 1.0,

@@ -32,6 +32,8 @@ for cluster, draws, floor in ((True, "device", 1000), (True, "device", 100000), 
                       "frames_per_s_steady": round(len(steady) / sum(steady), 1),
                       "ms_per_frame_steady": round(1e3 * sum(steady) / len(steady), 4),
                       "ms_frame_max_steady": round(1e3 * max(steady), 3),
+                      "slowest_frames": sorted(((round(1e3 * t, 3), i + 2) for i, t in enumerate(steady)), reverse=True)[:4],
+                      "ms_per_frame_median": round(1e3 * sorted(steady)[len(steady) // 2], 4),
                       "host_enqueue_ms": round(1e3 * st["avg_timer"]["host_enqueue"], 4),
                       "N_final": st["num_particles"][-1], "N_min": min(st["num_particles"]),
                       "rmse_t_mm_final": round(1e3 * st["rmse_t"][-1], 2)}))
