@@ -410,7 +410,7 @@ static int filter_step_impl(midas_ctx* ctx, const midas_codebook* cb, const mida
     // concurrently with the particle update, which does not need the scores; the fork / join events cost ~8 us,
     // the overlap saves the ~60 us of the scoring.
     const bool defer_batch = mfma && ctx->overlap;
-    if ((B == 1 && ctx->overlap) || defer_batch)
+    if ((B == 1 && ctx->overlap) || defer_batch || (B > 1 && s.score_stamps_dev))
         if ((rc = midas_scratch(ctx, Bz * N * sizeof(double), &lp_raw))) return rc;
     if (defer_batch && !ctx->side) {
         MIDAS_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
@@ -452,11 +452,25 @@ static int filter_step_impl(midas_ctx* ctx, const midas_codebook* cb, const mida
     pa.part_rmse = (double*)prm;
     if (B == 1 && s.score_stamps_dev && s.score_epoch) { pa.sp.stamps = s.score_stamps_dev; pa.sp.epoch = s.score_epoch; }
     bool defer = false;
+    // a batch with stamps (B x K of them): every trajectory's particle waves score the rows they need from its own code -
+    // the float64 arithmetic of the single-trajectory step, no matrix-core pass, no side stream
+    const bool sparse_batch = B > 1 && s.score_stamps_dev && s.score_epoch && cb->dtype == MIDAS_F32 &&
+                              (cb->D == 128 || cb->D == 256 || cb->D == 512 || cb->D == 1024) && (uintptr_t)cb->emb % 16 == 0 &&
+                              (uintptr_t)s.code_dev % 16 == 0;
+    if (sparse_batch) {
+        pa.sp.stamps = s.score_stamps_dev; pa.sp.epoch = s.score_epoch;
+        pa.sp.emb = (const float*)cb->emb; pa.sp.norms = cb->norms; pa.sp.code = s.code_dev; pa.sp.scores = (double*)scores;
+        pa.sp.nj = cb->D / 64;
+        pa.scores = nullptr;  // deferred: the tail gathers the scores
+        prof_mark(ctx, 1);
+        if ((rc = launch_particle_update(ctx, tree6, tree3, pa))) return rc;
+        defer = true;
+    }
     if (B == 1 && ctx->overlap) {
         prof_mark(ctx, 1);  // fused front: reported in the particle_update slot, the score slot stays empty
         if ((rc = launch_frame_front(ctx, tree6, tree3, pa, cb, s.code_dev, (double*)scores, &defer))) return rc;
     }
-    if (defer_batch) {
+    if (defer_batch && !sparse_batch) {
         hipStream_t main_stream = ctx->stream;
         MIDAS_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, main_stream));  // the codes, and last frame's readers of `scores`
         MIDAS_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));

@@ -1246,6 +1246,9 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
         if (a.scores) { a.scores += b * a.score_stride; a.x += o; a.e += o; a.part_max += b * nwaves; a.part_min += b * nwaves; }
         if (a.gt16) { a.gt16 += b * 16; a.part_rmse += 2 * b * nwaves; }
         if (a.status_reset) a.status_reset += 2 * b;
+        if (a.sp.stamps) {  // sparse scoring per trajectory: its own stamps, tactile code and score row
+            a.sp.stamps += b * a.score_stride; a.sp.scores += b * a.score_stride; a.sp.code += b * (int64_t)(a.sp.nj * 64);
+        }
         a.slot_base += o;
     }
     const int64_t n = wave * 64 + lane;

@@ -386,6 +386,13 @@ class BatchFilterEngine:
         self.rmse = torch.zeros((B, 2), dtype=torch.float64, device=d)
         self.telemetry = torch.zeros(16, dtype=torch.int64, device=d)
         self.step_count = 0
+        # sparse scoring per trajectory (B x K stamps): the particle waves score the rows their trajectory needs with the
+        # float64 arithmetic of the single-trajectory step; MIDAS_DENSE_SCORES=1 keeps the matrix-core pass over all rows
+        import os as _os
+        self.sparse_scores = self.codebook.emb.dtype == torch.float32 and self.codebook.D in (128, 256, 512, 1024) and \
+            _os.environ.get("MIDAS_DENSE_SCORES", "0") != "1"
+        self._stamps = torch.zeros((B, self.codebook.K), dtype=torch.int32, device=d) if self.sparse_scores else None
+        self._epoch = 0
 
     def set_particles(self, poses):
         poses = torch.as_tensor(poses).to(self.device, torch.float32)
@@ -420,6 +427,9 @@ class BatchFilterEngine:
         a.std_t, a.std_r, a.seed, a.step = self.sig_t, self.sig_r, self.seed, self.step_count
         a.prune_thr, a.softmax, a.resample_mode = self.pen_max, int(self.softmax), self.mode
         a.status, a.telemetry = _ptr(self.status), _ptr(self.telemetry)
+        if self.sparse_scores:
+            self._epoch += 1
+            a.score_stamps, a.score_epoch = _ptr(self._stamps), self._epoch
         self._keep = (odoms, codes, gts, tn, rot, u)
         self.ctx.bind_current_stream()
         self.ctx.check(self.ctx.lib.midas_filter_step_batch(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h,

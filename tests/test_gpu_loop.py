@@ -280,3 +280,31 @@ def test_filter_runner_device_draws_tracks_and_anneals(dev):
     assert min(stats["num_particles"]) >= 1000 and min(stats["num_particles"]) < 20000  # annealed
     assert all(f["err"] == 0 for f in stats["frames"])
     assert stats["frames"][0]["mode"] == 0 and any(f["mode"] == 1 for f in stats["frames"])
+
+
+@pytest.mark.parametrize("N0", [1, 7, 63, 300, 1025])
+def test_loop_engine_tiny_particle_sets(dev, oracle, N0):
+    """Edge sizes: one particle, less than a chunk, less than a wave, a few hundred (floor above the count: annealing can only
+    add), just over a tile of the single-workgroup annealing - every frame against the oracle's loop body."""
+    from midastouch_amd.loop_engine import LoopEngine
+    from midastouch_amd.synthetic import make_codebook, make_trajectory
+    K, D, T, seed = 1500, 128, 12, 77
+    cb = make_codebook(K=K, D=D, seed=1021, mesh_points=8000)
+    traj = make_trajectory(cb, T=T + 1, seed=2021)
+    rng = np.random.default_rng(N0)
+    d0 = np.linalg.norm(cb.poses[:, :3, 3] - traj.gt_poses[0][:3, 3], axis=1)
+    poses = cb.poses[rng.choice(np.argsort(d0)[:200], N0)]
+    floor = max(N0 // 2, 1)
+    loop = oracle.OracleLoop(cb.poses, cb.embeddings, cb.mesh_vertices, floor=floor, cluster_every=3)
+    eng = LoopEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N0, seed=seed, floor=floor, cluster_every=3, device=dev)
+    eng.set_particles(torch.as_tensor(poses))
+    labels = np.zeros(N0, dtype=np.int64)
+    for t in range(T):
+        n = poses.shape[0]
+        tn, rot = oracle.philox_noise(n, seed, t, np.float32(2e-4), np.float32(0.5))
+        ref = loop.step(poses, labels, traj.odoms[t + 1], traj.codes[t + 1], tn, rot, gt=traj.gt_poses[t + 1],
+                        draws=lambda n2: oracle.philox_uniform64(n2, seed, t))
+        eng.step(torch.as_tensor(traj.odoms[t + 1]), torch.as_tensor(traj.codes[t + 1]), gt=torch.as_tensor(traj.gt_poses[t + 1]))
+        _compare_frame(eng.frame_view(), ref, t, t % 3 == 0)
+        poses, labels = ref["poses"], ref["labels"]
+    assert int(eng.ctl_i[14].item()) == 0  # no limit / bound error flagged

@@ -238,7 +238,9 @@ def test_step_full_size_properties(dev):
         assert torch.equal(d.argmin(dim=1).int(), eng.nn_idx[:512])
 
 
-def test_batch_engine_matches_oracle_per_trajectory(dev, oracle):
+@pytest.mark.parametrize("dense", ["0", "1"])
+def test_batch_engine_matches_oracle_per_trajectory(dev, oracle, dense, monkeypatch):
+    monkeypatch.setenv("MIDAS_DENSE_SCORES", dense)  # 1: the matrix-core pass over all rows; 0: sparse, per trajectory
     """BASELINE config 5 shape (B trajectories per frame): each trajectory of the batch equals the oracle run with
     the matrix-core scores and the Philox streams keyed by b*N + n - indices exact, weights 1e-12."""
     from midastouch_amd.engine import BatchFilterEngine
@@ -256,7 +258,9 @@ def test_batch_engine_matches_oracle_per_trajectory(dev, oracle):
         codes = torch.as_tensor(np.stack([tr.codes[t] for tr in trajs])).to(dev)
         gts = torch.as_tensor(np.stack([tr.gt_poses[t] for tr in trajs])).to(dev)
         eng.step(odoms, codes, gts)
-        sc = oracle.score_codebook_batch(cb.embeddings, codes.cpu().numpy())
+        # sparse scoring (default): the float64 scores of the single-trajectory step; dense: the matrix-core order
+        sc = (np.stack([oracle.score_codebook(cb.embeddings, c) for c in codes.cpu().numpy()]) if eng.sparse_scores
+              else oracle.score_codebook_batch(cb.embeddings, codes.cpu().numpy()))
         tn_all, rot_all = oracle.philox_noise(B * N, 4000, t - 1, np.float32(1e-4), np.float32(0.5))
         u_all = oracle.philox_uniform64(B * N, 4000, t - 1)
         for b in range(B):
