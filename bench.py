@@ -328,6 +328,9 @@ def main():
                                "device Philox draws, %s resample" % (N, K, D, "multinomial" if args.resample == "weighted_random" else "systematic"),
                    "particles_per_gpu": N, "particles_total": N * world, "codebook_rows": K, "embedding_dim": D,
                    "parallelism": "particle-sharded x%d" % world if sharded else "single",
+                   # weak scaling: `value` counts a frame of the G x N-particle filter as G steps of N particles; the frame
+                   # rate of that one global filter is value / G
+                   "global_filter_frames_per_sec": args.steps / dt,
                    "engine": ("sharded, exchange=" + eng.exchange) if sharded else ("eager: 3 launches/frame" if args.eager else
                                                         "pipelined: resample of frame t folded into the front kernel of frame t+1, 2 launches/frame"),
                    "arith": "f32 poses/NN, f64 scores/weights/CDF", "last_status": status,

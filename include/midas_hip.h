@@ -250,6 +250,9 @@ typedef struct midas_lazy_args {
     uint64_t* telemetry_dev;           /* NULL or 16 cumulative counters (see midas_step_args) */
     uint32_t* score_stamps_dev;        /* sparse scoring, see midas_step_args (midas_lazy_run advances the epoch by one per frame) */
     uint32_t score_epoch;
+    double* rmse_dev;                  /* NULL or 3 out (needs gt16_dev, part_rmse_dev): this frame's {rmse_t, rmse_r, device clock
+                                        * in us} - particle_rmse is taken on the propagated particles (filter.py:164), so the
+                                        * frame's own statistics exist without materialising its resample */
 } midas_lazy_args;
 int midas_lazy_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
                     const midas_lazy_args* args);

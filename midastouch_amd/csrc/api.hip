@@ -566,7 +566,7 @@ MIDAS_EXPORT int midas_lazy_step(midas_ctx* ctx, const midas_codebook* cb, const
                                  const midas_lazy_args* args) {
     MIDAS_ENTER(ctx);
     MIDAS_REQUIRE(ctx, cb && tree6 && tree3 && args && tree6->dim == 6 && tree3->dim == 3 && tree6->K == cb->K);
-    return lazy_step_impl(ctx, cb, tree6, tree3, *args, nullptr);
+    return lazy_step_impl(ctx, cb, tree6, tree3, *args, (args->gt16_dev && args->part_rmse_dev) ? args->rmse_dev : nullptr);
 }
 
 MIDAS_EXPORT int midas_lazy_run(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,

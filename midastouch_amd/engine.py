@@ -191,7 +191,15 @@ class PipelinedFilterEngine(FilterEngine):
     weights_res = _materialised("weights_res")
     hint = _materialised("hint")
     ridx = _materialised("ridx")
-    rmse = _materialised("rmse")
+
+    @property
+    def rmse(self):
+        """rmse of the latest frame's propagated particles (filter.py:164): written by the frame itself, no materialisation."""
+        return self._rmse_frame[:2] if self._pending else self._rmse
+
+    @rmse.setter
+    def rmse(self, v):
+        self._rmse = v
 
     def __init__(self, *args, **kw):
         self._pending = False
@@ -212,6 +220,7 @@ class PipelinedFilterEngine(FilterEngine):
         self._cur = 0
         self._draw = (None, -1.0, 0)
         self._had_gt = False
+        self._rmse_frame = torch.zeros(3, **f64)
 
     # the latest frame's own outputs
     @property
@@ -272,6 +281,7 @@ class PipelinedFilterEngine(FilterEngine):
         a.telemetry = _ptr(self.telemetry)
         if self.sparse_scores:
             a.score_stamps, a.score_epoch = _ptr(self._stamps), self._next_epoch()
+        a.rmse = _ptr(self._rmse_frame) if gt is not None else None
         self._keep = (odom, code, gt, tn, rot, pu)
         self.ctx.bind_current_stream()
         self.ctx.check(self.ctx.lib.midas_lazy_step(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h, C.byref(a)))
@@ -319,6 +329,8 @@ class PipelinedFilterEngine(FilterEngine):
         self.ctx.bind_current_stream()
         self.ctx.check(self.ctx.lib.midas_lazy_run(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h, C.byref(a), T, _ptr(log)))
         self.step_count += T
+        if log is not None:
+            self._rmse_frame.copy_(log[-1])
         self._draw = (None, -1.0, self.step_count - 1)
         self._had_gt = gts is not None
         self._pending, self._flushed = True, False

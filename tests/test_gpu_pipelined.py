@@ -166,11 +166,13 @@ def test_run_equals_stepping(dev):
     for t in range(1, 1 + T + 4):
         a.step(odoms[t], codes[t], gt=gts[t])
         if t in (3, 10):
-            rm.append(a.rmse.clone())  # materialises: the next frame starts unfolded, as run() must handle too
+            rm.append(a.rmse.clone())  # the frame's own statistic: no materialisation needed for it
+            a.flush()                  # ... this materialises: the next frame starts unfolded, as run() must handle too
     # b: three frames stepped, a flush, then runs of odd and even length, then single steps again
     for t in (1, 2, 3):
         b.step(odoms[t], codes[t], gt=gts[t])
     assert torch.equal(b.rmse, rm[0])
+    b.flush()
     log1 = b.run(odoms[4:11], codes[4:11], gts[4:11])          # 7 frames (odd)
     assert torch.equal(b.rmse, rm[1]) and torch.equal(log1[-1, :2], rm[1])
     assert (log1[1:, 2] > log1[:-1, 2]).all()  # device clock at the end of each frame
