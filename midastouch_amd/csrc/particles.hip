@@ -1269,7 +1269,7 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
     // frame's propagated poses
     int64_t src = n;
     if (rs_lds && live) {
-        src = lazy_source(a.rs, rs_lds, n, a.N);
+        src = (a.ablate & 8) ? n : lazy_source(a.rs, rs_lds, n, a.N);  // ablate 8 (profiling): no search, own slot
         if (a.rs.ridx_out) a.rs.ridx_out[n] = (int32_t)src;
     }
     const float* pose_src = rs_lds ? a.rs.poses_prev : a.poses_in;
