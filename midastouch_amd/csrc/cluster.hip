@@ -150,7 +150,10 @@ __global__ __launch_bounds__(256) void k_loop_cluster_moments(const int32_t* __r
 MD void jacobi4(double A[4][4], double V[4][4]) {
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) V[i][j] = i == j ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 32; ++sweep) {
+#ifndef MIDAS_JACOBI_SWEEPS
+#define MIDAS_JACOBI_SWEEPS 32
+#endif
+    for (int sweep = 0; sweep < MIDAS_JACOBI_SWEEPS; ++sweep) {
         double off = 0.0, dia = 0.0;
         for (int i = 0; i < 4; ++i) {
             dia += A[i][i] * A[i][i];

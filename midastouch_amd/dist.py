@@ -216,18 +216,35 @@ class TorchDistComm:
 
     def all_gather(self, t: torch.Tensor) -> torch.Tensor:
         t = t.contiguous()
-        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         if self._into:
+            out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
             self.dist.all_gather_into_tensor(out, t, group=self.group)
-        else:
-            self.dist.all_gather(list(out.chunk(self.world)), t, group=self.group)
-        return out
-
+            return out
+        # gloo (CPU tests, or several processes sharing one GPU): through host memory
+        h = t.cpu()
+        out = torch.empty((self.world * h.shape[0],) + tuple(h.shape[1:]), dtype=h.dtype)
+        self.dist.all_gather(list(out.chunk(self.world)), h, group=self.group)
+        return out.to(t.device)
 
     def all_to_all(self, send: torch.Tensor, in_splits, out_splits) -> torch.Tensor:
-        out = torch.empty((sum(out_splits),), dtype=send.dtype, device=send.device)
-        self.dist.all_to_all_single(out, send.contiguous(), list(out_splits), list(in_splits), group=self.group)
-        return out
+        if self._into:
+            out = torch.empty((sum(out_splits),), dtype=send.dtype, device=send.device)
+            self.dist.all_to_all_single(out, send.contiguous(), list(out_splits), list(in_splits), group=self.group)
+            return out
+        h = send.contiguous().cpu()
+        out = torch.empty((sum(out_splits),), dtype=h.dtype)
+        # gloo has no all_to_all_single on every build: the same exchange as point-to-point pairs
+        ins, outs = list(h.split(list(in_splits))), list(out.split(list(out_splits)))
+        reqs = []
+        for r in range(self.world):
+            if r == self.rank:
+                outs[r].copy_(ins[r])
+                continue
+            reqs.append(self.dist.isend(ins[r].clone(), r, group=self.group))
+            reqs.append(self.dist.irecv(outs[r], r, group=self.group))
+        for q in reqs:
+            q.wait()
+        return out.to(send.device)
 
 
 class SingleComm:

@@ -1,5 +1,7 @@
-"""Two real ranks over RCCL (one process per GPU): the particle-sharded frame, every exchange form, against the ORACLE's
-frame of all particles.  Needs two MI355X in the box; skips itself otherwise (the driver's 1-GPU tier)."""
+"""Two real ranks (one process each): the particle-sharded frame, every exchange form, against the ORACLE's frame of all
+particles.  Over RCCL with one GPU per process when the box has two MI355X (skips itself otherwise: the driver's 1-GPU
+tier); and on ONE GPU shared by the two processes with gloo carrying the exchanges - the whole multi-process path
+(HipShardBackend kernels, TorchDistComm, the exchange protocol) except RCCL's transport."""
 import os
 import socket
 
@@ -21,13 +23,16 @@ def _data():
     return cb, traj, start
 
 
-def _worker(rank, world, port, exchange, out_dir):
+def _worker(rank, world, port, exchange, out_dir, shared_gpu=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    dev = torch.device("cuda", 0 if shared_gpu else rank)
+    torch.cuda.set_device(dev)
+    if shared_gpu:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from midastouch_amd.dist import ShardedFilterEngine
     cb, traj, start = _data()
     eng = ShardedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N_LOC, seed=SEED, device=dev, exchange=exchange)
@@ -41,16 +46,13 @@ def _worker(rank, world, port, exchange, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["a2a_fixed", "a2a", "allgather"])
-def test_two_ranks_over_rccl_match_the_oracle(tmp_path, oracle, exchange):
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs two GPUs")
+def _run_and_check(tmp_path, oracle, exchange, shared_gpu):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(2, port, exchange, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, exchange, str(tmp_path), shared_gpu), nprocs=2, join=True)
     parts = [torch.load(os.path.join(str(tmp_path), f"r{r}.pt"), weights_only=False) for r in range(2)]
     cb, traj, start = _data()
     ofl = oracle.OracleFilter(cb.poses, cb.embeddings, cb.mesh_vertices)
@@ -64,3 +66,17 @@ def test_two_ranks_over_rccl_match_the_oracle(tmp_path, oracle, exchange):
         assert np.array_equal(got("ridx"), ref["ridx"]), t
         assert np.array_equal(got("poses"), ref["poses"]), t
         poses = ref["poses"]
+
+
+@pytest.mark.parametrize("exchange", ["a2a_fixed", "a2a", "allgather"])
+def test_two_ranks_over_rccl_match_the_oracle(tmp_path, oracle, exchange):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _run_and_check(tmp_path, oracle, exchange, shared_gpu=False)
+
+
+@pytest.mark.parametrize("exchange", ["a2a_fixed", "a2a", "allgather"])
+def test_two_processes_sharing_one_gpu_match_the_oracle(tmp_path, oracle, exchange):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _run_and_check(tmp_path, oracle, exchange, shared_gpu=True)
