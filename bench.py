@@ -144,7 +144,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-loop", action="store_true", help="skip the reference-named loop (filter() with clustering + annealing)")
     ap.add_argument("--sharded", action="store_true", help="use the particle-sharded engine even on one GPU (smoke test)")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "a2a", "a2a_fixed", "allgather"], help="sharded engine: form of the resample exchange")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "peer", "a2a", "a2a_fixed", "allgather"], help="sharded engine: form of the resample exchange")
     ap.add_argument("--eager", action="store_true", help="materialise the resampled particles every frame (three launches per frame)")
     ap.add_argument("--resample", default="weighted_random", choices=["weighted_random", "low_var"],
                     help="resampler mode (particle_filter.py:230-307): the reference's default multinomial draws, or systematic")
@@ -310,7 +310,7 @@ def main():
         loop_rate = reference_loop_rate(cb, traj, N, dev, tree, eng.tree3)
     exchange_info = None
     if sharded:
-        exchange_info = {"form": eng.exchange}
+        exchange_info = {"form": eng.exchange, "peer_mapping": "ok" if eng.exchange == "peer" else (eng.peer_error or "not tried")}
         if eng.exchange == "a2a_fixed":  # rows beyond the overflow block's capacity would have been lost: must not happen
             ov = eng.backend.overflow_rows(eng.st, world)
             exchange_info.update(segment_rows=eng.seg_cap, overflow_capacity=eng.ovf_cap, overflow_rows_last_frame=ov,

@@ -368,6 +368,12 @@ typedef struct midas_shard_route_args {
     void* ovf_dev;
     void* self_dev;                 /* fixed form: N x 88 bytes - the rows whose slot and source both live on this rank stay
                                      * here instead of travelling (unpacked like the others) */
+    /* Peer-mapped form of midas_shard_route_pack - no send buffer, no collective for the rows: peers_dev[d] is rank d's
+     * inbox (N x 88 bytes, midas_peer_alloc) as mapped into THIS process (midas_peer_open; the own inbox for d == rank);
+     * the owner of a slot's source stores the row straight into row `slot` of the destination's inbox (system-scope
+     * stores over xGMI).  Every slot of the filter has exactly one owner, so after a barrier across the ranks each inbox
+     * holds its N rows (midas_shard_unpack_peer).  NULL: the forms above. */
+    void* const* peers_dev;
 } midas_shard_route_args;
 int midas_shard_route_count(midas_ctx* ctx, const midas_shard_route_args* args);
 int midas_shard_route_pack(midas_ctx* ctx, const midas_shard_route_args* args);
@@ -377,6 +383,22 @@ int midas_shard_unpack(midas_ctx* ctx, int64_t N, const void* recv_dev, int32_t*
  * dest (the gathered overflow blocks) */
 int midas_shard_unpack_rows(midas_ctx* ctx, int64_t rows, const void* recv_dev, int32_t dest, int32_t* ridx_dev,
                             float* poses_out_dev, double* weights_out_dev, int32_t* hint_out_dev);
+/* ---- peer-mapped inboxes (the fourth exchange form; RCCL only carries the 1 KB block records and a barrier) ----
+ * midas_peer_alloc: `bytes` of fine-grained device memory (hipExtMallocWithFlags, what RCCL uses for buffers its peers
+ * write) + the 64-byte interprocess handle other ranks open it with.  midas_peer_open maps another process's inbox
+ * (hipIpcOpenMemHandle, lazy peer access over xGMI; a process on the SAME device works too - the shared-GPU test).
+ * midas_peer_probe_write / _check: start-up self test of the data path - every rank stores {nonce, rank} into row
+ * `rank` of every inbox, barrier, every rank checks its G rows (ok_dev[0] = 1 when all match) - run twice with different
+ * nonces so that a stale cached line would be caught; the caller falls back to the collective forms if any rank fails. */
+int midas_peer_alloc(midas_ctx* ctx, int64_t bytes, void** ptr_out, void* handle64_out);
+int midas_peer_free(midas_ctx* ctx, void* ptr);
+int midas_peer_open(midas_ctx* ctx, const void* handle64, void** ptr_out);
+int midas_peer_close(midas_ctx* ctx, void* ptr);
+int midas_peer_probe_write(midas_ctx* ctx, void* const* peers_dev, int32_t G, int32_t rank, int32_t nonce);
+int midas_peer_probe_check(midas_ctx* ctx, const void* inbox_dev, int32_t G, int32_t nonce, int32_t* ok_dev);
+/* the N rows of this rank's inbox -> slots (reads that bypass the non-coherent caches) */
+int midas_shard_unpack_peer(midas_ctx* ctx, int64_t N, const void* inbox_dev, int32_t* ridx_dev, float* poses_out_dev,
+                            double* weights_out_dev, int32_t* hint_out_dev);
 /* ---- the all_gather form of the exchange (every rank materialises its slice of the global CDF and gathers every
  * shard's packed block; G-1 times the bytes of the owner-side form, no read-back of counts) ---- */
 /* midas_shard_tail_fin: softmax applied unless softmax == 0 or |max x - min x| over r1_all <= 1e-8 (then e := x);

@@ -120,6 +120,7 @@ class ShardRouteArgs(C.Structure):
         ("seed", C.c_uint64), ("step", C.c_uint64),
         ("counts", C.c_void_p), ("send", C.c_void_p), ("weights", C.c_void_p),
         ("fixed_cap", C.c_int64), ("ovf_cap", C.c_int64), ("ovf", C.c_void_p), ("self_rows", C.c_void_p),
+        ("peers", C.c_void_p),
     ]
 
 
@@ -209,6 +210,13 @@ SIGNATURES = {
     "midas_shard_route_pack": (C.c_int, [_P, C.POINTER(ShardRouteArgs)]),
     "midas_shard_unpack": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P]),
     "midas_shard_unpack_rows": (C.c_int, [_P, _I64, _P, _I32, _P, _P, _P, _P]),
+    "midas_shard_unpack_peer": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P]),
+    "midas_peer_alloc": (C.c_int, [_P, _I64, C.POINTER(C.c_void_p), _P]),
+    "midas_peer_free": (C.c_int, [_P, _P]),
+    "midas_peer_open": (C.c_int, [_P, _P, C.POINTER(C.c_void_p)]),
+    "midas_peer_close": (C.c_int, [_P, _P]),
+    "midas_peer_probe_write": (C.c_int, [_P, _P, _I32, _I32, _I32]),
+    "midas_peer_probe_check": (C.c_int, [_P, _P, _I32, _I32, _P]),
     "midas_tail_resample": (C.c_int, [_P, C.POINTER(TailResampleArgs)]),
     "midas_profile_enable": (C.c_int, [_P, _I32]),
     "midas_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64), _I32]),

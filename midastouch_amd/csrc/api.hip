@@ -805,8 +805,8 @@ static int shard_route(midas_ctx* ctx, const midas_shard_route_args* args, bool 
     MIDAS_REQUIRE(ctx, s.N >= 256 && s.G > 0 && s.G <= 64 && s.rank >= 0 && s.rank < s.G && s.r1_all_dev && s.tables_dev &&
                            (uintptr_t)s.tables_dev % 128 == 0 && s.valid_dev && s.nn_idx_dev && s.poses_prop_dev && s.status_dev &&
                            s.counts_dev);
-    MIDAS_REQUIRE(ctx, !pack || (s.send_dev && s.weights_dev && (uintptr_t)s.send_dev % 8 == 0));
-    MIDAS_REQUIRE(ctx, !pack || s.fixed_cap == 0 || (s.fixed_cap > 0 && s.ovf_cap > 0 && s.ovf_dev && (uintptr_t)s.ovf_dev % 8 == 0 && s.self_dev && (uintptr_t)s.self_dev % 8 == 0 &&
+    MIDAS_REQUIRE(ctx, !pack || (s.weights_dev && (s.peers_dev || (s.send_dev && (uintptr_t)s.send_dev % 8 == 0))));
+    MIDAS_REQUIRE(ctx, !pack || s.peers_dev || s.fixed_cap == 0 || (s.fixed_cap > 0 && s.ovf_cap > 0 && s.ovf_dev && (uintptr_t)s.ovf_dev % 8 == 0 && s.self_dev && (uintptr_t)s.self_dev % 8 == 0 &&
                                                      s.G * s.fixed_cap < ((int64_t)1 << 31)));
     MIDAS_REQUIRE(ctx, s.resample_mode == MIDAS_RESAMPLE_MULTINOMIAL || s.resample_mode == MIDAS_RESAMPLE_SYSTEMATIC);
     return launch_shard_route(ctx, s, shard_tables_of(const_cast<double*>(s.tables_dev), s.N), pack);
@@ -834,6 +834,66 @@ MIDAS_EXPORT int midas_shard_unpack_rows(midas_ctx* ctx, int64_t rows, const voi
     MIDAS_ENTER(ctx);
     MIDAS_REQUIRE(ctx, rows > 0 && recv_dev && (uintptr_t)recv_dev % 8 == 0 && ridx_dev && poses_out_dev && weights_out_dev && hint_out_dev);
     return launch_shard_unpack(ctx, rows, recv_dev, ridx_dev, poses_out_dev, weights_out_dev, hint_out_dev, dest);
+}
+
+MIDAS_EXPORT int midas_shard_unpack_peer(midas_ctx* ctx, int64_t N, const void* inbox_dev, int32_t* ridx_dev, float* poses_out_dev,
+                                         double* weights_out_dev, int32_t* hint_out_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, N > 0 && inbox_dev && (uintptr_t)inbox_dev % 8 == 0 && ridx_dev && poses_out_dev && weights_out_dev && hint_out_dev);
+    return launch_shard_unpack_peer(ctx, N, inbox_dev, ridx_dev, poses_out_dev, weights_out_dev, hint_out_dev);
+}
+
+MIDAS_EXPORT int midas_peer_alloc(midas_ctx* ctx, int64_t bytes, void** ptr_out, void* handle64_out) {
+    MIDAS_ENTER(ctx);
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the interprocess handle is 64 bytes");
+    MIDAS_REQUIRE(ctx, bytes > 0 && ptr_out && handle64_out);
+    void* p = nullptr;
+    MIDAS_HIP_CHECK(ctx, hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained));
+    hipIpcMemHandle_t h;
+    const hipError_t e = hipIpcGetMemHandle(&h, p);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        MIDAS_HIP_CHECK(ctx, e);
+    }
+    MIDAS_HIP_CHECK(ctx, hipMemsetAsync(p, 0, (size_t)bytes, ctx->stream));
+    memcpy(handle64_out, &h, 64);
+    *ptr_out = p;
+    return MIDAS_OK;
+}
+
+MIDAS_EXPORT int midas_peer_free(midas_ctx* ctx, void* ptr) {
+    MIDAS_ENTER(ctx);
+    if (ptr) MIDAS_HIP_CHECK(ctx, hipFree(ptr));
+    return MIDAS_OK;
+}
+
+MIDAS_EXPORT int midas_peer_open(midas_ctx* ctx, const void* handle64, void** ptr_out) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, handle64 && ptr_out);
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, 64);
+    void* p = nullptr;
+    MIDAS_HIP_CHECK(ctx, hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    *ptr_out = p;
+    return MIDAS_OK;
+}
+
+MIDAS_EXPORT int midas_peer_close(midas_ctx* ctx, void* ptr) {
+    MIDAS_ENTER(ctx);
+    if (ptr) MIDAS_HIP_CHECK(ctx, hipIpcCloseMemHandle(ptr));
+    return MIDAS_OK;
+}
+
+MIDAS_EXPORT int midas_peer_probe_write(midas_ctx* ctx, void* const* peers_dev, int32_t G, int32_t rank, int32_t nonce) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, peers_dev && G > 0 && G <= 64 && rank >= 0 && rank < G);
+    return launch_peer_probe(ctx, peers_dev, nullptr, G, rank, nonce, nullptr);
+}
+
+MIDAS_EXPORT int midas_peer_probe_check(midas_ctx* ctx, const void* inbox_dev, int32_t G, int32_t nonce, int32_t* ok_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, inbox_dev && G > 0 && G <= 64 && ok_dev);
+    return launch_peer_probe(ctx, nullptr, inbox_dev, G, 0, nonce, ok_dev);
 }
 
 MIDAS_EXPORT int midas_tail_resample(midas_ctx* ctx, const midas_tail_resample_args* args) {

@@ -1181,7 +1181,19 @@ struct ShardRouteArgs {
     char* ovf = nullptr;
     int32_t* ovf_count = nullptr;
     char* self_rows = nullptr;  // [N] the rows this rank owns AND needs (they never travel)
+    // peer-mapped form: row `slot` of the destination's inbox, written in place (fine-grained memory, system-scope stores)
+    char* const* peers = nullptr;
 };
+
+// 8-byte pieces of a record in memory other agents write or read: stores / loads that bypass the non-coherent caches
+__device__ __forceinline__ void sys_store8(void* p, unsigned long long v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long sys_load8(const void* p) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long pack2(int lo, int hi) { return (unsigned long long)(unsigned)lo | ((unsigned long long)(unsigned)hi << 32); }
+__device__ __forceinline__ unsigned long long pack2f(float lo, float hi) { return pack2(__float_as_int(lo), __float_as_int(hi)); }
 
 template <bool PACK>
 __global__ __launch_bounds__(256) void k_shard_route(ShardRouteArgs a) {
@@ -1255,7 +1267,7 @@ __global__ __launch_bounds__(256) void k_shard_route(ShardRouteArgs a) {
     }
     const bool bad_total = !(total == total) || total == 0.0;
     const bool usable = s_tot[2] == 0.0 && !bad_total;
-    if ((!PACK || a.fixed_cap) && blockIdx.x == 0 && t == 0) {
+    if ((!PACK || a.fixed_cap || a.peers) && blockIdx.x == 0 && t == 0) {
         double kept = 0.0, st2 = 0.0, sr2 = 0.0;
         for (int r = 0; r < a.G; ++r) {
             const double* fl = a.r1_all + (int64_t)r * rec + 5 * a.nb;
@@ -1317,10 +1329,12 @@ __global__ __launch_bounds__(256) void k_shard_route(ShardRouteArgs a) {
     const bool mine = live && o == a.rank;
     const int d0 = (int)(((int64_t)blockIdx.x * 256) / N);  // a workgroup spans at most two destinations (N >= 256)
     int pos = 0;
-    if (mine) pos = atomicAdd(&s_cnt[d - d0], 1);
-    __syncthreads();
-    if (t < 2 && s_cnt[t]) s_base[t] = atomicAdd(&a.cursor[d0 + t], s_cnt[t]);
-    __syncthreads();
+    if (!a.peers) {
+        if (mine) pos = atomicAdd(&s_cnt[d - d0], 1);
+        __syncthreads();
+        if (t < 2 && s_cnt[t]) s_base[t] = atomicAdd(&a.cursor[d0 + t], s_cnt[t]);
+        __syncthreads();
+    }
     if (mine) {
         int64_t src;
         if (!usable) src = i - (int64_t)a.rank * N;  // the resampler keeps the particles
@@ -1328,6 +1342,20 @@ __global__ __launch_bounds__(256) void k_shard_route(ShardRouteArgs a) {
         else
             src = search_in_block(apply ? a.lp : a.lp_raw, apply ? a.gend : a.gend_raw, apply ? a.ggend : a.ggend_raw,
                                   b - a.rank * a.nb, N, a.rank == a.G - 1 ? N - 1 : -1, s_bp[b], total, tq, upper);
+        if (a.peers) {  // straight into the slot's row of the destination's inbox
+            char* rp = a.peers[d] + (size_t)(i - (int64_t)d * N) * ROUTE_REC;
+            const float4* ps = reinterpret_cast<const float4*>(a.poses_prop + src * 16);
+            const float4 r0 = ps[0], r1 = ps[1], r2 = ps[2], r3 = ps[3];
+            const double w = (ev[src] / S) * (a.valid[src] ? 1.0 : 0.0);
+            sys_store8(rp, pack2((int)(i - (int64_t)d * N), (int)((int64_t)a.rank * N + src)));
+            sys_store8(rp + 8, pack2(a.nn_idx[src], d));
+            sys_store8(rp + 16, (unsigned long long)__double_as_longlong(w));
+            sys_store8(rp + 24, pack2f(r0.x, r0.y)); sys_store8(rp + 32, pack2f(r0.z, r0.w));
+            sys_store8(rp + 40, pack2f(r1.x, r1.y)); sys_store8(rp + 48, pack2f(r1.z, r1.w));
+            sys_store8(rp + 56, pack2f(r2.x, r2.y)); sys_store8(rp + 64, pack2f(r2.z, r2.w));
+            sys_store8(rp + 72, pack2f(r3.x, r3.y)); sys_store8(rp + 80, pack2f(r3.z, r3.w));
+            return;
+        }
         char* rp = a.send + (size_t)(s_soff[d] + s_base[d - d0] + pos) * ROUTE_REC;
         if (a.fixed_cap && d == a.rank) {  // own slot, own source: stays here (systematic draws are mostly of this kind)
             rp = a.self_rows + (size_t)(s_base[d - d0] + pos) * ROUTE_REC;
@@ -1377,10 +1405,55 @@ __global__ __launch_bounds__(256) void k_shard_unpack(int64_t N, const char* __r
     for (int k = 0; k < 8; ++k) pd[k] = v[k];
 }
 
+// the N rows other ranks stored into this rank's inbox (row r = slot r)
+__global__ __launch_bounds__(256) void k_shard_unpack_peer(int64_t N, const char* __restrict__ inbox, int32_t* __restrict__ ridx,
+                                                           float* __restrict__ poses_out, double* __restrict__ weights_out,
+                                                           int32_t* __restrict__ hint_out) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    const char* rp = inbox + (size_t)r * ROUTE_REC;
+    unsigned long long v[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) v[k] = sys_load8(rp + 8 * k);
+    ridx[r] = (int32_t)(v[0] >> 32);
+    hint_out[r] = (int32_t)(v[1] & 0xFFFFFFFFull);
+    weights_out[r] = __longlong_as_double((long long)v[2]);
+    unsigned long long* pd = reinterpret_cast<unsigned long long*>(poses_out + r * 16);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pd[k] = v[3 + k];
+}
+
+// start-up self test of the peer data path (include/midas_hip.h)
+__global__ void k_peer_probe_write(char* const* peers, int G, int rank, int nonce) {
+    const int d = threadIdx.x;
+    if (d < G) sys_store8(peers[d] + (size_t)rank * ROUTE_REC, pack2(nonce, rank));
+}
+__global__ void k_peer_probe_check(const char* inbox, int G, int nonce, int32_t* ok) {
+    const int r = threadIdx.x;
+    const bool good = r >= G || sys_load8(inbox + (size_t)r * ROUTE_REC) == pack2(nonce, r);
+    const bool all = __all(good);
+    if (r == 0) ok[0] = all ? 1 : 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 #define LAUNCH_CHECK(ctx) MIDAS_HIP_CHECK(ctx, hipGetLastError())
+
+int launch_shard_unpack_peer(midas_ctx* ctx, int64_t N, const void* inbox, int32_t* ridx, float* poses_out, double* weights_out,
+                             int32_t* hint_out) {
+    hipLaunchKernelGGL(k_shard_unpack_peer, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, N, (const char*)inbox, ridx,
+                       poses_out, weights_out, hint_out);
+    LAUNCH_CHECK(ctx);
+    return MIDAS_OK;
+}
+
+int launch_peer_probe(midas_ctx* ctx, void* const* peers, const void* inbox, int G, int rank, int nonce, int32_t* ok) {
+    if (peers) hipLaunchKernelGGL(k_peer_probe_write, dim3(1), dim3(64), 0, ctx->stream, (char* const*)peers, G, rank, nonce);
+    else hipLaunchKernelGGL(k_peer_probe_check, dim3(1), dim3(64), 0, ctx->stream, (const char*)inbox, G, nonce, ok);
+    LAUNCH_CHECK(ctx);
+    return MIDAS_OK;
+}
 
 int launch_gather_f64(midas_ctx* ctx, int64_t N, const double* table, const int32_t* idx, double* out) {
     if (N == 0) return MIDAS_OK;
@@ -1574,7 +1647,10 @@ int launch_shard_route(midas_ctx* ctx, const midas_shard_route_args& r, const Ta
     a.softmax = r.softmax; a.mode = r.resample_mode; a.u_all = r.u_all_dev; a.u32 = r.u32; a.seed = r.seed; a.step = r.step;
     a.counts = r.counts_dev; a.cursor = r.counts_dev + 2 * r.G; a.send = (char*)r.send_dev; a.weights = r.weights_dev;
     const unsigned grid = (unsigned)ceil_div((int64_t)r.G * r.N, 256);
-    if (pack && r.fixed_cap > 0) {  // one pass, no counts: padded segments + overflow block
+    if (pack && r.peers_dev) {  // rows stored straight into the destinations' inboxes
+        a.peers = (char* const*)r.peers_dev;
+        hipLaunchKernelGGL(k_shard_route<true>, dim3(grid), dim3(256), 0, ctx->stream, a);
+    } else if (pack && r.fixed_cap > 0) {  // one pass, no counts: padded segments + overflow block
         a.fixed_cap = r.fixed_cap; a.ovf_cap = r.ovf_cap; a.ovf = (char*)r.ovf_dev; a.ovf_count = r.counts_dev + 2 * r.G + r.G;
         a.self_rows = (char*)r.self_dev;
         MIDAS_HIP_CHECK(ctx, hipMemsetAsync(r.self_dev, 0xFF, (size_t)r.N * ROUTE_REC, ctx->stream));

@@ -13,6 +13,10 @@ its global reductions; between the local kernels the ranks exchange:
       total (the split sizes are read back from the device, one small synchronisation per frame).
       exchange="allgather": every rank materialises its slice of the global CDF and all ranks gather ONE packed block
       [cdf | weights | propagated poses | NN indices] (84 N bytes per rank, G-1 times the bytes, no read-back).
+      exchange="a2a_fixed": the owner-side form without the count pass (fixed-capacity segments + an overflow block).
+      exchange="peer": the owner stores the row straight into the destination's inbox, device memory every process of
+      the node has mapped (interprocess handles, xGMI); the ranks only gather the R1 record and a barrier word
+      (DESIGN.md section 5).
 
 The local kernels are the single-GPU ones: the fused front (particle update + codebook scoring in one launch)
 and the deferred tail that gathers the scores itself.
@@ -29,6 +33,7 @@ backend is HIP-only (`HipShardBackend`); tests may inject another one.  There is
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -155,6 +160,48 @@ class HipShardBackend:
         """Rows the last fixed-capacity frame put into its overflow block (more than its capacity: rows were lost)."""
         return int(st.counts[3 * world].item())
 
+    # ---- peer-mapped inboxes: the owner stores a row straight into the destination's memory ----------------------
+    def peer_alloc(self, st) -> torch.Tensor:
+        """This shard's inbox (N rows of fine-grained device memory) -> its 64-byte interprocess handle."""
+        ptr, h = C.c_void_p(), (C.c_ubyte * 64)()
+        self.ctx.call("midas_peer_alloc", st.N * ROUTE_REC, C.byref(ptr), h)
+        st._inbox, st._opened = ptr.value, []
+        return torch.tensor(list(h), dtype=torch.uint8)
+
+    def peer_open(self, st, handle: torch.Tensor) -> int:
+        ptr, h = C.c_void_p(), (C.c_ubyte * 64)(*[int(v) for v in handle.tolist()])
+        self.ctx.call("midas_peer_open", h, C.byref(ptr))
+        st._opened.append(ptr.value)
+        return ptr.value
+
+    def peer_table(self, st, ptrs):
+        st._peers = torch.tensor([int(p) for p in ptrs], dtype=torch.int64, device=self.device)
+
+    def peer_release(self, st):
+        for p in getattr(st, "_opened", []):
+            self.ctx.call("midas_peer_close", C.c_void_p(p))
+        if getattr(st, "_inbox", None):
+            self.ctx.call("midas_peer_free", C.c_void_p(st._inbox))
+        st._inbox, st._opened, st._peers = None, [], None
+
+    def peer_probe_write(self, st, rank, world, nonce):
+        self.ctx.call("midas_peer_probe_write", _ptr(st._peers), world, rank, nonce)
+
+    def peer_probe_check(self, st, world, nonce) -> torch.Tensor:
+        ok = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.ctx.call("midas_peer_probe_check", C.c_void_p(st._inbox), world, nonce, _ptr(ok))
+        return ok
+
+    def route_push(self, st, r1_all, rank, world, softmax, mode, u_all, u32, seed, step, want_rmse):
+        a = self._route_args(st, r1_all, rank, world, softmax, mode, u_all, u32, seed, step, want_rmse)
+        a.peers = _ptr(st._peers)
+        self.ctx.bind_current_stream()
+        self.ctx.check(self.ctx.lib.midas_shard_route_pack(self.ctx.h, C.byref(a)))
+
+    def unpack_peer(self, st):
+        self.ctx.call("midas_shard_unpack_peer", st.N, C.c_void_p(st._inbox), _ptr(st.ridx), _ptr(st.poses), _ptr(st.weights_res),
+                      _ptr(st.hint))
+
     def tail_resample(self, st, pack_all, n_all, mode, u, u32, seed, step):
         a = TailResampleArgs()
         a.N, a.N_all, a.slot_base = st.N, n_all, st.slot_base
@@ -202,6 +249,9 @@ class ShardState:
         self.telemetry.zero_()
         self.hint.fill_(-1)
         self.r1.zero_()
+        self.sync = e((1,), torch.int32)            # what the ranks gather as a barrier (peer-mapped exchange)
+        self.sync.zero_()
+        self._inbox = self._peers = None
 
 
 class TorchDistComm:
@@ -281,8 +331,8 @@ class ShardedFilterEngine:
                      "low_var_batch": _lib.RESAMPLE_SYSTEMATIC}[resample]
         self.step_count = 0
         self.use_hint = True
-        if exchange not in ("auto", "a2a", "a2a_fixed", "allgather"):
-            raise MidasError("exchange must be 'auto', 'a2a', 'a2a_fixed' or 'allgather'")
+        if exchange not in ("auto", "a2a", "a2a_fixed", "allgather", "peer"):
+            raise MidasError("exchange must be 'auto', 'peer', 'a2a', 'a2a_fixed' or 'allgather'")
         # a2a_fixed: per destination a segment of 1.5 x the expected N / G rows (after a resample every rank owns ~1 / G of
         # the weight mass), the rest through an overflow block of N / 4 rows that every rank gathers
         self.seg_cap = -(-int(1.5 * self.N / self.world + 64) // 8) * 8
@@ -294,6 +344,54 @@ class ShardedFilterEngine:
         # traffic is whatever the weight distribution makes it - counted exchange there)
         auto = "allgather" if self.world < 4 else ("a2a_fixed" if self.mode == _lib.RESAMPLE_MULTINOMIAL else "a2a")
         self.exchange = auto if exchange == "auto" else exchange
+        # "peer": rows stored straight into the destination's memory (inboxes mapped into every process, xGMI), RCCL only
+        # carries the block records and a barrier.  Ranks in separate processes connect here (a collective); it is what
+        # "auto" picks under RCCL when the start-up self test of the mapped path passes on every rank.  Shards of one process
+        # (tests) are wired with connect_local_peers().
+        self.peer_error = None
+        separate = isinstance(self.comm, TorchDistComm) and hasattr(self.backend, "peer_alloc")
+        if exchange == "peer" and separate:
+            if not self.connect_peers():
+                raise MidasError(f"peer-mapped exchange unavailable: {self.peer_error}")
+        elif exchange == "auto" and separate and self.world > 1 and getattr(self.comm, "_into", False) and os.environ.get("MIDAS_PEER_EXCHANGE", "1") != "0":
+            if self.connect_peers():
+                self.exchange = "peer"
+
+    def connect_peers(self) -> bool:
+        """Collective: allocate this rank's inbox, swap the interprocess handles, map the others' inboxes, run the self test
+        twice.  True when EVERY rank came through (otherwise everything is released again and `peer_error` says why)."""
+        b, st, G, dev = self.backend, self.st, self.world, self.st.poses.device
+        msg = torch.zeros(65, dtype=torch.uint8)
+        try:
+            msg[:64] = b.peer_alloc(st)
+            msg[64] = 1
+        except MidasError as e:
+            self.peer_error = f"rank {self.rank}: {e}"
+        all_msg = self.comm.all_gather(msg.to(dev)).cpu().view(G, 65)
+        ok = bool(all_msg[:, 64].all())
+        if ok:
+            try:
+                b.peer_table(st, [st._inbox if r == self.rank else b.peer_open(st, all_msg[r, :64]) for r in range(G)])
+            except MidasError as e:
+                ok, self.peer_error = False, f"rank {self.rank}: {e}"
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        ok = bool(self.comm.all_gather(flag).min().item())
+        if ok:
+            for nonce in (0x5EED0001, 0x5EED0002):  # twice: a line cached from the first round must not satisfy the second
+                b.peer_probe_write(st, self.rank, G, nonce)
+                self.comm.all_gather(st.sync)       # every rank has written
+                good = self.comm.all_gather(b.peer_probe_check(st, G, nonce))
+                if not bool(good.min().item()):
+                    ok, self.peer_error = False, "self test of the mapped path failed on ranks " + str((good == 0).nonzero().flatten().tolist())
+                    break
+        if not ok:
+            if self.peer_error is None:
+                self.peer_error = "another rank could not map the inboxes"
+            try:
+                b.peer_release(st)
+            except MidasError:
+                pass
+        return ok
 
     # convenience views used by bench.py / tests (same names as FilterEngine)
     poses = property(lambda self: self.st.poses)
@@ -353,6 +451,12 @@ class ShardedFilterEngine:
             recv = yield ("a2a", send, eq, eq)
             ovf_all = yield ovf
             b.unpack_fixed(st, recv, ovf_all, self.rank)
+        elif self.exchange == "peer":
+            if st._peers is None:
+                raise MidasError("peer-mapped exchange: the inboxes are not connected (connect_peers / connect_local_peers)")
+            b.route_push(st, r1_all, self.rank, G, self.softmax, self.mode, u, u32, self.seed, self.step_count, gt is not None)
+            yield st.sync  # barrier: every rank has stored the rows it owns (the reply is not looked at)
+            b.unpack_peer(st)
         else:
             b.tail_fin(st, r1_all, self.rank, G, self.N_total, self.softmax, gt is not None)
             pack_all = yield st.pack
@@ -373,6 +477,15 @@ class ShardedFilterEngine:
                 msg = gen.send(self._exchange(msg))
         except StopIteration:
             pass
+
+
+def connect_local_peers(engines):
+    """Wire the inboxes of shards that live in ONE process (tests, run_lockstep): plain pointers, nothing to map."""
+    for e in engines:
+        e.backend.peer_alloc(e.st)
+    for e in engines:
+        e.backend.peer_table(e.st, [o.st._inbox for o in engines])
+        e.exchange = "peer"
 
 
 def run_lockstep(engines, per_rank_args):

@@ -25,7 +25,7 @@ class FakeComm:
     all_to_all = all_gather
 
 
-@pytest.mark.parametrize("exchange", ["a2a", "allgather", "a2a_fixed", "a2a_fixed_tight"])
+@pytest.mark.parametrize("exchange", ["a2a", "allgather", "a2a_fixed", "a2a_fixed_tight", "peer"])
 @pytest.mark.parametrize("shards,mode", [(2, "weighted_random"), (3, "low_var"), (1, "weighted_random")])
 def test_sharded_hip_equals_fused_engine(dev, shards, mode, exchange):
     from midastouch_amd.dist import HipShardBackend, ShardedFilterEngine, run_lockstep
@@ -47,6 +47,9 @@ def test_sharded_hip_equals_fused_engine(dev, shards, mode, exchange):
     if tight:
         for e in engs:
             e.seg_cap = (n_loc // shards) * 7 // 8 // 8 * 8
+    if exchange == "peer":  # shards of one process: the inboxes are plain pointers
+        from midastouch_amd.dist import connect_local_peers
+        connect_local_peers(engs)
     for r, e in enumerate(engs):
         e.set_particles(torch.as_tensor(start[r * n_loc:(r + 1) * n_loc]))
         e.project_to_codebook()
@@ -95,7 +98,7 @@ def test_codebook_row_sharding_equals_replicated(dev):
         assert np.array_equal(cat("poses"), single.poses.cpu().numpy()), t
 
 
-@pytest.mark.parametrize("exchange", ["a2a", "allgather"])
+@pytest.mark.parametrize("exchange", ["a2a", "allgather", "peer"])
 def test_sharded_host_uniforms_replicated(dev, exchange):
     """Parity mode: the uniforms of ALL slots are given to every shard (both exchange forms)."""
     from midastouch_amd.dist import HipShardBackend, ShardedFilterEngine, run_lockstep
@@ -110,6 +113,9 @@ def test_sharded_host_uniforms_replicated(dev, exchange):
     single.set_particles(torch.as_tensor(start))
     be = HipShardBackend(cb.poses, cb.embeddings, cb.mesh_vertices, dev)
     engs = [ShardedFilterEngine(num_particles=n_loc, backend=be, comm=FakeComm(r, shards), exchange=exchange) for r in range(shards)]
+    if exchange == "peer":
+        from midastouch_amd.dist import connect_local_peers
+        connect_local_peers(engs)
     for r, e in enumerate(engs):
         e.set_particles(torch.as_tensor(start[r * n_loc:(r + 1) * n_loc]))
     for t in range(1, 5):

@@ -41,6 +41,7 @@ def _worker(rank, world, port, exchange, out_dir, shared_gpu=False):
     for t in range(1, FRAMES + 1):
         eng.step(torch.as_tensor(traj.odoms[t]).to(dev), torch.as_tensor(traj.codes[t]).to(dev), gt=torch.as_tensor(traj.gt_poses[t]).to(dev))
         res.append({k: getattr(eng, k).cpu().numpy().copy() for k in ("nn_idx", "weights", "ridx", "poses", "status", "rmse")})
+    res[0]["exchange"] = eng.exchange
     torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -54,6 +55,10 @@ def _run_and_check(tmp_path, oracle, exchange, shared_gpu):
     s.close()
     mp.spawn(_worker, args=(2, port, exchange, str(tmp_path), shared_gpu), nprocs=2, join=True)
     parts = [torch.load(os.path.join(str(tmp_path), f"r{r}.pt"), weights_only=False) for r in range(2)]
+    if exchange != "auto":
+        assert all(p[0]["exchange"] == exchange for p in parts)
+    else:  # under RCCL "auto" maps the inboxes when the start-up self test passes on both ranks
+        assert parts[0][0]["exchange"] == parts[1][0]["exchange"]
     cb, traj, start = _data()
     ofl = oracle.OracleFilter(cb.poses, cb.embeddings, cb.mesh_vertices)
     poses = start
@@ -68,14 +73,14 @@ def _run_and_check(tmp_path, oracle, exchange, shared_gpu):
         poses = ref["poses"]
 
 
-@pytest.mark.parametrize("exchange", ["a2a_fixed", "a2a", "allgather"])
+@pytest.mark.parametrize("exchange", ["peer", "auto", "a2a_fixed", "a2a", "allgather"])
 def test_two_ranks_over_rccl_match_the_oracle(tmp_path, oracle, exchange):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
     _run_and_check(tmp_path, oracle, exchange, shared_gpu=False)
 
 
-@pytest.mark.parametrize("exchange", ["a2a_fixed", "a2a", "allgather"])
+@pytest.mark.parametrize("exchange", ["peer", "a2a_fixed", "a2a", "allgather"])
 def test_two_processes_sharing_one_gpu_match_the_oracle(tmp_path, oracle, exchange):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
