@@ -688,16 +688,42 @@ MD void row_best(float& d, int& i) {
 #undef MIDAS_STEP
 }
 
-// Four owners at a time, one per 16-lane row: the row walks the next 64 records of its owner's list in four steps of
-// 16 (all eight loads per lane in flight together) and reduces inside the row with DPP - the four owners are
+// COOP_G owners at a time, one per group of 64 / COOP_G lanes: the group walks the next 64 records of its owner's list in
+// 64 / L steps of L (all the loads of a lane in flight together) and reduces inside the group with DPP - the owners are
 // evaluated by the same instructions, where the whole-wave form spent them once per owner.  The certificate is the
 // one of the 64-record chunk (its last record's rho against the final best); an owner it does not settle comes back
 // in the next pass with its next 64 records, until its list is exhausted (then: the list's outer radius, the twin).
+// A wave of c2 has ~10 open owners (up to ~20): with four per pass (16-lane rows) that was three to five dependent
+// round trips, with eight it is two or three.
+// 1: the stamps are requested before the prune and looked at after it.  Measured: slower (front 34 -> 45 us) - the particle
+// waves run in lock step, so with the look deferred nearly every wave still finds the old stamps and exchanges.
+#ifndef MIDAS_CLAIM_DEFER
+#define MIDAS_CLAIM_DEFER 0
+#endif
+#ifndef MIDAS_COOP_G
+#define MIDAS_COOP_G 8
+#endif
+constexpr int COOP_G = MIDAS_COOP_G, COOP_L = 64 / COOP_G, COOP_STEPS = 64 / COOP_L;
+static_assert(COOP_G == 4 || COOP_G == 8 || COOP_G == 16, "owners per pass");
+// minimum over a group of COOP_L lanes of (d, idx), ties to the smaller idx; every lane of the group gets the result
+MD void group_best(float& d, int& i) {
+#define MIDAS_STEP(CTRL)                                                              \
+    {                                                                                 \
+        const float od = __uint_as_float(dpp_u32<CTRL>(__float_as_uint(d)));          \
+        const int oi = (int)dpp_u32<CTRL>((uint32_t)i);                                \
+        if (od < d || (od == d && oi < i)) { d = od; i = oi; }                         \
+    }
+    MIDAS_STEP(DPP_XOR1) MIDAS_STEP(DPP_XOR2)
+    if (COOP_L >= 8) MIDAS_STEP(DPP_HALF_MIRROR)
+    if (COOP_L >= 16) MIDAS_STEP(0x140 /* row_mirror */)
+#undef MIDAS_STEP
+}
+
 MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_lane, float& best, int64_t& bi, bool need,
                  bool& done) {
-    const int lane = threadIdx.x & 63, row = lane >> 4, j = lane & 15;
+    const int lane = threadIdx.x & 63, grp = lane / COOP_L, j = lane % COOP_L;
     int nrec = NN_SOLO;  // next record of this lane's list (owners only)
-    // pass after pass: every open owner gets its next 64 records, four owners per instruction stream
+    // pass after pass: every open owner gets its next 64 records, COOP_G owners per instruction stream
     for (;;) {
         const bool open_lane = need && !done && nrec <= NBR_M;
         unsigned long long todo = __ballot(open_lane);
@@ -705,13 +731,13 @@ MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_
         const int my_rank = (int)__builtin_popcountll(todo & ((1ull << lane) - 1ull));  // rank among this pass's owners
         int served = 0;
         while (todo) {
-            int owner[4];
+            int mine = -1;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                owner[k] = todo ? (int)__builtin_ctzll(todo) : -1;
+            for (int k = 0; k < COOP_G; ++k) {
+                const int o = todo ? (int)__builtin_ctzll(todo) : -1;
                 todo &= todo - 1;  // 0 & anything stays 0
+                mine = grp == k ? o : mine;
             }
-            const int mine = row == 0 ? owner[0] : row == 1 ? owner[1] : row == 2 ? owner[2] : owner[3];
             const int src = mine >= 0 ? mine : lane;
             float qq[6];
 #pragma unroll
@@ -724,40 +750,40 @@ MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_
             const int hh = mine >= 0 ? hh_s : 0;
             const int first = mine >= 0 ? first_s : 0;  // records first .. first+63, clamped to the list
             const Nbr6* nb = tv.nbrs + (size_t)hh * NBR_REC;
-            Nbr6 e[4];
+            Nbr6 e[COOP_STEPS];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int s = first + 16 * m + j;
+            for (int m = 0; m < COOP_STEPS; ++m) {
+                const int s = first + COOP_L * m + j;
                 e[m] = nb[s <= NBR_M ? s : NBR_M];
             }
             float d = INFINITY, rho_last = 0.f;
             int id = 0x7fffffff;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < COOP_STEPS; ++m) {
                 Point6 p;
 #pragma unroll
                 for (int a = 0; a < 6; ++a) p.c[a] = e[m].c[a];
                 const float dm = dist2(qq, p);
-                const bool in = first + 16 * m + j <= NBR_M;
+                const bool in = first + COOP_L * m + j <= NBR_M;
                 if (in && (dm < d || (dm == d && e[m].idx < id))) { d = dm; id = e[m].idx; }  // NaN never wins
                 rho_last = in ? e[m].rho : rho_last;
             }
-            row_best(d, id);
+            group_best(d, id);
             if (d < bb || (d == bb && id < b_i)) { bb = d; b_i = id; }
             // largest rho scanned = the last valid record of the chunk (clamped loads repeat the list's last record);
             // once the list is exhausted the bound is the distance of the first entry NOT in it
-            rho_last = __shfl(rho_last, lane | 15);
+            rho_last = __shfl(rho_last, lane | (COOP_L - 1));
             const bool at_end = first + 63 >= NBR_M;
             const float bound = at_end ? tv.rho_out[hh] : rho_last;
             const float gg = fmaf_(bound - rr, 0.9999996f, -8e-7f * rr);
             const bool cert = gg > 0.0f && gg * gg * 0.99997f > bb;
-            // hand the rows' results to the owners: owner with rank r among this group sits in row r - served
-            const int from = 16 * ((my_rank - served) & 3);
+            // hand the groups' results to the owners: the owner with rank r among this pass sits in group r - served
+            const int from = COOP_L * ((my_rank - served) & (COOP_G - 1));
             const float rb = __shfl(bb, from);
             const int ri = __shfl(b_i, from);
             const int rc = __shfl((int)cert, from);
-            if (open_lane && my_rank >= served && my_rank < served + 4) { best = rb; bi = ri; done = rc != 0; nrec += 64; }
-            served += 4;
+            if (open_lane && my_rank >= served && my_rank < served + COOP_G) { best = rb; bi = ri; done = rc != 0; nrec += 64; }
+            served += COOP_G;
         }
     }
     // lists exhausted without a certificate: second chance from the entry across the angle-pi cut, whole wave (rare)
@@ -951,21 +977,32 @@ MD void store_pose(float* p, const float* P) {
     for (int i = 0; i < 4; ++i) v[i] = make_float4(P[i * 4 + 0], P[i * 4 + 1], P[i * 4 + 2], P[i * 4 + 3]);
 }
 
-MD void propagate_one(int64_t n, int64_t n_global, const float* P, const float* O, const float* tn_arr,
-                      const float* rot_arr, float std_t, float std_r, uint64_t seed, uint64_t step, float* out) {
+// the part of the motion model that does not depend on the particle's pose: NO = O @ Tn(noise of slot n)
+MD void noise_odom(int64_t n, int64_t n_global, const float* O, const float* tn_arr, const float* rot_arr, float std_t,
+                   float std_r, uint64_t seed, uint64_t step, float* NO) {
     float tn[3], rot[3];
     if (tn_arr) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) { tn[j] = tn_arr[n * 3 + j]; rot[j] = rot_arr[n * 3 + j]; }
+        // (the host draws are consumed inside this branch: values still "in flight" at the join make the compiler wait
+        // for every outstanding load there, including ones the caller issued to travel during the arithmetic below)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(tn[j]), "+v"(rot[j]));
     } else {
         float z[6];
         philox_normals6((uint64_t)n_global, seed, step, z);
 #pragma unroll
         for (int j = 0; j < 3; ++j) { tn[j] = z[j] * std_t; rot[j] = z[3 + j] * std_r; }
     }
-    float Tn[16], NO[16];
+    float Tn[16];
     noise_transform(tn, rot, Tn);
     mat4_mul(O, Tn, NO);
+}
+
+MD void propagate_one(int64_t n, int64_t n_global, const float* P, const float* O, const float* tn_arr,
+                      const float* rot_arr, float std_t, float std_r, uint64_t seed, uint64_t step, float* out) {
+    float NO[16];
+    noise_odom(n, n_global, O, tn_arr, rot_arr, std_t, std_r, seed, step, NO);
     mat4_mul(P, NO, out);
 }
 
@@ -1152,6 +1189,7 @@ MD void lazy_tables(const LazyResample& rs, double* rs_lds) {
     const int t = threadIdx.x;
     const int b = t < rs.nb ? t : rs.nb - 1;  // nb <= 256: one block per thread, clamped loads
     const double bt = rs.btot[b], btr = rs.btot_raw[b], bs = rs.bsum_e[b], bx = rs.bmax[b], bn = rs.bmin[b];
+    const int32_t status = rs.status_prev[0];  // with the records: read in lazy_source it was a round trip of its own
     const bool in = t < rs.nb;
     double mx = in ? bx : -INFINITY, mn = in ? bn : INFINITY;
     const bool nan = in && ((bx != bx) || (bn != bn));
@@ -1180,6 +1218,7 @@ MD void lazy_tables(const LazyResample& rs, double* rs_lds) {
         rs_lds[512] = acc;
         rs_lds[513] = apply ? S : 1.0;
         rs_lds[514] = apply ? 1.0 : 0.0;
+        rs_lds[515] = status != 0 ? 1.0 : 0.0;
     }
     __syncthreads();
     const double total = rs_lds[512];
@@ -1191,14 +1230,64 @@ MD void lazy_tables(const LazyResample& rs, double* rs_lds) {
     __syncthreads();
 }
 
+// The same tables built by ONE wave for itself (nb <= 64: N <= 262144), split in two so that the pose-independent half of
+// the motion model runs between the loads and their use: no workgroup barrier, no serial LDS loop - the sequential block
+// prefix is a left fold over lane values read with v_readlane (the same additions in the same order as lazy_tables).
+// Layout of the wave's block (LAZY_WAVE_LDS doubles): [0, 64) block prefix | [64, 128) block ends | 128 total | 130 apply |
+// 131 status of the previous frame.
+constexpr int LAZY_WAVE_LD = 64, LAZY_WAVE_LDS = 2 * LAZY_WAVE_LD + 4;
+struct LazyRecords { double bt, btr, bx, bn; int32_t status; };
+MD LazyRecords lazy_records_load(const LazyResample& rs) {
+    const int lane = threadIdx.x & 63;
+    const int b = lane < rs.nb ? lane : rs.nb - 1;
+    LazyRecords r;
+    r.bt = rs.btot[b]; r.btr = rs.btot_raw[b]; r.bx = rs.bmax[b]; r.bn = rs.bmin[b];
+    r.status = rs.status_prev[0];
+    return r;
+}
+MD void lazy_tables_wave(const LazyResample& rs, const LazyRecords& r, double* rs_lds) {
+    const int lane = threadIdx.x & 63;
+    const bool in = lane < rs.nb;
+    double mx = in ? r.bx : -INFINITY, mn = in ? r.bn : INFINITY;
+    const bool nan = in && ((r.bx != r.bx) || (r.bn != r.bn));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double a = __shfl_xor(mx, o), c = __shfl_xor(mn, o);
+        mx = a > mx ? a : mx;
+        mn = c < mn ? c : mn;
+    }
+    if (__any(nan)) { mx = NAN; mn = NAN; }
+    const bool apply = rs.softmax && !(__builtin_fabs(mx - mn) <= LAZY_ISCLOSE_ATOL);
+    const double w = in ? (apply ? r.bt : r.btr) : 0.0;
+    double acc = 0.0, bp = 0.0;
+    for (int i = 0; i < rs.nb; ++i) {
+        bp = lane == i ? acc : bp;
+        acc = acc + rl_f64(w, i);
+    }
+    const double total = acc;
+    if (in) {
+        rs_lds[lane] = bp;
+        rs_lds[LAZY_WAVE_LD + lane] = (lane == rs.nb - 1) ? 1.0 : (bp + w) / total;
+    }
+    if (lane == 0) {
+        rs_lds[2 * LAZY_WAVE_LD] = total;
+        rs_lds[2 * LAZY_WAVE_LD + 2] = apply ? 1.0 : 0.0;
+        rs_lds[2 * LAZY_WAVE_LD + 3] = r.status != 0 ? 1.0 : 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Per-lane part: the source particle of slot n (what k_tail_b2 writes to ridx[n]).
-MD int64_t lazy_source(const LazyResample& rs, const double* rs_lds, int64_t n, int64_t N) {
+// ld = stride of the table block: 256 (lazy_tables, one block per workgroup) or LAZY_WAVE_LD (lazy_tables_wave)
+MD int64_t lazy_source(const LazyResample& rs, const double* rs_lds, int64_t n, int64_t N, int ld = 256) {
     const double* s_bp = rs_lds;
-    const double* s_end = rs_lds + 256;
-    const double total = rs_lds[512];
-    const bool apply = rs_lds[514] != 0.0;
+    const double* s_end = rs_lds + ld;
+    const double total = rs_lds[2 * ld];
+    const bool apply = rs_lds[2 * ld + 2] != 0.0;
     const bool bad_total = !(total == total) || total == 0.0;
-    if (rs.status_prev[0] != 0 || bad_total) return n;  // unusable weights: the resampler keeps the particles
+    if (rs_lds[2 * ld + 3] != 0.0 || bad_total) return n;  // unusable weights: the resampler keeps the particles
     const double* __restrict__ lp = apply ? rs.lp : rs.lp_raw;
     const double* __restrict__ gend = apply ? rs.gend : rs.gend_raw;
     double tq;
@@ -1229,8 +1318,10 @@ MD int64_t lazy_source(const LazyResample& rs, const double* rs_lds, int64_t n, 
 // =================================================================================================
 // One wave = 64 consecutive particles of trajectory `traj`; `wave` counts the waves of that trajectory,
 // `nwaves` = waves per trajectory (strides of the per-wave partial arrays), s_cd = this wave's LDS columns.
+// WT (with rs_lds): the wave builds the resample tables itself (lazy_tables_wave; rs_lds = its own LAZY_WAVE_LDS doubles)
+template <bool WT = false>
 MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, ParticleUpdateArgs a, int64_t wave,
-                             int nwaves, int traj, double* s_cd, const double* rs_lds = nullptr) {
+                             int nwaves, int traj, double* s_cd, double* rs_lds = nullptr) {
     const int lane = threadIdx.x & 63;
     if (a.n_live) {  // variable particle count: the grid covers the capacity, the waves past the live set leave
         const int64_t nl = *a.n_live;
@@ -1268,17 +1359,40 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
     // source of the particle: its own slot, or - resample of the previous frame folded in - slot src of the previous
     // frame's propagated poses
     int64_t src = n;
+    float NO[16];
+    if (WT) {
+        // the block records travel while the pose-independent half of the motion model (draws, noise transform,
+        // O @ Tn: half of the propagate's arithmetic) is computed; the tables are then built from registers
+        // (memory operations come back in order: the odometry is requested BEFORE the records, or waiting for it would
+        // be waiting for them)
+        float O[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) O[i] = a.odom16[i];
+        __builtin_amdgcn_sched_barrier(0);
+        const LazyRecords rec = lazy_records_load(a.rs);
+        __builtin_amdgcn_sched_barrier(0);
+        if (live) noise_odom(n, n + a.slot_base, O, a.tn, a.rot, a.std_t, a.std_r, a.seed, a.step, NO);
+        lazy_tables_wave(a.rs, rec, rs_lds);
+    }
     if (rs_lds && live) {
-        src = (a.ablate & 8) ? n : lazy_source(a.rs, rs_lds, n, a.N);  // ablate 8 (profiling): no search, own slot
+        // ablate 8 (profiling): no search, own slot
+        src = (a.ablate & 8) ? n : lazy_source(a.rs, rs_lds, n, a.N, WT ? LAZY_WAVE_LD : 256);
         if (a.rs.ridx_out) a.rs.ridx_out[n] = (int32_t)src;
     }
     const float* pose_src = rs_lds ? a.rs.poses_prev : a.poses_in;
+    // the hint travels with the pose (behind the store of the propagated pose it would be a round trip of its own)
+    const int32_t hint = !live ? -1 : rs_lds ? a.rs.nn_prev[src] : a.hint_in ? a.hint_in[n] : -1;
     if (live) {
-        float P[16], O[16];
+        float P[16];
         load_pose(pose_src + src * 16, P);
+        if (WT) {
+            mat4_mul(P, NO, R);
+        } else {
+            float O[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) O[i] = a.odom16[i];
-        propagate_one(n, n + a.slot_base, P, O, a.tn, a.rot, a.std_t, a.std_r, a.seed, a.step, R);
+            for (int i = 0; i < 16; ++i) O[i] = a.odom16[i];
+            propagate_one(n, n + a.slot_base, P, O, a.tn, a.rot, a.std_t, a.std_r, a.seed, a.step, R);
+        }
         store_pose(a.poses_prop + n * 16, R);
         se3_feature(R, 0.99f, 0.01f, f);
     }
@@ -1286,7 +1400,6 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
     // nearest codebook entry
     int32_t bi = 0;
     float bd;
-    const int32_t hint = !live ? -1 : rs_lds ? a.rs.nn_prev[src] : a.hint_in ? a.hint_in[n] : -1;
     if (a.ablate & 1) {  // profiling only: trust the hint
         bi = hint < 0 ? 0 : hint;
     } else {
@@ -1302,7 +1415,13 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
             if (lane == 0 && m) atomicAdd(&a.telemetry[0], (unsigned long long)__popcll(m));
         }
     }
-    if (a.sp.stamps) score_claimed_rows_nj(a.sp, live, bi);  // the first particle of the frame on an entry has it scored
+    // sparse scoring: the first particle of the frame on an entry has it scored - the exchanges leave here, the answers are
+    // looked at after the prune
+    RowClaim claim{false, 0u};
+    if (a.sp.stamps && !(a.ablate & 16)) {  // ablate 16 (profiling): nobody scores
+        claim = claim_rows_issue(a.sp, live, bi);
+        if (!MIDAS_CLAIM_DEFER) score_claimed_rows_nj(a.sp, claim, bi);
+    }
     // prune: valid <=> some mesh vertex within sqrt(t2) of the particle
     double q3[3] = {(double)R[3], (double)R[7], (double)R[11]};
     double best = a.t2;
@@ -1323,6 +1442,7 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
         if (lane == 0 && m) atomicAdd(&a.telemetry[1], (unsigned long long)__popcll(m));
     }
     if (mv >= 0) ok = mv == 1;
+    if (MIDAS_CLAIM_DEFER && a.sp.stamps && !(a.ablate & 16)) score_claimed_rows_nj(a.sp, claim, bi);
     tc[6] = clock64();
     if (live) {
         a.nn_idx[n] = bi;
@@ -1376,20 +1496,26 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
 // particle waves each and start first, workgroups [n_pu, ...) stream sixteen codebook rows each behind them
 // and fill the memory pipes the particle waves leave idle.
 // LAZY: the resample of the previous frame runs as a prologue of the particle waves (midas_lazy_step).
-template <typename T, int NJ, bool LAZY>
-__global__ __launch_bounds__(256) void k_frame_front(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a,
-                                                     int n_pu, int nwaves, const T* __restrict__ emb,
-                                                     const double* __restrict__ norms, const double* __restrict__ code,
-                                                     double* __restrict__ scores, int64_t K) {
-    __shared__ double s_cd[4][KD_MAX_LEVELS * 64];
-    __shared__ double s_rs[3 * LAZY_MAX_BLOCKS + 8];
+// LAZY 2: the same with the tables built per wave (nb <= 64), which also frees the workgroup size: FW = waves per
+// workgroup.  With FW = 1 the 1563 particle waves of c2 spread 6 - 7 per CU; workgroups of four land 4 or 8 on a CU.
+template <typename T, int NJ, int LAZY, int FW>
+__global__ __launch_bounds__(64 * FW) void k_frame_front(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a,
+                                                         int n_pu, int nwaves, const T* __restrict__ emb,
+                                                         const double* __restrict__ norms, const double* __restrict__ code,
+                                                         double* __restrict__ scores, int64_t K) {
+    static_assert(LAZY != 1 || FW == 4, "the workgroup-level tables take 256 threads");
+    __shared__ double s_cd[FW][KD_MAX_LEVELS * 64];
+    __shared__ double s_rs[LAZY == 1 ? 3 * LAZY_MAX_BLOCKS + 8 : LAZY == 2 ? FW * LAZY_WAVE_LDS : 8];
     const int w = threadIdx.x >> 6;
     if ((int)blockIdx.x < n_pu) {
-        if (LAZY) lazy_tables(a.rs, s_rs);
-        const int64_t wave = (int64_t)blockIdx.x * 4 + w;
-        if (wave < nwaves) particle_update_wave(t6, t3, a, wave, nwaves, 0, s_cd[w], LAZY ? s_rs : nullptr);
+        if (LAZY == 1) lazy_tables(a.rs, s_rs);
+        const int64_t wave = (int64_t)blockIdx.x * FW + w;
+        if (wave < nwaves) {
+            if (LAZY == 2) particle_update_wave<true>(t6, t3, a, wave, nwaves, 0, s_cd[w], s_rs + w * LAZY_WAVE_LDS);
+            else particle_update_wave(t6, t3, a, wave, nwaves, 0, s_cd[w], LAZY ? s_rs : nullptr);
+        }
     } else {
-        score_wave<T, NJ, 0>(emb, norms, code, scores, K, (int64_t)(blockIdx.x - n_pu) * 4 + w);
+        score_wave<T, NJ, 0>(emb, norms, code, scores, K, (int64_t)(blockIdx.x - n_pu) * FW + w);
     }
 }
 
@@ -1558,7 +1684,11 @@ __global__ __launch_bounds__(256, MIDAS_NNP_OCC) void k_particle_nn_prune(TreeVi
         if (lane == 0 && m) atomicAdd(&a.telemetry[0], (unsigned long long)__popcll(m));
     }
     const int32_t nn = (int32_t)dpp_u32<BC_FIRST>((uint32_t)(int32_t)bi);
-    if (a.sp.stamps) score_claimed_rows_nj(a.sp, owner && live, nn);
+    RowClaim claim{false, 0u};
+    if (a.sp.stamps) {
+        claim = claim_rows_issue(a.sp, owner && live, nn);
+        if (!MIDAS_CLAIM_DEFER) score_claimed_rows_nj(a.sp, claim, nn);
+    }
     // ---- prune: header + records 1 .. 16 of the entry's vertex list in one round trip ----
     const float* pr = a.poses_prop + pc * 16;
     const double q3[3] = {(double)pr[3], (double)pr[7], (double)pr[11]};
@@ -1604,6 +1734,7 @@ __global__ __launch_bounds__(256, MIDAS_NNP_OCC) void k_particle_nn_prune(TreeVi
         a.nn_idx[p] = nn;
         a.valid[p] = ok ? 1 : 0;
     }
+    if (MIDAS_CLAIM_DEFER && a.sp.stamps) score_claimed_rows_nj(a.sp, claim, nn);
 }
 
 // =================================================================================================
@@ -1742,13 +1873,22 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
         *launched = true;
         return MIDAS_OK;
     }
+    // the single kernel: workgroup-level tables (more than 64 summation blocks) or per-wave tables, then FW waves per
+    // workgroup (MIDAS_FRONT_WAVES = 1 | 4; default 1 with sparse scoring, 4 beside the streaming workgroups)
+    static const int fw_env = getenv("MIDAS_FRONT_WAVES") ? atoi(getenv("MIDAS_FRONT_WAVES")) : 0;
+    static const int wt_env = getenv("MIDAS_WAVE_TABLES") ? atoi(getenv("MIDAS_WAVE_TABLES")) : 1;
+    const bool wave_tables = a.rs.enabled && a.rs.nb <= LAZY_WAVE_LD && wt_env != 0;
+    const int fw = (a.rs.enabled && !wave_tables) ? 4 : fw_env == 1 || fw_env == 4 ? fw_env : (a.sp.stamps ? 1 : 4);
+    const int n_pu_fw = (nwaves + fw - 1) / fw;
+    const unsigned grid_fw = (unsigned)(n_pu_fw + (a.sp.stamps ? 0 : ceil_div(cb->K, 4 * fw)));
+#define MIDAS_FRONT_L(NJ, LZ, FW)                                                                                     \
+    hipLaunchKernelGGL((k_frame_front<float, NJ, LZ, FW>), dim3(grid_fw), dim3(64 * FW), 0, ctx->stream,               \
+                       view_of<Kd6>(t6), view_of<Kd3>(t3), a, n_pu_fw, nwaves, emb, cb->norms, code, scores, cb->K)
 #define MIDAS_FRONT(NJ)                                                                                              \
-    if (a.rs.enabled)                                                                                                \
-        hipLaunchKernelGGL((k_frame_front<float, NJ, true>), dim3(grid), dim3(256), 0, ctx->stream, view_of<Kd6>(t6), \
-                           view_of<Kd3>(t3), a, n_pu, nwaves, emb, cb->norms, code, scores, cb->K);                  \
-    else                                                                                                             \
-        hipLaunchKernelGGL((k_frame_front<float, NJ, false>), dim3(grid), dim3(256), 0, ctx->stream, view_of<Kd6>(t6), \
-                           view_of<Kd3>(t3), a, n_pu, nwaves, emb, cb->norms, code, scores, cb->K)
+    if (!a.rs.enabled) { if (fw == 1) MIDAS_FRONT_L(NJ, 0, 1); else MIDAS_FRONT_L(NJ, 0, 4); }                        \
+    else if (!wave_tables) MIDAS_FRONT_L(NJ, 1, 4);                                                                   \
+    else if (fw == 1) MIDAS_FRONT_L(NJ, 2, 1);                                                                        \
+    else MIDAS_FRONT_L(NJ, 2, 4)
     switch (cb->D) {
         case 512: MIDAS_FRONT(8); break;
         case 256: MIDAS_FRONT(4); break;
@@ -1756,6 +1896,7 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
         default: MIDAS_FRONT(16); break;
     }
 #undef MIDAS_FRONT
+#undef MIDAS_FRONT_L
     MIDAS_HIP_CHECK(ctx, hipGetLastError());
     *launched = true;
     return MIDAS_OK;

@@ -41,8 +41,11 @@ MD int64_t search_in_block(const double* __restrict__ lp, const double* __restri
     for (int j = 0; j < 16; ++j) c += (j < n_in_group && left(bp + v[j])) ? 1 : 0;
     c = c < n_in_group ? c : n_in_group - 1;
     const int64_t s0 = (c0 + c) << 4;
-    const double v_prev = lp[s0 > b_lo ? s0 - 1 : b_lo];  // the slot before the chunk (same block)
+    double v_prev = lp[s0 > b_lo ? s0 - 1 : b_lo];  // the slot before the chunk (same block)
     fetch16(lp + s0);
+    // pinned to the chunk's round trip: left to itself the compiler sinks this load into the fix-up branch below, where it
+    // is a dependent round trip of its own
+    asm volatile("" : "+v"(v_prev));
     int pos = 0;
 #pragma unroll
     for (int j = 0; j < SCAN_CHUNK; ++j) pos += (s0 + j < b_hi && left(bp + v[j])) ? 1 : 0;

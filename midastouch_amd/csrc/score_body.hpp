@@ -87,24 +87,43 @@ MD void score_wave(const T* __restrict__ emb, const double* __restrict__ norms, 
 // exchanges the row's stamp with the frame's epoch; whoever finds an older stamp is the first of the whole frame to need
 // the row and has the wave score it - four rows at a time in score_wave's layout (quarter-wave per row, lane s owns floats
 // [64 j + 4 s, + 4) for ascending j, xor butterfly), so every score is bit-identical to the dense kernel's.
-template <int NJ>
-MD void score_claimed_rows(const SparseScore& sp, bool want, int32_t row) {
-    constexpr int D = NJ * 64;
-    const int lane = threadIdx.x & 63, s = lane & 15, qd = lane >> 4;
+// The claim is split in two: claim_rows_issue elects the leaders and requests their rows' stamps (nobody waits for them),
+// the caller goes on with work that does not need the scores (the prune), and score_claimed_rows looks at the stamps -
+// long since back -, exchanges the old ones and scores the rows this wave was first on; the row's norm travels with the
+// row.  (As one step - stamp read, exchange, row fetch, norm fetch, each waiting for the one before - a claiming wave was
+// four dependent round trips longer than the others, and the kernel ends with its slowest wave.  Exchanging without the
+// look first was measured too: every wave then hammers the same few dozen stamps - front 34 -> 44 us.)
+struct RowClaim { bool leader; uint32_t old; };
+MD RowClaim claim_rows_issue(const SparseScore& sp, bool want, int32_t row) {
+    const int lane = threadIdx.x & 63;
     // leaders: the first lane of each distinct row among the wanting lanes (a per-lane look at the stamps first was
     // measured: 64 scattered 4-byte loads per wave cost more than the election they save - 17.7k vs 20.5k steps/s)
-    bool leader = false;
+    RowClaim c;
+    c.leader = false;
     unsigned long long todo = __ballot(want);
     while (todo) {
         const int l = __builtin_ctzll(todo);
         const int32_t r = __shfl(row, l);
         const unsigned long long same = __ballot(want && row == r);
-        leader |= lane == l;
+        c.leader |= lane == l;
         todo &= ~same;
     }
-    // only the leaders look (after the first waves of a frame nearly every needed row carries the epoch already), then exchange
+    c.old = sp.epoch;
+    if (c.leader) c.old = sp.stamps[row];
+    return c;
+}
+
+template <int NJ>
+MD void score_claimed_rows(const SparseScore& sp, const RowClaim& c, int32_t row) {
+    constexpr int D = NJ * 64;
+    const int lane = threadIdx.x & 63, s = lane & 15, qd = lane >> 4;
+    // (after the first waves of a frame nearly every needed row carries the epoch already)
     bool claim = false;
-    if (leader && sp.stamps[row] != sp.epoch) claim = atomicExch(&sp.stamps[row], sp.epoch) != sp.epoch;
+#if defined(MIDAS_CLAIM_PLAIN) && MIDAS_CLAIM_PLAIN
+    if (c.leader && c.old != sp.epoch) { sp.stamps[row] = sp.epoch; claim = true; }  // profiling: no exchange, duplicates allowed
+#else
+    if (c.leader && c.old != sp.epoch) claim = atomicExch(&sp.stamps[row], sp.epoch) != sp.epoch;
+#endif
     unsigned long long m = __ballot(claim);
     while (m) {
         int32_t mine = -1;
@@ -122,6 +141,7 @@ MD void score_claimed_rows(const SparseScore& sp, bool want, int32_t row) {
         float4 v[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) v[j] = *reinterpret_cast<const float4*>(rp + j * 64);
+        const double nrm = sp.norms[have ? mine : 0];  // travels with the row
         double acc = 0.0, ne2 = 0.0;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -138,17 +158,17 @@ MD void score_claimed_rows(const SparseScore& sp, bool want, int32_t row) {
         if (have && s == 0) {
             double ne = __builtin_sqrt(ne2);
             ne = ne < COS_EPS ? COS_EPS : ne;
-            sp.scores[mine] = acc / (ne * sp.norms[mine]);
+            sp.scores[mine] = acc / (ne * nrm);
         }
     }
 }
 
-MD void score_claimed_rows_nj(const SparseScore& sp, bool want, int32_t row) {
+MD void score_claimed_rows_nj(const SparseScore& sp, const RowClaim& c, int32_t row) {
     switch (sp.nj) {
-        case 8: score_claimed_rows<8>(sp, want, row); break;
-        case 4: score_claimed_rows<4>(sp, want, row); break;
-        case 2: score_claimed_rows<2>(sp, want, row); break;
-        default: score_claimed_rows<16>(sp, want, row); break;
+        case 8: score_claimed_rows<8>(sp, c, row); break;
+        case 4: score_claimed_rows<4>(sp, c, row); break;
+        case 2: score_claimed_rows<2>(sp, c, row); break;
+        default: score_claimed_rows<16>(sp, c, row); break;
     }
 }
 
