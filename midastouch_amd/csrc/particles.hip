@@ -573,6 +573,123 @@ constexpr int MESH_SOLO = MIDAS_MESH_SOLO;
 static_assert(NN_SOLO % NN_BATCH == 0 && NBR_M % NN_BATCH == 0 && MESH_SOLO % MESH_BATCH == 0 && MESH_M % MESH_BATCH == 0,
               "scan batches must tile the solo prefixes and the lists");
 
+// ---- half-record screening ------------------------------------------------------------------------------------------
+// A record is two 16-byte pieces: lo = c[0..3], hi = {c[4], c[5], idx, rho}.  dist2 adds the six squared differences
+// in order, every step an fma onto the sum so far, so the sum after four terms P4 is a LOWER bound of the finished
+// distance in the computed arithmetic (adding a non-negative term and rounding never lowers a sum).  A record whose
+// P4 already exceeds the best distance can neither win nor tie: its second piece is not fetched at all.  On the
+// bench workloads 1 - 6 of 32 records pass the screen (the lists are sorted by 6-d distance from the entry, and most
+// of a neighbour's offset is in the translation), so a scan issues about half the loads - and the particle kernels
+// are bound by the number of scattered 16-byte loads a CU's vector cache can look up, not by bytes.
+// The certificate needs rho only once per batch: of the batch's last record (the largest; everything behind is farther).
+#ifndef MIDAS_SCREEN
+#define MIDAS_SCREEN 1
+#endif
+MD float part4(const float* q, const float4& lo) {
+    const float d0 = q[0] - lo.x, d1 = q[1] - lo.y, d2 = q[2] - lo.z, d3 = q[3] - lo.w;
+    float d = d0 * d0;
+    d = fmaf_(d1, d1, d);
+    d = fmaf_(d2, d2, d);
+    d = fmaf_(d3, d3, d);
+    return d;
+}
+MD float full_from(const float* q, float p4, const float4& hi) {  // == dist2(q, record), bit for bit
+    const float d4 = q[4] - hi.x, d5 = q[5] - hi.y;
+    float d = fmaf_(d4, d4, p4);
+    d = fmaf_(d5, d5, d);
+    return d;
+}
+// P[j] for a per-lane j as a chain of selects on registers (the empty asm keeps the compiler from turning the chain
+// back into an indexed array, which it would put in scratch memory)
+template <int B>
+MD float pick(const float* P, int j) {
+    float v = P[0];
+#pragma unroll
+    for (int k = 1; k < B; ++k) {
+        v = j == k ? P[k] : v;
+        asm volatile("" : "+v"(v));
+    }
+    return v;
+}
+template <int B>
+MD int pick(const int* P, int j) {
+    int v = P[0];
+#pragma unroll
+    for (int k = 1; k < B; ++k) {
+        v = j == k ? P[k] : v;
+        asm volatile("" : "+v"(v));
+    }
+    return v;
+}
+
+// Scans records [0, NN_SOLO) of entry h's list (record 0 = the entry itself, fetched whole with the first batch so that
+// r = |q - F_h| costs no round trip of its own).  Per batch: the first pieces of its records and the second piece of
+// its last one in one round trip; then the second pieces of up to two records that pass the screen in another (the
+// lines are in the vector cache by then); a lane with more takes them one at a time (rare).
+template <bool FIRST>
+MD void nn6_hint_batch(const float4* __restrict__ nb4, int s0, const float* q, int32_t h, float& best, int64_t& bi, float& r,
+                       float& rslack, int& scanned, bool& certified) {
+    float4 lo[NN_BATCH];
+#pragma unroll
+    for (int j = 0; j < NN_BATCH; ++j) lo[j] = nb4[2 * (s0 + j)];
+    const float4 hl = nb4[2 * (s0 + NN_BATCH - 1) + 1];
+    float P[NN_BATCH];
+#pragma unroll
+    for (int j = 0; j < NN_BATCH; ++j) P[j] = part4(q, lo[j]);
+    if (FIRST) {  // the entry itself: the starting candidate (a NaN distance stays, as in a serial scan)
+        const float4 h0 = nb4[1];
+        best = full_from(q, P[0], h0);
+        bi = h;
+        r = __builtin_sqrtf(best);
+        rslack = -8e-7f * r;
+    }
+    unsigned mask = 0;
+#pragma unroll
+    for (int j = FIRST ? 1 : 0; j < NN_BATCH; ++j) mask |= (P[j] <= best ? 1u : 0u) << j;
+    scanned += __popc(mask);
+    const unsigned m1 = mask & ~(1u << (NN_BATCH - 1)), m2 = m1 & (m1 - 1u);
+    // two second pieces, unconditionally (a lane without a candidate re-reads a piece it holds: conditional loads would
+    // be waited for one at a time)
+    const int j1 = m1 ? __builtin_ctz(m1) : NN_BATCH - 1, j2 = m2 ? __builtin_ctz(m2) : NN_BATCH - 1;
+    const float4 ha = nb4[2 * (s0 + j1) + 1];
+    const float4 hb = nb4[2 * (s0 + j2) + 1];
+    auto take = [&](float p4, const float4& hi) {
+        const float d = full_from(q, p4, hi);
+        const int32_t id = __float_as_int(hi.z);
+        if (d < best || (d == best && (int64_t)id < bi)) { best = d; bi = id; }
+    };
+    if (m1) take(pick<NN_BATCH>(P, j1), ha);
+    if (m2) take(pick<NN_BATCH>(P, j2), hb);
+    if (mask >> (NN_BATCH - 1)) take(P[NN_BATCH - 1], hl);
+    unsigned rest = m2 & (m2 - 1u);
+    while (rest) {  // more than two candidates among the batch's first records
+        const int j = __builtin_ctz(rest);
+        rest &= rest - 1u;
+        take(pick<NN_BATCH>(P, j), nb4[2 * (s0 + j) + 1]);
+    }
+    // every record behind this batch is at least this far (lower bound of |q - F| with slack for the rounding of r, rho)
+    const float g = fmaf_(hl.w - r, 0.9999996f, rslack);
+    certified = g > 0.0f && g * g * 0.99997f > best;
+}
+
+MD bool nn6_hint_scan_screened(const TreeView<Kd6>& tv, const float* q, int32_t h, float& best, int64_t& bi, int* n_scanned,
+                               float* r_out = nullptr) {
+    const float4* __restrict__ nb4 = reinterpret_cast<const float4*>(tv.nbrs + (size_t)h * NBR_REC);
+    float r = 0.f, rslack = 0.f;
+    int scanned = 0;
+    bool certified = false;
+    nn6_hint_batch<true>(nb4, 0, q, h, best, bi, r, rslack, scanned, certified);
+#pragma unroll 1
+    for (int s0 = NN_BATCH; s0 < NN_SOLO && !certified; s0 += NN_BATCH)
+        nn6_hint_batch<false>(nb4, s0, q, h, best, bi, r, rslack, scanned, certified);
+    if (r_out) *r_out = r;
+    if (n_scanned) *n_scanned = scanned;
+    return certified;
+}
+
+// The unscreened form (whole records, one round trip per batch): what the batch step and the largest particle sets run -
+// there the waves are many and short of registers, and a batch in two round trips costs more than the loads it saves
+// (c5: 353 -> 376 us per batch frame with the screen, c2's front 32.2 -> 30.8 us).
 // Scans records [0, NN_SOLO) of entry h's list (record 0 = the entry itself); the first batch is fetched
 // together with the entry so that r = |q - F_h| costs no round trip of its own.
 MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t h, float& best, int64_t& bi, int* n_scanned,
@@ -613,6 +730,7 @@ MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t h, float&
     if (n_scanned) *n_scanned = scanned;
     return certified;
 }
+
 
 // ---- wave-cooperative continuation of the list scans ------------------------------------------------
 // Most lanes certify inside their first batch of records; the few that do not used to walk the rest of
@@ -719,6 +837,7 @@ MD void group_best(float& d, int& i) {
 #undef MIDAS_STEP
 }
 
+template <bool SCREEN = false>
 MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_lane, float& best, int64_t& bi, bool need,
                  bool& done) {
     const int lane = threadIdx.x & 63, grp = lane / COOP_L, j = lane % COOP_L;
@@ -749,6 +868,50 @@ MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_
             const int hh_s = __shfl(hint, src), first_s = __shfl(nrec, src);
             const int hh = mine >= 0 ? hh_s : 0;
             const int first = mine >= 0 ? first_s : 0;  // records first .. first+63, clamped to the list
+            float d = INFINITY, rho_last = 0.f;
+            int id = 0x7fffffff;
+            if (SCREEN) {
+            // half-record screening (see part4): first pieces of the lane's records and the second piece of its last one,
+            // then the second pieces of the records whose partial distance does not exceed the owner's best
+            const float4* __restrict__ nb4 = reinterpret_cast<const float4*>(tv.nbrs + (size_t)hh * NBR_REC);
+            float4 lo[COOP_STEPS];
+            int sc[COOP_STEPS];
+#pragma unroll
+            for (int m = 0; m < COOP_STEPS; ++m) {
+                const int s = first + COOP_L * m + j;
+                sc[m] = s <= NBR_M ? s : NBR_M;
+                lo[m] = nb4[2 * sc[m]];
+            }
+            const float4 hl = nb4[2 * sc[COOP_STEPS - 1] + 1];
+            float P[COOP_STEPS];
+            unsigned mask = 0;
+#pragma unroll
+            for (int m = 0; m < COOP_STEPS; ++m) {
+                P[m] = part4(qq, lo[m]);
+                const bool in = first + COOP_L * m + j <= NBR_M;
+                mask |= (in && P[m] <= bb ? 1u : 0u) << m;
+            }
+            const unsigned m1 = mask & ~(1u << (COOP_STEPS - 1)), m2 = m1 & (m1 - 1u);
+            const int k1 = m1 ? __builtin_ctz(m1) : COOP_STEPS - 1, k2 = m2 ? __builtin_ctz(m2) : COOP_STEPS - 1;
+            const int s1 = pick<COOP_STEPS>(sc, k1), s2 = pick<COOP_STEPS>(sc, k2);
+            const float4 ha = nb4[2 * s1 + 1];
+            const float4 hb = nb4[2 * s2 + 1];
+            auto take = [&](float p4, const float4& hi) {
+                const float dm = full_from(qq, p4, hi);
+                const int im = __float_as_int(hi.z);
+                if (dm < d || (dm == d && im < id)) { d = dm; id = im; }  // NaN never wins
+            };
+            if (m1) take(pick<COOP_STEPS>(P, k1), ha);
+            if (m2) take(pick<COOP_STEPS>(P, k2), hb);
+            if (mask >> (COOP_STEPS - 1)) take(P[COOP_STEPS - 1], hl);
+            unsigned rest = m2 & (m2 - 1u);
+            while (rest) {
+                const int k = __builtin_ctz(rest);
+                rest &= rest - 1u;
+                take(pick<COOP_STEPS>(P, k), nb4[2 * pick<COOP_STEPS>(sc, k) + 1]);
+            }
+            rho_last = hl.w;  // of this lane's last record: the group's last lane holds the chunk's last (when the chunk is whole)
+            } else {
             const Nbr6* nb = tv.nbrs + (size_t)hh * NBR_REC;
             Nbr6 e[COOP_STEPS];
 #pragma unroll
@@ -756,8 +919,6 @@ MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_
                 const int s = first + COOP_L * m + j;
                 e[m] = nb[s <= NBR_M ? s : NBR_M];
             }
-            float d = INFINITY, rho_last = 0.f;
-            int id = 0x7fffffff;
 #pragma unroll
             for (int m = 0; m < COOP_STEPS; ++m) {
                 Point6 p;
@@ -767,6 +928,7 @@ MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_
                 const bool in = first + COOP_L * m + j <= NBR_M;
                 if (in && (dm < d || (dm == d && e[m].idx < id))) { d = dm; id = e[m].idx; }  // NaN never wins
                 rho_last = in ? e[m].rho : rho_last;
+            }
             }
             group_best(d, id);
             if (d < bb || (d == bb && id < b_i)) { bb = d; b_i = id; }
@@ -943,7 +1105,7 @@ MD int mesh_list_check(const MeshRec* __restrict__ vlist, int32_t h, const doubl
 
 // Wave-level NN: per-lane hint scan, then the octets serve the lanes it could not certify.
 // Must be called by every lane of the wave (`live` = this lane holds a query).
-template <bool STATS = false>
+template <bool STATS = false, bool SCREEN = false>
 MD bool nn6_wave(const TreeView<Kd6>& tv, const float* q, bool live, int32_t hint, int32_t& idx, float& d2, float* cd,
                  int* n_leaves = nullptr, int* n_nodes = nullptr, int* n_scanned = nullptr, long long* t_solo = nullptr) {
     float best = INFINITY;
@@ -951,9 +1113,11 @@ MD bool nn6_wave(const TreeView<Kd6>& tv, const float* q, bool live, int32_t hin
     bool done = !live;
     const bool hinted = live && hint >= 0 && (int64_t)hint < tv.K;
     float r_lane = 0.f;
-    if (hinted) done = nn6_hint_scan(tv, q, hint, best, bi, n_scanned, &r_lane);  // records 0 .. NN_SOLO-1, per lane
+    if (hinted)  // records 0 .. NN_SOLO-1, per lane
+        done = SCREEN ? nn6_hint_scan_screened(tv, q, hint, best, bi, n_scanned, &r_lane)
+                      : nn6_hint_scan(tv, q, hint, best, bi, n_scanned, &r_lane);
     if (t_solo) *t_solo = clock64();
-    nn6_coop(tv, q, hint, r_lane, best, bi, hinted && !done, done);                         // the rest, whole wave per lane
+    nn6_coop<SCREEN>(tv, q, hint, r_lane, best, bi, hinted && !done, done);                 // the rest, whole wave per lane
     wave_search<Kd6, false, STATS>(tv, q, best, bi, !done, cd, n_leaves, n_nodes);
     idx = (int32_t)bi;
     d2 = best;
@@ -1319,7 +1483,8 @@ MD int64_t lazy_source(const LazyResample& rs, const double* rs_lds, int64_t n, 
 // One wave = 64 consecutive particles of trajectory `traj`; `wave` counts the waves of that trajectory,
 // `nwaves` = waves per trajectory (strides of the per-wave partial arrays), s_cd = this wave's LDS columns.
 // WT (with rs_lds): the wave builds the resample tables itself (lazy_tables_wave; rs_lds = its own LAZY_WAVE_LDS doubles)
-template <bool WT = false>
+// SCREEN: half-record screening in the list scans (see part4)
+template <bool WT = false, bool SCREEN = false>
 MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, ParticleUpdateArgs a, int64_t wave,
                              int nwaves, int traj, double* s_cd, double* rs_lds = nullptr) {
     const int lane = threadIdx.x & 63;
@@ -1404,7 +1569,7 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
         bi = hint < 0 ? 0 : hint;
     } else {
         int nscan = 0;
-        const bool fb = nn6_wave(t6, f, live, hint, bi, bd, reinterpret_cast<float*>(s_cd), nullptr, nullptr, &nscan, &tc[2]);
+        const bool fb = nn6_wave<false, SCREEN>(t6, f, live, hint, bi, bd, reinterpret_cast<float*>(s_cd), nullptr, nullptr, &nscan, &tc[2]);
         tc[3] = clock64();
         if (a.telemetry && (a.ablate & 4)) {  // MIDAS_ABLATE=4: scan statistics (profiling only), flushed at the end
             st_nn = __ballot(live && nscan >= NN_SOLO - 1);
@@ -1511,8 +1676,10 @@ __global__ __launch_bounds__(64 * FW) void k_frame_front(TreeView<Kd6> t6, TreeV
         if (LAZY == 1) lazy_tables(a.rs, s_rs);
         const int64_t wave = (int64_t)blockIdx.x * FW + w;
         if (wave < nwaves) {
-            if (LAZY == 2) particle_update_wave<true>(t6, t3, a, wave, nwaves, 0, s_cd[w], s_rs + w * LAZY_WAVE_LDS);
-            else particle_update_wave(t6, t3, a, wave, nwaves, 0, s_cd[w], LAZY ? s_rs : nullptr);
+            // one-wave workgroups = the small-set regime (see launch_frame_front): screened scans
+            constexpr bool SCREEN = FW == 1 && MIDAS_SCREEN;
+            if (LAZY == 2) particle_update_wave<true, SCREEN>(t6, t3, a, wave, nwaves, 0, s_cd[w], s_rs + w * LAZY_WAVE_LDS);
+            else particle_update_wave<false, SCREEN>(t6, t3, a, wave, nwaves, 0, s_cd[w], LAZY ? s_rs : nullptr);
         }
     } else {
         score_wave<T, NJ, 0>(emb, norms, code, scores, K, (int64_t)(blockIdx.x - n_pu) * FW + w);

@@ -47,5 +47,10 @@ print(names)
 for tag, sel in (("slowest", order[-6:]), ("median", order[nw // 2 - 3: nw // 2 + 3]), ("fastest", order[:3])):
     for w in sel:
         print(f"  {tag} wave {w}: life {life[w]:.1f} us | {int(dd[w,2])} {int(dd[w,3])} {int(dd[w,6])} | " + " ".join(str(int(x)) for x in dd[w, 8:16]))
+for lo in list(range(0, nw, 128)):
+    hi = min(nw, lo + 128)
+    print(f"  waves {lo:5d}..{hi:5d}: life mean {life[lo:hi].mean():.1f} max {life[lo:hi].max():.1f} | prop {dd[lo:hi,8].mean():.0f} nn_solo {dd[lo:hi,9].mean():.0f} nn_coop {dd[lo:hi,10].mean():.0f} mesh {dd[lo:hi,11].mean():.0f}")
+print("  last 32 waves: life", np.round(life[-32:], 1).tolist())
+print("  last 32 waves: prop", dd[-32:, 8].astype(int).tolist())
 print("last frame, wave lifetime us: p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(life, [10, 50, 90, 99, 100])))
 print("[nn tree, prune tree, nn coop lanes, prune coop lanes, nn coop waves, prune coop waves, nn records scanned, -]")
