@@ -89,6 +89,11 @@ int midas_tree_attach_mesh(midas_ctx* ctx, midas_tree* tree6, const midas_tree* 
  * per query that seeds the search bound; d2_dev nullable.  Replaces kneighbors (tactile_tree.py:50-52). */
 int midas_nn6(midas_ctx* ctx, const midas_tree* tree, int64_t N, const float* feat6_dev,
               const int32_t* hint_dev, int32_t* idx_dev, float* d2_dev);
+/* idx[n*k + r] = the r-th nearest codebook entry of query n by (squared distance, index), exact (brute force over the
+ * codebook, one wave per query); 1 <= k <= 64, k <= K; d2_dev nullable.  Replaces kneighbors(n_neighbors = nn) for nn > 1
+ * (tactile_tree/tactile_tree.py:43-58; the filter itself only asks for nn = 1). */
+int midas_knn6(midas_ctx* ctx, const midas_tree* tree, int64_t N, const float* feat6_dev, int32_t k,
+               int32_t* idx_dev, float* d2_dev);
 /* Diagnostic twin of midas_nn6: leaves / tree nodes visited per query (used to tune the tree). */
 int midas_nn6_stats(midas_ctx* ctx, const midas_tree* tree, int64_t N, const float* feat6_dev,
                     const int32_t* hint_dev, int32_t* leaves_dev, int32_t* nodes_dev);

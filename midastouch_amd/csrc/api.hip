@@ -251,6 +251,14 @@ MIDAS_EXPORT int midas_nn6(midas_ctx* ctx, const midas_tree* tree, int64_t N, co
     return launch_nn6(ctx, tree, N, feat6_dev, hint_dev, idx_dev, d2_dev);
 }
 
+MIDAS_EXPORT int midas_knn6(midas_ctx* ctx, const midas_tree* tree, int64_t N, const float* feat6_dev, int32_t k,
+                            int32_t* idx_dev, float* d2_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, tree && tree->dim == 6 && N >= 0 && k >= 1 && k <= 64 && (int64_t)k <= tree->K &&
+                           (N == 0 || (feat6_dev && idx_dev)));
+    return launch_knn6(ctx, tree, N, feat6_dev, k, idx_dev, d2_dev);
+}
+
 MIDAS_EXPORT int midas_nn6_stats(midas_ctx* ctx, const midas_tree* tree, int64_t N, const float* feat6_dev,
                                  const int32_t* hint_dev, int32_t* leaves_dev, int32_t* nodes_dev) {
     MIDAS_ENTER(ctx);

@@ -238,6 +238,7 @@ struct ParticleUpdateArgs {
     SparseScore sp;                           // stamps != nullptr: only the rows that are some particle's nearest entry are scored
 };
 int particle_update_blocks(int64_t N);
+int launch_knn6(midas_ctx* ctx, const midas_tree* t, int64_t N, const float* feat6, int32_t k, int32_t* idx, float* d2);
 int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t3, const ParticleUpdateArgs& a,
                        const midas_codebook* cb, const double* code, double* scores, bool* launched);
 int launch_particle_update(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t3, const ParticleUpdateArgs& a);

@@ -1942,6 +1942,69 @@ int launch_nn6(midas_ctx* ctx, const midas_tree* t, int64_t N, const float* feat
     return MIDAS_OK;
 }
 
+// ---- exact k nearest codebook entries (tactile_tree.py:43-58 with n_neighbors > 1) --------------------------------------
+// One wave per query, brute force over the tree's leaf slots (empty slots carry +inf coordinates): every lane keeps the k
+// best of the slots it visits in its own LDS column, sorted by (distance, index); the wave then merges the 64 columns,
+// taking the smallest head k times.  Distances are the spec's dist2 chain, ties go to the smaller index, so column 0 of
+// the result is what midas_nn6 returns.  Not on the filter's path (it uses nn = 1): a query costs one pass over the codebook.
+constexpr int KNN_MAX = 64;
+__global__ __launch_bounds__(64) void k_knn6(TreeView<Kd6> tv, int64_t N, const float* __restrict__ feat, int k,
+                                            int32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
+    extern __shared__ unsigned char s_knn[];
+    float* s_d = reinterpret_cast<float*>(s_knn);
+    int* s_i = reinterpret_cast<int*>(s_d + (size_t)k * 64);
+    const int lane = threadIdx.x & 63;
+    const int64_t n = blockIdx.x;
+    float q[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) q[a] = feat[n * 6 + a];
+    for (int s = 0; s < k; ++s) { s_d[s * 64 + lane] = INFINITY; s_i[s * 64 + lane] = 0x7fffffff; }
+    const int64_t nslots = ((int64_t)LEAF_CAP) << (3 * tv.levels);
+    float worst_d = INFINITY;
+    int worst_i = 0x7fffffff;
+    for (int64_t slot = lane; slot < nslots; slot += 64) {
+        const Point6 p = tv.pts[slot];
+        const float d = dist2(q, p);
+        const int id = p.idx;
+        if (d < worst_d || (d == worst_d && id < worst_i)) {  // NaN never enters
+            int pos = k - 1;
+            while (pos > 0) {
+                const float pd = s_d[(pos - 1) * 64 + lane];
+                const int pi = s_i[(pos - 1) * 64 + lane];
+                if (pd < d || (pd == d && pi < id)) break;
+                s_d[pos * 64 + lane] = pd;
+                s_i[pos * 64 + lane] = pi;
+                --pos;
+            }
+            s_d[pos * 64 + lane] = d;
+            s_i[pos * 64 + lane] = id;
+            worst_d = s_d[(k - 1) * 64 + lane];
+            worst_i = s_i[(k - 1) * 64 + lane];
+        }
+    }
+    int ptr = 0;
+    for (int r = 0; r < k; ++r) {
+        const float hd = ptr < k ? s_d[ptr * 64 + lane] : INFINITY;
+        const int hi = ptr < k ? s_i[ptr * 64 + lane] : 0x7fffffff;
+        float bd = hd;
+        int bi = hi;
+        wave_best(bd, bi);
+        if (lane == 0) {
+            idx_out[n * k + r] = bi;
+            if (d2_out) d2_out[n * k + r] = bd;
+        }
+        if (hi == bi && bi != 0x7fffffff) ++ptr;  // an entry sits in exactly one column
+    }
+}
+
+int launch_knn6(midas_ctx* ctx, const midas_tree* t, int64_t N, const float* feat6, int32_t k, int32_t* idx, float* d2) {
+    if (N == 0) return MIDAS_OK;
+    hipLaunchKernelGGL(k_knn6, dim3((unsigned)N), dim3(64), (size_t)k * 64 * 8, ctx->stream, view_of<Kd6>(t), N, feat6, (int)k,
+                       idx, d2);
+    MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    return MIDAS_OK;
+}
+
 int launch_nn6_stats(midas_ctx* ctx, const midas_tree* t, int64_t N, const float* feat6, const int32_t* hint,
                      int32_t* leaves, int32_t* nodes) {
     if (N == 0) return MIDAS_OK;

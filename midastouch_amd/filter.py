@@ -152,6 +152,7 @@ def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str
     events = [torch.cuda.Event(enable_timing=True)]
     events[0].record()
     prev_idx, count, fixed_idx, total_time = 0, 0, 0, 0.0
+    frame_idx = []  # the sequence frame each iteration looked at (pace="wallclock" skips and repeats)
     import gc
     gc.collect()
     gc.freeze()  # the libraries' ~10^6 long-lived objects out of the collector's way: no 30 ms pass in the middle of a run
@@ -205,6 +206,7 @@ def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str
             print(f"[{idx}] RMSE {1000 * rec['rmse_t']:.1f} mm {rec['rmse_r']:.0f} deg P {rec['n_after']} "
                   f"rate {1.0 / max(events[-2].elapsed_time(ev) * 1e-3, 1e-9):.1f} Hz")
         motion_time.append(time.time() - start)
+        frame_idx.append(idx)
         prev_idx = idx
         count += 1
     torch.cuda.synchronize(device)
@@ -222,6 +224,7 @@ def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str
     filter_stats["avg_timer"] = {"tactile": 0.0, "motion": 0.0, "meas": filter_stats["avg_time"],
                                  "host_enqueue": float(np.average(motion_time)) if motion_time else 0.0}
     filter_stats["frames"] = eng.read_log(0, count)
+    filter_stats["frame_idx"] = frame_idx
     if results_path is not None:
         save_filter_stats(filter_stats, results_path)
     return filter_stats

@@ -128,6 +128,17 @@ def nn6(tree: Tree, feat: torch.Tensor, hint: torch.Tensor | None = None, want_d
     return (idx, d2) if want_d2 else idx
 
 
+def knn6(tree: Tree, feat: torch.Tensor, k: int, want_d2: bool = False):
+    """(N, k) int32 indices of the k nearest codebook entries per query, by (distance, index); exact (tactile_tree.py:50-52
+    with n_neighbors = k)."""
+    feat = feat.float().contiguous()
+    n = feat.shape[0]
+    idx = torch.empty((n, k), dtype=torch.int32, device=feat.device)
+    d2 = torch.empty((n, k), dtype=torch.float32, device=feat.device) if want_d2 else None
+    _ctx(feat).call("midas_knn6", tree.h, n, _ptr(feat), int(k), _ptr(idx), _ptr(d2))
+    return (idx, d2) if want_d2 else idx
+
+
 def nn6_stats(tree: Tree, feat: torch.Tensor, hint: torch.Tensor | None = None):
     """Diagnostic: (leaves visited, nodes visited) per query."""
     feat = feat.float().contiguous()

@@ -149,11 +149,20 @@ class tactile_tree:
         return ops.nn6(self.tree, R3_SE3(query), hint=hint)
 
     def SE3_NN(self, _query, nn=1):
-        """Best SE(3) match by R3 + log-map distance (reference :43-58): (poses, cam_poses, embeddings)."""
-        if nn != 1:
-            raise NotImplementedError("SE3_NN supports nn=1 (the only value the filter uses)")
-        idx = self.SE3_NN_idx(_query)
-        return ops.gather_rows(self.poses, idx), ops.gather_rows(self.cam_poses, idx), NNCodes(self, idx)
+        """Best SE(3) matches by R3 + log-map distance (reference :43-58): (poses, cam_poses, embeddings).  nn = 1 (what the
+        filter asks for): (N,4,4), (N,4,4) and a lazy (N,D) view; nn > 1: the nn nearest per query in order, as the reference
+        returns them - (N,nn,4,4), (N,nn,4,4), (N,nn,D) float64 (squeezed for a single query, as the reference's indexing does)."""
+        if nn == 1:
+            idx = self.SE3_NN_idx(_query)
+            return ops.gather_rows(self.poses, idx), ops.gather_rows(self.cam_poses, idx), NNCodes(self, idx)
+        self._require_tree()
+        query = torch.as_tensor(_query).to(self.poses.device)
+        query = query[None] if query.dim() == 2 else query
+        idx = ops.knn6(self.tree, R3_SE3(query), int(nn))  # (N, nn)
+        flat = idx.reshape(-1)
+        shape = (idx.shape[0], int(nn)) if idx.shape[0] > 1 else (int(nn),)
+        return (ops.gather_rows(self.poses, flat).view(*shape, 4, 4), ops.gather_rows(self.cam_poses, flat).view(*shape, 4, 4),
+                ops.gather_rows(self.embeddings, flat).double().view(*shape, -1))
 
     def get_poses(self):
         return self.poses, self.cam_poses

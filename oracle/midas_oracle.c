@@ -13,6 +13,7 @@
  *   mo_se3_feature      tactile_tree/tactile_tree.py:73-77 (R3_SE3) + modules/pose.py:19-23
  *                       (theseus SO3.log_map - third-party, absent from the checkout, unpinned)
  *   mo_nn6              tactile_tree/tactile_tree.py:43-58 (SE3_NN: pynanoflann 0.0.9 exact 1-NN, L2)
+ *   mo_knn6             the same call with n_neighbors = k
  *   mo_nn3              modules/particle_filter.py:386-391 (sklearn KDTree.query k=1)
  *   mo_score*           modules/particle_filter.py:455-457 (cosine_similarity, eps 1e-8)
  *   mo_softmax          modules/particle_filter.py:459-468 (isclose guard + Softmax(dim=0))
@@ -338,6 +339,41 @@ MO_API void mo_se3_feature(int64_t N, const float* poses, float wt, float wr, fl
         feat6[n * 6 + 3] = wr * w[0];
         feat6[n * 6 + 4] = wr * w[1];
         feat6[n * 6 + 5] = wr * w[2];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* exact k nearest neighbours by (distance, index) (tactile_tree.py:50-52 with n_neighbors = k)  */
+/* ------------------------------------------------------------------------------------------ */
+MO_API void mo_knn6(int64_t N, int64_t K, int32_t k, const float* q6, const float* c6, int32_t* idx, float* d2out) {
+    for (int64_t n = 0; n < N; ++n) {
+        const float* q = q6 + n * 6;
+        int32_t* bi = idx + n * k;
+        float* bd = d2out + n * k;
+        int32_t have = 0;
+        for (int64_t j = 0; j < K; ++j) {
+            const float* p = c6 + j * 6;
+            float d0 = q[0] - p[0], d1 = q[1] - p[1], d2 = q[2] - p[2];
+            float d3 = q[3] - p[3], d4 = q[4] - p[4], d5 = q[5] - p[5];
+            float d = d0 * d0;
+            d = fmaf(d1, d1, d);
+            d = fmaf(d2, d2, d);
+            d = fmaf(d3, d3, d);
+            d = fmaf(d4, d4, d);
+            d = fmaf(d5, d5, d);
+            if (!(d == d)) continue;
+            int32_t pos = have;
+            if (have == k) {
+                if (!(d < bd[k - 1])) continue; /* j ascends: an equal distance never displaces an earlier index */
+                pos = k - 1;
+            } else {
+                ++have;
+            }
+            while (pos > 0 && d < bd[pos - 1]) { bd[pos] = bd[pos - 1]; bi[pos] = bi[pos - 1]; --pos; }
+            bd[pos] = d;
+            bi[pos] = (int32_t)j;
+        }
+        for (int32_t r = have; r < k; ++r) { bd[r] = INFINITY; bi[r] = 0x7fffffff; }
     }
 }
 

@@ -157,6 +157,15 @@ def nn6(query_feat, cb_feat):
     return idx, d2
 
 
+def knn6(query_feat, cb_feat, k):
+    """(N, k) indices / squared distances of the k nearest entries by (distance, index) (tactile_tree.py:50-52, n_neighbors = k)."""
+    q, c = _f32(query_feat), _f32(cb_feat)
+    idx = np.empty((q.shape[0], k), dtype=np.int32)
+    d2 = np.empty((q.shape[0], k), dtype=np.float32)
+    lib().mo_knn6(C.c_int64(q.shape[0]), C.c_int64(c.shape[0]), C.c_int32(k), _p(q), _p(c), _p(idx), _p(d2))
+    return idx, d2
+
+
 def nn3_dist(poses, verts):
     poses, verts = _f32(poses).reshape(-1, 4, 4), _f64(verts)
     dist = np.empty(poses.shape[0], dtype=np.float64)

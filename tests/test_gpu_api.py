@@ -166,6 +166,15 @@ def test_particle_rmse_and_se3_nn(dev, setup, oracle, golden):
     assert codes.shape == (800, 256) and codes.to_tensor().dtype == torch.float64
     assert np.array_equal(codes.to_tensor().cpu().numpy(), cb.embeddings.astype(np.float64)[idx])
     assert len(tree) == cb.K and tree.get_pose(5).shape == (4, 4) and tree.get_embedding(5).dtype == torch.float64
+    # nn > 1 (tactile_tree.py:43-58): the nn nearest per query in order, (N, nn, ...) like the reference's fancy indexing
+    p3, c3, e3 = tree.SE3_NN(torch.as_tensor(q[:50]).to(dev), nn=3)
+    idx3 = oracle.knn6(oracle.R3_SE3(q[:50]), oracle.R3_SE3(cb.poses), 3)[0]
+    assert p3.shape == (50, 3, 4, 4) and c3.shape == (50, 3, 4, 4) and e3.shape == (50, 3, 256) and e3.dtype == torch.float64
+    assert np.array_equal(p3.cpu().numpy(), cb.poses[idx3]) and np.array_equal(c3.cpu().numpy(), cb.cam_poses[idx3])
+    assert np.array_equal(e3.cpu().numpy(), cb.embeddings.astype(np.float64)[idx3])
+    assert np.array_equal(idx3[:, 0], idx[:50])
+    p1, _, e1 = tree.SE3_NN(torch.as_tensor(q[0]).to(dev), nn=4)  # a single (4,4) query: squeezed like the reference
+    assert p1.shape == (4, 4, 4) and e1.shape == (4, 256)
 
 
 def test_reference_loop_runs_and_tracks(dev):
@@ -200,3 +209,35 @@ def test_filter_real_settings_and_stats_file(dev, tmp_path):
     back = np.load(str(tmp_path / "filter_stats.npy"), allow_pickle=True).item()
     assert back["traj_size"] == 24 and len(back["cluster_poses"]) == 24 and not back["cluster_poses"][0].is_cuda
     assert back["rmse_t"] == stats["rmse_t"]
+
+
+def test_wallclock_pacing_skips_and_repeats_frames(dev, monkeypatch):
+    """pace="wallclock": idx = int(frame_rate * total_time) (filter.py:134-135).  With a host clock that charges 2.5 frame
+    periods to every iteration the loop looks at frames 0, 2, 5, 7, ... - frame 2 still initialises (prev_idx == 0, as in the
+    reference), the odometry of a skipped stretch is composed from the measured poses - and still tracks; with a clock that
+    charges 0.4 periods frames repeat."""
+    import types
+    from midastouch_amd import filter as filt
+    from midastouch_amd.config import load_config
+    cfg = load_config(["expt.params.num_particles=3000", "expt.codebook_size=4000"])
+    seq = filt.synthetic_sequence(cfg, dev, T=48)
+    rate = float(cfg.expt.frame_rate)
+    for per_iter in (2.5, 0.5):
+        clock = {"t": 0.0}
+
+        def fake_time():  # the loop charges (read after the frame's event) - (read at the top of the iteration)
+            clock["t"] += per_iter / rate
+            return clock["t"]
+
+        monkeypatch.setattr(filt, "time", types.SimpleNamespace(time=fake_time, sleep=lambda s: None))
+        stats = filt.filter(cfg, seq=seq, device=dev, pace="wallclock", max_frames=48)
+        seen = np.asarray(stats["frame_idx"])
+        steps = np.diff(seen)
+        assert seen[0] == 0 and seen[-1] >= 48 - 3 and seen.max() < 48
+        if per_iter > 1:   # slow host: frames are skipped, two or three at a time
+            assert set(steps.tolist()) <= {2, 3} and abs(steps.mean() - per_iter) < 0.15, seen[:12]
+        else:              # fast host: every frame is looked at about twice
+            assert set(steps.tolist()) <= {0, 1} and abs(len(seen) - 48 / per_iter) <= 3, seen[:12]
+        assert len(stats["rmse_t"]) == len(seen) and np.isfinite(stats["rmse_t"]).all()
+        assert stats["rmse_t"][-1] < 0.02
+    monkeypatch.undo()

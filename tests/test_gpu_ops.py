@@ -112,6 +112,23 @@ def test_nn6_ties_and_small_trees(dev, ops, oracle):
         assert np.array_equal(ops.nn6(tree, T(q, dev)).cpu().numpy(), ref), K
 
 
+def test_knn6_exact_order_and_ties(dev, ops, oracle):
+    """k nearest by (distance, index): equal to the oracle's brute force, duplicates included; column 0 == midas_nn6."""
+    rng = np.random.default_rng(21)
+    for K, k in ((5, 5), (40, 3), (700, 8), (5000, 64), (3000, 17)):
+        pts = rng.standard_normal((K, 6)).astype(np.float32)
+        pts[K // 2:] = pts[: K - K // 2] if K >= 40 else pts[K // 2:]  # duplicated points: ties -> smaller index first
+        q = np.concatenate([pts[:30], rng.standard_normal((70, 6)).astype(np.float32)])
+        tree = ops.Tree(T(pts, dev))
+        idx, d2 = ops.knn6(tree, T(q, dev), k, want_d2=True)
+        ref_i, ref_d = oracle.knn6(q, pts, k)
+        assert np.array_equal(idx.cpu().numpy(), ref_i), (K, k)
+        assert np.array_equal(d2.cpu().numpy(), ref_d), (K, k)
+        assert np.array_equal(idx[:, 0].cpu().numpy(), ops.nn6(tree, T(q, dev)).cpu().numpy())
+    with pytest.raises(Exception):
+        ops.knn6(tree, T(q, dev), 65)
+
+
 def test_nn3_dist_bit_exact(dev, ops, oracle, cb, golden):
     verts = cb.mesh_vertices
     tree = ops.Tree(T(verts, dev))

@@ -131,3 +131,18 @@ def test_philox_streams(oracle):
         assert [int(v) for v in oracle.philox_raw(ctr, key)] == exp
     u2 = oracle.philox_uniform64(4, 4000, 8)
     assert not np.array_equal(u[:4], u2)
+
+
+def test_oracle_knn6_matches_ckdtree(oracle):
+    """mo_knn6 (the spec of midas_knn6 / SE3_NN(nn > 1)): same neighbours in the same order as scipy's exact k-NN on
+    well-separated points; the float32 fma-chain distances agree with float64 to rounding."""
+    rng = np.random.default_rng(5)
+    pts = rng.standard_normal((3000, 6)).astype(np.float32)
+    q = rng.standard_normal((200, 6)).astype(np.float32)
+    idx, d2 = oracle.knn6(q, pts, 9)
+    dk, ik = cKDTree(pts.astype(np.float64)).query(q.astype(np.float64), k=9)
+    assert np.array_equal(idx, ik.astype(np.int32))
+    np.testing.assert_allclose(np.sqrt(d2.astype(np.float64)), dk, rtol=2e-6)
+    assert np.array_equal(idx[:, 0], oracle.nn6(q, pts)[0])
+    i2, _ = oracle.knn6(np.zeros((1, 6), np.float32), np.zeros((4, 6), np.float32), 3)  # all tied: index order
+    assert i2.tolist() == [[0, 1, 2]]
