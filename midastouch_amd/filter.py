@@ -153,6 +153,7 @@ def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str
     events[0].record()
     prev_idx, count, fixed_idx, total_time = 0, 0, 0, 0.0
     frame_idx = []  # the sequence frame each iteration looked at (pace="wallclock" skips and repeats)
+    records = []    # frame-log rows read back so far
     import gc
     gc.collect()
     gc.freeze()  # the libraries' ~10^6 long-lived objects out of the collector's way: no 30 ms pass in the middle of a run
@@ -164,6 +165,9 @@ def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str
             fixed_idx += 1
         if idx >= traj_size:
             break
+        if count and count % eng.log_frames == 0:
+            # wall-clock pace on a fast host repeats frames: more iterations than the engine's frame log (a ring) holds
+            records.extend(eng.read_log(count - eng.log_frames, count))
         start = time.time()
         moving = prev_idx > 0
         if not moving:  # (filter.py:152,156-160) - like the reference, frames seen while prev_idx == 0 re-initialise
@@ -211,7 +215,8 @@ def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str
         count += 1
     torch.cuda.synchronize(device)
     gc.unfreeze()
-    for rec, e0, e1 in zip(eng.read_log(0, count), events, events[1:]):
+    records.extend(eng.read_log(len(records), count))
+    for rec, e0, e1 in zip(records, events, events[1:]):
         filter_stats["rmse_t"].append(rec["rmse_t"])
         filter_stats["rmse_r"].append(rec["rmse_r"])
         filter_stats["cluster_poses"].append(torch.as_tensor(rec["cluster_poses"]))
@@ -223,7 +228,7 @@ def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str
     # the reference's three timers: perception is upstream of this path; motion and measurement share one launch here
     filter_stats["avg_timer"] = {"tactile": 0.0, "motion": 0.0, "meas": filter_stats["avg_time"],
                                  "host_enqueue": float(np.average(motion_time)) if motion_time else 0.0}
-    filter_stats["frames"] = eng.read_log(0, count)
+    filter_stats["frames"] = records
     filter_stats["frame_idx"] = frame_idx
     if results_path is not None:
         save_filter_stats(filter_stats, results_path)
