@@ -115,6 +115,37 @@ def test_pipelined_equals_eager_full_size(dev):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("N", [65537, 262144, 262145])
+def test_front_kernel_form_boundaries(dev, oracle, N):
+    """The single front kernel changes form with the particle count: two kernels up to 65536 particles, one-wave workgroups
+    with per-wave resample tables and screened list scans up to 64 summation blocks (262144), workgroup-level tables and
+    whole-record scans above.  Either side of both boundaries: pipelined == eager == oracle (indices exact)."""
+    from midastouch_amd.engine import FilterEngine, PipelinedFilterEngine
+    K, D = 2000, 128
+    cb, traj = _setup(N, K, D, 31)
+    ofl = oracle.OracleFilter(cb.poses, cb.embeddings, cb.mesh_vertices)
+    rng = np.random.default_rng(N)
+    poses = cb.poses[rng.integers(0, K, N)]
+    od, co = torch.as_tensor(traj.odoms).to(dev), torch.as_tensor(traj.codes).to(dev)
+    engs = [cls(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4700, device=dev) for cls in (FilterEngine, PipelinedFilterEngine)]
+    for e in engs:
+        e.set_particles(torch.as_tensor(poses))
+    for t in range(1, 5):
+        for e in engs:
+            e.step(od[t], co[t])
+        assert torch.equal(engs[0].nn_idx, engs[1].nn_idx) and torch.equal(engs[0].poses_prop, engs[1].poses_prop), f"frame {t}"
+        if t <= 2:  # against the oracle (brute-force NN over K entries per particle: a second or two per frame)
+            tn, rot = oracle.philox_noise(N, 4700, t - 1, np.float32(2e-4), np.float32(0.5))
+            ref = ofl.step(poses, traj.odoms[t], traj.codes[t], tn, rot, u=oracle.philox_uniform64(N, 4700, t - 1))
+            assert np.array_equal(engs[1].nn_idx.cpu().numpy(), ref["nn_idx"]), f"frame {t}: NN index"
+            poses = ref["poses"]
+            if t == 2:
+                assert np.array_equal(engs[1].ridx.cpu().numpy(), ref["ridx"]), "resample indices"
+                assert np.array_equal(engs[1].poses.cpu().numpy(), ref["poses"]), "resampled poses"
+    assert torch.equal(engs[0].ridx, engs[1].ridx) and torch.equal(engs[0].poses, engs[1].poses)
+    assert torch.equal(engs[0].weights, engs[1].weights)
+
+
 def test_pipelined_rejects_unsupported_layout(dev):
     from midastouch_amd._lib import MidasError
     from midastouch_amd.engine import PipelinedFilterEngine
