@@ -143,6 +143,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-loop", action="store_true", help="skip the reference-named loop (filter() with clustering + annealing)")
+    ap.add_argument("--no-diffuse", action="store_true", help="skip the diffuse-regime figure (profiling runs: keeps the wide-start frames out of the kernel statistics)")
     ap.add_argument("--sharded", action="store_true", help="use the particle-sharded engine even on one GPU (smoke test)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "peer", "a2a", "a2a_fixed", "allgather"], help="sharded engine: form of the resample exchange")
     ap.add_argument("--eager", action="store_true", help="materialise the resampled particles every frame (three launches per frame)")
@@ -232,7 +233,7 @@ def main():
     frames(0, 2)  # library load, allocator, first-touch: not part of any figure
     torch.cuda.synchronize()
     diffuse = None
-    if not sharded:  # the first frames after a wide start: hints are stale, the cloud covers the whole object
+    if not sharded and not args.no_diffuse:  # the first frames after a wide start: hints are stale, the cloud covers the whole object
         wide_init(200 + rank)
         tele0 = eng.telemetry.cpu().numpy().copy()
         ND = 20
