@@ -85,6 +85,12 @@ int midas_tree_destroy(midas_tree* tree);
  * their NN entry with the same exact predicate and only the rest search the mesh tree.  Synchronous. */
 int midas_tree_attach_mesh(midas_ctx* ctx, midas_tree* tree6, const midas_tree* tree3,
                            const float* cb_poses_dev);
+/* Test / inspection hook: copies one of the tree's per-entry lists to host memory.  what = 0 neighbour records
+ * (K x 513 x 32 B), 1 rho_out (K floats), 2 twin (K int32), 3 mesh-vertex records (K x 257 x 32 B, after
+ * midas_tree_attach_mesh); bytes must be the array's size.  The lists are built on the device (index_build.hip; brute
+ * force, float64 distances, (distance, index) order) - MIDAS_HOST_INDEX=1 selects the host builder they are checked against.
+ * No reference counterpart (pynanoflann / sklearn trees: tactile_tree/tactile_tree.py:34-41, modules/particle_filter.py:108-110). */
+int midas_tree_export(midas_ctx* ctx, const midas_tree* tree, int32_t what, void* dst_host, int64_t bytes);
 /* idx[n] = argmin_k |feat6[n] - F_k|^2 (ties -> smallest k); hint_dev (nullable) = a candidate index
  * per query that seeds the search bound; d2_dev nullable.  Replaces kneighbors (tactile_tree.py:50-52). */
 int midas_nn6(midas_ctx* ctx, const midas_tree* tree, int64_t N, const float* feat6_dev,

@@ -183,6 +183,7 @@ SIGNATURES = {
     "midas_tree_attach_mesh": (C.c_int, [_P, _P, _P, _P]),
     "midas_nn6": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P]),
     "midas_knn6": (C.c_int, [_P, _P, _I64, _P, C.c_int32, _P, _P]),
+    "midas_tree_export": (C.c_int, [_P, _P, C.c_int32, _P, _I64]),
     "midas_nn6_stats": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P]),
     "midas_nn3": (C.c_int, [_P, _P, _I64, _P, _P]),
     "midas_propagate": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P, _F, _F, _U64, _U64]),

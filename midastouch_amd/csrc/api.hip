@@ -229,6 +229,23 @@ MIDAS_EXPORT int midas_tree_attach_mesh(midas_ctx* ctx, midas_tree* tree6, const
     return attach_mesh_impl(ctx, tree6, tree3, cb_poses_dev);
 }
 
+MIDAS_EXPORT int midas_tree_export(midas_ctx* ctx, const midas_tree* tree, int32_t what, void* dst_host, int64_t bytes) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, tree && dst_host && bytes >= 0 && what >= 0 && what <= 3);
+    const void* src = nullptr;
+    int64_t have = 0;
+    switch (what) {
+        case 0: src = tree->nbrs; have = tree->nbrs ? tree->K * NBR_REC * (int64_t)sizeof(Nbr6) : 0; break;
+        case 1: src = tree->rho_out; have = tree->rho_out ? tree->K * (int64_t)sizeof(float) : 0; break;
+        case 2: src = tree->twin; have = tree->twin ? tree->K * (int64_t)sizeof(int32_t) : 0; break;
+        default: src = tree->vlist; have = tree->vlist ? tree->K * MESH_REC * (int64_t)sizeof(MeshRec) : 0; break;
+    }
+    MIDAS_REQUIRE(ctx, src && bytes == have);
+    MIDAS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    MIDAS_HIP_CHECK(ctx, hipMemcpy(dst_host, src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return MIDAS_OK;
+}
+
 MIDAS_EXPORT int midas_tree_destroy(midas_tree* t) {
     if (!t) return MIDAS_OK;
     (void)hipStreamSynchronize(t->ctx->stream);

@@ -238,6 +238,9 @@ struct ParticleUpdateArgs {
     SparseScore sp;                           // stamps != nullptr: only the rows that are some particle's nearest entry are scored
 };
 int particle_update_blocks(int64_t N);
+bool index_build_on_host();  // MIDAS_HOST_INDEX=1: the host builders of round 1 (checkers of the device builders)
+int build_neighbour_graph_device(midas_ctx* ctx, midas_tree* t);
+int build_vertex_lists_device(midas_ctx* ctx, midas_tree* t6, const midas_tree* t3, const float* cb_poses_dev);
 int launch_knn6(midas_ctx* ctx, const midas_tree* t, int64_t N, const float* feat6, int32_t k, int32_t* idx, float* d2);
 int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t3, const ParticleUpdateArgs& a,
                        const midas_codebook* cb, const double* code, double* scores, bool* launched);

@@ -223,6 +223,7 @@ static void build_neighbour_graph(HostTree<Kd6>& t, const float* P, int64_t K) {
 // exactly unless the list runs out first.
 int attach_mesh_impl(midas_ctx* ctx, midas_tree* t6, const midas_tree* t3, const float* cb_poses_dev) {
     MIDAS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!index_build_on_host()) return build_vertex_lists_device(ctx, t6, t3, cb_poses_dev);
     const HostTree<Kd3>* mesh = reinterpret_cast<const HostTree<Kd3>*>(t3->host);
     if (!mesh) return midas_set_error(ctx, MIDAS_ERR_INVALID, "attach_mesh", "mesh tree has no host copy");
     const int64_t K = t6->K;
@@ -290,8 +291,14 @@ int tree_build_impl(midas_ctx* ctx, int32_t dim, int64_t K, const void* points_d
         std::vector<float> host((size_t)K * 6);
         MIDAS_HIP_CHECK(ctx, hipMemcpy(host.data(), points_dev, host.size() * sizeof(float), hipMemcpyDeviceToHost));
         HostTree<Kd6> h = build_tree<Kd6>(host.data(), K);
-        build_neighbour_graph(h, host.data(), K);
-        return upload_tree<Kd6>(ctx, h, K, out);
+        if (index_build_on_host()) {
+            build_neighbour_graph(h, host.data(), K);
+            return upload_tree<Kd6>(ctx, h, K, out);
+        }
+        // the box tree (K log K) on the host, the neighbour graph (K x K) on the device (index_build.hip)
+        int rc = upload_tree<Kd6>(ctx, h, K, out);
+        if (rc) return rc;
+        return build_neighbour_graph_device(ctx, out);
     }
     std::vector<double> host((size_t)K * 3);
     MIDAS_HIP_CHECK(ctx, hipMemcpy(host.data(), points_dev, host.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -1947,7 +1954,6 @@ int launch_nn6(midas_ctx* ctx, const midas_tree* t, int64_t N, const float* feat
 // best of the slots it visits in its own LDS column, sorted by (distance, index); the wave then merges the 64 columns,
 // taking the smallest head k times.  Distances are the spec's dist2 chain, ties go to the smaller index, so column 0 of
 // the result is what midas_nn6 returns.  Not on the filter's path (it uses nn = 1): a query costs one pass over the codebook.
-constexpr int KNN_MAX = 64;
 __global__ __launch_bounds__(64) void k_knn6(TreeView<Kd6> tv, int64_t N, const float* __restrict__ feat, int k,
                                             int32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
     extern __shared__ unsigned char s_knn[];

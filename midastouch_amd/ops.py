@@ -100,6 +100,16 @@ class Tree:
         self.ctx.call("midas_tree_attach_mesh", self.h, mesh_tree.h, _ptr(cb_poses))
         self._mesh = mesh_tree  # keep the mesh tree alive while the lists refer to it
 
+    def export(self, what: str):
+        """Host copy (numpy uint8 / float32 / int32) of one of the per-entry lists: "nbrs" (K, 513, 32) bytes, "rho_out" (K,),
+        "twin" (K,), "vlist" (K, 257, 32) bytes.  For tests and inspection (midas_tree_export)."""
+        import numpy as np
+        code, shape, dt = {"nbrs": (0, (self.K, 513, 32), np.uint8), "rho_out": (1, (self.K,), np.float32),
+                           "twin": (2, (self.K,), np.int32), "vlist": (3, (self.K, 257, 32), np.uint8)}[what]
+        out = np.empty(shape, dtype=dt)
+        self.ctx.call("midas_tree_export", self.h, code, C.c_void_p(out.ctypes.data), out.nbytes)
+        return out
+
     def __del__(self):  # pragma: no cover
         try:
             if self.h:
