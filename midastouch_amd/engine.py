@@ -396,7 +396,9 @@ class BatchFilterEngine:
         self.ridx = torch.zeros((B, N), dtype=torch.int32, device=d)
         self.status = torch.zeros((B, 2), dtype=torch.int32, device=d)
         self.rmse = torch.zeros((B, 2), dtype=torch.float64, device=d)
-        self.telemetry = torch.zeros(16, dtype=torch.int64, device=d)
+        import os
+        extra = 16 * B * ((N + 63) // 64) if int(os.environ.get("MIDAS_ABLATE", "0")) & 4 else 0  # per-wave statistics (profiling)
+        self.telemetry = torch.zeros(16 + extra, dtype=torch.int64, device=d)
         self.step_count = 0
         # sparse scoring per trajectory (B x K stamps): the particle waves score the rows their trajectory needs with the
         # float64 arithmetic of the single-trajectory step; MIDAS_DENSE_SCORES=1 keeps the matrix-core pass over all rows
