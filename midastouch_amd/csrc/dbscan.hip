@@ -141,15 +141,58 @@ __device__ __forceinline__ int db_cell_of(const DbGrid& g, float x, float y, flo
     return (cz * g.dy + cy) * g.dx + cx;
 }
 
+// ---- one atomic per distinct cell of a wave ----------------------------------------------------------------------------
+// A gathered cloud sits in a handful of cells: per-lane atomics on one counter serialise (8000 particles in three cells:
+// 63 us for a counting pass).  The lanes of a wave that share a cell are served by one atomic of their leader; after
+// DB_AGG_KEYS distinct cells (a spread cloud: no contention there) the remaining lanes go one by one.
+constexpr int DB_AGG_KEYS = 6;
+// returns this lane's value of the counter before its own increment, as a per-lane atomicAdd(.., 1) would (any order)
+__device__ __forceinline__ int db_cell_fetch_inc(int* counters, int c, bool active) {
+    const int lane = threadIdx.x & 63;
+    int result = 0;
+    unsigned long long todo = __ballot(active);
+    for (int it = 0; it < DB_AGG_KEYS && todo; ++it) {
+        const int l = __builtin_ctzll(todo);
+        const int cl = __shfl(c, l);
+        const unsigned long long same = __ballot(active && c == cl) & todo;
+        int base = 0;
+        if (lane == l) base = atomicAdd(&counters[cl], (int)__popcll(same));
+        base = __shfl(base, l);
+        if ((same >> lane) & 1ull) result = base + (int)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1ull) result = atomicAdd(&counters[c], 1);
+    return result;
+}
+// atomicMin(&arr[c], val) for the active lanes
+__device__ __forceinline__ void db_cell_min(int32_t* arr, int c, int32_t val, bool active) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(active);
+    for (int it = 0; it < DB_AGG_KEYS && todo; ++it) {
+        const int l = __builtin_ctzll(todo);
+        const int cl = __shfl(c, l);
+        const unsigned long long same = __ballot(active && c == cl) & todo;
+        int32_t m = ((same >> lane) & 1ull) ? val : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int32_t x = __shfl_xor(m, o); m = x < m ? x : m; }
+        if (lane == l) atomicMin(&arr[cl], m);
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1ull) atomicMin(&arr[c], val);
+}
+
 __global__ __launch_bounds__(256) void k_db_count(DbArgs a) {
     const DbGrid g = *a.grid;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= g.n) return;
-    const float* P = a.poses + i * 16;
-    int cx, cy, cz;
-    const int c = db_cell_of(g, P[3], P[7], P[11], cx, cy, cz);
-    a.cid[i] = c;
-    atomicAdd(&a.cell_count[c], 1);
+    const bool in = i < g.n;
+    int c = 0;
+    if (in) {
+        const float* P = a.poses + i * 16;
+        int cx, cy, cz;
+        c = db_cell_of(g, P[3], P[7], P[11], cx, cy, cz);
+        a.cid[i] = c;
+    }
+    (void)db_cell_fetch_inc(a.cell_count, c, in);
 }
 
 // exclusive scan of the cell populations (one workgroup); the counters become the scatter cursors
@@ -195,10 +238,11 @@ __global__ __launch_bounds__(1024) void k_db_scan(DbArgs a) {
 __global__ __launch_bounds__(256) void k_db_scatter(DbArgs a) {
     const DbGrid g = *a.grid;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= g.n) return;
+    const bool in = i < g.n;
+    const int c = in ? a.cid[i] : 0;
+    const int p = db_cell_fetch_inc(a.cell_count, c, in);
+    if (!in) return;
     const float* P = a.poses + i * 16;
-    const int c = a.cid[i];
-    const int p = atomicAdd(&a.cell_count[c], 1);
     a.s_orig[p] = (int32_t)i;
     a.s_pt[p] = make_float4(P[3], P[7], P[11], __int_as_float(c));
 }
@@ -231,24 +275,25 @@ __global__ __launch_bounds__(256) void k_db_core(DbArgs a) {
     DbGrid* gp = a.grid;
     const DbGrid g = *gp;
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= g.n) return;
-    const float4 me = a.s_pt[p];
-    const int c = __float_as_int(me.w);
-    const int cnt = a.cell_start[c + 1] - a.cell_start[c];
-    int state = cnt >= g.ms ? 1 : 0;  // 1 core, 0 not core, 2 undecided
-    if (!state) {
-        int upper = cnt;
-        db_for_cells(g, c, false, [&](int c2) { upper += a.cell_start[c2 + 1] - a.cell_start[c2]; return false; });
-        if (upper >= g.ms) state = 2;
+    const bool in = p < g.n;
+    int c = 0, state = 0;  // 1 core, 0 not core, 2 undecided
+    int32_t orig = 0;
+    if (in) {
+        const float4 me = a.s_pt[p];
+        c = __float_as_int(me.w);
+        const int cnt = a.cell_start[c + 1] - a.cell_start[c];
+        state = cnt >= g.ms ? 1 : 0;
+        if (!state) {
+            int upper = cnt;
+            db_for_cells(g, c, false, [&](int c2) { upper += a.cell_start[c2 + 1] - a.cell_start[c2]; return false; });
+            if (upper >= g.ms) state = 2;
+        }
+        orig = a.s_orig[p];
+        a.parent[orig] = orig;
+        if (state == 2) a.work[atomicAdd(&gp->nwork, 1)] = (int32_t)p;
+        else a.s_core[p] = (uint8_t)state;
     }
-    const int32_t orig = a.s_orig[p];
-    a.parent[orig] = orig;
-    if (state == 2) {
-        a.work[atomicAdd(&gp->nwork, 1)] = (int32_t)p;
-        return;
-    }
-    a.s_core[p] = (uint8_t)state;
-    if (state) atomicMin(&a.cell_rep[c], orig);
+    db_cell_min(a.cell_rep, c, orig, in && state == 1);
 }
 
 // Pass 2, one wave per undecided point: the lanes share the candidates of each cell (coalesced), the count stops at
