@@ -12,6 +12,7 @@
 // then the blocks in order.
 #include "midas_internal.hpp"
 #include "midas_math.hpp"
+#include "cluster_rot.hpp"
 
 namespace midas {
 
@@ -146,67 +147,31 @@ __global__ __launch_bounds__(256) void k_loop_cluster_moments(const int32_t* __r
     cluster_moments_body(n, poses, w64, (const float*)nullptr, labels, C, [](int c) { return (int64_t)(c - 1); }, part, s_w);
 }
 
-// cyclic Jacobi on a symmetric 4x4 (float64): A -> diag, V = eigenvectors (columns)
-MD void jacobi4(double A[4][4], double V[4][4]) {
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) V[i][j] = i == j ? 1.0 : 0.0;
-#ifndef MIDAS_JACOBI_SWEEPS
-#define MIDAS_JACOBI_SWEEPS 32
-#endif
-    for (int sweep = 0; sweep < MIDAS_JACOBI_SWEEPS; ++sweep) {
-        double off = 0.0, dia = 0.0;
-        for (int i = 0; i < 4; ++i) {
-            dia += A[i][i] * A[i][i];
-            for (int j = i + 1; j < 4; ++j) off += A[i][j] * A[i][j];
-        }
-        // converged when the off-diagonal mass is below rounding of the diagonal (the eigenvector error is of the order
-        // sqrt(off) / gap: 1e-15 here, far below the float32 the result is rounded to)
-        if (off < 1e-40 || off < 1e-30 * dia) break;
-        for (int p = 0; p < 3; ++p)
-            for (int q = p + 1; q < 4; ++q) {
-                if (__builtin_fabs(A[p][q]) < 1e-300 || A[p][q] * A[p][q] < 1e-34 * dia) continue;
-                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-                const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (__builtin_fabs(theta) + __builtin_sqrt(theta * theta + 1.0));
-                const double c = 1.0 / __builtin_sqrt(tt * tt + 1.0), s = tt * c;
-                for (int k = 0; k < 4; ++k) {
-                    const double akp = A[k][p], akq = A[k][q];
-                    A[k][p] = c * akp - s * akq;
-                    A[k][q] = s * akp + c * akq;
-                }
-                for (int k = 0; k < 4; ++k) {
-                    const double apk = A[p][k], aqk = A[q][k];
-                    A[p][k] = c * apk - s * aqk;
-                    A[q][k] = s * apk + c * aqk;
-                }
-                for (int k = 0; k < 4; ++k) {
-                    const double vkp = V[k][p], vkq = V[k][q];
-                    V[k][p] = c * vkp - s * vkq;
-                    V[k][q] = s * vkp + c * vkq;
-                }
-            }
-    }
-}
-
 // one 64-thread workgroup per cluster: blocks summed in order, then the closed forms
+// rot_out (loop step): the normalised moment matrix goes there (10 doubles per cluster) and the rotation entries of the
+// centre are left to whoever solves it (cluster_rotation_write, beside the annealing); nullptr: solved here
 MD void cluster_finish_body(int nblocks, int C, int c, const double* __restrict__ part, float* __restrict__ centers,
-                            float* __restrict__ stds, int64_t* __restrict__ counts, double* s_m) {
+                            float* __restrict__ stds, int64_t* __restrict__ counts, double* s_m, double* __restrict__ rot_out = nullptr) {
     const int t = threadIdx.x;
     if (t < CL_MOM) {
-        // blocks in order; eight partials are fetched together (independent loads), then added one after the other
+        // blocks in order; FB partials are fetched together (independent loads: one round trip), then added one after the
+        // other (32 at a time: a small set's 40 blocks are two trips instead of five)
+        constexpr int FB = 32;
         double r = part[(size_t)c * CL_MOM + t];
-        for (int b0 = 1; b0 < nblocks; b0 += 8) {
-            double x[8];
+        for (int b0 = 1; b0 < nblocks; b0 += FB) {
+            double x[FB];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < FB; ++j) {
                 const int b = b0 + j < nblocks ? b0 + j : nblocks - 1;
                 x[j] = part[((size_t)b * C + c) * CL_MOM + t];
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (b0 + j >= nblocks) break;
-                if (t == M_WMAX) r = x[j] > r ? x[j] : r;
-                else if (t == M_WMIN) r = x[j] < r ? x[j] : r;
-                else r = r + x[j];
+            for (int j = 0; j < FB; ++j) {
+                if (b0 + j < nblocks) {
+                    if (t == M_WMAX) r = x[j] > r ? x[j] : r;
+                    else if (t == M_WMIN) r = x[j] < r ? x[j] : r;
+                    else r = r + x[j];
+                }
             }
         }
         s_m[t] = r;
@@ -226,23 +191,16 @@ MD void cluster_finish_body(int nblocks, int C, int c, const double* __restrict_
     const bool flat = __builtin_fabsf(d) <= 1e-8f;
     const int oq = flat ? M_QQ1 : M_QQW, ot = flat ? M_T1 : M_TW, ott = flat ? M_TT1 : M_TTW;
     const double sw = flat ? s_m[M_CNT] : s_m[M_SW];
-    double A[4][4], V[4][4];
-    int k = 0;
-    for (int i = 0; i < 4; ++i)
-        for (int j = i; j < 4; ++j) { A[i][j] = A[j][i] = s_m[oq + k] / sw; ++k; }
-    jacobi4(A, V);
-    int best = 0;
-    for (int i = 1; i < 4; ++i)
-        if (A[i][i] > A[best][best]) best = i;
-    double qx = V[0][best], qy = V[1][best], qz = V[2][best], qw = V[3][best];
-    if (qw < 0.0) { qx = -qx; qy = -qy; qz = -qz; qw = -qw; }  // :139
-    const double n = __builtin_sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
-    qx /= n; qy /= n; qz /= n; qw /= n;
+    double A10[10];
+    for (int k = 0; k < 10; ++k) A10[k] = s_m[oq + k] / sw;
+    if (rot_out) {
+        for (int k = 0; k < 10; ++k) rot_out[(size_t)c * 10 + k] = A10[k];
+    } else {
+        cluster_rotation_write(A10, out);
+    }
     float mean[3];
     for (int i = 0; i < 3; ++i) mean[i] = (float)(s_m[ot + i] / sw);
-    out[0] = (float)(1.0 - 2.0 * (qy * qy + qz * qz)); out[1] = (float)(2.0 * (qx * qy - qz * qw)); out[2] = (float)(2.0 * (qx * qz + qy * qw)); out[3] = mean[0];
-    out[4] = (float)(2.0 * (qx * qy + qz * qw)); out[5] = (float)(1.0 - 2.0 * (qx * qx + qz * qz)); out[6] = (float)(2.0 * (qy * qz - qx * qw)); out[7] = mean[1];
-    out[8] = (float)(2.0 * (qx * qz - qy * qw)); out[9] = (float)(2.0 * (qy * qz + qx * qw)); out[10] = (float)(1.0 - 2.0 * (qx * qx + qy * qy)); out[11] = mean[2];
+    out[3] = mean[0]; out[7] = mean[1]; out[11] = mean[2];
     out[12] = 0.f; out[13] = 0.f; out[14] = 0.f; out[15] = 1.f;
     // sum w (t - m)^2 / sum w with m the float32 centre, from the moments
     for (int i = 0; i < 3; ++i) {
@@ -263,21 +221,23 @@ __global__ __launch_bounds__(64) void k_cluster_finish(int nblocks, int C, const
 // loop engine: cluster slot c = blockIdx.x of the LOOP_MAX_CLUSTERS launched; rows of label c - 1
 __global__ __launch_bounds__(64) void k_loop_cluster_finish(const int32_t* __restrict__ ctl_i, const double* __restrict__ part,
                                                             float* __restrict__ centers, float* __restrict__ stds,
-                                                            int64_t* __restrict__ counts) {
+                                                            int64_t* __restrict__ counts, double* __restrict__ rot) {
     __shared__ double s_m[CL_MOM];
     const int64_t n = ctl_i[LOOP_I_N];
     int C = ctl_i[LOOP_I_NCL] + 1;
     C = C > LOOP_MAX_CLUSTERS ? LOOP_MAX_CLUSTERS : C;
     if ((int)blockIdx.x >= C) return;
-    cluster_finish_body((int)((n + 255) / 256), C, blockIdx.x, part, centers, stds, counts, s_m);
+    cluster_finish_body((int)((n + 255) / 256), C, blockIdx.x, part, centers, stds, counts, s_m, rot);
 }
 
+// rot: LOOP_MAX_CLUSTERS x 10 doubles - the moment matrices whose eigenproblem the annealing kernel's second workgroup solves
+// (the decision only needs the translation spreads: the float64 Jacobi, 15 us on one thread, runs beside the selection)
 int launch_loop_cluster(midas_ctx* ctx, int64_t cap, const int32_t* ctl_i, const float* poses, const double* w64,
-                        const int32_t* labels, double* part, float* centers, float* stds, int64_t* counts) {
+                        const int32_t* labels, double* part, float* centers, float* stds, int64_t* counts, double* rot) {
     hipLaunchKernelGGL(k_loop_cluster_moments, dim3((unsigned)ceil_div(cap, 256)), dim3(256), 0, ctx->stream, ctl_i, poses, w64,
                        labels, part);
     hipLaunchKernelGGL(k_loop_cluster_finish, dim3(LOOP_MAX_CLUSTERS), dim3(64), 0, ctx->stream, ctl_i, (const double*)part, centers,
-                       stds, counts);
+                       stds, counts, rot);
     MIDAS_HIP_CHECK(ctx, hipGetLastError());
     return MIDAS_OK;
 }

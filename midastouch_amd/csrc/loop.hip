@@ -23,6 +23,7 @@
 
 #include "midas_internal.hpp"
 #include "midas_math.hpp"
+#include "cluster_rot.hpp"
 #include "tail_block.hpp"
 
 namespace midas {
@@ -264,7 +265,9 @@ MD void loop_decide(int32_t* __restrict__ ctl_i, double* __restrict__ ctl_d, con
     float sum = 0.f;
     for (int c = 0; c < C; ++c) {
         if (counts_all[c] == 0) continue;
-        for (int i = 0; i < 16; ++i) centers_out[np * 16 + i] = centers_all[c * 16 + i];
+        // the translation and the bottom row; the rotation entries of the row come from loop_rotations (second workgroup)
+        for (int i = 3; i < 12; i += 4) centers_out[np * 16 + i] = centers_all[c * 16 + i];
+        for (int i = 12; i < 16; ++i) centers_out[np * 16 + i] = centers_all[c * 16 + i];
         for (int i = 0; i < 3; ++i) {
             const float s = stds_all[c * 3 + i];
             stds_out[np * 3 + i] = s;
@@ -305,11 +308,28 @@ MD void loop_decide(int32_t* __restrict__ ctl_i, double* __restrict__ ctl_d, con
     k_out = k;
 }
 
+// Second workgroup of the annealing kernels: the rotation of every present cluster's centre (float64 Jacobi on the moment
+// matrix k_loop_cluster_finish left in `rot`), written into the compact row loop_decide gives the cluster - the selection
+// does not wait for it.  Lane c < 8 of one wave takes cluster slot c.
+MD void loop_rotations(const int32_t* __restrict__ ctl_i, const int64_t* __restrict__ counts_all, const double* __restrict__ rot,
+                       float* __restrict__ centers_out) {
+    int C = ctl_i[LOOP_I_NCL] + 1;
+    C = C > LOOP_MAX_CLUSTERS ? LOOP_MAX_CLUSTERS : C;
+    const int c = threadIdx.x;
+    if (c >= C || counts_all[c] == 0) return;
+    int np = 0;
+    for (int j = 0; j < c; ++j) np += counts_all[j] != 0 ? 1 : 0;
+    double A10[10];
+    for (int k = 0; k < 10; ++k) A10[k] = rot[(size_t)c * 10 + k];
+    cluster_rotation_write(A10, centers_out + np * 16);
+}
+
 __global__ __launch_bounds__(256) void k_loop_decide(int32_t* __restrict__ ctl_i, double* __restrict__ ctl_d,
                                                      const float* __restrict__ centers_all, const float* __restrict__ stds_all,
                                                      const int64_t* __restrict__ counts_all, float* __restrict__ centers_out,
                                                      float* __restrict__ stds_out, uint32_t* __restrict__ hist,
-                                                     int32_t* __restrict__ sel_state, int32_t floor_n) {
+                                                     int32_t* __restrict__ sel_state, int32_t floor_n, const double* __restrict__ rot) {
+    if (blockIdx.x == 1) { loop_rotations(ctl_i, counts_all, rot, centers_out); return; }
     const int t = threadIdx.x;
     for (int i = t; i < SEL_PASSES * SEL_BINS; i += 256) hist[i] = 0u;
     for (int i = t; i < 4 * (SEL_PASSES + 2); i += 256) sel_state[i] = 0;
@@ -611,7 +631,9 @@ __global__ __launch_bounds__(1024) void k_loop_anneal_small(int32_t* __restrict_
                                                             const float* __restrict__ centers_all, const float* __restrict__ stds_all,
                                                             const int64_t* __restrict__ counts_all, float* __restrict__ centers_out,
                                                             float* __restrict__ stds_out, int32_t floor_n,
-                                                            const double* __restrict__ w, int32_t* __restrict__ src) {
+                                                            const double* __restrict__ w, int32_t* __restrict__ src,
+                                                            const double* __restrict__ rot) {
+    if (DECIDE && blockIdx.x == 1) { loop_rotations(ctl_i, counts_all, rot, centers_out); return; }
     __shared__ uint32_t s_h[SEL_BINS];
     __shared__ int s_w[40];
     __shared__ uint64_t s_key[LOOP_SMALL_PAIRS];
@@ -944,7 +966,8 @@ int launch_anneal_select(midas_ctx* ctx, int64_t N, const double* w, int32_t mod
     if (N <= LOOP_SMALL_MAX && small && atoi(small)) {
         hipLaunchKernelGGL(k_loop_identity, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, (int32_t)N, src);
         hipLaunchKernelGGL(k_loop_anneal_small<false>, dim3(1), dim3(1024), 0, ctx->stream, (int32_t*)ctl, (double*)nullptr,
-                           (const float*)nullptr, (const float*)nullptr, (const int64_t*)nullptr, (float*)nullptr, (float*)nullptr, 0, w, src);
+                           (const float*)nullptr, (const float*)nullptr, (const int64_t*)nullptr, (float*)nullptr, (float*)nullptr, 0, w, src,
+                           (const double*)nullptr);
         LAUNCH_CHECK(ctx);
         return MIDAS_OK;
     }
@@ -1012,7 +1035,8 @@ int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree*
             return rc;
     }
     if (phases & MIDAS_LOOP_ANNEAL) {
-        void *part, *cen, *sd, *cnt;
+        void *part, *cen, *sd, *cnt, *rot;
+        if ((rc = midas_scratch(ctx, LOOP_MAX_CLUSTERS * 10 * sizeof(double), &rot))) return rc;
         if ((rc = midas_scratch(ctx, (size_t)ceil_div(cap, 256) * LOOP_MAX_CLUSTERS * 36 * sizeof(double), &part))) return rc;
         if ((rc = midas_scratch(ctx, LOOP_MAX_CLUSTERS * 16 * sizeof(float), &cen))) return rc;
         if ((rc = midas_scratch(ctx, LOOP_MAX_CLUSTERS * 3 * sizeof(float), &sd))) return rc;
@@ -1020,15 +1044,16 @@ int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree*
         SelectScratch ss;
         if ((rc = select_scratch(ctx, cap, ss))) return rc;
         if ((rc = launch_loop_cluster(ctx, cap, s.ctl_i_dev, s.poses_prop_dev, s.weights_dev, s.labels_dev, (double*)part, (float*)cen,
-                                      (float*)sd, (int64_t*)cnt)))
+                                      (float*)sd, (int64_t*)cnt, (double*)rot)))
             return rc;
         if (s.anneal_small && cap <= LOOP_SMALL_MAX) {
-            hipLaunchKernelGGL(k_loop_anneal_small<true>, dim3(1), dim3(1024), 0, st, s.ctl_i_dev, s.ctl_d_dev, (const float*)cen, (const float*)sd,
-                               (const int64_t*)cnt, s.cluster_poses_dev, s.cluster_stds_dev, s.floor, (const double*)s.weights_dev, s.src_dev);
+            hipLaunchKernelGGL(k_loop_anneal_small<true>, dim3(2), dim3(1024), 0, st, s.ctl_i_dev, s.ctl_d_dev, (const float*)cen, (const float*)sd,
+                               (const int64_t*)cnt, s.cluster_poses_dev, s.cluster_stds_dev, s.floor, (const double*)s.weights_dev, s.src_dev,
+                               (const double*)rot);
             LAUNCH_CHECK(ctx);
         } else {
-            hipLaunchKernelGGL(k_loop_decide, dim3(1), dim3(256), 0, st, s.ctl_i_dev, s.ctl_d_dev, (const float*)cen, (const float*)sd,
-                               (const int64_t*)cnt, s.cluster_poses_dev, s.cluster_stds_dev, ss.hist, ss.state, s.floor);
+            hipLaunchKernelGGL(k_loop_decide, dim3(2), dim3(256), 0, st, s.ctl_i_dev, s.ctl_d_dev, (const float*)cen, (const float*)sd,
+                               (const int64_t*)cnt, s.cluster_poses_dev, s.cluster_stds_dev, ss.hist, ss.state, s.floor, (const double*)rot);
             if ((rc = launch_select(ctx, cap, s.ctl_i_dev, s.weights_dev, s.src_dev, ss))) return rc;
         }
     }

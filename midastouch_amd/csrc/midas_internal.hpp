@@ -324,7 +324,7 @@ int launch_cluster_centers(midas_ctx* ctx, int64_t N, const float* poses, const 
                            int64_t* counts);
 
 int launch_loop_cluster(midas_ctx* ctx, int64_t cap, const int32_t* ctl_i, const float* poses, const double* w64,
-                        const int32_t* labels, double* part, float* centers, float* stds, int64_t* counts);
+                        const int32_t* labels, double* part, float* centers, float* stds, int64_t* counts, double* rot);
 
 // loop.hip / dbscan.hip - the reference's whole loop body on a variable-size particle set (midas_loop_step)
 int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* t6, const midas_tree* t3,
