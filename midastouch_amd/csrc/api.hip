@@ -1,5 +1,6 @@
 // api.hip - context, scratch, profiling and the extern "C" surface of libmidas_hip.so.
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -27,6 +28,8 @@ static ScratchState* scratch_of(midas_ctx* ctx) { return reinterpret_cast<Scratc
 static int scratch_reset(midas_ctx* ctx) {
     ScratchState* s = scratch_of(ctx);
     if (s->chunks.size() > 1) {  // consolidate: one chunk large enough for the last call's total
+        static const bool log = getenv("MIDAS_SCRATCH_LOG") != nullptr;
+        if (log) fprintf(stderr, "[midas] scratch: %zu chunks -> one of %zu bytes (stream sync, free, malloc)\n", s->chunks.size(), s->total + (s->total >> 2) + 4096);
         MIDAS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         for (auto& c : s->chunks) (void)hipFree(c.p);
         s->chunks.clear();
