@@ -297,6 +297,20 @@ typedef struct midas_lazy_flush_args {
 } midas_lazy_flush_args;
 int midas_lazy_flush(midas_ctx* ctx, const midas_lazy_flush_args* args);
 
+/* The pipelined step for a BATCH of B independent trajectories against one codebook (BASELINE config 5; the reference runs one
+ * trajectory per process, filter/filter.py:150-190 - here they share a launch, trajectory = grid.y).  Same argument structs; every
+ * per-trajectory array gains a leading batch dimension, contiguous: poses (B, N, 16), nn_idx / valid / ridx / hint / weights
+ * (B, N), status (B, 2), scores and score_stamps (B, K), odom16 / gt16 (B, 16), code (B, D), part_rmse (B, 2 * ceil(N / 64)),
+ * rmse (B, 3) for the step [rmse_t, rmse_r, device clock] and (B, 2) for the flush, u (B, N); `tables_dev` holds B blocks of
+ * midas_lazy_tables_doubles(N) doubles, 128-byte aligned.  Draws are keyed per trajectory as in midas_filter_step_batch
+ * (Philox key = trajectory * N + slot; the systematic offset's key = seed + trajectory), so every trajectory is bit-identical
+ * to a single-trajectory run of the batch step.  Needs score stamps (sparse scoring), a float32 codebook with D in
+ * {128, 256, 512, 1024}, 16 <= N <= 262144. */
+int64_t midas_lazy_tables_doubles(int64_t N);
+int midas_lazy_step_batch(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
+                          const midas_lazy_args* args, int32_t B);
+int midas_lazy_flush_batch(midas_ctx* ctx, const midas_lazy_flush_args* args, int32_t B);
+
 
 /* ---- particle-sharded step (one process per GPU; the caller runs the collectives between the calls) ---- */
 /* The frame of midas_filter_step split at its three global reductions so that N_total particles can be

@@ -202,6 +202,9 @@ SIGNATURES = {
     "midas_lazy_step": (C.c_int, [_P, _P, _P, _P, C.POINTER(LazyArgs)]),
     "midas_lazy_run": (C.c_int, [_P, _P, _P, _P, C.POINTER(LazyArgs), _I32, _P]),
     "midas_lazy_flush": (C.c_int, [_P, C.POINTER(LazyFlushArgs)]),
+    "midas_lazy_tables_doubles": (C.c_int64, [_I64]),
+    "midas_lazy_step_batch": (C.c_int, [_P, _P, _P, _P, C.POINTER(LazyArgs), _I32]),
+    "midas_lazy_flush_batch": (C.c_int, [_P, C.POINTER(LazyFlushArgs), _I32]),
     "midas_loop_step": (C.c_int, [_P, _P, _P, _P, C.POINTER(LoopArgs), _I32]),
     "midas_dbscan": (C.c_int, [_P, _I64, _P, _D, _I64, _P, _P]),
     "midas_anneal_select": (C.c_int, [_P, _I64, _P, _I32, _I64, _P]),

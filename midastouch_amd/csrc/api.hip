@@ -588,7 +588,12 @@ static TailTables tables_of(double* t, int64_t N) {
 }
 
 static int lazy_step_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
-                          const midas_lazy_args& s, double* rmse_out);
+                          const midas_lazy_args& s, double* rmse_out, int32_t B = 1, int64_t tstride = 0);
+static int64_t tables_doubles(int64_t N) {  // size of one trajectory's table block (tables_of), padded to whole 128-byte lines
+    const int64_t ng = ceil_div(N, SCAN_CHUNK), nb = ceil_div(N, SCAN_BLOCK);
+    const int64_t raw = 4 * (ceil_div(N, 16) * 16) + 2 * (ceil_div(ng, 16) * 16) + 37 * nb;
+    return ceil_div(raw, 16) * 16;
+}
 
 MIDAS_EXPORT int midas_lazy_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
                                  const midas_lazy_args* args) {
@@ -629,7 +634,7 @@ MIDAS_EXPORT int midas_lazy_run(midas_ctx* ctx, const midas_codebook* cb, const 
 }
 
 static int lazy_step_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
-                          const midas_lazy_args& s, double* rmse_out) {
+                          const midas_lazy_args& s, double* rmse_out, int32_t B, int64_t tstride) {
     MIDAS_REQUIRE(ctx, s.N > 0 && ceil_div(s.N, SCAN_BLOCK) <= LAZY_MAX_BLOCKS && s.poses_prop_dev && s.nn_idx_dev && s.valid_dev &&
                            s.status_dev && s.tables_dev && (uintptr_t)s.tables_dev % 128 == 0 && s.scores_dev && s.odom16_dev && s.code_dev);
     MIDAS_REQUIRE(ctx, s.resample_prev ? (s.poses_prop_prev_dev && s.nn_idx_prev_dev && s.status_prev_dev &&
@@ -642,6 +647,8 @@ static int lazy_step_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_
     const TailTables tb = tables_of(s.tables_dev, N);
     ParticleUpdateArgs pa;
     pa.N = N;
+    pa.batch = B;
+    pa.score_stride = cb->K;
     pa.poses_in = s.poses_in_dev;
     pa.poses_prop = s.poses_prop_dev;
     pa.odom16 = s.odom16_dev;
@@ -674,6 +681,7 @@ static int lazy_step_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_
         r.nb = (int)ceil_div(N, SCAN_BLOCK); r.ng = (int)ceil_div(N, SCAN_CHUNK);
         r.softmax = s.softmax; r.mode = s.resample_mode; r.u = s.u_prev_dev; r.u32 = s.u32_prev;
         r.seed = s.seed; r.step = s.step_prev;
+        r.tstride = tstride;
     }
     if (ctx->prof && ctx->ev_ready) {
         (void)hipEventRecord(ctx->ev[6], ctx->stream);
@@ -682,12 +690,21 @@ static int lazy_step_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_
     prof_mark(ctx, 1);
     bool launched = false;
     int rc;
-    if ((rc = launch_frame_front(ctx, tree6, tree3, pa, cb, s.code_dev, s.scores_dev, &launched))) return rc;
-    if (!launched)
-        return midas_set_error(ctx, MIDAS_ERR_INVALID, "codebook", "the pipelined step needs a float32 codebook with D in {128,256,512,1024}");
+    if (B > 1 && !s.resample_prev) {
+        // a batch's first frame (nothing to fold in yet): the plain particle update over grid.y, sparse scoring per trajectory
+        MIDAS_REQUIRE(ctx, pa.sp.stamps && cb->dtype == MIDAS_F32 && (cb->D == 128 || cb->D == 256 || cb->D == 512 || cb->D == 1024) &&
+                               (uintptr_t)cb->emb % 16 == 0 && (uintptr_t)s.code_dev % 16 == 0);
+        pa.sp.emb = (const float*)cb->emb; pa.sp.norms = cb->norms; pa.sp.code = s.code_dev; pa.sp.scores = s.scores_dev; pa.sp.nj = cb->D / 64;
+        if ((rc = launch_particle_update(ctx, tree6, tree3, pa))) return rc;
+    } else {
+        if ((rc = launch_frame_front(ctx, tree6, tree3, pa, cb, s.code_dev, s.scores_dev, &launched))) return rc;
+        if (!launched)
+            return midas_set_error(ctx, MIDAS_ERR_INVALID, "codebook", B > 1 ? "the pipelined batch step needs a float32 codebook with D in {128,256,512,1024}, score stamps and N <= 262144"
+                                                                              : "the pipelined step needs a float32 codebook with D in {128,256,512,1024}");
+    }
     prof_mark(ctx, 2);
-    if ((rc = launch_tail_a2(ctx, N, s.scores_dev, s.nn_idx_dev, s.valid_dev, s.softmax, tb, s.status_dev, 1, 0, true,
-                             pa.gt16 ? s.part_rmse_dev : nullptr, rmse_out)))
+    if ((rc = launch_tail_a2(ctx, N, s.scores_dev, s.nn_idx_dev, s.valid_dev, s.softmax, tb, s.status_dev, B, cb->K, true,
+                             pa.gt16 ? s.part_rmse_dev : nullptr, rmse_out, B > 1 ? tstride : 0)))
         return rc;
     prof_mark(ctx, 3);
     if (ctx->prof && ctx->ev_ready) {
@@ -710,16 +727,22 @@ static int lazy_step_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_
     return MIDAS_OK;
 }
 
+static int lazy_flush_impl(midas_ctx* ctx, const midas_lazy_flush_args& s, int32_t B, int64_t tstride);
+
 MIDAS_EXPORT int midas_lazy_flush(midas_ctx* ctx, const midas_lazy_flush_args* args) {
     MIDAS_ENTER(ctx);
     MIDAS_REQUIRE(ctx, args != nullptr);
-    const midas_lazy_flush_args& s = *args;
+    return lazy_flush_impl(ctx, *args, 1, 0);
+}
+
+static int lazy_flush_impl(midas_ctx* ctx, const midas_lazy_flush_args& s, int32_t B, int64_t tstride) {
     MIDAS_REQUIRE(ctx, s.N > 0 && s.tables_dev && s.valid_dev && s.nn_idx_dev && s.poses_prop_dev && s.status_dev && s.weights_dev &&
                            s.ridx_dev && s.poses_out_dev && s.weights_out_dev && s.hint_out_dev && s.poses_out_dev != s.poses_prop_dev);
     MIDAS_REQUIRE(ctx, s.resample_mode == MIDAS_RESAMPLE_MULTINOMIAL || s.resample_mode == MIDAS_RESAMPLE_SYSTEMATIC);
     const TailTables tb = tables_of(const_cast<double*>(s.tables_dev), s.N);
     StepTailArgs ta;
-    ta.batch = 1;
+    ta.batch = B;
+    ta.tstride = B > 1 ? tstride : 0;
     ta.N = s.N;
     ta.npart = 0;
     ta.x = nullptr; ta.e = nullptr; ta.cdf = nullptr; ta.part_max = nullptr; ta.part_min = nullptr;
@@ -741,6 +764,24 @@ MIDAS_EXPORT int midas_lazy_flush(midas_ctx* ctx, const midas_lazy_flush_args* a
     ta.part_rmse = (s.part_rmse_dev && s.rmse_dev) ? s.part_rmse_dev : nullptr;
     ta.rmse_out = s.rmse_dev;
     return launch_tail_b2(ctx, ta, tb);
+}
+
+// ---- pipelined batch (config 5): B trajectories, grid.y, one table block per trajectory -------------------------------
+MIDAS_EXPORT int64_t midas_lazy_tables_doubles(int64_t N) { return N > 0 ? tables_doubles(N) : 0; }
+
+MIDAS_EXPORT int midas_lazy_step_batch(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
+                                       const midas_lazy_args* args, int32_t B) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, cb && tree6 && tree3 && args && tree6->dim == 6 && tree3->dim == 3 && tree6->K == cb->K && B >= 1);
+    MIDAS_REQUIRE(ctx, args->score_stamps_dev && args->score_epoch && ceil_div(args->N, SCAN_BLOCK) <= 64 && args->N >= SCAN_CHUNK);
+    return lazy_step_impl(ctx, cb, tree6, tree3, *args, (args->gt16_dev && args->part_rmse_dev) ? args->rmse_dev : nullptr, B,
+                          tables_doubles(args->N));
+}
+
+MIDAS_EXPORT int midas_lazy_flush_batch(midas_ctx* ctx, const midas_lazy_flush_args* args, int32_t B) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, args != nullptr && B >= 1);
+    return lazy_flush_impl(ctx, *args, B, tables_doubles(args->N));
 }
 
 // ---- particle-sharded step pieces -------------------------------------------------------------------

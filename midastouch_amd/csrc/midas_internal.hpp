@@ -190,6 +190,9 @@ struct LazyResample {
     const double* u;                                                 // nullable: the previous frame's uniforms
     float u32;
     uint64_t seed, step;                                             // Philox key / counter of the previous frame's draws
+    int64_t tstride = 0;      // batch of trajectories: doubles between two trajectories' table blocks
+    int64_t key_base = 0;     // Philox key of this trajectory's slot 0 (trajectory * N), set per trajectory in the kernel
+    int32_t traj = 0;         // trajectory (the systematic draw's key is seed + trajectory, as in k_tail_b2)
 };
 
 // sparse scoring inside the particle kernels (score_body.hpp score_claimed_rows)
@@ -286,6 +289,7 @@ struct StepTailArgs {
     double* x_raw = nullptr;   // [N] scratch: raw scores, written only where the guard may fire
     double* lp_raw = nullptr;  // [N] scratch: block-local prefix of x*valid, likewise
     int64_t score_stride = 0;  // K: scores are (batch, K)
+    int64_t tstride = 0;       // pipelined batch: doubles between two trajectories' table blocks (tables_of layout per trajectory)
 };
 int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base);
 // the deferred tail on explicit tables (what k_tail_a2 writes and k_tail_b2 / the lazy front read)
@@ -296,7 +300,7 @@ struct TailTables {
 };
 int launch_tail_a2(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
                    int32_t softmax, const TailTables& tb, int32_t* status, int batch = 1, int64_t score_stride = 0,
-                   bool padded_tables = false, const double* part_rmse = nullptr, double* rmse_out = nullptr);  // padded: per-slot tables hold a multiple of 16 values (tables_of, api.hip)
+                   bool padded_tables = false, const double* part_rmse = nullptr, double* rmse_out = nullptr, int64_t tstride = 0);  // padded: per-slot tables hold a multiple of 16 values (tables_of, api.hip)
 int launch_tail_b2(midas_ctx* ctx, const StepTailArgs& a, const TailTables& tb);  // a.x, a.e, a.cdf, a.lp_raw unused
 int launch_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
                         int32_t softmax, const TailTables& tb, double* r1, int32_t* status);

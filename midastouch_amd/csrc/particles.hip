@@ -1464,10 +1464,10 @@ MD int64_t lazy_source(const LazyResample& rs, const double* rs_lds, int64_t n, 
     double tq;
     bool upper;
     if (rs.mode == MIDAS_RESAMPLE_MULTINOMIAL) {
-        tq = rs.u ? rs.u[n] : philox_uniform53((uint64_t)n, rs.seed, rs.step);
+        tq = rs.u ? rs.u[n] : philox_uniform53((uint64_t)(n + rs.key_base), rs.seed, rs.step);
         upper = false;
     } else {
-        const float r = rs.u32 >= 0.0f ? rs.u32 : philox_uniform24(rs.seed, rs.step);
+        const float r = rs.u32 >= 0.0f ? rs.u32 : philox_uniform24(rs.seed + (uint64_t)rs.traj, rs.step);
         const float off = r / (float)N;
         tq = (double)n / (double)N + (double)off;
         tq = tq >= 1.0 ? tq - 1.0 : tq;
@@ -1513,6 +1513,16 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
             a.sp.stamps += b * a.score_stride; a.sp.scores += b * a.score_stride; a.sp.code += b * (int64_t)(a.sp.nj * 64);
         }
         a.slot_base += o;
+        if (a.rs.enabled) {  // pipelined batch: per-trajectory table blocks, previous-frame arrays and draws
+            const int64_t ts = b * a.rs.tstride;
+            a.rs.e += ts; a.rs.x_raw += ts; a.rs.lp += ts; a.rs.lp_raw += ts; a.rs.gend += ts; a.rs.gend_raw += ts;
+            a.rs.ggend += ts; a.rs.ggend_raw += ts; a.rs.bsum_e += ts; a.rs.btot += ts; a.rs.btot_raw += ts; a.rs.bmax += ts; a.rs.bmin += ts;
+            a.rs.poses_prev += o * 16; a.rs.nn_prev += o; a.rs.status_prev += 2 * b;
+            if (a.rs.ridx_out) a.rs.ridx_out += o;
+            if (a.rs.u) a.rs.u += o;
+            a.rs.key_base = o;
+            a.rs.traj = traj;
+        }
     }
     const int64_t n = wave * 64 + lane;
     const bool live = n < a.N;
@@ -1670,7 +1680,8 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
 // LAZY: the resample of the previous frame runs as a prologue of the particle waves (midas_lazy_step).
 // LAZY 2: the same with the tables built per wave (nb <= 64), which also frees the workgroup size: FW = waves per
 // workgroup.  With FW = 1 the 1563 particle waves of c2 spread 6 - 7 per CU; workgroups of four land 4 or 8 on a CU.
-template <typename T, int NJ, int LAZY, int FW>
+// SCR = false (batch of trajectories, grid.y): whole-record list scans - the screen costs the batch step more than it saves
+template <typename T, int NJ, int LAZY, int FW, bool SCR = true>
 __global__ __launch_bounds__(64 * FW) void k_frame_front(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a,
                                                          int n_pu, int nwaves, const T* __restrict__ emb,
                                                          const double* __restrict__ norms, const double* __restrict__ code,
@@ -1684,9 +1695,10 @@ __global__ __launch_bounds__(64 * FW) void k_frame_front(TreeView<Kd6> t6, TreeV
         const int64_t wave = (int64_t)blockIdx.x * FW + w;
         if (wave < nwaves) {
             // one-wave workgroups = the small-set regime (see launch_frame_front): screened scans
-            constexpr bool SCREEN = FW == 1 && MIDAS_SCREEN;
-            if (LAZY == 2) particle_update_wave<true, SCREEN>(t6, t3, a, wave, nwaves, 0, s_cd[w], s_rs + w * LAZY_WAVE_LDS);
-            else particle_update_wave<false, SCREEN>(t6, t3, a, wave, nwaves, 0, s_cd[w], LAZY ? s_rs : nullptr);
+            constexpr bool SCREEN = FW == 1 && MIDAS_SCREEN && SCR;
+            const int traj = (int)blockIdx.y;
+            if (LAZY == 2) particle_update_wave<true, SCREEN>(t6, t3, a, wave, nwaves, traj, s_cd[w], s_rs + w * LAZY_WAVE_LDS);
+            else particle_update_wave<false, SCREEN>(t6, t3, a, wave, nwaves, traj, s_cd[w], LAZY ? s_rs : nullptr);
         }
     } else {
         score_wave<T, NJ, 0>(emb, norms, code, scores, K, (int64_t)(blockIdx.x - n_pu) * FW + w);
@@ -2057,7 +2069,9 @@ int launch_particle_update(midas_ctx* ctx, const midas_tree* t6, const midas_tre
 int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t3, const ParticleUpdateArgs& a_in,
                        const midas_codebook* cb, const double* code, double* scores, bool* launched) {
     *launched = false;
-    if (a_in.N == 0 || a_in.batch > 1 || cb->dtype != MIDAS_F32) return MIDAS_OK;
+    if (a_in.N == 0 || cb->dtype != MIDAS_F32) return MIDAS_OK;
+    // a batch of trajectories (grid.y) only in the pipelined form with per-wave tables and sparse scoring (midas_lazy_step_batch)
+    if (a_in.batch > 1 && !(a_in.rs.enabled && a_in.rs.nb <= LAZY_WAVE_LD && a_in.sp.stamps)) return MIDAS_OK;
     if ((uintptr_t)cb->emb % 16 != 0 || (uintptr_t)code % 16 != 0) return MIDAS_OK;
     if (cb->D != 512 && cb->D != 256 && cb->D != 128 && cb->D != 1024) return MIDAS_OK;
     ParticleUpdateArgs a = a_in;
@@ -2079,7 +2093,7 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
     static const int split_env = getenv("MIDAS_SPLIT_FRONT") ? atoi(getenv("MIDAS_SPLIT_FRONT")) : 1;
     // a live count in device memory (loop engine): the set shrinks within a few frames of annealing, so the two-kernel form
     // whatever the capacity
-    const bool split_front = split_env >= 2 || (split_env == 1 && ((a.rs.enabled && a.N <= 65536) || a.N <= 2048 || a.n_live));
+    const bool split_front = a.batch <= 1 && (split_env >= 2 || (split_env == 1 && ((a.rs.enabled && a.N <= 65536) || a.N <= 2048 || a.n_live)));
     const int lpp = split_env == 3 ? 2 : 4;
     if (split_front && !(a.ablate & 7)) {
         void* feat;
@@ -2114,14 +2128,17 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
     static const int fw_env = getenv("MIDAS_FRONT_WAVES") ? atoi(getenv("MIDAS_FRONT_WAVES")) : 0;
     static const int wt_env = getenv("MIDAS_WAVE_TABLES") ? atoi(getenv("MIDAS_WAVE_TABLES")) : 1;
     const bool wave_tables = a.rs.enabled && a.rs.nb <= LAZY_WAVE_LD && wt_env != 0;
-    const int fw = (a.rs.enabled && !wave_tables) ? 4 : fw_env == 1 || fw_env == 4 ? fw_env : (a.sp.stamps ? 1 : 4);
+    const int fw = a.batch > 1 ? 1 : (a.rs.enabled && !wave_tables) ? 4 : fw_env == 1 || fw_env == 4 ? fw_env : (a.sp.stamps ? 1 : 4);
     const int n_pu_fw = (nwaves + fw - 1) / fw;
     const unsigned grid_fw = (unsigned)(n_pu_fw + (a.sp.stamps ? 0 : ceil_div(cb->K, 4 * fw)));
 #define MIDAS_FRONT_L(NJ, LZ, FW)                                                                                     \
     hipLaunchKernelGGL((k_frame_front<float, NJ, LZ, FW>), dim3(grid_fw), dim3(64 * FW), 0, ctx->stream,               \
                        view_of<Kd6>(t6), view_of<Kd3>(t3), a, n_pu_fw, nwaves, emb, cb->norms, code, scores, cb->K)
 #define MIDAS_FRONT(NJ)                                                                                              \
-    if (!a.rs.enabled) { if (fw == 1) MIDAS_FRONT_L(NJ, 0, 1); else MIDAS_FRONT_L(NJ, 0, 4); }                        \
+    if (a.batch > 1)                                                                                                  \
+        hipLaunchKernelGGL((k_frame_front<float, NJ, 2, 1, false>), dim3(grid_fw, (unsigned)a.batch), dim3(64), 0, ctx->stream, \
+                           view_of<Kd6>(t6), view_of<Kd3>(t3), a, n_pu_fw, nwaves, emb, cb->norms, code, scores, cb->K);  \
+    else if (!a.rs.enabled) { if (fw == 1) MIDAS_FRONT_L(NJ, 0, 1); else MIDAS_FRONT_L(NJ, 0, 4); }                   \
     else if (!wave_tables) MIDAS_FRONT_L(NJ, 1, 4);                                                                   \
     else if (fw == 1) MIDAS_FRONT_L(NJ, 2, 1);                                                                        \
     else MIDAS_FRONT_L(NJ, 2, 4)

@@ -503,9 +503,17 @@ __global__ __launch_bounds__(256) void k_tail_a2(int64_t N, const double* __rest
 __global__ __launch_bounds__(256) void k_tail_a2d(int64_t N, const double* __restrict__ scores, const int32_t* __restrict__ nn_idx,
                                                   const uint8_t* __restrict__ valid, int32_t softmax, TailTables tb, bool padded,
                                                   int32_t* __restrict__ status, double* __restrict__ flags_out,
-                                                  const double* __restrict__ part_rmse, int nrm, double* __restrict__ rmse_out) {
+                                                  const double* __restrict__ part_rmse, int nrm, double* __restrict__ rmse_out,
+                                                  int64_t score_stride = 0, int64_t tstride = 0) {
     __shared__ double s_gtot[16];
     __shared__ double s_red[24];
+    if (blockIdx.y) {  // pipelined batch: trajectory blockIdx.y - its own table block (tables_of layout), scores, arrays, rmse triple
+        const int64_t b = blockIdx.y, o = b * N, ts = b * tstride;
+        scores += b * score_stride; nn_idx += o; valid += o; status += 2 * b;
+        tb.e += ts; tb.x_raw += ts; tb.lp += ts; tb.lp_raw += ts; tb.gend += ts; tb.gend_raw += ts; tb.ggend += ts; tb.ggend_raw += ts;
+        tb.bsum_e += ts; tb.btot += ts; tb.btot_raw += ts; tb.bmax += ts; tb.bmin += ts;
+        if (part_rmse) { part_rmse += 2 * b * nrm; rmse_out += 3 * b; }
+    }
     int kept = 0;
     bool nan = false;
     tail_a_direct(N, (int)blockIdx.x, scores, nn_idx, valid, softmax, tb, padded, s_gtot, s_red, kept, nan);
@@ -824,6 +832,7 @@ struct TailB2Args {
     const double* part_rmse;
     int nrm;
     double* rmse_out;
+    int64_t tstride;  // > 0: batch with one table block per trajectory (pipelined batch), 0: array-major batch tables
 };
 
 __global__ __launch_bounds__(256) void k_tail_b2(TailB2Args a) {
@@ -838,8 +847,14 @@ __global__ __launch_bounds__(256) void k_tail_b2(TailB2Args a) {
     __shared__ int s_apply;
     if (blockIdx.y) {  // batch of trajectories (plain strides)
         const int64_t b = blockIdx.y, o = b * a.N;
-        a.e += o; a.x_raw += o; a.lp += o; a.lp_raw += o; a.gend += b * a.ng; a.gend_raw += b * a.ng;
-        a.bsum_e += b * a.nb; a.btot += b * a.nb; a.btot_raw += b * a.nb; a.bmax += b * a.nb; a.bmin += b * a.nb;
+        if (a.tstride) {
+            const int64_t ts = b * a.tstride;
+            a.e += ts; a.x_raw += ts; a.lp += ts; a.lp_raw += ts; a.gend += ts; a.gend_raw += ts;
+            a.bsum_e += ts; a.btot += ts; a.btot_raw += ts; a.bmax += ts; a.bmin += ts;
+        } else {
+            a.e += o; a.x_raw += o; a.lp += o; a.lp_raw += o; a.gend += b * a.ng; a.gend_raw += b * a.ng;
+            a.bsum_e += b * a.nb; a.btot += b * a.nb; a.btot_raw += b * a.nb; a.bmax += b * a.nb; a.bmin += b * a.nb;
+        }
         a.valid += o; a.status += 2 * b; a.weights += o;
         if (a.u) a.u += o;
         a.ridx += o; a.poses_prop += o * 16; a.poses_out += o * 16; a.weights_out += o; a.nn_idx += o; a.hint_out += o;
@@ -1593,13 +1608,13 @@ int debug_tb2_clocks(long long* out16) { return hipMemcpyFromSymbol(out16, HIP_S
 
 int launch_tail_a2(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
                    int32_t softmax, const TailTables& tb, int32_t* status, int batch, int64_t score_stride, bool padded_tables,
-                   const double* part_rmse, double* rmse_out) {
+                   const double* part_rmse, double* rmse_out, int64_t tstride) {
     const int nb = (int)ceil_div(N, SCAN_BLOCK);
     static const bool direct = !(getenv("MIDAS_TAIL_DIRECT") && atoi(getenv("MIDAS_TAIL_DIRECT")) == 0);
-    if (direct && batch <= 1 && N >= SCAN_CHUNK) {
-        hipLaunchKernelGGL(k_tail_a2d, dim3((unsigned)nb), dim3(256), 0, ctx->stream, N, scores, nn_idx, valid, softmax, tb,
-                           padded_tables, status, (double*)nullptr, part_rmse, particle_update_blocks(N),
-                           part_rmse ? rmse_out : (double*)nullptr);
+    if (direct && (batch <= 1 || tstride > 0) && N >= SCAN_CHUNK) {
+        hipLaunchKernelGGL(k_tail_a2d, dim3((unsigned)nb, (unsigned)(batch > 1 ? batch : 1)), dim3(256), 0, ctx->stream, N, scores, nn_idx,
+                           valid, softmax, tb, padded_tables, status, (double*)nullptr, part_rmse, particle_update_blocks(N),
+                           part_rmse ? rmse_out : (double*)nullptr, score_stride, tstride);
         LAUNCH_CHECK(ctx);
         return MIDAS_OK;
     }
@@ -1628,6 +1643,7 @@ int launch_tail_b2(midas_ctx* ctx, const StepTailArgs& a, const TailTables& tb) 
     b.u = a.u; b.u32 = a.u32; b.seed = a.seed; b.step = a.step; b.ridx = a.ridx; b.poses_prop = a.poses_prop;
     b.poses_out = a.poses_out; b.weights_out = a.weights_out; b.nn_idx = a.nn_idx; b.hint_out = a.hint_out;
     b.part_rmse = a.part_rmse; b.nrm = a.part_rmse ? particle_update_blocks(a.N) : 0; b.rmse_out = a.rmse_out;
+    b.tstride = a.tstride;
     hipLaunchKernelGGL(k_tail_b2, dim3((unsigned)ceil_div(a.N, 256), (unsigned)(a.batch > 1 ? a.batch : 1)), dim3(256),
                        (size_t)(nt + 3 * nb) * sizeof(double), ctx->stream, b);
     LAUNCH_CHECK(ctx);

@@ -450,3 +450,143 @@ class BatchFilterEngine:
                                                             C.byref(a), self.B))
         self.hint, self.hint_next = self.hint_next, self.hint
         self.step_count += 1
+
+
+class PipelinedBatchFilterEngine(BatchFilterEngine):
+    """BatchFilterEngine with every trajectory's resample folded into the next frame's front kernel (midas_lazy_step_batch):
+    two launches per batch frame - the front with the trajectory as grid.y (one-wave workgroups, per-wave resample tables)
+    and the LDS-free tail - instead of particle update + tail + resample-gather.  As with PipelinedFilterEngine the
+    resampled particle set of the latest frame is implicit until somebody reads it: `poses`, `weights`, `weights_res`,
+    `hint`, `ridx`, `status` materialise it (`flush()`, bit-identical to BatchFilterEngine's), `nn_idx` / `poses_prop` /
+    `rmse` of the latest frame are always there.  Needs sparse scoring (float32 codebook, D in {128, 256, 512, 1024}) and
+    16 <= N <= 262144 particles per trajectory."""
+
+    poses = _materialised("poses")
+    weights = _materialised("weights")
+    weights_res = _materialised("weights_res")
+    hint = _materialised("hint")
+    ridx = _materialised("ridx")
+
+    def __init__(self, *args, **kw):
+        self._pending, self._flushed = False, True
+        super().__init__(*args, **kw)
+        B, N, d = self.B, self.N, self.device
+        if not self.sparse_scores or N < 16 or N > 262144:
+            raise MidasError("PipelinedBatchFilterEngine needs a float32 codebook with D in {128,256,512,1024} (sparse scoring) "
+                             "and 16 <= N <= 262144")
+        f64 = dict(dtype=torch.float64, device=d)
+        self._prop = [self.poses_prop, torch.zeros_like(self.poses_prop)]
+        self._nn = [self.nn_idx, torch.zeros_like(self.nn_idx)]
+        self._st = [torch.zeros((B, 2), dtype=torch.int32, device=d) for _ in range(2)]
+        self._valid = torch.zeros((B, N), dtype=torch.uint8, device=d)
+        self._tstride = int(self.ctx.lib.midas_lazy_tables_doubles(N))
+        self._tables = torch.zeros(B * self._tstride, **f64)
+        self._scores = torch.zeros((B, self.codebook.K), **f64)
+        self._part_rmse = torch.zeros((B, 2 * ((N + 63) // 64)), **f64)
+        self._rmse_frame = torch.zeros((B, 3), **f64)
+        self._cur, self._draw, self._had_gt = 0, (None, -1.0, 0), False
+
+    # storage behind the materialised properties (the base constructor assigns them)
+    @property
+    def status(self):
+        self.flush()
+        return self._st[self._cur]
+
+    @status.setter
+    def status(self, v):
+        pass
+
+    @property
+    def nn_idx(self):
+        return self._nn[self._cur] if hasattr(self, "_nn") else self._nn0
+
+    @nn_idx.setter
+    def nn_idx(self, v):
+        self._nn0 = v
+
+    @property
+    def poses_prop(self):
+        return self._prop[self._cur] if hasattr(self, "_prop") else self._prop0
+
+    @poses_prop.setter
+    def poses_prop(self, v):
+        self._prop0 = v
+
+    @property
+    def rmse(self):
+        return self._rmse_frame[:, :2] if self._pending else self._rmse
+
+    @rmse.setter
+    def rmse(self, v):
+        self._rmse = v
+
+    def set_particles(self, poses):
+        self._pending, self._flushed = False, True
+        poses = torch.as_tensor(poses).to(self.device, torch.float32)
+        if tuple(poses.shape) != (self.B, self.N, 4, 4):
+            raise MidasError(f"expected ({self.B},{self.N},4,4) poses, got {tuple(poses.shape)}")
+        self._poses.copy_(poses)
+        self._hint.fill_(-1)
+
+    def project_to_codebook(self):
+        self.flush()
+        idx = ops.nn6(self.tree6, ops.se3_feature(self._poses.view(-1, 4, 4)))
+        self._poses.copy_(ops.gather_rows(self.cb_poses, idx).view_as(self._poses))
+        self._hint.copy_(idx.view_as(self._hint))
+
+    def step(self, odoms, codes, gts=None, tn=None, rot=None, u=None, u32=-1.0):
+        d, B, N = self.device, self.B, self.N
+        if (tn is None) != (rot is None):
+            raise MidasError("tn and rot (the motion model's host draws) come together or not at all")
+        odoms, gts = operand(odoms, "odoms", torch.float32, (B, 4, 4), d), operand(gts, "gt poses", torch.float32, (B, 4, 4), d)
+        codes = operand(codes, "tactile codes", torch.float64, (B, self.codebook.D), d)
+        tn, rot = operand(tn, "tn", torch.float32, (B, N, 3), d), operand(rot, "rot", torch.float32, (B, N, 3), d)
+        u = operand(u, "u", torch.float64, (B, N), d)
+        cur, nxt = self._cur, self._cur ^ 1
+        fold = self._pending and not self._flushed
+        a = LazyArgs()
+        a.N = N
+        a.poses_prop_prev, a.nn_idx_prev, a.status_prev = _ptr(self._prop[cur]), _ptr(self._nn[cur]), _ptr(self._st[cur])
+        a.poses_prop, a.nn_idx, a.valid, a.status = _ptr(self._prop[nxt]), _ptr(self._nn[nxt]), _ptr(self._valid), _ptr(self._st[nxt])
+        a.tables, a.scores = _ptr(self._tables), _ptr(self._scores)
+        a.part_rmse = _ptr(self._part_rmse) if gts is not None else None
+        a.resample_prev = int(fold)
+        a.poses_in, a.hint_in = _ptr(self._poses), _ptr(self._hint)
+        pu, pu32, pstep = self._draw
+        a.resample_mode, a.u_prev, a.u32_prev, a.step_prev = self.mode, _ptr(pu), float(pu32), int(pstep)
+        a.ridx = _ptr(self._ridx) if fold else None
+        a.odom16, a.code, a.gt16 = _ptr(odoms), _ptr(codes), _ptr(gts)
+        a.tn, a.rot = _ptr(tn), _ptr(rot)
+        a.std_t, a.std_r, a.seed, a.step = self.sig_t, self.sig_r, self.seed, self.step_count
+        a.prune_thr, a.softmax = self.pen_max, int(self.softmax)
+        a.telemetry = _ptr(self.telemetry)
+        self._epoch += 1
+        a.score_stamps, a.score_epoch = _ptr(self._stamps), self._epoch
+        a.rmse = _ptr(self._rmse_frame) if gts is not None else None
+        self._keep = (odoms, codes, gts, tn, rot, pu)
+        self.ctx.bind_current_stream()
+        self.ctx.check(self.ctx.lib.midas_lazy_step_batch(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h, C.byref(a), B))
+        self._draw = (None if u is None else u.clone(), float(u32), self.step_count)
+        self._had_gt = gts is not None
+        self._pending, self._flushed, self._cur = True, False, nxt
+        self.step_count += 1
+
+    def flush(self):
+        """Materialise the latest frame's resample of every trajectory."""
+        if not self._pending or self._flushed:
+            return
+        cur = self._cur
+        u, u32, stp = self._draw
+        a = LazyFlushArgs()
+        a.N = self.N
+        a.tables, a.valid, a.nn_idx, a.poses_prop = _ptr(self._tables), _ptr(self._valid), _ptr(self._nn[cur]), _ptr(self._prop[cur])
+        a.status = _ptr(self._st[cur])
+        a.part_rmse = _ptr(self._part_rmse) if self._had_gt else None
+        a.softmax, a.resample_mode, a.u, a.u32 = int(self.softmax), self.mode, _ptr(u), float(u32)
+        a.seed, a.step = self.seed, int(stp)
+        a.weights, a.ridx, a.poses_out = _ptr(self._weights), _ptr(self._ridx), _ptr(self._poses)
+        a.weights_out, a.hint_out = _ptr(self._weights_res), _ptr(self._hint)
+        a.rmse = _ptr(self._rmse) if self._had_gt else None
+        self.ctx.bind_current_stream()
+        self.ctx.check(self.ctx.lib.midas_lazy_flush_batch(self.ctx.h, C.byref(a), self.B))
+        self._flushed = True

@@ -275,3 +275,40 @@ def test_batch_engine_matches_oracle_per_trajectory(dev, oracle, dense, monkeypa
             rt, rr = oracle.particle_rmse(ref["poses_prop"], trajs[b].gt_poses[t])
             assert eng.rmse[b, 0].item() == pytest.approx(rt, rel=1e-9)
             poses[b] = ref["poses"]
+
+
+@pytest.mark.parametrize("mode", ["weighted_random", "low_var"])
+@pytest.mark.parametrize("read_every", [1, 3, 100])
+def test_pipelined_batch_engine_equals_batch_engine(dev, mode, read_every):
+    """midas_lazy_step_batch (every trajectory's resample folded into the next frame's front kernel, trajectory = grid.y) against
+    midas_filter_step_batch, which the test above pins to the oracle: NN indices, propagated poses and rmse every frame, the
+    materialised particle set whenever it is read - bit-identical, device draws and host uniforms."""
+    from midastouch_amd.engine import BatchFilterEngine, PipelinedBatchFilterEngine
+    from midastouch_amd.synthetic import make_trajectory
+    B, N, K, D = 4, 9000, 3000, 256   # three summation blocks per trajectory, ragged
+    cb, traj, scale = _setup(N, K, D, seed=6, obj="cotter-pin")
+    trajs = [make_trajectory(cb, T=12, seed=2300 + b) for b in range(B)]
+    rng = np.random.default_rng(5)
+    start = torch.as_tensor(np.stack([cb.poses[rng.integers(0, K, N)] for _ in range(B)]))
+    engs = [cls(cb.poses, cb.embeddings, cb.mesh_vertices, B, N, sig_t=1e-4, sig_r=0.5, seed=4100, resample=mode, device=dev)
+            for cls in (BatchFilterEngine, PipelinedBatchFilterEngine)]
+    for e in engs:
+        e.set_particles(start)
+        e.project_to_codebook()
+    gen = torch.Generator().manual_seed(9)
+    for t in range(1, 10):
+        odoms = torch.as_tensor(np.stack([tr.odoms[t] for tr in trajs])).to(dev)
+        codes = torch.as_tensor(np.stack([tr.codes[t] for tr in trajs])).to(dev)
+        gts = torch.as_tensor(np.stack([tr.gt_poses[t] for tr in trajs])).to(dev)
+        u = torch.rand((B, N), dtype=torch.float64, generator=gen) if (t % 4 == 0 and mode == "weighted_random") else None
+        for e in engs:
+            e.step(odoms, codes, gts, u=u)
+        a, b = engs
+        assert torch.equal(a.nn_idx, b.nn_idx), f"frame {t}: NN index"
+        assert torch.equal(a.poses_prop, b.poses_prop), f"frame {t}: propagated poses"
+        assert torch.equal(a.rmse, b.rmse), f"frame {t}: rmse"
+        if t % read_every == 0:
+            for name in ("ridx", "poses", "weights", "weights_res", "hint", "status"):
+                assert torch.equal(getattr(a, name), getattr(b, name)), f"frame {t}: {name}"
+    for name in ("ridx", "poses", "weights", "weights_res", "hint", "status"):
+        assert torch.equal(getattr(engs[0], name), getattr(engs[1], name)), name

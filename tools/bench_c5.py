@@ -3,7 +3,7 @@
 import json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from midastouch_amd.engine import BatchFilterEngine
+from midastouch_amd.engine import BatchFilterEngine, PipelinedBatchFilterEngine
 from midastouch_amd.synthetic import make_codebook, make_trajectory
 dev = torch.device("cuda", 0)
 cb = make_codebook("cotter-pin", K=50000, D=512, seed=1005)
@@ -11,8 +11,9 @@ B, N = 64, 10000
 trs = [make_trajectory(cb, T=40, seed=2200 + b) for b in range(8)]
 od = torch.as_tensor(np.stack([trs[b % 8].odoms for b in range(B)], axis=1)).to(dev)
 co = torch.as_tensor(np.stack([trs[b % 8].codes for b in range(B)], axis=1)).to(dev)
+ENG = PipelinedBatchFilterEngine if os.environ.get("MIDAS_C5_PIPELINED", "1") != "0" else BatchFilterEngine
 for init in ("spread", "near"):
-    eng = BatchFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, B, N, device=dev)
+    eng = ENG(cb.poses, cb.embeddings, cb.mesh_vertices, B, N, device=dev)
     rng = np.random.default_rng(1)
     if init == "spread":
         start = np.stack([cb.poses[rng.integers(0, 50000, N)] for _ in range(B)])
@@ -30,4 +31,4 @@ for init in ("spread", "near"):
     us = (time.perf_counter() - t0) / 60 * 1e6
     tele = eng.telemetry.cpu().numpy()[:2] / 70.0
     print(f"   tree fallbacks per batch step: nn {tele[0]:.1f}, prune {tele[1]:.1f}")
-    print(f"c5 init={init}: {us:.1f} us per batch step, {B * 1e6 / us:.0f} trajectory-steps/s, lib={os.environ.get('MIDAS_HIP_LIB', 'default')[-12:]}")
+    print(f"c5 init={init}: {us:.1f} us per batch step, {B * 1e6 / us:.0f} trajectory-steps/s, engine={ENG.__name__}")
