@@ -4,7 +4,7 @@
 import json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from midastouch_amd.engine import BatchFilterEngine, FilterEngine, PipelinedFilterEngine
+from midastouch_amd.engine import BatchFilterEngine, FilterEngine, PipelinedBatchFilterEngine, PipelinedFilterEngine
 from midastouch_amd.synthetic import make_codebook, make_trajectory
 dev = torch.device("cuda", 0)
 
@@ -29,13 +29,15 @@ for tag, cls in (("eager", FilterEngine), ("pipelined", PipelinedFilterEngine)):
 cb = make_codebook("cotter-pin", K=50000, D=512, seed=1005)
 B, N = 64, 10000
 trs = [make_trajectory(cb, T=40, seed=2200 + b) for b in range(8)]
-eng = BatchFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, B, N, device=dev)
-rng = np.random.default_rng(1)
-eng.set_particles(torch.as_tensor(np.stack([cb.poses[rng.integers(0, 50000, N)] for _ in range(B)]))); eng.project_to_codebook()
 od = torch.as_tensor(np.stack([trs[b % 8].odoms for b in range(B)], axis=1)).to(dev)   # (T,B,4,4)
 co = torch.as_tensor(np.stack([trs[b % 8].codes for b in range(B)], axis=1)).to(dev)
-us = run(eng, lambda i: eng.step(od[1 + i % 38], co[1 + i % 38]), n=60)
-res["c5_B64_N10k_K50k_D512"] = {"us_per_batch_step": round(us, 1), "trajectory_steps_per_s": round(B * 1e6 / us)}
+for tag, cls in (("", PipelinedBatchFilterEngine), ("_eager", BatchFilterEngine)):
+    eng = cls(cb.poses, cb.embeddings, cb.mesh_vertices, B, N, device=dev)
+    rng = np.random.default_rng(1)
+    eng.set_particles(torch.as_tensor(np.stack([cb.poses[rng.integers(0, 50000, N)] for _ in range(B)]))); eng.project_to_codebook()
+    us = run(eng, lambda i: eng.step(od[1 + i % 38], co[1 + i % 38]), n=60)
+    res["c5_B64_N10k_K50k_D512" + tag] = {"us_per_batch_step": round(us, 1), "trajectory_steps_per_s": round(B * 1e6 / us)}
+    del eng
 
 cb = make_codebook("035_power_drill", K=50000, D=512, seed=1003); tr = make_trajectory(cb, T=70, seed=2003)
 N = 1_000_000
