@@ -2084,8 +2084,8 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
     }
     const unsigned grid = (unsigned)(n_pu + (a.sp.stamps ? 0 : ceil_div(cb->K, 16)));
     const float* emb = (const float*)cb->emb;
-    // Two-kernel form (group-parallel list scans, see k_particle_nn_prune) while its N/16 waves fit the chip at once (4 waves
-    // per SIMD at 112 registers = 65536 particles with four lanes each).  Measured at K = 50k, D = 512 the pipelined frame
+    // Two-kernel form (group-parallel list scans, see k_particle_nn_prune) for small particle sets (round 1's rule was "while
+    // its N/16 waves fit the chip at once": 65536 particles).  Measured at K = 50k, D = 512 the pipelined frame
     // gains 6 - 15 % for N = 4k .. 40k; when the particle set is materialised every frame the extra launch boundary only pays
     // off for the smallest sets; at N = 100k the four-lane form (two rounds of waves) loses 4 %, the two-lane form (one
     // round, two trips) 8 %, at N = 1M 7 %: there the single kernel stays.
@@ -2093,7 +2093,10 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
     static const int split_env = getenv("MIDAS_SPLIT_FRONT") ? atoi(getenv("MIDAS_SPLIT_FRONT")) : 1;
     // a live count in device memory (loop engine): the set shrinks within a few frames of annealing, so the two-kernel form
     // whatever the capacity
-    const bool split_front = a.batch <= 1 && (split_env >= 2 || (split_env == 1 && ((a.rs.enabled && a.N <= 65536) || a.N <= 2048 || a.n_live)));
+    // (re-measured after the single kernel's second pass - per-wave tables, one-wave workgroups, screened scans: pipelined,
+    // split / single at N = 6k 29.6k / 27.5k steps/s, 8k 29.0k / 27.9k, 12k 28.3k / 28.5k, 20k 25.8k / 27.1k, 65k 21.0k / 22.9k:
+    // the two-kernel form now pays up to ~10 000 particles instead of 65 536; the loop step (live count) keeps it: 126 / 138 us)
+    const bool split_front = a.batch <= 1 && (split_env >= 2 || (split_env == 1 && ((a.rs.enabled && a.N <= 10240) || a.N <= 2048 || a.n_live)));
     const int lpp = split_env == 3 ? 2 : 4;
     if (split_front && !(a.ablate & 7)) {
         void* feat;

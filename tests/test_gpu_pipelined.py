@@ -115,9 +115,9 @@ def test_pipelined_equals_eager_full_size(dev):
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("N", [65537, 262144, 262145])
+@pytest.mark.parametrize("N", [10240, 10241, 65537, 262144, 262145])
 def test_front_kernel_form_boundaries(dev, oracle, N):
-    """The single front kernel changes form with the particle count: two kernels up to 65536 particles, one-wave workgroups
+    """The single front kernel changes form with the particle count: two kernels up to 10240 particles, one-wave workgroups
     with per-wave resample tables and screened list scans up to 64 summation blocks (262144), workgroup-level tables and
     whole-record scans above.  Either side of both boundaries: pipelined == eager == oracle (indices exact)."""
     from midastouch_amd.engine import FilterEngine, PipelinedFilterEngine
