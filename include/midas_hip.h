@@ -341,6 +341,9 @@ typedef struct midas_shard_front_args {
     uint64_t* telemetry_dev;    /* NULL or 16 cumulative counters (see midas_step_args) */
     int32_t* status_dev;        /* 2: zeroed here, filled by midas_shard_tail_a / midas_shard_tail_fin */
     double* flags_dev;          /* the NaN / kept counters of this rank's exchange record (r1 + 5 nb): zeroed here */
+    uint32_t* score_stamps_dev; /* NULL or K: sparse scoring as in midas_step_args (the local particles' waves score the rows
+                                 * they need; ignored when scores_ready) */
+    uint32_t score_epoch;       /* this frame's stamp value, != 0 and different from every value still in score_stamps_dev */
 } midas_shard_front_args;
 /* propagate + feature + NN + prune for the local particles and - in the same launch when the codebook is
  * replicated - the codebook scores (particle_filter.py:359-403, tactile_tree.py:43-58) */

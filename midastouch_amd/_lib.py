@@ -74,6 +74,7 @@ class ShardFrontArgs(C.Structure):
         ("telemetry", C.c_void_p),
         ("status", C.c_void_p),
         ("flags", C.c_void_p),
+        ("score_stamps", C.c_void_p), ("score_epoch", C.c_uint32),
     ]
 
 

@@ -823,10 +823,12 @@ MIDAS_EXPORT int midas_shard_front(midas_ctx* ctx, const midas_codebook* cb, con
     pa.flags_reset = s.flags_dev;
     pa.gt16 = prm ? s.gt16_dev : nullptr;
     pa.part_rmse = (double*)prm;
+    if (!s.scores_ready && s.score_stamps_dev && s.score_epoch) { pa.sp.stamps = s.score_stamps_dev; pa.sp.epoch = s.score_epoch; }
     bool fused = false;
     if (!s.scores_ready && ctx->overlap)
         if ((rc = launch_frame_front(ctx, tree6, tree3, pa, cb, s.code_dev, s.scores_dev, &fused))) return rc;
     if (!fused) {
+        pa.sp = SparseScore();  // the unfused form scores every row first
         if (!s.scores_ready)
             if ((rc = launch_score(ctx, cb, 1, s.code_dev, s.scores_dev))) return rc;
         if ((rc = launch_particle_update(ctx, tree6, tree3, pa))) return rc;

@@ -71,6 +71,9 @@ class HipShardBackend:
         self.tree6.attach_mesh(self.tree3, self.cb_poses)
         self.K = int(self.cb_poses.shape[0])
         self.D = int(emb.shape[1])
+        import os
+        self._sparse = (row_shard is None and self.codebook.emb.dtype == torch.float32 and self.D in (128, 256, 512, 1024) and
+                        os.environ.get("MIDAS_DENSE_SCORES", "0") != "1")
 
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.device)
@@ -97,6 +100,16 @@ class HipShardBackend:
         a.telemetry = _ptr(st.telemetry)
         a.status = _ptr(st.status)
         a.flags = _ptr(st.r1[5 * st.nb:])
+        if not scores_ready and self._sparse:
+            # sparse scoring (replicated codebook): this rank's particle waves score the rows they need, one stamp array per state
+            stamps = getattr(st, "_stamps", None)
+            if stamps is None:
+                st._stamps = stamps = torch.zeros(self.codebook.K, dtype=torch.int32, device=st.poses.device)
+                st._epoch = 0
+            st._epoch = st._epoch + 1 if st._epoch < 0x7FFFFFF0 else 1
+            if st._epoch == 1:
+                stamps.zero_()
+            a.score_stamps, a.score_epoch = _ptr(stamps), st._epoch
         self.ctx.bind_current_stream()
         self.ctx.check(self.ctx.lib.midas_shard_front(self.ctx.h, None if scores_ready else self.codebook.h,
                                                       self.tree6.h, self.tree3.h, C.byref(a)))
