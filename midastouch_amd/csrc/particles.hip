@@ -1789,7 +1789,7 @@ MD float dpp_f32(float v) { return __uint_as_float(dpp_u32<CTRL>(__float_as_uint
 // lane, with two lanes two; header + 16 records of the vertex list are one round trip either way.
 static_assert(NN_SOLO == 32 && MESH_SOLO == 16, "the group scans fetch 32 / 16 records");
 #ifndef MIDAS_NNP_OCC
-#define MIDAS_NNP_OCC 4
+#define MIDAS_NNP_OCC 2  // the two-kernel form only serves small sets now (<= 10 240 particles, the loop step): registers over occupancy
 #endif
 template <int LPP>
 __global__ __launch_bounds__(256, MIDAS_NNP_OCC) void k_particle_nn_prune(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a,
@@ -1870,22 +1870,25 @@ __global__ __launch_bounds__(256, MIDAS_NNP_OCC) void k_particle_nn_prune(TreeVi
         if (lane == 0 && m) atomicAdd(&a.telemetry[0], (unsigned long long)__popcll(m));
     }
     const int32_t nn = (int32_t)dpp_u32<BC_FIRST>((uint32_t)(int32_t)bi);
+    // ---- prune: header + records 1 .. 16 of the entry's vertex list in one round trip, requested BEFORE the row claim of the
+    // sparse scoring so that the claim's look at the stamps (a round trip of its own) runs beside it ----
+    const float* pr = a.poses_prop + pc * 16;
+    const double q3[3] = {(double)pr[3], (double)pr[7], (double)pr[11]};
+    int mv = -1;  // 1 valid, 0 invalid, -1 undecided
+    double lim = 0.0;
+    MeshRec hd, e[MESH_PER_LANE];
+    if (a.vlist) {
+        const MeshRec* vl = a.vlist + (size_t)(live ? nn : 0) * MESH_REC;
+        hd = vl[0];
+#pragma unroll
+        for (int j = 0; j < MESH_PER_LANE; ++j) e[j] = vl[1 + LPP * j + g];
+    }
     RowClaim claim{false, 0u};
     if (a.sp.stamps) {
         claim = claim_rows_issue(a.sp, owner && live, nn);
         if (!MIDAS_CLAIM_DEFER) score_claimed_rows_nj(a.sp, claim, nn);
     }
-    // ---- prune: header + records 1 .. 16 of the entry's vertex list in one round trip ----
-    const float* pr = a.poses_prop + pc * 16;
-    const double q3[3] = {(double)pr[3], (double)pr[7], (double)pr[11]};
-    int mv = -1;  // 1 valid, 0 invalid, -1 undecided
-    double lim = 0.0;
     if (a.vlist) {
-        const MeshRec* vl = a.vlist + (size_t)(live ? nn : 0) * MESH_REC;
-        const MeshRec hd = vl[0];
-        MeshRec e[MESH_PER_LANE];
-#pragma unroll
-        for (int j = 0; j < MESH_PER_LANE; ++j) e[j] = vl[1 + LPP * j + g];
         Point3 ph;
         ph.c[0] = hd.c[0]; ph.c[1] = hd.c[1]; ph.c[2] = hd.c[2];
         const double delta = __builtin_sqrt(dist2(q3, ph)) * (1.0 + 1e-12);
