@@ -1078,10 +1078,13 @@ MD void mesh_coop(const MeshRec* __restrict__ vlist, int32_t h, const double* tq
 // entry h.  Returns 1 (valid: an actual vertex passes the exact test d2 <= t2), 0 (invalid: every vertex not
 // yet scanned is provably farther than thr, triangle inequality with slack far above float64 rounding) or
 // -1 (list exhausted: the caller runs the tree search).
+// PRE: header and first batch (records 0 .. MESH_BATCH) were fetched by the caller ahead of time (registers: a compile-time
+// choice - a pointer that may or may not refer to them would put them in scratch memory)
+template <bool PRE = false>
 MD int mesh_list_check(const MeshRec* __restrict__ vlist, int32_t h, const double* tq, double t2, double thr,
-                       int max_records = MESH_M, double* lim_out = nullptr) {
+                       int max_records = MESH_M, double* lim_out = nullptr, const MeshRec* pre = nullptr) {
     const MeshRec* vl = vlist + (size_t)h * MESH_REC;
-    const MeshRec hd = vl[0];
+    const MeshRec hd = PRE ? pre[0] : vl[0];
     Point3 ph;
     ph.c[0] = hd.c[0]; ph.c[1] = hd.c[1]; ph.c[2] = hd.c[2];
     const double delta = __builtin_sqrt(dist2(tq, ph)) * (1.0 + 1e-12);
@@ -1091,8 +1094,13 @@ MD int mesh_list_check(const MeshRec* __restrict__ vlist, int32_t h, const doubl
     // per record "provably too far" is tested before "hit", so the first event decides
     for (int s0 = 1; s0 <= max_records; s0 += MESH_BATCH) {
         MeshRec e[MESH_BATCH];
+        if (PRE && s0 == 1) {
 #pragma unroll
-        for (int j = 0; j < MESH_BATCH; ++j) e[j] = vl[s0 + j];
+            for (int j = 0; j < MESH_BATCH; ++j) e[j] = pre[1 + j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < MESH_BATCH; ++j) e[j] = vl[s0 + j];
+        }
         unsigned hits = 0, stops = 0;
 #pragma unroll
         for (int j = 0; j < MESH_BATCH; ++j) {
@@ -1491,7 +1499,9 @@ MD int64_t lazy_source(const LazyResample& rs, const double* rs_lds, int64_t n, 
 // `nwaves` = waves per trajectory (strides of the per-wave partial arrays), s_cd = this wave's LDS columns.
 // WT (with rs_lds): the wave builds the resample tables itself (lazy_tables_wave; rs_lds = its own LAZY_WAVE_LDS doubles)
 // SCREEN: half-record screening in the list scans (see part4)
-template <bool WT = false, bool SCREEN = false>
+// PREF: the vertex list's header and first batch are requested before the sparse-scoring claim (72 more registers: only
+// where two waves per SIMD are all the launch needs, N <= 131072 in one-wave workgroups)
+template <bool WT = false, bool SCREEN = false, bool PREF = false>
 MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, ParticleUpdateArgs a, int64_t wave,
                              int nwaves, int traj, double* s_cd, double* rs_lds = nullptr) {
     const int lane = threadIdx.x & 63;
@@ -1599,6 +1609,15 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
     }
     // sparse scoring: the first particle of the frame on an entry has it scored - the exchanges leave here, the answers are
     // looked at after the prune
+    // (small-set regime, registers to spare: the vertex list's header and first batch are requested before the claim, whose
+    // look at the stamps is a round trip of its own)
+    constexpr bool PRE = PREF;
+    MeshRec pre[PRE ? 1 + MESH_BATCH : 1];
+    if (PRE && a.vlist != nullptr) {
+        const MeshRec* vl = a.vlist + (size_t)(live ? bi : 0) * MESH_REC;
+#pragma unroll
+        for (int j = 0; j < (PRE ? 1 + MESH_BATCH : 1); ++j) pre[j] = vl[j];
+    }
     RowClaim claim{false, 0u};
     if (a.sp.stamps && !(a.ablate & 16)) {  // ablate 16 (profiling): nobody scores
         claim = claim_rows_issue(a.sp, live, bi);
@@ -1612,7 +1631,7 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
     if (a.ablate & 2) mv = 1;
     else if (a.vlist) {
         double lim_lane = 0.0;
-        if (live) mv = mesh_list_check(a.vlist, bi, q3, a.t2, a.thr, MESH_SOLO, &lim_lane);  // first records, per lane
+        if (live) mv = mesh_list_check<PRE>(a.vlist, bi, q3, a.t2, a.thr, MESH_SOLO, &lim_lane, pre);  // first records, per lane
         tc[4] = clock64();
         if (a.telemetry && (a.ablate & 4)) st_mesh = __ballot(live && mv < 0);
         mesh_coop(a.vlist, bi, q3, a.t2, lim_lane, live && mv < 0, mv);             // the rest, whole wave per lane
@@ -1681,7 +1700,7 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
 // LAZY 2: the same with the tables built per wave (nb <= 64), which also frees the workgroup size: FW = waves per
 // workgroup.  With FW = 1 the 1563 particle waves of c2 spread 6 - 7 per CU; workgroups of four land 4 or 8 on a CU.
 // SCR = false (batch of trajectories, grid.y): whole-record list scans - the screen costs the batch step more than it saves
-template <typename T, int NJ, int LAZY, int FW, bool SCR = true>
+template <typename T, int NJ, int LAZY, int FW, bool SCR = true, bool PREF = false>
 __global__ __launch_bounds__(64 * FW) void k_frame_front(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a,
                                                          int n_pu, int nwaves, const T* __restrict__ emb,
                                                          const double* __restrict__ norms, const double* __restrict__ code,
@@ -1697,8 +1716,8 @@ __global__ __launch_bounds__(64 * FW) void k_frame_front(TreeView<Kd6> t6, TreeV
             // one-wave workgroups = the small-set regime (see launch_frame_front): screened scans
             constexpr bool SCREEN = FW == 1 && MIDAS_SCREEN && SCR;
             const int traj = (int)blockIdx.y;
-            if (LAZY == 2) particle_update_wave<true, SCREEN>(t6, t3, a, wave, nwaves, traj, s_cd[w], s_rs + w * LAZY_WAVE_LDS);
-            else particle_update_wave<false, SCREEN>(t6, t3, a, wave, nwaves, traj, s_cd[w], LAZY ? s_rs : nullptr);
+            if (LAZY == 2) particle_update_wave<true, SCREEN, PREF>(t6, t3, a, wave, nwaves, traj, s_cd[w], s_rs + w * LAZY_WAVE_LDS);
+            else particle_update_wave<false, SCREEN, PREF>(t6, t3, a, wave, nwaves, traj, s_cd[w], LAZY ? s_rs : nullptr);
         }
     } else {
         score_wave<T, NJ, 0>(emb, norms, code, scores, K, (int64_t)(blockIdx.x - n_pu) * FW + w);
@@ -2146,6 +2165,9 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
                            view_of<Kd6>(t6), view_of<Kd3>(t3), a, n_pu_fw, nwaves, emb, cb->norms, code, scores, cb->K);  \
     else if (!a.rs.enabled) { if (fw == 1) MIDAS_FRONT_L(NJ, 0, 1); else MIDAS_FRONT_L(NJ, 0, 4); }                   \
     else if (!wave_tables) MIDAS_FRONT_L(NJ, 1, 4);                                                                   \
+    else if (fw == 1 && a.N <= 131072)                                                                                \
+        hipLaunchKernelGGL((k_frame_front<float, NJ, 2, 1, true, true>), dim3(grid_fw), dim3(64), 0, ctx->stream,     \
+                           view_of<Kd6>(t6), view_of<Kd3>(t3), a, n_pu_fw, nwaves, emb, cb->norms, code, scores, cb->K); \
     else if (fw == 1) MIDAS_FRONT_L(NJ, 2, 1);                                                                        \
     else MIDAS_FRONT_L(NJ, 2, 4)
     switch (cb->D) {
