@@ -17,27 +17,23 @@ void tree_free_host(midas_tree* t);
 }
 
 // ---- scratch: bump allocator over library-owned device chunks, reset at every API entry ----------
+// The chunks live as long as the context: a reset only rewinds to the first one, a request that does not fit the current
+// chunk moves on to the next, and only a request that fits none allocates (at least twice the largest chunk so far).  The first
+// form freed and re-allocated one consolidated chunk whenever a call had needed more than one - a stream synchronisation,
+// hipFree and hipMalloc of tens of MB in the middle of a run: the 5 - 30 ms frames the loop showed now and then whenever a
+// phase combination asked for more than any frame before it (MIDAS_SCRATCH_LOG=1 reports every new chunk).
 struct ScratchChunk { void* p; size_t cap; };
 struct ScratchState {
     std::vector<ScratchChunk> chunks;
-    size_t used = 0;   // in chunks.back()
+    size_t cur = 0;    // chunk in use
+    size_t used = 0;   // bytes taken from chunks[cur]
     size_t total = 0;  // bytes requested since the last reset
 };
 static ScratchState* scratch_of(midas_ctx* ctx) { return reinterpret_cast<ScratchState*>(ctx->scratch); }
 
 static int scratch_reset(midas_ctx* ctx) {
     ScratchState* s = scratch_of(ctx);
-    if (s->chunks.size() > 1) {  // consolidate: one chunk large enough for the last call's total
-        static const bool log = getenv("MIDAS_SCRATCH_LOG") != nullptr;
-        if (log) fprintf(stderr, "[midas] scratch: %zu chunks -> one of %zu bytes (stream sync, free, malloc)\n", s->chunks.size(), s->total + (s->total >> 2) + 4096);
-        MIDAS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        for (auto& c : s->chunks) (void)hipFree(c.p);
-        s->chunks.clear();
-        void* p = nullptr;
-        size_t cap = s->total + (s->total >> 2) + 4096;
-        if (hipMalloc(&p, cap) != hipSuccess) return midas_set_error(ctx, MIDAS_ERR_NOMEM, "hipMalloc(scratch)", "out of device memory");
-        s->chunks.push_back({p, cap});
-    }
+    s->cur = 0;
     s->used = 0;
     s->total = 0;
     return MIDAS_OK;
@@ -47,14 +43,23 @@ int midas_scratch(midas_ctx* ctx, size_t bytes, void** out) {
     ScratchState* s = scratch_of(ctx);
     bytes = (bytes + 255) & ~(size_t)255;
     s->total += bytes;
-    if (s->chunks.empty() || s->used + bytes > s->chunks.back().cap) {
-        void* p = nullptr;
+    while (s->cur < s->chunks.size() && s->used + bytes > s->chunks[s->cur].cap) { ++s->cur; s->used = 0; }
+    if (s->cur == s->chunks.size()) {
         size_t cap = bytes > (size_t)(1 << 20) ? bytes : (size_t)(1 << 20);
-        if (hipMalloc(&p, cap) != hipSuccess) return midas_set_error(ctx, MIDAS_ERR_NOMEM, "hipMalloc(scratch)", "out of device memory");
+        size_t largest = 0;
+        for (const auto& c : s->chunks) largest = c.cap > largest ? c.cap : largest;
+        cap = cap > 2 * largest ? cap : 2 * largest;
+        void* p = nullptr;
+        if (hipMalloc(&p, cap) != hipSuccess) {
+            cap = bytes > (size_t)(1 << 20) ? bytes : (size_t)(1 << 20);  // not the generous size then: what is needed
+            if (hipMalloc(&p, cap) != hipSuccess) return midas_set_error(ctx, MIDAS_ERR_NOMEM, "hipMalloc(scratch)", "out of device memory");
+        }
+        static const bool log = getenv("MIDAS_SCRATCH_LOG") != nullptr;
+        if (log) fprintf(stderr, "[midas] scratch: chunk %zu of %zu bytes\n", s->chunks.size(), cap);
         s->chunks.push_back({p, cap});
         s->used = 0;
     }
-    *out = (char*)s->chunks.back().p + s->used;
+    *out = (char*)s->chunks[s->cur].p + s->used;
     s->used += bytes;
     return MIDAS_OK;
 }
