@@ -312,3 +312,27 @@ def test_pipelined_batch_engine_equals_batch_engine(dev, mode, read_every):
                 assert torch.equal(getattr(a, name), getattr(b, name)), f"frame {t}: {name}"
     for name in ("ridx", "poses", "weights", "weights_res", "hint", "status"):
         assert torch.equal(getattr(engs[0], name), getattr(engs[1], name)), name
+
+
+@pytest.mark.parametrize("B,N", [(1, 16), (2, 17), (3, 4097), (2, 300)])
+def test_pipelined_batch_engine_edge_sizes(dev, B, N):
+    """Ragged / smallest sizes of the pipelined batch step (one chunk, a chunk and a slot, a block and a slot), no ground truth."""
+    from midastouch_amd.engine import BatchFilterEngine, PipelinedBatchFilterEngine
+    from midastouch_amd.synthetic import make_trajectory
+    K, D = 900, 128
+    cb, traj, scale = _setup(N, K, D, seed=8)
+    trajs = [make_trajectory(cb, T=8, seed=2400 + b) for b in range(B)]
+    rng = np.random.default_rng(B * 1000 + N)
+    start = torch.as_tensor(np.stack([cb.poses[rng.integers(0, K, N)] for _ in range(B)]))
+    engs = [cls(cb.poses, cb.embeddings, cb.mesh_vertices, B, N, seed=4200, device=dev) for cls in (BatchFilterEngine, PipelinedBatchFilterEngine)]
+    for e in engs:
+        e.set_particles(start)
+    for t in range(1, 6):
+        odoms = torch.as_tensor(np.stack([tr.odoms[t] for tr in trajs])).to(dev)
+        codes = torch.as_tensor(np.stack([tr.codes[t] for tr in trajs])).to(dev)
+        for e in engs:
+            e.step(odoms, codes)
+        assert torch.equal(engs[0].nn_idx, engs[1].nn_idx) and torch.equal(engs[0].poses_prop, engs[1].poses_prop), f"frame {t}"
+        if t in (2, 5):
+            for name in ("ridx", "poses", "weights", "weights_res", "hint", "status"):
+                assert torch.equal(getattr(engs[0], name), getattr(engs[1], name)), f"frame {t}: {name}"
