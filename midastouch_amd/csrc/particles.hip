@@ -704,6 +704,7 @@ MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t h, float&
     const Nbr6* nb = tv.nbrs + (size_t)h * NBR_REC;
     float r = 0.f, rslack = 0.f;
     int scanned = 0;
+    int b32 = h;  // record 0 overwrites the incoming candidate; list indices are int32
     bool certified = false;
 #pragma unroll 1
     for (int s0 = 0; s0 < NN_SOLO && !certified; s0 += NN_BATCH) {
@@ -715,24 +716,25 @@ MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t h, float&
             Point6 p;
 #pragma unroll
             for (int a = 0; a < 6; ++a) p.c[a] = e[j].c[a];
+            const float d = dist2(q, p);
             if (s0 == 0 && j == 0) {  // the entry itself: the starting candidate (a NaN distance stays, as in a serial scan)
-                best = dist2(q, p);
-                bi = h;
+                best = d;
                 r = __builtin_sqrtf(best);
                 rslack = -8e-7f * r;
-            } else if (!certified) {
+            } else {
+                // Serial semantics without branches (the compiler turned the nested conditions into exec-mask regions, ~25
+                // scalar / mask instructions per record): a record counts while no earlier one has certified;
                 // lower bound of |q - F| for this and every later record, with slack for the rounding of r and rho
                 const float g = fmaf_(e[j].rho - r, 0.9999996f, rslack);
-                if (g > 0.0f && g * g * 0.99997f > best) {
-                    certified = true;
-                } else {
-                    const float d = dist2(q, p);
-                    if (d < best || (d == best && (int64_t)e[j].idx < bi)) { best = d; bi = e[j].idx; }
-                    ++scanned;
-                }
+                certified |= (g > 0.0f) & (g * g * 0.99997f > best);
+                const bool better = !certified & ((d < best) | ((d == best) & (e[j].idx < b32)));
+                best = better ? d : best;
+                b32 = better ? e[j].idx : b32;
+                scanned += certified ? 0 : 1;
             }
         }
     }
+    bi = b32;
     if (r_out) *r_out = r;
     if (n_scanned) *n_scanned = scanned;
     return certified;
@@ -828,8 +830,17 @@ MD void row_best(float& d, int& i) {
 #ifndef MIDAS_COOP_G
 #define MIDAS_COOP_G 8
 #endif
-constexpr int COOP_G = MIDAS_COOP_G, COOP_L = 64 / COOP_G, COOP_STEPS = 64 / COOP_L;
+// records an owner gets per pass (64: eight steps of eight lanes; 32 halves the records fetched past the certificate
+// on codebooks where a typical list needs 40 - 60 of them)
+#ifndef MIDAS_COOP_CHUNK
+#define MIDAS_COOP_CHUNK 64
+#endif
+#ifndef MIDAS_COOP_PIECES
+#define MIDAS_COOP_PIECES 0
+#endif
+constexpr int COOP_G = MIDAS_COOP_G, COOP_L = 64 / COOP_G, COOP_CHUNK = MIDAS_COOP_CHUNK, COOP_STEPS = COOP_CHUNK / COOP_L;
 static_assert(COOP_G == 4 || COOP_G == 8 || COOP_G == 16, "owners per pass");
+static_assert(COOP_STEPS >= 1 && COOP_STEPS * COOP_L == COOP_CHUNK, "a chunk is whole steps of the group");
 // minimum over a group of COOP_L lanes of (d, idx), ties to the smaller idx; every lane of the group gets the result
 MD void group_best(float& d, int& i) {
 #define MIDAS_STEP(CTRL)                                                              \
@@ -874,7 +885,7 @@ MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_
             // (shuffles stay unconditional: a lane outside the branch could not serve as a source)
             const int hh_s = __shfl(hint, src), first_s = __shfl(nrec, src);
             const int hh = mine >= 0 ? hh_s : 0;
-            const int first = mine >= 0 ? first_s : 0;  // records first .. first+63, clamped to the list
+            const int first = mine >= 0 ? first_s : 0;  // records first .. first+COOP_CHUNK-1, clamped to the list
             float d = INFINITY, rho_last = 0.f;
             int id = 0x7fffffff;
             if (SCREEN) {
@@ -918,6 +929,36 @@ MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_
                 take(pick<COOP_STEPS>(P, k), nb4[2 * pick<COOP_STEPS>(sc, k) + 1]);
             }
             rho_last = hl.w;  // of this lane's last record: the group's last lane holds the chunk's last (when the chunk is whole)
+            } else if (MIDAS_COOP_PIECES) {
+            // piece-contiguous fetch: the 2 COOP_L 16-byte pieces of a step's COOP_L records are read by the group as two
+            // runs of COOP_L consecutive pieces (lane j: pieces j and COOP_L + j), so a load instruction touches each line
+            // once and whole; lane pairs then swap one piece: the even lane keeps record j/2 of the step's first half (its
+            // own first piece + the neighbour's), the odd lane record j/2 of the second half.  Same records, same
+            // distances, same (distance, index) minimum - only which lane evaluates which record changes.
+            const float4* __restrict__ nb4 = reinterpret_cast<const float4*>(tv.nbrs + (size_t)hh * NBR_REC);
+            const int odd = j & 1;
+            float4 pa[COOP_STEPS], pb[COOP_STEPS];
+#pragma unroll
+            for (int m = 0; m < COOP_STEPS; ++m) {
+                const int ra = first + COOP_L * m + (j >> 1), rb = ra + COOP_L / 2;
+                pa[m] = nb4[2 * (ra <= NBR_M ? ra : NBR_M) + odd];
+                pb[m] = nb4[2 * (rb <= NBR_M ? rb : NBR_M) + odd];
+            }
+#pragma unroll
+            for (int m = 0; m < COOP_STEPS; ++m) {
+                const float4 give = odd ? pa[m] : pb[m];
+                float4 got;
+                got.x = __uint_as_float(dpp_u32<DPP_XOR1>(__float_as_uint(give.x)));
+                got.y = __uint_as_float(dpp_u32<DPP_XOR1>(__float_as_uint(give.y)));
+                got.z = __uint_as_float(dpp_u32<DPP_XOR1>(__float_as_uint(give.z)));
+                got.w = __uint_as_float(dpp_u32<DPP_XOR1>(__float_as_uint(give.w)));
+                const float4 lo = odd ? got : pa[m], hi = odd ? pb[m] : got;
+                const float dm = full_from(qq, part4(qq, lo), hi);  // == dist2(qq, record), bit for bit
+                const int im = __float_as_int(hi.z);
+                const bool in = first + COOP_L * m + (j >> 1) + (odd ? COOP_L / 2 : 0) <= NBR_M;
+                if (in && (dm < d || (dm == d && im < id))) { d = dm; id = im; }  // NaN never wins
+                rho_last = in ? hi.w : rho_last;
+            }
             } else {
             const Nbr6* nb = tv.nbrs + (size_t)hh * NBR_REC;
             Nbr6 e[COOP_STEPS];
@@ -933,7 +974,9 @@ MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_
                 for (int a = 0; a < 6; ++a) p.c[a] = e[m].c[a];
                 const float dm = dist2(qq, p);
                 const bool in = first + COOP_L * m + j <= NBR_M;
-                if (in && (dm < d || (dm == d && e[m].idx < id))) { d = dm; id = e[m].idx; }  // NaN never wins
+                const bool better = in & ((dm < d) | ((dm == d) & (e[m].idx < id)));  // NaN never wins; no short circuits: no branches
+                d = better ? dm : d;
+                id = better ? e[m].idx : id;
                 rho_last = in ? e[m].rho : rho_last;
             }
             }
@@ -942,7 +985,7 @@ MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_
             // largest rho scanned = the last valid record of the chunk (clamped loads repeat the list's last record);
             // once the list is exhausted the bound is the distance of the first entry NOT in it
             rho_last = __shfl(rho_last, lane | (COOP_L - 1));
-            const bool at_end = first + 63 >= NBR_M;
+            const bool at_end = first + COOP_CHUNK - 1 >= NBR_M;
             const float bound = at_end ? tv.rho_out[hh] : rho_last;
             const float gg = fmaf_(bound - rr, 0.9999996f, -8e-7f * rr);
             const bool cert = gg > 0.0f && gg * gg * 0.99997f > bb;
@@ -951,7 +994,7 @@ MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_
             const float rb = __shfl(bb, from);
             const int ri = __shfl(b_i, from);
             const int rc = __shfl((int)cert, from);
-            if (open_lane && my_rank >= served && my_rank < served + COOP_G) { best = rb; bi = ri; done = rc != 0; nrec += 64; }
+            if (open_lane && my_rank >= served && my_rank < served + COOP_G) { best = rb; bi = ri; done = rc != 0; nrec += COOP_CHUNK; }
             served += COOP_G;
         }
     }
@@ -1686,9 +1729,18 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
     }
 }
 
+#ifndef MIDAS_XCD_TRAJ
+#define MIDAS_XCD_TRAJ 0  // measured: 371 against 319 us per c5 batch frame with the affinity
+#endif
 __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a) {
     __shared__ double s_cd[KD_MAX_LEVELS * 64];  // child-distance columns, reused by both searches
-    particle_update_wave(t6, t3, a, blockIdx.x, gridDim.x, blockIdx.y, s_cd);
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    if (MIDAS_XCD_TRAJ && gridDim.y > 1 && (gridDim.y & 7u) == 0) {  // XCD c serves the trajectories c mod 8 (see k_frame_front)
+        const unsigned L = by * gridDim.x + bx, c = L & 7u, s = L >> 3;
+        by = c + 8u * (s / gridDim.x);
+        bx = s % gridDim.x;
+    }
+    particle_update_wave(t6, t3, a, bx, gridDim.x, by, s_cd);
 }
 
 // Front kernel of the fused single-trajectory step: the particle update (latency-bound: dependent scattered
@@ -1700,8 +1752,11 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
 // LAZY 2: the same with the tables built per wave (nb <= 64), which also frees the workgroup size: FW = waves per
 // workgroup.  With FW = 1 the 1563 particle waves of c2 spread 6 - 7 per CU; workgroups of four land 4 or 8 on a CU.
 // SCR = false (batch of trajectories, grid.y): whole-record list scans - the screen costs the batch step more than it saves
+#ifndef MIDAS_BATCH_OCC
+#define MIDAS_BATCH_OCC 1  // waves per SIMD the batch form (SCR = false) is compiled for (1 = no register cap)
+#endif
 template <typename T, int NJ, int LAZY, int FW, bool SCR = true, bool PREF = false>
-__global__ __launch_bounds__(64 * FW) void k_frame_front(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a,
+__global__ __launch_bounds__(64 * FW, (!SCR && FW == 1) ? MIDAS_BATCH_OCC : 1) void k_frame_front(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a,
                                                          int n_pu, int nwaves, const T* __restrict__ emb,
                                                          const double* __restrict__ norms, const double* __restrict__ code,
                                                          double* __restrict__ scores, int64_t K) {
@@ -1709,18 +1764,28 @@ __global__ __launch_bounds__(64 * FW) void k_frame_front(TreeView<Kd6> t6, TreeV
     __shared__ double s_cd[FW][KD_MAX_LEVELS * 64];
     __shared__ double s_rs[LAZY == 1 ? 3 * LAZY_MAX_BLOCKS + 8 : LAZY == 2 ? FW * LAZY_WAVE_LDS : 8];
     const int w = threadIdx.x >> 6;
-    if ((int)blockIdx.x < n_pu) {
+    // A batch of trajectories (grid.y): workgroups go to the eight XCDs round robin by linear id, so with the plain
+    // (x = wave, y = trajectory) reading every XCD's L2 holds the neighbour and vertex lists of ALL trajectories.  Read
+    // instead as: XCD c serves the trajectories t = c mod 8 - its L2 then only sees an eighth of the batch's lists
+    // (placement is a matter of speed only: any (trajectory, wave) pair is served exactly once either way).
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    if (MIDAS_XCD_TRAJ && !SCR && gridDim.y > 1 && (gridDim.y & 7u) == 0 && n_pu == (int)gridDim.x) {
+        const unsigned L = by * gridDim.x + bx, c = L & 7u, s = L >> 3;
+        by = c + 8u * (s / gridDim.x);
+        bx = s % gridDim.x;
+    }
+    if ((int)bx < n_pu) {
         if (LAZY == 1) lazy_tables(a.rs, s_rs);
-        const int64_t wave = (int64_t)blockIdx.x * FW + w;
+        const int64_t wave = (int64_t)bx * FW + w;
         if (wave < nwaves) {
             // one-wave workgroups = the small-set regime (see launch_frame_front): screened scans
             constexpr bool SCREEN = FW == 1 && MIDAS_SCREEN && SCR;
-            const int traj = (int)blockIdx.y;
+            const int traj = (int)by;
             if (LAZY == 2) particle_update_wave<true, SCREEN, PREF>(t6, t3, a, wave, nwaves, traj, s_cd[w], s_rs + w * LAZY_WAVE_LDS);
             else particle_update_wave<false, SCREEN, PREF>(t6, t3, a, wave, nwaves, traj, s_cd[w], LAZY ? s_rs : nullptr);
         }
     } else {
-        score_wave<T, NJ, 0>(emb, norms, code, scores, K, (int64_t)(blockIdx.x - n_pu) * FW + w);
+        score_wave<T, NJ, 0>(emb, norms, code, scores, K, (int64_t)(bx - n_pu) * FW + w);
     }
 }
 
