@@ -264,6 +264,7 @@ MIDAS_EXPORT int midas_tree_destroy(midas_tree* t) {
     if (t->rho_out) (void)hipFree(t->rho_out);
     if (t->twin) (void)hipFree(t->twin);
     if (t->vlist) (void)hipFree(t->vlist);
+    if (t->vscr) (void)hipFree(t->vscr);
     tree_free_host(t);
     delete t;
     return MIDAS_OK;
@@ -477,6 +478,7 @@ static int filter_step_impl(midas_ctx* ctx, const midas_codebook* cb, const mida
     pa.t2 = squared_threshold(s.prune_thr);
     pa.thr = s.prune_thr;
     pa.vlist = (tree6->vlist && tree6->vlist_mesh == tree3) ? (const MeshRec*)tree6->vlist : nullptr;
+    pa.vscr = pa.vlist ? (const MeshScr*)tree6->vscr : nullptr;
     pa.telemetry = (unsigned long long*)s.telemetry_dev;
     pa.status_reset = s.status_dev;
     pa.part_max = (double*)pmax;
@@ -670,6 +672,7 @@ static int lazy_step_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_
     pa.t2 = squared_threshold(s.prune_thr);
     pa.thr = s.prune_thr;
     pa.vlist = (tree6->vlist && tree6->vlist_mesh == tree3) ? (const MeshRec*)tree6->vlist : nullptr;
+    pa.vscr = pa.vlist ? (const MeshScr*)tree6->vscr : nullptr;
     pa.telemetry = (unsigned long long*)s.telemetry_dev;
     pa.status_reset = s.status_dev;
     pa.gt16 = (s.gt16_dev && s.part_rmse_dev) ? s.gt16_dev : nullptr;
@@ -823,6 +826,7 @@ MIDAS_EXPORT int midas_shard_front(midas_ctx* ctx, const midas_codebook* cb, con
     pa.t2 = squared_threshold(s.prune_thr);
     pa.thr = s.prune_thr;
     pa.vlist = (tree6->vlist && tree6->vlist_mesh == tree3) ? (const MeshRec*)tree6->vlist : nullptr;
+    pa.vscr = pa.vlist ? (const MeshScr*)tree6->vscr : nullptr;
     pa.telemetry = (unsigned long long*)s.telemetry_dev;
     pa.status_reset = s.status_dev;
     pa.flags_reset = s.flags_dev;

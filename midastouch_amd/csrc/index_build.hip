@@ -229,7 +229,34 @@ __global__ __launch_bounds__(SEL_T) void k_build_vlists(const Point3* __restrict
     }
 }
 
+__global__ __launch_bounds__(256) void k_vertex_screen(int64_t n, const MeshRec* __restrict__ in, MeshScr* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const MeshRec r = in[i];
+    MeshScr o;
+    o.c[0] = (float)r.c[0]; o.c[1] = (float)r.c[1]; o.c[2] = (float)r.c[2];  // round to nearest; inf padding stays inf
+    o.rho = r.rho;
+    out[i] = o;
+}
+
 }  // namespace
+
+int build_vertex_screen(midas_ctx* ctx, midas_tree* t6) {
+    if (t6->vscr) { (void)hipFree(t6->vscr); t6->vscr = nullptr; }
+    static const bool off = getenv("MIDAS_NO_VSCR") && atoi(getenv("MIDAS_NO_VSCR")) != 0;
+    if (off || !t6->vlist) return MIDAS_OK;
+    const int64_t n = t6->K * MESH_REC;
+    if (hipMalloc(&t6->vscr, (size_t)n * sizeof(MeshScr)) != hipSuccess) {  // optional: the float64 lists decide alone
+        (void)hipGetLastError();
+        t6->vscr = nullptr;
+        return MIDAS_OK;
+    }
+    hipLaunchKernelGGL(k_vertex_screen, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, (const MeshRec*)t6->vlist,
+                       (MeshScr*)t6->vscr);
+    MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    MIDAS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return MIDAS_OK;
+}
 
 bool index_build_on_host() {
     const char* e = getenv("MIDAS_HOST_INDEX");
@@ -258,7 +285,7 @@ int build_vertex_lists_device(midas_ctx* ctx, midas_tree* t6, const midas_tree* 
     MIDAS_HIP_CHECK(ctx, hipGetLastError());
     MIDAS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     t6->vlist_mesh = t3;
-    return MIDAS_OK;
+    return build_vertex_screen(ctx, t6);
 }
 
 }  // namespace midas

@@ -48,6 +48,9 @@ constexpr int NBR_REC = NBR_M + 1;  // record 0 = the entry itself
 
 // Mesh-vertex record of the prune fast path: the vertices nearest to a codebook entry's translation.
 struct alignas(16) MeshRec { double c[3]; float rho; int32_t pad; };
+// float32 screening copy of a MeshRec (vertex rounded to nearest; the header's translation is a float32 value already):
+// half the bytes and float32 arithmetic for the decisions that are not within rounding of the threshold (mesh_screen_check)
+struct alignas(16) MeshScr { float c[3]; float rho; };
 constexpr int MESH_M = 256;
 constexpr int MESH_REC = MESH_M + 1;  // record 0 = header: c = the entry's translation, rho = distance of the
                                       // first vertex NOT in the list
@@ -111,6 +114,7 @@ struct midas_tree {
     float* rho_out;  // [K] (dim 6)
     int32_t* twin;   // [K] (dim 6)
     void* vlist;     // MeshRec[K * MESH_REC] (dim 6, after midas_tree_attach_mesh)
+    void* vscr;      // MeshScr[K * MESH_REC]: float32 screening copy of vlist (nullable)
     const midas_tree* vlist_mesh;  // the mesh tree the lists were built from
     void* host;      // host copy of the tree (dim 3: used to build the lists)
 };
@@ -229,6 +233,7 @@ struct ParticleUpdateArgs {
     double t2;             // squared prune threshold (exact: sqrt(d2) > thr  <=>  d2 > t2)
     double thr;            // the threshold itself (triangle-inequality tests of the vertex lists)
     const MeshRec* vlist;  // nullable: per-codebook-entry mesh vertex lists
+    const MeshScr* vscr = nullptr;  // nullable: their float32 screening copy (only read when vlist is set)
     double* part_max;      // [nblocks]
     double* part_min;      // [nblocks]
     const float* gt16;     // nullable
@@ -243,6 +248,7 @@ struct ParticleUpdateArgs {
 int particle_update_blocks(int64_t N);
 bool index_build_on_host();  // MIDAS_HOST_INDEX=1: the host builders of round 1 (checkers of the device builders)
 int build_neighbour_graph_device(midas_ctx* ctx, midas_tree* t);
+int build_vertex_screen(midas_ctx* ctx, midas_tree* t6);  // t6->vscr from t6->vlist (MIDAS_NO_VSCR=1: none)
 int build_vertex_lists_device(midas_ctx* ctx, midas_tree* t6, const midas_tree* t3, const float* cb_poses_dev);
 int launch_knn6(midas_ctx* ctx, const midas_tree* t, int64_t N, const float* feat6, int32_t k, int32_t* idx, float* d2);
 int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t3, const ParticleUpdateArgs& a,

@@ -261,7 +261,7 @@ int attach_mesh_impl(midas_ctx* ctx, midas_tree* t6, const midas_tree* t3, const
     MIDAS_HIP_CHECK(ctx, hipMalloc(&t6->vlist, recs.size() * sizeof(MeshRec)));
     MIDAS_HIP_CHECK(ctx, hipMemcpy(t6->vlist, recs.data(), recs.size() * sizeof(MeshRec), hipMemcpyHostToDevice));
     t6->vlist_mesh = t3;
-    return MIDAS_OK;
+    return build_vertex_screen(ctx, t6);
 }
 
 template <class KD>
@@ -699,15 +699,29 @@ MD bool nn6_hint_scan_screened(const TreeView<Kd6>& tv, const float* q, int32_t 
 // (c5: 353 -> 376 us per batch frame with the screen, c2's front 32.2 -> 30.8 us).
 // Scans records [0, NN_SOLO) of entry h's list (record 0 = the entry itself); the first batch is fetched
 // together with the entry so that r = |q - F_h| costs no round trip of its own.
-MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t h, float& best, int64_t& bi, int* n_scanned,
+// MIDAS_NN_HOPS > 0: a lane whose first batch holds an entry closer than the hinted one (and no certificate yet) starts
+// over from THAT entry's list, up to MIDAS_NN_HOPS times - the certificate's radius is |q - pivot| + best, so a closer
+// pivot needs fewer records (the answer is the exact nearest entry whatever the pivot); `h` returns the pivot the
+// cooperative continuation must go on with.
+#ifndef MIDAS_NN_HOPS
+#define MIDAS_NN_HOPS 0
+#endif
+MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t& h, float& best, int64_t& bi, int* n_scanned,
                       float* r_out = nullptr) {
     const Nbr6* nb = tv.nbrs + (size_t)h * NBR_REC;
     float r = 0.f, rslack = 0.f;
     int scanned = 0;
     int b32 = h;  // record 0 overwrites the incoming candidate; list indices are int32
     bool certified = false;
+    int hops = 0;
 #pragma unroll 1
     for (int s0 = 0; s0 < NN_SOLO && !certified; s0 += NN_BATCH) {
+        if (MIDAS_NN_HOPS > 0 && s0 == NN_BATCH && hops < MIDAS_NN_HOPS && b32 != h) {  // a closer pivot: its list from the start
+            h = b32;
+            nb = tv.nbrs + (size_t)h * NBR_REC;
+            s0 = 0;
+            ++hops;
+        }
         Nbr6 e[NN_BATCH];
 #pragma unroll
         for (int j = 0; j < NN_BATCH; ++j) e[j] = nb[s0 + j];
@@ -1159,6 +1173,66 @@ MD int mesh_list_check(const MeshRec* __restrict__ vlist, int32_t h, const doubl
     }
     if (max_records < MESH_M) return -1;
     return ((double)hd.rho * (1.0 - 1e-7) > lim) ? 0 : -1;
+}
+
+// The same decision from the float32 screening copy of the list (half the bytes per record - the particle kernels are bound
+// by the bytes their scattered loads move through the vector cache, tools/probes/ta_probe.hip - and float32 instead of
+// float64 arithmetic).  tq is a float32 value already (a pose entry) and so is the header; a vertex v was rounded to
+// nearest, |v_f - v| <= 2^-24 |v| per coordinate, and |v| <= |tq| + d, so the true distance d and the one between the
+// float32 points d~ satisfy |d - d~| <= E + 1.1e-7 d~ with E = 2.5e-7 (|tq_x| + |tq_y| + |tq_z|); the computed squared
+// distance is within 4e-7 (relative) of d~^2.  Hence, with 4e-6 of relative slack on the squares:
+//   d2f <= (thr - E)^2 (1 - 4e-6)  =>  d <= thr  (a sure hit: the exact test d2 <= t2 holds - t2 is thr^2 to 1e-16),
+//   d2f >= (thr + E)^2 (1 + 4e-6)  =>  d >  thr  (a sure miss),
+// and anything between (about one record in 10^5; also NaN) is AMBIGUOUS: the lane returns -2 and the caller decides it
+// with mesh_list_check on the float64 records.  "Provably too far" uses a bound that is never below the exact path's
+// (a later stop is still a correct stop): rho > (thr + |tq - header| (1 + 1e-6)) (1 + 1e-6).  Events in record order,
+// stop before hit on the same record, as in mesh_list_check; 1 / 0 / -1 mean the same.
+MD float dist2f3(const float* q, const MeshScr& p) {
+    const float d0 = q[0] - p.c[0], d1 = q[1] - p.c[1], d2 = q[2] - p.c[2];
+    float d = d0 * d0;
+    d = fmaf_(d1, d1, d);
+    d = fmaf_(d2, d2, d);
+    return d;
+}
+template <bool PRE = false>
+MD int mesh_screen_check(const MeshScr* __restrict__ vscr, int32_t h, const float* tqf, double thr, int max_records,
+                         double* lim_out, const MeshScr* pre = nullptr) {
+    const MeshScr* vs = vscr + (size_t)h * MESH_REC;
+    const MeshScr hd = PRE ? pre[0] : vs[0];
+    const float thr_up = __double2float_ru(thr), thr_dn = __double2float_rd(thr);
+    const float E = 2.5e-7f * (__builtin_fabsf(tqf[0]) + __builtin_fabsf(tqf[1]) + __builtin_fabsf(tqf[2]));
+    const float lo = thr_dn - E, hi = thr_up + E;
+    const float t2lo = lo > 0.0f ? lo * lo * (1.0f - 4e-6f) : -1.0f;  // no sure hits when the threshold is within E
+    const float t2hi = hi * hi * (1.0f + 4e-6f);
+    const float delta_up = __builtin_sqrtf(dist2f3(tqf, hd)) * (1.0f + 1e-6f);
+    const float limf = (thr_up + delta_up) * (1.0f + 1e-6f) + 1e-30f;
+    if (lim_out) *lim_out = (double)limf;
+    for (int s0 = 1; s0 <= max_records; s0 += MESH_BATCH) {
+        MeshScr e[MESH_BATCH];
+        if (PRE && s0 == 1) {
+#pragma unroll
+            for (int j = 0; j < MESH_BATCH; ++j) e[j] = pre[1 + j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < MESH_BATCH; ++j) e[j] = vs[s0 + j];
+        }
+        unsigned hits = 0, stops = 0, amb = 0;
+#pragma unroll
+        for (int j = 0; j < MESH_BATCH; ++j) {
+            const float d = dist2f3(tqf, e[j]);
+            const bool hit = d <= t2lo, miss = d >= t2hi;
+            stops |= (e[j].rho > limf ? 1u : 0u) << j;
+            hits |= (hit ? 1u : 0u) << j;
+            amb |= ((hit | miss) ? 0u : 1u) << j;
+        }
+        if (hits | stops | amb) {
+            const int fh = hits ? __builtin_ctz(hits) : 32, fs = stops ? __builtin_ctz(stops) : 32, fa = amb ? __builtin_ctz(amb) : 32;
+            if (fs <= fh && fs <= fa) return 0;
+            return fh < fa ? 1 : -2;
+        }
+    }
+    if (max_records < MESH_M) return -1;
+    return hd.rho > limf ? 0 : -1;
 }
 
 // Wave-level NN: per-lane hint scan, then the octets serve the lanes it could not certify.
@@ -1654,12 +1728,13 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
     // looked at after the prune
     // (small-set regime, registers to spare: the vertex list's header and first batch are requested before the claim, whose
     // look at the stamps is a round trip of its own)
+    // (of the float32 screening copy; without one the float64 list is read after the claim)
     constexpr bool PRE = PREF;
-    MeshRec pre[PRE ? 1 + MESH_BATCH : 1];
-    if (PRE && a.vlist != nullptr) {
-        const MeshRec* vl = a.vlist + (size_t)(live ? bi : 0) * MESH_REC;
+    MeshScr pre[PRE ? 1 + MESH_BATCH : 1];
+    if (PRE && a.vscr != nullptr) {
+        const MeshScr* vs = a.vscr + (size_t)(live ? bi : 0) * MESH_REC;
 #pragma unroll
-        for (int j = 0; j < (PRE ? 1 + MESH_BATCH : 1); ++j) pre[j] = vl[j];
+        for (int j = 0; j < (PRE ? 1 + MESH_BATCH : 1); ++j) pre[j] = vs[j];
     }
     RowClaim claim{false, 0u};
     if (a.sp.stamps && !(a.ablate & 16)) {  // ablate 16 (profiling): nobody scores
@@ -1674,7 +1749,15 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
     if (a.ablate & 2) mv = 1;
     else if (a.vlist) {
         double lim_lane = 0.0;
-        if (live) mv = mesh_list_check<PRE>(a.vlist, bi, q3, a.t2, a.thr, MESH_SOLO, &lim_lane, pre);  // first records, per lane
+        if (a.vscr) {  // first records, per lane: float32 screening copy, the float64 records only for what it cannot decide
+            const float tqf[3] = {R[3], R[7], R[11]};
+            if (live) mv = mesh_screen_check<PRE>(a.vscr, bi, tqf, a.thr, MESH_SOLO, &lim_lane, pre);
+            if (__ballot(mv == -2)) {
+                if (mv == -2) mv = mesh_list_check<false>(a.vlist, bi, q3, a.t2, a.thr, MESH_SOLO, &lim_lane);
+            }
+        } else if (live) {
+            mv = mesh_list_check<false>(a.vlist, bi, q3, a.t2, a.thr, MESH_SOLO, &lim_lane);
+        }
         tc[4] = clock64();
         if (a.telemetry && (a.ablate & 4)) st_mesh = __ballot(live && mv < 0);
         mesh_coop(a.vlist, bi, q3, a.t2, lim_lane, live && mv < 0, mv);             // the rest, whole wave per lane
