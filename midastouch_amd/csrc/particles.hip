@@ -849,6 +849,9 @@ MD void row_best(float& d, int& i) {
 #ifndef MIDAS_COOP_CHUNK
 #define MIDAS_COOP_CHUNK 64
 #endif
+#ifndef MIDAS_COOP_LDS
+#define MIDAS_COOP_LDS 0  // measured: no change on c5 (305 against 304 us) - the scalar steps run beside other waves' vector work
+#endif
 #ifndef MIDAS_COOP_PIECES
 #define MIDAS_COOP_PIECES 0
 #endif
@@ -871,7 +874,7 @@ MD void group_best(float& d, int& i) {
 
 template <bool SCREEN = false>
 MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_lane, float& best, int64_t& bi, bool need,
-                 bool& done) {
+                 bool& done, int* own_lds = nullptr) {
     const int lane = threadIdx.x & 63, grp = lane / COOP_L, j = lane % COOP_L;
     int nrec = NN_SOLO;  // next record of this lane's list (owners only)
     // pass after pass: every open owner gets its next 64 records, COOP_G owners per instruction stream
@@ -880,14 +883,29 @@ MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_
         unsigned long long todo = __ballot(open_lane);
         if (!todo) break;
         const int my_rank = (int)__builtin_popcountll(todo & ((1ull << lane) - 1ull));  // rank among this pass's owners
+        const int n_own = (int)__builtin_popcountll(todo);
+        // own_lds (64 ints of the wave's LDS): the owners' lane numbers in rank order, written once per round, so a pass
+        // reads its group's owner with one LDS load instead of COOP_G scalar find-first-set / clear steps
+        if (MIDAS_COOP_LDS && own_lds) {
+            if (open_lane) own_lds[my_rank] = lane;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         int served = 0;
-        while (todo) {
+        while ((MIDAS_COOP_LDS && own_lds) ? served < n_own : todo != 0) {
             int mine = -1;
+            if (MIDAS_COOP_LDS && own_lds) {
+                const int slot = served + grp;
+                const int v = own_lds[slot < 63 ? slot : 63];
+                mine = slot < n_own ? v : -1;
+            } else {
 #pragma unroll
-            for (int k = 0; k < COOP_G; ++k) {
-                const int o = todo ? (int)__builtin_ctzll(todo) : -1;
-                todo &= todo - 1;  // 0 & anything stays 0
-                mine = grp == k ? o : mine;
+                for (int k = 0; k < COOP_G; ++k) {
+                    const int o = todo ? (int)__builtin_ctzll(todo) : -1;
+                    todo &= todo - 1;  // 0 & anything stays 0
+                    mine = grp == k ? o : mine;
+                }
             }
             const int src = mine >= 0 ? mine : lane;
             float qq[6];
@@ -1249,7 +1267,7 @@ MD bool nn6_wave(const TreeView<Kd6>& tv, const float* q, bool live, int32_t hin
         done = SCREEN ? nn6_hint_scan_screened(tv, q, hint, best, bi, n_scanned, &r_lane)
                       : nn6_hint_scan(tv, q, hint, best, bi, n_scanned, &r_lane);
     if (t_solo) *t_solo = clock64();
-    nn6_coop<SCREEN>(tv, q, hint, r_lane, best, bi, hinted && !done, done);                 // the rest, whole wave per lane
+    nn6_coop<SCREEN>(tv, q, hint, r_lane, best, bi, hinted && !done, done, reinterpret_cast<int*>(cd));  // the rest, whole wave per lane
     wave_search<Kd6, false, STATS>(tv, q, best, bi, !done, cd, n_leaves, n_nodes);
     idx = (int32_t)bi;
     d2 = best;
