@@ -592,6 +592,9 @@ static_assert(NN_SOLO % NN_BATCH == 0 && NBR_M % NN_BATCH == 0 && MESH_SOLO % ME
 #ifndef MIDAS_SCREEN
 #define MIDAS_SCREEN 1
 #endif
+#ifndef MIDAS_TAKE_BRANCHFREE
+#define MIDAS_TAKE_BRANCHFREE 1  // candidate updates of the screened scans as selects (0: the short-circuit form)
+#endif
 MD float part4(const float* q, const float4& lo) {
     const float d0 = q[0] - lo.x, d1 = q[1] - lo.y, d2 = q[2] - lo.z, d3 = q[3] - lo.w;
     float d = d0 * d0;
@@ -660,6 +663,26 @@ MD void nn6_hint_batch(const float4* __restrict__ nb4, int s0, const float* q, i
     const int j1 = m1 ? __builtin_ctz(m1) : NN_BATCH - 1, j2 = m2 ? __builtin_ctz(m2) : NN_BATCH - 1;
     const float4 ha = nb4[2 * (s0 + j1) + 1];
     const float4 hb = nb4[2 * (s0 + j2) + 1];
+#if MIDAS_TAKE_BRANCHFREE
+    int b32 = (int)bi;  // list indices are int32
+    auto take = [&](float p4, const float4& hi, bool on) {  // no short circuits: selects instead of exec-mask regions
+        const float d = full_from(q, p4, hi);
+        const int32_t id = __float_as_int(hi.z);
+        const bool better = on & ((d < best) | ((d == best) & (id < b32)));
+        best = better ? d : best;
+        b32 = better ? id : b32;
+    };
+    take(pick<NN_BATCH>(P, j1), ha, m1 != 0);
+    take(pick<NN_BATCH>(P, j2), hb, m2 != 0);
+    take(P[NN_BATCH - 1], hl, (mask >> (NN_BATCH - 1)) != 0);
+    unsigned rest = m2 & (m2 - 1u);
+    while (rest) {  // more than two candidates among the batch's first records
+        const int j = __builtin_ctz(rest);
+        rest &= rest - 1u;
+        take(pick<NN_BATCH>(P, j), nb4[2 * (s0 + j) + 1], true);
+    }
+    bi = b32;
+#else
     auto take = [&](float p4, const float4& hi) {
         const float d = full_from(q, p4, hi);
         const int32_t id = __float_as_int(hi.z);
@@ -674,6 +697,7 @@ MD void nn6_hint_batch(const float4* __restrict__ nb4, int s0, const float* q, i
         rest &= rest - 1u;
         take(pick<NN_BATCH>(P, j), nb4[2 * (s0 + j) + 1]);
     }
+#endif
     // every record behind this batch is at least this far (lower bound of |q - F| with slack for the rounding of r, rho)
     const float g = fmaf_(hl.w - r, 0.9999996f, rslack);
     certified = g > 0.0f && g * g * 0.99997f > best;
@@ -946,19 +970,23 @@ MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_
             const int s1 = pick<COOP_STEPS>(sc, k1), s2 = pick<COOP_STEPS>(sc, k2);
             const float4 ha = nb4[2 * s1 + 1];
             const float4 hb = nb4[2 * s2 + 1];
-            auto take = [&](float p4, const float4& hi) {
+            auto take = [&](float p4, const float4& hi, bool on) {
                 const float dm = full_from(qq, p4, hi);
                 const int im = __float_as_int(hi.z);
-                if (dm < d || (dm == d && im < id)) { d = dm; id = im; }  // NaN never wins
+                if (MIDAS_TAKE_BRANCHFREE) {
+                    const bool better = on & ((dm < d) | ((dm == d) & (im < id)));  // NaN never wins
+                    d = better ? dm : d;
+                    id = better ? im : id;
+                } else if (on && (dm < d || (dm == d && im < id))) { d = dm; id = im; }
             };
-            if (m1) take(pick<COOP_STEPS>(P, k1), ha);
-            if (m2) take(pick<COOP_STEPS>(P, k2), hb);
-            if (mask >> (COOP_STEPS - 1)) take(P[COOP_STEPS - 1], hl);
+            take(pick<COOP_STEPS>(P, k1), ha, m1 != 0);
+            take(pick<COOP_STEPS>(P, k2), hb, m2 != 0);
+            take(P[COOP_STEPS - 1], hl, (mask >> (COOP_STEPS - 1)) != 0);
             unsigned rest = m2 & (m2 - 1u);
             while (rest) {
                 const int k = __builtin_ctz(rest);
                 rest &= rest - 1u;
-                take(pick<COOP_STEPS>(P, k), nb4[2 * pick<COOP_STEPS>(sc, k) + 1]);
+                take(pick<COOP_STEPS>(P, k), nb4[2 * pick<COOP_STEPS>(sc, k) + 1], true);
             }
             rho_last = hl.w;  // of this lane's last record: the group's last lane holds the chunk's last (when the chunk is whole)
             } else if (MIDAS_COOP_PIECES) {
