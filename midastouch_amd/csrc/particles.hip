@@ -794,7 +794,9 @@ MD void wave_best(float& d, int& i) {
     {                                                                                 \
         const float od = __uint_as_float(dpp_u32<CTRL>(__float_as_uint(d)));          \
         const int oi = (int)dpp_u32<CTRL>((uint32_t)i);                                \
-        if (od < d || (od == d && oi < i)) { d = od; i = oi; }                         \
+        const bool ob = (od < d) | ((od == d) & (oi < i));                            \
+        d = ob ? od : d;                                                               \
+        i = ob ? oi : i;                                                               \
     }
     MIDAS_STEP(DPP_XOR1) MIDAS_STEP(DPP_XOR2) MIDAS_STEP(DPP_HALF_MIRROR) MIDAS_STEP(0x140 /* row_mirror */)
 #undef MIDAS_STEP
@@ -847,7 +849,9 @@ MD void row_best(float& d, int& i) {
     {                                                                                 \
         const float od = __uint_as_float(dpp_u32<CTRL>(__float_as_uint(d)));          \
         const int oi = (int)dpp_u32<CTRL>((uint32_t)i);                                \
-        if (od < d || (od == d && oi < i)) { d = od; i = oi; }                         \
+        const bool ob = (od < d) | ((od == d) & (oi < i));                            \
+        d = ob ? od : d;                                                               \
+        i = ob ? oi : i;                                                               \
     }
     MIDAS_STEP(DPP_XOR1) MIDAS_STEP(DPP_XOR2) MIDAS_STEP(DPP_HALF_MIRROR) MIDAS_STEP(0x140 /* row_mirror */)
 #undef MIDAS_STEP
@@ -888,7 +892,9 @@ MD void group_best(float& d, int& i) {
     {                                                                                 \
         const float od = __uint_as_float(dpp_u32<CTRL>(__float_as_uint(d)));          \
         const int oi = (int)dpp_u32<CTRL>((uint32_t)i);                                \
-        if (od < d || (od == d && oi < i)) { d = od; i = oi; }                         \
+        const bool ob = (od < d) | ((od == d) & (oi < i));                            \
+        d = ob ? od : d;                                                               \
+        i = ob ? oi : i;                                                               \
     }
     MIDAS_STEP(DPP_XOR1) MIDAS_STEP(DPP_XOR2)
     if (COOP_L >= 8) MIDAS_STEP(DPP_HALF_MIRROR)
@@ -1041,7 +1047,11 @@ MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_
             }
             }
             group_best(d, id);
-            if (d < bb || (d == bb && id < b_i)) { bb = d; b_i = id; }
+            {
+                const bool gb = (d < bb) | ((d == bb) & (id < b_i));
+                bb = gb ? d : bb;
+                b_i = gb ? id : b_i;
+            }
             // largest rho scanned = the last valid record of the chunk (clamped loads repeat the list's last record);
             // once the list is exhausted the bound is the distance of the first entry NOT in it
             rho_last = __shfl(rho_last, lane | (COOP_L - 1));
