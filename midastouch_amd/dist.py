@@ -276,11 +276,25 @@ class TorchDistComm:
         self.dist, self.group = dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self._into = dist.get_backend(group) == "nccl"
+        self._bufs = {}
+
+    def _out(self, shape, dtype, device):
+        """Receive buffer for a collective: two per (shape, dtype), alternating - allocating one per call was ~5 us of host
+        time per collective in a frame that is bound by its host-side enqueueing (tools/shard_host_cost.py); a buffer is
+        written again two calls later, behind everything the stream was given in between."""
+        key = (tuple(shape), dtype, device)
+        slot = self._bufs.get(key)
+        if slot is None:
+            slot = self._bufs[key] = [[torch.empty(shape, dtype=dtype, device=device) for _ in range(2)], 0]
+            if len(self._bufs) > 64:  # variable split sizes (exchange="a2a"): do not hoard
+                self._bufs = {key: slot}
+        slot[1] ^= 1
+        return slot[0][slot[1]]
 
     def all_gather(self, t: torch.Tensor) -> torch.Tensor:
         t = t.contiguous()
         if self._into:
-            out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            out = self._out((self.world * t.shape[0],) + tuple(t.shape[1:]), t.dtype, t.device)
             self.dist.all_gather_into_tensor(out, t, group=self.group)
             return out
         # gloo (CPU tests, or several processes sharing one GPU): through host memory
@@ -291,7 +305,7 @@ class TorchDistComm:
 
     def all_to_all(self, send: torch.Tensor, in_splits, out_splits) -> torch.Tensor:
         if self._into:
-            out = torch.empty((sum(out_splits),), dtype=send.dtype, device=send.device)
+            out = self._out((sum(out_splits),), send.dtype, send.device)
             self.dist.all_to_all_single(out, send.contiguous(), list(out_splits), list(in_splits), group=self.group)
             return out
         h = send.contiguous().cpu()
