@@ -411,6 +411,13 @@ int midas_shard_unpack(midas_ctx* ctx, int64_t N, const void* recv_dev, int32_t*
  * dest (the gathered overflow blocks) */
 int midas_shard_unpack_rows(midas_ctx* ctx, int64_t rows, const void* recv_dev, int32_t dest, int32_t* ridx_dev,
                             float* poses_out_dev, double* weights_out_dev, int32_t* hint_out_dev);
+/* the three unpack passes of a fixed-capacity frame in ONE call (the frame is bound by the host's enqueueing, ~14 us per call):
+ * the received segments (every record), the gathered overflow blocks (records for `rank`), the rows this rank owned and
+ * needed itself (every record); any of the three may have 0 rows.  Same kernels, same results as three midas_shard_unpack_rows
+ * calls (midastouch_amd/dist.py unpack_fixed; no counterpart in the reference, whose filter is a single process). */
+int midas_shard_unpack_fixed(midas_ctx* ctx, int64_t rows_recv, const void* recv_dev, int64_t rows_ovf, const void* ovf_all_dev,
+                             int32_t rank, int64_t rows_self, const void* self_dev, int32_t* ridx_dev, float* poses_out_dev,
+                             double* weights_out_dev, int32_t* hint_out_dev);
 /* ---- peer-mapped inboxes (the fourth exchange form; RCCL only carries the 1 KB block records and a barrier) ----
  * midas_peer_alloc: `bytes` of fine-grained device memory (hipExtMallocWithFlags, what RCCL uses for buffers its peers
  * write) + the 64-byte interprocess handle other ranks open it with.  midas_peer_open maps another process's inbox

@@ -216,6 +216,7 @@ SIGNATURES = {
     "midas_shard_route_pack": (C.c_int, [_P, C.POINTER(ShardRouteArgs)]),
     "midas_shard_unpack": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P]),
     "midas_shard_unpack_rows": (C.c_int, [_P, _I64, _P, _I32, _P, _P, _P, _P]),
+    "midas_shard_unpack_fixed": (C.c_int, [_P, _I64, _P, _I64, _P, _I32, _I64, _P, _P, _P, _P, _P]),
     "midas_shard_unpack_peer": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P]),
     "midas_peer_alloc": (C.c_int, [_P, _I64, C.POINTER(C.c_void_p), _P]),
     "midas_peer_free": (C.c_int, [_P, _P]),

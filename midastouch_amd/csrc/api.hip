@@ -916,6 +916,21 @@ MIDAS_EXPORT int midas_shard_unpack_rows(midas_ctx* ctx, int64_t rows, const voi
     return launch_shard_unpack(ctx, rows, recv_dev, ridx_dev, poses_out_dev, weights_out_dev, hint_out_dev, dest);
 }
 
+MIDAS_EXPORT int midas_shard_unpack_fixed(midas_ctx* ctx, int64_t rows_recv, const void* recv_dev, int64_t rows_ovf,
+                                          const void* ovf_all_dev, int32_t rank, int64_t rows_self, const void* self_dev,
+                                          int32_t* ridx_dev, float* poses_out_dev, double* weights_out_dev, int32_t* hint_out_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, rows_recv >= 0 && rows_ovf >= 0 && rows_self >= 0 && rank >= 0 && ridx_dev && poses_out_dev && weights_out_dev &&
+                           hint_out_dev);
+    MIDAS_REQUIRE(ctx, (rows_recv == 0 || (recv_dev && (uintptr_t)recv_dev % 8 == 0)) && (rows_ovf == 0 || (ovf_all_dev && (uintptr_t)ovf_all_dev % 8 == 0)) &&
+                           (rows_self == 0 || (self_dev && (uintptr_t)self_dev % 8 == 0)));
+    int rc = MIDAS_OK;
+    if (rows_recv > 0) rc = launch_shard_unpack(ctx, rows_recv, recv_dev, ridx_dev, poses_out_dev, weights_out_dev, hint_out_dev, -1);
+    if (rc == MIDAS_OK && rows_ovf > 0) rc = launch_shard_unpack(ctx, rows_ovf, ovf_all_dev, ridx_dev, poses_out_dev, weights_out_dev, hint_out_dev, rank);
+    if (rc == MIDAS_OK && rows_self > 0) rc = launch_shard_unpack(ctx, rows_self, self_dev, ridx_dev, poses_out_dev, weights_out_dev, hint_out_dev, -1);
+    return rc;
+}
+
 MIDAS_EXPORT int midas_shard_unpack_peer(midas_ctx* ctx, int64_t N, const void* inbox_dev, int32_t* ridx_dev, float* poses_out_dev,
                                          double* weights_out_dev, int32_t* hint_out_dev) {
     MIDAS_ENTER(ctx);

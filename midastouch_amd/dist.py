@@ -165,9 +165,8 @@ class HipShardBackend:
         return send, st._ovf
 
     def unpack_fixed(self, st, recv, ovf_all, rank):
-        for buf, dest in ((recv, -1), (ovf_all, rank), (st._self, -1)):
-            self.ctx.call("midas_shard_unpack_rows", buf.numel() // ROUTE_REC, _ptr(buf), int(dest), _ptr(st.ridx), _ptr(st.poses),
-                          _ptr(st.weights_res), _ptr(st.hint))
+        self.ctx.call("midas_shard_unpack_fixed", recv.numel() // ROUTE_REC, _ptr(recv), ovf_all.numel() // ROUTE_REC, _ptr(ovf_all), int(rank),
+                      st._self.numel() // ROUTE_REC, _ptr(st._self), _ptr(st.ridx), _ptr(st.poses), _ptr(st.weights_res), _ptr(st.hint))
 
     def overflow_rows(self, st, world):
         """Rows the last fixed-capacity frame put into its overflow block (more than its capacity: rows were lost)."""
