@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void k_loop_xe(const int32_t* __restrict__ ctl
     if (softmax) {
 #pragma unroll
         for (int j = 0; j < SCAN_CHUNK; ++j) {
-            v[j] = exp(v[j] - 1.0);
+            v[j] = exp_spec(v[j] - 1.0);
             __builtin_amdgcn_sched_barrier(0);  // one exponential at a time (registers)
         }
     }

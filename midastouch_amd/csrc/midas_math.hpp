@@ -92,6 +92,41 @@ MD float log_spec(float x) {
     return r;
 }
 
+// float64 exponential of the softmax numerators (spec: oracle/midas_oracle.c mo_exp states the same operations):
+// k = rint(x / ln 2), two-step fma reduction by fdlibm's split of ln 2, degree-13 Taylor polynomial in Horner fma steps,
+// two exact power-of-two factors (one rounding, also for subnormal results).  A math library's exp is not bit-identical
+// between libm and the device; the numerators decide the resample CDF and with it the indices.
+MD double pow2i_spec(int k) { return __longlong_as_double((long long)((uint64_t)(k + 1023) << 52)); }
+MD double exp_spec(double x) {
+    const double INV_LN2 = 1.44269504088896338700e+00;
+    const double LN2_HI = 6.93147180369123816490e-01;
+    const double LN2_LO = 1.90821492927058770002e-10;
+    // clamped argument for the arithmetic (the special cases are selected at the end: no branches)
+    const double xc = x > 709.782712893384 ? 709.782712893384 : (x < -745.2 ? -745.2 : x);
+    const double kf = __builtin_rint(xc * INV_LN2);
+    double r = fma_(-kf, LN2_HI, xc);
+    r = fma_(-kf, LN2_LO, r);
+    double p = 1.6059043836821613e-10;
+    p = fma_(p, r, 2.08767569878681e-09);
+    p = fma_(p, r, 2.505210838544172e-08);
+    p = fma_(p, r, 2.755731922398589e-07);
+    p = fma_(p, r, 2.7557319223985893e-06);
+    p = fma_(p, r, 2.48015873015873e-05);
+    p = fma_(p, r, 1.984126984126984e-04);
+    p = fma_(p, r, 1.388888888888889e-03);
+    p = fma_(p, r, 8.333333333333333e-03);
+    p = fma_(p, r, 4.1666666666666664e-02);
+    p = fma_(p, r, 1.6666666666666666e-01);
+    p = fma_(p, r, 0.5);
+    p = fma_(p, r, 1.0);
+    p = fma_(p, r, 1.0);
+    const int k = (int)kf, k1 = k >> 1, k2 = k - k1;
+    double v = (p * pow2i_spec(k1)) * pow2i_spec(k2);
+    v = x > 709.782712893384 ? (double)INFINITY : v;
+    v = x < -745.2 ? 0.0 : v;
+    return x != x ? x : v;
+}
+
 // ---- Philox4x32-10 ---------------------------------------------------------------------------
 struct u32x4 { uint32_t x, y, z, w; };
 

@@ -1674,7 +1674,9 @@ MD int64_t lazy_source(const LazyResample& rs, const double* rs_lds, int64_t n, 
 // SCREEN: half-record screening in the list scans (see part4)
 // PREF: the vertex list's header and first batch are requested before the sparse-scoring claim (72 more registers: only
 // where two waves per SIMD are all the launch needs, N <= 131072 in one-wave workgroups)
-template <bool WT = false, bool SCREEN = false, bool PREF = false>
+// STATS (profiling instantiations only, chosen by MIDAS_ABLATE != 0): per-wave phase clocks, scan statistics and the ablation
+// switches; the production instantiations read no clock and test no switch
+template <bool WT = false, bool SCREEN = false, bool PREF = false, bool STATS = false>
 MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, ParticleUpdateArgs a, int64_t wave,
                              int nwaves, int traj, double* s_cd, double* rs_lds = nullptr) {
     const int lane = threadIdx.x & 63;
@@ -1714,9 +1716,12 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
         if (a.flags_reset) { a.flags_reset[0] = 0.0; a.flags_reset[1] = 0.0; }
     }
     unsigned long long st_nn = 0, st_mesh = 0, st_scan = 0;
+    int st_rows = 0;
+    const int ablate = STATS ? a.ablate : 0;
     long long tc[10];  // phase clocks, reported with MIDAS_ABLATE=4
-    tc[0] = clock64();
-    const long long wall0 = wall_clock64();  // 100 MHz
+#define MIDAS_TICK(i) do { if (STATS) tc[i] = clock64(); } while (0)
+    MIDAS_TICK(0);
+    const long long wall0 = STATS ? wall_clock64() : 0;  // 100 MHz
     double x = 0.0, et2 = 0.0, ang2 = 0.0;
     float R[16], f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1741,7 +1746,7 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
     }
     if (rs_lds && live) {
         // ablate 8 (profiling): no search, own slot
-        src = (a.ablate & 8) ? n : lazy_source(a.rs, rs_lds, n, a.N, WT ? LAZY_WAVE_LD : 256);
+        src = (ablate & 8) ? n : lazy_source(a.rs, rs_lds, n, a.N, WT ? LAZY_WAVE_LD : 256);
         if (a.rs.ridx_out) a.rs.ridx_out[n] = (int32_t)src;
     }
     const float* pose_src = rs_lds ? a.rs.poses_prev : a.poses_in;
@@ -1761,17 +1766,18 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
         store_pose(a.poses_prop + n * 16, R);
         se3_feature(R, 0.99f, 0.01f, f);
     }
-    tc[1] = clock64();
+    MIDAS_TICK(1);
     // nearest codebook entry
     int32_t bi = 0;
     float bd;
-    if (a.ablate & 1) {  // profiling only: trust the hint
+    if (ablate & 1) {  // profiling only: trust the hint
         bi = hint < 0 ? 0 : hint;
     } else {
         int nscan = 0;
-        const bool fb = nn6_wave<false, SCREEN>(t6, f, live, hint, bi, bd, reinterpret_cast<float*>(s_cd), nullptr, nullptr, &nscan, &tc[2]);
-        tc[3] = clock64();
-        if (a.telemetry && (a.ablate & 4)) {  // MIDAS_ABLATE=4: scan statistics (profiling only), flushed at the end
+        const bool fb = nn6_wave<false, SCREEN>(t6, f, live, hint, bi, bd, reinterpret_cast<float*>(s_cd), nullptr, nullptr, STATS ? &nscan : nullptr,
+                                                STATS ? &tc[2] : nullptr);
+        MIDAS_TICK(3);
+        if (a.telemetry && (ablate & 4)) {  // MIDAS_ABLATE=4: scan statistics (profiling only), flushed at the end
             st_nn = __ballot(live && nscan >= NN_SOLO - 1);
             st_scan = (unsigned long long)wave_sum((double)nscan);
         }
@@ -1793,16 +1799,17 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
         for (int j = 0; j < (PRE ? 1 + MESH_BATCH : 1); ++j) pre[j] = vs[j];
     }
     RowClaim claim{false, 0u};
-    if (a.sp.stamps && !(a.ablate & 16)) {  // ablate 16 (profiling): nobody scores
+    if (a.sp.stamps && !(ablate & 16)) {  // ablate 16 (profiling): nobody scores
         claim = claim_rows_issue(a.sp, live, bi);
-        if (!MIDAS_CLAIM_DEFER) score_claimed_rows_nj(a.sp, claim, bi);
+        if (!MIDAS_CLAIM_DEFER) st_rows = score_claimed_rows_nj(a.sp, claim, bi);
     }
+    MIDAS_TICK(9);
     // prune: valid <=> some mesh vertex within sqrt(t2) of the particle
     double q3[3] = {(double)R[3], (double)R[7], (double)R[11]};
     double best = a.t2;
     int64_t vi = 0;
     int mv = -1;  // 1 valid, 0 invalid, -1 undecided
-    if (a.ablate & 2) mv = 1;
+    if (ablate & 2) mv = 1;
     else if (a.vlist) {
         double lim_lane = 0.0;
         if (a.vscr) {  // first records, per lane: float32 screening copy, the float64 records only for what it cannot decide
@@ -1814,25 +1821,25 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
         } else if (live) {
             mv = mesh_list_check<false>(a.vlist, bi, q3, a.t2, a.thr, MESH_SOLO, &lim_lane);
         }
-        tc[4] = clock64();
-        if (a.telemetry && (a.ablate & 4)) st_mesh = __ballot(live && mv < 0);
+        MIDAS_TICK(4);
+        if (a.telemetry && (ablate & 4)) st_mesh = __ballot(live && mv < 0);
         mesh_coop(a.vlist, bi, q3, a.t2, lim_lane, live && mv < 0, mv);             // the rest, whole wave per lane
     }
-    tc[5] = clock64();
+    MIDAS_TICK(5);
     bool ok = wave_search<Kd3, true>(t3, q3, best, vi, live && mv < 0, s_cd);
     if (a.telemetry) {
         const unsigned long long m = __ballot(live && mv < 0);
         if (lane == 0 && m) atomicAdd(&a.telemetry[1], (unsigned long long)__popcll(m));
     }
     if (mv >= 0) ok = mv == 1;
-    if (MIDAS_CLAIM_DEFER && a.sp.stamps && !(a.ablate & 16)) score_claimed_rows_nj(a.sp, claim, bi);
-    tc[6] = clock64();
+    if (MIDAS_CLAIM_DEFER && a.sp.stamps && !(ablate & 16)) st_rows = score_claimed_rows_nj(a.sp, claim, bi);
+    MIDAS_TICK(6);
     if (live) {
         a.nn_idx[n] = bi;
         if (a.scores) {  // nullptr: the scoring runs concurrently, the tail gathers the scores
             x = a.scores[bi];
             a.x[n] = x;
-            a.e[n] = exp(x - 1.0);
+            a.e[n] = exp_spec(x - 1.0);
         }
         a.valid[n] = ok ? 1 : 0;
         if (a.gt16) {
@@ -1842,7 +1849,7 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
             rmse_terms(R, G, et2, ang2);
         }
     }
-    tc[7] = clock64();
+    MIDAS_TICK(7);
     // per-wave extrema of x over live lanes
     const double NEG = -INFINITY, POS = INFINITY;
     if (a.scores) {
@@ -1854,23 +1861,27 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
         ang2 = wave_sum(ang2);
         if (lane == 0) { a.part_rmse[2 * wave] = et2; a.part_rmse[2 * wave + 1] = ang2; }
     }
-    if (a.telemetry && (a.ablate & 4) && lane == 0) {
+    if (STATS && a.telemetry && (ablate & 4) && lane == 0) {
         // MIDAS_ABLATE=4: per-wave scan statistics and phase clocks, plain stores into the wave's own 16 slots
         // behind the 16 cumulative counters (the caller sized the buffer 16 + 16 * waves)
         tc[8] = clock64();
         unsigned long long* w = a.telemetry + 16 + 16 * ((size_t)traj * nwaves + wave);
+        w[0] += (unsigned long long)st_rows;                 // codebook rows this wave scored (sparse scoring)
+        w[1] = (unsigned long long)wall0;                    // start of the wave (100 MHz wall clock, not cumulative)
         w[2] += (unsigned long long)__popcll(st_nn); w[4] += st_nn ? 1 : 0;
         w[3] += (unsigned long long)__popcll(st_mesh); w[5] += st_mesh ? 1 : 0;
         w[6] += st_scan;
         w[7] += (unsigned long long)(wall_clock64() - wall0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) w[8 + i] += (unsigned long long)(tc[i + 1] - tc[i]);
+        for (int i = 0; i < 8; ++i) w[8 + i] += (unsigned long long)(i == 3 ? tc[9] - tc[3] : i == 4 ? tc[5] - tc[9] : tc[i + 1] - tc[i]);  // [3] claim + scoring, [4] prune lists
     }
+#undef MIDAS_TICK
 }
 
 #ifndef MIDAS_XCD_TRAJ
 #define MIDAS_XCD_TRAJ 0  // measured: 371 against 319 us per c5 batch frame with the affinity
 #endif
+template <bool STATS>
 __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a) {
     __shared__ double s_cd[KD_MAX_LEVELS * 64];  // child-distance columns, reused by both searches
     unsigned bx = blockIdx.x, by = blockIdx.y;
@@ -1879,7 +1890,7 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
         by = c + 8u * (s / gridDim.x);
         bx = s % gridDim.x;
     }
-    particle_update_wave(t6, t3, a, bx, gridDim.x, by, s_cd);
+    particle_update_wave<false, false, false, STATS>(t6, t3, a, bx, gridDim.x, by, s_cd);
 }
 
 // Front kernel of the fused single-trajectory step: the particle update (latency-bound: dependent scattered
@@ -1894,7 +1905,7 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
 #ifndef MIDAS_BATCH_OCC
 #define MIDAS_BATCH_OCC 1  // waves per SIMD the batch form (SCR = false) is compiled for (1 = no register cap)
 #endif
-template <typename T, int NJ, int LAZY, int FW, bool SCR = true, bool PREF = false>
+template <typename T, int NJ, int LAZY, int FW, bool SCR = true, bool PREF = false, bool STATS = false>
 __global__ __launch_bounds__(64 * FW, (!SCR && FW == 1) ? MIDAS_BATCH_OCC : 1) void k_frame_front(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a,
                                                          int n_pu, int nwaves, const T* __restrict__ emb,
                                                          const double* __restrict__ norms, const double* __restrict__ code,
@@ -1920,8 +1931,8 @@ __global__ __launch_bounds__(64 * FW, (!SCR && FW == 1) ? MIDAS_BATCH_OCC : 1) v
             // one-wave workgroups = the small-set regime (see launch_frame_front): screened scans
             constexpr bool SCREEN = FW == 1 && MIDAS_SCREEN && SCR;
             const int traj = (int)by;
-            if (LAZY == 2) particle_update_wave<true, SCREEN, PREF>(t6, t3, a, wave, nwaves, traj, s_cd[w], s_rs + w * LAZY_WAVE_LDS);
-            else particle_update_wave<false, SCREEN, PREF>(t6, t3, a, wave, nwaves, traj, s_cd[w], LAZY ? s_rs : nullptr);
+            if (LAZY == 2) particle_update_wave<true, SCREEN, PREF, STATS>(t6, t3, a, wave, nwaves, traj, s_cd[w], s_rs + w * LAZY_WAVE_LDS);
+            else particle_update_wave<false, SCREEN, PREF, STATS>(t6, t3, a, wave, nwaves, traj, s_cd[w], LAZY ? s_rs : nullptr);
         }
     } else {
         score_wave<T, NJ, 0>(emb, norms, code, scores, K, (int64_t)(bx - n_pu) * FW + w);
@@ -2285,8 +2296,9 @@ int launch_particle_update(midas_ctx* ctx, const midas_tree* t6, const midas_tre
     // MIDAS_ABLATE (profiling only, results become wrong): bit 0 skips the NN search, bit 1 the mesh prune
     static const int ablate = getenv("MIDAS_ABLATE") ? atoi(getenv("MIDAS_ABLATE")) : 0;
     a.ablate = ablate;
-    hipLaunchKernelGGL(k_particle_update, dim3((unsigned)particle_update_blocks(a.N), (unsigned)(a.batch > 1 ? a.batch : 1)), dim3(64), 0, ctx->stream,
-                       view_of<Kd6>(t6), view_of<Kd3>(t3), a);
+    const dim3 grid((unsigned)particle_update_blocks(a.N), (unsigned)(a.batch > 1 ? a.batch : 1));
+    if (ablate) hipLaunchKernelGGL(k_particle_update<true>, grid, dim3(64), 0, ctx->stream, view_of<Kd6>(t6), view_of<Kd3>(t3), a);
+    else hipLaunchKernelGGL(k_particle_update<false>, grid, dim3(64), 0, ctx->stream, view_of<Kd6>(t6), view_of<Kd3>(t3), a);
     MIDAS_HIP_CHECK(ctx, hipGetLastError());
     return MIDAS_OK;
 }
@@ -2360,6 +2372,25 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
     const int fw = a.batch > 1 ? 1 : (a.rs.enabled && !wave_tables) ? 4 : fw_env == 1 || fw_env == 4 ? fw_env : (a.sp.stamps ? 1 : 4);
     const int n_pu_fw = (nwaves + fw - 1) / fw;
     const unsigned grid_fw = (unsigned)(n_pu_fw + (a.sp.stamps ? 0 : ceil_div(cb->K, 4 * fw)));
+    // profiling instantiations (MIDAS_ABLATE != 0; D = 512, one-wave workgroups): phase clocks, scan statistics, ablation switches
+    if (a.ablate && cb->D == 512 && fw == 1) {
+        bool done = true;
+        if (a.batch > 1)
+            hipLaunchKernelGGL((k_frame_front<float, 8, 2, 1, false, false, true>), dim3(grid_fw, (unsigned)a.batch), dim3(64), 0, ctx->stream,
+                               view_of<Kd6>(t6), view_of<Kd3>(t3), a, n_pu_fw, nwaves, emb, cb->norms, code, scores, cb->K);
+        else if (!a.rs.enabled)
+            hipLaunchKernelGGL((k_frame_front<float, 8, 0, 1, true, false, true>), dim3(grid_fw), dim3(64), 0, ctx->stream,
+                               view_of<Kd6>(t6), view_of<Kd3>(t3), a, n_pu_fw, nwaves, emb, cb->norms, code, scores, cb->K);
+        else if (wave_tables && a.N <= 131072)
+            hipLaunchKernelGGL((k_frame_front<float, 8, 2, 1, true, true, true>), dim3(grid_fw), dim3(64), 0, ctx->stream,
+                               view_of<Kd6>(t6), view_of<Kd3>(t3), a, n_pu_fw, nwaves, emb, cb->norms, code, scores, cb->K);
+        else done = false;
+        if (done) {
+            MIDAS_HIP_CHECK(ctx, hipGetLastError());
+            *launched = true;
+            return MIDAS_OK;
+        }
+    }
 #define MIDAS_FRONT_L(NJ, LZ, FW)                                                                                     \
     hipLaunchKernelGGL((k_frame_front<float, NJ, LZ, FW>), dim3(grid_fw), dim3(64 * FW), 0, ctx->stream,               \
                        view_of<Kd6>(t6), view_of<Kd3>(t3), a, n_pu_fw, nwaves, emb, cb->norms, code, scores, cb->K)

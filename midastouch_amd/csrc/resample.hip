@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_exp_partial(int64_t N, const double* __
         double e = 0.0;
         if (i < N) {
             const double xi = x[i];
-            e = apply ? exp(xi - mx) : xi;
+            e = apply ? exp_spec(xi - mx) : xi;
             e_out[i] = e;
         }
         v[j] = e;
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void k_tail_a2(int64_t N, const double* __rest
         double e[SCAN_CHUNK];
 #pragma unroll
         for (int k = 0; k < SCAN_CHUNK; ++k) {
-            e[k] = exp(x[k] - 1.0);
+            e[k] = exp_spec(x[k] - 1.0);
             const int64_t i = base + k * 256 + t;
             if (i < N) e_out[i] = e[k];
         }

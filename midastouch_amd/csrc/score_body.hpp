@@ -114,7 +114,7 @@ MD RowClaim claim_rows_issue(const SparseScore& sp, bool want, int32_t row) {
 }
 
 template <int NJ>
-MD void score_claimed_rows(const SparseScore& sp, const RowClaim& c, int32_t row) {
+MD int score_claimed_rows(const SparseScore& sp, const RowClaim& c, int32_t row) {  // returns the rows this wave scored
     constexpr int D = NJ * 64;
     const int lane = threadIdx.x & 63, s = lane & 15, qd = lane >> 4;
     // (after the first waves of a frame nearly every needed row carries the epoch already)
@@ -125,6 +125,7 @@ MD void score_claimed_rows(const SparseScore& sp, const RowClaim& c, int32_t row
     if (c.leader && c.old != sp.epoch) claim = atomicExch(&sp.stamps[row], sp.epoch) != sp.epoch;
 #endif
     unsigned long long m = __ballot(claim);
+    const int nrows = (int)__builtin_popcountll(m);
     while (m) {
         int32_t mine = -1;
 #pragma unroll
@@ -161,14 +162,15 @@ MD void score_claimed_rows(const SparseScore& sp, const RowClaim& c, int32_t row
             sp.scores[mine] = acc / (ne * nrm);
         }
     }
+    return nrows;
 }
 
-MD void score_claimed_rows_nj(const SparseScore& sp, const RowClaim& c, int32_t row) {
+MD int score_claimed_rows_nj(const SparseScore& sp, const RowClaim& c, int32_t row) {
     switch (sp.nj) {
-        case 8: score_claimed_rows<8>(sp, c, row); break;
-        case 4: score_claimed_rows<4>(sp, c, row); break;
-        case 2: score_claimed_rows<2>(sp, c, row); break;
-        default: score_claimed_rows<16>(sp, c, row); break;
+        case 8: return score_claimed_rows<8>(sp, c, row);
+        case 4: return score_claimed_rows<4>(sp, c, row);
+        case 2: return score_claimed_rows<2>(sp, c, row);
+        default: return score_claimed_rows<16>(sp, c, row);
     }
 }
 

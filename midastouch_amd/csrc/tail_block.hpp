@@ -171,7 +171,7 @@ MD void tail_a_direct(int64_t N, int blk, const double* __restrict__ scores, con
     if (need_soft) {
 #pragma unroll
         for (int j = 0; j < SCAN_CHUNK; ++j) {
-            v[j] = exp(v[j] - 1.0);
+            v[j] = exp_spec(v[j] - 1.0);
             __builtin_amdgcn_sched_barrier(0);  // one exponential at a time: sixteen interleaved ones cost ~80 registers
         }
         store_chunk(tb.e, v);

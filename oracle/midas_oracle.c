@@ -530,10 +530,58 @@ MO_API double mo_blocked_scan(int64_t N, const double* w, double* prefix) {
     return BP;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* float64 exponential (spec)                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+/* The softmax numerators exp(x - shift) (modules/particle_filter.py:466-468, torch Softmax) decide the
+ * resample CDF and with it the indices, so the exponential is a SPEC function like the float32 ones
+ * above (a math library's exp differs between libm and the device's in the last place):
+ *   k = rint(x / ln 2); r = x - k ln2_hi - k ln2_lo (two fma steps, fdlibm's split of ln 2);
+ *   exp(r) = Horner of the degree-13 Taylor polynomial in fma steps (|r| <= 0.3466: truncation < 5e-18);
+ *   result = p * 2^(k >> 1) * 2^(k - (k >> 1))  (two exact power-of-two factors: one rounding, also
+ *   in the subnormal range).  x > 709.78... -> +inf, x < -745.14 -> 0, NaN -> NaN.
+ * Within 1 ulp of the correctly rounded value on the arguments the path uses (checked against libm in
+ * tests/test_oracle_math.py). */
+static double mo_pow2i(int k) {  /* 2^k for -1022 <= k <= 1023 */
+    union { uint64_t u; double d; } v;
+    v.u = (uint64_t)(k + 1023) << 52;
+    return v.d;
+}
+MO_API double mo_exp(double x) {
+    if (x != x) return x;
+    if (x > 709.782712893384) return INFINITY;
+    if (x < -745.2) return 0.0;
+    const double INV_LN2 = 1.44269504088896338700e+00;
+    const double LN2_HI = 6.93147180369123816490e-01;
+    const double LN2_LO = 1.90821492927058770002e-10;
+    const double kf = rint(x * INV_LN2);
+    double r = fma(-kf, LN2_HI, x);
+    r = fma(-kf, LN2_LO, r);
+    double p = 1.6059043836821613e-10;          /* 1/13! */
+    p = fma(p, r, 2.08767569878681e-09);        /* 1/12! */
+    p = fma(p, r, 2.505210838544172e-08);       /* 1/11! */
+    p = fma(p, r, 2.755731922398589e-07);       /* 1/10! */
+    p = fma(p, r, 2.7557319223985893e-06);      /* 1/9!  */
+    p = fma(p, r, 2.48015873015873e-05);        /* 1/8!  */
+    p = fma(p, r, 1.984126984126984e-04);       /* 1/7!  */
+    p = fma(p, r, 1.388888888888889e-03);       /* 1/6!  */
+    p = fma(p, r, 8.333333333333333e-03);       /* 1/5!  */
+    p = fma(p, r, 4.1666666666666664e-02);      /* 1/4!  */
+    p = fma(p, r, 1.6666666666666666e-01);      /* 1/3!  */
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const int k = (int)kf, k1 = k >> 1, k2 = k - k1;
+    return (p * mo_pow2i(k1)) * mo_pow2i(k2);
+}
+MO_API void mo_exp_vec(int64_t N, const double* x, double shift, double* out) {
+    for (int64_t i = 0; i < N; ++i) out[i] = mo_exp(x[i] - shift);
+}
+
 /*
  * weights -> softmax.  get_similarity tail (particle_filter.py:459-468):
  * if |max-min| <= 1e-8 (torch.isclose(.., 0) with default atol) or !softmax -> copy x;
- * else w = exp(x - max) / blocked_sum(exp(x - max)).
+ * else w = mo_exp(x - max) / blocked_sum(mo_exp(x - max)).
  * returns 1 when softmax was applied.
  */
 MO_API int mo_softmax(int64_t N, const double* x, int softmax, double* w) {
@@ -547,7 +595,7 @@ MO_API int mo_softmax(int64_t N, const double* x, int softmax, double* w) {
         if (w != x) memcpy(w, x, (size_t)N * sizeof(double));
         return 0;
     }
-    for (int64_t i = 0; i < N; ++i) w[i] = exp(x[i] - mx);
+    for (int64_t i = 0; i < N; ++i) w[i] = mo_exp(x[i] - mx);
     double S = mo_blocked_scan(N, w, NULL);
     for (int64_t i = 0; i < N; ++i) w[i] = w[i] / S;
     return 1;

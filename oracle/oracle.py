@@ -45,6 +45,8 @@ def lib():
         _lib.mo_blocked_scan.restype = C.c_double
         _lib.mo_softmax.restype = C.c_int
         _lib.mo_cdf.restype = C.c_int
+        _lib.mo_exp.restype = C.c_double
+        _lib.mo_exp.argtypes = [C.c_double]
     return _lib
 
 
@@ -206,20 +208,31 @@ def softmax_weights(x, softmax: bool = True):
     return w, bool(applied)
 
 
-def softmax_numerators(x, softmax: bool = True, shift=None):
-    """e = exp(x - shift) (libm exp), or x itself when the softmax is skipped; returns (e, applied).
+def softmax_numerators(x, softmax: bool = True, shift=None, exp: str = "spec"):
+    """e = exp(x - shift) (the spec exponential mo_exp; exp="libm": the C library's, for the mismatch probes), or x itself
+    when the softmax is skipped; returns (e, applied).
 
     shift None -> max(x) (torch's Softmax).  The fused step uses the constant shift 1.0: the scores are
     cosines (<= 1), the softmax is shift-invariant, and a constant lets every particle take its exponential
     without waiting for a global maximum (csrc/particles.hip k_particle_update)."""
-    import math
     x = _f64(x).ravel()
     mx, mn = float(np.max(x)), float(np.min(x))
     applied = bool(softmax) and not (abs(mx - mn) <= 1e-8)
     if not applied:
         return x.copy(), False
     c = mx if shift is None else float(shift)
-    return np.array([math.exp(v) for v in (x - c)], dtype=np.float64), True
+    if exp == "libm":
+        import math
+        return np.array([math.exp(v) for v in (x - c)], dtype=np.float64), True
+    return exp_spec(x, c), True
+
+
+def exp_spec(x, shift: float = 0.0):
+    """mo_exp(x - shift) elementwise: the float64 exponential of the arithmetic spec (midas_math.hpp exp_spec on the device)."""
+    x = _f64(x).ravel()
+    out = np.empty_like(x)
+    lib().mo_exp_vec(C.c_int64(x.shape[0]), _p(x), C.c_double(float(shift)), _p(out))
+    return out
 
 
 def get_similarity(code, targets, softmax: bool = True):

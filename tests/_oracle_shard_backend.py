@@ -65,7 +65,7 @@ class OracleShardBackend:
         nb = st.nb
         te, tx, tlp, tlpr = self._views(st)
         x = st.scores.numpy()[st.nn_idx.numpy()]
-        e = np.array([math.exp(v) for v in (x - 1.0)])  # glibc exp, constant shift 1
+        e = orc.exp_spec(x, 1.0)  # the spec exponential, constant shift 1
         valid = st.valid.numpy().astype(bool)
         te.copy_(torch.as_tensor(e))
         tx.copy_(torch.as_tensor(x))

@@ -33,6 +33,27 @@ def test_sincos_atan2_log_accuracy(oracle):
     assert np.max(np.abs(lg - np.log(v.astype(np.float64))) / np.maximum(1.0, np.abs(np.log(v.astype(np.float64))))) < 3e-7
 
 
+def test_exp_spec_accuracy_and_edges(oracle):
+    """mo_exp, the float64 exponential of the softmax numerators (modules/particle_filter.py:466-468 through torch's
+    Softmax): within 1 ulp of the C library's over the path's range and over the whole finite range, exact edge cases."""
+    import math
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-2.0, 0.0, 100000), rng.uniform(-745.0, 709.0, 100000), rng.standard_normal(20000) * 1e-3])
+    e = oracle.exp_spec(x)
+    ref = np.array([math.exp(v) for v in x])
+    ulp = np.spacing(ref)
+    assert np.max(np.abs(e - ref) / ulp) <= 1.0
+    assert np.mean(e == ref) > 0.9  # mostly the correctly rounded value
+    assert np.all(np.diff(oracle.exp_spec(np.sort(x))) >= 0)  # monotone on the sample
+    edge = np.array([0.0, -0.0, 1.0, 709.782712893384, 709.79, -745.3, np.inf, -np.inf, -745.1, 5e-324])
+    out = oracle.exp_spec(edge)
+    assert out[0] == 1.0 and out[1] == 1.0 and out[2] == math.e and out[3] == math.exp(709.782712893384)
+    assert out[4] == np.inf and out[5] == 0.0 and out[6] == np.inf and out[7] == 0.0 and out[8] == 5e-324 and out[9] == 1.0
+    assert np.isnan(oracle.exp_spec(np.array([np.nan]))[0])
+    # the shift argument: exp(x - shift), one subtraction before the reduction
+    assert np.array_equal(oracle.exp_spec(x[:1000], 1.0), oracle.exp_spec(x[:1000] - 1.0))
+
+
 def test_so3_log_vs_scipy(oracle):
     rng = np.random.default_rng(1)
     rv = rng.standard_normal((5000, 3))
