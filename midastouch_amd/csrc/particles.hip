@@ -703,13 +703,30 @@ MD void nn6_hint_batch(const float4* __restrict__ nb4, int s0, const float* q, i
     certified = g > 0.0f && g * g * 0.99997f > best;
 }
 
-MD bool nn6_hint_scan_screened(const TreeView<Kd6>& tv, const float* q, int32_t h, float& best, int64_t& bi, int* n_scanned,
+// Pivot switch across the rotation-angle-pi cut.  The feature's rotation part is 0.01 log(R): a particle whose rotation angle
+// passes pi reappears 2 pi 0.01 = 63 mm-equivalents away from its ancestor's nearest entry, and no list of that entry can
+// certify anything for it - the lane would walk all NBR_M records (eight cooperative passes of cold fetches) before the
+// twin entry gets its turn.  With uniformly distributed yaws about 0.5 % of the particles of a spread cloud cross the cut in a
+// frame, i.e. every second wave has such a lane and ends 30 us after the others (phase clocks of the diffuse regime,
+// profiles/r03_diffuse_*).  So: a lane that finds itself farther than FLIP_R from the hinted entry (nothing near an entry is:
+// codebook spacings are millimetres) continues from the entry's TWIN - the entry nearest to the hinted one's image across the
+// cut - whose index travels with the first batch.  Any pivot is a correct pivot (the certificate is relative to the list
+// scanned, the continuation and the tree search stay behind it), so this changes which records are read, never the answer.
+constexpr float FLIP_R = 0.02f;
+MD bool nn6_hint_scan_screened(const TreeView<Kd6>& tv, const float* q, int32_t& h, float& best, int64_t& bi, int* n_scanned,
                                float* r_out = nullptr) {
     const float4* __restrict__ nb4 = reinterpret_cast<const float4*>(tv.nbrs + (size_t)h * NBR_REC);
     float r = 0.f, rslack = 0.f;
     int scanned = 0;
     bool certified = false;
+    const int32_t tw = tv.twin[h];  // with the first batch: behind it, it would be a round trip of its own
     nn6_hint_batch<true>(nb4, 0, q, h, best, bi, r, rslack, scanned, certified);
+    if (!certified && r > FLIP_R && tw >= 0) {
+        h = tw;
+        nb4 = reinterpret_cast<const float4*>(tv.nbrs + (size_t)h * NBR_REC);
+        scanned = 0;
+        nn6_hint_batch<true>(nb4, 0, q, h, best, bi, r, rslack, scanned, certified);
+    }
 #pragma unroll 1
     for (int s0 = NN_BATCH; s0 < NN_SOLO && !certified; s0 += NN_BATCH)
         nn6_hint_batch<false>(nb4, s0, q, h, best, bi, r, rslack, scanned, certified);
@@ -738,8 +755,17 @@ MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t& h, float
     int b32 = h;  // record 0 overwrites the incoming candidate; list indices are int32
     bool certified = false;
     int hops = 0;
+    int32_t tw = tv.twin[h];  // pivot switch across the angle-pi cut (see nn6_hint_scan_screened); once
 #pragma unroll 1
     for (int s0 = 0; s0 < NN_SOLO && !certified; s0 += NN_BATCH) {
+        if (s0 == NN_BATCH && r > FLIP_R && tw >= 0) {  // far from the hinted entry: its twin's list from the start
+            h = tw;
+            tw = -1;
+            b32 = h;
+            nb = tv.nbrs + (size_t)h * NBR_REC;
+            s0 = 0;
+            scanned = 0;
+        }
         if (MIDAS_NN_HOPS > 0 && s0 == NN_BATCH && hops < MIDAS_NN_HOPS && b32 != h) {  // a closer pivot: its list from the start
             h = b32;
             nb = tv.nbrs + (size_t)h * NBR_REC;
@@ -1301,7 +1327,7 @@ MD bool nn6_wave(const TreeView<Kd6>& tv, const float* q, bool live, int32_t hin
     bool done = !live;
     const bool hinted = live && hint >= 0 && (int64_t)hint < tv.K;
     float r_lane = 0.f;
-    if (hinted)  // records 0 .. NN_SOLO-1, per lane
+    if (hinted)  // records 0 .. NN_SOLO-1, per lane; `hint` comes back as the pivot whose list was scanned
         done = SCREEN ? nn6_hint_scan_screened(tv, q, hint, best, bi, n_scanned, &r_lane)
                       : nn6_hint_scan(tv, q, hint, best, bi, n_scanned, &r_lane);
     if (t_solo) *t_solo = clock64();
@@ -2047,19 +2073,22 @@ __global__ __launch_bounds__(256, MIDAS_NNP_OCC) void k_particle_nn_prune(TreeVi
     const float4* fp = reinterpret_cast<const float4*>(feat + pc);
     const float4 f0 = fp[0], f1 = fp[1];
     const float q[6] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y};
-    const int32_t hint = live ? __float_as_int(f1.z) : -1;
+    int32_t hint = live ? __float_as_int(f1.z) : -1;
     // ---- nearest codebook entry: the solo records of the hinted entry's list ----
     float best = INFINITY, r_lane = 0.f;
     int64_t bi = 0;
     bool done = !live;
     const bool hinted = live && hint >= 0 && (int64_t)hint < t6.K;
-    const Nbr6* nb = t6.nbrs + (size_t)(hinted ? hint : 0) * NBR_REC;
+    int32_t piv = hinted ? hint : 0;  // the entry whose list is scanned: the hint, or its twin across the angle-pi cut
+    int32_t tw = t6.twin[piv];        // (see nn6_hint_scan_screened: a particle far from the hinted entry has crossed the cut)
+    const Nbr6* nb = t6.nbrs + (size_t)piv * NBR_REC;
+    int pass = 0;                     // group-uniform: the group's next batch of 8 LPP records
 #pragma unroll 1
-    for (int pass = 0; pass < NN_PASSES; ++pass) {
-        if (pass > 0 && !__any(hinted && !done)) break;
+    while (__any(hinted && !done && pass < NN_PASSES)) {
+        const int pc_ = pass < NN_PASSES ? pass : NN_PASSES - 1;  // finished groups re-read their last batch (unused)
         Nbr6 e[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = nb[pass * 8 * LPP + LPP * j + g];
+        for (int j = 0; j < 8; ++j) e[j] = nb[pc_ * 8 * LPP + LPP * j + g];
         float d0 = 0.f, ld = INFINITY;
         int li = 0x7fffffff;
 #pragma unroll
@@ -2083,10 +2112,11 @@ __global__ __launch_bounds__(256, MIDAS_NNP_OCC) void k_particle_nn_prune(TreeVi
 #undef MIDAS_GSTEP
         d0 = dpp_f32<BC_FIRST>(d0);
         const float rho_last = dpp_f32<BC_LAST>(e[7].rho);  // the largest rho fetched so far
-        if (hinted && !done) {
+        bool flip = false;
+        if (hinted && !done && pass < NN_PASSES) {
             if (pass == 0) {
                 best = d0;  // a NaN distance stays, as in the serial scan
-                bi = hint;
+                bi = piv;
                 r_lane = __builtin_sqrtf(d0);
             }
             if (ld < best || (ld == best && (int64_t)li < bi)) { best = ld; bi = li; }
@@ -2094,8 +2124,17 @@ __global__ __launch_bounds__(256, MIDAS_NNP_OCC) void k_particle_nn_prune(TreeVi
             // of r and rho, as in nn6_hint_scan): nothing unseen can beat or tie the best
             const float gg = fmaf_(rho_last - r_lane, 0.9999996f, -8e-7f * r_lane);
             done = gg > 0.0f && gg * gg * 0.99997f > best;
+            flip = pass == 0 && !done && r_lane > FLIP_R && tw >= 0;
+        }
+        if (flip) {  // the twin's list from its start (once: tw = -1)
+            piv = tw;
+            tw = -1;
+            nb = t6.nbrs + (size_t)piv * NBR_REC;
+        } else {
+            ++pass;
         }
     }
+    hint = hinted ? piv : hint;
     nn6_coop(t6, q, hint, r_lane, best, bi, owner && hinted && !done, done);  // the rest of the list, owners = first lanes
     const bool fb = owner && live && !done;
     wave_search<Kd6, false>(t6, q, best, bi, fb, reinterpret_cast<float*>(s_cd[w]));

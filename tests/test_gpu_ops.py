@@ -101,6 +101,43 @@ def test_nn6_exact(dev, ops, oracle, cb):
     assert np.array_equal(idx2.cpu().numpy(), ref_idx)
 
 
+def test_nn6_pivot_switch_across_pi_cut(dev, ops, oracle):
+    """Particles whose rotation angle passes pi reappear 63 mm-equivalents away from their ancestor's nearest entry in the
+    feature space of R3_SE3 (tactile_tree/tactile_tree.py:73-77: 0.01 log R flips sign at the cut).  The hinted scan
+    continues from the hinted entry's twin: same exact answer as the brute force, and neither the whole 512-record list
+    nor the tree search is needed for them (what made the frames after a wide start slow)."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(31)
+    K = 6000
+    ax = rng.standard_normal((K, 3))
+    ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+    ang = np.where(rng.random(K) < 0.5, np.pi - rng.uniform(0, 0.3, K), rng.uniform(0, np.pi, K))
+    P = np.zeros((K, 4, 4), dtype=np.float32)
+    P[:, :3, :3] = Rotation.from_rotvec(ax * ang[:, None]).as_matrix()
+    P[:, :3, 3] = rng.uniform(-0.02, 0.02, (K, 3))
+    P[:, 3, 3] = 1
+    feat = oracle.R3_SE3(P)
+    tree = ops.Tree(T(feat, dev))
+    src = np.flatnonzero(ang > np.pi - 0.03)
+    src = np.concatenate([src, rng.integers(0, K, 2000)])
+    Q = P[src].copy()
+    dR = Rotation.from_rotvec(rng.standard_normal((len(src), 3)) * 0.02).as_matrix().astype(np.float32)
+    Q[:, :3, :3] = Q[:, :3, :3] @ dR
+    Q[:, :3, 3] += (rng.standard_normal((len(src), 3)) * 2e-4).astype(np.float32)
+    q = oracle.R3_SE3(Q)
+    ref, _ = oracle.nn6(q, feat)
+    far = np.linalg.norm(q - feat[src], axis=1) > 0.02  # crossed the cut: far from the hinted entry
+    assert far.sum() > 20
+    idx = ops.nn6(tree, T(q, dev), hint=T(src.astype(np.int32), dev))
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    leaves, nodes = ops.nn6_stats(tree, T(q, dev), T(src.astype(np.int32), dev))
+    leaves, nodes = leaves.cpu().numpy(), nodes.cpu().numpy()
+    assert np.all(leaves[far] == 0), "cut-crossing particles fell back to the tree search"
+    # nodes = -(1 + records scanned by the lane itself) for lanes the solo scan certified (at most NN_SOLO = 32 records)
+    solo = nodes[far] < 0
+    assert solo.mean() > 0.9, "cut-crossing particles should certify from the twin's first records"
+
+
 def test_nn6_ties_and_small_trees(dev, ops, oracle):
     rng = np.random.default_rng(11)
     for K in (1, 2, 7, 8, 9, 17, 100):
