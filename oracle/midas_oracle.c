@@ -421,42 +421,67 @@ MO_API void mo_nn3(int64_t N, int64_t M, const float* poses, const double* verts
 /* ------------------------------------------------------------------------------------------ */
 /* cosine scores of one tactile code against every codebook row                               */
 /* ------------------------------------------------------------------------------------------ */
-/* s_k = <e, C_k> / (max(|e|,eps) * max(|C_k|,eps)), eps = 1e-8, float64 accumulation. */
-MO_API void mo_score_f32(int64_t K, int64_t D, const float* emb, const double* code, double* scores) {
-    double ne = 0.0;
-    for (int64_t j = 0; j < D; ++j) ne += code[j] * code[j];
-    ne = sqrt(ne);
-    if (ne < 1e-8) ne = 1e-8;
-    for (int64_t k = 0; k < K; ++k) {
-        const float* row = emb + k * D;
-        double dot = 0.0, nr = 0.0;
-        for (int64_t j = 0; j < D; ++j) {
-            double v = (double)row[j];
-            dot += v * code[j];
-            nr += v * v;
-        }
-        nr = sqrt(nr);
-        if (nr < 1e-8) nr = 1e-8;
-        scores[k] = dot / (ne * nr);
+/* s_k = <e, C_k> / (max(|e|,eps) * max(|C_k|,eps)), eps = 1e-8, float64 accumulation (cosine_similarity,
+ * modules/particle_filter.py:455-457).  SUMMATION ORDER (spec; csrc/score_body.hpp score_wave / score_claimed_rows and
+ * csrc/score.hip k_score_generic state the same): the D products are dealt to 16 partial sums - for D in {128, 256,
+ * 512, 1024} partial s takes elements 64 j + 4 s + c (j ascending, c = 0..3), for any other D elements s, s + 16, ... -
+ * each a sequential fma chain from +0.0; the 16 partials are then added as a balanced tree in the order of an
+ * xor-butterfly (offsets 8, 4, 2, 1).  |e|^2 and |C_k|^2 are summed the same way.  With the order fixed the scores -
+ * and through the softmax numerators the resample CDF - are bit-identical between this oracle and the kernels. */
+static double mo_quarter_tree(const double* a) {
+    double b[16], c[16], d[16];
+    for (int s = 0; s < 16; ++s) b[s] = a[s] + a[s ^ 8];
+    for (int s = 0; s < 16; ++s) c[s] = b[s] + b[s ^ 4];
+    for (int s = 0; s < 16; ++s) d[s] = c[s] + c[s ^ 2];
+    return d[0] + d[1];
+}
+static int mo_score_reg_layout(int64_t D) { return D == 128 || D == 256 || D == 512 || D == 1024; }
+/* element index of the t-th term of partial s, or -1 past the end */
+static int64_t mo_score_elem(int64_t D, int reg, int s, int64_t t) {
+    const int64_t d = reg ? 64 * (t / 4) + 4 * s + (t % 4) : s + 16 * t;
+    return d < D ? d : -1;
+}
+#define MO_SCORE_BODY(ROWTYPE)                                                                      \
+    const int reg = mo_score_reg_layout(D);                                                         \
+    const int64_t nt = reg ? D / 16 : (D + 15) / 16;                                                \
+    double pe[16];                                                                                  \
+    for (int s = 0; s < 16; ++s) {                                                                  \
+        double acc = 0.0;                                                                           \
+        for (int64_t t = 0; t < nt; ++t) {                                                          \
+            const int64_t d = mo_score_elem(D, reg, s, t);                                          \
+            if (d >= 0) acc = fma(code[d], code[d], acc);                                           \
+        }                                                                                           \
+        pe[s] = acc;                                                                                \
+    }                                                                                               \
+    double ne = sqrt(mo_quarter_tree(pe));                                                          \
+    if (ne < 1e-8) ne = 1e-8;                                                                       \
+    for (int64_t k = 0; k < K; ++k) {                                                               \
+        const ROWTYPE* row = emb + k * D;                                                           \
+        double pd[16], pn[16];                                                                      \
+        for (int s = 0; s < 16; ++s) {                                                              \
+            double dot = 0.0, nr = 0.0;                                                             \
+            for (int64_t t = 0; t < nt; ++t) {                                                      \
+                const int64_t d = mo_score_elem(D, reg, s, t);                                      \
+                if (d >= 0) {                                                                       \
+                    const double v = (double)row[d];                                                \
+                    dot = fma(v, code[d], dot);                                                     \
+                    nr = fma(v, v, nr);                                                             \
+                }                                                                                   \
+            }                                                                                       \
+            pd[s] = dot;                                                                            \
+            pn[s] = nr;                                                                             \
+        }                                                                                           \
+        double nr = sqrt(mo_quarter_tree(pn));                                                      \
+        if (nr < 1e-8) nr = 1e-8;                                                                   \
+        scores[k] = mo_quarter_tree(pd) / (ne * nr);                                                \
     }
+
+MO_API void mo_score_f32(int64_t K, int64_t D, const float* emb, const double* code, double* scores) {
+    MO_SCORE_BODY(float)
 }
 
 MO_API void mo_score_f64(int64_t K, int64_t D, const double* emb, const double* code, double* scores) {
-    double ne = 0.0;
-    for (int64_t j = 0; j < D; ++j) ne += code[j] * code[j];
-    ne = sqrt(ne);
-    if (ne < 1e-8) ne = 1e-8;
-    for (int64_t k = 0; k < K; ++k) {
-        const double* row = emb + k * D;
-        double dot = 0.0, nr = 0.0;
-        for (int64_t j = 0; j < D; ++j) {
-            dot += row[j] * code[j];
-            nr += row[j] * row[j];
-        }
-        nr = sqrt(nr);
-        if (nr < 1e-8) nr = 1e-8;
-        scores[k] = dot / (ne * nr);
-    }
+    MO_SCORE_BODY(double)
 }
 
 /*
