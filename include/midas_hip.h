@@ -264,6 +264,15 @@ typedef struct midas_lazy_args {
     double* rmse_dev;                  /* NULL or 3 out (needs gt16_dev, part_rmse_dev): this frame's {rmse_t, rmse_r, device clock
                                         * in us} - particle_rmse is taken on the propagated particles (filter.py:164), so the
                                         * frame's own statistics exist without materialising its resample */
+    int32_t* score_list_dev;           /* NULL or 2 + 2 K int32, zero-initialised by the caller: prediction lists of the sparse
+                                        * scoring (single trajectory).  [0], [1] = the two lists' lengths, then two lists of K
+                                        * rows.  The frame with score_epoch e scores list (e >> 1) & 1 - the rows the frame
+                                        * before it used, stamped e - 1 by that frame's tail - with streaming workgroups of its
+                                        * front launch, and its own tail writes the other list.  With a list the caller advances
+                                        * score_epoch by TWO per frame (midas_lazy_run does) and zeroes the two lengths whenever it
+                                        * zeroes the stamps.  Same scores as without (which rows are scored by whom is all
+                                        * that changes); replaces nothing in the reference - it gathers all N rows every frame
+                                        * (tactile_tree/tactile_tree.py:54-58) */
 } midas_lazy_args;
 int midas_lazy_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
                     const midas_lazy_args* args);

@@ -92,7 +92,7 @@ class LazyArgs(C.Structure):
         ("odom16", C.c_void_p), ("code", C.c_void_p), ("gt16", C.c_void_p), ("tn", C.c_void_p), ("rot", C.c_void_p),
         ("std_t", C.c_float), ("std_r", C.c_float), ("seed", C.c_uint64), ("step", C.c_uint64),
         ("prune_thr", C.c_double), ("softmax", C.c_int32), ("telemetry", C.c_void_p),
-        ("score_stamps", C.c_void_p), ("score_epoch", C.c_uint32), ("rmse", C.c_void_p),
+        ("score_stamps", C.c_void_p), ("score_epoch", C.c_uint32), ("rmse", C.c_void_p), ("score_list", C.c_void_p),
     ]
 
 

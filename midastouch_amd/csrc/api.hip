@@ -632,7 +632,11 @@ MIDAS_EXPORT int midas_lazy_run(midas_ctx* ctx, const midas_codebook* cb, const 
         a.u32_prev = -1.0f;
         a.step_prev = a.step;
         a.step += 1;
-        if (a.score_stamps_dev) a.score_epoch = a.score_epoch + 1 ? a.score_epoch + 1 : 1;  // never 0
+        if (a.score_stamps_dev) {  // never 0; two per frame with a prediction list (the tag between two epochs marks its rows)
+            const uint32_t inc = a.score_list_dev ? 2u : 1u;
+            MIDAS_REQUIRE(ctx, a.score_epoch < 0xFFFFFFF0u - inc);  // the caller restarts the epochs (and zeroes the stamps) long before
+            a.score_epoch += inc;
+        }
         a.odom16_dev += 16;
         a.code_dev += cb->D;
         if (a.gt16_dev) a.gt16_dev += 16;
@@ -678,6 +682,19 @@ static int lazy_step_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_
     pa.gt16 = (s.gt16_dev && s.part_rmse_dev) ? s.gt16_dev : nullptr;
     pa.part_rmse = s.part_rmse_dev;
     if (s.score_stamps_dev && s.score_epoch) { pa.sp.stamps = s.score_stamps_dev; pa.sp.epoch = s.score_epoch; }
+    ScorePredict predict;
+    if (pa.sp.stamps && s.score_list_dev && B == 1 && s.score_epoch >= 2 && N >= SCAN_CHUNK) {
+        const int par = (int)((s.score_epoch >> 1) & 1u);
+        int32_t* base = s.score_list_dev;
+        pa.sp.pred_tag = s.score_epoch - 1u;
+        pa.sp.list_count = base + par;
+        pa.sp.list = base + 2 + (int64_t)par * cb->K;
+        pa.sp.list_cap = (int32_t)(cb->K < 0x7fffffff ? cb->K : 0x7fffffff);
+        pa.sp.next_count = base + (par ^ 1);
+        predict.stamps = s.score_stamps_dev; predict.epoch = s.score_epoch; predict.K = cb->K;
+        predict.count = base + (par ^ 1);
+        predict.list = base + 2 + (int64_t)(par ^ 1) * cb->K;
+    }
     if (s.resample_prev) {
         LazyResample& r = pa.rs;
         r.enabled = true;
@@ -712,7 +729,7 @@ static int lazy_step_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_
     }
     prof_mark(ctx, 2);
     if ((rc = launch_tail_a2(ctx, N, s.scores_dev, s.nn_idx_dev, s.valid_dev, s.softmax, tb, s.status_dev, B, cb->K, true,
-                             pa.gt16 ? s.part_rmse_dev : nullptr, rmse_out, B > 1 ? tstride : 0)))
+                             pa.gt16 ? s.part_rmse_dev : nullptr, rmse_out, B > 1 ? tstride : 0, predict.stamps ? &predict : nullptr)))
         return rc;
     prof_mark(ctx, 3);
     if (ctx->prof && ctx->ev_ready) {

@@ -208,6 +208,22 @@ struct SparseScore {
     const double* code = nullptr;
     double* scores = nullptr;
     int nj = 0;                   // D / 64
+    // prediction list (single-trajectory fused front): the rows the previous frame used, listed and stamped `pred_tag`
+    // (= epoch - 1) by that frame's tail kernel; scored by streaming waves of the front launch (score_list_wave)
+    uint32_t pred_tag = 0;              // 0: no prediction in this launch (every stamp other than `epoch` is stale)
+    const int32_t* list = nullptr;      // [list_cap]
+    const int32_t* list_count = nullptr;
+    int32_t* next_count = nullptr;      // the other list's counter, zeroed by the front for this frame's tail
+    int32_t list_cap = 0;
+};
+// what the tail kernel needs to build the next frame's list: rows whose stamp is `epoch` (claimed or confirmed in this
+// frame) are appended to `list` and re-stamped epoch + 1, the next frame's pred_tag (its epoch is epoch + 2)
+struct ScorePredict {
+    uint32_t* stamps = nullptr;
+    uint32_t epoch = 0;
+    int64_t K = 0;
+    int32_t* list = nullptr;
+    int32_t* count = nullptr;
 };
 
 struct ParticleUpdateArgs {
@@ -306,7 +322,8 @@ struct TailTables {
 };
 int launch_tail_a2(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
                    int32_t softmax, const TailTables& tb, int32_t* status, int batch = 1, int64_t score_stride = 0,
-                   bool padded_tables = false, const double* part_rmse = nullptr, double* rmse_out = nullptr, int64_t tstride = 0);  // padded: per-slot tables hold a multiple of 16 values (tables_of, api.hip)
+                   bool padded_tables = false, const double* part_rmse = nullptr, double* rmse_out = nullptr, int64_t tstride = 0,
+                   const ScorePredict* predict = nullptr);  // padded: per-slot tables hold a multiple of 16 values (tables_of, api.hip)
 int launch_tail_b2(midas_ctx* ctx, const StepTailArgs& a, const TailTables& tb);  // a.x, a.e, a.cdf, a.lp_raw unused
 int launch_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
                         int32_t softmax, const TailTables& tb, double* r1, int32_t* status);

@@ -1740,6 +1740,7 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
     if (wave == 0 && lane == 0) {
         if (a.status_reset) { a.status_reset[0] = 0; a.status_reset[1] = 0; }
         if (a.flags_reset) { a.flags_reset[0] = 0.0; a.flags_reset[1] = 0.0; }
+        if (a.sp.next_count) *a.sp.next_count = 0;  // this frame's tail appends the next frame's prediction list
     }
     unsigned long long st_nn = 0, st_mesh = 0, st_scan = 0;
     int st_rows = 0;
@@ -1960,6 +1961,8 @@ __global__ __launch_bounds__(64 * FW, (!SCR && FW == 1) ? MIDAS_BATCH_OCC : 1) v
             if (LAZY == 2) particle_update_wave<true, SCREEN, PREF, STATS>(t6, t3, a, wave, nwaves, traj, s_cd[w], s_rs + w * LAZY_WAVE_LDS);
             else particle_update_wave<false, SCREEN, PREF, STATS>(t6, t3, a, wave, nwaves, traj, s_cd[w], LAZY ? s_rs : nullptr);
         }
+    } else if (a.sp.list) {  // prediction list: the rows the previous frame used, four per wave-instruction
+        score_list_wave<NJ>(a.sp, (int)(bx - n_pu) * FW + w, ((int)gridDim.x - n_pu) * FW);
     } else {
         score_wave<T, NJ, 0>(emb, norms, code, scores, K, (int64_t)(bx - n_pu) * FW + w);
     }
@@ -2359,6 +2362,10 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
     if (a.sp.stamps) {  // sparse scoring: the particle waves score the rows they need, no streaming workgroups
         a.sp.emb = (const float*)cb->emb; a.sp.norms = cb->norms; a.sp.code = code; a.sp.scores = scores; a.sp.nj = cb->D / 64;
     }
+    // prediction list: scored by streaming workgroups of the single-kernel form only; elsewhere the tags are not honoured
+    // (a row stamped pred_tag is then simply stale and gets claimed: same scores)
+    static const int list_wgs_env = getenv("MIDAS_LIST_WAVES") ? atoi(getenv("MIDAS_LIST_WAVES")) : 1024;
+    const bool use_list = a.sp.stamps && a.sp.list && a.batch <= 1 && list_wgs_env > 0;
     const unsigned grid = (unsigned)(n_pu + (a.sp.stamps ? 0 : ceil_div(cb->K, 16)));
     const float* emb = (const float*)cb->emb;
     // Two-kernel form (group-parallel list scans, see k_particle_nn_prune) for small particle sets (round 1's rule was "while
@@ -2376,6 +2383,7 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
     const bool split_front = a.batch <= 1 && (split_env >= 2 || (split_env == 1 && ((a.rs.enabled && a.N <= 10240) || a.N <= 2048 || a.n_live)));
     const int lpp = split_env == 3 ? 2 : 4;
     if (split_front && !(a.ablate & 7)) {
+        a.sp.pred_tag = 0; a.sp.list = nullptr;  // (next_count stays: the tail appends whatever form the front had)
         void* feat;
         int rc = midas_scratch(ctx, (size_t)a.N * sizeof(PuFeat), &feat);
         if (rc) return rc;
@@ -2410,7 +2418,8 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
     const bool wave_tables = a.rs.enabled && a.rs.nb <= LAZY_WAVE_LD && wt_env != 0;
     const int fw = a.batch > 1 ? 1 : (a.rs.enabled && !wave_tables) ? 4 : fw_env == 1 || fw_env == 4 ? fw_env : (a.sp.stamps ? 1 : 4);
     const int n_pu_fw = (nwaves + fw - 1) / fw;
-    const unsigned grid_fw = (unsigned)(n_pu_fw + (a.sp.stamps ? 0 : ceil_div(cb->K, 4 * fw)));
+    if (!use_list) { a.sp.pred_tag = 0; a.sp.list = nullptr; }
+    const unsigned grid_fw = (unsigned)(n_pu_fw + (a.sp.stamps ? (use_list ? (list_wgs_env + fw - 1) / fw : 0) : ceil_div(cb->K, 4 * fw)));
     // profiling instantiations (MIDAS_ABLATE != 0; D = 512, one-wave workgroups): phase clocks, scan statistics, ablation switches
     if (a.ablate && cb->D == 512 && fw == 1) {
         bool done = true;

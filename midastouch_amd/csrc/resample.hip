@@ -500,13 +500,61 @@ __global__ __launch_bounds__(256) void k_tail_a2(int64_t N, const double* __rest
 // k_tail_a2 in the chunk-per-thread view (tail_block.hpp): every thread reads and writes its own 16-slot chunk from one
 // address, nothing goes through LDS.  Same outputs, 5.5 us instead of 8.0 at N = 100k (two barriers and two LDS round
 // trips fewer on a latency-bound kernel).  Single trajectory, N >= 16; MIDAS_TAIL_DIRECT=0 selects k_tail_a2.
+// Extra workgroups of the tail (blockIdx.x >= nb): the prediction list of the NEXT frame's sparse scoring.  Every row whose
+// stamp is this frame's epoch was somebody's nearest entry in this frame (claimed by its first particle, or confirmed from
+// the previous list): it goes on the list - order is immaterial, one counter bump per wave - and is re-stamped epoch + 1,
+// the tag the next front (epoch + 2) honours as "being scored by my streaming waves".  A cloud moves a fraction of the
+// codebook's spacing per frame, so most of the rows it needs were needed the frame before: they are then scored by
+// balanced, coalesced streaming waves instead of by whichever particle wave touches them first (in the frames after a
+// wide start a wave claimed up to 64 rows = 16 rounds of cold 8 KB fetches, and the kernel ends with its slowest wave).
+constexpr int PREDICT_PER_THREAD = 4;
+MD void predict_scan(const ScorePredict& pr, int blk) {
+    const int lane = threadIdx.x & 63;
+    const int64_t k0 = ((int64_t)blk * 256 + threadIdx.x) * PREDICT_PER_THREAD;
+    uint32_t st[PREDICT_PER_THREAD];
+    if (k0 + PREDICT_PER_THREAD <= pr.K) {
+        const uint4 v = *reinterpret_cast<const uint4*>(pr.stamps + k0);
+        st[0] = v.x; st[1] = v.y; st[2] = v.z; st[3] = v.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < PREDICT_PER_THREAD; ++j) st[j] = k0 + j < pr.K ? pr.stamps[k0 + j] : 0u;
+    }
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < PREDICT_PER_THREAD; ++j) n += (k0 + j < pr.K && st[j] == pr.epoch) ? 1 : 0;
+    // exclusive prefix of n over the wave, one counter bump per wave
+    int incl = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    const int total = __shfl(incl, 63);
+    if (total == 0) return;
+    int base = 0;
+    if (lane == 63) base = atomicAdd(pr.count, total);
+    base = __shfl(base, 63);
+    int pos = base + incl - n;
+#pragma unroll
+    for (int j = 0; j < PREDICT_PER_THREAD; ++j)
+        if (k0 + j < pr.K && st[j] == pr.epoch) {
+            pr.list[pos++] = (int32_t)(k0 + j);
+            pr.stamps[k0 + j] = pr.epoch + 1u;
+        }
+}
+
 __global__ __launch_bounds__(256) void k_tail_a2d(int64_t N, const double* __restrict__ scores, const int32_t* __restrict__ nn_idx,
                                                   const uint8_t* __restrict__ valid, int32_t softmax, TailTables tb, bool padded,
                                                   int32_t* __restrict__ status, double* __restrict__ flags_out,
                                                   const double* __restrict__ part_rmse, int nrm, double* __restrict__ rmse_out,
-                                                  int64_t score_stride = 0, int64_t tstride = 0) {
+                                                  int64_t score_stride = 0, int64_t tstride = 0, int nb_tail = 0x7fffffff,
+                                                  ScorePredict pr = ScorePredict()) {
     __shared__ double s_gtot[16];
     __shared__ double s_red[24];
+    if ((int)blockIdx.x >= nb_tail) {  // (single trajectory only: the launcher adds these workgroups when pr.stamps is set)
+        predict_scan(pr, (int)blockIdx.x - nb_tail);
+        return;
+    }
     if (blockIdx.y) {  // pipelined batch: trajectory blockIdx.y - its own table block (tables_of layout), scores, arrays, rmse triple
         const int64_t b = blockIdx.y, o = b * N, ts = b * tstride;
         scores += b * score_stride; nn_idx += o; valid += o; status += 2 * b;
@@ -1608,13 +1656,16 @@ int debug_tb2_clocks(long long* out16) { return hipMemcpyFromSymbol(out16, HIP_S
 
 int launch_tail_a2(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
                    int32_t softmax, const TailTables& tb, int32_t* status, int batch, int64_t score_stride, bool padded_tables,
-                   const double* part_rmse, double* rmse_out, int64_t tstride) {
+                   const double* part_rmse, double* rmse_out, int64_t tstride, const ScorePredict* predict) {
     const int nb = (int)ceil_div(N, SCAN_BLOCK);
     static const bool direct = !(getenv("MIDAS_TAIL_DIRECT") && atoi(getenv("MIDAS_TAIL_DIRECT")) == 0);
+    const bool with_list = predict && predict->stamps && predict->list && batch <= 1;
+    if (with_list && !(direct && N >= SCAN_CHUNK)) return midas_set_error(ctx, MIDAS_ERR_INVALID, "score_list", "the prediction list needs the direct tail kernel (N >= 16)");
     if (direct && (batch <= 1 || tstride > 0) && N >= SCAN_CHUNK) {
-        hipLaunchKernelGGL(k_tail_a2d, dim3((unsigned)nb, (unsigned)(batch > 1 ? batch : 1)), dim3(256), 0, ctx->stream, N, scores, nn_idx,
+        const int nscan = with_list ? (int)ceil_div(predict->K, 256 * PREDICT_PER_THREAD) : 0;
+        hipLaunchKernelGGL(k_tail_a2d, dim3((unsigned)(nb + nscan), (unsigned)(batch > 1 ? batch : 1)), dim3(256), 0, ctx->stream, N, scores, nn_idx,
                            valid, softmax, tb, padded_tables, status, (double*)nullptr, part_rmse, particle_update_blocks(N),
-                           part_rmse ? rmse_out : (double*)nullptr, score_stride, tstride);
+                           part_rmse ? rmse_out : (double*)nullptr, score_stride, tstride, nb, with_list ? *predict : ScorePredict());
         LAUNCH_CHECK(ctx);
         return MIDAS_OK;
     }

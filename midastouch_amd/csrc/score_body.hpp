@@ -113,16 +113,54 @@ MD RowClaim claim_rows_issue(const SparseScore& sp, bool want, int32_t row) {
     return c;
 }
 
+// four rows (one per quarter-wave; mine < 0: none) against the code, in score_wave's layout and summation order
+template <int NJ>
+MD void score_rows4(const SparseScore& sp, int32_t mine) {
+    constexpr int D = NJ * 64;
+    const int lane = threadIdx.x & 63, s = lane & 15;
+    const bool have = mine >= 0;
+    const float* rp = sp.emb + (size_t)(have ? mine : 0) * D + s * 4;
+    float4 v[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) v[j] = *reinterpret_cast<const float4*>(rp + j * 64);
+    const double nrm = sp.norms[have ? mine : 0];  // travels with the row
+    double acc = 0.0, ne2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const double2* p = reinterpret_cast<const double2*>(sp.code + j * 64 + s * 4);
+        const double2 a = p[0], b = p[1];
+        ne2 = fma_(a.x, a.x, ne2); ne2 = fma_(a.y, a.y, ne2); ne2 = fma_(b.x, b.x, ne2); ne2 = fma_(b.y, b.y, ne2);
+        acc = fma_((double)v[j].x, a.x, acc);
+        acc = fma_((double)v[j].y, a.y, acc);
+        acc = fma_((double)v[j].z, b.x, acc);
+        acc = fma_((double)v[j].w, b.y, acc);
+    }
+    ne2 = quarter_reduce(ne2);
+    acc = quarter_reduce(acc);
+    if (have && s == 0) {
+        double ne = __builtin_sqrt(ne2);
+        ne = ne < COS_EPS ? COS_EPS : ne;
+        sp.scores[mine] = acc / (ne * nrm);
+    }
+}
+
 template <int NJ>
 MD int score_claimed_rows(const SparseScore& sp, const RowClaim& c, int32_t row) {  // returns the rows this wave scored
-    constexpr int D = NJ * 64;
-    const int lane = threadIdx.x & 63, s = lane & 15, qd = lane >> 4;
+    const int lane = threadIdx.x & 63, qd = lane >> 4;
     // (after the first waves of a frame nearly every needed row carries the epoch already)
     bool claim = false;
+    // Prediction list (sp.pred_tag != 0): the tail of the previous frame stamped the rows that frame used with pred_tag and
+    // listed them; streaming waves of THIS launch score the list (score_list_wave), so a leader that finds the tag only
+    // confirms the row is in use again (a plain store: every confirmer writes the same value) and nobody claims it.
+    const bool predicted = sp.pred_tag != 0u && c.old == sp.pred_tag;
+    if (c.leader && predicted) sp.stamps[row] = sp.epoch;
 #if defined(MIDAS_CLAIM_PLAIN) && MIDAS_CLAIM_PLAIN
-    if (c.leader && c.old != sp.epoch) { sp.stamps[row] = sp.epoch; claim = true; }  // profiling: no exchange, duplicates allowed
+    if (c.leader && c.old != sp.epoch && !predicted) { sp.stamps[row] = sp.epoch; claim = true; }  // profiling: no exchange, duplicates allowed
 #else
-    if (c.leader && c.old != sp.epoch) claim = atomicExch(&sp.stamps[row], sp.epoch) != sp.epoch;
+    if (c.leader && c.old != sp.epoch && !predicted) {
+        const uint32_t was = atomicExch(&sp.stamps[row], sp.epoch);
+        claim = was != sp.epoch && !(sp.pred_tag != 0u && was == sp.pred_tag);
+    }
 #endif
     unsigned long long m = __ballot(claim);
     const int nrows = (int)__builtin_popcountll(m);
@@ -137,30 +175,7 @@ MD int score_claimed_rows(const SparseScore& sp, const RowClaim& c, int32_t row)
                 mine = qd == q ? r : mine;
             }
         }
-        const bool have = mine >= 0;
-        const float* rp = sp.emb + (size_t)(have ? mine : 0) * D + s * 4;
-        float4 v[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) v[j] = *reinterpret_cast<const float4*>(rp + j * 64);
-        const double nrm = sp.norms[have ? mine : 0];  // travels with the row
-        double acc = 0.0, ne2 = 0.0;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const double2* p = reinterpret_cast<const double2*>(sp.code + j * 64 + s * 4);
-            const double2 a = p[0], b = p[1];
-            ne2 = fma_(a.x, a.x, ne2); ne2 = fma_(a.y, a.y, ne2); ne2 = fma_(b.x, b.x, ne2); ne2 = fma_(b.y, b.y, ne2);
-            acc = fma_((double)v[j].x, a.x, acc);
-            acc = fma_((double)v[j].y, a.y, acc);
-            acc = fma_((double)v[j].z, b.x, acc);
-            acc = fma_((double)v[j].w, b.y, acc);
-        }
-        ne2 = quarter_reduce(ne2);
-        acc = quarter_reduce(acc);
-        if (have && s == 0) {
-            double ne = __builtin_sqrt(ne2);
-            ne = ne < COS_EPS ? COS_EPS : ne;
-            sp.scores[mine] = acc / (ne * nrm);
-        }
+        score_rows4<NJ>(sp, mine);
     }
     return nrows;
 }
@@ -171,6 +186,20 @@ MD int score_claimed_rows_nj(const SparseScore& sp, const RowClaim& c, int32_t r
         case 4: return score_claimed_rows<4>(sp, c, row);
         case 2: return score_claimed_rows<2>(sp, c, row);
         default: return score_claimed_rows<16>(sp, c, row);
+    }
+}
+
+// Streaming wave `wave` of `nstream`: the rows of the prediction list, four per wave-instruction, strided over the waves.
+// Two rounds are kept in flight (the rows of a spread cloud are cold: a round is one long trip to memory).
+template <int NJ>
+MD void score_list_wave(const SparseScore& sp, int wave, int nstream) {
+    const int lane = threadIdx.x & 63, qd = lane >> 4;
+    int count = *sp.list_count;
+    count = count < 0 ? 0 : (count > sp.list_cap ? sp.list_cap : count);
+    for (int i = wave * 4; i < count; i += nstream * 4) {
+        const int k = i + qd;
+        const int32_t mine = k < count ? sp.list[k] : -1;
+        score_rows4<NJ>(sp, mine);
     }
 }
 

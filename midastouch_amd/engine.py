@@ -20,6 +20,26 @@ from . import _lib, ops
 from ._lib import LazyArgs, LazyFlushArgs, MidasError, StepArgs, _ptr
 
 
+EPOCH_LIMIT = 0x7FFFFFF0
+
+
+def advance_epoch(eng, n: int = 1) -> int:
+    """First of n consecutive sparse-scoring epochs of an engine (`_epoch`, `_stamps`, optionally `_score_list`): non-zero,
+    spaced by 2 when the engine keeps a prediction list (the value between two epochs tags the listed rows), never reused
+    while the stamps live - before the 32-bit counter could wrap (2.5 days at 20k frames/s) the stamps and the list lengths
+    are zeroed and the count restarts, so a stale stamp can never equal a current epoch."""
+    lst = getattr(eng, "_score_list", None)
+    inc = 2 if lst is not None else 1
+    if eng._epoch + inc * n >= EPOCH_LIMIT:
+        eng._stamps.zero_()
+        if lst is not None:
+            lst[:2].zero_()
+        eng._epoch = 0
+    first = eng._epoch + inc
+    eng._epoch += inc * n
+    return first
+
+
 def operand(t, name: str, dtype, shape, device):
     """A frame operand as the C ABI reads it: on `device`, `dtype`, contiguous, exactly `shape` elements (the kernels
     take raw pointers and check nothing).  Host tensors (the reference's CPU-generator draws), float32 tactile codes
@@ -88,10 +108,8 @@ class FilterEngine:
         self._epoch = 0
 
     def _next_epoch(self, n: int = 1) -> int:
-        """First of n consecutive score epochs (non-zero, never reused while the stamps live)."""
-        first = self._epoch + 1
-        self._epoch += n
-        return first
+        """First of n consecutive score epochs (see advance_epoch)."""
+        return advance_epoch(self, n)
 
     # ---- state ----------------------------------------------------------------------------------
     def set_particles(self, poses: torch.Tensor):
@@ -221,6 +239,11 @@ class PipelinedFilterEngine(FilterEngine):
         self._draw = (None, -1.0, 0)
         self._had_gt = False
         self._rmse_frame = torch.zeros(3, **f64)
+        # prediction lists of the sparse scoring (include/midas_hip.h score_list_dev): the rows a frame used are scored for
+        # the next frame by streaming workgroups of its front launch.  MIDAS_SCORE_LIST=0: every row by its first particle.
+        import os
+        self._score_list = torch.zeros(2 + 2 * self.K, dtype=torch.int32, device=dev) \
+            if self.sparse_scores and os.environ.get("MIDAS_SCORE_LIST", "1") != "0" and N >= 16 else None
 
     # the latest frame's own outputs
     @property
@@ -281,6 +304,7 @@ class PipelinedFilterEngine(FilterEngine):
         a.telemetry = _ptr(self.telemetry)
         if self.sparse_scores:
             a.score_stamps, a.score_epoch = _ptr(self._stamps), self._next_epoch()
+            a.score_list = _ptr(self._score_list)
         a.rmse = _ptr(self._rmse_frame) if gt is not None else None
         self._keep = (odom, code, gt, tn, rot, pu)
         self.ctx.bind_current_stream()
@@ -324,6 +348,7 @@ class PipelinedFilterEngine(FilterEngine):
         a.telemetry = _ptr(self.telemetry)
         if self.sparse_scores:
             a.score_stamps, a.score_epoch = _ptr(self._stamps), self._next_epoch(T)
+            a.score_list = _ptr(self._score_list)
         log = torch.zeros((T, 3), dtype=torch.float64, device=d) if gts is not None else None
         self._keep = (odoms, codes, gts, log)
         self.ctx.bind_current_stream()
@@ -442,8 +467,7 @@ class BatchFilterEngine:
         a.prune_thr, a.softmax, a.resample_mode = self.pen_max, int(self.softmax), self.mode
         a.status, a.telemetry = _ptr(self.status), _ptr(self.telemetry)
         if self.sparse_scores:
-            self._epoch += 1
-            a.score_stamps, a.score_epoch = _ptr(self._stamps), self._epoch
+            a.score_stamps, a.score_epoch = _ptr(self._stamps), advance_epoch(self)
         self._keep = (odoms, codes, gts, tn, rot, u)
         self.ctx.bind_current_stream()
         self.ctx.check(self.ctx.lib.midas_filter_step_batch(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h,
@@ -560,8 +584,7 @@ class PipelinedBatchFilterEngine(BatchFilterEngine):
         a.std_t, a.std_r, a.seed, a.step = self.sig_t, self.sig_r, self.seed, self.step_count
         a.prune_thr, a.softmax = self.pen_max, int(self.softmax)
         a.telemetry = _ptr(self.telemetry)
-        self._epoch += 1
-        a.score_stamps, a.score_epoch = _ptr(self._stamps), self._epoch
+        a.score_stamps, a.score_epoch = _ptr(self._stamps), advance_epoch(self)
         a.rmse = _ptr(self._rmse_frame) if gts is not None else None
         self._keep = (odoms, codes, gts, tn, rot, pu)
         self.ctx.bind_current_stream()

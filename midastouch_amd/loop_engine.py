@@ -242,8 +242,8 @@ class LoopEngine:
         a.anneal_small = int(self._grid_n <= 16384)
         a.telemetry = _ptr(self.telemetry)
         if self.sparse_scores and phases & _lib.LOOP_FRONT:
-            self._epoch += 1
-            a.score_stamps, a.score_epoch = _ptr(self._stamps), self._epoch
+            from .engine import advance_epoch
+            a.score_stamps, a.score_epoch = _ptr(self._stamps), advance_epoch(self)
         self._keep = keep
         self.ctx.bind_current_stream()
         self.ctx.check(self.ctx.lib.midas_loop_step(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h, C.byref(a), int(phases)))

@@ -214,3 +214,80 @@ def test_run_equals_stepping(dev):
     for name in ("poses", "weights", "weights_res", "ridx", "hint", "rmse"):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     assert torch.isfinite(log2).all() and log2.shape == (T - 10, 3)
+
+
+@pytest.mark.parametrize("N", [20000, 300000])
+def test_prediction_list_same_results(dev, oracle, monkeypatch, N):
+    """Sparse scoring with the prediction list (the rows a frame used are scored for the next one by streaming workgroups,
+    include/midas_hip.h score_list_dev) against the oracle and against the engine without a list: which wave scores a row is
+    all that changes.  N = 20000: per-wave tables, one-wave workgroups; N = 300000: workgroup tables, four-wave workgroups.
+    Spread start (every particle its own codebook entry: the regime the list is for), stepped frame by frame and by one
+    midas_lazy_run call."""
+    from midastouch_amd.engine import PipelinedFilterEngine
+    K, D, seed = 6000, 256, 4500
+    cb, traj = _setup(N, K, D, 9)
+    rng = np.random.default_rng(5)
+    start = cb.poses[rng.integers(0, K, N)]
+    engs = {}
+    for tag, env in (("list", "1"), ("nolist", "0")):
+        monkeypatch.setenv("MIDAS_SCORE_LIST", env)
+        engs[tag] = PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=seed, device=dev)
+        engs[tag].set_particles(torch.as_tensor(start))
+    assert engs["list"]._score_list is not None and engs["nolist"]._score_list is None
+    ofl = oracle.OracleFilter(cb.poses, cb.embeddings, cb.mesh_vertices) if N <= 20000 else None
+    poses = start
+    od, co = torch.as_tensor(traj.odoms).to(dev), torch.as_tensor(traj.codes).to(dev)
+    for t in range(1, 8):
+        for e in engs.values():
+            e.step(od[t], co[t])
+        a, b = engs["list"], engs["nolist"]
+        assert np.array_equal(a.nn_idx.cpu().numpy(), b.nn_idx.cpu().numpy()), f"frame {t}"
+        used = torch.unique(a.nn_idx).long()
+        assert torch.equal(a._scores[used], b._scores[used]), f"frame {t}: scores of the rows in use"
+        if t >= 2:  # from the second frame on the list is non-empty and most of the rows in use were on it
+            par = (a._epoch >> 1) & 1
+            n_listed = int(a._score_list[par ^ 1].item())  # written by this frame's tail for the next frame
+            assert n_listed == used.numel(), f"frame {t}: the list holds {n_listed} rows, {used.numel()} are in use"
+        if t % 3 == 0 or ofl is not None:
+            assert np.array_equal(a.ridx.cpu().numpy(), b.ridx.cpu().numpy()), f"frame {t}"
+            assert np.array_equal(a.weights.cpu().numpy(), b.weights.cpu().numpy()), f"frame {t}"
+        if ofl is not None:
+            tn, rot = oracle.philox_noise(N, seed, t - 1, np.float32(2e-4), np.float32(0.5))
+            ref = ofl.step(poses, traj.odoms[t], traj.codes[t], tn, rot, u=oracle.philox_uniform64(N, seed, t - 1))
+            assert np.array_equal(a.nn_idx.cpu().numpy(), ref["nn_idx"]) and np.array_equal(a.ridx.cpu().numpy(), ref["ridx"])
+            assert np.array_equal(a.weights.cpu().numpy(), ref["weights"])
+            poses = ref["poses"]
+    # the same frames again by ONE call (midas_lazy_run advances the epoch by two per frame itself)
+    for e in engs.values():
+        e.set_particles(torch.as_tensor(start))
+        e.step_count = 0
+        e.step(od[1], co[1])
+        e.run(od[2:8], co[2:8])
+    assert np.array_equal(engs["list"].nn_idx.cpu().numpy(), engs["nolist"].nn_idx.cpu().numpy())
+    assert np.array_equal(engs["list"].ridx.cpu().numpy(), engs["nolist"].ridx.cpu().numpy())
+    assert np.array_equal(engs["list"].weights.cpu().numpy(), engs["nolist"].weights.cpu().numpy())
+
+
+def test_epoch_wrap_restarts_stamps_and_lists(dev):
+    """advance_epoch: before the 32-bit epoch could wrap, the stamps and the list lengths are zeroed and the count restarts
+    (a stale stamp equal to a current epoch would make a row look scored: ADVICE round 2)."""
+    from midastouch_amd.engine import EPOCH_LIMIT, PipelinedFilterEngine, advance_epoch
+    N, K, D = 20000, 3000, 256
+    cb, traj = _setup(N, K, D, 3)
+    eng = PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=1, device=dev)
+    ref = PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=1, device=dev)
+    rng = np.random.default_rng(2)
+    start = torch.as_tensor(cb.poses[rng.integers(0, K, N)])
+    eng.set_particles(start)
+    ref.set_particles(start)
+    od, co = torch.as_tensor(traj.odoms).to(dev), torch.as_tensor(traj.codes).to(dev)
+    eng._epoch = EPOCH_LIMIT - 7  # three frames before the restart
+    for t in range(1, 9):
+        eng.step(od[t], co[t])
+        ref.step(od[t], co[t])
+        assert 0 < eng._epoch < EPOCH_LIMIT
+        assert np.array_equal(eng.nn_idx.cpu().numpy(), ref.nn_idx.cpu().numpy())
+        used = torch.unique(eng.nn_idx).long()
+        assert torch.equal(eng._scores[used], ref._scores[used]), f"frame {t}"
+    assert eng._epoch < 100  # restarted
+    assert np.array_equal(eng.ridx.cpu().numpy(), ref.ridx.cpu().numpy())
