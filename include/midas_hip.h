@@ -133,6 +133,19 @@ int midas_softmax(midas_ctx* ctx, int64_t N, const double* x_dev, int32_t softma
 int midas_prune(midas_ctx* ctx, int64_t N, double* w_dev, const double* dist_dev, double thr,
                 int32_t* nvalid_dev);
 
+/* ---- torch's CPU random stream on the device ---------------------------------------------------- */
+/* The reference draws on torch's default CPU generator (at::mt19937).  Under torch.manual_seed(s) the resampler's
+ * WeightedRandomSampler / torch.multinomial(weights.double(), N, True) (modules/particle_filter.py:245) consumes two 32-bit
+ * outputs per sample - the stream of torch.rand(N, dtype=float64) - and each torch.normal of add_noise_to_odom (:326-335)
+ * one output per float32 value (+ 16 when the size is not a multiple of 16).  These two calls reproduce that stream from a
+ * generator state kept in device memory (state_dev: 626 uint32, caller-owned), so "bit-exact resample indices under a
+ * fixed seed" needs neither a host generator nor a per-frame upload of uniforms.
+ * midas_mt19937_seed: the state of torch.manual_seed(seed) (low 32 bits, as at::mt19937 takes them).
+ * midas_mt19937_rand64: discards skip_words 32-bit outputs, then writes the next N float64 uniforms
+ * ((hi << 32 | lo) & (2^53 - 1)) * 2^-53 to out_dev (NULL with N == 0: skip only), and leaves the state advanced. */
+int midas_mt19937_seed(midas_ctx* ctx, uint64_t seed, uint32_t* state_dev);
+int midas_mt19937_rand64(midas_ctx* ctx, uint32_t* state_dev, int64_t skip_words, int64_t N, double* out_dev);
+
 /* ---- resample  (K6, K7, K8) ------------------------------------------------------------------ */
 /* cdf = blocked_prefix(w) / total, cdf[N-1] = 1 (float64, fixed summation order - DESIGN.md).
  * status_dev[0] = 0 ok, 1 all weights zero, 2 NaN present (resampler returns its input unchanged,

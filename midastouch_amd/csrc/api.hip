@@ -343,6 +343,18 @@ MIDAS_EXPORT int midas_cdf(midas_ctx* ctx, int64_t N, const double* w_dev, doubl
     return launch_cdf(ctx, N, w_dev, cdf_dev, status_dev);
 }
 
+MIDAS_EXPORT int midas_mt19937_seed(midas_ctx* ctx, uint64_t seed, uint32_t* state_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, state_dev != nullptr);
+    return launch_mt_seed(ctx, seed, state_dev);
+}
+
+MIDAS_EXPORT int midas_mt19937_rand64(midas_ctx* ctx, uint32_t* state_dev, int64_t skip_words, int64_t N, double* out_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, state_dev != nullptr && skip_words >= 0 && N >= 0 && (N == 0 || out_dev != nullptr));
+    return launch_mt_rand64(ctx, state_dev, skip_words, N, out_dev);
+}
+
 MIDAS_EXPORT int midas_resample_search(midas_ctx* ctx, int64_t N, const double* cdf_dev, int64_t M, int32_t mode,
                                        const double* u_dev, float u32, uint64_t seed, uint64_t step, int32_t* idx_dev) {
     MIDAS_ENTER(ctx);

@@ -364,6 +364,10 @@ int launch_anneal_select(midas_ctx* ctx, int64_t N, const double* w, int32_t mod
 int launch_dbscan(midas_ctx* ctx, int64_t cap, const int32_t* n_dev, const float* poses, double eps, int64_t min_samples,
                   int32_t* labels_out, int32_t* ncl_out, int32_t* err_out);
 
+// mt19937.hip - torch's CPU generator stream on the device
+int launch_mt_seed(midas_ctx* ctx, uint64_t seed, uint32_t* state);
+int launch_mt_rand64(midas_ctx* ctx, uint32_t* state, int64_t skip_words, int64_t N, double* out);
+
 // topn.hip
 int launch_topn_pose_error(midas_ctx* ctx, int32_t B, int64_t K, const double* scores, int64_t row0, int32_t n,
                            const double* feat, int32_t d, double* err_out, int32_t* idx_out);

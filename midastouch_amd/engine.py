@@ -279,7 +279,21 @@ class PipelinedFilterEngine(FilterEngine):
         self.flush()
         return super().project_to_codebook()
 
+    def seed_torch_stream(self, seed):
+        """Resample draws from the device replica of torch's CPU generator under torch.manual_seed(seed) (torch_rng.py):
+        every step() without explicit `u` then resamples with the uniforms torch.multinomial would consume
+        (modules/particle_filter.py:245).  With host motion noise (tn, rot given) the stream first steps over the words those
+        two torch.normal calls took, so it stays aligned with a host generator seeded alike.  seed=None: back to Philox."""
+        from .torch_rng import TorchCpuStream
+        self.torch_stream = None if seed is None else TorchCpuStream(seed, self.device)
+        return self.torch_stream
+
     def step(self, odom, code, gt=None, tn=None, rot=None, u=None, u32=-1.0, multiplier: float = 1.0):
+        stream = getattr(self, "torch_stream", None)
+        if stream is not None and u is None and self.mode == _lib.RESAMPLE_MULTINOMIAL:
+            if tn is not None:
+                stream.skip_normal(3 * self.N).skip_normal(3 * self.N)
+            u = stream.rand64(self.N)
         odom, code, gt, tn, rot, u = self._operands(odom, code, gt, tn, rot, u)
         cur, nxt = self._cur, self._cur ^ 1
         fold = self._pending and not self._flushed
@@ -310,7 +324,7 @@ class PipelinedFilterEngine(FilterEngine):
         self.ctx.bind_current_stream()
         self.ctx.check(self.ctx.lib.midas_lazy_step(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h, C.byref(a)))
         # this frame's resample draws, consumed by the next step or by flush()
-        self._draw = (None if u is None else u.clone(), float(u32), self.step_count)
+        self._draw = (None if u is None else (u if stream is not None else u.clone()), float(u32), self.step_count)
         self._had_gt = gt is not None
         self._pending, self._flushed, self._cur = True, False, nxt
         self.step_count += 1

@@ -276,6 +276,15 @@ class particle_filter:
         return particles
 
     # ---------------------------------------------------------------------------------------------
+    def seed_device_stream(self, seed: int):
+        """torch.manual_seed(seed) for the resampler's draws, kept on the device: `resampler("weighted_random")` then takes
+        the uniforms torch.multinomial would consume (modules/particle_filter.py:245) from the device replica of torch's
+        CPU generator (midastouch_amd/torch_rng.py) - the reference's indices bit for bit, nothing generated on the host.
+        `seed=None` returns to the host generator."""
+        from .torch_rng import TorchCpuStream
+        self.torch_stream = None if seed is None else TorchCpuStream(seed, self.device)
+        return self.torch_stream
+
     def resampler(self, _particles: Particles, resample: str = "weighted_random") -> Particles:
         """Importance resampling (:230-307).
 
@@ -293,7 +302,10 @@ class particle_filter:
         if int(status.item()) != 0:  # all-zero or NaN weights: return the input (:240-241)
             return particles
         if resample == "weighted_random":
-            u = torch.rand(nSamples, dtype=torch.float64)
+            # the draws torch.multinomial would take from the CPU generator: from that generator itself, or - after
+            # seed_device_stream() - from its replica on the device (no host generator, no upload of N float64)
+            stream = getattr(self, "torch_stream", None)
+            u = stream.rand64(nSamples) if stream is not None else torch.rand(nSamples, dtype=torch.float64)
             idxs = ops.resample_search(cdf, nSamples, _lib.RESAMPLE_MULTINOMIAL, u=u)
         elif resample in ("low_var", "low_var_batch"):
             offset = torch.rand(1)

@@ -668,6 +668,47 @@ MO_API void mo_search_systematic(int64_t N, const double* cdf, int64_t M, float 
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* torch's CPU generator stream (at::mt19937)                                                 */
+/* ------------------------------------------------------------------------------------------ */
+/* The reference's draws come from torch's default CPU generator: torch.manual_seed(s) seeds MT19937 with the low 32
+ * bits of s (ATen/core/MT19937RNGEngine.h); torch.multinomial(w.double(), N, True) - what WeightedRandomSampler calls,
+ * modules/particle_filter.py:245 - and torch.rand(N, dtype=float64) both take, per value, two 32-bit outputs as
+ * ((hi << 32 | lo) & (2^53 - 1)) * 2^-53 (at::uniform_real_distribution<double>).  Restated from the published algorithm
+ * (Matsumoto & Nishimura 1998); pinned against torch.rand itself in tests/test_torch_stream.py (torch is importable on
+ * every box).  mo_mt19937_rand64 skips `skip_words` outputs after seeding, then writes N uniforms. */
+typedef struct { uint32_t mt[624]; int pos; } mo_mt;
+static void mo_mt_seed(mo_mt* g, uint32_t seed) {
+    g->mt[0] = seed;
+    for (int j = 1; j < 624; ++j) g->mt[j] = 1812433253u * (g->mt[j - 1] ^ (g->mt[j - 1] >> 30)) + (uint32_t)j;
+    g->pos = 624;
+}
+static uint32_t mo_mt_next(mo_mt* g) {
+    if (g->pos >= 624) {
+        uint32_t* mt = g->mt;
+        for (int k = 0; k < 624; ++k) {
+            const uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+            mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        g->pos = 0;
+    }
+    uint32_t y = g->mt[g->pos++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+MO_API void mo_mt19937_rand64(uint64_t seed, int64_t skip_words, int64_t N, double* out) {
+    mo_mt g;
+    mo_mt_seed(&g, (uint32_t)(seed & 0xffffffffu));
+    for (int64_t i = 0; i < skip_words; ++i) (void)mo_mt_next(&g);
+    for (int64_t i = 0; i < N; ++i) {
+        const uint64_t hi = mo_mt_next(&g), lo = mo_mt_next(&g);
+        out[i] = (double)(((hi << 32) | lo) & ((1ull << 53) - 1ull)) * 1.1102230246251565e-16;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* particle_rmse                                                                              */
 /* ------------------------------------------------------------------------------------------ */
 MO_API void mo_rmse(int64_t N, const float* poses, const float* gt16, double* out2) {

@@ -120,6 +120,21 @@ def philox_uniform64(N, seed, step):
     return u
 
 
+def torch_rand64(seed: int, N: int, skip_words: int = 0):
+    """torch.rand(N, dtype=float64) after torch.manual_seed(seed) and `skip_words` earlier 32-bit draws - the stream
+    torch.multinomial consumes in the resampler (particle_filter.py:245); restated MT19937 (mo_mt19937_rand64)."""
+    u = np.empty(N, dtype=np.float64)
+    lib().mo_mt19937_rand64(C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), C.c_int64(skip_words), C.c_int64(N), _p(u))
+    return u
+
+
+def torch_normal_words(numel: int) -> int:
+    """32-bit outputs one torch.normal(mean, std, size) of `numel` float32 values takes from the CPU generator (ATen
+    normal_fill: one per value, and the last 16 are drawn again when numel is not a multiple of 16; numel >= 16)."""
+    assert numel >= 16
+    return numel + (16 if numel % 16 else 0)
+
+
 def philox_raw(ctr, key):
     ctr = np.ascontiguousarray(ctr, dtype=np.uint32)
     key = np.ascontiguousarray(key, dtype=np.uint32)

@@ -1,0 +1,124 @@
+"""torch's CPU random stream (at::mt19937) restated: the oracle's generator against torch itself on the CPU (torch is
+importable on every box), the device generator (csrc/mt19937.hip) against torch on the GPU box.  This is the stream the
+reference's resampler consumes (modules/particle_filter.py:245: WeightedRandomSampler -> torch.multinomial on the default CPU
+generator), so with it "bit-exact resample indices under a fixed seed" needs no host generator in the loop."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+SEEDS = (0, 1, 42, 3000, 123456789, 2**32 + 5, 2**63 + 7, 0xFFFFFFFF)
+SIZES = (1, 311, 312, 313, 623, 624, 625, 100_000, 1_000_000)
+
+
+def test_oracle_stream_equals_torch_rand(oracle):
+    for seed in SEEDS:
+        for N in SIZES:
+            if N == 1_000_000 and seed not in (42, 3000):
+                continue
+            torch.manual_seed(seed)
+            ref = torch.rand(N, dtype=torch.float64).numpy()
+            assert np.array_equal(oracle.torch_rand64(seed, N), ref), (seed, N)
+
+
+def test_oracle_stream_alignment_with_the_reference_draw_order(oracle):
+    """One frame of the reference's draws (add_noise_to_odom: tn then rot, particle_filter.py:326-335; then the resampler's
+    multinomial, :245): the uniforms behind the normals' words are what torch.multinomial consumes."""
+    for N in (6, 1000, 4096, 33333):
+        torch.manual_seed(11)
+        torch.normal(0.0, 2e-4, size=(N, 3))
+        torch.normal(0.0, 0.5, size=(N, 3))
+        w = torch.rand(N, dtype=torch.float64)
+        skip = 2 * oracle.torch_normal_words(3 * N)
+        assert np.array_equal(oracle.torch_rand64(11, N, skip), w.numpy()), N
+        # and the multinomial itself == inverse-CDF search on that stream
+        torch.manual_seed(12)
+        idx = torch.multinomial(w, N, True).numpy()
+        ridx, status = oracle.resample_indices(w.numpy(), "weighted_random", u=oracle.torch_rand64(12, N))
+        assert status == 0 and np.array_equal(ridx, idx), N
+
+
+@pytest.mark.gpu
+def test_device_stream_equals_torch_rand():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from midastouch_amd.torch_rng import TorchCpuStream
+    dev = torch.device("cuda", 0)
+    for seed in SEEDS:
+        for N in SIZES:
+            if N == 1_000_000 and seed not in (42, 3000):
+                continue
+            torch.manual_seed(seed)
+            ref = torch.rand(N, dtype=torch.float64)
+            got = TorchCpuStream(seed, dev).rand64(N).cpu()
+            assert torch.equal(got, ref), (seed, N)
+    # consecutive draws continue the stream (odd and even lengths: values straddling the 624-word blocks), skips included
+    torch.manual_seed(5)
+    st = TorchCpuStream(5, dev)
+    for n in (1, 2, 311, 313, 7, 100_000, 624, 3):
+        assert torch.equal(st.rand64(n).cpu(), torch.rand(n, dtype=torch.float64)), n
+    torch.manual_seed(6)
+    st.manual_seed(6)
+    for N in (1000, 33333):
+        tn, rot = torch.normal(0.0, 2e-4, size=(N, 3)), torch.normal(0.0, 0.5, size=(N, 3))
+        u = torch.rand(N, dtype=torch.float64)
+        assert torch.equal(st.skip_normal(3 * N).skip_normal(3 * N).rand64(N).cpu(), u), N
+
+
+@pytest.mark.gpu
+def test_resampler_on_the_device_stream_matches_reference_digests(golden):
+    """G2b (the reference's own resampler at N = 100 000 under torch.manual_seed, tools/gen_goldens_r2.py) through
+    particle_filter.resampler with the draws taken from the device replica of torch's generator: the reference's index
+    arrays bit for bit, no host generator involved (the default generator is seeded differently on purpose)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from _recipes import g2b_cases, sha
+    from midastouch_amd.config import load_config
+    from midastouch_amd.particle_filter import Particles, particle_filter
+    dev = torch.device("cuda", 0)
+    pf = particle_filter(load_config(), np.zeros((8, 3)), 1.0, downsample=1, device=dev)
+    g = golden("g2b_resampler_100k")
+    n = int(g["N"])
+    poses = torch.eye(4, device=dev)[None].repeat(n, 1, 1).contiguous()
+    checked = 0
+    for ci, w, mode, seed, ref_sha, head, tail in g2b_cases(g):
+        if mode != "weighted_random":
+            continue
+        parts = Particles(poses, torch.as_tensor(w).to(dev), torch.arange(n, dtype=torch.float32, device=dev))
+        torch.manual_seed(seed + 1)  # not the reference's seed: the host generator must play no part
+        pf.seed_device_stream(seed)
+        res = pf.resampler(parts, resample=mode)
+        idx = res.labels.cpu().numpy().astype(np.int32)
+        assert np.array_equal(idx[:64], head) and np.array_equal(idx[-64:], tail), ci
+        assert sha(idx) == ref_sha, ci
+        checked += 1
+    assert checked == 12
+
+
+@pytest.mark.gpu
+def test_pipelined_engine_on_the_device_stream_equals_host_uniforms():
+    """PipelinedFilterEngine.seed_torch_stream(s): the frames resample with torch's stream generated on the device - the
+    same particle sets as with u = torch.rand(N, float64) of a host generator seeded s passed in every frame."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from midastouch_amd.engine import PipelinedFilterEngine
+    from midastouch_amd.synthetic import make_codebook, make_trajectory
+    dev = torch.device("cuda", 0)
+    N, K, D = 30000, 3000, 256
+    cb = make_codebook("004_sugar_box", K=K, D=D, seed=1001)
+    traj = make_trajectory(cb, T=10, seed=2001)
+    rng = np.random.default_rng(3)
+    start = torch.as_tensor(cb.poses[rng.integers(0, K, N)])
+    a = PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=77, device=dev)
+    b = PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=77, device=dev)
+    a.set_particles(start)
+    b.set_particles(start)
+    a.seed_torch_stream(2024)
+    torch.manual_seed(2024)
+    od, co = torch.as_tensor(traj.odoms).to(dev), torch.as_tensor(traj.codes).to(dev)
+    for t in range(1, 8):
+        a.step(od[t], co[t])
+        b.step(od[t], co[t], u=torch.rand(N, dtype=torch.float64))
+        if t % 3 == 0:
+            assert torch.equal(a.ridx, b.ridx) and torch.equal(a.poses, b.poses), t
+    assert torch.equal(a.ridx, b.ridx) and torch.equal(a.weights, b.weights)
