@@ -1995,6 +1995,7 @@ MD void particle_front_wave(ParticleUpdateArgs a, int64_t wave, const double* rs
     if (wave == 0 && lane == 0) {
         if (a.status_reset) { a.status_reset[0] = 0; a.status_reset[1] = 0; }
         if (a.flags_reset) { a.flags_reset[0] = 0.0; a.flags_reset[1] = 0.0; }
+        if (a.sp.next_count) *a.sp.next_count = 0;  // this frame's tail appends the next frame's prediction list
     }
     double et2 = 0.0, ang2 = 0.0;
     int64_t src = n;

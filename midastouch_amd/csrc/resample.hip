@@ -538,8 +538,13 @@ MD void predict_scan(const ScorePredict& pr, int blk) {
 #pragma unroll
     for (int j = 0; j < PREDICT_PER_THREAD; ++j)
         if (k0 + j < pr.K && st[j] == pr.epoch) {
-            pr.list[pos++] = (int32_t)(k0 + j);
-            pr.stamps[k0 + j] = pr.epoch + 1u;
+            // (distinct rows, counter zeroed by the front: pos < K; a row that would not fit simply stays unlisted and untagged -
+            // its first particle of the next frame claims it)
+            if (pos < pr.K) {
+                pr.list[pos] = (int32_t)(k0 + j);
+                pr.stamps[k0 + j] = pr.epoch + 1u;
+            }
+            ++pos;
         }
 }
 

@@ -213,7 +213,7 @@ class PipelinedFilterEngine(FilterEngine):
     @property
     def rmse(self):
         """rmse of the latest frame's propagated particles (filter.py:164): written by the frame itself, no materialisation."""
-        return self._rmse_frame[:2] if self._pending else self._rmse
+        return self._rmse_last[:2] if self._pending else self._rmse
 
     @rmse.setter
     def rmse(self, v):
@@ -239,6 +239,8 @@ class PipelinedFilterEngine(FilterEngine):
         self._draw = (None, -1.0, 0)
         self._had_gt = False
         self._rmse_frame = torch.zeros(3, **f64)
+        self._rmse_last = self._rmse_frame   # where the latest frame left {rmse_t, rmse_r, clock}: _rmse_frame or a row of the run log
+        self._log = None                     # per-frame log of run(): kept between calls (every row is written by its frame)
         # prediction lists of the sparse scoring (include/midas_hip.h score_list_dev): the rows a frame used are scored for
         # the next frame by streaming workgroups of its front launch.  MIDAS_SCORE_LIST=0: every row by its first particle.
         import os
@@ -325,6 +327,7 @@ class PipelinedFilterEngine(FilterEngine):
         self.ctx.check(self.ctx.lib.midas_lazy_step(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h, C.byref(a)))
         # this frame's resample draws, consumed by the next step or by flush()
         self._draw = (None if u is None else (u if stream is not None else u.clone()), float(u32), self.step_count)
+        self._rmse_last = self._rmse_frame
         self._had_gt = gt is not None
         self._pending, self._flushed, self._cur = True, False, nxt
         self.step_count += 1
@@ -363,13 +366,17 @@ class PipelinedFilterEngine(FilterEngine):
         if self.sparse_scores:
             a.score_stamps, a.score_epoch = _ptr(self._stamps), self._next_epoch(T)
             a.score_list = _ptr(self._score_list)
-        log = torch.zeros((T, 3), dtype=torch.float64, device=d) if gts is not None else None
+        log = None
+        if gts is not None:  # no fill, no copy afterwards: launches of their own in front of / behind the frames
+            if self._log is None or self._log.shape[0] < T:
+                self._log = torch.empty((max(T, 256), 3), dtype=torch.float64, device=d)
+            log = self._log[:T]
         self._keep = (odoms, codes, gts, log)
         self.ctx.bind_current_stream()
         self.ctx.check(self.ctx.lib.midas_lazy_run(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h, C.byref(a), T, _ptr(log)))
         self.step_count += T
         if log is not None:
-            self._rmse_frame.copy_(log[-1])
+            self._rmse_last = log[T - 1]
         self._draw = (None, -1.0, self.step_count - 1)
         self._had_gt = gts is not None
         self._pending, self._flushed = True, False
