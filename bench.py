@@ -114,7 +114,7 @@ def cpu_baseline(cb, traj, N, budget_s=12.0, max_steps=40):
                                    f"particle (K x D GEMV instead of the (N,D) gather), same threads, {dt2:.1f} s"}
 
 
-def reference_loop_rate(cb, traj, N, dev, tree, mesh_tree, T=200):
+def reference_loop_rate(cb, traj, N, dev, tree, mesh_tree, T=200, floor=1000):
     """midastouch_amd.filter.filter - the reference's loop body with DBSCAN every 50th frame, cluster centres and annealing
     every frame (filter/filter.py:150-190), N0 = N, device draws - over T frames of the same trajectory: frames / s after the
     two initial frames (whose init_filter runs on the host like the reference's)."""
@@ -125,11 +125,100 @@ def reference_loop_rate(cb, traj, N, dev, tree, mesh_tree, T=200):
     T = min(T, traj.gt_poses.shape[0])
     seq = Sequence(torch.as_tensor(traj.gt_poses[:T]).to(dev), torch.as_tensor(traj.meas_poses[:T]).to(dev),
                    torch.as_tensor(traj.codes[:T]).to(dev), tree, cb.mesh_vertices, "004_sugar_box", mesh_tree=mesh_tree)
-    st = run_filter(cfg, seq, device=dev)
+    st = run_filter(cfg, seq, device=dev, floor=floor)
     steady = st["time"][2:]
     return {"frames_per_sec": len(steady) / sum(steady), "ms_per_frame": 1e3 * sum(steady) / len(steady), "frames": len(steady),
-            "N0": N, "N_final": st["num_particles"][-1], "N_min": min(st["num_particles"]),
+            "N0": N, "floor": floor, "N_final": st["num_particles"][-1], "N_min": min(st["num_particles"]),
+            "ms_frame_median": 1e3 * sorted(steady)[len(steady) // 2],
             "ms_frame_max": 1e3 * max(steady), "rmse_t_mm_final": 1e3 * st["rmse_t"][-1]}
+
+
+def config5_rate(dev, frames=60):
+    """BASELINE configs[4] (c5): B = 64 trajectories x N = 10 000 particles on the cotter pin's 50k x 512 codebook, pipelined batch
+    engine (two launches per batch frame), device draws: us per batch frame from a spread start and from a start near the truth."""
+    from midastouch_amd.engine import PipelinedBatchFilterEngine
+    from midastouch_amd.synthetic import make_codebook, make_trajectory
+
+    cb = make_codebook("cotter-pin", K=50000, D=512, seed=1005)
+    B, N = 64, 10000
+    trs = [make_trajectory(cb, T=40, seed=2200 + b) for b in range(8)]
+    od = torch.as_tensor(np.stack([trs[b % 8].odoms for b in range(B)], axis=1)).to(dev)
+    co = torch.as_tensor(np.stack([trs[b % 8].codes for b in range(B)], axis=1)).to(dev)
+    out = {"workload": "c5: cotter-pin, B=64 trajectories x N=10000 particles, K=50000 x D=512, device draws, pipelined batch step"}
+    eng = PipelinedBatchFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, B, N, device=dev)
+    rng = np.random.default_rng(1)
+    for init in ("spread", "near"):
+        if init == "spread":
+            start = np.stack([cb.poses[rng.integers(0, 50000, N)] for _ in range(B)])
+        else:
+            start = []
+            for b in range(B):
+                d0 = np.linalg.norm(cb.poses[:, :3, 3] - trs[b % 8].gt_poses[0][:3, 3], axis=1)
+                start.append(cb.poses[rng.choice(np.argsort(d0)[:2500], N)])
+            start = np.stack(start)
+        eng.set_particles(torch.as_tensor(start))
+        eng.project_to_codebook()
+        for i in range(10):
+            eng.step(od[1 + i % 38], co[1 + i % 38])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(frames):
+            eng.step(od[1 + (10 + i) % 38], co[1 + (10 + i) % 38])
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) / frames * 1e6
+        out[init] = {"us_per_batch_frame": us, "trajectory_steps_per_sec": B * 1e6 / us}
+    return out
+
+
+def parity_mode_rate(cb, traj, N, dev, tree, mesh_tree, steps=100):
+    """The fixed-seed mode at c2: every frame resamples with the draws torch.multinomial would take from torch's CPU
+    generator under torch.manual_seed(3000) (modules/particle_filter.py:245), generated by the device replica of that
+    generator (midas_mt19937_rand64) - the mode in which resample indices are bit-exact against the reference's
+    (tests/test_torch_stream.py, fixture G2b).  Motion noise stays on the device Philox streams (torch.normal's float32 path
+    goes through a vectorised math library whose results are not reproducible).  One step() call per frame."""
+    from midastouch_amd.engine import PipelinedFilterEngine
+
+    eng = PipelinedFilterEngine(tree, None, mesh_tree, N, seed=4000, device=dev)
+    rng = np.random.default_rng(0)
+    eng.set_particles(torch.as_tensor(cb.poses[rng.integers(0, cb.K, N)]))
+    eng.project_to_codebook()
+    eng.seed_torch_stream(3000)
+    odoms, codes = torch.as_tensor(traj.odoms).to(dev), torch.as_tensor(traj.codes).to(dev)
+    T = odoms.shape[0]
+    for i in range(20):
+        eng.step(odoms[1 + i % (T - 1)], codes[1 + i % (T - 1)])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        eng.step(odoms[1 + (20 + i) % (T - 1)], codes[1 + (20 + i) % (T - 1)])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"steps_per_sec": steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
+            "draws": "resample: device replica of torch's CPU mt19937 under torch.manual_seed(3000) (torch.rand(N, float64) stream, "
+                     "generated on the stream before each frame); motion noise: device Philox",
+            "status": eng.status.cpu().numpy().tolist()}
+
+
+def parity_probe(eng, N, seed):
+    """How many resample indices of the last frame would differ had the softmax numerators been taken with the C library's exp
+    instead of the spec exponential (hard part 2: expected 0 - 2 at N = 10^5)?  Uses the device's own nearest
+    entries, scores and prune mask; the CDF (blocked order) and the search are the oracle's.  Also checks that the spec path
+    reproduces the device's indices exactly.  Part of the CPU leg: the oracle is the checker here, never the thing measured."""
+    from oracle import oracle as orc
+
+    ridx = eng.ridx.cpu().numpy()  # materialises the last frame
+    nn = eng.nn_idx.cpu().numpy()
+    valid = eng._valid.cpu().numpy().astype(bool)
+    x = eng._scores.cpu().numpy()[nn]
+    step = eng._draw[2]
+    u = orc.philox_uniform64(N, seed, step)
+    out = {}
+    for tag, e in (("spec_exp", orc.exp_spec(x, 1.0)), ("libm_exp", np.exp(x - 1.0))):
+        ref, status = orc.resample_indices(e * valid, "weighted_random", u=u)
+        out["index_mismatches_vs_" + tag] = int((ref != ridx).sum()) if status == 0 else None
+    out["note"] = ("last frame of the run, N = %d: resample indices of the device against the oracle's search over the blocked CDF of "
+                   "exp(x - 1) * mask with the spec exponential (must be 0) and with libm's exp (SURVEY 7 hard part 2)" % N)
+    return out
 
 
 def main():
@@ -144,6 +233,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-loop", action="store_true", help="skip the reference-named loop (filter() with clustering + annealing)")
     ap.add_argument("--no-diffuse", action="store_true", help="skip the diffuse-regime figure (profiling runs: keeps the wide-start frames out of the kernel statistics)")
+    ap.add_argument("--no-extras", action="store_true", help="skip config.c5, config.parity_mode and roofline.dense (profiling runs)")
     ap.add_argument("--sharded", action="store_true", help="use the particle-sharded engine even on one GPU (smoke test)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "peer", "a2a", "a2a_fixed", "allgather"], help="sharded engine: form of the resample exchange")
     ap.add_argument("--eager", action="store_true", help="materialise the resampled particles every frame (three launches per frame)")
@@ -257,6 +347,7 @@ def main():
     import gc
     gc.collect()
     gc.disable()
+    tele_before = None if sharded else eng.telemetry.cpu().numpy().copy()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -275,6 +366,10 @@ def main():
     gc.enable()
     if run_log is not None:
         run_log = run_log.clone()
+    rows_timed = None
+    if tele_before is not None:  # codebook rows the timed frames scored (sparse scoring): claimed by particle waves + off the list
+        td = eng.telemetry.cpu().numpy()[:4].astype(np.int64) - tele_before[:4].astype(np.int64)
+        rows_timed = {"by_particle_waves_per_frame": float(td[2]) / args.steps, "off_prediction_list_per_frame": float(td[3]) / args.steps}
     ms_per_step = dt / args.steps * 1e3
     status = eng.status.cpu().numpy().tolist()
     # the same engine with the resampled particle set materialised (read) after every frame: three launches per frame
@@ -311,6 +406,11 @@ def main():
     loop_rate = None
     if not sharded and not args.no_loop:
         loop_rate = reference_loop_rate(cb, traj, N, dev, tree, eng.tree3)
+        loop_rate["note"] = ("the reference's annealing floor (1000) lets the set shrink to N_final within about ten frames, so this is "
+                             "mostly a small-N figure; floor_N holds all N particles (the rate a caller sees who never lets the set anneal): "
+                             "bound by its DBSCAN frames (every 50th, ms_frame_max)")
+        if not args.no_extras:
+            loop_rate["floor_N"] = reference_loop_rate(cb, traj, N, dev, tree, eng.tree3, T=110, floor=N)
     exchange_info = None
     if sharded:
         exchange_info = {"form": eng.exchange, "peer_mapping": "ok" if eng.exchange == "peer" else (eng.peer_error or "not tried")}
@@ -345,6 +445,7 @@ def main():
                    "steps_per_sec_materialised_every_frame": eager_rate,
                    "reference_loop_frames_per_sec": loop_rate,
                    "per_step": step_stats, "per_step_in_timed_call": run_stats, "diffuse_regime": diffuse, "exchange": exchange_info,
+                   "rows_scored_in_timed_region": rows_timed,
                    "tree_search_fallbacks_per_frame": {"nn": tele[0] / frames_run, "prune": tele[1] / frames_run}},
     }
 
@@ -352,37 +453,54 @@ def main():
     if not sharded and not args.no_profile:
         # one kernel bracketed at a time (two events per frame) so the others run back to back
         names = ["score_codebook", "particle_update", "tail_a", "tail_b"]
-        per, fi = {}, args.warmup + 3 * args.steps
-        for slot, name in enumerate(names):
-            eng.profile(True, only_slot=slot)
-            eng.profile_read(reset=True)
-            for i in range(NPROF):
-                frame(fi)
-                fi += 1
-            ms, calls = eng.profile_read(reset=True)
-            # an empty event pair recorded in the same frames measures the bracketing overhead; remove it
-            per[name] = max(ms[name] - ms["event_pair_overhead"], 0.0) / calls
-            per.setdefault("event_pair_overhead", ms["event_pair_overhead"] / calls)
-        eng.profile(False)
+        fi = args.warmup + 3 * args.steps
+
+        def kernel_pass(slots):
+            nonlocal fi
+            per_ = {}
+            for slot in slots:
+                eng.profile(True, only_slot=slot)
+                eng.profile_read(reset=True)
+                for i in range(NPROF):
+                    frame(fi)
+                    fi += 1
+                ms, calls = eng.profile_read(reset=True)
+                # an empty event pair recorded in the same frames measures the bracketing overhead; remove it
+                per_[names[slot]] = max(ms[names[slot]] - ms["event_pair_overhead"], 0.0) / calls
+                per_.setdefault("event_pair_overhead", ms["event_pair_overhead"] / calls)
+            eng.profile(False)
+            return per_
+
+        tele_p0 = eng.telemetry.cpu().numpy()[:4].astype(np.int64)
+        per = kernel_pass(range(4))
+        tele_p1 = eng.telemetry.cpu().numpy()[:4].astype(np.int64)
+        rows_prof = float((tele_p1[2] - tele_p0[2]) + (tele_p1[3] - tele_p0[3])) / (4 * NPROF)
         overhead = per.pop("event_pair_overhead")
         fused = per["score_codebook"] == 0.0  # the scoring shares the launch of the particle update (k_frame_front)
+        sparse = bool(getattr(eng, "sparse_scores", False))
+        row_bytes = 4 * D + 8 + 24  # embedding row + its norm + the entry's 6-d feature (first record of its neighbour list)
         if fused:
             per = {"frame_front": per["particle_update"], "tail_a": per["tail_a"], "tail_b": per["tail_b"]}
             if per["tail_b"] == 0.0:  # pipelined: no separate resample launch
                 per.pop("tail_b")
             groups = {"frame_front": per["frame_front"], "tail": per["tail_a"] + per.get("tail_b", 0.0)}
-            # algorithmic bytes of the front: scoring + particle update (+ the folded resample's share when pipelined)
-            ab["frame_front"] = ab["score_codebook"] + ab["particle_update"] + (0 if "tail_b" in per else N * PER_PARTICLE_FOLDED)
+            folded = 0 if "tail_b" in per else N * PER_PARTICLE_FOLDED
+            # SURVEY 8(d)'s model charges all K rows to every frame; the kernel needs the rows some particle's nearest entry
+            # points at (measured: telemetry [2] + [3]), so its own byte count is per-particle bytes + those rows
+            ab["frame_front"] = ab["score_codebook"] + ab["particle_update"] + folded
+            needed = N * PER_PARTICLE_UPDATE + folded + (rows_prof * row_bytes if sparse else ab["score_codebook"] + K * 24)
             dom = "frame_front"
         else:
             groups = {"score_codebook": per["score_codebook"], "particle_update": per["particle_update"],
                       "tail": per["tail_a"] + per["tail_b"]}
             dom = max(("score_codebook", "particle_update"), key=lambda k: groups[k])
-        achieved = ab[dom] / (groups[dom] * 1e-3) / 1e9
+            needed = ab[dom]
+        achieved = needed / (groups[dom] * 1e-3) / 1e9
+        survey = ab[dom] / (groups[dom] * 1e-3) / 1e9
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (PMC counters
-        # cannot be read from inside the process): profiles/r02_traffic.json, tools/pmc_traffic.sh
+        # cannot be read from inside the process): profiles/r03_traffic.json, tools/pmc_traffic.sh
         traffic, traffic_src = None, None
-        for name in ("r02_traffic.json", "r01_traffic.json"):
+        for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(REPO, "profiles", name)))
                 traffic, traffic_src = tj["kernels"][dom]["hbm_bytes"], "profiles/" + name
@@ -391,14 +509,32 @@ def main():
                 pass
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                           "algorithmic_bytes_per_launch": ab[dom], "kernel_ms": groups[dom],
+                           "algorithmic_bytes_per_launch": needed, "kernel_ms": groups[dom],
+                           "rows_scored_per_launch": rows_prof if sparse else float(K),
                            "per_kernel_ms": per, "event_pair_overhead_ms": overhead,
-                           "step_bytes": ab["step"],
-                           "step_frac": ab["step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "note": "achieved = SURVEY.md 8(d) algorithmic bytes (which charge all K rows of the codebook to every "
-                                   "step) / kernel time; with sparse scoring the kernel touches only the rows in use, so `traffic` "
-                                   "(PMC) is BELOW the algorithmic bytes and the kernel is bound by the dependent-fetch chain of a "
-                                   "particle wave, not by bandwidth (DESIGN.md section 4)"}
+                           "frac_survey_model": survey / HBM_PEAK_GBS, "survey_model_bytes_per_launch": ab[dom],
+                           "step_bytes_survey_model": ab["step"],
+                           "step_frac_survey_model": ab["step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "note": "achieved = bytes this launch has to move / its HIP-event time: N x (140 update + 80 folded resample) + "
+                                   "rows x (4 D + 32), rows = codebook rows actually scored per frame (sparse scoring: the rows some particle's "
+                                   "nearest entry points at, counted by the kernels) - the kernel is bound by the dependent-fetch chain of a "
+                                   "particle wave, not by bandwidth (DESIGN.md section 4).  frac_survey_model keeps SURVEY.md 8(d)'s byte model, "
+                                   "which charges all K rows of the codebook to every frame although the sparse kernel does not read them; "
+                                   "roofline.dense is the same frame with every row streamed (the K1 GEMV the north-star names)"}
+        if fused and sparse and not args.no_extras:
+            # the dense K1 beside it: every codebook row streamed by the front kernel (horizontal fusion, MIDAS_DENSE_SCORES=1 form) -
+            # what a caller with the heat-map on runs every frame (filter/filter.py:213-215); the survey model's bytes are real here
+            eng.sparse_scores = False
+            for i in range(10):
+                frame(fi)
+                fi += 1
+            dper = kernel_pass([1, 2])
+            eng.sparse_scores = True
+            d_ms = dper["particle_update"]
+            out["roofline"]["dense"] = {"kernel": "frame_front with the codebook stream (all K rows)", "kernel_ms": d_ms,
+                                        "algorithmic_bytes_per_launch": ab["frame_front"], "achieved": ab["frame_front"] / (d_ms * 1e-3) / 1e9,
+                                        "frac": ab["frame_front"] / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "tail_a_ms": dper["tail_a"],
+                                        "score_stream_bytes": ab["score_codebook"]}
     if sharded:
         # no per-kernel event passes in the sharded frame: the step-level figure per GPU (each rank moves the algorithmic
         # bytes of its own N particles and of the whole replicated codebook every frame)
@@ -407,8 +543,14 @@ def main():
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                            "algorithmic_bytes_per_launch": ab["step"], "kernel_ms": ms_per_step, "step_bytes": ab["step"],
                            "step_frac": achieved / HBM_PEAK_GBS}
+    if not sharded and not args.no_extras:
+        out["config"]["parity_mode"] = parity_mode_rate(cb, traj, N, dev, tree, eng.tree3)
+        if N == 100_000 and K == 50_000 and D == 512:  # beside the headline workload only
+            out["config"]["c5"] = config5_rate(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cb, traj, N)
+        if not sharded and not args.eager and args.resample == "weighted_random":
+            out["cpu_baseline"]["parity_probe"] = parity_probe(eng, N, 4000)
     if rank == 0:
         try:  # anything native libraries left in the C stdio buffer goes out first: the JSON line is the last line
             import ctypes

@@ -218,7 +218,7 @@ typedef struct midas_step_args {
     int32_t softmax;
     int32_t resample_mode;
     int32_t* status_dev;         /* [0] cdf status (see midas_cdf), [1] particles kept by the prune */
-    uint64_t* telemetry_dev;     /* NULL or 16 cumulative counters: [0],[1] particles whose NN / prune needed the tree search; [2..15] scan statistics and phase clocks (MIDAS_ABLATE=4) */
+    uint64_t* telemetry_dev;     /* NULL or 16 cumulative counters: [0],[1] particles whose NN / prune needed the tree search; [2] codebook rows scored by particle waves (sparse scoring: first particle on a row), [3] rows scored off the prediction list; the rest reserved (profiling builds keep per-wave statistics behind them, MIDAS_ABLATE=4) */
     uint32_t* score_stamps_dev;  /* NULL: every codebook row is scored every frame.  Else K uint32 stamps, zeroed once by the caller, together with
                                     * score_epoch (non-zero, different on every frame that uses these stamps): only the rows that are
                                     * some particle's nearest entry are scored - by the particle kernels themselves, same arithmetic,

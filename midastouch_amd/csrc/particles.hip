@@ -1860,6 +1860,7 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
     }
     if (mv >= 0) ok = mv == 1;
     if (MIDAS_CLAIM_DEFER && a.sp.stamps && !(ablate & 16)) st_rows = score_claimed_rows_nj(a.sp, claim, bi);
+    if (a.telemetry && st_rows && lane == 0) atomicAdd(&a.telemetry[2], (unsigned long long)st_rows);  // rows scored by particle waves
     MIDAS_TICK(6);
     if (live) {
         a.nn_idx[n] = bi;
@@ -1962,6 +1963,10 @@ __global__ __launch_bounds__(64 * FW, (!SCR && FW == 1) ? MIDAS_BATCH_OCC : 1) v
             else particle_update_wave<false, SCREEN, PREF, STATS>(t6, t3, a, wave, nwaves, traj, s_cd[w], LAZY ? s_rs : nullptr);
         }
     } else if (a.sp.list) {  // prediction list: the rows the previous frame used, four per wave-instruction
+        if ((int)bx == n_pu && threadIdx.x == 0 && a.telemetry) {  // rows scored off the list (cumulative, for the bench's byte count)
+            const int c = *a.sp.list_count;
+            if (c > 0) atomicAdd(&a.telemetry[3], (unsigned long long)(c < a.sp.list_cap ? c : a.sp.list_cap));
+        }
         score_list_wave<NJ>(a.sp, (int)(bx - n_pu) * FW + w, ((int)gridDim.x - n_pu) * FW);
     } else {
         score_wave<T, NJ, 0>(emb, norms, code, scores, K, (int64_t)(bx - n_pu) * FW + w);
@@ -2163,7 +2168,10 @@ __global__ __launch_bounds__(256, MIDAS_NNP_OCC) void k_particle_nn_prune(TreeVi
     RowClaim claim{false, 0u};
     if (a.sp.stamps) {
         claim = claim_rows_issue(a.sp, owner && live, nn);
-        if (!MIDAS_CLAIM_DEFER) score_claimed_rows_nj(a.sp, claim, nn);
+        if (!MIDAS_CLAIM_DEFER) {
+            const int nr = score_claimed_rows_nj(a.sp, claim, nn);
+            if (a.telemetry && nr && lane == 0) atomicAdd(&a.telemetry[2], (unsigned long long)nr);
+        }
     }
     if (a.vlist) {
         Point3 ph;

@@ -1,14 +1,19 @@
 #!/bin/bash
-# End-of-round artefacts (GPU box): GPU test log, bench line, rocprofv3 kernel statistics (steady state, default bench, c5), per-launch
-# trace statistics of the front, other configs, the reference-named loop.  usage: tools/round_end.sh <tag>   -> gpurun_out/<tag>_*
+# End-of-round artefacts (GPU box): GPU test log, the bench line with the DRIVER'S flags (--gpus 1 --steps 20 --warmup 5: what
+# BENCH_rNN records) and with 200 steps, rocprofv3 kernel statistics of both, per-launch statistics of the driver's timed region,
+# HBM traffic (PMC passes), other configs, the reference-named loop.  usage: tools/round_end.sh <tag>   -> gpurun_out/<tag>_*
 cd "$(dirname "$0")/.."
 T=${1:-rXX}
-python -m pytest tests -m gpu -x -q > gpurun_out/${T}_gputests.log 2>&1; grep -aE "passed|failed" gpurun_out/${T}_gputests.log
-python bench.py > gpurun_out/${T}_bench_line.json 2> gpurun_out/${T}_bench.err; cut -c1-300 gpurun_out/${T}_bench_line.json
-tools/prof_stats.sh ${T}_steady 300 python bench.py --steps 200 --warmup 100 --no-cpu-baseline --no-loop --no-diffuse | head -8
+python -m pytest tests -m gpu -q > gpurun_out/${T}_gputests.log 2>&1; grep -aE "passed|failed" gpurun_out/${T}_gputests.log
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${T}_bench_driver_line.json 2> gpurun_out/${T}_bench_driver.err; cut -c1-300 gpurun_out/${T}_bench_driver_line.json
+python bench.py --no-cpu-baseline --no-extras > gpurun_out/${T}_bench_line_200.json 2> gpurun_out/${T}_bench_200.err; cut -c1-300 gpurun_out/${T}_bench_line_200.json
+tools/prof_stats.sh ${T}_driver 400 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-loop | head -8
+f=$(find gpurun_out/prof_${T}_driver -name "*kernel_trace.csv" | head -1)
+[ -n "$f" ] && python tools/driver_trace_stats.py $f 5 20 gpurun_out/${T}_driver_trace.json | head -30
+tools/prof_stats.sh ${T}_steady 300 python bench.py --steps 200 --warmup 100 --no-cpu-baseline --no-loop --no-diffuse --no-extras | head -8
 f=$(find gpurun_out/prof_${T}_steady -name "*kernel_trace.csv" | head -1)
 [ -n "$f" ] && python tools/front_trace_stats.py $f 200 gpurun_out/${T}_front_trace.json
-tools/prof_stats.sh ${T}_bench 400 python bench.py --no-cpu-baseline | head -6
+tools/pmc_traffic.sh ${T}_traffic > gpurun_out/${T}_pmc_traffic_summary.txt 2>&1; python tools/make_traffic_json.py gpurun_out/pmc_${T}_traffic gpurun_out/${T}_traffic.json | head -20
 tools/prof_stats.sh ${T}_c5 300 python tools/bench_c5.py | head -8
 python tools/bench_configs.py > gpurun_out/${T}_other_configs.json 2> gpurun_out/${T}_other_configs.err; cat gpurun_out/${T}_other_configs.json | cut -c1-600
 python tools/bench_filter_loop.py > gpurun_out/${T}_filter_loop.jsonl 2>&1; tail -2 gpurun_out/${T}_filter_loop.jsonl | cut -c1-400
