@@ -340,13 +340,15 @@ def main():
                    "tree_search_fallbacks_per_frame": {"nn": float(tele1[0] - tele0[0]) / ND, "prune": float(tele1[1] - tele0[1]) / ND},
                    "note": "per-step HIP events (one step per call), frames 1..20 after init_filter(gt_0, N) + projection"}
         wide_init(100 + rank)
-    frames(0, args.warmup)
-    torch.cuda.synchronize()
     # the interpreter's cyclic collector walks ~10^6 objects of the imported libraries when a generation-2 pass falls into
-    # the timed region (tens of ms against a 5 - 10 ms region: seen in 3 of 12 runs); it is parked for the measurement
+    # the timed region (tens of ms against a 1 - 10 ms region: seen in 3 of 12 runs); it is parked for the measurement -
+    # BEFORE the warm-up frames: a collection takes a few hundred ms during which the device idles and clocks down, and the
+    # first launches after such a pause were slow enough to add 0.2 ms to a 1 ms timed region
     import gc
     gc.collect()
     gc.disable()
+    frames(0, args.warmup)
+    torch.cuda.synchronize()
     tele_before = None if sharded else eng.telemetry.cpu().numpy().copy()
     if dist is not None:
         dist.barrier()

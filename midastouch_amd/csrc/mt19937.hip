@@ -10,7 +10,8 @@
 // generator's state lives in device memory and a single workgroup advances it: the recurrence
 //     x[k+624] = x[k+397] ^ twist(x[k], x[k+1])
 // is sequential from block to block (624 words) but parallel inside one in three phases (k < 227 reads only old words,
-// 227 <= k < 454 reads the new words of phase one, the rest those of phase two), so a block costs three barriers.
+// 227 <= k < 454 reads the new words of phase one, the rest those of phase two), so a block costs three barriers; a block's
+// 312 doubles are written out beside the first phase of the next block.
 // Pure 32-bit integer arithmetic: the words equal at::mt19937's bit for bit (tests: against torch.rand / torch.manual_seed).
 #include "midas_internal.hpp"
 
@@ -31,21 +32,6 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
-// next block of 624 words: old -> nw (two LDS buffers: no word is overwritten while somebody may still read it)
-__device__ __forceinline__ void mt_twist(const uint32_t* old, uint32_t* nw) {
-    const int t = threadIdx.x;
-    if (t < MT_N - MT_M) nw[t] = mt_mix(old[t], old[t + 1], old[t + MT_M]);
-    __syncthreads();
-    if (t < MT_N - MT_M) { const int k = t + (MT_N - MT_M); nw[k] = mt_mix(old[k], old[k + 1], nw[k - (MT_N - MT_M)]); }
-    __syncthreads();
-    {
-        const int k = t + 2 * (MT_N - MT_M);
-        if (k < MT_N - 1) nw[k] = mt_mix(old[k], old[k + 1], nw[k - (MT_N - MT_M)]);
-        else if (k == MT_N - 1) nw[k] = mt_mix(old[k], nw[0], nw[MT_M - 1]);
-    }
-    __syncthreads();
-}
-
 // state: [0, 624) the current block (already twisted), [624] = words of it consumed so far (624: a new block is due)
 __global__ __launch_bounds__(1) void k_mt_seed(uint32_t seed, uint32_t* __restrict__ state) {
     uint32_t x = seed;
@@ -58,59 +44,82 @@ __global__ __launch_bounds__(1) void k_mt_seed(uint32_t seed, uint32_t* __restri
     state[MT_N + 1] = 0;
 }
 
-__global__ __launch_bounds__(256) void k_mt_rand64(uint32_t* __restrict__ state, long long skip, long long N, double* __restrict__ out) {
-    __shared__ uint32_t s_a[MT_N], s_b[MT_N];
+// One workgroup of MT_THREADS threads.  The two blocks live in ONE LDS array indexed by a toggle (two arrays behind swapped
+// pointers made the compiler address them with flat instructions).  A block costs three barriers: the doubles of the block
+// before it are written out beside phase one of the next (they read the old buffer only).
+constexpr int MT_THREADS = 320, MT_P = MT_N - MT_M;  // 227 words per phase
+struct MtEmit { int pos, end; long long gw; bool more; };  // words [pos, end) of the block; gw = stream index of word `pos`; more: the stream goes on
+
+__global__ __launch_bounds__(MT_THREADS) void k_mt_rand64(uint32_t* __restrict__ state, long long skip, long long N, double* __restrict__ out) {
+    __shared__ uint32_t s_mt[2][MT_N];
     __shared__ uint32_t s_carry;
     const int t = threadIdx.x;
-    for (int k = t; k < MT_N; k += 256) s_a[k] = state[k];
+    for (int k = t; k < MT_N; k += MT_THREADS) s_mt[0][k] = state[k];
     int pos = (int)state[MT_N];
+    int b = 0;
     __syncthreads();
-    uint32_t *cur = s_a, *nxt = s_b;
+    auto phase_a = [&]() { if (t < MT_P) s_mt[b ^ 1][t] = mt_mix(s_mt[b][t], s_mt[b][t + 1], s_mt[b][t + MT_M]); };
+    auto phase_b = [&]() { if (t < MT_P) { const int k = t + MT_P; s_mt[b ^ 1][k] = mt_mix(s_mt[b][k], s_mt[b][k + 1], s_mt[b ^ 1][t]); } };
+    auto phase_c = [&]() {
+        const int k = t + 2 * MT_P;
+        if (k < MT_N - 1) s_mt[b ^ 1][k] = mt_mix(s_mt[b][k], s_mt[b][k + 1], s_mt[b ^ 1][k - MT_P]);
+        else if (k == MT_N - 1) s_mt[b ^ 1][k] = mt_mix(s_mt[b][k], s_mt[b ^ 1][0], s_mt[b ^ 1][MT_M - 1]);
+    };
+    // 2 N words -> N doubles: (hi << 32 | lo) & (2^53 - 1), times 2^-53 (at::uniform_real_distribution<double>); hi = even stream index
+    auto emit = [&](const MtEmit& e) {
+        const uint32_t* cur = s_mt[b];
+        const int odd = (int)(e.gw & 1);
+        if (odd && t == MT_THREADS - 1) {  // the block starts with the low word of a value whose high word ended the block before
+            const unsigned long long r = (((unsigned long long)s_carry << 32) | mt_temper(cur[e.pos])) & ((1ull << 53) - 1ull);
+            out[e.gw >> 1] = (double)r * 1.1102230246251565e-16;
+        }
+        const int o = e.pos + odd + 2 * t;
+        if (o < e.end) {
+            const uint32_t hi = mt_temper(cur[o]);
+            if (o + 1 < e.end) {
+                const unsigned long long r = (((unsigned long long)hi << 32) | mt_temper(cur[o + 1])) & ((1ull << 53) - 1ull);
+                out[(e.gw + (o - e.pos)) >> 1] = (double)r * 1.1102230246251565e-16;
+            } else {
+                s_carry = hi;  // its partner is the first word of the next block
+            }
+        }
+    };
     // skip: whole blocks are twisted over, the rest is an offset
     while (skip > 0) {
         const int avail = MT_N - pos;
         if (skip >= avail) {
             skip -= avail;
-            mt_twist(cur, nxt);
-            uint32_t* sw = cur; cur = nxt; nxt = sw;
+            phase_a(); __syncthreads(); phase_b(); __syncthreads(); phase_c(); __syncthreads();
+            b ^= 1;
             pos = 0;
         } else {
             pos += (int)skip;
             skip = 0;
         }
     }
-    // 2 N words -> N doubles: (hi << 32 | lo) & (2^53 - 1), times 2^-53 (at::uniform_real_distribution<double>)
     const long long W = 2 * N;
-    long long done = 0;
-    while (done < W) {
-        if (pos == MT_N) {
-            mt_twist(cur, nxt);
-            uint32_t* sw = cur; cur = nxt; nxt = sw;
+    long long gw = 0;
+    bool pend = false;
+    MtEmit pe{0, 0, 0, false};
+    while (true) {
+        if (pos == MT_N && gw < W) {
+            phase_a();
+            if (pend) { emit(pe); pend = false; }
+            __syncthreads(); phase_b(); __syncthreads(); phase_c(); __syncthreads();
+            b ^= 1;
             pos = 0;
         }
-        const long long left = W - done;
+        if (gw >= W) break;
+        const long long left = W - gw;
         const int m = (int)(left < (long long)(MT_N - pos) ? left : (long long)(MT_N - pos));
-        for (int i = t; i < m; i += 256) {
-            const long long gw = done + i;
-            const uint32_t w = mt_temper(cur[pos + i]);
-            if ((gw & 1) == 0) {
-                if (i + 1 < m) {
-                    const uint32_t lo = mt_temper(cur[pos + i + 1]);
-                    const unsigned long long r = (((unsigned long long)w << 32) | lo) & ((1ull << 53) - 1ull);
-                    out[gw >> 1] = (double)r * 1.1102230246251565e-16;
-                } else {
-                    s_carry = w;  // its partner is the first word of the next block
-                }
-            } else if (i == 0) {
-                const unsigned long long r = (((unsigned long long)s_carry << 32) | w) & ((1ull << 53) - 1ull);
-                out[gw >> 1] = (double)r * 1.1102230246251565e-16;
-            }
-        }
-        done += m;
+        pe.pos = pos; pe.end = pos + m; pe.gw = gw; pe.more = left > m;
+        pend = true;
+        gw += m;
         pos += m;
-        __syncthreads();
     }
-    for (int k = t; k < MT_N; k += 256) state[k] = cur[k];
+    if (pend) emit(pe);
+    __syncthreads();
+    for (int k = t; k < MT_N; k += MT_THREADS) state[k] = s_mt[b][k];
     if (t == 0) state[MT_N] = (uint32_t)pos;
 }
 
@@ -122,7 +131,7 @@ int launch_mt_seed(midas_ctx* ctx, uint64_t seed, uint32_t* state) {
 
 int launch_mt_rand64(midas_ctx* ctx, uint32_t* state, int64_t skip_words, int64_t N, double* out) {
     if (N == 0 && skip_words == 0) return MIDAS_OK;
-    hipLaunchKernelGGL(k_mt_rand64, dim3(1), dim3(256), 0, ctx->stream, state, (long long)skip_words, (long long)N, out);
+    hipLaunchKernelGGL(k_mt_rand64, dim3(1), dim3(MT_THREADS), 0, ctx->stream, state, (long long)skip_words, (long long)N, out);
     MIDAS_HIP_CHECK(ctx, hipGetLastError());
     return MIDAS_OK;
 }
