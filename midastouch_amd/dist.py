@@ -249,7 +249,7 @@ class ShardState:
         ng = (N + 15) // 16
         self.tables = e((4 * (-(-N // 16) * 16) + 2 * (-(-ng // 16) * 16) + 32 * self.nb,), torch.float64)
         self.tables.zero_()
-        self.counts = e((3 * 64,), torch.int32)     # send counts | receive counts | scratch of the owner-side resample
+        self.counts = e((3 * 64 + 4,), torch.int32)  # send counts | receive counts | scratch of the owner-side resample | [3 G]: overflow rows (fixed-capacity form); G <= 64
         self.scores = e((int(K),), torch.float64)   # the frame's codebook scores
         self.valid = e((N,), torch.uint8)
         self.hint = e((N,), torch.int32)
@@ -370,6 +370,12 @@ class ShardedFilterEngine:
         # traffic is whatever the weight distribution makes it - counted exchange there)
         auto = "allgather" if self.world < 4 else ("a2a_fixed" if self.mode == _lib.RESAMPLE_MULTINOMIAL else "a2a")
         self.exchange = auto if exchange == "auto" else exchange
+        if self.world > 64:
+            raise MidasError("at most 64 particle shards (the per-pair counters of the exchange hold 64 ranks)")
+        # fixed-capacity form: the overflow block's fill of every frame is copied to pinned host memory behind the frame and
+        # looked at before the next one and before anything of the particle set is read (no synchronisation of its own)
+        self._ovf_host = None
+        self._ovf_pending = [None, None]
         # "peer": rows stored straight into the destination's memory (inboxes mapped into every process, xGMI), RCCL only
         # carries the block records and a barrier.  Ranks in separate processes connect here (a collective); it is what
         # "auto" picks under RCCL when the start-up self test of the mapped path passes on every rank.  Shards of one process
@@ -420,15 +426,81 @@ class ShardedFilterEngine:
         return ok
 
     # convenience views used by bench.py / tests (same names as FilterEngine)
-    poses = property(lambda self: self.st.poses)
-    poses_prop = property(lambda self: self.st.poses_prop)
-    weights = property(lambda self: self.st.weights)
-    weights_res = property(lambda self: self.st.weights_res)
-    nn_idx = property(lambda self: self.st.nn_idx)
-    hint = property(lambda self: self.st.hint)
-    ridx = property(lambda self: self.st.ridx)
-    status = property(lambda self: self.st.status)
-    rmse = property(lambda self: self.st.rmse)
+    def _view(name):
+        def get(self):
+            self._check_overflow(wait=True)  # a frame that lost rows must not be read as if it were whole
+            return getattr(self.st, name)
+        return property(get)
+
+    poses = _view("poses")
+    poses_prop = _view("poses_prop")
+    weights = _view("weights")
+    weights_res = _view("weights_res")
+    nn_idx = _view("nn_idx")
+    hint = _view("hint")
+    ridx = _view("ridx")
+    status = _view("status")
+    rmse = _view("rmse")
+    del _view
+
+    # -- fixed-capacity exchange: rows beyond segment + overflow capacity are LOST (the kernel cannot grow a buffer): loud ----
+    def _watch_overflow(self):
+        """Behind a frame of the fixed-capacity form: its overflow count goes to one of two pinned slots; the slot's previous
+        tenant (the frame two back, long finished - the host never runs that far ahead of a frame's collectives) is looked at
+        first.  No synchronisation beyond that."""
+        st, G = self.st, self.world
+        if self._ovf_host is None:
+            z = torch.zeros(2, dtype=torch.int32)
+            self._ovf_host = z.pin_memory() if st.counts.is_cuda else z
+            self._ovf_pending = [None, None]  # per slot: (frame, event)
+        k = self.step_count & 1
+        self._check_slot(k, wait=True)
+        self._ovf_host[k:k + 1].copy_(st.counts[3 * G:3 * G + 1], non_blocking=True)
+        ev = None
+        if st.counts.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+        self._ovf_pending[k] = (self.step_count, ev)
+
+    def _check_slot(self, k, wait):
+        pend = self._ovf_pending[k]
+        if pend is None:
+            return
+        frame, ev = pend
+        if ev is not None:
+            if wait:
+                ev.synchronize()
+            elif not ev.query():
+                return
+        self._ovf_pending[k] = None
+        n = int(self._ovf_host[k])
+        if n > self.ovf_cap:
+            raise MidasError(f"exchange='a2a_fixed': frame {frame} needed {n} overflow rows, the block holds {self.ovf_cap} - "
+                             f"{n - self.ovf_cap} resampled particles were lost (one rank owns much more than 1/{self.world} of the "
+                             "weight mass).  Use exchange='a2a' (counted segments) or 'peer' for such clouds")
+
+    def _check_overflow(self, wait: bool = False):
+        """Raises when the fixed-capacity exchange of a finished frame dropped rows (one rank owned far more than 1 / G of the
+        weight mass): that frame's particle set is incomplete and every later frame builds on it."""
+        if self._ovf_host is None:
+            return
+        for k in (0, 1):
+            self._check_slot(k, wait)
+
+    def close(self):
+        """Release the peer-mapped inbox and the interprocess mappings (fine-grained device memory is not returned by the
+        garbage collector)."""
+        if getattr(self.st, "_inbox", None) or getattr(self.st, "_opened", None):
+            try:
+                self.backend.peer_release(self.st)
+            except Exception:
+                pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def set_particles(self, poses):
         poses = torch.as_tensor(poses).to(self.st.poses.device, torch.float32)
@@ -477,6 +549,7 @@ class ShardedFilterEngine:
             recv = yield ("a2a", send, eq, eq)
             ovf_all = yield ovf
             b.unpack_fixed(st, recv, ovf_all, self.rank)
+            self._watch_overflow()
         elif self.exchange == "peer":
             if st._peers is None:
                 raise MidasError("peer-mapped exchange: the inboxes are not connected (connect_peers / connect_local_peers)")

@@ -157,64 +157,66 @@ def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str
     import gc
     gc.collect()
     gc.freeze()  # the libraries' ~10^6 long-lived objects out of the collector's way: no 30 ms pass in the middle of a run
-    while True:
-        if pace == "wallclock":
-            idx = int(frame_rate * total_time)
-        else:
-            idx = fixed_idx
-            fixed_idx += 1
-        if idx >= traj_size:
-            break
-        if count and count % eng.log_frames == 0:
-            # wall-clock pace on a fast host repeats frames: more iterations than the engine's frame log (a ring) holds
-            records.extend(eng.read_log(count - eng.log_frames, count))
-        start = time.time()
-        moving = prev_idx > 0
-        if not moving:  # (filter.py:152,156-160) - like the reference, frames seen while prev_idx == 0 re-initialise
-            particles = pf.init_filter(gt_p[idx, :], init_particles)
-            eng.set_particles(particles.poses, reset_annealing=count == 0)
-            eng.project_to_codebook()
-            odom = eye
-        else:
-            odom = step_odoms[prev_idx] if idx == prev_idx + 1 else inv_meas[prev_idx] @ meas_p[idx, :]
-        unit = count % max(int(update_freq), 1) != 0  # filter_real.py:205-212: no measurement update on this frame
-        kw = dict(gt=gt_p[idx, :], dbscan=cluster and count % 50 == 0, unit_weights=unit, std_override=None if moving else (0.0, 0.0))
-        if draws == "host":
-            n = eng.n
-            std_t, std_r = (pf.motion_noise["sig_t"], pf.motion_noise["sig_r"]) if moving else (0.0, 0.0)
-            if moving:  # add_noise_to_odom's draws, its order (:326-335); the initial frames draw inside init_filter
-                kw["tn"] = torch.normal(mean=pf.motion_noise["mu"], std=std_t, size=(n, 3))
-                kw["rot"] = torch.normal(mean=pf.motion_noise["mu"], std=std_r, size=(n, 3))
+    try:
+        while True:
+            if pace == "wallclock":
+                idx = int(frame_rate * total_time)
             else:
-                kw["tn"], kw["rot"] = torch.zeros((n, 3)), torch.zeros((n, 3))
-            eng.step(odom, seq.codes[idx], phases=_lib.LOOP_FRONT | _lib.LOOP_DBSCAN | _lib.LOOP_ANNEAL, **kw)
-            n_set = int(eng.ctl_i[_lib.LOOP_I_NSET].item())
-            eng.step(None, None, u=torch.rand(n_set, dtype=torch.float64), phases=_lib.LOOP_RESAMPLE)  # multinomial's stream
-        else:
-            eng.step(odom, seq.codes[idx], **kw)
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record()
-        events.append(ev)
-        if every_frame:
-            ev.synchronize()
-            total_time += events[-2].elapsed_time(ev) * 1e-3 if pace != "wallclock" else time.time() - start
-        if viz is not None:
-            heatmap_weights = pf.get_similarity(seq.codes[idx][None], heatmap_embeddings, softmax=False)
-            rec = eng.frame_view()
-            # the visualiser reads particles.poses asynchronously (viz/visualizer.py:329-361): hand it a snapshot
-            snap = Particles(rec["poses"].clone(), rec["weights_res"].clone(), rec["labels"].clone())
-            viz.update(snap, torch.as_tensor(rec["cluster_poses"]), torch.as_tensor(rec["cluster_stds"]), gt_p[idx, :], heatmap_poses,
-                       heatmap_weights, None, None, None, idx)
-        if progress:
-            rec = eng.read_log(count, count + 1)[0]
-            print(f"[{idx}] RMSE {1000 * rec['rmse_t']:.1f} mm {rec['rmse_r']:.0f} deg P {rec['n_after']} "
-                  f"rate {1.0 / max(events[-2].elapsed_time(ev) * 1e-3, 1e-9):.1f} Hz")
-        motion_time.append(time.time() - start)
-        frame_idx.append(idx)
-        prev_idx = idx
-        count += 1
-    torch.cuda.synchronize(device)
-    gc.unfreeze()
+                idx = fixed_idx
+                fixed_idx += 1
+            if idx >= traj_size:
+                break
+            if count and count % eng.log_frames == 0:
+                # wall-clock pace on a fast host repeats frames: more iterations than the engine's frame log (a ring) holds
+                records.extend(eng.read_log(count - eng.log_frames, count))
+            start = time.time()
+            moving = prev_idx > 0
+            if not moving:  # (filter.py:152,156-160) - like the reference, frames seen while prev_idx == 0 re-initialise
+                particles = pf.init_filter(gt_p[idx, :], init_particles)
+                eng.set_particles(particles.poses, reset_annealing=count == 0)
+                eng.project_to_codebook()
+                odom = eye
+            else:
+                odom = step_odoms[prev_idx] if idx == prev_idx + 1 else inv_meas[prev_idx] @ meas_p[idx, :]
+            unit = count % max(int(update_freq), 1) != 0  # filter_real.py:205-212: no measurement update on this frame
+            kw = dict(gt=gt_p[idx, :], dbscan=cluster and count % 50 == 0, unit_weights=unit, std_override=None if moving else (0.0, 0.0))
+            if draws == "host":
+                n = eng.n
+                std_t, std_r = (pf.motion_noise["sig_t"], pf.motion_noise["sig_r"]) if moving else (0.0, 0.0)
+                if moving:  # add_noise_to_odom's draws, its order (:326-335); the initial frames draw inside init_filter
+                    kw["tn"] = torch.normal(mean=pf.motion_noise["mu"], std=std_t, size=(n, 3))
+                    kw["rot"] = torch.normal(mean=pf.motion_noise["mu"], std=std_r, size=(n, 3))
+                else:
+                    kw["tn"], kw["rot"] = torch.zeros((n, 3)), torch.zeros((n, 3))
+                eng.step(odom, seq.codes[idx], phases=_lib.LOOP_FRONT | _lib.LOOP_DBSCAN | _lib.LOOP_ANNEAL, **kw)
+                n_set = int(eng.ctl_i[_lib.LOOP_I_NSET].item())
+                eng.step(None, None, u=torch.rand(n_set, dtype=torch.float64), phases=_lib.LOOP_RESAMPLE)  # multinomial's stream
+            else:
+                eng.step(odom, seq.codes[idx], **kw)
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            events.append(ev)
+            if every_frame:
+                ev.synchronize()
+                total_time += events[-2].elapsed_time(ev) * 1e-3 if pace != "wallclock" else time.time() - start
+            if viz is not None:
+                heatmap_weights = pf.get_similarity(seq.codes[idx][None], heatmap_embeddings, softmax=False)
+                rec = eng.frame_view()
+                # the visualiser reads particles.poses asynchronously (viz/visualizer.py:329-361): hand it a snapshot
+                snap = Particles(rec["poses"].clone(), rec["weights_res"].clone(), rec["labels"].clone())
+                viz.update(snap, torch.as_tensor(rec["cluster_poses"]), torch.as_tensor(rec["cluster_stds"]), gt_p[idx, :], heatmap_poses,
+                           heatmap_weights, None, None, None, idx)
+            if progress:
+                rec = eng.read_log(count, count + 1)[0]
+                print(f"[{idx}] RMSE {1000 * rec['rmse_t']:.1f} mm {rec['rmse_r']:.0f} deg P {rec['n_after']} "
+                      f"rate {1.0 / max(events[-2].elapsed_time(ev) * 1e-3, 1e-9):.1f} Hz")
+            motion_time.append(time.time() - start)
+            frame_idx.append(idx)
+            prev_idx = idx
+            count += 1
+        torch.cuda.synchronize(device)
+    finally:
+        gc.unfreeze()  # also when a frame raises: a frozen collector would outlive the run
     records.extend(eng.read_log(len(records), count))
     for rec, e0, e1 in zip(records, events, events[1:]):
         filter_stats["rmse_t"].append(rec["rmse_t"])

@@ -267,6 +267,16 @@ class LoopEngine:
             L = rows[f % self.log_frames]
             npres = int(L[10])
             cl = L[16:16 + 19 * min(npres, 8)].reshape(-1, 19)
+            err = int(L[15])
+            if err & 2:
+                raise MidasError(f"frame {f}: the particle cloud exceeded the device DBSCAN's grid (128 cells of side 0.577 eps per axis) "
+                                 "or its 62-cluster limit - the labels, and the annealing driven by them, are not the reference's; "
+                                 "use a larger eps or cluster=False")
+            if err & 8:
+                import warnings
+                warnings.warn(f"frame {f}: {npres} cluster labels present, the log row keeps the centres of the first 8")
+            if err & 4:
+                raise MidasError(f"frame {f}: the live particle count exceeded the bound the launches were sized for")
             out.append(dict(frame=f, n=int(L[1]), n_after=int(L[2]), rmse_t=float(L[3]), rmse_r=float(L[4]), kept=int(L[5]),
                             drifted=bool(L[6]), status=int(L[7]), mode=int(L[8]), k=int(L[9]), clusters=npres, var=float(L[11]),
                             S=float(L[12]), raw=bool(L[13]), ncl=int(L[14]), err=int(L[15]),

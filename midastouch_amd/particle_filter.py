@@ -198,7 +198,16 @@ class particle_filter:
         the 6-d SE(3) logarithms on the host through sklearn like the reference."""
         particles = copy.copy(_particles)
         if method == "euclidean":
-            labels, _ = ops.dbscan(particles.poses, eps)
+            labels, info = ops.dbscan(particles.poses, eps)
+            if int(info[1].item()) != 0:
+                # the device grid (128 cells of side 0.577 eps per axis, 62 clusters) does not hold this cloud at this eps: its
+                # labels are not sklearn's.  Say so and do what the reference does (sklearn on the host, :215-217).
+                import warnings
+                from sklearn.cluster import DBSCAN
+                warnings.warn(f"cluster_particles: the cloud exceeds the device DBSCAN's grid at eps={eps} "
+                              f"(extent > {128 * 0.577 * eps:.3g} m or more than 62 clusters); clustering on the host like the reference")
+                data = particles.poses[:, :3, 3].cpu().numpy()
+                labels = torch.as_tensor(DBSCAN(eps=eps, min_samples=int(len(particles) / 5)).fit(data).labels_, device=particles.poses.device)
             particles.labels = labels.to(torch.int64)
             return particles
         if method != "logmap":

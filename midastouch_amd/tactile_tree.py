@@ -93,6 +93,7 @@ class tactile_tree:
         self.poses = torch.as_tensor(poses).float()
         self.cam_poses = torch.as_tensor(cam_poses).float()
         self.embeddings = torch.as_tensor(embeddings)
+        self.embedding_dtype = self.embeddings.dtype  # what the caller stored: the dtype gathers are returned in (:54-58)
         self.tree_size = self.poses.shape[0]
         self.logmap_pose = None
         self.tree, self._codebook = None, None
@@ -151,7 +152,8 @@ class tactile_tree:
     def SE3_NN(self, _query, nn=1):
         """Best SE(3) matches by R3 + log-map distance (reference :43-58): (poses, cam_poses, embeddings).  nn = 1 (what the
         filter asks for): (N,4,4), (N,4,4) and a lazy (N,D) view; nn > 1: the nn nearest per query in order, as the reference
-        returns them - (N,nn,4,4), (N,nn,4,4), (N,nn,D) float64 (squeezed for a single query, as the reference's indexing does)."""
+        returns them - (N,nn,4,4), (N,nn,4,4), (N,nn,D) in the dtype the embeddings were stored with (float64 in the reference's
+        codebooks; squeezed for a single query, as the reference's indexing does).  nn <= 64."""
         if nn == 1:
             idx = self.SE3_NN_idx(_query)
             return ops.gather_rows(self.poses, idx), ops.gather_rows(self.cam_poses, idx), NNCodes(self, idx)
@@ -162,7 +164,7 @@ class tactile_tree:
         flat = idx.reshape(-1)
         shape = (idx.shape[0], int(nn)) if idx.shape[0] > 1 else (int(nn),)
         return (ops.gather_rows(self.poses, flat).view(*shape, 4, 4), ops.gather_rows(self.cam_poses, flat).view(*shape, 4, 4),
-                ops.gather_rows(self.embeddings, flat).double().view(*shape, -1))
+                ops.gather_rows(self.embeddings, flat).to(self.embedding_dtype).view(*shape, -1))
 
     def get_poses(self):
         return self.poses, self.cam_poses
@@ -174,7 +176,7 @@ class tactile_tree:
         return EmbeddingMatrix(self)
 
     def get_embedding(self, idx):
-        return self.embeddings[idx, :].double()
+        return self.embeddings[idx, :].to(self.embedding_dtype)
 
     # -- on-disk container (replaces the dill pickle of build_codebook.py:136-137) --------
     def save(self, path: str):

@@ -158,3 +158,42 @@ def test_single_rank_process_group_nccl(dev, exchange):
             assert torch.equal(a.ridx, b.ridx) and torch.equal(a.weights, b.weights) and torch.equal(a.poses, b.poses)
     finally:
         dist.destroy_process_group()
+
+
+def test_fixed_capacity_exchange_is_loud_when_rows_are_lost(dev):
+    """exchange="a2a_fixed" with all the weight mass on ONE shard (the other shard's particles sit off the surface and are
+    pruned): every resampled slot draws its source from that shard, far beyond segment + overflow capacity.  The frame
+    cannot be completed in that form - it must say so (it used to keep stale rows silently), and the counted
+    form on the same cloud is exact."""
+    from midastouch_amd.dist import HipShardBackend, ShardedFilterEngine, run_lockstep
+    from midastouch_amd.engine import FilterEngine
+    from midastouch_amd._lib import MidasError
+    from midastouch_amd.synthetic import make_codebook, make_trajectory
+    shards, n_loc, K, D = 2, 4096, 3000, 256
+    N = shards * n_loc
+    cb = make_codebook(K=K, D=D, seed=1000)
+    traj = make_trajectory(cb, T=6, seed=2000)
+    rng = np.random.default_rng(4)
+    start = cb.poses[rng.integers(0, K, N)].copy()
+    start[n_loc:, :3, 3] += 0.05  # shard 1: 5 cm off the surface -> pruned (pen_max = 2 mm), zero weight
+    be = HipShardBackend(cb.poses, cb.embeddings, cb.mesh_vertices, dev)
+    od, code = torch.as_tensor(traj.odoms[1]).to(dev), torch.as_tensor(traj.codes[1]).to(dev)
+    engs = [ShardedFilterEngine(num_particles=n_loc, backend=be, comm=FakeComm(r, shards), exchange="a2a_fixed") for r in range(shards)]
+    for r, e in enumerate(engs):
+        e.set_particles(torch.as_tensor(start[r * n_loc:(r + 1) * n_loc]))
+    run_lockstep(engs, [((od, code), {}) for _ in engs])
+    # rank 0 owns every source: it sends n_loc rows to rank 1 (segment 1.5 n_loc / 2 + overflow n_loc / 4 < n_loc)
+    assert engs[0].seg_cap + engs[0].ovf_cap < n_loc
+    with pytest.raises(MidasError, match="a2a_fixed.*lost"):
+        for e in engs:
+            e.ridx  # reading the particle set of a frame that lost rows
+    # the counted form completes the same frame: equal to the fused engine
+    single = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, device=dev)
+    single.set_particles(torch.as_tensor(start))
+    single.step(od, code)
+    engs = [ShardedFilterEngine(num_particles=n_loc, backend=be, comm=FakeComm(r, shards), exchange="a2a") for r in range(shards)]
+    for r, e in enumerate(engs):
+        e.set_particles(torch.as_tensor(start[r * n_loc:(r + 1) * n_loc]))
+    run_lockstep(engs, [((od, code), {}) for _ in engs])
+    assert np.array_equal(torch.cat([e.ridx for e in engs]).cpu().numpy(), single.ridx.cpu().numpy())
+    assert int(single.status[1]) <= n_loc  # only shard 0's particles survived the prune
