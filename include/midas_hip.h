@@ -456,6 +456,63 @@ int midas_peer_probe_check(midas_ctx* ctx, const void* inbox_dev, int32_t G, int
 /* the N rows of this rank's inbox -> slots (reads that bypass the non-coherent caches) */
 int midas_shard_unpack_peer(midas_ctx* ctx, int64_t N, const void* inbox_dev, int32_t* ridx_dev, float* poses_out_dev,
                             double* weights_out_dev, int32_t* hint_out_dev);
+/* ---- the sharded frame by ONE call, on a library-owned RCCL communicator ------------------------------------------------
+ * The reference has no distributed code; BASELINE.json's north_star asks for the particle shards of a node to combine
+ * their per-shard weight sums "with an RCCL all-reduce ... over xGMI".  midas_comm wraps an ncclComm_t the LIBRARY owns
+ * (librccl opened with dlopen: rccl_path = the copy to use, e.g. the one torch has loaded; NULL = the loader's default):
+ *   midas_comm_unique_id   rank 0 obtains the 128-byte id and hands it to the others (any channel: a store, a file);
+ *   midas_comm_create      collective over the ranks (ncclCommInitRank);  midas_comm_all_gather: bytes % 8 == 0.
+ * midas_shard_step enqueues, on the context's stream and without returning to the host in between, the phases selected:
+ *   MIDAS_SHARD_PHASE_LOCAL     midas_shard_front + midas_shard_tail_a on this rank's particles (record r1_dev)
+ *   MIDAS_SHARD_PHASE_GATHER    ncclAllGather of the records -> r1_all_dev (G x (5 nb + 4) doubles); needs `comm`
+ *   MIDAS_SHARD_PHASE_ROUTE     owner-side resample straight into the peers' inboxes (midas_shard_route_pack, peer form),
+ *                               then this rank stores frame_tag into slot `rank` of the flag block of every inbox
+ *                               (G uint64 at inbox + flag_offset, flag_offset >= 88 N)
+ *   MIDAS_SHARD_PHASE_UNPACK    the unpack kernel waits until all G slots of its OWN inbox carry the tag (bounded: 2 s,
+ *                               then status[0] |= 16), then inbox -> slots - device-side flags over the mapped inboxes
+ *                               instead of a second collective.
+ * A caller without RCCL between its ranks (tests: two processes sharing one GPU) runs LOCAL, gathers the records itself,
+ * then runs ROUTE | UNPACK; shards of ONE process on one stream must run every shard's ROUTE before any UNPACK (a waiting
+ * kernel in front of the kernel it waits for would never end).  frame_tag must grow from frame to frame (the flag slots are
+ * never reset).
+ * midas_shard_run: T frames by one call (device draws; odom16_dev / code_dev / gt16_dev advance by one frame each, step,
+ * frame_tag and score_epoch by one).  The resampled particles land in poses_out_dev / hint_out_dev, which the engine
+ * passes as the next frame's poses_in_dev / hint_in_dev (the same buffers). */
+typedef struct midas_comm midas_comm;
+int midas_comm_unique_id(midas_ctx* ctx, const char* rccl_path, void* id128_out);
+int midas_comm_create(midas_ctx* ctx, const char* rccl_path, const void* id128, int32_t world, int32_t rank, midas_comm** out);
+int midas_comm_destroy(midas_comm* comm);
+int midas_comm_all_gather(midas_comm* comm, const void* send_dev, void* recv_dev, int64_t bytes);
+#define MIDAS_SHARD_PHASE_LOCAL 1
+#define MIDAS_SHARD_PHASE_GATHER 2
+#define MIDAS_SHARD_PHASE_ROUTE 4
+#define MIDAS_SHARD_PHASE_UNPACK 8
+typedef struct midas_shard_step_args {
+    midas_shard_front_args front;   /* as midas_shard_front (rmse_sums_dev = r1_dev + 5 nb + 2, flags_dev = r1_dev + 5 nb) */
+    int32_t softmax;
+    double* tables_dev;             /* as midas_shard_tail_a */
+    double* r1_dev;                 /* 5 nb + 4: this rank's record */
+    double* r1_all_dev;             /* G x (5 nb + 4) */
+    int32_t G, rank, resample_mode;
+    const double* u_all_dev;        /* NULL -> Philox, or G * N uniforms (the same on every rank) */
+    float u32;
+    int32_t* counts_dev;            /* 3 G + 1 ints of scratch */
+    double* weights_dev;            /* N out: masked weights before the resample */
+    double* rmse_dev;               /* NULL or 2 out */
+    void* const* peers_dev;         /* G inbox addresses as mapped into this process (midas_peer_open) */
+    void* inbox_dev;                /* this rank's inbox: N x 88 bytes of rows, then the flag block */
+    int64_t flag_offset;
+    uint64_t frame_tag;
+    int32_t* ridx_dev;              /* N out */
+    float* poses_out_dev;           /* N x 16 out */
+    double* weights_out_dev;        /* N out */
+    int32_t* hint_out_dev;          /* N out */
+} midas_shard_step_args;
+int midas_shard_step(midas_ctx* ctx, midas_comm* comm, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
+                     const midas_shard_step_args* args, int32_t phases);
+int midas_shard_run(midas_ctx* ctx, midas_comm* comm, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
+                    const midas_shard_step_args* first, int32_t T);
+
 /* ---- the all_gather form of the exchange (every rank materialises its slice of the global CDF and gathers every
  * shard's packed block; G-1 times the bytes of the owner-side form, no read-back of counts) ---- */
 /* midas_shard_tail_fin: softmax applied unless softmax == 0 or |max x - min x| over r1_all <= 1e-8 (then e := x);

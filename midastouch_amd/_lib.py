@@ -125,6 +125,20 @@ class ShardRouteArgs(C.Structure):
     ]
 
 
+class ShardStepArgs(C.Structure):
+    """midas_shard_step_args (include/midas_hip.h)."""
+
+    _fields_ = [
+        ("front", ShardFrontArgs),
+        ("softmax", C.c_int32), ("tables", C.c_void_p), ("r1", C.c_void_p), ("r1_all", C.c_void_p),
+        ("G", C.c_int32), ("rank", C.c_int32), ("resample_mode", C.c_int32),
+        ("u_all", C.c_void_p), ("u32", C.c_float),
+        ("counts", C.c_void_p), ("weights", C.c_void_p), ("rmse", C.c_void_p),
+        ("peers", C.c_void_p), ("inbox", C.c_void_p), ("flag_offset", C.c_int64), ("frame_tag", C.c_uint64),
+        ("ridx", C.c_void_p), ("poses_out", C.c_void_p), ("weights_out", C.c_void_p), ("hint_out", C.c_void_p),
+    ]
+
+
 class TailResampleArgs(C.Structure):
     """midas_tail_resample_args (include/midas_hip.h)."""
 
@@ -220,6 +234,12 @@ SIGNATURES = {
     "midas_shard_unpack_rows": (C.c_int, [_P, _I64, _P, _I32, _P, _P, _P, _P]),
     "midas_shard_unpack_fixed": (C.c_int, [_P, _I64, _P, _I64, _P, _I32, _I64, _P, _P, _P, _P, _P]),
     "midas_shard_unpack_peer": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P]),
+    "midas_comm_unique_id": (C.c_int, [_P, C.c_char_p, _P]),
+    "midas_comm_create": (C.c_int, [_P, C.c_char_p, _P, _I32, _I32, C.POINTER(C.c_void_p)]),
+    "midas_comm_destroy": (C.c_int, [_P]),
+    "midas_comm_all_gather": (C.c_int, [_P, _P, _P, _I64]),
+    "midas_shard_step": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(ShardStepArgs), _I32]),
+    "midas_shard_run": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(ShardStepArgs), _I32]),
     "midas_peer_alloc": (C.c_int, [_P, _I64, C.POINTER(C.c_void_p), _P]),
     "midas_peer_free": (C.c_int, [_P, _P]),
     "midas_peer_open": (C.c_int, [_P, _P, C.POINTER(C.c_void_p)]),

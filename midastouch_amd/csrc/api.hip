@@ -822,9 +822,16 @@ MIDAS_EXPORT int midas_lazy_flush_batch(midas_ctx* ctx, const midas_lazy_flush_a
 }
 
 // ---- particle-sharded step pieces -------------------------------------------------------------------
+static int shard_front_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
+                            const midas_shard_front_args* args);
 MIDAS_EXPORT int midas_shard_front(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
                                    const midas_tree* tree3, const midas_shard_front_args* args) {
     MIDAS_ENTER(ctx);
+    return shard_front_impl(ctx, cb, tree6, tree3, args);
+}
+
+static int shard_front_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
+                            const midas_shard_front_args* args) {
     MIDAS_REQUIRE(ctx, tree6 && tree3 && args && tree6->dim == 6 && tree3->dim == 3);
     const midas_shard_front_args& s = *args;
     MIDAS_REQUIRE(ctx, s.scores_ready || (cb && tree6->K == cb->K && s.code_dev));
@@ -1018,6 +1025,85 @@ MIDAS_EXPORT int midas_peer_probe_check(midas_ctx* ctx, const void* inbox_dev, i
     MIDAS_ENTER(ctx);
     MIDAS_REQUIRE(ctx, inbox_dev && G > 0 && G <= 64 && ok_dev);
     return launch_peer_probe(ctx, nullptr, inbox_dev, G, 0, nonce, ok_dev);
+}
+
+// ---- the sharded frame enqueued by ONE call, on a library-owned RCCL communicator ------------------------------------------
+struct midas_comm;
+extern "C" int midas_comm_all_gather(midas_comm* c, const void* send_dev, void* recv_dev, int64_t bytes);
+
+static int shard_step_impl(midas_ctx* ctx, midas_comm* comm, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
+                           const midas_shard_step_args& s, int32_t phases) {
+    MIDAS_REQUIRE(ctx, phases != 0 && (phases & ~15) == 0);
+    MIDAS_REQUIRE(ctx, s.front.N >= 256 && s.G >= 1 && s.G <= 64 && s.rank >= 0 && s.rank < s.G && s.tables_dev && s.r1_dev && s.r1_all_dev);
+    const int64_t N = s.front.N;
+    const int nb = (int)ceil_div(N, SCAN_BLOCK);
+    const int64_t rec = 5 * (int64_t)nb + 4;
+    int rc;
+    if (phases & MIDAS_SHARD_PHASE_LOCAL) {  // propagate / NN / prune / scoring, then the shard's softmax tables and its record
+        if ((rc = shard_front_impl(ctx, cb, tree6, tree3, &s.front))) return rc;
+        MIDAS_REQUIRE(ctx, (uintptr_t)s.tables_dev % 128 == 0);
+        if ((rc = launch_shard_tail_a(ctx, N, s.front.scores_dev, s.front.nn_idx_dev, s.front.valid_dev, s.softmax,
+                                      shard_tables_of(s.tables_dev, N), s.r1_dev, s.front.status_dev)))
+            return rc;
+    }
+    if (phases & MIDAS_SHARD_PHASE_GATHER) {  // one record per rank, in rank order, to every rank
+        MIDAS_REQUIRE(ctx, comm != nullptr);
+        if ((rc = midas_comm_all_gather(comm, s.r1_dev, s.r1_all_dev, rec * (int64_t)sizeof(double)))) return rc;
+    }
+    if (phases & (MIDAS_SHARD_PHASE_ROUTE | MIDAS_SHARD_PHASE_UNPACK))
+        MIDAS_REQUIRE(ctx, s.peers_dev && s.inbox_dev && s.flag_offset >= N * 88 && s.flag_offset % 8 == 0 && s.frame_tag != 0 &&
+                               s.counts_dev && s.weights_dev && s.ridx_dev && s.poses_out_dev && s.weights_out_dev && s.hint_out_dev);
+    if (phases & MIDAS_SHARD_PHASE_ROUTE) {  // owner-side resample into the peers' inboxes, then the completion flags
+        midas_shard_route_args r;
+        memset(&r, 0, sizeof(r));
+        r.N = N; r.G = s.G; r.rank = s.rank;
+        r.r1_all_dev = s.r1_all_dev; r.tables_dev = s.tables_dev; r.valid_dev = s.front.valid_dev; r.nn_idx_dev = s.front.nn_idx_dev;
+        r.poses_prop_dev = s.front.poses_prop_dev; r.status_dev = s.front.status_dev; r.rmse_dev = s.rmse_dev;
+        r.softmax = s.softmax; r.resample_mode = s.resample_mode; r.u_all_dev = s.u_all_dev; r.u32 = s.u32;
+        r.seed = s.front.seed; r.step = s.front.step;
+        r.counts_dev = s.counts_dev; r.weights_dev = s.weights_dev; r.peers_dev = s.peers_dev;
+        if ((rc = shard_route(ctx, &r, true))) return rc;
+        if ((rc = launch_peer_flag_write(ctx, s.peers_dev, s.G, s.rank, s.flag_offset, s.frame_tag))) return rc;
+    }
+    if (phases & MIDAS_SHARD_PHASE_UNPACK) {  // wait for every rank's flag in the own inbox, then inbox -> slots
+        if ((rc = launch_shard_unpack_peer_wait(ctx, N, s.inbox_dev, s.ridx_dev, s.poses_out_dev, s.weights_out_dev, s.hint_out_dev,
+                                                s.G, s.flag_offset, s.frame_tag, s.front.status_dev)))
+            return rc;
+    }
+    return MIDAS_OK;
+}
+
+MIDAS_EXPORT int midas_shard_step(midas_ctx* ctx, midas_comm* comm, const midas_codebook* cb, const midas_tree* tree6,
+                                  const midas_tree* tree3, const midas_shard_step_args* args, int32_t phases) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, args != nullptr);
+    return shard_step_impl(ctx, comm, cb, tree6, tree3, *args, phases);
+}
+
+MIDAS_EXPORT int midas_shard_run(midas_ctx* ctx, midas_comm* comm, const midas_codebook* cb, const midas_tree* tree6,
+                                 const midas_tree* tree3, const midas_shard_step_args* first, int32_t T) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, first != nullptr && comm != nullptr && cb != nullptr && T >= 1);
+    MIDAS_REQUIRE(ctx, !first->front.tn_dev && !first->front.rot_dev && !first->u_all_dev && !first->front.scores_ready);
+    midas_shard_step_args a = *first;
+    for (int32_t f = 0; f < T; ++f) {
+        int rc = f ? scratch_reset(ctx) : MIDAS_OK;
+        if (rc) return rc;
+        if ((rc = shard_step_impl(ctx, comm, cb, tree6, tree3, a, MIDAS_SHARD_PHASE_LOCAL | MIDAS_SHARD_PHASE_GATHER | MIDAS_SHARD_PHASE_ROUTE | MIDAS_SHARD_PHASE_UNPACK)))
+            return rc;
+        // next frame: the resampled particles are in poses_out / hint_out (= the front's inputs: the engine passes the same buffers)
+        a.front.step += 1;
+        a.frame_tag += 1;
+        a.u32 = -1.0f;
+        if (a.front.score_stamps_dev) {
+            MIDAS_REQUIRE(ctx, a.front.score_epoch < 0xFFFFFFF0u);
+            a.front.score_epoch += 1;
+        }
+        a.front.odom16_dev += 16;
+        a.front.code_dev += cb->D;
+        if (a.front.gt16_dev) a.front.gt16_dev += 16;
+    }
+    return MIDAS_OK;
 }
 
 MIDAS_EXPORT int midas_tail_resample(midas_ctx* ctx, const midas_tail_resample_args* args) {

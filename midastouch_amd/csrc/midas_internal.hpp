@@ -333,6 +333,9 @@ int launch_shard_unpack(midas_ctx* ctx, int64_t N, const void* recv, int32_t* ri
 int launch_shard_unpack_peer(midas_ctx* ctx, int64_t N, const void* inbox, int32_t* ridx, float* poses_out, double* weights_out,
                              int32_t* hint_out);
 int launch_peer_probe(midas_ctx* ctx, void* const* peers, const void* inbox, int G, int rank, int nonce, int32_t* ok);
+int launch_peer_flag_write(midas_ctx* ctx, void* const* peers, int G, int rank, int64_t flag_off, uint64_t tag);
+int launch_shard_unpack_peer_wait(midas_ctx* ctx, int64_t N, const void* inbox, int32_t* ridx, float* poses_out, double* weights_out,
+                                  int32_t* hint_out, int G, int64_t flag_off, uint64_t tag, int32_t* status);
 int debug_tb2_clocks(long long* out16);
 int launch_tail_a(midas_ctx* ctx, int64_t N, const double* x, const uint8_t* valid, int np, int pstride,
                   const double* pmax_all, const double* pmin_all, int32_t softmax, double* e_io, double* lp_out,

@@ -1491,6 +1491,47 @@ __global__ __launch_bounds__(256) void k_shard_unpack_peer(int64_t N, const char
     for (int k = 0; k < 8; ++k) pd[k] = v[3 + k];
 }
 
+// Device-side completion flags of the peer-mapped exchange (the C-side sharded frame, midas_shard_step): behind its route
+// kernel - a kernel boundary, so every row it stored is out - a rank stores the frame's tag into slot `rank` of the flag
+// block that follows the N rows of every inbox; the unpack kernel of a rank waits until all G slots of its OWN inbox carry the
+// tag.  That replaces the 4-byte collective the host-driven frame used as a barrier.  No cycle: a rank's flag kernel sits
+// behind its record all_gather, which completes only when every rank has joined it - and every rank enqueues its join before
+// its own waiting kernel.  The wait is bounded (2 s of the 100 MHz wall clock): on expiry status[0] gets bit 16 and the
+// kernel goes on - a stuck peer must not hang the device.
+__global__ void k_peer_flag_write(char* const* peers, int G, int rank, long long flag_off, unsigned long long tag) {
+    const int d = threadIdx.x;
+    if (d < G) __hip_atomic_store(reinterpret_cast<unsigned long long*>(peers[d] + flag_off) + rank, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(256) void k_shard_unpack_peer_wait(int64_t N, const char* __restrict__ inbox, int32_t* __restrict__ ridx,
+                                                                float* __restrict__ poses_out, double* __restrict__ weights_out,
+                                                                int32_t* __restrict__ hint_out, int G, long long flag_off,
+                                                                unsigned long long tag, int32_t* __restrict__ status) {
+    if ((int)threadIdx.x < G) {
+        const unsigned long long* f = reinterpret_cast<const unsigned long long*>(inbox + flag_off) + threadIdx.x;
+        const long long t0 = wall_clock64();
+        bool late = false;
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < tag) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > 200000000ll) { late = true; break; }
+        }
+        if (late && status) atomicOr(&status[0], 16);
+    }
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    const char* rp = inbox + (size_t)r * ROUTE_REC;
+    unsigned long long v[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) v[k] = sys_load8(rp + 8 * k);
+    ridx[r] = (int32_t)(v[0] >> 32);
+    hint_out[r] = (int32_t)(v[1] & 0xFFFFFFFFull);
+    weights_out[r] = __longlong_as_double((long long)v[2]);
+    unsigned long long* pd = reinterpret_cast<unsigned long long*>(poses_out + r * 16);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pd[k] = v[3 + k];
+}
+
 // start-up self test of the peer data path (include/midas_hip.h)
 __global__ void k_peer_probe_write(char* const* peers, int G, int rank, int nonce) {
     const int d = threadIdx.x;
@@ -1512,6 +1553,20 @@ int launch_shard_unpack_peer(midas_ctx* ctx, int64_t N, const void* inbox, int32
                              int32_t* hint_out) {
     hipLaunchKernelGGL(k_shard_unpack_peer, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, N, (const char*)inbox, ridx,
                        poses_out, weights_out, hint_out);
+    LAUNCH_CHECK(ctx);
+    return MIDAS_OK;
+}
+
+int launch_peer_flag_write(midas_ctx* ctx, void* const* peers, int G, int rank, int64_t flag_off, uint64_t tag) {
+    hipLaunchKernelGGL(k_peer_flag_write, dim3(1), dim3(64), 0, ctx->stream, (char* const*)peers, G, rank, (long long)flag_off, (unsigned long long)tag);
+    LAUNCH_CHECK(ctx);
+    return MIDAS_OK;
+}
+
+int launch_shard_unpack_peer_wait(midas_ctx* ctx, int64_t N, const void* inbox, int32_t* ridx, float* poses_out, double* weights_out,
+                                  int32_t* hint_out, int G, int64_t flag_off, uint64_t tag, int32_t* status) {
+    hipLaunchKernelGGL(k_shard_unpack_peer_wait, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, N, (const char*)inbox, ridx,
+                       poses_out, weights_out, hint_out, G, (long long)flag_off, (unsigned long long)tag, status);
     LAUNCH_CHECK(ctx);
     return MIDAS_OK;
 }

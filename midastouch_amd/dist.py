@@ -176,7 +176,9 @@ class HipShardBackend:
     def peer_alloc(self, st) -> torch.Tensor:
         """This shard's inbox (N rows of fine-grained device memory) -> its 64-byte interprocess handle."""
         ptr, h = C.c_void_p(), (C.c_ubyte * 64)()
-        self.ctx.call("midas_peer_alloc", st.N * ROUTE_REC, C.byref(ptr), h)
+        # N rows, then the completion flags of the C-side frame (one uint64 per rank, include/midas_hip.h midas_shard_step)
+        st._flag_off = st.N * ROUTE_REC
+        self.ctx.call("midas_peer_alloc", st._flag_off + 64 * 8, C.byref(ptr), h)
         st._inbox, st._opened = ptr.value, []
         return torch.tensor(list(h), dtype=torch.uint8)
 
@@ -188,6 +190,78 @@ class HipShardBackend:
 
     def peer_table(self, st, ptrs):
         st._peers = torch.tensor([int(p) for p in ptrs], dtype=torch.int64, device=self.device)
+
+    # ---- the whole frame by one C call (midas_shard_step / midas_shard_run; peer-mapped exchange with device-side flags) ----
+    def rccl_path(self):
+        """The librccl the process already has (torch's): the library opens THAT copy for its own communicator."""
+        d = os.path.join(os.path.dirname(torch.__file__), "lib")
+        for name in ("librccl.so", "librccl.so.1"):
+            if os.path.exists(os.path.join(d, name)):
+                return os.path.join(d, name).encode()
+        return None
+
+    def comm_unique_id(self) -> torch.Tensor:
+        buf = (C.c_ubyte * 128)()
+        self.ctx.call("midas_comm_unique_id", self.rccl_path(), buf)
+        return torch.tensor(list(buf), dtype=torch.uint8)
+
+    def comm_create(self, id128: torch.Tensor, world: int, rank: int):
+        buf = (C.c_ubyte * 128)(*[int(v) for v in id128.tolist()])
+        h = C.c_void_p()
+        self.ctx.bind_current_stream()
+        self.ctx.call("midas_comm_create", self.rccl_path(), buf, int(world), int(rank), C.byref(h))
+        return h
+
+    def comm_destroy(self, h):
+        if h:
+            self.ctx.lib.midas_comm_destroy(h)
+
+    def step_args(self, st, odom, code, gt, std_t, std_r, seed, step, prune_thr, use_hint, r1_all, rank, world, softmax, mode,
+                  u_all, u32, frame_tag):
+        from ._lib import ShardStepArgs
+        a = ShardStepArgs()
+        f = a.front
+        f.N, f.slot_base = st.N, st.slot_base
+        f.poses_in, f.poses_prop = _ptr(st.poses), _ptr(st.poses_prop)
+        f.hint_in = _ptr(st.hint) if use_hint else None
+        f.nn_idx, f.valid = _ptr(st.nn_idx), _ptr(st.valid)
+        f.odom16, f.code, f.gt16 = _ptr(odom), _ptr(code), _ptr(gt)
+        f.scores, f.scores_ready = _ptr(st.scores), 0
+        f.rmse_sums = _ptr(st.r1[5 * st.nb + 2:]) if gt is not None else None
+        f.std_t, f.std_r, f.seed, f.step, f.prune_thr = std_t, std_r, seed, step, prune_thr
+        f.telemetry, f.status, f.flags = _ptr(st.telemetry), _ptr(st.status), _ptr(st.r1[5 * st.nb:])
+        if self._sparse:
+            stamps = getattr(st, "_stamps", None)
+            if stamps is None:
+                st._stamps = stamps = torch.zeros(self.codebook.K, dtype=torch.int32, device=st.poses.device)
+                st._epoch = 0
+            f.score_stamps = _ptr(stamps)
+        a.softmax, a.tables, a.r1, a.r1_all = int(softmax), _ptr(st.tables), _ptr(st.r1), _ptr(r1_all)
+        a.G, a.rank, a.resample_mode = world, rank, mode
+        a.u_all, a.u32 = _ptr(u_all), float(u32)
+        a.counts, a.weights = _ptr(st.counts), _ptr(st.weights)
+        a.rmse = _ptr(st.rmse) if gt is not None else None
+        a.peers, a.inbox, a.flag_offset, a.frame_tag = _ptr(st._peers), C.c_void_p(st._inbox), st._flag_off, int(frame_tag)
+        a.ridx, a.poses_out, a.weights_out, a.hint_out = _ptr(st.ridx), _ptr(st.poses), _ptr(st.weights_res), _ptr(st.hint)
+        return a
+
+    def next_epochs(self, st, n=1) -> int:
+        """First of n consecutive sparse-scoring epochs of this shard's stamps (restart + zeroed stamps long before a wrap)."""
+        if st._epoch + n >= 0x7FFFFFF0:
+            st._stamps.zero_()
+            st._epoch = 0
+        first = st._epoch + 1
+        st._epoch += n
+        return first
+
+    def step_c(self, st, a, comm_h, phases, T=None):
+        if self._sparse and (phases & 1):
+            a.front.score_epoch = self.next_epochs(st, 1 if T is None else T)
+        self.ctx.bind_current_stream()
+        if T is None:
+            self.ctx.check(self.ctx.lib.midas_shard_step(self.ctx.h, comm_h, self.codebook.h, self.tree6.h, self.tree3.h, C.byref(a), int(phases)))
+        else:
+            self.ctx.check(self.ctx.lib.midas_shard_run(self.ctx.h, comm_h, self.codebook.h, self.tree6.h, self.tree3.h, C.byref(a), int(T)))
 
     def peer_release(self, st):
         for p in getattr(st, "_opened", []):
@@ -357,8 +431,8 @@ class ShardedFilterEngine:
                      "low_var_batch": _lib.RESAMPLE_SYSTEMATIC}[resample]
         self.step_count = 0
         self.use_hint = True
-        if exchange not in ("auto", "a2a", "a2a_fixed", "allgather", "peer"):
-            raise MidasError("exchange must be 'auto', 'peer', 'a2a', 'a2a_fixed' or 'allgather'")
+        if exchange not in ("auto", "a2a", "a2a_fixed", "allgather", "peer", "peer_c"):
+            raise MidasError("exchange must be 'auto', 'peer_c', 'peer', 'a2a', 'a2a_fixed' or 'allgather'")
         # a2a_fixed: per destination a segment of 1.5 x the expected N / G rows (after a resample every rank owns ~1 / G of
         # the weight mass), the rest through an overflow block of N / 4 rows that every rank gathers
         self.seg_cap = -(-int(1.5 * self.N / self.world + 64) // 8) * 8
@@ -380,14 +454,77 @@ class ShardedFilterEngine:
         # carries the block records and a barrier.  Ranks in separate processes connect here (a collective); it is what
         # "auto" picks under RCCL when the start-up self test of the mapped path passes on every rank.  Shards of one process
         # (tests) are wired with connect_local_peers().
+        # "peer_c": the same exchange with the WHOLE frame enqueued by one C call on a communicator the library owns
+        # (midas_shard_step: kernels, the record all_gather by RCCL, device-side completion flags instead of the barrier
+        # collective) - what "auto" picks when it can; without RCCL between the ranks (gloo: tests) the record gather stays
+        # with `comm` and the frame is two C calls around it.
         self.peer_error = None
+        self._ccomm = None
+        self._r1_all = None
         separate = isinstance(self.comm, TorchDistComm) and hasattr(self.backend, "peer_alloc")
-        if exchange == "peer" and separate:
+        rccl = bool(getattr(self.comm, "_into", False))
+        want_c = os.environ.get("MIDAS_SHARD_C", "1") != "0" and hasattr(self.backend, "step_c")
+        if exchange in ("peer", "peer_c") and separate:
             if not self.connect_peers():
                 raise MidasError(f"peer-mapped exchange unavailable: {self.peer_error}")
-        elif exchange == "auto" and separate and self.world > 1 and getattr(self.comm, "_into", False) and os.environ.get("MIDAS_PEER_EXCHANGE", "1") != "0":
+            if exchange == "peer_c" and rccl:
+                self.connect_c_comm()
+        elif exchange == "auto" and separate and rccl and (self.world > 1 or want_c) and os.environ.get("MIDAS_PEER_EXCHANGE", "1") != "0":
             if self.connect_peers():
                 self.exchange = "peer"
+                if want_c and self.connect_c_comm(required=False):
+                    self.exchange = "peer_c"
+
+    def connect_c_comm(self, required: bool = True) -> bool:
+        """Collective: rank 0 obtains an RCCL unique id, every rank receives it over `comm` and joins the library-owned
+        communicator (midas_comm_create).  True when every rank holds one."""
+        b, dev = self.backend, self.st.poses.device
+        ok, err = True, None
+        try:
+            ident = b.comm_unique_id() if self.rank == 0 else torch.zeros(128, dtype=torch.uint8)
+        except MidasError as e:
+            ok, err, ident = False, str(e), torch.zeros(128, dtype=torch.uint8)
+        ident = self.comm.all_gather(ident.to(dev)).cpu().view(self.world, 128)[0]
+        if ok:
+            try:
+                self._ccomm = b.comm_create(ident, self.world, self.rank)
+            except MidasError as e:
+                ok, err = False, str(e)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        ok = bool(self.comm.all_gather(flag).min().item())
+        if not ok:
+            if self._ccomm is not None:
+                b.comm_destroy(self._ccomm)
+                self._ccomm = None
+            self.peer_error = err or "another rank could not create the library's communicator"
+            if required:
+                raise MidasError(f"library-owned RCCL communicator unavailable: {self.peer_error}")
+        return ok
+
+    def _c_args(self, odom, code, gt, u, u32, mul, r1_all):
+        st, b = self.st, self.backend
+        return b.step_args(st, odom, code, gt, mul * self.sig_t, mul * self.sig_r, self.seed, self.step_count, self.pen_max,
+                           self.use_hint, r1_all, self.rank, self.world, self.softmax, self.mode, u, u32, self.step_count + 1)
+
+    def _r1_all_buf(self):
+        if self._r1_all is None:
+            self._r1_all = torch.empty(self.world * self.st.r1.numel(), dtype=torch.float64, device=self.st.poses.device)
+        return self._r1_all
+
+    def run(self, odoms, codes, gts=None):
+        """T frames by ONE C call (midas_shard_run; exchange "peer_c" on the library's communicator, device draws)."""
+        if self.exchange != "peer_c" or self._ccomm is None:
+            raise MidasError("run() needs exchange='peer_c' with the library-owned RCCL communicator")
+        from .engine import operand
+        d, D = self.st.poses.device, int(self.backend.D)
+        T = int(torch.as_tensor(odoms).shape[0])
+        odoms = operand(odoms, "odoms", torch.float32, (T, 4, 4), d)
+        codes = operand(codes, "tactile codes", torch.float64, (T, D), d)
+        gts = operand(gts, "gt poses", torch.float32, (T, 4, 4), d)
+        self._keep = (odoms, codes, gts)
+        a = self._c_args(odoms, codes, gts, None, -1.0, 1.0, self._r1_all_buf())
+        self.backend.step_c(self.st, a, self._ccomm, 15, T=T)
+        self.step_count += T
 
     def connect_peers(self) -> bool:
         """Collective: allocate this rank's inbox, swap the interprocess handles, map the others' inboxes, run the self test
@@ -488,8 +625,14 @@ class ShardedFilterEngine:
             self._check_slot(k, wait)
 
     def close(self):
-        """Release the peer-mapped inbox and the interprocess mappings (fine-grained device memory is not returned by the
-        garbage collector)."""
+        """Release the library's communicator, the peer-mapped inbox and the interprocess mappings (fine-grained device memory
+        is not returned by the garbage collector)."""
+        if getattr(self, "_ccomm", None) is not None:
+            try:
+                self.backend.comm_destroy(self._ccomm)
+            except Exception:
+                pass
+            self._ccomm = None
         if getattr(self.st, "_inbox", None) or getattr(self.st, "_opened", None):
             try:
                 self.backend.peer_release(self.st)
@@ -528,6 +671,27 @@ class ShardedFilterEngine:
         tn, rot = operand(tn, "tn", torch.float32, (self.N, 3), d), operand(rot, "rot", torch.float32, (self.N, 3), d)
         u = operand(u, "u (the uniforms of all slots of the filter)", torch.float64, (self.N_total,), d)
         self._keep = (odom, code, gt, tn, rot, u)
+        if self.exchange == "peer_c":
+            if getattr(b, "row_shard", None) is not None or tn is not None:
+                raise MidasError("exchange='peer_c' takes a replicated codebook and device motion noise (use 'peer' otherwise)")
+            if st._peers is None:
+                raise MidasError("peer-mapped exchange: the inboxes are not connected (connect_peers / connect_local_peers)")
+            if self._ccomm is not None:  # kernels, RCCL all_gather of the records, flags, unpack: one call
+                b.step_c(st, self._c_args(odom, code, gt, u, u32, mul, self._r1_all_buf()), self._ccomm, 15)
+            else:                        # no RCCL between the ranks: the record gather goes through `comm`
+                a = self._c_args(odom, code, gt, u, u32, mul, None)
+                b.step_c(st, a, None, 1)
+                r1_all = yield st.r1
+                a.r1_all = _ptr(r1_all)
+                self._keep = self._keep + (r1_all,)
+                if getattr(self, "_one_stream", False):  # shards of one process: every shard's rows and flags before any wait
+                    b.step_c(st, a, None, 4)
+                    yield st.sync
+                    b.step_c(st, a, None, 8)
+                else:
+                    b.step_c(st, a, None, 12)
+            self.step_count += 1
+            return
         ready = False
         if getattr(b, "row_shard", None) is not None:  # codebook rows sharded: gather the score slices first
             st.scores.copy_((yield b.score_slice(code)))
@@ -578,13 +742,15 @@ class ShardedFilterEngine:
             pass
 
 
-def connect_local_peers(engines):
-    """Wire the inboxes of shards that live in ONE process (tests, run_lockstep): plain pointers, nothing to map."""
+def connect_local_peers(engines, exchange="peer"):
+    """Wire the inboxes of shards that live in ONE process (tests, run_lockstep): plain pointers, nothing to map.
+    exchange="peer_c": the C-side frame (midas_shard_step) with the record gather done by run_lockstep."""
     for e in engines:
         e.backend.peer_alloc(e.st)
     for e in engines:
         e.backend.peer_table(e.st, [o.st._inbox for o in engines])
-        e.exchange = "peer"
+        e.exchange = exchange
+        e._one_stream = True
 
 
 def run_lockstep(engines, per_rank_args):

@@ -25,7 +25,7 @@ class FakeComm:
     all_to_all = all_gather
 
 
-@pytest.mark.parametrize("exchange", ["a2a", "allgather", "a2a_fixed", "a2a_fixed_tight", "peer"])
+@pytest.mark.parametrize("exchange", ["a2a", "allgather", "a2a_fixed", "a2a_fixed_tight", "peer", "peer_c"])
 @pytest.mark.parametrize("shards,mode", [(2, "weighted_random"), (3, "low_var"), (1, "weighted_random")])
 def test_sharded_hip_equals_fused_engine(dev, shards, mode, exchange):
     from midastouch_amd.dist import HipShardBackend, ShardedFilterEngine, run_lockstep
@@ -47,9 +47,9 @@ def test_sharded_hip_equals_fused_engine(dev, shards, mode, exchange):
     if tight:
         for e in engs:
             e.seg_cap = (n_loc // shards) * 7 // 8 // 8 * 8
-    if exchange == "peer":  # shards of one process: the inboxes are plain pointers
+    if exchange in ("peer", "peer_c"):  # shards of one process: the inboxes are plain pointers
         from midastouch_amd.dist import connect_local_peers
-        connect_local_peers(engs)
+        connect_local_peers(engs, exchange)  # "peer_c": the C-side frame (midas_shard_step), records gathered by run_lockstep
     for r, e in enumerate(engs):
         e.set_particles(torch.as_tensor(start[r * n_loc:(r + 1) * n_loc]))
         e.project_to_codebook()
@@ -129,9 +129,11 @@ def test_sharded_host_uniforms_replicated(dev, exchange):
         assert np.array_equal(cat("poses"), single.poses.cpu().numpy()), t
 
 
-@pytest.mark.parametrize("exchange", ["a2a", "allgather"])
+@pytest.mark.parametrize("exchange", ["a2a", "allgather", "peer_c", "auto"])
 def test_single_rank_process_group_nccl(dev, exchange):
-    """world_size 1 through torch.distributed's nccl (= RCCL) backend: the real communicator path."""
+    """world_size 1 through torch.distributed's nccl (= RCCL) backend: the real communicator path.  "peer_c" / "auto": the
+    whole frame by one C call on the LIBRARY's own RCCL communicator (midas_comm_create: its id travels over torch's
+    group), record all_gather by ncclAllGather, inbox + completion flags; then T frames by one midas_shard_run call."""
     import os
     import torch.distributed as dist
     from midastouch_amd.dist import ShardedFilterEngine
@@ -151,11 +153,25 @@ def test_single_rank_process_group_nccl(dev, exchange):
         for e in (a, b):
             e.set_particles(torch.as_tensor(start))
             e.project_to_codebook()
+        if exchange in ("peer_c", "auto"):
+            assert b.exchange == "peer_c" and b._ccomm is not None, b.peer_error
         for t in range(1, 5):
             od, code = torch.as_tensor(traj.odoms[t]).to(dev), torch.as_tensor(traj.codes[t]).to(dev)
             a.step(od, code)
             b.step(od, code)
             assert torch.equal(a.ridx, b.ridx) and torch.equal(a.weights, b.weights) and torch.equal(a.poses, b.poses)
+        if b.exchange == "peer_c":
+            ods, codes = torch.as_tensor(traj.odoms[1:5]).to(dev), torch.as_tensor(traj.codes[1:5]).to(dev)
+            for e in (a, b):
+                e.set_particles(torch.as_tensor(start))
+                e.project_to_codebook()
+                e.step_count = 0
+            b.run(ods, codes)
+            for t in range(4):
+                a.step(ods[t], codes[t])
+            assert torch.equal(a.ridx, b.ridx) and torch.equal(a.weights, b.weights) and torch.equal(a.poses, b.poses)
+            assert int(b.status[0]) == 0
+            b.close()
     finally:
         dist.destroy_process_group()
 

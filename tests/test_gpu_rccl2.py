@@ -1,7 +1,9 @@
 """Two real ranks (one process each): the particle-sharded frame, every exchange form, against the ORACLE's frame of all
 particles.  Over RCCL with one GPU per process when the box has two MI355X (skips itself otherwise: the driver's 1-GPU
 tier); and on ONE GPU shared by the two processes with gloo carrying the exchanges - the whole multi-process path
-(HipShardBackend kernels, TorchDistComm, the exchange protocol) except RCCL's transport."""
+(HipShardBackend kernels, TorchDistComm, the exchange protocol) except RCCL's transport.  "peer_c" is the C-side frame
+(midas_shard_step): over RCCL one call per frame on the library's own communicator; on the shared GPU two calls around the
+gloo gather of the records, the rows and the completion flags going through the interprocess-mapped inboxes either way."""
 import os
 import socket
 
@@ -73,14 +75,14 @@ def _run_and_check(tmp_path, oracle, exchange, shared_gpu):
         poses = ref["poses"]
 
 
-@pytest.mark.parametrize("exchange", ["peer", "auto", "a2a_fixed", "a2a", "allgather"])
+@pytest.mark.parametrize("exchange", ["peer_c", "peer", "auto", "a2a_fixed", "a2a", "allgather"])
 def test_two_ranks_over_rccl_match_the_oracle(tmp_path, oracle, exchange):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
     _run_and_check(tmp_path, oracle, exchange, shared_gpu=False)
 
 
-@pytest.mark.parametrize("exchange", ["peer", "a2a_fixed", "a2a", "allgather"])
+@pytest.mark.parametrize("exchange", ["peer_c", "peer", "a2a_fixed", "a2a", "allgather"])
 def test_two_processes_sharing_one_gpu_match_the_oracle(tmp_path, oracle, exchange):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
