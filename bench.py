@@ -235,7 +235,7 @@ def main():
     ap.add_argument("--no-diffuse", action="store_true", help="skip the diffuse-regime figure (profiling runs: keeps the wide-start frames out of the kernel statistics)")
     ap.add_argument("--no-extras", action="store_true", help="skip config.c5, config.parity_mode and roofline.dense (profiling runs)")
     ap.add_argument("--sharded", action="store_true", help="use the particle-sharded engine even on one GPU (smoke test)")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "peer", "a2a", "a2a_fixed", "allgather"], help="sharded engine: form of the resample exchange")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "peer_c", "peer", "a2a", "a2a_fixed", "allgather"], help="sharded engine: form of the resample exchange")
     ap.add_argument("--eager", action="store_true", help="materialise the resampled particles every frame (three launches per frame)")
     ap.add_argument("--resample", default="weighted_random", choices=["weighted_random", "low_var"],
                     help="resampler mode (particle_filter.py:230-307): the reference's default multinomial draws, or systematic")
@@ -298,7 +298,8 @@ def main():
     def frames(i0, n):
         """n consecutive frames starting at trajectory position i0; one C-ABI call where the engine has one"""
         t0_ = 1 + i0 % (T - 1)
-        if hasattr(eng, "run") and not args.eager and t0_ + n <= T:
+        can_run = hasattr(eng, "run") and (not sharded or (eng.exchange == "peer_c" and eng._ccomm is not None))
+        if can_run and not args.eager and t0_ + n <= T:
             return eng.run(odoms[t0_:t0_ + n], codes[t0_:t0_ + n], gts[t0_:t0_ + n])
         for i in range(n):
             frame(i0 + i)
@@ -443,7 +444,8 @@ def main():
                                "(same arithmetic, same scores); %d distinct rows in the last frame" % int(torch.unique(eng.nn_idx).numel()))
                    if getattr(eng, "sparse_scores", False) else "dense: all K rows every frame",
                    "init": "init_filter(gt_0, N) (sigma_t = mesh scale / 3, sigma_r = 60 deg) projected onto the codebook",
-                   "timed_region": "K steps by one midas_lazy_run call" if hasattr(eng, "run") and not args.eager else "K step() calls",
+                   "timed_region": ("K steps by one midas_shard_run call (library-owned RCCL communicator)" if sharded and eng.exchange == "peer_c" and eng._ccomm is not None
+                                    else "K steps by one midas_lazy_run call" if hasattr(eng, "run") and not sharded and not args.eager else "K step() calls"),
                    "steps_per_sec_materialised_every_frame": eager_rate,
                    "reference_loop_frames_per_sec": loop_rate,
                    "per_step": step_stats, "per_step_in_timed_call": run_stats, "diffuse_regime": diffuse, "exchange": exchange_info,

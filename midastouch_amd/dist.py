@@ -501,10 +501,12 @@ class ShardedFilterEngine:
                 raise MidasError(f"library-owned RCCL communicator unavailable: {self.peer_error}")
         return ok
 
-    def _c_args(self, odom, code, gt, u, u32, mul, r1_all):
+    def _c_args(self, odom, code, gt, u, u32, mul, r1_all, frames=1):
         st, b = self.st, self.backend
+        tag = getattr(self, "_frame_tag", 0) + 1   # grows for the life of the inboxes, whatever happens to step_count
+        self._frame_tag = tag + frames - 1
         return b.step_args(st, odom, code, gt, mul * self.sig_t, mul * self.sig_r, self.seed, self.step_count, self.pen_max,
-                           self.use_hint, r1_all, self.rank, self.world, self.softmax, self.mode, u, u32, self.step_count + 1)
+                           self.use_hint, r1_all, self.rank, self.world, self.softmax, self.mode, u, u32, tag)
 
     def _r1_all_buf(self):
         if self._r1_all is None:
@@ -522,7 +524,7 @@ class ShardedFilterEngine:
         codes = operand(codes, "tactile codes", torch.float64, (T, D), d)
         gts = operand(gts, "gt poses", torch.float32, (T, 4, 4), d)
         self._keep = (odoms, codes, gts)
-        a = self._c_args(odoms, codes, gts, None, -1.0, 1.0, self._r1_all_buf())
+        a = self._c_args(odoms, codes, gts, None, -1.0, 1.0, self._r1_all_buf(), frames=T)
         self.backend.step_c(self.st, a, self._ccomm, 15, T=T)
         self.step_count += T
 
