@@ -1034,7 +1034,8 @@ extern "C" int midas_comm_all_gather(midas_comm* c, const void* send_dev, void* 
 static int shard_step_impl(midas_ctx* ctx, midas_comm* comm, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
                            const midas_shard_step_args& s, int32_t phases) {
     MIDAS_REQUIRE(ctx, phases != 0 && (phases & ~15) == 0);
-    MIDAS_REQUIRE(ctx, s.front.N >= 256 && s.G >= 1 && s.G <= 64 && s.rank >= 0 && s.rank < s.G && s.tables_dev && s.r1_dev && s.r1_all_dev);
+    MIDAS_REQUIRE(ctx, s.front.N >= 256 && s.G >= 1 && s.G <= 64 && s.rank >= 0 && s.rank < s.G && s.tables_dev && s.r1_dev);
+    MIDAS_REQUIRE(ctx, s.r1_all_dev || !(phases & (MIDAS_SHARD_PHASE_GATHER | MIDAS_SHARD_PHASE_ROUTE)));
     const int64_t N = s.front.N;
     const int nb = (int)ceil_div(N, SCAN_BLOCK);
     const int64_t rec = 5 * (int64_t)nb + 4;

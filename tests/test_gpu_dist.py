@@ -197,8 +197,9 @@ def test_fixed_capacity_exchange_is_loud_when_rows_are_lost(dev):
     engs = [ShardedFilterEngine(num_particles=n_loc, backend=be, comm=FakeComm(r, shards), exchange="a2a_fixed") for r in range(shards)]
     for r, e in enumerate(engs):
         e.set_particles(torch.as_tensor(start[r * n_loc:(r + 1) * n_loc]))
+        e.seg_cap, e.ovf_cap = 1024, 512  # (the defaults - 1.5 n / G + 64 and n / 4 - already fall short from four ranks on)
     run_lockstep(engs, [((od, code), {}) for _ in engs])
-    # rank 0 owns every source: it sends n_loc rows to rank 1 (segment 1.5 n_loc / 2 + overflow n_loc / 4 < n_loc)
+    # rank 0 owns every source: it sends n_loc rows to rank 1, far more than segment + overflow block hold
     assert engs[0].seg_cap + engs[0].ovf_cap < n_loc
     with pytest.raises(MidasError, match="a2a_fixed.*lost"):
         for e in engs:
