@@ -289,6 +289,12 @@ typedef struct midas_lazy_args {
 } midas_lazy_args;
 int midas_lazy_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
                     const midas_lazy_args* args);
+/* The prediction list from scratch, for a particle set that did not come out of a frame (after the projection onto the
+ * codebook, filter/filter.py:159-160, where every particle's nearest entry nn_idx_dev[n] is known): lists the distinct rows
+ * and tags them for the frame that runs with score_epoch + 2.  score_epoch: an epoch of the caller's sequence (even step
+ * of 2) that no frame has used. */
+int midas_score_list_seed(midas_ctx* ctx, int64_t K, uint32_t* score_stamps_dev, uint32_t score_epoch, int32_t* score_list_dev,
+                          int64_t N, const int32_t* nn_idx_dev);
 /* T consecutive frames of midas_lazy_step enqueued by one call (device Philox draws): frame f takes odom16_dev + 16 f,
  * code_dev + D f and (when given) gt16_dev + 16 f, alternates the two buffer sets of `first` (frame 0 uses first's own
  * assignment, frame 1 the swapped one, ...) and folds the resample of the frame before it; rmse_log_dev (NULL or 3 T

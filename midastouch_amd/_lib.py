@@ -207,6 +207,7 @@ SIGNATURES = {
     "midas_softmax": (C.c_int, [_P, _I64, _P, _I32, _P]),
     "midas_prune": (C.c_int, [_P, _I64, _P, _P, _D, _P]),
     "midas_cdf": (C.c_int, [_P, _I64, _P, _P, _P]),
+    "midas_score_list_seed": (C.c_int, [_P, _I64, _P, C.c_uint32, _P, _I64, _P]),
     "midas_mt19937_seed": (C.c_int, [_P, _U64, _P]),
     "midas_mt19937_rand64": (C.c_int, [_P, _P, _I64, _I64, _P]),
     "midas_resample_search": (C.c_int, [_P, _I64, _P, _I64, _I32, _P, _F, _U64, _U64, _P]),

@@ -803,6 +803,18 @@ static int lazy_flush_impl(midas_ctx* ctx, const midas_lazy_flush_args& s, int32
     return launch_tail_b2(ctx, ta, tb);
 }
 
+MIDAS_EXPORT int midas_score_list_seed(midas_ctx* ctx, int64_t K, uint32_t* score_stamps_dev, uint32_t score_epoch, int32_t* score_list_dev,
+                                       int64_t N, const int32_t* nn_idx_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, K > 0 && score_stamps_dev && score_epoch >= 2 && score_epoch < 0xFFFFFFF0u && score_list_dev && N > 0 && nn_idx_dev);
+    const int par = (int)((score_epoch >> 1) & 1u);
+    ScorePredict pr;
+    pr.stamps = score_stamps_dev; pr.epoch = score_epoch; pr.K = K;
+    pr.count = score_list_dev + (par ^ 1);
+    pr.list = score_list_dev + 2 + (int64_t)(par ^ 1) * K;
+    return launch_predict_seed(ctx, N, nn_idx_dev, pr);
+}
+
 // ---- pipelined batch (config 5): B trajectories, grid.y, one table block per trajectory -------------------------------
 MIDAS_EXPORT int64_t midas_lazy_tables_doubles(int64_t N) { return N > 0 ? tables_doubles(N) : 0; }
 

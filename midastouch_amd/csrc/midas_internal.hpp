@@ -324,6 +324,7 @@ int launch_tail_a2(midas_ctx* ctx, int64_t N, const double* scores, const int32_
                    int32_t softmax, const TailTables& tb, int32_t* status, int batch = 1, int64_t score_stride = 0,
                    bool padded_tables = false, const double* part_rmse = nullptr, double* rmse_out = nullptr, int64_t tstride = 0,
                    const ScorePredict* predict = nullptr);  // padded: per-slot tables hold a multiple of 16 values (tables_of, api.hip)
+int launch_predict_seed(midas_ctx* ctx, int64_t N, const int32_t* idx, const ScorePredict& pr);
 int launch_tail_b2(midas_ctx* ctx, const StepTailArgs& a, const TailTables& tb);  // a.x, a.e, a.cdf, a.lp_raw unused
 int launch_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
                         int32_t softmax, const TailTables& tb, double* r1, int32_t* status);

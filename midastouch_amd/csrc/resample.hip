@@ -548,6 +548,24 @@ MD void predict_scan(const ScorePredict& pr, int blk) {
         }
 }
 
+// prediction list from scratch (the particle set was replaced: projection onto the codebook, filter/filter.py:159-160): the rows
+// idx[n] are stamped `epoch`, predict_scan then lists them and tags them epoch + 1 for the frame with epoch + 2
+__global__ __launch_bounds__(256) void k_predict_mark(int64_t N, const int32_t* __restrict__ idx, uint32_t* __restrict__ stamps, int64_t K, uint32_t epoch) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int32_t r = idx[n];
+    if (r >= 0 && r < K) stamps[r] = epoch;  // every marker of a row stores the same value
+}
+__global__ __launch_bounds__(256) void k_predict_scan(ScorePredict pr) { predict_scan(pr, (int)blockIdx.x); }
+
+int launch_predict_seed(midas_ctx* ctx, int64_t N, const int32_t* idx, const ScorePredict& pr) {
+    MIDAS_HIP_CHECK(ctx, hipMemsetAsync(pr.count, 0, sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(k_predict_mark, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, N, idx, pr.stamps, pr.K, pr.epoch);
+    hipLaunchKernelGGL(k_predict_scan, dim3((unsigned)ceil_div(pr.K, 256 * PREDICT_PER_THREAD)), dim3(256), 0, ctx->stream, pr);
+    MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    return MIDAS_OK;
+}
+
 __global__ __launch_bounds__(256) void k_tail_a2d(int64_t N, const double* __restrict__ scores, const int32_t* __restrict__ nn_idx,
                                                   const uint8_t* __restrict__ valid, int32_t softmax, TailTables tb, bool padded,
                                                   int32_t* __restrict__ status, double* __restrict__ flags_out,

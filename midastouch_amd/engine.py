@@ -279,7 +279,13 @@ class PipelinedFilterEngine(FilterEngine):
 
     def project_to_codebook(self):
         self.flush()
-        return super().project_to_codebook()
+        idx = super().project_to_codebook()
+        if self._score_list is not None:
+            # every particle's nearest entry is known: the first frame's rows go on the prediction list right away (they would
+            # otherwise all be claimed by whichever particle wave touches them first - up to 64 rows a wave after a wide start)
+            self.ctx.bind_current_stream()
+            self.ctx.call("midas_score_list_seed", self.K, _ptr(self._stamps), self._next_epoch(), _ptr(self._score_list), self.N, _ptr(idx))
+        return idx
 
     def seed_torch_stream(self, seed):
         """Resample draws from the device replica of torch's CPU generator under torch.manual_seed(seed) (torch_rng.py):

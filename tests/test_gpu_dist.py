@@ -69,8 +69,9 @@ def test_sharded_hip_equals_fused_engine(dev, shards, mode, exchange):
             np.testing.assert_allclose(e.rmse.cpu().numpy(), single.rmse.cpu().numpy(), rtol=1e-12)
 
 
-def test_codebook_row_sharding_equals_replicated(dev):
-    """BASELINE config 4 shape: embedding rows sharded over the ranks, score slices gathered - same frame bit for bit."""
+def test_codebook_row_sharding_equals_replicated(dev, oracle):
+    """BASELINE config 4 shape: embedding rows sharded over the ranks, score slices gathered - same frame bit for bit as the
+    replicated engine AND as the ORACLE's frame of all particles (scores, weights and indices are spec arithmetic: exact)."""
     from midastouch_amd.dist import HipShardBackend, ShardedFilterEngine, run_lockstep
     from midastouch_amd.engine import FilterEngine
     from midastouch_amd.synthetic import make_codebook, make_trajectory
@@ -88,6 +89,8 @@ def test_codebook_row_sharding_equals_replicated(dev):
         e = ShardedFilterEngine(num_particles=n_loc, backend=be, comm=FakeComm(r, shards))
         e.set_particles(torch.as_tensor(start[r * n_loc:(r + 1) * n_loc]))
         engs.append(e)
+    ofl = oracle.OracleFilter(cb.poses, cb.embeddings, cb.mesh_vertices)
+    poses = start
     for t in range(1, 6):
         od, code = torch.as_tensor(traj.odoms[t]).to(dev), torch.as_tensor(traj.codes[t]).to(dev)
         single.step(od, code)
@@ -96,6 +99,15 @@ def test_codebook_row_sharding_equals_replicated(dev):
         assert np.array_equal(cat("weights"), single.weights.cpu().numpy()), t
         assert np.array_equal(cat("ridx"), single.ridx.cpu().numpy()), t
         assert np.array_equal(cat("poses"), single.poses.cpu().numpy()), t
+        # the oracle's frame of all N particles (device Philox draws keyed by the global slot)
+        tn, rot = oracle.philox_noise(N, 4000, t - 1, np.float32(2e-4), np.float32(0.5))
+        ref = ofl.step(poses, traj.odoms[t], traj.codes[t], tn, rot, u=oracle.philox_uniform64(N, 4000, t - 1))
+        assert np.array_equal(cat("nn_idx"), ref["nn_idx"]), t
+        assert np.array_equal(engs[0].st.scores.cpu().numpy(), ref["scores"]), t  # the gathered slices == the whole codebook's scores
+        assert np.array_equal(cat("weights"), ref["weights"]), t
+        assert np.array_equal(cat("ridx"), ref["ridx"]), t
+        assert np.array_equal(cat("poses"), ref["poses"]), t
+        poses = ref["poses"]
 
 
 @pytest.mark.parametrize("exchange", ["a2a", "allgather", "peer"])

@@ -291,3 +291,34 @@ def test_epoch_wrap_restarts_stamps_and_lists(dev):
         assert torch.equal(eng._scores[used], ref._scores[used]), f"frame {t}"
     assert eng._epoch < 100  # restarted
     assert np.array_equal(eng.ridx.cpu().numpy(), ref.ridx.cpu().numpy())
+
+
+def test_prediction_list_seeded_at_projection(dev, monkeypatch):
+    """project_to_codebook (filter/filter.py:159-160) knows every particle's nearest entry: the first frame's rows are listed
+    there and then (midas_score_list_seed), so the first frame after a wide start scores them with streaming workgroups too.
+    Same particle sets as the engine without a list."""
+    from midastouch_amd.engine import PipelinedFilterEngine
+    N, K, D = 20000, 6000, 256
+    cb, traj = _setup(N, K, D, 11)
+    rng = np.random.default_rng(6)
+    start = cb.poses[rng.integers(0, K, N)].copy()
+    start[:, :3, 3] += (rng.standard_normal((N, 3)) * 1e-3).astype(np.float32)
+    engs = {}
+    for tag, env in (("list", "1"), ("nolist", "0")):
+        monkeypatch.setenv("MIDAS_SCORE_LIST", env)
+        e = engs[tag] = PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=9, device=dev)
+        e.set_particles(torch.as_tensor(start))
+        idx = e.project_to_codebook()
+    a, b = engs["list"], engs["nolist"]
+    par = (a._epoch >> 1) & 1
+    assert int(a._score_list[par ^ 1].item()) == torch.unique(idx).numel()  # the list the first frame (epoch + 2) will score
+    rows0 = int(a.telemetry[2].item())
+    od, co = torch.as_tensor(traj.odoms).to(dev), torch.as_tensor(traj.codes).to(dev)
+    for t in range(1, 5):
+        a.step(od[t], co[t])
+        b.step(od[t], co[t])
+        assert torch.equal(a.nn_idx, b.nn_idx), t
+        if t == 1:  # most of the first frame's rows came off the seeded list, not from claims by particle waves
+            listed, claimed = int(a.telemetry[3].item()), int(a.telemetry[2].item()) - rows0
+            assert listed == torch.unique(idx).numel() and claimed < listed // 2, (listed, claimed)
+    assert torch.equal(a.ridx, b.ridx) and torch.equal(a.weights, b.weights) and torch.equal(a.poses, b.poses)
