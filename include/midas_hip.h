@@ -186,6 +186,16 @@ int midas_cluster_centers(midas_ctx* ctx, int64_t N, const float* poses_dev, con
  * set to 0 (:64), the n best-scoring entries are selected (value descending, smaller index first on ties; np.argpartition
  * leaves ties unspecified) and err_dev[b] = min over them of |feat[j] - feat[row0 + b]|_2 (feat_dev: K x d float64, d <= 16).
  * idx_dev: NULL or B x n int32, the selected entries best first (-1 padded when K < n).  1 <= n <= 256. */
+/* The whole top_n_error of a codebook against itself (single_touch_test.py:35-73) by one call: the K x K x D self-similarity
+ * as a float32 GEMM on the matrix cores (v_mfma_f32_16x16x4_f32: exact float32 fma chains in midas_score_batch's order),
+ * in panels of rows_per_panel query rows (>= 128; a panel is rows x K float32 of scratch), each consumed by the selection
+ * above (cosine = (double)dot / (|E_i| |E_j|), diagonal 0, n best, best pose error).  float32 embeddings, D % 32 == 0.
+ * err_dev: K float64; idx_dev: NULL or K x n int32. */
+/* one panel of it: panel_dev[(i - i0) * ldo + j] = <E_i, E_j> (raw float32 dot products) for i in [i0, i0 + R), all j;
+ * ldo >= ceil(K / 128) * 128, the panel holds ceil(R / 128) * 128 rows (whole tiles are written) */
+int midas_selfsim_panel(midas_ctx* ctx, const midas_codebook* cb, int64_t i0, int64_t R, float* panel_dev, int64_t ldo);
+int midas_selfsim_topn(midas_ctx* ctx, const midas_codebook* cb, int32_t n, const double* feat_dev, int32_t d,
+                       int64_t rows_per_panel, double* err_dev, int32_t* idx_dev);
 int midas_topn_pose_error(midas_ctx* ctx, int32_t B, int64_t K, const double* scores_dev, int64_t row0, int32_t n,
                           const double* feat_dev, int32_t d, double* err_dev, int32_t* idx_dev);
 

@@ -214,6 +214,8 @@ SIGNATURES = {
     "midas_gather_rows": (C.c_int, [_P, _I64, _P, _P, _P, _I32]),
     "midas_rmse": (C.c_int, [_P, _I64, _P, _P, _P]),
     "midas_topn_pose_error": (C.c_int, [_P, _I32, _I64, _P, _I64, _I32, _P, _I32, _P, _P]),
+    "midas_selfsim_topn": (C.c_int, [_P, _P, _I32, _P, _I32, _I64, _P, _P]),
+    "midas_selfsim_panel": (C.c_int, [_P, _P, _I64, _I64, _P, _I64]),
     "midas_cluster_centers": (C.c_int, [_P, _I64, _P, _P, _P, _P, _I32, _P, _P, _P, _P]),
     "midas_filter_step": (C.c_int, [_P, _P, _P, _P, C.POINTER(StepArgs)]),
     "midas_filter_step_batch": (C.c_int, [_P, _P, _P, _P, C.POINTER(StepArgs), _I32]),

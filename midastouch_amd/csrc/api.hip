@@ -1169,6 +1169,33 @@ MIDAS_EXPORT int midas_dbscan(midas_ctx* ctx, int64_t N, const float* poses_dev,
     return launch_dbscan(ctx, N, nullptr, poses_dev, eps, min_samples, labels_dev, ncl_dev, ncl_dev + 1);
 }
 
+MIDAS_EXPORT int midas_selfsim_panel(midas_ctx* ctx, const midas_codebook* cb, int64_t i0, int64_t R, float* panel_dev, int64_t ldo) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, cb && cb->dtype == MIDAS_F32 && cb->D % 32 == 0 && (uintptr_t)cb->emb % 16 == 0 && panel_dev && (uintptr_t)panel_dev % 16 == 0);
+    MIDAS_REQUIRE(ctx, i0 >= 0 && R >= 1 && i0 + R <= cb->K && ldo >= ceil_div(cb->K, 128) * 128 && ldo % 4 == 0);
+    return launch_selfsim_panel(ctx, cb, i0, R, panel_dev, ldo);
+}
+
+MIDAS_EXPORT int midas_selfsim_topn(midas_ctx* ctx, const midas_codebook* cb, int32_t n, const double* feat_dev, int32_t d,
+                                    int64_t rows_per_panel, double* err_dev, int32_t* idx_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, cb && cb->dtype == MIDAS_F32 && cb->D % 32 == 0 && (uintptr_t)cb->emb % 16 == 0 && feat_dev && err_dev);
+    MIDAS_REQUIRE(ctx, n >= 1 && n <= 256 && d >= 1 && d <= 16 && rows_per_panel >= 128);
+    const int64_t K = cb->K, ldo = ceil_div(K, 128) * 128;
+    const int64_t R = ceil_div(rows_per_panel < K ? rows_per_panel : K, 128) * 128;
+    void* panel;
+    int rc = midas_scratch(ctx, (size_t)R * ldo * sizeof(float), &panel);
+    if (rc) return rc;
+    for (int64_t i0 = 0; i0 < K; i0 += R) {
+        const int64_t rows = K - i0 < R ? K - i0 : R;
+        if ((rc = launch_selfsim_panel(ctx, cb, i0, rows, (float*)panel, ldo))) return rc;
+        if ((rc = launch_topn_pose_error_dots(ctx, (int32_t)rows, K, (const float*)panel, ldo, cb->norms, i0, n, feat_dev, d, err_dev + i0,
+                                              idx_dev ? idx_dev + i0 * n : nullptr)))
+            return rc;
+    }
+    return MIDAS_OK;
+}
+
 #ifdef MIDAS_DEBUG_CLOCKS
 MIDAS_EXPORT int midas_debug_tb2_clocks(long long* out16) { return midas::debug_tb2_clocks(out16); }
 #endif

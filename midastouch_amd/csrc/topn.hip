@@ -39,9 +39,12 @@ MD void tn_sort(double* s_v, int* s_i) {
         }
 }
 
-__global__ __launch_bounds__(256) void k_topn_pose_error(int64_t K, const double* __restrict__ scores, int64_t row0, int n,
-                                                         const double* __restrict__ feat, int d, double* __restrict__ err_out,
-                                                         int32_t* __restrict__ idx_out) {
+// DOTS: the row is a float32 panel row of raw dot products (selfsim.hip; stride ld), turned into cosines here with the
+// float64 row norms - (double)dot / (|E_self| |E_j|), the division midas_score_batch performs in its epilogue
+template <bool DOTS>
+__global__ __launch_bounds__(256) void k_topn_pose_error(int64_t K, const void* __restrict__ scores_, int64_t ld, const double* __restrict__ norms,
+                                                         int64_t row0, int n, const double* __restrict__ feat, int d,
+                                                         double* __restrict__ err_out, int32_t* __restrict__ idx_out) {
     __shared__ double s_v[TN_CAP];
     __shared__ int s_i[TN_CAP];
     __shared__ int s_cnt;
@@ -49,7 +52,9 @@ __global__ __launch_bounds__(256) void k_topn_pose_error(int64_t K, const double
     __shared__ double s_red[4];
     const int t = threadIdx.x;
     const int64_t row = blockIdx.x, self = row0 + row;
-    const double* __restrict__ x = scores + row * K;
+    const double* __restrict__ x = reinterpret_cast<const double*>(scores_) + row * ld;
+    const float* __restrict__ xf = reinterpret_cast<const float*>(scores_) + row * ld;
+    const double nself = DOTS ? norms[self] : 1.0;
     for (int e = t; e < TN_CAP; e += 256) { s_v[e] = -INFINITY; s_i[e] = 0x7fffffff; }
     if (t == 0) { s_cnt = 0; s_thr = -INFINITY; }
     __syncthreads();
@@ -59,8 +64,8 @@ __global__ __launch_bounds__(256) void k_topn_pose_error(int64_t K, const double
         double v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int64_t j = base + k * 256 + t;
-            v[k] = x[j < K ? j : K - 1];
+            const int64_t j = base + k * 256 + t, jc = j < K ? j : K - 1;
+            v[k] = DOTS ? (double)xf[jc] / (nself * norms[jc]) : x[jc];
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -114,8 +119,16 @@ __global__ __launch_bounds__(256) void k_topn_pose_error(int64_t K, const double
 
 int launch_topn_pose_error(midas_ctx* ctx, int32_t B, int64_t K, const double* scores, int64_t row0, int32_t n,
                            const double* feat, int32_t d, double* err_out, int32_t* idx_out) {
-    hipLaunchKernelGGL(k_topn_pose_error, dim3((unsigned)B), dim3(256), 0, ctx->stream, K, scores, row0, (int)n, feat, (int)d,
-                       err_out, idx_out);
+    hipLaunchKernelGGL(k_topn_pose_error<false>, dim3((unsigned)B), dim3(256), 0, ctx->stream, K, (const void*)scores, K, (const double*)nullptr, row0, (int)n,
+                       feat, (int)d, err_out, idx_out);
+    MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    return MIDAS_OK;
+}
+
+int launch_topn_pose_error_dots(midas_ctx* ctx, int32_t B, int64_t K, const float* panel, int64_t ld, const double* norms, int64_t row0, int32_t n,
+                                const double* feat, int32_t d, double* err_out, int32_t* idx_out) {
+    hipLaunchKernelGGL(k_topn_pose_error<true>, dim3((unsigned)B), dim3(256), 0, ctx->stream, K, (const void*)panel, ld, norms, row0, (int)n, feat,
+                       (int)d, err_out, idx_out);
     MIDAS_HIP_CHECK(ctx, hipGetLastError());
     return MIDAS_OK;
 }

@@ -2,8 +2,9 @@
 
 `top_n_error` is the reference's K x K self-similarity of the embeddings followed by a per-row top-25 and the best pose
 error among them.  Here the similarity rows come from the scoring kernels tile by tile (exact float64 GEMV rows by default;
-`fast=True` scores 64 queries per pass over the codebook on the matrix cores, float32 accumulation) and the selection
-kernel (`midas_topn_pose_error`) consumes each tile in one pass - the K x K matrix (20 GB at K = 50 k) never exists.
+`fast=True`: the self-similarity as a float32 GEMM on the matrix cores, `midas_selfsim_topn` - panels of `panel_rows`
+queries against all K entries) and the selection kernel (`midas_topn_pose_error`) consumes each tile in one pass - the
+K x K matrix (20 GB at K = 50 k) never exists.
 The heat-map of `filter/filter.py:213-215` is `particle_filter.get_similarity(code, codebook.get_embeddings(), softmax=False)`.
 """
 from __future__ import annotations
@@ -17,7 +18,7 @@ NUM_NEIGHBORS = 25  # single_touch_test.py:32
 
 
 def top_n_error(embeddings: torch.Tensor, poses: torch.Tensor, n: int = NUM_NEIGHBORS, fast: bool = False,
-                tile: int = 256, want_idx: bool = False):
+                tile: int = 256, want_idx: bool = False, panel_rows: int = 2048):
     """(K,) float64: for every codebook entry the smallest |pose_j - pose_i| among its n most similar entries
     (diagonal similarity set to 0 like `np.fill_diagonal(C, 0)`).  embeddings (K, D) and poses (K, d) on a HIP device."""
     emb = embeddings if isinstance(embeddings, torch.Tensor) else torch.as_tensor(embeddings)
@@ -28,6 +29,11 @@ def top_n_error(embeddings: torch.Tensor, poses: torch.Tensor, n: int = NUM_NEIG
     K = emb.shape[0]
     out = torch.empty((K,), dtype=torch.float64, device=emb.device)
     idx_all = torch.empty((K, n), dtype=torch.int32, device=emb.device) if want_idx else None
+    if fast and cb.emb.dtype == torch.float32 and cb.D % 32 == 0:
+        # the whole K x K x D self-similarity as a float32 GEMM on the matrix cores (midas_selfsim_topn), panel by panel
+        cb.ctx.call("midas_selfsim_topn", cb.h, int(n), ops._ptr(feat), int(feat.shape[1]), int(panel_rows), ops._ptr(out),
+                    ops._ptr(idx_all))
+        return (out, idx_all) if want_idx else out
     tile = min(int(tile), 64) if fast else int(tile)
     for i0 in range(0, K, tile):
         q = cb.emb[i0:i0 + tile].to(torch.float64)

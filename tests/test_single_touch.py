@@ -63,3 +63,50 @@ def test_random_error_host():
     poses = np.random.default_rng(0).uniform(-0.1, 0.1, (200, 3))
     e = get_random_error(poses, n=25, rng=np.random.default_rng(1))
     assert 0.0 < e < 0.1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,D", [(3000, 256), (1000, 128), (700, 512), (130, 64)])
+def test_selfsim_panel_equals_batched_scorer_bit_for_bit(K, D, oracle):
+    """k_selfsim_mfma (the K x K x D float32 GEMM of top_n_error on the matrix cores): every dot product equals the oracle's
+    float32 fma chain in the matrix-core order (mo_score_batch_f32's numerator) bit for bit - whole tiles, ragged edges,
+    panels that start in the middle of the codebook."""
+    from midastouch_amd import ops
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(K + D)
+    E = rng.standard_normal((K, D)).astype(np.float32)
+    cbk = ops.Codebook(torch.as_tensor(E).to(dev))
+    ldo = -(-K // 128) * 128
+    for i0, R in ((0, min(K, 300)), (K // 3, min(K - K // 3, 129))):
+        panel = torch.zeros((-(-R // 128) * 128, ldo), dtype=torch.float32, device=dev)
+        cbk.ctx.call("midas_selfsim_panel", cbk.h, i0, R, ops._ptr(panel), ldo)
+        got = panel[:R, :K].cpu().numpy()
+        # the oracle's chain: for c (16 d-values), s, g: acc = fmaf(E_j[d], E_i[d], acc), d = 16 c + 4 g + s
+        order = np.array([16 * c + 4 * g + s for c in range(D // 16) for s in range(4) for g in range(4)])
+        rows = rng.choice(R, size=min(R, 12), replace=False)
+        for r in rows:
+            acc = np.zeros(K, dtype=np.float32)
+            q = E[i0 + r]
+            for dd in order:  # float32 fma emulated in float64 (the product of two float32 is exact there, one rounding)
+                acc = (E[:, dd].astype(np.float64) * np.float64(q[dd]) + acc.astype(np.float64)).astype(np.float32)
+            assert np.array_equal(got[r], acc), (K, D, i0, r)
+
+
+@pytest.mark.gpu
+def test_top_n_error_gemm_path_matches_reference_arithmetic():
+    """fast=True (midas_selfsim_topn) against the numpy restatement of the reference's arithmetic: the selected sets agree
+    wherever the n-th and (n+1)-th similarities are apart by more than float32 accumulation error."""
+    from midastouch_amd.single_touch import top_n_error
+    dev = torch.device("cuda", 0)
+    for K, D, n, rows in ((2500, 256, 25, 512), (900, 128, 7, 128)):
+        cb = make_codebook(K=K, D=D, seed=1300 + K, mesh_points=2000)
+        poses = cb.poses[:, :3, 3].astype(np.float64)
+        ref, best, C = ref_top_n_error(cb.embeddings, poses, n)
+        err, idx = top_n_error(torch.as_tensor(cb.embeddings).to(dev), torch.as_tensor(poses).to(dev), n=n, fast=True, want_idx=True, panel_rows=rows)
+        idx = idx.cpu().numpy()
+        srt = -np.sort(-C, axis=1)
+        clear = (srt[:, n - 1] - srt[:, n]) > 1e-5
+        assert clear.mean() > 0.9
+        same = np.array([set(idx[i]) == set(best[i]) for i in range(K)])
+        assert same[clear].all()
+        np.testing.assert_allclose(err.cpu().numpy()[clear], ref[clear], rtol=1e-12, atol=1e-15)
