@@ -1183,17 +1183,43 @@ MIDAS_EXPORT int midas_selfsim_topn(midas_ctx* ctx, const midas_codebook* cb, in
     MIDAS_REQUIRE(ctx, n >= 1 && n <= 256 && d >= 1 && d <= 16 && rows_per_panel >= 128);
     const int64_t K = cb->K, ldo = ceil_div(K, 128) * 128;
     const int64_t R = ceil_div(rows_per_panel < K ? rows_per_panel : K, 128) * 128;
+    const int64_t npanels = ceil_div(K, R);
+    // Two panels: the selection of panel p (bound by its reads of the panel and by LDS sorts) runs on a side stream beside
+    // the GEMM of panel p + 1 (bound by the matrix pipe).  Events hand the panels back and forth.
+    const int nbuf = npanels > 1 ? 2 : 1;
     void* panel;
-    int rc = midas_scratch(ctx, (size_t)R * ldo * sizeof(float), &panel);
+    int rc = midas_scratch(ctx, (size_t)nbuf * R * ldo * sizeof(float), &panel);
     if (rc) return rc;
-    for (int64_t i0 = 0; i0 < K; i0 += R) {
-        const int64_t rows = K - i0 < R ? K - i0 : R;
-        if ((rc = launch_selfsim_panel(ctx, cb, i0, rows, (float*)panel, ldo))) return rc;
-        if ((rc = launch_topn_pose_error_dots(ctx, (int32_t)rows, K, (const float*)panel, ldo, cb->norms, i0, n, feat_dev, d, err_dev + i0,
-                                              idx_dev ? idx_dev + i0 * n : nullptr)))
-            return rc;
+    if (!ctx->side) MIDAS_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    hipEvent_t ev_gemm[2] = {nullptr, nullptr}, ev_sel[2] = {nullptr, nullptr};
+    for (int k = 0; k < nbuf; ++k) {
+        MIDAS_HIP_CHECK(ctx, hipEventCreateWithFlags(&ev_gemm[k], hipEventDisableTiming));
+        MIDAS_HIP_CHECK(ctx, hipEventCreateWithFlags(&ev_sel[k], hipEventDisableTiming));
     }
-    return MIDAS_OK;
+    hipStream_t main_stream = ctx->stream;
+    // the side stream starts behind whatever the main stream holds (the caller's inputs)
+    MIDAS_HIP_CHECK(ctx, hipEventRecord(ev_sel[0], main_stream));
+    MIDAS_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ev_sel[0], 0));
+    rc = MIDAS_OK;
+    for (int64_t p = 0; p < npanels && rc == MIDAS_OK; ++p) {
+        const int k = (int)(p % nbuf);
+        const int64_t i0 = p * R, rows = K - i0 < R ? K - i0 : R;
+        float* pan = (float*)panel + (size_t)k * R * ldo;
+        if (p >= nbuf) MIDAS_HIP_CHECK(ctx, hipStreamWaitEvent(main_stream, ev_sel[k], 0));  // the panel's previous tenant has been consumed
+        rc = launch_selfsim_panel(ctx, cb, i0, rows, pan, ldo);
+        if (rc) break;
+        MIDAS_HIP_CHECK(ctx, hipEventRecord(ev_gemm[k], main_stream));
+        MIDAS_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ev_gemm[k], 0));
+        ctx->stream = ctx->side;  // the launcher enqueues on ctx->stream
+        rc = launch_topn_pose_error_dots(ctx, (int32_t)rows, K, pan, ldo, cb->norms, i0, n, feat_dev, d, err_dev + i0,
+                                         idx_dev ? idx_dev + i0 * n : nullptr);
+        ctx->stream = main_stream;
+        if (rc) break;
+        MIDAS_HIP_CHECK(ctx, hipEventRecord(ev_sel[k], ctx->side));
+    }
+    for (int k = 0; k < nbuf; ++k) (void)hipStreamWaitEvent(main_stream, ev_sel[k], 0);  // the results are ordered behind the main stream again
+    for (int k = 0; k < nbuf; ++k) { (void)hipEventDestroy(ev_gemm[k]); (void)hipEventDestroy(ev_sel[k]); }
+    return rc;
 }
 
 #ifdef MIDAS_DEBUG_CLOCKS

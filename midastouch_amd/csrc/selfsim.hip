@@ -45,28 +45,36 @@ __global__ __launch_bounds__(256, 2) void k_selfsim_mfma(const float* __restrict
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, i = lane & 15;
     const int wi = wave >> 1, wj = wave & 1;
     const int64_t ibase = i0 + (int64_t)ti_ * SS_T, jbase = (int64_t)tj_ * SS_T;
-    // ---- staging: thread t moves 64 bytes of row t/2 of each operand per chunk ----
-    const int srow = t >> 1, shalf = t & 1;
-    const int64_t ja = jbase + srow < K ? jbase + srow : K - 1, ib = ibase + srow < K ? ibase + srow : K - 1;  // surplus rows: computed, never read
-    const float* ga = emb + ja * (int64_t)D + shalf * 16;
-    const float* gb = emb + ib * (int64_t)D + shalf * 16;
-    const int soff = srow * SS_LD + shalf * 16;
+    // ---- staging: per chunk a thread moves one 16-byte piece of four rows of each operand; the eight threads of a row fetch its
+    // whole 128-byte line (a vector-cache lookup per LINE, not per piece: rows fetched as half lines by thread pairs kept the
+    // load path as busy as the matrix pipe) ----
+    const int srow = t >> 3, spiece = t & 7;
+    const float* ga[4];
+    const float* gb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // surplus rows (beyond K): clamped, computed, never read
+        const int64_t ja = jbase + srow + 32 * q < K ? jbase + srow + 32 * q : K - 1;
+        const int64_t ib = ibase + srow + 32 * q < K ? ibase + srow + 32 * q : K - 1;
+        ga[q] = emb + ja * (int64_t)D + 4 * spiece;
+        gb[q] = emb + ib * (int64_t)D + 4 * spiece;
+    }
+    const int soff = srow * SS_LD + 4 * spiece;
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;  // staging registers (named: arrays behind lambdas went to scratch memory)
 #define SS_FETCH(d0)                                                                                         \
     do {                                                                                                     \
-        ra0 = *reinterpret_cast<const float4*>(ga + (d0));      ra1 = *reinterpret_cast<const float4*>(ga + (d0) + 4);  \
-        ra2 = *reinterpret_cast<const float4*>(ga + (d0) + 8);  ra3 = *reinterpret_cast<const float4*>(ga + (d0) + 12); \
-        rb0 = *reinterpret_cast<const float4*>(gb + (d0));      rb1 = *reinterpret_cast<const float4*>(gb + (d0) + 4);  \
-        rb2 = *reinterpret_cast<const float4*>(gb + (d0) + 8);  rb3 = *reinterpret_cast<const float4*>(gb + (d0) + 12); \
+        ra0 = *reinterpret_cast<const float4*>(ga[0] + (d0)); ra1 = *reinterpret_cast<const float4*>(ga[1] + (d0));  \
+        ra2 = *reinterpret_cast<const float4*>(ga[2] + (d0)); ra3 = *reinterpret_cast<const float4*>(ga[3] + (d0));  \
+        rb0 = *reinterpret_cast<const float4*>(gb[0] + (d0)); rb1 = *reinterpret_cast<const float4*>(gb[1] + (d0));  \
+        rb2 = *reinterpret_cast<const float4*>(gb[2] + (d0)); rb3 = *reinterpret_cast<const float4*>(gb[3] + (d0));  \
     } while (0)
 #define SS_STAGE(buf)                                                                                        \
     do {                                                                                                     \
         float* da = &s_a[buf][soff];                                                                         \
         float* db = &s_b[buf][soff];                                                                         \
-        *reinterpret_cast<float4*>(da) = ra0;      *reinterpret_cast<float4*>(da + 4) = ra1;                 \
-        *reinterpret_cast<float4*>(da + 8) = ra2;  *reinterpret_cast<float4*>(da + 12) = ra3;                \
-        *reinterpret_cast<float4*>(db) = rb0;      *reinterpret_cast<float4*>(db + 4) = rb1;                 \
-        *reinterpret_cast<float4*>(db + 8) = rb2;  *reinterpret_cast<float4*>(db + 12) = rb3;                \
+        *reinterpret_cast<float4*>(da) = ra0;                *reinterpret_cast<float4*>(da + 32 * SS_LD) = ra1;  \
+        *reinterpret_cast<float4*>(da + 64 * SS_LD) = ra2;   *reinterpret_cast<float4*>(da + 96 * SS_LD) = ra3;  \
+        *reinterpret_cast<float4*>(db) = rb0;                *reinterpret_cast<float4*>(db + 32 * SS_LD) = rb1;  \
+        *reinterpret_cast<float4*>(db + 64 * SS_LD) = rb2;   *reinterpret_cast<float4*>(db + 96 * SS_LD) = rb3;  \
     } while (0)
     ss_f32x4 acc[4][4];
 #pragma unroll

@@ -18,7 +18,7 @@ NUM_NEIGHBORS = 25  # single_touch_test.py:32
 
 
 def top_n_error(embeddings: torch.Tensor, poses: torch.Tensor, n: int = NUM_NEIGHBORS, fast: bool = False,
-                tile: int = 256, want_idx: bool = False, panel_rows: int = 2048):
+                tile: int = 256, want_idx: bool = False, panel_rows: int = 4096):
     """(K,) float64: for every codebook entry the smallest |pose_j - pose_i| among its n most similar entries
     (diagonal similarity set to 0 like `np.fill_diagonal(C, 0)`).  embeddings (K, D) and poses (K, d) on a HIP device."""
     emb = embeddings if isinstance(embeddings, torch.Tensor) else torch.as_tensor(embeddings)

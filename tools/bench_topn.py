@@ -30,7 +30,8 @@ panel = torch.empty((-(-R // 128) * 128, ldo), dtype=torch.float32, device=dev)
 lib, ctx = codebook.ctx.lib, codebook.ctx
 import ctypes as C
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-if hasattr(lib, "midas_selfsim_panel"):
+for R in (R, 4096, 8192):
+    panel = torch.empty((-(-R // 128) * 128, ldo), dtype=torch.float32, device=dev)
     for _ in range(2):
         ctx.call("midas_selfsim_panel", codebook.h, 0, R, ops._ptr(panel), ldo)
     e0.record()
@@ -38,5 +39,5 @@ if hasattr(lib, "midas_selfsim_panel"):
         ctx.call("midas_selfsim_panel", codebook.h, 0, R, ops._ptr(panel), ldo)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
-    res["k_selfsim_mfma"] = {"panel_rows": R, "ms": ms, "tflops": 2.0 * R * K * D / (ms * 1e-3) / 1e12, "frac_of_157.3": 2.0 * R * K * D / (ms * 1e-3) / 1e12 / 157.3}
+    res[f"k_selfsim_mfma_{R}"] = {"panel_rows": R, "ms": ms, "tflops": 2.0 * R * K * D / (ms * 1e-3) / 1e12, "frac_of_157.3": 2.0 * R * K * D / (ms * 1e-3) / 1e12 / 157.3}
 print(json.dumps(res))
