@@ -52,12 +52,17 @@ class HipShardBackend:
     all_gather of the per-rank score slices; poses, the NN index and the mesh index stay replicated.
     """
 
-    def __init__(self, cb_poses, cb_embeddings, mesh_vertices, device, row_shard=None):
+    def __init__(self, cb_poses, cb_embeddings, mesh_vertices, device, row_shard=None, share=None):
+        """share: another backend of the SAME process and codebook whose replicated indices (poses, 6-d features, neighbour /
+        vertex lists, mesh tree) this one uses instead of building its own (several shards on one GPU: tests, row sharding)."""
         self.ctx = _lib.context(device)
         self.device = self.ctx.device
-        self.cb_poses = torch.as_tensor(cb_poses).to(self.device, torch.float32).contiguous()
-        self.cb_feat = ops.se3_feature(self.cb_poses)
-        self.tree6 = ops.Tree(self.cb_feat)
+        if share is not None:
+            self.cb_poses, self.cb_feat, self.tree6 = share.cb_poses, share.cb_feat, share.tree6
+        else:
+            self.cb_poses = torch.as_tensor(cb_poses).to(self.device, torch.float32).contiguous()
+            self.cb_feat = ops.se3_feature(self.cb_poses)
+            self.tree6 = ops.Tree(self.cb_feat)
         emb = torch.as_tensor(cb_embeddings)
         self.row_shard = row_shard
         if row_shard is not None:
@@ -67,8 +72,11 @@ class HipShardBackend:
                 raise MidasError("codebook-row sharding needs K divisible by the number of ranks")
             emb = emb[r * (K // w):(r + 1) * (K // w)]
         self.codebook = ops.Codebook(emb.to(self.device))
-        self.tree3 = ops.Tree(torch.as_tensor(mesh_vertices).to(self.device, torch.float64))
-        self.tree6.attach_mesh(self.tree3, self.cb_poses)
+        if share is not None:
+            self.tree3 = share.tree3
+        else:
+            self.tree3 = ops.Tree(torch.as_tensor(mesh_vertices).to(self.device, torch.float64))
+            self.tree6.attach_mesh(self.tree3, self.cb_poses)
         self.K = int(self.cb_poses.shape[0])
         self.D = int(emb.shape[1])
         import os

@@ -123,6 +123,81 @@ def test_sharded_engine_vs_oracle(dev, oracle):
             poses = ref["poses"]
 
 
+class _Cat:
+    """The shards of one process seen as one engine (what _check_frame reads)."""
+
+    def __init__(self, engs):
+        self.engs, self.N = engs, sum(e.N for e in engs)
+
+    def __getattr__(self, name):
+        if name == "status":
+            return self.engs[0].status
+        return torch.cat([getattr(e, name) for e in self.engs])
+
+
+@pytest.mark.parametrize("exchange", ["peer_c", "a2a"])
+def test_config3_partitioned_full_size(dev, oracle, exchange):
+    """c3 in its PARTITIONED form at (nearly) full size on one GPU: eight particle shards of 122 880 (30 summation blocks each,
+    983 040 particles in all) against the replicated 50k x 512 codebook, stepped in lock-step - the frame of all particles
+    (device draws keyed by the global slot) against the oracle's arithmetic downstream of the device's NN / prune decisions,
+    which are checked by brute force on a sample; and bit for bit against the fused single-engine frame."""
+    from midastouch_amd.dist import HipShardBackend, ShardedFilterEngine, connect_local_peers, run_lockstep
+    from midastouch_amd.engine import FilterEngine
+    from midastouch_amd.synthetic import make_codebook, make_trajectory
+    from test_gpu_dist import FakeComm
+    G, n_loc, K, D, seed = 8, 122_880, 50_000, 512, 4000
+    N = G * n_loc
+    cb = make_codebook("035_power_drill", K=K, D=D, seed=1003)
+    traj = make_trajectory(cb, T=5, seed=2003)
+    start = cb.poses[np.random.default_rng(0).integers(0, K, N)]
+    be = HipShardBackend(cb.poses, cb.embeddings, cb.mesh_vertices, dev)
+    engs = [ShardedFilterEngine(num_particles=n_loc, backend=be, comm=FakeComm(r, G), seed=seed, exchange="a2a") for r in range(G)]
+    if exchange == "peer_c":
+        connect_local_peers(engs, "peer_c")
+    single = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=seed, device=dev)
+    single.set_particles(torch.as_tensor(start))
+    for r, e in enumerate(engs):
+        e.set_particles(torch.as_tensor(start[r * n_loc:(r + 1) * n_loc]))
+    whole = _Cat(engs)
+    for t in range(1, 3):
+        od, code = torch.as_tensor(traj.odoms[t]).to(dev), torch.as_tensor(traj.codes[t]).to(dev)
+        run_lockstep(engs, [((od, code), {}) for _ in engs])
+        single.step(od, code)
+        assert torch.equal(whole.nn_idx, single.nn_idx) and torch.equal(whole.ridx, single.ridx), t
+        assert torch.equal(whole.poses, single.poses) and torch.equal(whole.weights, single.weights), t
+        _check_frame(whole, oracle, cb, traj.codes[t], seed, t - 1)
+    for e in engs:
+        e.close()
+
+
+def test_config4_partitioned_full_size(dev, oracle):
+    """c4 in its PARTITIONED form at full size on one GPU: the 500k x 512 codebook's embedding rows split over eight shards
+    (62 500 rows each; the pose index is shared between the in-process shards, on a node every GPU holds it), eight particle
+    shards of 12 288: score slices gathered, then the sharded frame - against the oracle (scores of all 500k rows exact,
+    weights / indices exact downstream of the device's NN / prune decisions, those by brute force on a sample)."""
+    from midastouch_amd.dist import HipShardBackend, ShardedFilterEngine, run_lockstep
+    from midastouch_amd.synthetic import make_codebook, make_trajectory
+    from test_gpu_dist import FakeComm
+    G, n_loc, K, D, seed = 8, 12_288, 500_000, 512, 4000
+    cb = make_codebook("025_mug", K=K, D=D, seed=1004)
+    traj = make_trajectory(cb, T=4, seed=2004)
+    start = cb.poses[np.random.default_rng(0).integers(0, K, G * n_loc)]
+    engs, first = [], None
+    for r in range(G):
+        be = HipShardBackend(cb.poses, cb.embeddings, cb.mesh_vertices, dev, row_shard=(r, G), share=first)
+        first = first or be
+        assert be.codebook.K == K // G
+        e = ShardedFilterEngine(num_particles=n_loc, backend=be, comm=FakeComm(r, G), seed=seed)
+        e.set_particles(torch.as_tensor(start[r * n_loc:(r + 1) * n_loc]))
+        engs.append(e)
+    whole = _Cat(engs)
+    for t in range(1, 3):
+        od, code = torch.as_tensor(traj.odoms[t]).to(dev), torch.as_tensor(traj.codes[t]).to(dev)
+        run_lockstep(engs, [((od, code), {}) for _ in engs])
+        _check_frame(whole, oracle, cb, traj.codes[t], seed, t - 1)
+        assert np.array_equal(engs[3].st.scores.cpu().numpy(), oracle.score_codebook(cb.embeddings, traj.codes[t])), t
+
+
 @pytest.mark.parametrize("engine", ["BatchFilterEngine", "PipelinedBatchFilterEngine"])
 def test_config5_batch_full_size(dev, oracle, engine):
     """c5 at its full size on one GPU: B = 64 trajectories x N = 10 000 particles against the cotter pin's dense 50k x 512
