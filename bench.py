@@ -241,6 +241,13 @@ def main():
                     help="resampler mode (particle_filter.py:230-307): the reference's default multinomial draws, or systematic")
     args = ap.parse_args()
 
+    def guarded(fn, *a, **kw):
+        """the figures beside the headline must not cost the line: a failure is reported in their place"""
+        try:
+            return fn(*a, **kw)
+        except Exception as e:  # noqa: BLE001
+            return {"error": f"{type(e).__name__}: {e}"}
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -323,6 +330,21 @@ def main():
     wide_init(100 + rank)
     frames(0, 2)  # library load, allocator, first-touch: not part of any figure
     torch.cuda.synchronize()
+    exchange_fallback = None
+    if sharded and eng.exchange in ("peer", "peer_c"):
+        # the peer-mapped forms wait (bounded) for rows / flags other ranks store into this rank's memory: if that path does not
+        # deliver on this node (status bit 16 on any rank after the first frames), every rank falls back to the counted
+        # all_to_all over torch.distributed rather than timing a frame that lost its exchange
+        bad = torch.tensor([int(eng.status[0].item()) & 16], dtype=torch.int32, device=dev)
+        if dist is not None and world > 1:
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()):
+            exchange_fallback = f"{eng.exchange} -> a2a (flags of the peer-mapped exchange did not arrive)"
+            eng.close()
+            eng = ShardedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=4000, device=dev, exchange="a2a", resample=args.resample)
+            wide_init(100 + rank)
+            frames(0, 2)
+            torch.cuda.synchronize()
     diffuse = None
     if not sharded and not args.no_diffuse:  # the first frames after a wide start: hints are stale, the cloud covers the whole object
         wide_init(200 + rank)
@@ -413,10 +435,12 @@ def main():
                              "mostly a small-N figure; floor_N holds all N particles (the rate a caller sees who never lets the set anneal): "
                              "bound by its DBSCAN frames (every 50th, ms_frame_max)")
         if not args.no_extras:
-            loop_rate["floor_N"] = reference_loop_rate(cb, traj, N, dev, tree, eng.tree3, T=110, floor=N)
+            loop_rate["floor_N"] = guarded(reference_loop_rate, cb, traj, N, dev, tree, eng.tree3, T=110, floor=N)
     exchange_info = None
     if sharded:
-        exchange_info = {"form": eng.exchange, "peer_mapping": "ok" if eng.exchange == "peer" else (eng.peer_error or "not tried")}
+        exchange_info = {"form": eng.exchange, "peer_mapping": "ok" if eng.exchange in ("peer", "peer_c") else (eng.peer_error or "not tried"),
+                         "library_owned_rccl_communicator": bool(getattr(eng, "_ccomm", None) is not None), "fallback": exchange_fallback,
+                         "status_last_frame": eng.status.cpu().numpy().tolist()}
         if eng.exchange == "a2a_fixed":  # rows beyond the overflow block's capacity would have been lost: must not happen
             ov = eng.backend.overflow_rows(eng.st, world)
             exchange_info.update(segment_rows=eng.seg_cap, overflow_capacity=eng.ovf_cap, overflow_rows_last_frame=ov,
@@ -548,13 +572,13 @@ def main():
                            "algorithmic_bytes_per_launch": ab["step"], "kernel_ms": ms_per_step, "step_bytes": ab["step"],
                            "step_frac": achieved / HBM_PEAK_GBS}
     if not sharded and not args.no_extras:
-        out["config"]["parity_mode"] = parity_mode_rate(cb, traj, N, dev, tree, eng.tree3)
+        out["config"]["parity_mode"] = guarded(parity_mode_rate, cb, traj, N, dev, tree, eng.tree3)
         if N == 100_000 and K == 50_000 and D == 512:  # beside the headline workload only
-            out["config"]["c5"] = config5_rate(dev)
+            out["config"]["c5"] = guarded(config5_rate, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cb, traj, N)
         if not sharded and not args.eager and args.resample == "weighted_random":
-            out["cpu_baseline"]["parity_probe"] = parity_probe(eng, N, 4000)
+            out["cpu_baseline"]["parity_probe"] = guarded(parity_probe, eng, N, 4000)
     if rank == 0:
         try:  # anything native libraries left in the C stdio buffer goes out first: the JSON line is the last line
             import ctypes
