@@ -6,8 +6,12 @@
 // at sensor rate.  min_samples is huge (N / 5), which shapes the algorithm:
 //   * uniform grid of side h = 0.577 eps (cube diagonal < eps): all points of a cell are mutual neighbours, candidates
 //     live in the 5 x 5 x 5 cells around a point (two cells away is already > eps apart in that axis);
-//   * core test: cell population first (no distance at all), then the population of the 125 cells as an upper bound,
-//     then exact tests with an early exit at min_samples;
+//   * core test: cell population first (no distance at all); then, from the TIGHT bounding box of every cell's points, a
+//     lower bound (cells whose box lies wholly within eps of the point count in full) and an upper bound (cells whose box
+//     is wholly beyond eps count nothing) over the 125 cells; only a point neither bound decides gets exact tests, and
+//     those only against the cells its ball cuts, with an early exit at min_samples.  (Round 2 had the 125-cell population
+//     as the only bound: a converged cloud of 100k particles spread over a few cells of 12k - below N / 5 each - sent 30k
+//     points into 20k exact tests each, 34 ms a call.)
 //   * components: the core points of a cell form a clique -> one representative per cell; a core point only needs ONE
 //     partner within eps per neighbouring cell to join that cell's component (lock-free union-find, larger root under
 //     smaller, so a root is the smallest particle index of its cluster);
@@ -52,6 +56,7 @@ struct DbArgs {
     int32_t* cell_start;    // [DB_MAXCELLS + 1]
     int32_t* cell_rep;      // [DB_MAXCELLS] smallest particle index among the cell's core points (INT_MAX: none)
     int32_t* cell_num;      // [DB_MAXCELLS] cluster number of the cell's core points (-1: none)
+    uint32_t* cell_box;     // [6][DB_MAXCELLS] tight bounds of the cell's points (lo x y z, hi x y z) as order-preserving keys
     int32_t* cid;           // [N] cell of particle i
     int32_t* s_orig;        // [N] sorted position -> particle
     float4* s_pt;           // [N] sorted position -> (x, y, z, cell id as int bits)
@@ -129,6 +134,38 @@ __global__ __launch_bounds__(64) void k_db_setup(DbArgs a, int nblocks) {
     g.err = err;
     g.nwork = 0;
     *a.grid = g;
+}
+
+// float32 <-> uint32 keys whose unsigned order is the floats' order (atomicMin / atomicMax on bounds)
+__device__ __forceinline__ uint32_t db_key(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float db_unkey(uint32_t k) { return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
+
+// Squared distance bounds between point p and the tight box of cell c2, IN THE PREDICATE'S ARITHMETIC (float64 on the float32
+// coordinates, ((dx dx) + dy dy) + dz dz): for every point q of the cell |p_a - q_a| lies between the per-axis gap and the
+// per-axis far distance, and rounding is monotone through the differences, squares and sums - so maxd2 <= r2 means EVERY
+// point of the cell passes the exact test and mind2 > r2 means none does.
+__device__ __forceinline__ void db_box_bounds(const DbArgs& a, int c2, const float4& p, double& mind2, double& maxd2) {
+    double lo[3], hi[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        lo[d] = (double)db_unkey(a.cell_box[(size_t)d * DB_MAXCELLS + c2]);
+        hi[d] = (double)db_unkey(a.cell_box[(size_t)(3 + d) * DB_MAXCELLS + c2]);
+    }
+    const double pc[3] = {(double)p.x, (double)p.y, (double)p.z};
+    double gmin[3], gmax[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const double u = pc[d] - lo[d], v = hi[d] - pc[d];  // both >= 0 inside the box
+        gmax[d] = u > v ? u : v;
+        const double below = lo[d] - pc[d], above = pc[d] - hi[d];
+        const double g = below > above ? below : above;
+        gmin[d] = g > 0.0 ? g : 0.0;
+    }
+    mind2 = gmin[0] * gmin[0]; mind2 += gmin[1] * gmin[1]; mind2 += gmin[2] * gmin[2];
+    maxd2 = gmax[0] * gmax[0]; maxd2 += gmax[1] * gmax[1]; maxd2 += gmax[2] * gmax[2];
 }
 
 __device__ __forceinline__ int db_cell_of(const DbGrid& g, float x, float y, float z, int& cx, int& cy, int& cz) {
@@ -225,7 +262,11 @@ __global__ __launch_bounds__(1024) void k_db_scan(DbArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = base + t * 8 + j;
-            if (c < g.ncells) { a.cell_start[c] = run; a.cell_count[c] = run; a.cell_rep[c] = 0x7fffffff; a.cell_num[c] = -1; }
+            if (c < g.ncells) {
+                a.cell_start[c] = run; a.cell_count[c] = run; a.cell_rep[c] = 0x7fffffff; a.cell_num[c] = -1;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { a.cell_box[(size_t)d * DB_MAXCELLS + c] = 0xFFFFFFFFu; a.cell_box[(size_t)(3 + d) * DB_MAXCELLS + c] = 0u; }
+            }
             run += v[j];
         }
         __syncthreads();
@@ -241,10 +282,45 @@ __global__ __launch_bounds__(256) void k_db_scatter(DbArgs a) {
     const bool in = i < g.n;
     const int c = in ? a.cid[i] : 0;
     const int p = db_cell_fetch_inc(a.cell_count, c, in);
-    if (!in) return;
-    const float* P = a.poses + i * 16;
-    a.s_orig[p] = (int32_t)i;
-    a.s_pt[p] = make_float4(P[3], P[7], P[11], __int_as_float(c));
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (in) {
+        const float* P = a.poses + i * 16;
+        x = P[3]; y = P[7]; z = P[11];
+        a.s_orig[p] = (int32_t)i;
+        a.s_pt[p] = make_float4(x, y, z, __int_as_float(c));
+    }
+    // tight bounds of the cell's points: the lanes of a wave that share a cell reduce first (one atomic per cell and bound)
+    const uint32_t k[3] = {db_key(x), db_key(y), db_key(z)};
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(in);
+    for (int it = 0; it < DB_AGG_KEYS && todo; ++it) {
+        const int l = __builtin_ctzll(todo);
+        const int cl = __shfl(c, l);
+        const unsigned long long same = __ballot(in && c == cl) & todo;
+        const bool mine = (same >> lane) & 1ull;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            uint32_t mn = mine ? k[d] : 0xFFFFFFFFu, mx = mine ? k[d] : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t u = (uint32_t)__shfl_xor((int)mn, o), v = (uint32_t)__shfl_xor((int)mx, o);
+                mn = u < mn ? u : mn;
+                mx = v > mx ? v : mx;
+            }
+            if (lane == l) {
+                atomicMin(&a.cell_box[(size_t)d * DB_MAXCELLS + cl], mn);
+                atomicMax(&a.cell_box[(size_t)(3 + d) * DB_MAXCELLS + cl], mx);
+            }
+        }
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1ull) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            atomicMin(&a.cell_box[(size_t)d * DB_MAXCELLS + c], k[d]);
+            atomicMax(&a.cell_box[(size_t)(3 + d) * DB_MAXCELLS + c], k[d]);
+        }
+    }
 }
 
 __device__ __forceinline__ bool db_within(const float4& p, const float4& q, double r2) {
@@ -284,9 +360,17 @@ __global__ __launch_bounds__(256) void k_db_core(DbArgs a) {
         const int cnt = a.cell_start[c + 1] - a.cell_start[c];
         state = cnt >= g.ms ? 1 : 0;
         if (!state) {
-            int upper = cnt;
-            db_for_cells(g, c, false, [&](int c2) { upper += a.cell_start[c2 + 1] - a.cell_start[c2]; return false; });
-            if (upper >= g.ms) state = 2;
+            int lower = cnt, upper = cnt;  // the own cell: all of it within eps
+            db_for_cells(g, c, false, [&](int c2) {
+                const int pop = a.cell_start[c2 + 1] - a.cell_start[c2];
+                if (pop == 0) return false;
+                double mind2, maxd2;
+                db_box_bounds(a, c2, me, mind2, maxd2);
+                if (maxd2 <= a.r2) { lower += pop; upper += pop; }
+                else if (mind2 <= a.r2) upper += pop;
+                return lower >= g.ms;
+            });
+            state = lower >= g.ms ? 1 : (upper >= g.ms ? 2 : 0);
         }
         orig = a.s_orig[p];
         a.parent[orig] = orig;
@@ -308,8 +392,13 @@ __global__ __launch_bounds__(256) void k_db_core_count(DbArgs a) {
         const int c = __float_as_int(me.w);
         int cnt = a.cell_start[c + 1] - a.cell_start[c];
         db_for_cells(g, c, false, [&](int c2) {
-            const int e = a.cell_start[c2 + 1];
-            for (int q0 = a.cell_start[c2]; q0 < e; q0 += 64) {
+            const int e = a.cell_start[c2 + 1], b0 = a.cell_start[c2];
+            if (e == b0) return false;
+            double mind2, maxd2;
+            db_box_bounds(a, c2, me, mind2, maxd2);
+            if (mind2 > a.r2) return false;                               // wholly beyond eps
+            if (maxd2 <= a.r2) { cnt += e - b0; return cnt >= g.ms; }     // wholly within eps: no test needed
+            for (int q0 = b0; q0 < e; q0 += 64) {
                 const int q = q0 + lane;
                 const bool in = q < e && db_within(me, a.s_pt[q < e ? q : e - 1], a.r2);
                 cnt += __popcll(__ballot(in));
@@ -368,6 +457,9 @@ __global__ __launch_bounds__(256) void k_db_link(DbArgs a) {
         const int32_t rep2 = a.cell_rep[c2];
         if (rep2 == 0x7fffffff) return false;  // no core point there
         if (db_find(a.parent, rep2) == db_find(a.parent, orig)) return false;
+        double mind2, maxd2;
+        db_box_bounds(a, c2, me, mind2, maxd2);
+        if (mind2 > a.r2) return false;  // nobody of that cell is within eps
         const int e = a.cell_start[c2 + 1];
         for (int q = a.cell_start[c2]; q < e; ++q)
             if (a.s_core[q] && db_within(me, a.s_pt[q], a.r2)) { db_union(a.parent, orig, rep2); break; }
@@ -461,6 +553,7 @@ int launch_dbscan(midas_ctx* ctx, int64_t cap, const int32_t* n_dev, const float
     DB_SCRATCH(cell_start, int32_t, DB_MAXCELLS + 1);
     DB_SCRATCH(cell_rep, int32_t, DB_MAXCELLS);
     DB_SCRATCH(cell_num, int32_t, DB_MAXCELLS);
+    DB_SCRATCH(cell_box, uint32_t, 6 * (size_t)DB_MAXCELLS);
     DB_SCRATCH(cid, int32_t, cap);
     DB_SCRATCH(s_orig, int32_t, cap);
     DB_SCRATCH(s_pt, float4, cap);

@@ -37,7 +37,7 @@ def test_dbscan_matches_reference_fixture(dev, golden):
         assert info.cpu().tolist() == [int(ref.max()) + 1, 0]
 
 
-@pytest.mark.parametrize("case", ["blobs_small_ms", "many_clusters", "chain", "spread20k", "dense", "single"])
+@pytest.mark.parametrize("case", ["blobs_small_ms", "many_clusters", "chain", "spread20k", "dense", "single", "converged24k", "two_scales"])
 def test_dbscan_matches_oracle(dev, oracle, case):
     from midastouch_amd import ops
     rng = np.random.default_rng(hash(case) % 1000)
@@ -59,6 +59,11 @@ def test_dbscan_matches_oracle(dev, oracle, case):
         X = rng.uniform(-0.5, 0.5, (20000, 3)) * np.array([0.038, 0.089, 0.175])
     elif case == "dense":  # everything inside a couple of cells
         X = rng.normal(0, 0.0015, (5000, 3))
+    elif case == "converged24k":  # a converged cloud over a few cells, each below N / 5: decided by the cells' tight boxes
+        X = rng.normal(0, 0.0022, (24000, 3)) + np.array([0.0029, 0.0029, 0.0029])  # centred on a cell corner
+    elif case == "two_scales":  # a tight core, a halo around eps (boxes cut by the ball: exact tests) and far noise
+        X = np.concatenate([rng.normal(0, 0.001, (6000, 3)), rng.normal(0, 0.006, (6000, 3)), rng.uniform(-0.05, 0.05, (3000, 3))])
+        X = X[rng.permutation(len(X))]
     else:
         X = np.zeros((1, 3))
     X = X.astype(np.float32)
