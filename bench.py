@@ -435,7 +435,7 @@ def main():
                              "mostly a small-N figure; floor_N holds all N particles (the rate a caller sees who never lets the set anneal): "
                              "bound by its DBSCAN frames (every 50th, ms_frame_max)")
         if not args.no_extras:
-            loop_rate["floor_N"] = guarded(reference_loop_rate, cb, traj, N, dev, tree, eng.tree3, T=110, floor=N)
+            loop_rate["floor_N"] = guarded(reference_loop_rate, cb, traj, N, dev, tree, eng.tree3, T=200, floor=N)
     exchange_info = None
     if sharded:
         exchange_info = {"form": eng.exchange, "peer_mapping": "ok" if eng.exchange in ("peer", "peer_c") else (eng.peer_error or "not tried"),
