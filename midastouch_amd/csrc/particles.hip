@@ -895,6 +895,9 @@ MD void row_best(float& d, int& i) {
 #ifndef MIDAS_CLAIM_DEFER
 #define MIDAS_CLAIM_DEFER 0
 #endif
+#ifndef MIDAS_CLAIM_HASH
+#define MIDAS_CLAIM_HASH 1  // leaders of the row claims through an LDS hash table (score_body.hpp claim_rows_issue); 0: ballot rounds
+#endif
 #ifndef MIDAS_COOP_G
 #define MIDAS_COOP_G 8
 #endif
@@ -1827,7 +1830,7 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
     }
     RowClaim claim{false, 0u};
     if (a.sp.stamps && !(ablate & 16)) {  // ablate 16 (profiling): nobody scores
-        claim = claim_rows_issue(a.sp, live, bi);
+        claim = claim_rows_issue(a.sp, live, bi, MIDAS_CLAIM_HASH ? reinterpret_cast<int*>(s_cd) : nullptr);
         if (!MIDAS_CLAIM_DEFER) st_rows = score_claimed_rows_nj(a.sp, claim, bi);
     }
     MIDAS_TICK(9);
@@ -2167,7 +2170,7 @@ __global__ __launch_bounds__(256, MIDAS_NNP_OCC) void k_particle_nn_prune(TreeVi
     }
     RowClaim claim{false, 0u};
     if (a.sp.stamps) {
-        claim = claim_rows_issue(a.sp, owner && live, nn);
+        claim = claim_rows_issue(a.sp, owner && live, nn, MIDAS_CLAIM_HASH ? reinterpret_cast<int*>(s_cd[w]) : nullptr);
         if (!MIDAS_CLAIM_DEFER) {
             const int nr = score_claimed_rows_nj(a.sp, claim, nn);
             if (a.telemetry && nr && lane == 0) atomicAdd(&a.telemetry[2], (unsigned long long)nr);

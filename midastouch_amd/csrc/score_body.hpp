@@ -94,19 +94,35 @@ MD void score_wave(const T* __restrict__ emb, const double* __restrict__ norms, 
 // four dependent round trips longer than the others, and the kernel ends with its slowest wave.  Exchanging without the
 // look first was measured too: every wave then hammers the same few dozen stamps - front 34 -> 44 us.)
 struct RowClaim { bool leader; uint32_t old; };
-MD RowClaim claim_rows_issue(const SparseScore& sp, bool want, int32_t row) {
+// lds64: 64 ints of the wave's own LDS (nullable).  With it the leaders are elected through a 64-slot hash table - every
+// wanting lane writes its lane number into slot hash(row), the slot's last writer leads its row, and a lane that finds
+// another ROW in its slot leads as well (so a row can have two leaders in a wave: both look, at most one wins the exchange -
+// the claim is idempotent); three instructions instead of one ballot / readlane / compare round per DISTINCT row, of which
+// a wave has ~40 in the steady state and 60 after a wide start (~3000 cycles of a 55 000-cycle wave).
+MD RowClaim claim_rows_issue(const SparseScore& sp, bool want, int32_t row, int* lds64 = nullptr) {
     const int lane = threadIdx.x & 63;
     // leaders: the first lane of each distinct row among the wanting lanes (a per-lane look at the stamps first was
     // measured: 64 scattered 4-byte loads per wave cost more than the election they save - 17.7k vs 20.5k steps/s)
     RowClaim c;
     c.leader = false;
-    unsigned long long todo = __ballot(want);
-    while (todo) {
-        const int l = __builtin_ctzll(todo);
-        const int32_t r = __shfl(row, l);
-        const unsigned long long same = __ballot(want && row == r);
-        c.leader |= lane == l;
-        todo &= ~same;
+    if (lds64) {
+        const int slot = (int)(((unsigned)row ^ ((unsigned)row >> 6) ^ ((unsigned)row >> 12)) & 63u);
+        if (want) lds64[slot] = lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int w = want ? lds64[slot] : lane;
+        const int32_t rw = __shfl(row, w);
+        c.leader = want && (w == lane || rw != row);
+    } else {
+        unsigned long long todo = __ballot(want);
+        while (todo) {
+            const int l = __builtin_ctzll(todo);
+            const int32_t r = __shfl(row, l);
+            const unsigned long long same = __ballot(want && row == r);
+            c.leader |= lane == l;
+            todo &= ~same;
+        }
     }
     c.old = sp.epoch;
     if (c.leader) c.old = sp.stamps[row];
