@@ -298,25 +298,11 @@ class PipelinedFilterEngine(FilterEngine):
 
     def step(self, odom, code, gt=None, tn=None, rot=None, u=None, u32=-1.0, multiplier: float = 1.0):
         stream = getattr(self, "torch_stream", None)
-        u_ready = None
         if stream is not None and u is None and self.mode == _lib.RESAMPLE_MULTINOMIAL:
             if tn is not None:
                 stream.skip_normal(3 * self.N).skip_normal(3 * self.N)
-            # this frame's uniforms are consumed by the NEXT frame's front kernel (the folded resample) or by flush(): the
-            # generator - one workgroup, 220 us per 10^5 uniforms - runs on a side stream beside this frame's kernels
-            if getattr(self, "_rng_side", None) is None:
-                self._rng_side = torch.cuda.Stream(device=self.device)
-                self._rng_bufs = [torch.empty(self.N, dtype=torch.float64, device=self.device) for _ in range(2)]
-            side, u = self._rng_side, self._rng_bufs[self.step_count & 1]
-            side.wait_stream(torch.cuda.current_stream(self.device))  # the buffer's previous tenant (two frames back) is consumed
-            with torch.cuda.stream(side):
-                stream.rand64(self.N, out=u)
-                u_ready = torch.cuda.Event()
-                u_ready.record(side)
+            u = stream.rand64(self.N)
         odom, code, gt, tn, rot, u = self._operands(odom, code, gt, tn, rot, u)
-        if getattr(self, "_u_ready", None) is not None:  # the previous frame's uniforms (u_prev below) come off the side stream
-            torch.cuda.current_stream(self.device).wait_event(self._u_ready)
-        self._u_ready = u_ready
         cur, nxt = self._cur, self._cur ^ 1
         fold = self._pending and not self._flushed
         a = LazyArgs()
@@ -409,8 +395,6 @@ class PipelinedFilterEngine(FilterEngine):
             return
         cur = self._cur
         u, u32, stp = self._draw
-        if getattr(self, "_u_ready", None) is not None:  # uniforms generated on the side stream (seed_torch_stream)
-            torch.cuda.current_stream(self.device).wait_event(self._u_ready)
         a = LazyFlushArgs()
         a.N = self.N
         a.tables, a.valid, a.nn_idx, a.poses_prop = _ptr(self._tables), _ptr(self._valid), _ptr(self._nn[cur]), _ptr(self._prop[cur])
