@@ -481,12 +481,14 @@ int midas_shard_unpack_peer(midas_ctx* ctx, int64_t N, const void* inbox_dev, in
  * midas_shard_step enqueues, on the context's stream and without returning to the host in between, the phases selected:
  *   MIDAS_SHARD_PHASE_LOCAL     midas_shard_front + midas_shard_tail_a on this rank's particles (record r1_dev)
  *   MIDAS_SHARD_PHASE_GATHER    ncclAllGather of the records -> r1_all_dev (G x (5 nb + 4) doubles); needs `comm`
- *   MIDAS_SHARD_PHASE_ROUTE     owner-side resample straight into the peers' inboxes (midas_shard_route_pack, peer form),
- *                               then this rank stores frame_tag into slot `rank` of the flag block of every inbox
- *                               (G uint64 at inbox + flag_offset, flag_offset >= 88 N)
- *   MIDAS_SHARD_PHASE_UNPACK    the unpack kernel waits until all G slots of its OWN inbox carry the tag (bounded: 2 s,
- *                               then status[0] |= 16), then inbox -> slots - device-side flags over the mapped inboxes
- *                               instead of a second collective.
+ *   MIDAS_SHARD_PHASE_ROUTE     owner-side resample straight into the peers' inboxes (midas_shard_route_pack, peer form)
+ *   MIDAS_SHARD_PHASE_UNPACK    the unpack kernel - launched behind the route kernel, so every row this rank stored is out -
+ *                               first stores frame_tag into slot `rank` of the flag block of every inbox (G uint64 at
+ *                               inbox + flag_offset, flag_offset >= 88 N), then waits until all G slots of its OWN inbox
+ *                               carry the tag (bounded: 2 s, then status[0] |= 16), then inbox -> slots: device-side flags
+ *                               over the mapped inboxes instead of a second collective
+ *   MIDAS_SHARD_PHASE_FLAG      (with ROUTE) the flags are published by a kernel of their own right behind the route kernel
+ *                               instead - shards of ONE process on one stream need every shard's flag out before any waits.
  * A caller without RCCL between its ranks (tests: two processes sharing one GPU) runs LOCAL, gathers the records itself,
  * then runs ROUTE | UNPACK; shards of ONE process on one stream must run every shard's ROUTE before any UNPACK (a waiting
  * kernel in front of the kernel it waits for would never end).  frame_tag must grow from frame to frame (the flag slots are
@@ -503,6 +505,7 @@ int midas_comm_all_gather(midas_comm* comm, const void* send_dev, void* recv_dev
 #define MIDAS_SHARD_PHASE_GATHER 2
 #define MIDAS_SHARD_PHASE_ROUTE 4
 #define MIDAS_SHARD_PHASE_UNPACK 8
+#define MIDAS_SHARD_PHASE_FLAG 16  /* with ROUTE: publish the flags by a kernel of their own right behind the route kernel */
 typedef struct midas_shard_step_args {
     midas_shard_front_args front;   /* as midas_shard_front (rmse_sums_dev = r1_dev + 5 nb + 2, flags_dev = r1_dev + 5 nb) */
     int32_t softmax;
@@ -523,6 +526,8 @@ typedef struct midas_shard_step_args {
     float* poses_out_dev;           /* N x 16 out */
     double* weights_out_dev;        /* N out */
     int32_t* hint_out_dev;          /* N out */
+    int32_t* score_list_dev;        /* NULL or 2 + 2 K int32, zero-initialised: prediction lists of the sparse scoring, as in
+                                     * midas_lazy_args (front.score_epoch then advances by TWO per frame; midas_shard_run does) */
 } midas_shard_step_args;
 int midas_shard_step(midas_ctx* ctx, midas_comm* comm, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
                      const midas_shard_step_args* args, int32_t phases);

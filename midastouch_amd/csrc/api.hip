@@ -835,15 +835,18 @@ MIDAS_EXPORT int midas_lazy_flush_batch(midas_ctx* ctx, const midas_lazy_flush_a
 
 // ---- particle-sharded step pieces -------------------------------------------------------------------
 static int shard_front_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
-                            const midas_shard_front_args* args);
+                            const midas_shard_front_args* args, void** part_rmse_out = nullptr, int32_t* score_list = nullptr,
+                            ScorePredict* predict_out = nullptr);
 MIDAS_EXPORT int midas_shard_front(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
                                    const midas_tree* tree3, const midas_shard_front_args* args) {
     MIDAS_ENTER(ctx);
     return shard_front_impl(ctx, cb, tree6, tree3, args);
 }
 
+// part_rmse_out (C-side frame): the per-wave rmse sums are left in scratch for the tail to add up (no k_reduce_partials launch);
+// score_list / predict_out (C-side frame): prediction lists of the sparse scoring as in midas_lazy_args.score_list_dev
 static int shard_front_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
-                            const midas_shard_front_args* args) {
+                            const midas_shard_front_args* args, void** part_rmse_out, int32_t* score_list, ScorePredict* predict_out) {
     MIDAS_REQUIRE(ctx, tree6 && tree3 && args && tree6->dim == 6 && tree3->dim == 3);
     const midas_shard_front_args& s = *args;
     MIDAS_REQUIRE(ctx, s.scores_ready || (cb && tree6->K == cb->K && s.code_dev));
@@ -881,6 +884,17 @@ static int shard_front_impl(midas_ctx* ctx, const midas_codebook* cb, const mida
     pa.gt16 = prm ? s.gt16_dev : nullptr;
     pa.part_rmse = (double*)prm;
     if (!s.scores_ready && s.score_stamps_dev && s.score_epoch) { pa.sp.stamps = s.score_stamps_dev; pa.sp.epoch = s.score_epoch; }
+    if (pa.sp.stamps && score_list && predict_out && s.score_epoch >= 2 && s.N >= SCAN_CHUNK && cb) {
+        const int par = (int)((s.score_epoch >> 1) & 1u);
+        pa.sp.pred_tag = s.score_epoch - 1u;
+        pa.sp.list_count = score_list + par;
+        pa.sp.list = score_list + 2 + (int64_t)par * cb->K;
+        pa.sp.list_cap = (int32_t)(cb->K < 0x7fffffff ? cb->K : 0x7fffffff);
+        pa.sp.next_count = score_list + (par ^ 1);
+        predict_out->stamps = s.score_stamps_dev; predict_out->epoch = s.score_epoch; predict_out->K = cb->K;
+        predict_out->count = score_list + (par ^ 1);
+        predict_out->list = score_list + 2 + (int64_t)(par ^ 1) * cb->K;
+    }
     bool fused = false;
     if (!s.scores_ready && ctx->overlap)
         if ((rc = launch_frame_front(ctx, tree6, tree3, pa, cb, s.code_dev, s.scores_dev, &fused))) return rc;
@@ -890,6 +904,8 @@ static int shard_front_impl(midas_ctx* ctx, const midas_codebook* cb, const mida
             if ((rc = launch_score(ctx, cb, 1, s.code_dev, s.scores_dev))) return rc;
         if ((rc = launch_particle_update(ctx, tree6, tree3, pa))) return rc;
     }
+    if (!fused && predict_out) *predict_out = ScorePredict();  // the unfused form scored every row: no list for the next frame
+    if (part_rmse_out) { *part_rmse_out = prm; return MIDAS_OK; }
     if (prm) return launch_reduce_partials(ctx, npart, nullptr, nullptr, (const double*)prm, nullptr, s.rmse_sums_dev);
     return MIDAS_OK;
 }
@@ -1045,7 +1061,7 @@ extern "C" int midas_comm_all_gather(midas_comm* c, const void* send_dev, void* 
 
 static int shard_step_impl(midas_ctx* ctx, midas_comm* comm, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
                            const midas_shard_step_args& s, int32_t phases) {
-    MIDAS_REQUIRE(ctx, phases != 0 && (phases & ~15) == 0);
+    MIDAS_REQUIRE(ctx, phases != 0 && (phases & ~31) == 0);
     MIDAS_REQUIRE(ctx, s.front.N >= 256 && s.G >= 1 && s.G <= 64 && s.rank >= 0 && s.rank < s.G && s.tables_dev && s.r1_dev);
     MIDAS_REQUIRE(ctx, s.r1_all_dev || !(phases & (MIDAS_SHARD_PHASE_GATHER | MIDAS_SHARD_PHASE_ROUTE)));
     const int64_t N = s.front.N;
@@ -1053,10 +1069,13 @@ static int shard_step_impl(midas_ctx* ctx, midas_comm* comm, const midas_codeboo
     const int64_t rec = 5 * (int64_t)nb + 4;
     int rc;
     if (phases & MIDAS_SHARD_PHASE_LOCAL) {  // propagate / NN / prune / scoring, then the shard's softmax tables and its record
-        if ((rc = shard_front_impl(ctx, cb, tree6, tree3, &s.front))) return rc;
+        void* prm = nullptr;
+        ScorePredict predict;
+        if ((rc = shard_front_impl(ctx, cb, tree6, tree3, &s.front, &prm, s.score_list_dev, &predict))) return rc;
         MIDAS_REQUIRE(ctx, (uintptr_t)s.tables_dev % 128 == 0);
         if ((rc = launch_shard_tail_a(ctx, N, s.front.scores_dev, s.front.nn_idx_dev, s.front.valid_dev, s.softmax,
-                                      shard_tables_of(s.tables_dev, N), s.r1_dev, s.front.status_dev)))
+                                      shard_tables_of(s.tables_dev, N), s.r1_dev, s.front.status_dev, (const double*)prm,
+                                      predict.stamps ? &predict : nullptr)))
             return rc;
     }
     if (phases & MIDAS_SHARD_PHASE_GATHER) {  // one record per rank, in rank order, to every rank
@@ -1076,11 +1095,14 @@ static int shard_step_impl(midas_ctx* ctx, midas_comm* comm, const midas_codeboo
         r.seed = s.front.seed; r.step = s.front.step;
         r.counts_dev = s.counts_dev; r.weights_dev = s.weights_dev; r.peers_dev = s.peers_dev;
         if ((rc = shard_route(ctx, &r, true))) return rc;
-        if ((rc = launch_peer_flag_write(ctx, s.peers_dev, s.G, s.rank, s.flag_offset, s.frame_tag))) return rc;
+        if (phases & MIDAS_SHARD_PHASE_FLAG)  // shards of one process on one stream: the flags must be out before ANY shard waits
+            if ((rc = launch_peer_flag_write(ctx, s.peers_dev, s.G, s.rank, s.flag_offset, s.frame_tag))) return rc;
     }
     if (phases & MIDAS_SHARD_PHASE_UNPACK) {  // wait for every rank's flag in the own inbox, then inbox -> slots
+        // (its first workgroup publishes this rank's flag unless ROUTE already did: the kernel sits behind the route kernel)
         if ((rc = launch_shard_unpack_peer_wait(ctx, N, s.inbox_dev, s.ridx_dev, s.poses_out_dev, s.weights_out_dev, s.hint_out_dev,
-                                                s.G, s.flag_offset, s.frame_tag, s.front.status_dev)))
+                                                s.G, s.flag_offset, s.frame_tag, s.front.status_dev,
+                                                (phases & MIDAS_SHARD_PHASE_FLAG) ? nullptr : s.peers_dev, s.rank)))
             return rc;
     }
     return MIDAS_OK;
@@ -1109,8 +1131,8 @@ MIDAS_EXPORT int midas_shard_run(midas_ctx* ctx, midas_comm* comm, const midas_c
         a.frame_tag += 1;
         a.u32 = -1.0f;
         if (a.front.score_stamps_dev) {
-            MIDAS_REQUIRE(ctx, a.front.score_epoch < 0xFFFFFFF0u);
-            a.front.score_epoch += 1;
+            MIDAS_REQUIRE(ctx, a.front.score_epoch < 0xFFFFFFF0u - 2u);
+            a.front.score_epoch += a.score_list_dev ? 2u : 1u;
         }
         a.front.odom16_dev += 16;
         a.front.code_dev += cb->D;

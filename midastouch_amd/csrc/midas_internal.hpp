@@ -327,7 +327,8 @@ int launch_tail_a2(midas_ctx* ctx, int64_t N, const double* scores, const int32_
 int launch_predict_seed(midas_ctx* ctx, int64_t N, const int32_t* idx, const ScorePredict& pr);
 int launch_tail_b2(midas_ctx* ctx, const StepTailArgs& a, const TailTables& tb);  // a.x, a.e, a.cdf, a.lp_raw unused
 int launch_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
-                        int32_t softmax, const TailTables& tb, double* r1, int32_t* status);
+                        int32_t softmax, const TailTables& tb, double* r1, int32_t* status, const double* part_rmse = nullptr,
+                        const ScorePredict* predict = nullptr);
 int launch_shard_route(midas_ctx* ctx, const midas_shard_route_args& r, const TailTables& tb, bool pack);
 int launch_shard_unpack(midas_ctx* ctx, int64_t N, const void* recv, int32_t* ridx, float* poses_out, double* weights_out,
                         int32_t* hint_out, int32_t dest = -1);
@@ -336,7 +337,7 @@ int launch_shard_unpack_peer(midas_ctx* ctx, int64_t N, const void* inbox, int32
 int launch_peer_probe(midas_ctx* ctx, void* const* peers, const void* inbox, int G, int rank, int nonce, int32_t* ok);
 int launch_peer_flag_write(midas_ctx* ctx, void* const* peers, int G, int rank, int64_t flag_off, uint64_t tag);
 int launch_shard_unpack_peer_wait(midas_ctx* ctx, int64_t N, const void* inbox, int32_t* ridx, float* poses_out, double* weights_out,
-                                  int32_t* hint_out, int G, int64_t flag_off, uint64_t tag, int32_t* status);
+                                  int32_t* hint_out, int G, int64_t flag_off, uint64_t tag, int32_t* status, void* const* peers, int rank);
 int debug_tb2_clocks(long long* out16);
 int launch_tail_a(midas_ctx* ctx, int64_t N, const double* x, const uint8_t* valid, int np, int pstride,
                   const double* pmax_all, const double* pmin_all, int32_t softmax, double* e_io, double* lp_out,

@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) void k_tail_a2d(int64_t N, const double* __res
                                                   int32_t* __restrict__ status, double* __restrict__ flags_out,
                                                   const double* __restrict__ part_rmse, int nrm, double* __restrict__ rmse_out,
                                                   int64_t score_stride = 0, int64_t tstride = 0, int nb_tail = 0x7fffffff,
-                                                  ScorePredict pr = ScorePredict()) {
+                                                  ScorePredict pr = ScorePredict(), bool rmse_raw = false) {
     __shared__ double s_gtot[16];
     __shared__ double s_red[24];
     if ((int)blockIdx.x >= nb_tail) {  // (single trajectory only: the launcher adds these workgroups when pr.stamps is set)
@@ -608,6 +608,11 @@ __global__ __launch_bounds__(256) void k_tail_a2d(int64_t N, const double* __res
         if (t == 0) {
             p = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
             q = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+            if (rmse_raw) {  // a shard's sums (added up across the ranks by whoever reads the exchange records): k_reduce_partials' order
+                rmse_out[0] = p;
+                rmse_out[1] = q;
+                return;
+            }
             rmse_out[0] = __builtin_sqrt(p / (double)N);
             rmse_out[1] = __builtin_sqrt(q / (double)N);
             rmse_out[2] = (double)wall_clock64() * 0.01;  // device wall clock (100 MHz) in us: where this frame ended
@@ -1524,7 +1529,12 @@ __global__ void k_peer_flag_write(char* const* peers, int G, int rank, long long
 __global__ __launch_bounds__(256) void k_shard_unpack_peer_wait(int64_t N, const char* __restrict__ inbox, int32_t* __restrict__ ridx,
                                                                 float* __restrict__ poses_out, double* __restrict__ weights_out,
                                                                 int32_t* __restrict__ hint_out, int G, long long flag_off,
-                                                                unsigned long long tag, int32_t* __restrict__ status) {
+                                                                unsigned long long tag, int32_t* __restrict__ status,
+                                                                char* const* __restrict__ peers, int rank) {
+    // peers != NULL: this kernel also PUBLISHES the rank's completion flag (its first workgroup, before anybody waits): it was
+    // launched behind the route kernel, so every row this rank stored is out - one launch fewer than a flag kernel of its own
+    if (peers && blockIdx.x == 0 && (int)threadIdx.x < G)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(peers[threadIdx.x] + flag_off) + rank, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((int)threadIdx.x < G) {
         const unsigned long long* f = reinterpret_cast<const unsigned long long*>(inbox + flag_off) + threadIdx.x;
         const long long t0 = wall_clock64();
@@ -1582,9 +1592,9 @@ int launch_peer_flag_write(midas_ctx* ctx, void* const* peers, int G, int rank, 
 }
 
 int launch_shard_unpack_peer_wait(midas_ctx* ctx, int64_t N, const void* inbox, int32_t* ridx, float* poses_out, double* weights_out,
-                                  int32_t* hint_out, int G, int64_t flag_off, uint64_t tag, int32_t* status) {
+                                  int32_t* hint_out, int G, int64_t flag_off, uint64_t tag, int32_t* status, void* const* peers, int rank) {
     hipLaunchKernelGGL(k_shard_unpack_peer_wait, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, N, (const char*)inbox, ridx,
-                       poses_out, weights_out, hint_out, G, (long long)flag_off, (unsigned long long)tag, status);
+                       poses_out, weights_out, hint_out, G, (long long)flag_off, (unsigned long long)tag, status, (char* const*)peers, rank);
     LAUNCH_CHECK(ctx);
     return MIDAS_OK;
 }
@@ -1698,14 +1708,21 @@ int launch_tail_fin(midas_ctx* ctx, int64_t N, const double* e, const double* x_
 
 // TA2 of one shard: the exchange record r1 = [bsum_e | btot | btot_raw | bmax | bmin | NaN count, kept count | ...]
 int launch_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
-                        int32_t softmax, const TailTables& tb, double* r1, int32_t* status) {
+                        int32_t softmax, const TailTables& tb, double* r1, int32_t* status, const double* part_rmse,
+                        const ScorePredict* predict) {
     const int nb = (int)ceil_div(N, SCAN_BLOCK);
     static const bool direct = !(getenv("MIDAS_TAIL_DIRECT") && atoi(getenv("MIDAS_TAIL_DIRECT")) == 0);
+    const bool with_list = predict && predict->stamps && predict->list;
+    if ((part_rmse || with_list) && !(direct && N >= SCAN_CHUNK))
+        return midas_set_error(ctx, MIDAS_ERR_INVALID, "shard tail", "rmse sums / prediction list in the tail need the direct tail kernel (N >= 16)");
     if (direct && N >= SCAN_CHUNK) {  // the shard's per-slot tables are padded (shard_tables_of, api.hip)
         TailTables t = tb;
         t.bsum_e = r1; t.btot = r1 + nb; t.btot_raw = r1 + 2 * nb; t.bmax = r1 + 3 * nb; t.bmin = r1 + 4 * nb;
-        hipLaunchKernelGGL(k_tail_a2d, dim3((unsigned)nb), dim3(256), 0, ctx->stream, N, scores, nn_idx, valid, softmax, t, true,
-                           status, r1 + 5 * nb, (const double*)nullptr, 0, (double*)nullptr);
+        const int nscan = with_list ? (int)ceil_div(predict->K, 256 * PREDICT_PER_THREAD) : 0;
+        // part_rmse: the front's per-wave sums are added up here (block 0) into r1[5 nb + 2 ..] instead of by a kernel of their own
+        hipLaunchKernelGGL(k_tail_a2d, dim3((unsigned)(nb + nscan)), dim3(256), 0, ctx->stream, N, scores, nn_idx, valid, softmax, t, true,
+                           status, r1 + 5 * nb, part_rmse, particle_update_blocks(N), part_rmse ? r1 + 5 * nb + 2 : (double*)nullptr,
+                           (int64_t)0, (int64_t)0, nb, with_list ? *predict : ScorePredict(), true);
         LAUNCH_CHECK(ctx);
         return MIDAS_OK;
     }

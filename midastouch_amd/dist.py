@@ -244,6 +244,9 @@ class HipShardBackend:
                 st._stamps = stamps = torch.zeros(self.codebook.K, dtype=torch.int32, device=st.poses.device)
                 st._epoch = 0
             f.score_stamps = _ptr(stamps)
+            if getattr(st, "_score_list", None) is None:  # prediction lists (include/midas_hip.h score_list_dev)
+                st._score_list = torch.zeros(2 + 2 * self.codebook.K, dtype=torch.int32, device=st.poses.device)
+            a.score_list = _ptr(st._score_list)
         a.softmax, a.tables, a.r1, a.r1_all = int(softmax), _ptr(st.tables), _ptr(st.r1), _ptr(r1_all)
         a.G, a.rank, a.resample_mode = world, rank, mode
         a.u_all, a.u32 = _ptr(u_all), float(u32)
@@ -254,12 +257,14 @@ class HipShardBackend:
         return a
 
     def next_epochs(self, st, n=1) -> int:
-        """First of n consecutive sparse-scoring epochs of this shard's stamps (restart + zeroed stamps long before a wrap)."""
-        if st._epoch + n >= 0x7FFFFFF0:
+        """First of n consecutive sparse-scoring epochs of this shard's stamps, spaced by two (the value between two epochs
+        tags the rows of the prediction list); restart + zeroed stamps and list lengths long before a wrap."""
+        if st._epoch + 2 * n >= 0x7FFFFFF0:
             st._stamps.zero_()
+            st._score_list[:2].zero_()
             st._epoch = 0
-        first = st._epoch + 1
-        st._epoch += n
+        first = st._epoch + 2
+        st._epoch += 2 * n
         return first
 
     def step_c(self, st, a, comm_h, phases, T=None):
@@ -695,9 +700,9 @@ class ShardedFilterEngine:
                 a.r1_all = _ptr(r1_all)
                 self._keep = self._keep + (r1_all,)
                 if getattr(self, "_one_stream", False):  # shards of one process: every shard's rows and flags before any wait
-                    b.step_c(st, a, None, 4)
+                    b.step_c(st, a, None, 4 | 16)
                     yield st.sync
-                    b.step_c(st, a, None, 8)
+                    b.step_c(st, a, None, 8 | 16)
                 else:
                     b.step_c(st, a, None, 12)
             self.step_count += 1
