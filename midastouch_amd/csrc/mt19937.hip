@@ -9,9 +9,9 @@
 // stream; round 2 took it from the host every frame (0.8 MB of uniforms over PCIe, 1.0 - 1.4k frames/s).  Here the
 // generator's state lives in device memory and a single workgroup advances it: the recurrence
 //     x[k+624] = x[k+397] ^ twist(x[k], x[k+1])
-// is sequential from block to block (624 words); inside a block word k >= 227 needs the new word k - 227, so a thread that
-// owns the words j, j + 227, j + 454 carries that dependence in its own registers and a block costs ONE barrier (see
-// k_mt_rand64); a block's 312 doubles are written out beside the compute of the next block.
+// is sequential from block to block (624 words) but parallel inside one in three phases (k < 227 reads only old words,
+// 227 <= k < 454 reads the new words of phase one, the rest those of phase two), so a block costs three barriers; a block's
+// 312 doubles are written out beside the first phase of the next block.
 // Pure 32-bit integer arithmetic: the words equal at::mt19937's bit for bit (tests: against torch.rand / torch.manual_seed).
 #include "midas_internal.hpp"
 
@@ -44,16 +44,11 @@ __global__ __launch_bounds__(1) void k_mt_seed(uint32_t seed, uint32_t* __restri
     state[MT_N + 1] = 0;
 }
 
-// One workgroup of MT_THREADS threads, ONE barrier per 624-word block.  Thread j < 227 owns the words j, j + 227 and j + 454 of
-// the next block: word k needs the previous block's words k and k + 1 (LDS, stable) and - for k >= 227 - the NEW word
-// k - 227, which is the thread's own previous result: a private chain of three mixes, no hand-over between threads.  The
-// one exception is word 623 = mix(prev[623], new[0], new[396]) (new[0] belongs to thread 0): it stays pending through the
-// block's barrier and is finalised at the start of the next block's compute by the two threads that read it (k = 622's
-// right neighbour, and the writer of the LDS copy); the output pass, which runs beside that compute, recomputes it the same
-// way instead of reading the slot that is being written.  Two buffers alternate; slot 623 of the buffer being overwritten is
-// never written by the compute (it is the pending one), so it still holds the word 623 the finalisation needs.
-constexpr int MT_THREADS = 256, MT_P = MT_N - MT_M;  // 227 words per dependent step
-struct MtEmit { int pos, end; long long gw; };      // words [pos, end) of the block; gw = stream index of word `pos`
+// One workgroup of MT_THREADS threads.  The two blocks live in ONE LDS array indexed by a toggle (two arrays behind swapped
+// pointers made the compiler address them with flat instructions).  A block costs three barriers: the doubles of the block
+// before it are written out beside phase one of the next (they read the old buffer only).
+constexpr int MT_THREADS = 320, MT_P = MT_N - MT_M;  // 227 words per phase
+struct MtEmit { int pos, end; long long gw; bool more; };  // words [pos, end) of the block; gw = stream index of word `pos`; more: the stream goes on
 
 __global__ __launch_bounds__(MT_THREADS) void k_mt_rand64(uint32_t* __restrict__ state, long long skip, long long N, double* __restrict__ out) {
     __shared__ uint32_t s_mt[2][MT_N];
@@ -61,62 +56,42 @@ __global__ __launch_bounds__(MT_THREADS) void k_mt_rand64(uint32_t* __restrict__
     const int t = threadIdx.x;
     for (int k = t; k < MT_N; k += MT_THREADS) s_mt[0][k] = state[k];
     int pos = (int)state[MT_N];
-    int b = 0;              // s_mt[b]: the current block
-    bool pending = false;   // s_mt[b][623] not finalised yet (its ingredients: s_mt[b ^ 1][623], s_mt[b][0], s_mt[b][396])
+    int b = 0;
     __syncthreads();
-    // word 623 of the current block, from LDS or - while pending - from its ingredients
-    auto word623 = [&]() { return pending ? mt_mix(s_mt[b ^ 1][MT_N - 1], s_mt[b][0], s_mt[b][MT_M - 1]) : s_mt[b][MT_N - 1]; };
-    auto cur_word = [&](int k) { return k == MT_N - 1 ? word623() : s_mt[b][k]; };
-    // the next block into s_mt[b ^ 1] (its word 623 stays pending); ends WITHOUT a barrier
-    auto compute = [&]() {
-        const uint32_t* old = s_mt[b];
-        uint32_t* nw = s_mt[b ^ 1];
-        if (t < MT_P) {
-            const int k1 = t + MT_P, k2 = t + 2 * MT_P;
-            const uint32_t o0 = old[t], o1 = old[t + 1], of = t + MT_M == MT_N - 1 ? word623() : old[t + MT_M];  // (t = 226 reads word 623)
-            const uint32_t p0 = old[k1], p1 = old[k1 + 1];
-            const bool third = k2 < MT_N - 1;  // k2 == 623 (t == 169) is the pending word
-            const uint32_t q0 = third ? old[k2] : 0u;
-            const uint32_t q1 = third ? (k2 + 1 == MT_N - 1 ? word623() : old[k2 + 1]) : 0u;
-            const uint32_t n0 = mt_mix(o0, o1, of);
-            const uint32_t n1 = mt_mix(p0, p1, n0);
-            nw[t] = n0;
-            nw[k1] = n1;
-            if (third) nw[k2] = mt_mix(q0, q1, n1);
-        }
-        if (pending && t == MT_THREADS - 1) s_mt[b][MT_N - 1] = word623();  // the LDS copy of the current block's last word
+    auto phase_a = [&]() { if (t < MT_P) s_mt[b ^ 1][t] = mt_mix(s_mt[b][t], s_mt[b][t + 1], s_mt[b][t + MT_M]); };
+    auto phase_b = [&]() { if (t < MT_P) { const int k = t + MT_P; s_mt[b ^ 1][k] = mt_mix(s_mt[b][k], s_mt[b][k + 1], s_mt[b ^ 1][t]); } };
+    auto phase_c = [&]() {
+        const int k = t + 2 * MT_P;
+        if (k < MT_N - 1) s_mt[b ^ 1][k] = mt_mix(s_mt[b][k], s_mt[b][k + 1], s_mt[b ^ 1][k - MT_P]);
+        else if (k == MT_N - 1) s_mt[b ^ 1][k] = mt_mix(s_mt[b][k], s_mt[b ^ 1][0], s_mt[b ^ 1][MT_M - 1]);
     };
-    auto advance = [&]() {  // after compute + barrier: the new block is current; its word 623 is pending
-        b ^= 1;
-        pending = true;
-        pos = 0;
-    };
-    // 2 N words -> N doubles: (hi << 32 | lo) & (2^53 - 1), times 2^-53 (at::uniform_real_distribution<double>); hi = even stream index.
-    // Reads the CURRENT block only (beside the compute of the next one, which writes the other buffer).
+    // 2 N words -> N doubles: (hi << 32 | lo) & (2^53 - 1), times 2^-53 (at::uniform_real_distribution<double>); hi = even stream index
     auto emit = [&](const MtEmit& e) {
+        const uint32_t* cur = s_mt[b];
         const int odd = (int)(e.gw & 1);
         if (odd && t == MT_THREADS - 1) {  // the block starts with the low word of a value whose high word ended the block before
-            const unsigned long long r = (((unsigned long long)s_carry << 32) | mt_temper(cur_word(e.pos))) & ((1ull << 53) - 1ull);
+            const unsigned long long r = (((unsigned long long)s_carry << 32) | mt_temper(cur[e.pos])) & ((1ull << 53) - 1ull);
             out[e.gw >> 1] = (double)r * 1.1102230246251565e-16;
         }
-        for (int o = e.pos + odd + 2 * t; o < e.end; o += 2 * MT_THREADS) {
-            const uint32_t hi = mt_temper(cur_word(o));
+        const int o = e.pos + odd + 2 * t;
+        if (o < e.end) {
+            const uint32_t hi = mt_temper(cur[o]);
             if (o + 1 < e.end) {
-                const unsigned long long r = (((unsigned long long)hi << 32) | mt_temper(cur_word(o + 1))) & ((1ull << 53) - 1ull);
+                const unsigned long long r = (((unsigned long long)hi << 32) | mt_temper(cur[o + 1])) & ((1ull << 53) - 1ull);
                 out[(e.gw + (o - e.pos)) >> 1] = (double)r * 1.1102230246251565e-16;
             } else {
                 s_carry = hi;  // its partner is the first word of the next block
             }
         }
     };
-    // skip: whole blocks are stepped over, the rest is an offset
+    // skip: whole blocks are twisted over, the rest is an offset
     while (skip > 0) {
         const int avail = MT_N - pos;
         if (skip >= avail) {
             skip -= avail;
-            compute();
-            __syncthreads();
-            advance();
+            phase_a(); __syncthreads(); phase_b(); __syncthreads(); phase_c(); __syncthreads();
+            b ^= 1;
+            pos = 0;
         } else {
             pos += (int)skip;
             skip = 0;
@@ -124,26 +99,25 @@ __global__ __launch_bounds__(MT_THREADS) void k_mt_rand64(uint32_t* __restrict__
     }
     const long long W = 2 * N;
     long long gw = 0;
-    bool pend_emit = false;
-    MtEmit pe{0, 0, 0};
+    bool pend = false;
+    MtEmit pe{0, 0, 0, false};
     while (true) {
         if (pos == MT_N && gw < W) {
-            compute();
-            if (pend_emit) { emit(pe); pend_emit = false; }
-            __syncthreads();
-            advance();
+            phase_a();
+            if (pend) { emit(pe); pend = false; }
+            __syncthreads(); phase_b(); __syncthreads(); phase_c(); __syncthreads();
+            b ^= 1;
+            pos = 0;
         }
         if (gw >= W) break;
         const long long left = W - gw;
         const int m = (int)(left < (long long)(MT_N - pos) ? left : (long long)(MT_N - pos));
-        pe.pos = pos; pe.end = pos + m; pe.gw = gw;
-        pend_emit = true;
+        pe.pos = pos; pe.end = pos + m; pe.gw = gw; pe.more = left > m;
+        pend = true;
         gw += m;
         pos += m;
     }
-    if (pend_emit) emit(pe);
-    __syncthreads();
-    if (pending && t == 0) s_mt[b][MT_N - 1] = word623();  // the state goes back complete
+    if (pend) emit(pe);
     __syncthreads();
     for (int k = t; k < MT_N; k += MT_THREADS) state[k] = s_mt[b][k];
     if (t == 0) state[MT_N] = (uint32_t)pos;
