@@ -1210,8 +1210,13 @@ MIDAS_EXPORT int midas_selfsim_topn(midas_ctx* ctx, const midas_codebook* cb, in
     // the GEMM of panel p + 1 (bound by the matrix pipe).  Events hand the panels back and forth.
     const int nbuf = npanels > 1 ? 2 : 1;
     void* panel;
-    int rc = midas_scratch(ctx, (size_t)nbuf * R * ldo * sizeof(float), &panel);
+    int rc = midas_scratch(ctx, ((size_t)nbuf * R + 1) * ldo * sizeof(float), &panel);  // + one row: float32 reciprocal norms (the selection's screen)
     if (rc) return rc;
+    float* rinv = (float*)panel + (size_t)nbuf * R * ldo;
+    rc = launch_topn_rinv(ctx, K, ldo, cb->norms, rinv);
+    if (rc) return rc;
+    const char* stream_env = getenv("MIDAS_TOPN_STREAM");  // 1: the streaming selection kernel for every row (A/B runs and tests)
+    if (stream_env && stream_env[0] == '1') rinv = nullptr;
     if (!ctx->side) MIDAS_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
     hipEvent_t ev_gemm[2] = {nullptr, nullptr}, ev_sel[2] = {nullptr, nullptr};
     for (int k = 0; k < nbuf; ++k) {
@@ -1233,7 +1238,7 @@ MIDAS_EXPORT int midas_selfsim_topn(midas_ctx* ctx, const midas_codebook* cb, in
         MIDAS_HIP_CHECK(ctx, hipEventRecord(ev_gemm[k], main_stream));
         MIDAS_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ev_gemm[k], 0));
         ctx->stream = ctx->side;  // the launcher enqueues on ctx->stream
-        rc = launch_topn_pose_error_dots(ctx, (int32_t)rows, K, pan, ldo, cb->norms, i0, n, feat_dev, d, err_dev + i0,
+        rc = launch_topn_pose_error_dots(ctx, (int32_t)rows, K, pan, ldo, cb->norms, rinv, i0, n, feat_dev, d, err_dev + i0,
                                          idx_dev ? idx_dev + i0 * n : nullptr);
         ctx->stream = main_stream;
         if (rc) break;

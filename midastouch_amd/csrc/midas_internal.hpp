@@ -377,8 +377,9 @@ int launch_mt_rand64(midas_ctx* ctx, uint32_t* state, int64_t skip_words, int64_
 int launch_topn_pose_error(midas_ctx* ctx, int32_t B, int64_t K, const double* scores, int64_t row0, int32_t n,
                            const double* feat, int32_t d, double* err_out, int32_t* idx_out);
 
-int launch_topn_pose_error_dots(midas_ctx* ctx, int32_t B, int64_t K, const float* panel, int64_t ld, const double* norms, int64_t row0, int32_t n,
-                                const double* feat, int32_t d, double* err_out, int32_t* idx_out);
+int launch_topn_rinv(midas_ctx* ctx, int64_t K, int64_t ld, const double* norms, float* rinv);
+int launch_topn_pose_error_dots(midas_ctx* ctx, int32_t B, int64_t K, const float* panel, int64_t ld, const double* norms, const float* rinv,
+                                int64_t row0, int32_t n, const double* feat, int32_t d, double* err_out, int32_t* idx_out);
 // selfsim.hip
 int launch_selfsim_panel(midas_ctx* ctx, const midas_codebook* cb, int64_t i0, int64_t R, float* panel, int64_t ldo);
 

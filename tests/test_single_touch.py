@@ -110,3 +110,40 @@ def test_top_n_error_gemm_path_matches_reference_arithmetic():
         same = np.array([set(idx[i]) == set(best[i]) for i in range(K)])
         assert same[clear].all()
         np.testing.assert_allclose(err.cpu().numpy()[clear], ref[clear], rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["regular", "ties", "small_n", "zero_row", "wide"])
+def test_selection_forms_of_the_gemm_path_agree(case, monkeypatch):
+    """The register-resident selection of a panel row (k_topn_dots_rows: float32 screen, float64 decision among the
+    candidates) against the streaming kernel on the same panels (MIDAS_TOPN_STREAM=1): the same indices in the same order and
+    the same errors - also where more rows tie than the candidate buffer holds (the row then goes through the streaming
+    form inside the kernel), where a row's own norm is zero, and on rows wider than one load round."""
+    from midastouch_amd.single_touch import top_n_error
+    dev = torch.device("cuda", 0)
+    K, D, n, rows = {"regular": (2500, 256, 25, 512), "ties": (3000, 128, 25, 1024), "small_n": (900, 128, 7, 128),
+                     "zero_row": (1500, 128, 25, 256), "wide": (20000, 64, 25, 2048)}[case]
+    rng = np.random.default_rng(77)
+    if case == "wide":
+        E = rng.standard_normal((K, D)).astype(np.float32)
+        poses = rng.uniform(-0.1, 0.1, (K, 3))
+    else:
+        cb = make_codebook(K=K, D=D, seed=1400 + K, mesh_points=2000)
+        E, poses = cb.embeddings.astype(np.float32).copy(), cb.poses[:, :3, 3].astype(np.float64)
+    if case == "ties":
+        E[500:2300] = E[499]       # 1801 identical rows: every one of them ties at cosine 1 with the others
+    if case == "zero_row":
+        E[7] = 0.0                 # every dot of this row is 0 (the norms are clamped away from 0): K scores tie at 0
+        E[100:140] = E[99]
+    emb, ps = torch.as_tensor(E).to(dev), torch.as_tensor(poses).to(dev)
+    monkeypatch.setenv("MIDAS_TOPN_STREAM", "1")
+    e0, i0 = top_n_error(emb, ps, n=n, fast=True, want_idx=True, panel_rows=rows)
+    monkeypatch.setenv("MIDAS_TOPN_STREAM", "0")
+    e1, i1 = top_n_error(emb, ps, n=n, fast=True, want_idx=True, panel_rows=rows)
+    i0, i1 = i0.cpu().numpy(), i1.cpu().numpy()
+    assert np.array_equal(i0, i1)
+    assert np.array_equal(e0.cpu().numpy(), e1.cpu().numpy(), equal_nan=True)
+    if case == "ties":
+        assert (i1[600] == np.r_[499:600, 601:2300][:n]).all()   # value descending, index ascending
+    if case == "zero_row":
+        assert (i1[7] == np.arange(n)).all()
