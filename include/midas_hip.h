@@ -435,9 +435,9 @@ typedef struct midas_shard_route_args {
     void* self_dev;                 /* fixed form: N x 88 bytes - the rows whose slot and source both live on this rank stay
                                      * here instead of travelling (unpacked like the others) */
     /* Peer-mapped form of midas_shard_route_pack - no send buffer, no collective for the rows: peers_dev[d] is rank d's
-     * inbox (N x 88 bytes, midas_peer_alloc) as mapped into THIS process (midas_peer_open; the own inbox for d == rank);
-     * the owner of a slot's source stores the row straight into row `slot` of the destination's inbox (system-scope
-     * stores over xGMI).  Every slot of the filter has exactly one owner, so after a barrier across the ranks each inbox
+     * inbox (N rows of 128 bytes, midas_peer_alloc; csrc/peer_row.hpp) as mapped into THIS process (midas_peer_open; the own
+     * inbox for d == rank); the owner of a slot's source stores the row straight into row `slot` of the destination's inbox
+     * (system-scope stores over xGMI, sixteen adjacent lanes per row: one whole 128-byte line).  Every slot of the filter has exactly one owner, so after a barrier across the ranks each inbox
      * holds its N rows (midas_shard_unpack_peer).  NULL: the forms above. */
     void* const* peers_dev;
 } midas_shard_route_args;
@@ -481,21 +481,26 @@ int midas_shard_unpack_peer(midas_ctx* ctx, int64_t N, const void* inbox_dev, in
  * midas_shard_step enqueues, on the context's stream and without returning to the host in between, the phases selected:
  *   MIDAS_SHARD_PHASE_LOCAL     midas_shard_front + midas_shard_tail_a on this rank's particles (record r1_dev)
  *   MIDAS_SHARD_PHASE_GATHER    ncclAllGather of the records -> r1_all_dev (G x (5 nb + 4) doubles); needs `comm`
- *   MIDAS_SHARD_PHASE_ROUTE     owner-side resample straight into the peers' inboxes (midas_shard_route_pack, peer form)
- *   MIDAS_SHARD_PHASE_UNPACK    the unpack kernel - launched behind the route kernel, so every row this rank stored is out -
- *                               first stores frame_tag into slot `rank` of the flag block of every inbox (G uint64 at
- *                               inbox + flag_offset, flag_offset >= 88 N), then waits until all G slots of its OWN inbox
- *                               carry the tag (bounded: 2 s, then status[0] |= 16), then inbox -> slots: device-side flags
- *                               over the mapped inboxes instead of a second collective
- *   MIDAS_SHARD_PHASE_FLAG      (with ROUTE) the flags are published by a kernel of their own right behind the route kernel
- *                               instead - shards of ONE process on one stream need every shard's flag out before any waits.
+ *   MIDAS_SHARD_PHASE_ROUTE     owner-side resample straight into the peers' inboxes (midas_shard_route_pack, peer form).  The
+ *                               LAST workgroup of the kernel to finish - every row this rank stores is out then - stores
+ *                               frame_tag into slot `rank` of the flag block of every inbox (G uint64 at inbox + flag_offset,
+ *                               flag_offset >= 128 N) and waits until all G slots of its OWN inbox carry the tag (bounded: 2 s,
+ *                               then status[0] |= 16): when the kernel ends, the inbox holds its N rows - device-side flags
+ *                               over the mapped inboxes instead of a second collective, polled by one wave
+ *   MIDAS_SHARD_PHASE_UNPACK    inbox -> slots (ridx / poses_out / weights_out / hint_out)
+ *   MIDAS_SHARD_PHASE_FLAG      shards of ONE process on one stream need every shard's flag out before any waits: with ROUTE
+ *                               the route kernel does not wait and the flags are published by a kernel of their own right
+ *                               behind it; with UNPACK the unpack kernel waits for the flags first.
  * A caller without RCCL between its ranks (tests: two processes sharing one GPU) runs LOCAL, gathers the records itself,
- * then runs ROUTE | UNPACK; shards of ONE process on one stream must run every shard's ROUTE before any UNPACK (a waiting
- * kernel in front of the kernel it waits for would never end).  frame_tag must grow from frame to frame (the flag slots are
+ * then runs ROUTE | UNPACK; shards of ONE process on one stream run every shard's ROUTE | FLAG before any UNPACK | FLAG (a
+ * waiting kernel in front of the kernel it waits for would never end).  frame_tag must grow from frame to frame (the flag slots are
  * never reset).
  * midas_shard_run: T frames by one call (device draws; odom16_dev / code_dev / gt16_dev advance by one frame each, step,
  * frame_tag and score_epoch by one).  The resampled particles land in poses_out_dev / hint_out_dev, which the engine
- * passes as the next frame's poses_in_dev / hint_in_dev (the same buffers). */
+ * passes as the next frame's poses_in_dev / hint_in_dev (the same buffers) - after the LAST frame of the call: in between the
+ * UNPACK phase is folded into the next frame's front kernel, which waits for the flags and takes particle `slot` from row
+ * `slot` of the inbox (one launch fewer per frame; ridx / weights_out are those of the call's last frame.
+ * MIDAS_SHARD_FOLD=0 in the environment: every frame unpacks). */
 typedef struct midas_comm midas_comm;
 int midas_comm_unique_id(midas_ctx* ctx, const char* rccl_path, void* id128_out);
 int midas_comm_create(midas_ctx* ctx, const char* rccl_path, const void* id128, int32_t world, int32_t rank, midas_comm** out);
@@ -519,7 +524,8 @@ typedef struct midas_shard_step_args {
     double* weights_dev;            /* N out: masked weights before the resample */
     double* rmse_dev;               /* NULL or 2 out */
     void* const* peers_dev;         /* G inbox addresses as mapped into this process (midas_peer_open) */
-    void* inbox_dev;                /* this rank's inbox: N x 88 bytes of rows, then the flag block */
+    void* inbox_dev;                /* this rank's inbox: N x 128 bytes of rows, then the flag block: 64 uint64 flags and one
+                                     * zero-initialised 64-byte line (the route kernel's workgroup counter): flag_offset + 576 bytes */
     int64_t flag_offset;
     uint64_t frame_tag;
     int32_t* ridx_dev;              /* N out */

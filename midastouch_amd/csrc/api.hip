@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "midas_internal.hpp"
+#include "peer_row.hpp"
 
 using namespace midas;
 
@@ -836,7 +837,7 @@ MIDAS_EXPORT int midas_lazy_flush_batch(midas_ctx* ctx, const midas_lazy_flush_a
 // ---- particle-sharded step pieces -------------------------------------------------------------------
 static int shard_front_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
                             const midas_shard_front_args* args, void** part_rmse_out = nullptr, int32_t* score_list = nullptr,
-                            ScorePredict* predict_out = nullptr);
+                            ScorePredict* predict_out = nullptr, const PeerInboxSrc* inbox = nullptr);
 MIDAS_EXPORT int midas_shard_front(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6,
                                    const midas_tree* tree3, const midas_shard_front_args* args) {
     MIDAS_ENTER(ctx);
@@ -845,8 +846,11 @@ MIDAS_EXPORT int midas_shard_front(midas_ctx* ctx, const midas_codebook* cb, con
 
 // part_rmse_out (C-side frame): the per-wave rmse sums are left in scratch for the tail to add up (no k_reduce_partials launch);
 // score_list / predict_out (C-side frame): prediction lists of the sparse scoring as in midas_lazy_args.score_list_dev
+// inbox (midas_shard_run, frames after the first): the particles are the rows of the rank's inbox - the previous frame's unpack
+// folded into this front (poses_in / hint_in are not read)
 static int shard_front_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
-                            const midas_shard_front_args* args, void** part_rmse_out, int32_t* score_list, ScorePredict* predict_out) {
+                            const midas_shard_front_args* args, void** part_rmse_out, int32_t* score_list, ScorePredict* predict_out,
+                            const PeerInboxSrc* inbox) {
     MIDAS_REQUIRE(ctx, tree6 && tree3 && args && tree6->dim == 6 && tree3->dim == 3);
     const midas_shard_front_args& s = *args;
     MIDAS_REQUIRE(ctx, s.scores_ready || (cb && tree6->K == cb->K && s.code_dev));
@@ -883,6 +887,7 @@ static int shard_front_impl(midas_ctx* ctx, const midas_codebook* cb, const mida
     pa.flags_reset = s.flags_dev;
     pa.gt16 = prm ? s.gt16_dev : nullptr;
     pa.part_rmse = (double*)prm;
+    if (inbox) pa.inbox = *inbox;
     if (!s.scores_ready && s.score_stamps_dev && s.score_epoch) { pa.sp.stamps = s.score_stamps_dev; pa.sp.epoch = s.score_epoch; }
     if (pa.sp.stamps && score_list && predict_out && s.score_epoch >= 2 && s.N >= SCAN_CHUNK && cb) {
         const int par = (int)((s.score_epoch >> 1) & 1u);
@@ -943,7 +948,7 @@ MIDAS_EXPORT int midas_shard_tail_fin(midas_ctx* ctx, int64_t N, const double* t
                            (double)N_total, softmax, rmse_dev, status_dev);
 }
 
-static int shard_route(midas_ctx* ctx, const midas_shard_route_args* args, bool pack) {
+static int shard_route(midas_ctx* ctx, const midas_shard_route_args* args, bool pack, const PeerRouteSync* sync = nullptr) {
     MIDAS_REQUIRE(ctx, args != nullptr);
     const midas_shard_route_args& s = *args;
     MIDAS_REQUIRE(ctx, s.N >= 256 && s.G > 0 && s.G <= 64 && s.rank >= 0 && s.rank < s.G && s.r1_all_dev && s.tables_dev &&
@@ -953,7 +958,7 @@ static int shard_route(midas_ctx* ctx, const midas_shard_route_args* args, bool 
     MIDAS_REQUIRE(ctx, !pack || s.peers_dev || s.fixed_cap == 0 || (s.fixed_cap > 0 && s.ovf_cap > 0 && s.ovf_dev && (uintptr_t)s.ovf_dev % 8 == 0 && s.self_dev && (uintptr_t)s.self_dev % 8 == 0 &&
                                                      s.G * s.fixed_cap < ((int64_t)1 << 31)));
     MIDAS_REQUIRE(ctx, s.resample_mode == MIDAS_RESAMPLE_MULTINOMIAL || s.resample_mode == MIDAS_RESAMPLE_SYSTEMATIC);
-    return launch_shard_route(ctx, s, shard_tables_of(const_cast<double*>(s.tables_dev), s.N), pack);
+    return launch_shard_route(ctx, s, shard_tables_of(const_cast<double*>(s.tables_dev), s.N), pack, sync);
 }
 
 MIDAS_EXPORT int midas_shard_route_count(midas_ctx* ctx, const midas_shard_route_args* args) {
@@ -1059,8 +1064,10 @@ MIDAS_EXPORT int midas_peer_probe_check(midas_ctx* ctx, const void* inbox_dev, i
 struct midas_comm;
 extern "C" int midas_comm_all_gather(midas_comm* c, const void* send_dev, void* recv_dev, int64_t bytes);
 
+// from_inbox (midas_shard_run): the front takes its particles from the rows of the inbox (the previous frame ran without its
+// UNPACK phase; its route kernel ended with the inbox complete)
 static int shard_step_impl(midas_ctx* ctx, midas_comm* comm, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
-                           const midas_shard_step_args& s, int32_t phases) {
+                           const midas_shard_step_args& s, int32_t phases, bool from_inbox = false) {
     MIDAS_REQUIRE(ctx, phases != 0 && (phases & ~31) == 0);
     MIDAS_REQUIRE(ctx, s.front.N >= 256 && s.G >= 1 && s.G <= 64 && s.rank >= 0 && s.rank < s.G && s.tables_dev && s.r1_dev);
     MIDAS_REQUIRE(ctx, s.r1_all_dev || !(phases & (MIDAS_SHARD_PHASE_GATHER | MIDAS_SHARD_PHASE_ROUTE)));
@@ -1071,7 +1078,12 @@ static int shard_step_impl(midas_ctx* ctx, midas_comm* comm, const midas_codeboo
     if (phases & MIDAS_SHARD_PHASE_LOCAL) {  // propagate / NN / prune / scoring, then the shard's softmax tables and its record
         void* prm = nullptr;
         ScorePredict predict;
-        if ((rc = shard_front_impl(ctx, cb, tree6, tree3, &s.front, &prm, s.score_list_dev, &predict))) return rc;
+        PeerInboxSrc src;
+        if (from_inbox) {
+            MIDAS_REQUIRE(ctx, s.inbox_dev && s.flag_offset >= N * PEER_ROW);
+            src.rows = (const char*)s.inbox_dev;
+        }
+        if ((rc = shard_front_impl(ctx, cb, tree6, tree3, &s.front, &prm, s.score_list_dev, &predict, from_inbox ? &src : nullptr))) return rc;
         MIDAS_REQUIRE(ctx, (uintptr_t)s.tables_dev % 128 == 0);
         if ((rc = launch_shard_tail_a(ctx, N, s.front.scores_dev, s.front.nn_idx_dev, s.front.valid_dev, s.softmax,
                                       shard_tables_of(s.tables_dev, N), s.r1_dev, s.front.status_dev, (const double*)prm,
@@ -1083,7 +1095,7 @@ static int shard_step_impl(midas_ctx* ctx, midas_comm* comm, const midas_codeboo
         if ((rc = midas_comm_all_gather(comm, s.r1_dev, s.r1_all_dev, rec * (int64_t)sizeof(double)))) return rc;
     }
     if (phases & (MIDAS_SHARD_PHASE_ROUTE | MIDAS_SHARD_PHASE_UNPACK))
-        MIDAS_REQUIRE(ctx, s.peers_dev && s.inbox_dev && s.flag_offset >= N * 88 && s.flag_offset % 8 == 0 && s.frame_tag != 0 &&
+        MIDAS_REQUIRE(ctx, s.peers_dev && s.inbox_dev && s.flag_offset >= N * PEER_ROW && s.flag_offset % 8 == 0 && s.frame_tag != 0 &&
                                s.counts_dev && s.weights_dev && s.ridx_dev && s.poses_out_dev && s.weights_out_dev && s.hint_out_dev);
     if (phases & MIDAS_SHARD_PHASE_ROUTE) {  // owner-side resample into the peers' inboxes, then the completion flags
         midas_shard_route_args r;
@@ -1094,16 +1106,20 @@ static int shard_step_impl(midas_ctx* ctx, midas_comm* comm, const midas_codeboo
         r.softmax = s.softmax; r.resample_mode = s.resample_mode; r.u_all_dev = s.u_all_dev; r.u32 = s.u32;
         r.seed = s.front.seed; r.step = s.front.step;
         r.counts_dev = s.counts_dev; r.weights_dev = s.weights_dev; r.peers_dev = s.peers_dev;
-        if ((rc = shard_route(ctx, &r, true))) return rc;
+        // without FLAG the route kernel's last workgroup publishes this rank's flag and waits for every rank's: when the kernel
+        // ends the inbox is complete (one polling wave; the word behind the 64 flags is its workgroup counter)
+        const PeerRouteSync sync{(const char*)s.inbox_dev, s.flag_offset, s.frame_tag};
+        if ((rc = shard_route(ctx, &r, true, (phases & MIDAS_SHARD_PHASE_FLAG) ? nullptr : &sync))) return rc;
         if (phases & MIDAS_SHARD_PHASE_FLAG)  // shards of one process on one stream: the flags must be out before ANY shard waits
             if ((rc = launch_peer_flag_write(ctx, s.peers_dev, s.G, s.rank, s.flag_offset, s.frame_tag))) return rc;
     }
-    if (phases & MIDAS_SHARD_PHASE_UNPACK) {  // wait for every rank's flag in the own inbox, then inbox -> slots
-        // (its first workgroup publishes this rank's flag unless ROUTE already did: the kernel sits behind the route kernel)
-        if ((rc = launch_shard_unpack_peer_wait(ctx, N, s.inbox_dev, s.ridx_dev, s.poses_out_dev, s.weights_out_dev, s.hint_out_dev,
-                                                s.G, s.flag_offset, s.frame_tag, s.front.status_dev,
-                                                (phases & MIDAS_SHARD_PHASE_FLAG) ? nullptr : s.peers_dev, s.rank)))
-            return rc;
+    if (phases & MIDAS_SHARD_PHASE_UNPACK) {  // inbox -> slots; with FLAG behind a wait for every rank's flag in the own inbox
+        if (phases & MIDAS_SHARD_PHASE_FLAG)
+            rc = launch_shard_unpack_peer_wait(ctx, N, s.inbox_dev, s.ridx_dev, s.poses_out_dev, s.weights_out_dev, s.hint_out_dev,
+                                               s.G, s.flag_offset, s.frame_tag, s.front.status_dev, nullptr, s.rank);
+        else
+            rc = launch_shard_unpack_peer(ctx, N, s.inbox_dev, s.ridx_dev, s.poses_out_dev, s.weights_out_dev, s.hint_out_dev);
+        if (rc) return rc;
     }
     return MIDAS_OK;
 }
@@ -1121,11 +1137,17 @@ MIDAS_EXPORT int midas_shard_run(midas_ctx* ctx, midas_comm* comm, const midas_c
     MIDAS_REQUIRE(ctx, first != nullptr && comm != nullptr && cb != nullptr && T >= 1);
     MIDAS_REQUIRE(ctx, !first->front.tn_dev && !first->front.rot_dev && !first->u_all_dev && !first->front.scores_ready);
     midas_shard_step_args a = *first;
+    // The unpack of every frame but the last is folded into the NEXT frame's front: the rows other ranks stored into this rank's
+    // inbox are read there, behind the same flag wait (MIDAS_SHARD_FOLD=0: every frame unpacks into the particle arrays).
+    // Safe with one inbox: a peer stores the rows of frame f + 1 behind its record all_gather of frame f + 1, which completes only
+    // when every rank has joined it - and a rank joins behind its own front of frame f + 1, the reader of the rows of frame f.
+    static const bool fold = !(getenv("MIDAS_SHARD_FOLD") && getenv("MIDAS_SHARD_FOLD")[0] == '0');
     for (int32_t f = 0; f < T; ++f) {
         int rc = f ? scratch_reset(ctx) : MIDAS_OK;
         if (rc) return rc;
-        if ((rc = shard_step_impl(ctx, comm, cb, tree6, tree3, a, MIDAS_SHARD_PHASE_LOCAL | MIDAS_SHARD_PHASE_GATHER | MIDAS_SHARD_PHASE_ROUTE | MIDAS_SHARD_PHASE_UNPACK)))
-            return rc;
+        const bool last = f == T - 1;
+        const int32_t phases = MIDAS_SHARD_PHASE_LOCAL | MIDAS_SHARD_PHASE_GATHER | MIDAS_SHARD_PHASE_ROUTE | ((last || !fold) ? MIDAS_SHARD_PHASE_UNPACK : 0);
+        if ((rc = shard_step_impl(ctx, comm, cb, tree6, tree3, a, phases, fold && f > 0))) return rc;
         // next frame: the resampled particles are in poses_out / hint_out (= the front's inputs: the engine passes the same buffers)
         a.front.step += 1;
         a.frame_tag += 1;

@@ -226,6 +226,17 @@ struct ScorePredict {
     int32_t* count = nullptr;
 };
 
+// Where a front kernel takes its particles from when the unpack of the previous frame is folded into it (midas_shard_run):
+// rows == nullptr: the particle arrays.
+struct PeerInboxSrc {
+    const char* rows = nullptr;        // this rank's inbox
+    long long flag_off = 0;            // bytes from the inbox to its flag block
+    unsigned long long tag = 0;        // the frame tag the rows must carry
+    int G = 0, rank = 0;
+    char* const* peers = nullptr;      // non-null: the launch publishes this rank's flag (its first wave) before anybody waits
+    int32_t* status = nullptr;         // bit 16 when a flag did not arrive within the bound
+};
+
 struct ParticleUpdateArgs {
     int64_t N;
     const float* poses_in;
@@ -260,6 +271,7 @@ struct ParticleUpdateArgs {
     double* flags_reset = nullptr;            // nullable: two float64 counters zeroed here (sharded exchange record)
     LazyResample rs;                          // fused front only
     SparseScore sp;                           // stamps != nullptr: only the rows that are some particle's nearest entry are scored
+    PeerInboxSrc inbox;                       // rows != nullptr: particles come from the rank's inbox (unpack folded in; forms without folded resample)
 };
 int particle_update_blocks(int64_t N);
 bool index_build_on_host();  // MIDAS_HOST_INDEX=1: the host builders of round 1 (checkers of the device builders)
@@ -329,7 +341,10 @@ int launch_tail_b2(midas_ctx* ctx, const StepTailArgs& a, const TailTables& tb);
 int launch_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
                         int32_t softmax, const TailTables& tb, double* r1, int32_t* status, const double* part_rmse = nullptr,
                         const ScorePredict* predict = nullptr);
-int launch_shard_route(midas_ctx* ctx, const midas_shard_route_args& r, const TailTables& tb, bool pack);
+// sync (peer form, C-side frame): the route kernel's last workgroup publishes the frame's completion flag and waits for every
+// rank's (the word behind the 64 flags of the own inbox counts the finished workgroups: zero between launches)
+struct PeerRouteSync { const char* inbox; long long flag_off; unsigned long long tag; };
+int launch_shard_route(midas_ctx* ctx, const midas_shard_route_args& r, const TailTables& tb, bool pack, const PeerRouteSync* sync = nullptr);
 int launch_shard_unpack(midas_ctx* ctx, int64_t N, const void* recv, int32_t* ridx, float* poses_out, double* weights_out,
                         int32_t* hint_out, int32_t dest = -1);
 int launch_shard_unpack_peer(midas_ctx* ctx, int64_t N, const void* inbox, int32_t* ridx, float* poses_out, double* weights_out,

@@ -14,6 +14,7 @@
 #include "midas_internal.hpp"
 #include "midas_math.hpp"
 #include "score_body.hpp"
+#include "peer_row.hpp"
 #include "resample_search.hpp"
 
 namespace midas {
@@ -1780,11 +1781,25 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
         if (a.rs.ridx_out) a.rs.ridx_out[n] = (int32_t)src;
     }
     const float* pose_src = rs_lds ? a.rs.poses_prev : a.poses_in;
+    // the sharded frame with the unpack folded in (midas_shard_run): the particle of slot n is row n of this rank's inbox, stored
+    // there by the owner of its source; the rows are complete - the route kernel in front of this launch ended with every
+    // rank's completion flag in
+    const bool from_inbox = !WT && a.inbox.rows != nullptr;
+    PeerRow row;
+    if (from_inbox && live) row = peer_row_load(a.inbox.rows, n);
     // the hint travels with the pose (behind the store of the propagated pose it would be a round trip of its own)
-    const int32_t hint = !live ? -1 : rs_lds ? a.rs.nn_prev[src] : a.hint_in ? a.hint_in[n] : -1;
+    const int32_t hint = !live ? -1 : from_inbox ? (int32_t)(row.head[1] & 0xFFFFFFFFull) : rs_lds ? a.rs.nn_prev[src] : a.hint_in ? a.hint_in[n] : -1;
     if (live) {
         float P[16];
-        load_pose(pose_src + src * 16, P);
+        if (from_inbox) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                P[2 * k] = __int_as_float((int)(row.pose[k] & 0xFFFFFFFFull));
+                P[2 * k + 1] = __int_as_float((int)(row.pose[k] >> 32));
+            }
+        } else {
+            load_pose(pose_src + src * 16, P);
+        }
         if (WT) {
             mat4_mul(P, NO, R);
         } else {
@@ -2392,7 +2407,7 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
     // (re-measured after the single kernel's second pass - per-wave tables, one-wave workgroups, screened scans: pipelined,
     // split / single at N = 6k 29.6k / 27.5k steps/s, 8k 29.0k / 27.9k, 12k 28.3k / 28.5k, 20k 25.8k / 27.1k, 65k 21.0k / 22.9k:
     // the two-kernel form now pays up to ~10 000 particles instead of 65 536; the loop step (live count) keeps it: 126 / 138 us)
-    const bool split_front = a.batch <= 1 && (split_env >= 2 || (split_env == 1 && ((a.rs.enabled && a.N <= 10240) || a.N <= 2048 || a.n_live)));
+    const bool split_front = a.batch <= 1 && !a.inbox.rows && (split_env >= 2 || (split_env == 1 && ((a.rs.enabled && a.N <= 10240) || a.N <= 2048 || a.n_live)));
     const int lpp = split_env == 3 ? 2 : 4;
     if (split_front && !(a.ablate & 7)) {
         a.sp.pred_tag = 0; a.sp.list = nullptr;  // (next_count stays: the tail appends whatever form the front had)

@@ -6,6 +6,7 @@
 // 4096 values); every level is a sequential float64 sum in index order starting from +0.0.
 #include "midas_internal.hpp"
 #include "midas_math.hpp"
+#include "peer_row.hpp"
 #include "resample_search.hpp"
 #include "tail_block.hpp"
 
@@ -1274,18 +1275,17 @@ struct ShardRouteArgs {
     char* self_rows = nullptr;  // [N] the rows this rank owns AND needs (they never travel)
     // peer-mapped form: row `slot` of the destination's inbox, written in place (fine-grained memory, system-scope stores)
     char* const* peers = nullptr;
+    // ... with the completion protocol inside this kernel (the C-side frame across processes): the LAST workgroup to finish
+    // publishes frame `tag` in slot `rank` of every inbox's flag block and then waits (bounded) until the own inbox carries
+    // every rank's tag - when the kernel ends this rank's inbox holds all N rows, and ONE wave polled for it.  (Polling from
+    // every workgroup of the consumer was measured: 1563 waves reading one address until it changes cost 26 us per frame.)
+    const char* own_inbox = nullptr;
+    long long flag_off = 0;
+    unsigned long long tag = 0;
+    unsigned* done = nullptr;  // workgroups finished, zero between launches (reset by the last one)
 };
 
-// 8-byte pieces of a record in memory other agents write or read: stores / loads that bypass the non-coherent caches
-__device__ __forceinline__ void sys_store8(void* p, unsigned long long v) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ unsigned long long sys_load8(const void* p) {
-    return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ unsigned long long pack2(int lo, int hi) { return (unsigned long long)(unsigned)lo | ((unsigned long long)(unsigned)hi << 32); }
-__device__ __forceinline__ unsigned long long pack2f(float lo, float hi) { return pack2(__float_as_int(lo), __float_as_int(hi)); }
-
+// (sys_store8 / sys_load8 / pack2: peer_row.hpp - the rows of the peer-mapped form are 128-byte lines written by sixteen lanes)
 template <bool PACK>
 __global__ __launch_bounds__(256) void k_shard_route(ShardRouteArgs a) {
     __shared__ double s_bp[TB_MAX_BLOCKS];
@@ -1367,7 +1367,8 @@ __global__ __launch_bounds__(256) void k_shard_route(ShardRouteArgs a) {
         int st = s_tot[2] != 0.0 ? 2 : 0;
         if (total != total) st |= 2;
         else if (total == 0.0) st |= 1;
-        a.status[0] = st;
+        if (a.own_inbox) atomicOr(&a.status[0], st);  // (zeroed by the front; the last workgroup may add the "flag late" bit)
+        else a.status[0] = st;
         a.status[1] = (int32_t)kept;
         if (a.rmse_out) { a.rmse_out[0] = __builtin_sqrt(st2 / a.n_total); a.rmse_out[1] = __builtin_sqrt(sr2 / a.n_total); }
     }
@@ -1418,9 +1419,58 @@ __global__ __launch_bounds__(256) void k_shard_route(ShardRouteArgs a) {
         a.weights[il] = (ev[il] / S) * (a.valid[il] ? 1.0 : 0.0);
     }
     const bool mine = live && o == a.rank;
+    if (a.peers) {
+        // straight into the slot's row of the destination's inbox: the rows of a wave are staged in LDS and go out sixteen
+        // lanes per row - whole 128-byte lines (peer_row.hpp)
+        __shared__ unsigned long long s_stage[4][64][PEER_PIECES];
+        __shared__ char* s_dst[4][64];
+        const int w = t >> 6, lane = t & 63;
+        const unsigned long long mm = __ballot(mine);
+        if (mine) {
+            int64_t src;
+            if (!usable) src = i - (int64_t)a.rank * N;  // the resampler keeps the particles
+            else if (past) src = N - 1;
+            else
+                src = search_in_block(apply ? a.lp : a.lp_raw, apply ? a.gend : a.gend_raw, apply ? a.ggend : a.ggend_raw,
+                                      b - a.rank * a.nb, N, a.rank == a.G - 1 ? N - 1 : -1, s_bp[b], total, tq, upper);
+            const float4* ps = reinterpret_cast<const float4*>(a.poses_prop + src * 16);
+            const float4 r0 = ps[0], r1 = ps[1], r2 = ps[2], r3 = ps[3];
+            const double wgt = (ev[src] / S) * (a.valid[src] ? 1.0 : 0.0);
+            const int k = __popcll(mm & ((1ull << lane) - 1ull));
+            unsigned long long* st = s_stage[w][k];
+            st[0] = pack2((int)(i - (int64_t)d * N), (int)((int64_t)a.rank * N + src));
+            st[1] = pack2(a.nn_idx[src], d);
+            st[2] = (unsigned long long)__double_as_longlong(wgt);
+            st[3] = 0ull;
+            st[4] = pack2f(r0.x, r0.y); st[5] = pack2f(r0.z, r0.w);
+            st[6] = pack2f(r1.x, r1.y); st[7] = pack2f(r1.z, r1.w);
+            st[8] = pack2f(r2.x, r2.y); st[9] = pack2f(r2.z, r2.w);
+            st[10] = pack2f(r3.x, r3.y); st[11] = pack2f(r3.z, r3.w);
+            s_dst[w][k] = a.peers[d] + (size_t)(i - (int64_t)d * N) * PEER_ROW;
+        }
+        __syncthreads();  // (uniform branch: every thread of the workgroup is here)
+        peer_rows_store(s_stage[w], s_dst[w], __popcll(mm));
+        if (a.own_inbox) {
+            // The barrier waits for every wave's outstanding stores (s_waitcnt vmcnt(0) in front of s_barrier), and the row
+            // stores are system-scope write-through stores: acknowledged = performed at the destination.  So the count needs
+            // no release of its own (a release fence here is a write-back of the XCD's whole L2 per workgroup: measured,
+            // +7 us per launch); the workgroup that sees the full count publishes with a system-scope release store.
+            __syncthreads();
+            __shared__ int s_last;
+            if (t == 0) s_last = __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+            __syncthreads();
+            if (s_last && w == 0) {
+                if (lane == 0) __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                PeerInboxSrc f;
+                f.rows = a.own_inbox; f.flag_off = a.flag_off; f.tag = a.tag; f.G = a.G; f.rank = a.rank; f.peers = a.peers; f.status = a.status;
+                peer_flags_publish_wait(f, true);
+            }
+        }
+        return;
+    }
     const int d0 = (int)(((int64_t)blockIdx.x * 256) / N);  // a workgroup spans at most two destinations (N >= 256)
     int pos = 0;
-    if (!a.peers) {
+    {
         if (mine) pos = atomicAdd(&s_cnt[d - d0], 1);
         __syncthreads();
         if (t < 2 && s_cnt[t]) s_base[t] = atomicAdd(&a.cursor[d0 + t], s_cnt[t]);
@@ -1433,20 +1483,6 @@ __global__ __launch_bounds__(256) void k_shard_route(ShardRouteArgs a) {
         else
             src = search_in_block(apply ? a.lp : a.lp_raw, apply ? a.gend : a.gend_raw, apply ? a.ggend : a.ggend_raw,
                                   b - a.rank * a.nb, N, a.rank == a.G - 1 ? N - 1 : -1, s_bp[b], total, tq, upper);
-        if (a.peers) {  // straight into the slot's row of the destination's inbox
-            char* rp = a.peers[d] + (size_t)(i - (int64_t)d * N) * ROUTE_REC;
-            const float4* ps = reinterpret_cast<const float4*>(a.poses_prop + src * 16);
-            const float4 r0 = ps[0], r1 = ps[1], r2 = ps[2], r3 = ps[3];
-            const double w = (ev[src] / S) * (a.valid[src] ? 1.0 : 0.0);
-            sys_store8(rp, pack2((int)(i - (int64_t)d * N), (int)((int64_t)a.rank * N + src)));
-            sys_store8(rp + 8, pack2(a.nn_idx[src], d));
-            sys_store8(rp + 16, (unsigned long long)__double_as_longlong(w));
-            sys_store8(rp + 24, pack2f(r0.x, r0.y)); sys_store8(rp + 32, pack2f(r0.z, r0.w));
-            sys_store8(rp + 40, pack2f(r1.x, r1.y)); sys_store8(rp + 48, pack2f(r1.z, r1.w));
-            sys_store8(rp + 56, pack2f(r2.x, r2.y)); sys_store8(rp + 64, pack2f(r2.z, r2.w));
-            sys_store8(rp + 72, pack2f(r3.x, r3.y)); sys_store8(rp + 80, pack2f(r3.z, r3.w));
-            return;
-        }
         char* rp = a.send + (size_t)(s_soff[d] + s_base[d - d0] + pos) * ROUTE_REC;
         if (a.fixed_cap && d == a.rank) {  // own slot, own source: stays here (systematic draws are mostly of this kind)
             rp = a.self_rows + (size_t)(s_base[d - d0] + pos) * ROUTE_REC;
@@ -1497,21 +1533,23 @@ __global__ __launch_bounds__(256) void k_shard_unpack(int64_t N, const char* __r
 }
 
 // the N rows other ranks stored into this rank's inbox (row r = slot r)
+__device__ __forceinline__ void unpack_peer_row(const char* __restrict__ inbox, int64_t r, int32_t* __restrict__ ridx, float* __restrict__ poses_out,
+                                                double* __restrict__ weights_out, int32_t* __restrict__ hint_out) {
+    const PeerRow v = peer_row_load(inbox, r);
+    ridx[r] = (int32_t)(v.head[0] >> 32);
+    hint_out[r] = (int32_t)(v.head[1] & 0xFFFFFFFFull);
+    weights_out[r] = __longlong_as_double((long long)v.head[2]);
+    unsigned long long* pd = reinterpret_cast<unsigned long long*>(poses_out + r * 16);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pd[k] = v.pose[k];
+}
+
 __global__ __launch_bounds__(256) void k_shard_unpack_peer(int64_t N, const char* __restrict__ inbox, int32_t* __restrict__ ridx,
                                                            float* __restrict__ poses_out, double* __restrict__ weights_out,
                                                            int32_t* __restrict__ hint_out) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= N) return;
-    const char* rp = inbox + (size_t)r * ROUTE_REC;
-    unsigned long long v[11];
-#pragma unroll
-    for (int k = 0; k < 11; ++k) v[k] = sys_load8(rp + 8 * k);
-    ridx[r] = (int32_t)(v[0] >> 32);
-    hint_out[r] = (int32_t)(v[1] & 0xFFFFFFFFull);
-    weights_out[r] = __longlong_as_double((long long)v[2]);
-    unsigned long long* pd = reinterpret_cast<unsigned long long*>(poses_out + r * 16);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) pd[k] = v[3 + k];
+    unpack_peer_row(inbox, r, ridx, poses_out, weights_out, hint_out);
 }
 
 // Device-side completion flags of the peer-mapped exchange (the C-side sharded frame, midas_shard_step): behind its route
@@ -1548,16 +1586,7 @@ __global__ __launch_bounds__(256) void k_shard_unpack_peer_wait(int64_t N, const
     __syncthreads();
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= N) return;
-    const char* rp = inbox + (size_t)r * ROUTE_REC;
-    unsigned long long v[11];
-#pragma unroll
-    for (int k = 0; k < 11; ++k) v[k] = sys_load8(rp + 8 * k);
-    ridx[r] = (int32_t)(v[0] >> 32);
-    hint_out[r] = (int32_t)(v[1] & 0xFFFFFFFFull);
-    weights_out[r] = __longlong_as_double((long long)v[2]);
-    unsigned long long* pd = reinterpret_cast<unsigned long long*>(poses_out + r * 16);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) pd[k] = v[3 + k];
+    unpack_peer_row(inbox, r, ridx, poses_out, weights_out, hint_out);
 }
 
 // start-up self test of the peer data path (include/midas_hip.h)
@@ -1796,7 +1825,7 @@ int launch_tail_b2(midas_ctx* ctx, const StepTailArgs& a, const TailTables& tb) 
     return MIDAS_OK;
 }
 
-int launch_shard_route(midas_ctx* ctx, const midas_shard_route_args& r, const TailTables& tb, bool pack) {
+int launch_shard_route(midas_ctx* ctx, const midas_shard_route_args& r, const TailTables& tb, bool pack, const PeerRouteSync* sync) {
     const int nb = (int)ceil_div(r.N, SCAN_BLOCK);
     if ((int64_t)r.G * nb > TB_MAX_BLOCKS)
         return midas_set_error(ctx, MIDAS_ERR_INVALID, "G*nb", "more than 4 M particles in total in the sharded step");
@@ -1811,6 +1840,7 @@ int launch_shard_route(midas_ctx* ctx, const midas_shard_route_args& r, const Ta
     const unsigned grid = (unsigned)ceil_div((int64_t)r.G * r.N, 256);
     if (pack && r.peers_dev) {  // rows stored straight into the destinations' inboxes
         a.peers = (char* const*)r.peers_dev;
+        if (sync) { a.own_inbox = sync->inbox; a.flag_off = sync->flag_off; a.tag = sync->tag; a.done = reinterpret_cast<unsigned*>(const_cast<char*>(sync->inbox) + sync->flag_off + 64 * 8); }
         hipLaunchKernelGGL(k_shard_route<true>, dim3(grid), dim3(256), 0, ctx->stream, a);
     } else if (pack && r.fixed_cap > 0) {  // one pass, no counts: padded segments + overflow block
         a.fixed_cap = r.fixed_cap; a.ovf_cap = r.ovf_cap; a.ovf = (char*)r.ovf_dev; a.ovf_count = r.counts_dev + 2 * r.G + r.G;

@@ -41,7 +41,8 @@ from . import _lib, ops
 from ._lib import MidasError, ShardFrontArgs, ShardRouteArgs, TailResampleArgs, _ptr
 
 BLOCK = 4096  # summation block of the CDF spec (csrc/resample.hip)
-ROUTE_REC = 88  # bytes per routed particle row (include/midas_hip.h)
+ROUTE_REC = 88  # bytes per routed particle row in the all_to_all forms (include/midas_hip.h)
+PEER_ROW = 128  # bytes per row of a peer-mapped inbox: one line, written by sixteen lanes (csrc/peer_row.hpp)
 
 
 class HipShardBackend:
@@ -184,9 +185,10 @@ class HipShardBackend:
     def peer_alloc(self, st) -> torch.Tensor:
         """This shard's inbox (N rows of fine-grained device memory) -> its 64-byte interprocess handle."""
         ptr, h = C.c_void_p(), (C.c_ubyte * 64)()
-        # N rows, then the completion flags of the C-side frame (one uint64 per rank, include/midas_hip.h midas_shard_step)
-        st._flag_off = st.N * ROUTE_REC
-        self.ctx.call("midas_peer_alloc", st._flag_off + 64 * 8, C.byref(ptr), h)
+        # N rows, then the completion flags of the C-side frame (one uint64 per rank, include/midas_hip.h midas_shard_step) and the
+        # route kernel's workgroup counter (one more 64-byte line; midas_peer_alloc zeroes the block)
+        st._flag_off = st.N * PEER_ROW
+        self.ctx.call("midas_peer_alloc", st._flag_off + 64 * 8 + 64, C.byref(ptr), h)
         st._inbox, st._opened = ptr.value, []
         return torch.tensor(list(h), dtype=torch.uint8)
 
