@@ -215,6 +215,11 @@ struct SparseScore {
     const int32_t* list_count = nullptr;
     int32_t* next_count = nullptr;      // the other list's counter, zeroed by the front for this frame's tail
     int32_t list_cap = 0;
+    // dense_thr > 0: a frame whose list holds more rows than this scores ALL rows with the streaming waves instead (K rows in one
+    // coalesced stream cost less than a few thousand scattered ones plus the claims of the rows the list missed - the frames after
+    // a wide start); the particle waves then only mark the rows they use (for the next frame's list) and score nothing
+    int32_t dense_thr = 0;
+    int64_t K = 0;
 };
 // what the tail kernel needs to build the next frame's list: rows whose stamp is `epoch` (claimed or confirmed in this
 // frame) are appended to `list` and re-stamped epoch + 1, the next frame's pred_tag (its epoch is epoch + 2)

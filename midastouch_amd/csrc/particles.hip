@@ -1748,6 +1748,7 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
     }
     unsigned long long st_nn = 0, st_mesh = 0, st_scan = 0;
     int st_rows = 0;
+    const bool dense_scores = scores_dense(a.sp);  // requested here, looked at after the nearest-neighbour search
     const int ablate = STATS ? a.ablate : 0;
     long long tc[10];  // phase clocks, reported with MIDAS_ABLATE=4
 #define MIDAS_TICK(i) do { if (STATS) tc[i] = clock64(); } while (0)
@@ -1846,7 +1847,7 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
     RowClaim claim{false, 0u};
     if (a.sp.stamps && !(ablate & 16)) {  // ablate 16 (profiling): nobody scores
         claim = claim_rows_issue(a.sp, live, bi, MIDAS_CLAIM_HASH ? reinterpret_cast<int*>(s_cd) : nullptr);
-        if (!MIDAS_CLAIM_DEFER) st_rows = score_claimed_rows_nj(a.sp, claim, bi);
+        if (!MIDAS_CLAIM_DEFER) st_rows = score_claimed_rows_nj(a.sp, claim, bi, dense_scores);
     }
     MIDAS_TICK(9);
     // prune: valid <=> some mesh vertex within sqrt(t2) of the particle
@@ -1877,7 +1878,7 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
         if (lane == 0 && m) atomicAdd(&a.telemetry[1], (unsigned long long)__popcll(m));
     }
     if (mv >= 0) ok = mv == 1;
-    if (MIDAS_CLAIM_DEFER && a.sp.stamps && !(ablate & 16)) st_rows = score_claimed_rows_nj(a.sp, claim, bi);
+    if (MIDAS_CLAIM_DEFER && a.sp.stamps && !(ablate & 16)) st_rows = score_claimed_rows_nj(a.sp, claim, bi, dense_scores);
     if (a.telemetry && st_rows && lane == 0) atomicAdd(&a.telemetry[2], (unsigned long long)st_rows);  // rows scored by particle waves
     MIDAS_TICK(6);
     if (live) {
@@ -1983,7 +1984,8 @@ __global__ __launch_bounds__(64 * FW, (!SCR && FW == 1) ? MIDAS_BATCH_OCC : 1) v
     } else if (a.sp.list) {  // prediction list: the rows the previous frame used, four per wave-instruction
         if ((int)bx == n_pu && threadIdx.x == 0 && a.telemetry) {  // rows scored off the list (cumulative, for the bench's byte count)
             const int c = *a.sp.list_count;
-            if (c > 0) atomicAdd(&a.telemetry[3], (unsigned long long)(c < a.sp.list_cap ? c : a.sp.list_cap));
+            if (a.sp.dense_thr > 0 && c > a.sp.dense_thr) atomicAdd(&a.telemetry[3], (unsigned long long)a.sp.K);  // all of them
+            else if (c > 0) atomicAdd(&a.telemetry[3], (unsigned long long)(c < a.sp.list_cap ? c : a.sp.list_cap));
         }
         score_list_wave<NJ>(a.sp, (int)(bx - n_pu) * FW + w, ((int)gridDim.x - n_pu) * FW);
     } else {
@@ -2393,6 +2395,13 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
     // (a row stamped pred_tag is then simply stale and gets claimed: same scores)
     static const int list_wgs_env = getenv("MIDAS_LIST_WAVES") ? atoi(getenv("MIDAS_LIST_WAVES")) : 1024;
     const bool use_list = a.sp.stamps && a.sp.list && a.batch <= 1 && list_wgs_env > 0;
+    // MIDAS_DENSE_ROWS=<rows>: a frame whose prediction list holds more rows scores the whole codebook with the streaming waves
+    // and its particle waves claim nothing (decided on the device, per frame).  Off by default: measured on the frames after a
+    // wide start (20k -> 400 distinct rows over the driver's window) it changes nothing (19.2 - 19.5k steps/s either way, thresholds
+    // 1500 / 3125 / 6000, 1024 - 4096 streaming waves) - with the prediction lists the claims are no longer what those frames wait for.
+    const char* dense_env = getenv("MIDAS_DENSE_ROWS");
+    a.sp.K = cb->K;
+    a.sp.dense_thr = use_list && dense_env ? atoi(dense_env) : 0;
     const unsigned grid = (unsigned)(n_pu + (a.sp.stamps ? 0 : ceil_div(cb->K, 16)));
     const float* emb = (const float*)cb->emb;
     // Two-kernel form (group-parallel list scans, see k_particle_nn_prune) for small particle sets (round 1's rule was "while

@@ -160,9 +160,16 @@ MD void score_rows4(const SparseScore& sp, int32_t mine) {
     }
 }
 
+// the frame's scoring mode (uniform; see SparseScore::dense_thr): read early by the particle waves, it is a round trip
+MD bool scores_dense(const SparseScore& sp) { return sp.list != nullptr && sp.dense_thr > 0 && *sp.list_count > sp.dense_thr; }
+
 template <int NJ>
-MD int score_claimed_rows(const SparseScore& sp, const RowClaim& c, int32_t row) {  // returns the rows this wave scored
+MD int score_claimed_rows(const SparseScore& sp, const RowClaim& c, int32_t row, bool dense = false) {  // returns the rows this wave scored
     const int lane = threadIdx.x & 63, qd = lane >> 4;
+    if (dense) {  // every row is being scored by the streaming waves: mark the rows in use, claim nothing
+        if (c.leader && c.old != sp.epoch) sp.stamps[row] = sp.epoch;
+        return 0;
+    }
     // (after the first waves of a frame nearly every needed row carries the epoch already)
     bool claim = false;
     // Prediction list (sp.pred_tag != 0): the tail of the previous frame stamped the rows that frame used with pred_tag and
@@ -196,12 +203,12 @@ MD int score_claimed_rows(const SparseScore& sp, const RowClaim& c, int32_t row)
     return nrows;
 }
 
-MD int score_claimed_rows_nj(const SparseScore& sp, const RowClaim& c, int32_t row) {
+MD int score_claimed_rows_nj(const SparseScore& sp, const RowClaim& c, int32_t row, bool dense = false) {
     switch (sp.nj) {
-        case 8: return score_claimed_rows<8>(sp, c, row);
-        case 4: return score_claimed_rows<4>(sp, c, row);
-        case 2: return score_claimed_rows<2>(sp, c, row);
-        default: return score_claimed_rows<16>(sp, c, row);
+        case 8: return score_claimed_rows<8>(sp, c, row, dense);
+        case 4: return score_claimed_rows<4>(sp, c, row, dense);
+        case 2: return score_claimed_rows<2>(sp, c, row, dense);
+        default: return score_claimed_rows<16>(sp, c, row, dense);
     }
 }
 
@@ -211,6 +218,13 @@ template <int NJ>
 MD void score_list_wave(const SparseScore& sp, int wave, int nstream) {
     const int lane = threadIdx.x & 63, qd = lane >> 4;
     int count = *sp.list_count;
+    if (sp.dense_thr > 0 && count > sp.dense_thr) {  // the whole codebook, rows in order (SparseScore::dense_thr)
+        for (int64_t i = (int64_t)wave * 4; i < sp.K; i += (int64_t)nstream * 4) {
+            const int64_t k = i + qd;
+            score_rows4<NJ>(sp, k < sp.K ? (int32_t)k : -1);
+        }
+        return;
+    }
     count = count < 0 ? 0 : (count > sp.list_cap ? sp.list_cap : count);
     for (int i = wave * 4; i < count; i += nstream * 4) {
         const int k = i + qd;

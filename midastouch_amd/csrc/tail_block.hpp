@@ -6,6 +6,9 @@
 
 namespace midas {
 
+#ifndef MIDAS_TAIL_EXP_ILP
+#define MIDAS_TAIL_EXP_ILP 1
+#endif
 constexpr double TAIL_ISCLOSE_ATOL = 1e-8;  // torch.isclose default atol (particle_filter.py:460-463)
 
 // Block-local part of the spec scan.  v[16] = this lane's chunk (absent values = +0.0).
@@ -172,7 +175,9 @@ MD void tail_a_direct(int64_t N, int blk, const double* __restrict__ scores, con
 #pragma unroll
         for (int j = 0; j < SCAN_CHUNK; ++j) {
             v[j] = exp_spec(v[j] - 1.0);
-            __builtin_amdgcn_sched_barrier(0);  // one exponential at a time: sixteen interleaved ones cost ~80 registers
+            // MIDAS_TAIL_EXP_ILP exponentials interleaved: each is a dependent chain of ~25 fma, and the workgroup is alone on its
+            // CU (one wave per SIMD) - nothing else hides the latency of the chain
+            if (j % MIDAS_TAIL_EXP_ILP == MIDAS_TAIL_EXP_ILP - 1) __builtin_amdgcn_sched_barrier(0);
         }
         store_chunk(tb.e, v);
         variant(v, tb.lp, tb.gend, tb.ggend, Wa, Wm, nan);

@@ -322,3 +322,40 @@ def test_prediction_list_seeded_at_projection(dev, monkeypatch):
             listed, claimed = int(a.telemetry[3].item()), int(a.telemetry[2].item()) - rows0
             assert listed == torch.unique(idx).numel() and claimed < listed // 2, (listed, claimed)
     assert torch.equal(a.ridx, b.ridx) and torch.equal(a.weights, b.weights) and torch.equal(a.poses, b.poses)
+
+
+@pytest.mark.gpu
+def test_dense_switch_of_the_prediction_list_same_results(dev, monkeypatch):
+    """MIDAS_DENSE_ROWS=<rows> (off by default; measured without gain, kept as a switch): frames whose prediction list holds
+    more rows have the streaming waves score the WHOLE codebook and the particle waves only mark the rows they use - decided
+    on the device frame by frame.  Same nearest entries, scores of the rows in use, resample indices and weights as without;
+    the list keeps following the rows in use, so a later frame below the threshold goes back to the list."""
+    from midastouch_amd.engine import PipelinedFilterEngine
+    N, K, D, seed = 20000, 6000, 256, 4600
+    cb, traj = _setup(N, K, D, 11)
+    start = cb.poses[np.random.default_rng(6).integers(0, K, N)]
+    od, co = torch.as_tensor(traj.odoms).to(dev), torch.as_tensor(traj.codes).to(dev)
+    engs = {}
+    for tag in ("dense", "list"):
+        engs[tag] = PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=seed, device=dev)
+        engs[tag].set_particles(torch.as_tensor(start))
+        engs[tag].project_to_codebook()
+    tele0 = int(engs["dense"].telemetry[3].item())
+    saw_dense = saw_list = False
+    for t in range(1, 9):
+        rows_before = int(engs["dense"].telemetry[3].item())
+        monkeypatch.setenv("MIDAS_DENSE_ROWS", "1000" if t <= 4 else "100000")  # four dense frames, then back to the list
+        engs["dense"].step(od[t], co[t])
+        monkeypatch.delenv("MIDAS_DENSE_ROWS")
+        engs["list"].step(od[t], co[t])
+        a, b = engs["dense"], engs["list"]
+        assert torch.equal(a.nn_idx, b.nn_idx), t
+        used = torch.unique(a.nn_idx).long()
+        assert torch.equal(a._scores[used], b._scores[used]), t
+        assert torch.equal(a.ridx, b.ridx) and torch.equal(a.weights, b.weights), t
+        par = (a._epoch >> 1) & 1
+        assert int(a._score_list[par ^ 1].item()) == used.numel(), t   # the next frame's list: the rows in use, whatever the mode
+        scored = int(a.telemetry[3].item()) - rows_before
+        saw_dense |= scored == K
+        saw_list |= 0 < scored < K
+    assert saw_dense and saw_list, (saw_dense, saw_list, int(engs["dense"].telemetry[3].item()) - tele0)
