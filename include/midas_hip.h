@@ -678,6 +678,12 @@ int midas_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* 
  * ncl_dev: 2 x int32 out {number of clusters, limit flag}. */
 int midas_dbscan(midas_ctx* ctx, int64_t N, const float* poses_dev, double eps, int64_t min_samples, int32_t* labels_dev,
                  int32_t* ncl_dev);
+/* cluster_particles(method="logmap") (particle_filter.py:218-223): DBSCAN of N points of `dim` (2 .. 6) float64 coordinates
+ * (row-major) - the 6-d SE(3) logarithms there -, all pairs, the same predicate and numbering as midas_dbscan (sklearn's
+ * labels).  min_samples < 0 -> N / 5.  info_dev: 2 x int32 out {number of clusters, spread steps taken (-1: not settled)}.
+ * Synchronises the stream (one look per spread step); not on the filter's loop. */
+int midas_dbscan_points(midas_ctx* ctx, int64_t N, int32_t dim, const double* points_dev, double eps, int64_t min_samples,
+                        int32_t* labels_dev, int32_t* info_dev);
 
 /* The selection step of particle_filter.annealing alone (modules/particle_filter.py:421-446, torch.topk + Particles.remove /
  * add): src_dev[0 .. n_set) = the annealed set as indices into the N particles.  mode 1: the N particles minus the k of

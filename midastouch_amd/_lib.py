@@ -228,6 +228,7 @@ SIGNATURES = {
     "midas_lazy_flush_batch": (C.c_int, [_P, C.POINTER(LazyFlushArgs), _I32]),
     "midas_loop_step": (C.c_int, [_P, _P, _P, _P, C.POINTER(LoopArgs), _I32]),
     "midas_dbscan": (C.c_int, [_P, _I64, _P, _D, _I64, _P, _P]),
+    "midas_dbscan_points": (C.c_int, [_P, _I64, C.c_int32, _P, _D, _I64, _P, _P]),
     "midas_anneal_select": (C.c_int, [_P, _I64, _P, _I32, _I64, _P]),
     "midas_shard_front": (C.c_int, [_P, _P, _P, _P, C.POINTER(ShardFrontArgs)]),
     "midas_shard_tail_a": (C.c_int, [_P, _I64, _P, _P, _P, _I32, _P, _P, _P]),

@@ -1213,6 +1213,14 @@ MIDAS_EXPORT int midas_dbscan(midas_ctx* ctx, int64_t N, const float* poses_dev,
     return launch_dbscan(ctx, N, nullptr, poses_dev, eps, min_samples, labels_dev, ncl_dev, ncl_dev + 1);
 }
 
+MIDAS_EXPORT int midas_dbscan_points(midas_ctx* ctx, int64_t N, int32_t dim, const double* points_dev, double eps, int64_t min_samples,
+                                     int32_t* labels_dev, int32_t* info_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, N > 0 && N < ((int64_t)1 << 31) && dim >= 2 && dim <= 6 && points_dev && labels_dev && info_dev && eps > 0.0);
+    MIDAS_HIP_CHECK(ctx, hipMemsetAsync(info_dev, 0, 2 * sizeof(int32_t), ctx->stream));
+    return launch_dbscan_points(ctx, N, dim, points_dev, eps, min_samples, labels_dev, info_dev);
+}
+
 MIDAS_EXPORT int midas_selfsim_panel(midas_ctx* ctx, const midas_codebook* cb, int64_t i0, int64_t R, float* panel_dev, int64_t ldo) {
     MIDAS_ENTER(ctx);
     MIDAS_REQUIRE(ctx, cb && cb->dtype == MIDAS_F32 && cb->D % 32 == 0 && (uintptr_t)cb->emb % 16 == 0 && panel_dev && (uintptr_t)panel_dev % 16 == 0);

@@ -386,6 +386,7 @@ int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree*
 int launch_anneal_select(midas_ctx* ctx, int64_t N, const double* w, int32_t mode, int64_t k, int32_t* src);
 // labels_out[i] in [-1, ncl) for the n = *n_dev (or N when n_dev is null) poses; min_samples < 0 -> n / 5 (cluster_particles);
 // ncl_out[0] = number of clusters; err_out (nullable) |= 2 when the grid / cluster limits were exceeded
+int launch_dbscan_points(midas_ctx* ctx, int64_t N, int32_t dim, const double* pts, double eps, int64_t min_samples, int32_t* labels, int32_t* info);
 int launch_dbscan(midas_ctx* ctx, int64_t cap, const int32_t* n_dev, const float* poses, double eps, int64_t min_samples,
                   int32_t* labels_out, int32_t* ncl_out, int32_t* err_out);
 

@@ -283,6 +283,19 @@ def dbscan(poses: torch.Tensor, eps: float = 1e-2, min_samples: int = -1):
     return labels, info
 
 
+def dbscan_points(points: torch.Tensor, eps: float = 1e-2, min_samples: int = -1):
+    """DBSCAN labels of N points in 2 .. 6 dimensions (cluster_particles(method="logmap"), particle_filter.py:218-223: the
+    6-d SE(3) logarithms), all pairs on the device in float64 - sklearn's predicate and numbering.
+    Returns (labels int32 (N,), info int32 (2,) = [clusters, spread steps or -1])."""
+    pts = points.to(torch.float64).contiguous()
+    if not pts.is_cuda:
+        raise MidasError("midastouch_amd kernels need tensors on a HIP device; there is no CPU fallback")
+    labels = torch.empty(pts.shape[0], dtype=torch.int32, device=pts.device)
+    info = torch.zeros(2, dtype=torch.int32, device=pts.device)
+    _ctx(pts).call("midas_dbscan_points", pts.shape[0], int(pts.shape[1]), _ptr(pts), float(eps), int(min_samples), _ptr(labels), _ptr(info))
+    return labels, info
+
+
 def anneal_select(weights: torch.Tensor, mode: int, k: int) -> torch.Tensor:
     """Index list of the annealed particle set (particle_filter.py:421-446): mode 1 = without the k smallest weights (order
     kept), mode 2 = everybody followed by the k largest (largest first); ties to the smaller index."""

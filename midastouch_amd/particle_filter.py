@@ -195,7 +195,7 @@ class particle_filter:
         """DBSCAN labels of the particles, min_samples = N / 5 (:208-228).  "euclidean" (what the loop uses, filter.py:183)
         runs on the device (midas_dbscan: exact float64 predicate on a uniform grid, clusters numbered by their first core
         point like sklearn's scan) - the reference's host call takes seconds to minutes at 100k particles; "logmap" clusters
-        the 6-d SE(3) logarithms on the host through sklearn like the reference."""
+        the 6-d SE(3) logarithms on the device too (midas_dbscan_points: all pairs, the same predicate and numbering)."""
         particles = copy.copy(_particles)
         if method == "euclidean":
             labels, info = ops.dbscan(particles.poses, eps)
@@ -212,13 +212,14 @@ class particle_filter:
             return particles
         if method != "logmap":
             raise ValueError(method)
-        from sklearn.cluster import DBSCAN
-
         from .pose import se3_log
 
-        data = se3_log(particles.poses).cpu().numpy()  # [V^-1 t, omega], the embedding th.SE3.log_map gives (:219-220)
-        clustering = DBSCAN(eps=eps, min_samples=int(len(particles) / 5)).fit(data)
-        particles.labels = torch.tensor(clustering.labels_, device=particles.labels.device)
+        data = se3_log(particles.poses)  # [V^-1 t, omega], the embedding th.SE3.log_map gives (:219-220)
+        # six dimensions: all pairs on the device (midas_dbscan_points, csrc/dbscan_nd.hip), sklearn's labels
+        labels, info = ops.dbscan_points(data, eps, int(len(particles) / 5))
+        if int(info[1].item()) < 0:
+            raise ops.MidasError("cluster_particles(logmap): the cluster spread did not settle")
+        particles.labels = labels.to(torch.int64).to(particles.labels.device)
         return particles
 
     def get_cluster_centers(self, _particles: Particles, method: str = "logmap") -> Tuple[torch.Tensor, torch.Tensor]:

@@ -73,6 +73,77 @@ def test_dbscan_matches_oracle(dev, oracle, case):
     assert np.array_equal(lab.cpu().numpy(), ref), case
 
 
+@pytest.mark.parametrize("case", ["blobs6", "chain6", "noise6", "border6", "three3", "single"])
+def test_dbscan_points_matches_sklearn(dev, case):
+    """midas_dbscan_points (cluster_particles(method="logmap"): six dimensions, all pairs) against sklearn's DBSCAN on the same
+    float64 points - labels equal element by element (same predicate, clusters numbered by their first core point, border
+    points to the smallest adjacent cluster); in three dimensions also against the grid kernel (midas_dbscan)."""
+    from sklearn.cluster import DBSCAN
+    from midastouch_amd import ops
+    rng = np.random.default_rng(len(case) * 7 + ord(case[0]))
+    eps, ms = 1e-2, -1
+    if case == "blobs6":
+        X = np.concatenate([rng.normal(c, 0.0025, (900, 6)) for c in (np.zeros(6), np.r_[0.05, 0, 0, 0.02, 0, 0], np.r_[0, 0.03, 0.03, 0, 0, 0.04])] +
+                           [rng.uniform(-0.05, 0.1, (500, 6))])
+        X = X[rng.permutation(len(X))]
+    elif case == "chain6":  # a long thin cluster: the spread needs many steps (pointer jumping shortens them)
+        t = rng.uniform(0, 0.6, 5000)
+        X = np.stack([t, 0.01 * np.sin(30 * t), 0.01 * np.cos(30 * t)] + [rng.normal(0, 0.0005, 5000) for _ in range(3)], axis=1)
+        ms = 40
+    elif case == "noise6":
+        X = rng.uniform(-1, 1, (2000, 6))
+    elif case == "border6":  # two dense cores a little more than eps apart with a sparse bridge: border points between two clusters
+        X = np.concatenate([rng.normal(0, 0.001, (800, 6)), rng.normal(0, 0.001, (800, 6)) + np.r_[0.032, 0, 0, 0, 0, 0],
+                            np.stack([rng.uniform(0.003, 0.029, 80)] + [rng.normal(0, 0.0005, 80) for _ in range(5)], axis=1)])
+        X = X[rng.permutation(len(X))]
+        ms = 300
+    elif case == "three3":
+        X = np.concatenate([rng.normal(c, 0.003, (700, 3)) for c in ([0, 0, 0], [0.04, 0, 0], [0, 0.05, 0.01])] + [rng.uniform(-0.03, 0.08, (400, 3))])
+        X = X.astype(np.float32).astype(np.float64)  # float32-valued: the grid kernel takes float32 translations
+        ms = 120
+    else:
+        X = np.zeros((1, 6))
+    n_min = max(len(X) // 5, 1) if ms < 0 else ms
+    ref = DBSCAN(eps=eps, min_samples=n_min).fit(X).labels_
+    lab, info = ops.dbscan_points(torch.as_tensor(X).to(dev), eps, n_min)
+    assert np.array_equal(lab.cpu().numpy(), ref), case
+    assert int(info[0].item()) == int(ref.max()) + 1 and int(info[1].item()) >= 1
+    if case == "border6":
+        assert (ref == -1).sum() < 80 and len(np.unique(ref[ref >= 0])) == 2   # the case holds what it is meant to
+    if case == "chain6":
+        assert int(info[1].item()) > 2
+    if X.shape[1] == 3:
+        lab3, _ = ops.dbscan(_poses_of(X.astype(np.float32), dev), eps, ms)
+        assert np.array_equal(lab3.cpu().numpy(), ref)
+
+
+def test_cluster_particles_logmap_on_device(dev):
+    """particle_filter.cluster_particles(method="logmap") (modules/particle_filter.py:218-223) against sklearn on the same SE(3)
+    logarithms: two pose clusters that differ in ROTATION only (the translations alone would be one cluster) and outliers."""
+    from scipy.spatial.transform import Rotation
+    from sklearn.cluster import DBSCAN
+    from midastouch_amd.particle_filter import Particles, particle_filter
+    from midastouch_amd.pose import se3_log
+    rng = np.random.default_rng(3)
+    N = 3000
+    P = np.tile(np.eye(4, dtype=np.float32), (N, 1, 1))
+    grp = rng.integers(0, 3, N)
+    base = np.array([[0.0, 0.0, 0.0], [0.0, 0.0, 0.05], [0.4, -0.3, 0.2]])
+    rv = base[grp] + rng.normal(0, 0.002, (N, 3))
+    rv[grp == 2] = rng.uniform(-1, 1, ((grp == 2).sum(), 3))
+    P[:, :3, :3] = Rotation.from_rotvec(rv).as_matrix().astype(np.float32)
+    P[:, :3, 3] = rng.normal(0, 0.002, (N, 3)).astype(np.float32)
+    poses = torch.as_tensor(P).to(dev)
+    pf = particle_filter.__new__(particle_filter)
+    parts = Particles(poses, torch.ones(N, device=dev), torch.zeros(N, dtype=torch.long, device=dev))
+    out = particle_filter.cluster_particles(pf, parts, method="logmap", eps=1e-2)
+    ref = DBSCAN(eps=1e-2, min_samples=N // 5).fit(se3_log(poses).cpu().numpy()).labels_
+    assert np.array_equal(out.labels.cpu().numpy(), ref)
+    assert len(np.unique(ref[ref >= 0])) == 2 and (ref == -1).sum() > 500
+    eu = particle_filter.cluster_particles(pf, parts, method="euclidean", eps=1e-2)
+    assert len(torch.unique(eu.labels)) == 1   # by translation the same particles are one cluster
+
+
 # ---- annealing selection ----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("small", [0, 1])
 @pytest.mark.parametrize("n", [5, 100, 1024, 1025, 4096, 4097, 10000, 16384, 100000])

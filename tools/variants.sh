@@ -9,7 +9,7 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hid
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   ( objs=""
-    for f in score particles resample cluster topn selfsim loop dbscan index_build mt19937 comm api; do
+    for f in score particles resample cluster topn selfsim loop dbscan dbscan_nd index_build mt19937 comm api; do
       /opt/rocm/bin/hipcc $F $flags -c $f.hip -o build/variants/$name.$f.o || exit 1
       objs="$objs build/variants/$name.$f.o"
     done
