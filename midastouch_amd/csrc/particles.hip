@@ -2475,6 +2475,11 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
             return MIDAS_OK;
         }
     }
+    // the vertex-list prefetch (PREF) also in the form without folded resample: eager engine 58.8 -> 55.3 us per frame at c2; not
+    // where the particles come from a shard's inbox (57.4 - 58.0 us either way: the row's registers are in use there).
+    // MIDAS_PREF_PLAIN=0: off
+    static const bool pref_env = !(getenv("MIDAS_PREF_PLAIN") && getenv("MIDAS_PREF_PLAIN")[0] == '0');
+    const bool pref_plain = pref_env && !a.inbox.rows;
 #define MIDAS_FRONT_L(NJ, LZ, FW)                                                                                     \
     hipLaunchKernelGGL((k_frame_front<float, NJ, LZ, FW>), dim3(grid_fw), dim3(64 * FW), 0, ctx->stream,               \
                        view_of<Kd6>(t6), view_of<Kd3>(t3), a, n_pu_fw, nwaves, emb, cb->norms, code, scores, cb->K)
@@ -2482,7 +2487,11 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
     if (a.batch > 1)                                                                                                  \
         hipLaunchKernelGGL((k_frame_front<float, NJ, 2, 1, false>), dim3(grid_fw, (unsigned)a.batch), dim3(64), 0, ctx->stream, \
                            view_of<Kd6>(t6), view_of<Kd3>(t3), a, n_pu_fw, nwaves, emb, cb->norms, code, scores, cb->K);  \
-    else if (!a.rs.enabled) { if (fw == 1) MIDAS_FRONT_L(NJ, 0, 1); else MIDAS_FRONT_L(NJ, 0, 4); }                   \
+    else if (!a.rs.enabled) {                                                                                         \
+        if (fw == 1 && a.N <= 131072 && pref_plain)                                                                   \
+            hipLaunchKernelGGL((k_frame_front<float, NJ, 0, 1, true, true>), dim3(grid_fw), dim3(64), 0, ctx->stream,   \
+                               view_of<Kd6>(t6), view_of<Kd3>(t3), a, n_pu_fw, nwaves, emb, cb->norms, code, scores, cb->K); \
+        else if (fw == 1) MIDAS_FRONT_L(NJ, 0, 1); else MIDAS_FRONT_L(NJ, 0, 4); }                                    \
     else if (!wave_tables) MIDAS_FRONT_L(NJ, 1, 4);                                                                   \
     else if (fw == 1 && a.N <= 131072)                                                                                \
         hipLaunchKernelGGL((k_frame_front<float, NJ, 2, 1, true, true>), dim3(grid_fw), dim3(64), 0, ctx->stream,     \
