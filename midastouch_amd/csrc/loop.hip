@@ -638,6 +638,8 @@ __global__ __launch_bounds__(1024) void k_loop_anneal_small(int32_t* __restrict_
     __shared__ int s_w[40];
     __shared__ uint64_t s_key[LOOP_SMALL_PAIRS];
     __shared__ int32_t s_idx[LOOP_SMALL_PAIRS];
+    __shared__ uint64_t s_small[64];
+    __shared__ uint64_t s_T[1];
     const int t = threadIdx.x;
     if (t == 0) {
         int mode = ctl_i[LOOP_I_MODE], k = ctl_i[LOOP_I_K];  // !DECIDE: a plan made by the host (midas_anneal_select)
@@ -682,11 +684,40 @@ __global__ __launch_bounds__(1024) void k_loop_anneal_small(int32_t* __restrict_
             const bool first = krem <= e0 + c0;
             s_w[32] = 2 * t + (first ? 0 : 1);
             s_w[33] = krem - e0 - (first ? 0 : c0);
+            s_w[34] = first ? c0 : c1;  // keys in the chosen bin
+            s_w[35] = 0;                // (counter of the short finish below)
         }
         __syncthreads();
         prefix = (prefix << width) | (uint64_t)s_w[32];
         krem = s_w[33];
+        const int in_bin = s_w[34];
         __syncthreads();
+        // Short finish: distinct weights leave a handful of keys in the bin after two or three digits (sign + exponent, then
+        // 11 mantissa bits at a time) - the remaining passes would each cost a histogram, a scan and five barriers to tell one
+        // key from none.  With at most 64 keys left, one wave ranks them: T = the key with #{< T} < krem <= #{<= T}.
+        if (in_bin <= 64 && p + 1 < SEL_PASSES) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j < mine_n && (key[j] >> shift) == prefix) s_small[atomicAdd(&s_w[35], 1)] = key[j];
+            __syncthreads();
+            if (t < 64) {
+                const uint64_t mk = t < in_bin ? s_small[t] : ~0ull;
+                int lt = 0, le = 0;
+                for (int m = 0; m < in_bin; ++m) {
+                    const uint64_t o = s_small[m];
+                    lt += o < mk ? 1 : 0;
+                    le += o <= mk ? 1 : 0;
+                }
+                if (t < in_bin && lt < krem && krem <= le) {  // every lane that holds T writes the same two values
+                    s_T[0] = mk;
+                    s_w[33] = krem - lt;
+                }
+            }
+            __syncthreads();
+            prefix = s_T[0];
+            krem = s_w[33];
+            break;
+        }
     }
     const uint64_t T = prefix;
     const int r = krem;
