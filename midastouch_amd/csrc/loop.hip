@@ -633,7 +633,17 @@ __global__ __launch_bounds__(1024) void k_loop_anneal_small(int32_t* __restrict_
                                                             float* __restrict__ stds_out, int32_t floor_n,
                                                             const double* __restrict__ w, int32_t* __restrict__ src,
                                                             const double* __restrict__ rot) {
-    if (DECIDE && blockIdx.x == 1) { loop_rotations(ctl_i, counts_all, rot, centers_out); return; }
+#ifdef MIDAS_ANNEAL_CLOCKS
+    const long long ck0 = wall_clock64();
+#define ACK(i) do { if (threadIdx.x == 0) ctl_d[56 + (i)] += (double)(wall_clock64() - ck0); } while (0)
+#define ctl_d_dbg(d, k) do { (d)[56 + 6] += 1.0; (d)[56 + 8] += (double)(k); } while (0)
+#define ctl_d_pass(d) do { (d)[56 + 15] += 1.0; } while (0)
+#else
+#define ctl_d_pass(d) do { } while (0)
+#define ACK(i) do { } while (0)
+#define ctl_d_dbg(d, k) do { } while (0)
+#endif
+    if (DECIDE && blockIdx.x == 1) { loop_rotations(ctl_i, counts_all, rot, centers_out); ACK(7); return; }
     __shared__ uint32_t s_h[SEL_BINS];
     __shared__ int s_w[40];
     __shared__ uint64_t s_key[LOOP_SMALL_PAIRS];
@@ -646,9 +656,10 @@ __global__ __launch_bounds__(1024) void k_loop_anneal_small(int32_t* __restrict_
         if (DECIDE) loop_decide(ctl_i, ctl_d, centers_all, stds_all, counts_all, centers_out, stds_out, floor_n, mode, k);
         const int n0 = ctl_i[LOOP_I_N];
         if (n0 > LOOP_SMALL_MAX) { ctl_i[LOOP_I_ERR] |= 4; mode = 0; }  // the caller's bound was wrong: no annealing, flagged
-        s_w[36] = mode; s_w[37] = k; s_w[38] = n0;
+        s_w[36] = mode; s_w[37] = k; s_w[38] = n0; s_w[39] = 0;
     }
     __syncthreads();
+    ACK(0);
     const int mode = s_w[36], k = s_w[37], n = s_w[38];
     if (!mode) {
         if (n > LOOP_SMALL_MAX && t == 0) { ctl_i[LOOP_I_MODE] = 0; ctl_i[LOOP_I_K] = 0; ctl_i[LOOP_I_NSET] = n; }
@@ -663,23 +674,67 @@ __global__ __launch_bounds__(1024) void k_loop_anneal_small(int32_t* __restrict_
         key[j] = select_key(w, i < n ? i : n - 1, mode);
     }
     const int mine_n = n - base < 0 ? 0 : n - base > 16 ? 16 : n - base;  // how many of them exist
+    ACK(1);
     // ---- radix select: the k-th smallest key T and how many of its equals to take (r)
-    uint64_t prefix = 0;
+    // The digits start at the highest bit in which the keys DIFFER (weights of one frame share sign and exponent, often the
+    // leading mantissa bits too): with the fixed windows of the large-set kernels the first pass put all 16 k keys into one bin -
+    // 16 k same-address LDS atomics one after the other, 15 - 24 us of this kernel's 30 - 50 (phase clocks, tools/anneal_clocks.py).
+    uint64_t kmin = ~0ull, kmax = 0ull;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (j < mine_n) { kmin = key[j] < kmin ? key[j] : kmin; kmax = key[j] > kmax ? key[j] : kmax; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t a = (uint64_t)__shfl_xor((long long)kmin, o), c = (uint64_t)__shfl_xor((long long)kmax, o);
+        kmin = a < kmin ? a : kmin;
+        kmax = c > kmax ? c : kmax;
+    }
+    if ((t & 63) == 0) { s_small[t >> 6] = kmin; s_small[16 + (t >> 6)] = kmax; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        kmin = s_small[w] < kmin ? s_small[w] : kmin;
+        kmax = s_small[16 + w] > kmax ? s_small[16 + w] : kmax;
+    }
+    __syncthreads();  // (s_small is used again below)
+    // Enough copies of the smallest key?  (The pruned particles' zeros when particles are dropped, the ~80 particles on the
+    // best-scoring entry when the best are duplicated: k is a per cent or two of the set.)  Then T is that key: no pass at all.
+    {
+        int eq = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) eq += (j < mine_n && key[j] == kmin) ? 1 : 0;
+        eq = lw_isum(eq);
+        if ((t & 63) == 0 && eq) atomicAdd(&s_w[39], eq);
+        __syncthreads();
+    }
+    const bool at_min = s_w[39] >= k;
+    ACK(9);
+    int top = (kmin == kmax || at_min) ? 0 : 64 - __builtin_clzll(kmin ^ kmax);  // bits [top, 64) are common to every key
+#ifdef MIDAS_ANNEAL_CLOCKS
+    long long ckl = wall_clock64();
+#define ACKD(i) do { if (threadIdx.x == 0) { const long long nw = wall_clock64(); ctl_d[56 + (i)] += (double)(nw - ckl); ckl = nw; } } while (0)
+#else
+#define ACKD(i) do { } while (0)
+#endif
+    uint64_t prefix = top >= 64 ? 0ull : (kmin >> top);  // (top == 0: T = kmin, r = k)
     int krem = k;
 #pragma unroll 1
-    for (int p = 0; p < SEL_PASSES; ++p) {
+    while (top > 0) {
+        const int width = top < 11 ? top : 11, shift = top - width;
         s_h[t] = 0u; s_h[t + 1024] = 0u;
         __syncthreads();
-        const int shift = kSelShift[p], width = kSelWidth[p];
+        ACKD(10);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const bool match = p == 0 || (key[j] >> (shift + width)) == prefix;
+            const bool match = top >= 64 || (key[j] >> top) == prefix;
             if (j < mine_n && match) atomicAdd(&s_h[(uint32_t)(key[j] >> shift) & ((1u << width) - 1u)], 1u);
         }
         __syncthreads();
+        ACKD(11);
         const int c0 = (int)s_h[2 * t], c1 = (int)s_h[2 * t + 1];
         int e0, e1, t0, t1;
         small_scan2(c0 + c1, 0, e0, e1, t0, t1, s_w);
+        ACKD(12);
         if (krem > e0 && krem <= e0 + c0 + c1) {  // exactly one thread
             const bool first = krem <= e0 + c0;
             s_w[32] = 2 * t + (first ? 0 : 1);
@@ -692,13 +747,38 @@ __global__ __launch_bounds__(1024) void k_loop_anneal_small(int32_t* __restrict_
         krem = s_w[33];
         const int in_bin = s_w[34];
         __syncthreads();
-        // Short finish: distinct weights leave a handful of keys in the bin after two or three digits (sign + exponent, then
-        // 11 mantissa bits at a time) - the remaining passes would each cost a histogram, a scan and five barriers to tell one
-        // key from none.  With at most 64 keys left, one wave ranks them: T = the key with #{< T} < krem <= #{<= T}.
-        if (in_bin <= 64 && p + 1 < SEL_PASSES) {
+        ACKD(13);
+        if (threadIdx.x == 0) ctl_d_pass(ctl_d);
+        top = shift;
+        // One value left?  Particles that share a nearest entry share its score and so their weight: a frame's 10^4 keys are
+        // ~100 distinct values (and the pruned particles' zeros), the chosen bin usually holds ONE of them, many times - the
+        // remaining digits would each be a pass of same-address atomics to learn nothing.  Somebody's key of the bin is the
+        // candidate; if every key of the bin equals it, it is T.
+        if (top > 0 && in_bin > 1) {
 #pragma unroll
             for (int j = 0; j < 16; ++j)
-                if (j < mine_n && (key[j] >> shift) == prefix) s_small[atomicAdd(&s_w[35], 1)] = key[j];
+                if (j < mine_n && (key[j] >> top) == prefix) s_T[0] = key[j];
+            __syncthreads();
+            const uint64_t cand = s_T[0];
+            int eq = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) eq += (j < mine_n && key[j] == cand) ? 1 : 0;
+            eq = lw_isum(eq);
+            if ((t & 63) == 0 && eq) atomicAdd(&s_w[35], eq);
+            __syncthreads();
+            const bool single = s_w[35] == in_bin;
+            __syncthreads();
+            if (t == 0) s_w[35] = 0;
+            if (single) { prefix = cand; ACKD(14); break; }  // krem of them are taken, in index order
+            __syncthreads();
+        }
+        // Short finish: distinct weights leave a handful of keys in the bin after one or two digits - further passes would each
+        // cost a histogram, a scan and five barriers to tell one key from none.  With at most 64 keys left, one wave ranks
+        // them: T = the key with #{< T} < krem <= #{<= T}.
+        if (in_bin <= 64 && top > 0) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j < mine_n && (key[j] >> top) == prefix) s_small[atomicAdd(&s_w[35], 1)] = key[j];
             __syncthreads();
             if (t < 64) {
                 const uint64_t mk = t < in_bin ? s_small[t] : ~0ull;
@@ -716,11 +796,13 @@ __global__ __launch_bounds__(1024) void k_loop_anneal_small(int32_t* __restrict_
             __syncthreads();
             prefix = s_T[0];
             krem = s_w[33];
+            ACKD(14);
             break;
         }
     }
     const uint64_t T = prefix;
     const int r = krem;
+    ACK(2);
     // ---- compaction in index order
     unsigned lbits = 0, ebits = 0;
 #pragma unroll
@@ -747,8 +829,27 @@ __global__ __launch_bounds__(1024) void k_loop_anneal_small(int32_t* __restrict_
             eb += ise ? 1 : 0;
         }
     }
+    ACK(3);
     if (mode != 2) return;
-    // ---- the k duplicates in topk's order: (key, index) ascending, bitonic network over the next power of two
+    // ---- the k duplicates in topk's order: (key, index) ascending
+    if (k <= 256) {
+        // few duplicates (the usual case: the variance ratio moves by a per cent or two per frame): every pair counts the pairs
+        // before it - one barrier pair instead of the network's log^2 stages of a 16-wave barrier each
+        __syncthreads();
+        uint64_t mk = 0;
+        int32_t mi = 0;
+        int rank = 0;
+        if (t < k) {
+            mk = s_key[t]; mi = s_idx[t];
+            for (int m = 0; m < k; ++m) rank += pair_less(s_key[m], s_idx[m], mk, mi) ? 1 : 0;
+        }
+        ACK(4);
+        if (t < k) src[n + rank] = mi;
+        ACK(5);
+        if (threadIdx.x == 0) { ctl_d_dbg(ctl_d, k); }
+        return;
+    }
+    // larger sets: bitonic network over the next power of two
     int P = 2;
     while (P < k) P <<= 1;
     __syncthreads();
@@ -767,7 +868,10 @@ __global__ __launch_bounds__(1024) void k_loop_anneal_small(int32_t* __restrict_
             __syncthreads();
         }
     }
+    ACK(4);
     for (int q = t; q < k; q += 1024) src[n + q] = s_idx[q];
+    ACK(5);
+    if (threadIdx.x == 0) { ctl_d_dbg(ctl_d, k); }
 }
 
 // ---- RESAMPLE -------------------------------------------------------------------------------------------------------
