@@ -1281,6 +1281,7 @@ MIDAS_EXPORT int midas_selfsim_topn(midas_ctx* ctx, const midas_codebook* cb, in
 
 #ifdef MIDAS_DEBUG_CLOCKS
 MIDAS_EXPORT int midas_debug_tb2_clocks(long long* out16) { return midas::debug_tb2_clocks(out16); }
+MIDAS_EXPORT int midas_debug_ta_clocks(long long* out16) { return midas::debug_ta_clocks(out16); }
 #endif
 
 // ---- profiling -----------------------------------------------------------------------------------

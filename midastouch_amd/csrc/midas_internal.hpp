@@ -359,6 +359,7 @@ int launch_peer_flag_write(midas_ctx* ctx, void* const* peers, int G, int rank, 
 int launch_shard_unpack_peer_wait(midas_ctx* ctx, int64_t N, const void* inbox, int32_t* ridx, float* poses_out, double* weights_out,
                                   int32_t* hint_out, int G, int64_t flag_off, uint64_t tag, int32_t* status, void* const* peers, int rank);
 int debug_tb2_clocks(long long* out16);
+int debug_ta_clocks(long long* out16);
 int launch_tail_a(midas_ctx* ctx, int64_t N, const double* x, const uint8_t* valid, int np, int pstride,
                   const double* pmax_all, const double* pmin_all, int32_t softmax, double* e_io, double* lp_out,
                   double* block_sums_e, double* block_totals_em, double* flags_out, int32_t* flag, int32_t* status,

@@ -275,4 +275,55 @@ MD void se3_feature(const float* P, float wt, float wr, float* f) {
     f[5] = wr * w[2];
 }
 
+// ---- wave-wide maximum / minimum / integer sum by DPP moves (no LDS round trips) ----------------------------------------------
+// quad permutes (lane^1, lane^2), row_half_mirror, row_mirror: every lane of a 16-lane row holds the row's result; row_bcast15
+// and row_bcast31 carry it up the rows; lane 63 holds the wave's, read back for everybody.  Order-insensitive operations only
+// (floating-point SUMS keep their shuffle butterflies: their order is part of the arithmetic spec).  A `__shfl_xor` butterfly of a
+// double is twelve dependent LDS-crossbar trips - 1.4 us of the tail kernel's 7.9 per workgroup.
+template <int CTRL, int ROW_MASK = 0xf>
+MD uint32_t dpp_move(uint32_t own, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)own, (int)v, CTRL, ROW_MASK, 0xf, false); }
+template <int CTRL, int ROW_MASK = 0xf>
+MD double dpp_move(double v) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = dpp_move<CTRL, ROW_MASK>((uint32_t)b, (uint32_t)b), hi = dpp_move<CTRL, ROW_MASK>((uint32_t)(b >> 32), (uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+// lane J of the own 16-lane row, to every lane of the row (row_newbcast)
+template <int J>
+MD double row_bcast(double v) { return dpp_move<0x150 + J>(v); }
+MD double wave_bcast63(double v) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), 63);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+#define MIDAS_DPP_REDUCE(v, OP)                                                        \
+    { auto t_ = dpp_move<0xB1>(v); v = OP(v, t_); }   /* lane ^ 1 */                    \
+    { auto t_ = dpp_move<0x4E>(v); v = OP(v, t_); }   /* lane ^ 2 */                    \
+    { auto t_ = dpp_move<0x141>(v); v = OP(v, t_); }  /* 7 - lane within the octet */   \
+    { auto t_ = dpp_move<0x140>(v); v = OP(v, t_); }  /* 15 - lane within the row */    \
+    { auto t_ = dpp_move<0x142, 0xa>(v); v = OP(v, t_); }  /* lane 15 of the row below, rows 1 and 3 */ \
+    { auto t_ = dpp_move<0x143, 0xc>(v); v = OP(v, t_); }  /* lane 31, rows 2 and 3 */
+MD double dpp_max_(double a, double b) { return b > a ? b : a; }
+MD double dpp_min_(double a, double b) { return b < a ? b : a; }
+MD double wave_max_dpp(double v) {  // NaN never wins a comparison (as in the shuffle form): callers flag NaN separately
+    MIDAS_DPP_REDUCE(v, dpp_max_)
+    return wave_bcast63(v);
+}
+MD double wave_min_dpp(double v) {
+    MIDAS_DPP_REDUCE(v, dpp_min_)
+    return wave_bcast63(v);
+}
+MD int wave_isum_dpp(int v) {
+    // (a sum is not idempotent: the mirrors add the OTHER half's total to lanes that all hold their own half's - still every
+    // element once; the row broadcasts add whole rows)
+    uint32_t u = (uint32_t)v;
+    u += dpp_move<0xB1>(u, u);
+    u += dpp_move<0x4E>(u, u);
+    u += dpp_move<0x141>(u, u);
+    u += dpp_move<0x140>(u, u);
+    u += dpp_move<0x142, 0xa>(0u, u);
+    u += dpp_move<0x143, 0xc>(0u, u);
+    return (int)(uint32_t)__builtin_amdgcn_readlane((int)u, 63);
+}
+
 }  // namespace midas

@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void k_tail_a2d(int64_t N, const double* __res
                                                   const double* __restrict__ part_rmse, int nrm, double* __restrict__ rmse_out,
                                                   int64_t score_stride = 0, int64_t tstride = 0, int nb_tail = 0x7fffffff,
                                                   ScorePredict pr = ScorePredict(), bool rmse_raw = false) {
-    __shared__ double s_gtot[16];
+    __shared__ double s_gtot[32];
     __shared__ double s_red[24];
     if ((int)blockIdx.x >= nb_tail) {  // (single trajectory only: the launcher adds these workgroups when pr.stamps is set)
         predict_scan(pr, (int)blockIdx.x - nb_tail);
@@ -881,6 +881,7 @@ __global__ __launch_bounds__(256) void k_tail_b(TailBArgs a) {
 constexpr int TB2_TAB = 8192;
 #ifdef MIDAS_DEBUG_CLOCKS  // phase clocks of one workgroup (tools/variants.sh dbg "-DMIDAS_DEBUG_CLOCKS"; tools/tb2_clocks.py)
 __device__ long long g_tb2_clk[16];
+__device__ long long g_ta_clk[16];
 #define TB2_CLK(k) if (blockIdx.x == 97 && threadIdx.x == 64) g_tb2_clk[k] = clock64();
 #define TB2_WALL(k) if (threadIdx.x == 64) { if (blockIdx.x == 0) g_tb2_clk[8 + k] = wall_clock64(); if (blockIdx.x == 195) g_tb2_clk[10 + k] = wall_clock64(); if (blockIdx.x == 390) g_tb2_clk[12 + k] = wall_clock64(); }
 #else
@@ -1776,6 +1777,7 @@ int launch_tail_resample(midas_ctx* ctx, const midas_tail_resample_args& r) {
 
 #ifdef MIDAS_DEBUG_CLOCKS
 int debug_tb2_clocks(long long* out16) { return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_tb2_clk), 16 * sizeof(long long)) == hipSuccess ? 0 : 1; }
+int debug_ta_clocks(long long* out16) { return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ta_clk), 16 * sizeof(long long)) == hipSuccess ? 0 : 1; }
 #endif
 
 int launch_tail_a2(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,

@@ -9,7 +9,13 @@ namespace midas {
 #ifndef MIDAS_TAIL_EXP_ILP
 #define MIDAS_TAIL_EXP_ILP 1
 #endif
-constexpr double TAIL_ISCLOSE_ATOL = 1e-8;  // torch.isclose default atol (particle_filter.py:460-463)
+constexpr double TAIL_ISCLOSE_ATOL = 1e-8;
+#ifdef MIDAS_DEBUG_CLOCKS  // phase clocks of one k_tail_a2d workgroup (tools/variants.sh dbg "-DMIDAS_DEBUG_CLOCKS"; tools/ta_clocks.py)
+extern __device__ long long g_ta_clk[16];
+#define TA_CLK(k) do { if (blk == 12 && threadIdx.x == 0) g_ta_clk[k] = clock64(); if (threadIdx.x == 0 && (k) == 0 && blk == 0) g_ta_clk[8] = wall_clock64(); if (threadIdx.x == 0 && (k) == 7 && blk == 0) g_ta_clk[9] = wall_clock64(); if (threadIdx.x == 0 && (k) == 0 && blk == 24) g_ta_clk[10] = wall_clock64(); if (threadIdx.x == 0 && (k) == 7 && blk == 24) g_ta_clk[11] = wall_clock64(); } while (0)
+#else
+#define TA_CLK(k) do { } while (0)
+#endif  // torch.isclose default atol (particle_filter.py:460-463)
 
 // Block-local part of the spec scan.  v[16] = this lane's chunk (absent values = +0.0).
 // l[j] = GP_g + (TP_c + local_j) (l may be v itself); returns the block total W (identical in every thread).
@@ -20,14 +26,13 @@ MD double block_scan(const double* v, double* l, double* s_gtot) {
 #pragma unroll
     for (int j = 0; j < SCAN_CHUNK; ++j) { run = run + v[j]; l[j] = run; }
     const double T = run;
-    const int lane = threadIdx.x & 63, c = threadIdx.x & 15, gbase = lane & ~15;
+    const int c = threadIdx.x & 15;
     double TP = 0.0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const double t = __shfl(T, gbase + j);
-        if (j < c) TP = TP + t;
-        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four exchanges in flight, not sixteen (registers)
-    }
+    // chunk totals of the own 16-lane row, lane by lane (DPP row broadcasts; `__shfl` was an LDS-crossbar trip each), added in order
+#define MIDAS_TP_STEP(J) { const double t_ = row_bcast<J>(T); if (J < c) TP = TP + t_; }
+    MIDAS_TP_STEP(0) MIDAS_TP_STEP(1) MIDAS_TP_STEP(2) MIDAS_TP_STEP(3) MIDAS_TP_STEP(4) MIDAS_TP_STEP(5) MIDAS_TP_STEP(6) MIDAS_TP_STEP(7)
+    MIDAS_TP_STEP(8) MIDAS_TP_STEP(9) MIDAS_TP_STEP(10) MIDAS_TP_STEP(11) MIDAS_TP_STEP(12) MIDAS_TP_STEP(13) MIDAS_TP_STEP(14) MIDAS_TP_STEP(15)
+#undef MIDAS_TP_STEP
     if (c == 15) s_gtot[threadIdx.x >> 4] = TP + T;
     __syncthreads();
     const int g = threadIdx.x >> 4;
@@ -50,14 +55,13 @@ MD double block_total(const double* v, double* s_gtot) {
     double T = 0.0;
 #pragma unroll
     for (int j = 0; j < SCAN_CHUNK; ++j) T = T + v[j];
-    const int lane = threadIdx.x & 63, c = threadIdx.x & 15, gbase = lane & ~15;
+    const int c = threadIdx.x & 15;
     double TP = 0.0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const double t = __shfl(T, gbase + j);
-        if (j < c) TP = TP + t;
-        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four exchanges in flight, not sixteen (registers)
-    }
+    // chunk totals of the own 16-lane row, lane by lane (DPP row broadcasts; `__shfl` was an LDS-crossbar trip each), added in order
+#define MIDAS_TP_STEP(J) { const double t_ = row_bcast<J>(T); if (J < c) TP = TP + t_; }
+    MIDAS_TP_STEP(0) MIDAS_TP_STEP(1) MIDAS_TP_STEP(2) MIDAS_TP_STEP(3) MIDAS_TP_STEP(4) MIDAS_TP_STEP(5) MIDAS_TP_STEP(6) MIDAS_TP_STEP(7)
+    MIDAS_TP_STEP(8) MIDAS_TP_STEP(9) MIDAS_TP_STEP(10) MIDAS_TP_STEP(11) MIDAS_TP_STEP(12) MIDAS_TP_STEP(13) MIDAS_TP_STEP(14) MIDAS_TP_STEP(15)
+#undef MIDAS_TP_STEP
     if (c == 15) s_gtot[threadIdx.x >> 4] = TP + T;
     __syncthreads();
     double W = 0.0;
@@ -73,12 +77,13 @@ MD double block_total(const double* v, double* s_gtot) {
 // range is within the isclose tolerance (see k_tail_a2).  Outputs are identical to k_tail_a2's; the per-slot tables are
 // written in whole 16-value chunks (the layouts are padded to multiples of 16, values past N are never read).
 // padded: the per-slot tables hold a multiple of 16 values, so the chunk that straddles N is stored whole too.  Needs N >= 16.
-// s_gtot: 16 doubles, s_red: 24 doubles of LDS.  kept_out (every thread): valid slots of the block; nan_out: some masked
+// s_gtot: 32 doubles (two reductions in flight), s_red: 24 doubles of LDS.  kept_out (every thread): valid slots of the block; nan_out: some masked
 // weight of the block is NaN.
 MD void tail_a_direct(int64_t N, int blk, const double* __restrict__ scores, const int32_t* __restrict__ nn_idx,
                       const uint8_t* __restrict__ valid, int32_t softmax, const TailTables& tb, bool padded, double* s_gtot,
                       double* s_red, int& kept_out, bool& nan_out) {
     const int t = threadIdx.x;
+    TA_CLK(0);
     const int64_t bbase = (int64_t)blk * SCAN_BLOCK, base = bbase + (int64_t)t * SCAN_CHUNK;
     // Sixteen contiguous slots from ONE address (the loads share it and travel together; a clamped index per slot would
     // cost an address register pair each).  A chunk that would run past N starts at N - 16 instead and is shifted below.
@@ -100,6 +105,7 @@ MD void tail_a_direct(int64_t N, int blk, const double* __restrict__ scores, con
             okbits >>= 1;
         }
     }
+    TA_CLK(1);
     double v[SCAN_CHUNK];
 #pragma unroll
     for (int j = 0; j < SCAN_CHUNK; ++j) v[j] = scores[nn[j]];
@@ -113,33 +119,35 @@ MD void tail_a_direct(int64_t N, int blk, const double* __restrict__ scores, con
         mn = in && v[j] < mn ? v[j] : mn;
     }
     int kept = __popc(okbits);
+    TA_CLK(2);
     // block extrema (NaN propagates, as torch.max / torch.min do)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double a = __shfl_xor(mx, o), c = __shfl_xor(mn, o);
-        mx = a > mx ? a : mx;
-        mn = c < mn ? c : mn;
-        kept += __shfl_xor(kept, o);
-    }
+    mx = wave_max_dpp(mx);
+    mn = wave_min_dpp(mn);
+    kept = wave_isum_dpp(kept);
     const bool wxnan = __any(xnan);
     if ((t & 63) == 0) { s_red[t >> 6] = mx; s_red[4 + (t >> 6)] = mn; s_red[8 + (t >> 6)] = wxnan ? 1.0 : 0.0; s_red[12 + (t >> 6)] = (double)kept; }
-    __syncthreads();
-    mx = s_red[0]; mn = s_red[4];
-    double f = s_red[8], kd = s_red[12];
+    // (no barrier of its own: the four waves' extrema are read behind the barrier inside the first block_total - the decision
+    // they feed, softmax or raw scores, is only needed after the first variant; a barrier pair here was 1.6 us of the
+    // workgroup's 7.9, tools/ta_clocks.py)
+    bool close = false;
+    auto block_extrema = [&]() {
+        mx = s_red[0]; mn = s_red[4];
+        double f = s_red[8], kd = s_red[12];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
-        mx = s_red[w] > mx ? s_red[w] : mx;
-        mn = s_red[4 + w] < mn ? s_red[4 + w] : mn;
-        f += s_red[8 + w];
-        kd += s_red[12 + w];
-    }
-    kept_out = (int)kd;
-    if (f != 0.0) { mx = NAN; mn = NAN; }
-    if (t == 0) { tb.bmax[blk] = mx; tb.bmin[blk] = mn; }
-    const bool close = __builtin_fabs(mx - mn) <= TAIL_ISCLOSE_ATOL;  // false on NaN
-    const bool need_soft = softmax != 0, need_raw = !softmax || close;
+        for (int w = 1; w < 4; ++w) {
+            mx = s_red[w] > mx ? s_red[w] : mx;
+            mn = s_red[4 + w] < mn ? s_red[4 + w] : mn;
+            f += s_red[8 + w];
+            kd += s_red[12 + w];
+        }
+        kept_out = (int)kd;
+        if (f != 0.0) { mx = NAN; mn = NAN; }
+        if (t == 0) { tb.bmax[blk] = mx; tb.bmin[blk] = mn; }
+        close = __builtin_fabs(mx - mn) <= TAIL_ISCLOSE_ATOL;  // false on NaN
+    };
+    const bool need_soft = softmax != 0;
     bool nan = false;
-    __syncthreads();
+    TA_CLK(3);
     // the own chunk of a per-slot table, as eight 16-byte stores from one address (padded layout: see above)
     auto store_chunk = [&](double* __restrict__ out, const double* val) {
         if (base + SCAN_CHUNK <= N || (padded && base < N)) {
@@ -153,22 +161,23 @@ MD void tail_a_direct(int64_t N, int blk, const double* __restrict__ scores, con
         }
     };
     // one variant, in place: val[j] of the own chunk -> sums, prefix, tables (val is consumed)
+    bool extrema_read = false;
     auto variant = [&](double* val, double* __restrict__ lp_out, double* __restrict__ gend_out,
                        double* __restrict__ ggend_out, double& W_all, double& W_masked, bool& vnan) {
 #pragma unroll
         for (int j = 0; j < SCAN_CHUNK; ++j) val[j] = base + j < N ? val[j] : 0.0;
         W_all = block_total(val, s_gtot);
-        __syncthreads();
+        if (!extrema_read) { block_extrema(); extrema_read = true; }  // behind block_total's barrier
+        // (the scan's group totals go to the second half of s_gtot: no barrier between the two reductions)
 #pragma unroll
         for (int j = 0; j < SCAN_CHUNK; ++j) {
             val[j] = val[j] * ((okbits >> j) & 1u ? 1.0 : 0.0);  // okbits is clear on out-of-range slots
             vnan |= val[j] != val[j];
         }
-        W_masked = block_scan(val, val, s_gtot);
+        W_masked = block_scan(val, val, s_gtot + 16);
         if (base < N) gend_out[(bbase >> 4) + t] = val[SCAN_CHUNK - 1];              // block-local prefix at the chunk end
         if ((t & 15) == 15) ggend_out[(bbase >> 8) + (t >> 4)] = val[SCAN_CHUNK - 1];  // ... at the end of each 256-slot group
         store_chunk(lp_out, val);
-        __syncthreads();
     };
     double Wa = 0.0, Wm = 0.0;
     if (need_soft) {
@@ -179,12 +188,17 @@ MD void tail_a_direct(int64_t N, int blk, const double* __restrict__ scores, con
             // CU (one wave per SIMD) - nothing else hides the latency of the chain
             if (j % MIDAS_TAIL_EXP_ILP == MIDAS_TAIL_EXP_ILP - 1) __builtin_amdgcn_sched_barrier(0);
         }
+        TA_CLK(4);
         store_chunk(tb.e, v);
+        TA_CLK(5);
         variant(v, tb.lp, tb.gend, tb.ggend, Wa, Wm, nan);
+        TA_CLK(6);
         if (t == 0) { tb.bsum_e[blk] = Wa; tb.btot[blk] = Wm; }
     }
+    const bool need_raw = !softmax || close;  // (softmax off: `close` is not looked at - the raw variant below reads the extrema)
     if (need_raw) {  // rare (every particle of the block shares one score) or the softmax is off
         if (need_soft) {  // the scores were consumed in place: gather them again
+            __syncthreads();  // (both halves of s_gtot are free again before the second variant writes them)
 #pragma unroll
             for (int j = 0; j < SCAN_CHUNK; ++j) v[j] = scores[nn[j]];
         }
@@ -197,6 +211,7 @@ MD void tail_a_direct(int64_t N, int blk, const double* __restrict__ scores, con
         tb.btot_raw[blk] = 0.0;
     }
     nan_out = __syncthreads_or(nan ? 1 : 0) != 0;
+    TA_CLK(7);
 }
 
 }  // namespace midas
