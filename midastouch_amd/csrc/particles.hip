@@ -1575,12 +1575,8 @@ MD void lazy_tables(const LazyResample& rs, double* rs_lds) {
     const bool in = t < rs.nb;
     double mx = in ? bx : -INFINITY, mn = in ? bn : INFINITY;
     const bool nan = in && ((bx != bx) || (bn != bn));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double a = __shfl_xor(mx, o), c = __shfl_xor(mn, o);
-        mx = a > mx ? a : mx;
-        mn = c < mn ? c : mn;
-    }
+    mx = wave_max_dpp(mx);  // (DPP moves: midas_math.hpp)
+    mn = wave_min_dpp(mn);
     const bool wn = __any(nan);
     if ((t & 63) == 0) { s_ex[t >> 6] = mx; s_ex[4 + (t >> 6)] = mn; s_ex[8 + (t >> 6)] = wn ? 1.0 : 0.0; }
     __syncthreads();
@@ -1632,12 +1628,8 @@ MD void lazy_tables_wave(const LazyResample& rs, const LazyRecords& r, double* r
     const bool in = lane < rs.nb;
     double mx = in ? r.bx : -INFINITY, mn = in ? r.bn : INFINITY;
     const bool nan = in && ((r.bx != r.bx) || (r.bn != r.bn));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double a = __shfl_xor(mx, o), c = __shfl_xor(mn, o);
-        mx = a > mx ? a : mx;
-        mn = c < mn ? c : mn;
-    }
+    mx = wave_max_dpp(mx);  // (DPP moves: midas_math.hpp)
+    mn = wave_min_dpp(mn);
     if (__any(nan)) { mx = NAN; mn = NAN; }
     const bool apply = rs.softmax && !(__builtin_fabs(mx - mn) <= LAZY_ISCLOSE_ATOL);
     const double w = in ? (apply ? r.bt : r.btr) : 0.0;
