@@ -460,6 +460,7 @@ __global__ __launch_bounds__(256) void k_db_link(DbArgs a) {
         double mind2, maxd2;
         db_box_bounds(a, c2, me, mind2, maxd2);
         if (mind2 > a.r2) return false;  // nobody of that cell is within eps
+        if (maxd2 <= a.r2) { db_union(a.parent, orig, rep2); return false; }  // everybody is: so is its core point
         const int e = a.cell_start[c2 + 1];
         for (int q = a.cell_start[c2]; q < e; ++q)
             if (a.s_core[q] && db_within(me, a.s_pt[q], a.r2)) { db_union(a.parent, orig, rep2); break; }
@@ -514,24 +515,38 @@ __global__ __launch_bounds__(256) void k_db_number(DbArgs a) {
     }
 }
 
-// border points: the smallest cluster number among the core points within eps; noise otherwise
+// border points: the smallest cluster number among the core points within eps; noise otherwise.
+// One WAVE per point (the lanes share a cell's candidates, any hit ends the cell): a thread per point walked the partial cells
+// of a dense cloud's halo one point after the other - 4.5 ms of the frame-50 DBSCAN at N = 100 k even with the box tests.
 __global__ __launch_bounds__(256) void k_db_border(DbArgs a) {
     const DbGrid g = *a.grid;
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= g.n || a.s_core[p]) return;
-    const float4 me = a.s_pt[p];
-    const int c = __float_as_int(me.w);
-    int best = 0x7fffffff;
-    db_for_cells(g, c, true, [&](int c2) {
-        const int num = a.cell_num[c2];
-        if (num < 0 || num >= best) return false;
-        if (c2 == c) { best = num; return false; }  // a core point of the own cell is within eps
-        const int e = a.cell_start[c2 + 1];
-        for (int q = a.cell_start[c2]; q < e; ++q)
-            if (a.s_core[q] && db_within(me, a.s_pt[q], a.r2)) { best = num; break; }
-        return false;
-    });
-    a.labels[a.s_orig[p]] = best == 0x7fffffff ? -1 : best;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * 256) >> 6;
+    for (int64_t p = wave; p < g.n; p += nwaves) {
+        if (a.s_core[p]) continue;
+        const float4 me = a.s_pt[p];
+        const int c = __float_as_int(me.w);
+        int best = 0x7fffffff;
+        db_for_cells(g, c, true, [&](int c2) {
+            const int num = a.cell_num[c2];
+            if (num < 0 || num >= best) return false;
+            if (c2 == c) { best = num; return false; }  // a core point of the own cell is within eps
+            // the cell's tight box first: wholly beyond eps - nobody to look at (a halo point next to a dense cell scanned all
+            // of its points for nothing: 16 ms of a 17 ms DBSCAN at N = 100 k); wholly within eps - its core point is a hit
+            double mind2, maxd2;
+            db_box_bounds(a, c2, me, mind2, maxd2);
+            if (mind2 > a.r2) return false;
+            if (maxd2 <= a.r2) { best = num; return false; }
+            const int e = a.cell_start[c2 + 1], b0 = a.cell_start[c2];
+            for (int q0 = b0; q0 < e; q0 += 64) {
+                const int q = q0 + lane, qc = q < e ? q : e - 1;
+                const bool hit = q < e && a.s_core[qc] && db_within(me, a.s_pt[qc], a.r2);
+                if (__any(hit)) { best = num; break; }
+            }
+            return false;
+        });
+        if (lane == 0) a.labels[a.s_orig[p]] = best == 0x7fffffff ? -1 : best;
+    }
 }
 
 int launch_dbscan(midas_ctx* ctx, int64_t cap, const int32_t* n_dev, const float* poses, double eps, int64_t min_samples,
