@@ -153,28 +153,73 @@ __global__ __launch_bounds__(256) void k_loop_cluster_moments(const int32_t* __r
 MD void cluster_finish_body(int nblocks, int C, int c, const double* __restrict__ part, float* __restrict__ centers,
                             float* __restrict__ stds, int64_t* __restrict__ counts, double* s_m, double* __restrict__ rot_out = nullptr) {
     const int t = threadIdx.x;
-    if (t < CL_MOM) {
-        // blocks in order; FB partials are fetched together (independent loads: one round trip), then added one after the
-        // other (32 at a time: a small set's 40 blocks are two trips instead of five)
-        constexpr int FB = 32;
-        double r = part[(size_t)c * CL_MOM + t];
-        for (int b0 = 1; b0 < nblocks; b0 += FB) {
-            double x[FB];
+    // blocks in order (the sums' order is part of the arithmetic).  The partials of CB blocks are staged in LDS by all 64 threads
+    // (independent loads in flight together), then moment t walks them - at N = 100 k (391 blocks) the direct form was
+    // thirteen dependent trips by 36 threads: 66 us, the longest kernel of the loop frame
+    constexpr int CB = 128;
+    __shared__ double s_part[CB * CL_MOM];
+    double r = 0.0;
+    for (int b0 = 0; b0 < nblocks; b0 += CB) {
+        const int nb = nblocks - b0 < CB ? nblocks - b0 : CB;
+        // (eighteen loads in flight per thread before the first LDS store: left as one load and one store per iteration the
+        // compiler waits for each load in turn - 72 dependent trips, slower than the form this replaces)
+        constexpr int LB = 18;
+        const int NT = (int)blockDim.x;  // 64 (midas_cluster_centers) or 256 (loop step: a chunk is one batch of loads)
+        for (int i0 = t; i0 < nb * CL_MOM; i0 += NT * LB) {
+            double x[LB];
 #pragma unroll
-            for (int j = 0; j < FB; ++j) {
-                const int b = b0 + j < nblocks ? b0 + j : nblocks - 1;
-                x[j] = part[((size_t)b * C + c) * CL_MOM + t];
+            for (int j = 0; j < LB; ++j) {
+                const int i = i0 + NT * j, ic = i < nb * CL_MOM ? i : nb * CL_MOM - 1;
+                const int b = ic / CL_MOM, m = ic - b * CL_MOM;
+                x[j] = part[((size_t)(b0 + b) * C + c) * CL_MOM + m];
             }
 #pragma unroll
-            for (int j = 0; j < FB; ++j) {
-                if (b0 + j < nblocks) {
-                    if (t == M_WMAX) r = x[j] > r ? x[j] : r;
-                    else if (t == M_WMIN) r = x[j] < r ? x[j] : r;
-                    else r = r + x[j];
-                }
+            for (int j = 0; j < LB; ++j)
+                if (i0 + NT * j < nb * CL_MOM) s_part[i0 + NT * j] = x[j];
+        }
+        __syncthreads();
+        // sixteen LDS reads in flight, then the chain in block order.  The sums' chain is ONE dependent addition per block: the
+        // two extrema (selects in the chain) are walked by lanes of their own where the workgroup has a second wave; whole batches
+        // first, the remainder one by one (no guards in the chain).  With a read, a wait and three branches per block the walk was
+        // 60 of the kernel's 65 us at 391 blocks.
+        const bool two_waves = blockDim.x >= 128;
+        const bool sums = t < CL_MOM && !(two_waves && (t == M_WMAX || t == M_WMIN));
+        const bool ext = two_waves ? (t == 64 || t == 65) : (t == M_WMAX || t == M_WMIN);
+        const int m = ext && two_waves ? (t == 64 ? M_WMAX : M_WMIN) : t;
+        if (sums && !(ext && !two_waves)) {
+            int b1 = 0;
+            if (b0 == 0) { r = s_part[m]; b1 = 1; }
+            for (; b1 + 16 <= nb; b1 += 16) {
+                double x[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) x[j] = s_part[(b1 + j) * CL_MOM + m];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) r = r + x[j];
+            }
+            for (; b1 < nb; ++b1) r = r + s_part[b1 * CL_MOM + m];
+        }
+        if (ext) {
+            const bool is_max = m == M_WMAX;
+            int b1 = 0;
+            if (b0 == 0) { r = s_part[m]; b1 = 1; }
+            for (; b1 + 16 <= nb; b1 += 16) {
+                double x[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) x[j] = s_part[(b1 + j) * CL_MOM + m];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) r = is_max ? (x[j] > r ? x[j] : r) : (x[j] < r ? x[j] : r);
+            }
+            for (; b1 < nb; ++b1) {
+                const double x = s_part[b1 * CL_MOM + m];
+                r = is_max ? (x > r ? x : r) : (x < r ? x : r);
             }
         }
-        s_m[t] = r;
+        __syncthreads();
+    }
+    {
+        const bool two_waves = blockDim.x >= 128;
+        if (two_waves && (t == 64 || t == 65)) s_m[t == 64 ? M_WMAX : M_WMIN] = r;
+        else if (t < CL_MOM && !(two_waves && (t == M_WMAX || t == M_WMIN))) s_m[t] = r;
     }
     __syncthreads();
     if (t != 0) return;
@@ -219,7 +264,7 @@ __global__ __launch_bounds__(64) void k_cluster_finish(int nblocks, int C, const
 }
 
 // loop engine: cluster slot c = blockIdx.x of the LOOP_MAX_CLUSTERS launched; rows of label c - 1
-__global__ __launch_bounds__(64) void k_loop_cluster_finish(const int32_t* __restrict__ ctl_i, const double* __restrict__ part,
+__global__ __launch_bounds__(256) void k_loop_cluster_finish(const int32_t* __restrict__ ctl_i, const double* __restrict__ part,
                                                             float* __restrict__ centers, float* __restrict__ stds,
                                                             int64_t* __restrict__ counts, double* __restrict__ rot) {
     __shared__ double s_m[CL_MOM];
@@ -236,7 +281,7 @@ int launch_loop_cluster(midas_ctx* ctx, int64_t cap, const int32_t* ctl_i, const
                         const int32_t* labels, double* part, float* centers, float* stds, int64_t* counts, double* rot) {
     hipLaunchKernelGGL(k_loop_cluster_moments, dim3((unsigned)ceil_div(cap, 256)), dim3(256), 0, ctx->stream, ctl_i, poses, w64,
                        labels, part);
-    hipLaunchKernelGGL(k_loop_cluster_finish, dim3(LOOP_MAX_CLUSTERS), dim3(64), 0, ctx->stream, ctl_i, (const double*)part, centers,
+    hipLaunchKernelGGL(k_loop_cluster_finish, dim3(LOOP_MAX_CLUSTERS), dim3(256), 0, ctx->stream, ctl_i, (const double*)part, centers,
                        stds, counts, rot);
     MIDAS_HIP_CHECK(ctx, hipGetLastError());
     return MIDAS_OK;
