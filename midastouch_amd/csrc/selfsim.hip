@@ -28,7 +28,16 @@ using ss_f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int SS_T = 128;            // tile edge (queries and entries)
 constexpr int SS_DC = 32;            // D-chunk staged per step
-constexpr int SS_LD = SS_DC + 4;     // LDS row stride in floats
+#ifndef MIDAS_SS_PAD
+#define MIDAS_SS_PAD 4
+#endif
+#ifndef MIDAS_SS_PIPE
+#define MIDAS_SS_PIPE 1  // the second half-chunk's LDS reads under the first half's MFMAs (sched_group_barrier): +1 TFLOP/s
+#endif
+#ifndef MIDAS_SS_PRIO
+#define MIDAS_SS_PRIO 1  // wave priority while it multiplies: 103 -> 109 TFLOP/s at panels of 4096 rows (the staging wave of the other workgroup no longer takes issue slots from it)
+#endif
+constexpr int SS_LD = SS_DC + MIDAS_SS_PAD;  // LDS row stride in floats
 constexpr int SS_PATCH = 8;          // tiles per patch edge
 
 __global__ __launch_bounds__(256, 2) void k_selfsim_mfma(const float* __restrict__ emb, int64_t K, int D, int64_t i0, int tiles_i, int tiles_j,
@@ -92,6 +101,9 @@ __global__ __launch_bounds__(256, 2) void k_selfsim_mfma(const float* __restrict
         __builtin_amdgcn_sched_barrier(0);  // (left alone the compiler sinks the loads behind the MFMAs and waits for them there)
         const float* pa = &s_a[buf][(wj * 64 + i) * SS_LD + 4 * g];
         const float* pb = &s_b[buf][(wi * 64 + i) * SS_LD + 4 * g];
+#if defined(MIDAS_SS_PRIO) && MIDAS_SS_PRIO
+        __builtin_amdgcn_s_setprio(MIDAS_SS_PRIO);
+#endif
 #pragma unroll
         for (int cc = 0; cc < SS_DC; cc += 16) {
             float4 fa[4], fb[4];
@@ -117,6 +129,17 @@ __global__ __launch_bounds__(256, 2) void k_selfsim_mfma(const float* __restrict
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
         }
+#if defined(MIDAS_SS_PIPE) && MIDAS_SS_PIPE
+        // order inside the chunk: the first half's eight LDS reads, 32 MFMAs, the second half's reads (their latency under the
+        // next 32 MFMAs), the remaining 96 MFMAs - left alone all sixteen reads are issued and waited for before the first MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 96, 0);
+#endif
+#if defined(MIDAS_SS_PRIO) && MIDAS_SS_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         // the other buffer: nobody reads it during this chunk.  Unconditional (after the last chunk it stores a copy nobody
         // reads): behind a condition the compiler sinks the loads into the branch, i.e. behind the MFMAs
         __builtin_amdgcn_sched_barrier(0);
