@@ -2403,12 +2403,12 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
     // round, two trips) 8 %, at N = 1M 7 %: there the single kernel stays.
     // MIDAS_SPLIT_FRONT = 0 never, 2 always with 4 lanes per particle, 3 always with 2.
     static const int split_env = getenv("MIDAS_SPLIT_FRONT") ? atoi(getenv("MIDAS_SPLIT_FRONT")) : 1;
-    // a live count in device memory (loop engine): the set shrinks within a few frames of annealing, so the two-kernel form
-    // whatever the capacity
+    // a live count in device memory (loop engine): the two-kernel form while the caller's bound of the count (a.N here) is small -
+    // the set shrinks within a few frames of annealing; a set held at 100k takes the single kernel (42 -> ~22 us at N = 100k)
     // (re-measured after the single kernel's second pass - per-wave tables, one-wave workgroups, screened scans: pipelined,
     // split / single at N = 6k 29.6k / 27.5k steps/s, 8k 29.0k / 27.9k, 12k 28.3k / 28.5k, 20k 25.8k / 27.1k, 65k 21.0k / 22.9k:
     // the two-kernel form now pays up to ~10 000 particles instead of 65 536; the loop step (live count) keeps it: 126 / 138 us)
-    const bool split_front = a.batch <= 1 && !a.inbox.rows && (split_env >= 2 || (split_env == 1 && ((a.rs.enabled && a.N <= 10240) || a.N <= 2048 || a.n_live)));
+    const bool split_front = a.batch <= 1 && !a.inbox.rows && (split_env >= 2 || (split_env == 1 && ((a.rs.enabled && a.N <= 10240) || a.N <= 2048 || (a.n_live && a.N <= 16384))));
     const int lpp = split_env == 3 ? 2 : 4;
     if (split_front && !(a.ablate & 7)) {
         a.sp.pred_tag = 0; a.sp.list = nullptr;  // (next_count stays: the tail appends whatever form the front had)
