@@ -140,7 +140,9 @@ def reference_loop_rate(cb, traj, N, dev, tree, mesh_tree, T=200, floor=1000):
     return {"frames_per_sec": len(steady) / sum(steady), "ms_per_frame": 1e3 * sum(steady) / len(steady), "frames": len(steady),
             "N0": N, "floor": floor, "N_final": st["num_particles"][-1], "N_min": min(st["num_particles"]),
             "ms_frame_median": 1e3 * sorted(steady)[len(steady) // 2],
-            "ms_frame_max": 1e3 * max(steady), "slowest_frame": 2 + int(np.argmax(steady)), "rmse_t_mm_final": 1e3 * st["rmse_t"][-1]}
+            "ms_frame_max": 1e3 * max(steady), "slowest_frame": 2 + int(np.argmax(steady)),
+            "slowest_frames": [{"frame": 2 + int(i), "ms": 1e3 * steady[int(i)]} for i in np.argsort(steady)[::-1][:3]],
+            "rmse_t_mm_final": 1e3 * st["rmse_t"][-1]}
 
 
 def config5_rate(dev, frames=60):
@@ -178,6 +180,85 @@ def config5_rate(dev, frames=60):
         us = (time.perf_counter() - t0) / frames * 1e6
         out[init] = {"us_per_batch_frame": us, "trajectory_steps_per_sec": B * 1e6 / us}
     return out
+
+
+def _timed_run(eng, od, co, T, warm, steps):
+    """steps frames by ONE midas_lazy_run call after `warm` frames (the form the headline is timed in), us per frame"""
+    eng.run(od[1:1 + warm], co[1:1 + warm])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.run(od[1 + warm:1 + warm + steps], co[1 + warm:1 + warm + steps])
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e6
+
+
+def config1_rates(dev, budget_s=4.0):
+    """BASELINE configs[0] (c1): 004_sugar_box, N = 1000 particles, ~5k-entry codebook, D = 256 (expt=ycb: config/expt/ycb.yaml:15,18,
+    config/tcn/default.yaml:19) - the reference's own CPU-runnable case.  GPU: the pipelined engine, frames by one run() call.
+    CPU: the reference-shaped torch-CPU frame (oracle/ref_shaped.py: 6-d tree query, (N,D) float64 gather, cosine, softmax,
+    mesh prune, torch.multinomial) on the host cores, a bounded sample - the reference's path at the reference's size."""
+    from midastouch_amd.engine import PipelinedFilterEngine
+    from midastouch_amd.synthetic import make_codebook, make_trajectory
+    from oracle.ref_shaped import RefShapedFilter
+
+    N, K, D = 1000, 5000, 256
+    cb = make_codebook("004_sugar_box", K=K, D=D, seed=1000)
+    tr = make_trajectory(cb, T=262, seed=2000)
+    od, co = torch.as_tensor(tr.odoms).to(dev), torch.as_tensor(tr.codes).to(dev)
+    eng = PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, device=dev)
+    start = cb.poses[np.random.default_rng(0).integers(0, K, N)]
+    eng.set_particles(torch.as_tensor(start))
+    eng.project_to_codebook()
+    us = _timed_run(eng, od, co, 262, 40, 200)
+    out = {"workload": "c1: 004_sugar_box, N=1000, K=5000, D=256", "gpu": {"steps_per_sec": 1e6 / us, "us_per_step": us, "steps": 200}}
+    nthreads = min(8, os.cpu_count() or 1)  # 1000 particles: more threads only add hand-over time
+    was = torch.get_num_threads()
+    torch.set_num_threads(nthreads)
+    try:
+        flt = RefShapedFilter(cb.poses, cb.embeddings, cb.mesh_vertices, workers=nthreads)
+        poses = torch.as_tensor(start)
+        odc, coc = torch.as_tensor(tr.odoms), torch.as_tensor(tr.codes)
+        torch.manual_seed(0)
+        poses, _ = flt.step(poses, odc[1], coc[1][None])
+        t0, done = time.perf_counter(), 0
+        while done < 2000 and time.perf_counter() - t0 < budget_s:
+            t = 2 + done % 258
+            poses, _ = flt.step(poses, odc[t], coc[t][None])
+            done += 1
+        dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(was)
+    out["cpu_reference_shaped"] = {"steps_per_sec": done / dt, "ms_per_step": 1e3 * dt / done, "cores": nthreads, "kind": "port",
+                                   "sample": f"{done} frames, {dt:.1f} s, torch CPU ops + scipy cKDTree (stands in for pynanoflann / sklearn)"}
+    out["gpu_over_cpu"] = out["gpu"]["steps_per_sec"] / out["cpu_reference_shaped"]["steps_per_sec"]
+    return out
+
+
+def big_config_rates(dev, which):
+    """c3 / c4 at their TOTAL size on this one GPU (the 8-GPU forms shard N resp. K): N = 1 M particles x 50k x 512, and
+    N = 100k x the whole 500k x 512 codebook.  us per frame, frames by one run() call; the step's algorithmic bytes."""
+    from midastouch_amd.engine import PipelinedFilterEngine
+    from midastouch_amd.synthetic import make_codebook, make_trajectory
+
+    obj, N, K, seed = {"c3": ("035_power_drill", 1_000_000, 50_000, 1003), "c4": ("025_mug", 100_000, 500_000, 1004)}[which]
+    D = 512
+    t0 = time.perf_counter()
+    cb = make_codebook(obj, K=K, D=D, seed=seed)
+    tr = make_trajectory(cb, T=72, seed=seed + 1000)
+    t1 = time.perf_counter()
+    eng = PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, device=dev)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    d0 = np.linalg.norm(cb.poses[:, :3, 3] - tr.gt_poses[0][:3, 3], axis=1)
+    near = np.argsort(d0)[: K // 20]
+    eng.set_particles(torch.as_tensor(cb.poses[np.random.default_rng(4).choice(near, N)]))
+    eng.project_to_codebook()
+    od, co = torch.as_tensor(tr.odoms).to(dev), torch.as_tensor(tr.codes).to(dev)
+    us = _timed_run(eng, od, co, 72, 20, 50)
+    ab = algorithmic_bytes(N, K, D)["step"]
+    return {"workload": f"{which} total on one GPU: {obj}, N={N}, K={K}, D={D}", "steps_per_sec": 1e6 / us, "us_per_step": us, "steps": 50,
+            "algorithmic_MB_per_step": ab / 1e6, "step_frac_of_hbm_peak_survey_model": ab / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "host_codebook_s": t1 - t0, "index_build_s": t2 - t1}
 
 
 def parity_mode_rate(cb, traj, N, dev, tree, mesh_tree, steps=100):
@@ -231,6 +312,68 @@ def parity_probe(eng, N, seed):
     return out
 
 
+def free_port() -> int:
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def self_launch(gpus: int, launch_check: bool = False) -> int:
+    """`python bench.py --gpus N` without a launcher: re-executes this script under torch.distributed.run (--nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1, a free port), one rank per GPU.  Returns the launcher's exit code: non-zero
+    when any rank failed (torch.distributed.run tears the others down).  Only rank 0 writes to stdout."""
+    import subprocess
+
+    if not launch_check:
+        if not torch.cuda.is_available():
+            print("bench.py needs MI355X GPUs: no HIP device visible", file=sys.stderr)
+            return 2
+        if torch.cuda.device_count() < gpus:
+            print("bench.py --gpus %d: only %d GPU(s) visible on this node" % (gpus, torch.cuda.device_count()), file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    if env.get("NCCL_DEBUG", "").upper() in ("VERSION", "INFO"):  # RCCL's banner goes to stdout, behind the JSON line
+        del env["NCCL_DEBUG"]
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(rank: int, local_rank: int, world: int) -> int:
+    """The launch path on its own: process group over RCCL (one GPU per rank) or gloo (no GPU: the CPU test), one all_reduce,
+    one JSON line from rank 0."""
+    import torch.distributed as dist
+
+    gpu = torch.cuda.is_available() and torch.cuda.device_count() > local_rank
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        os.environ["MASTER_PORT"] = str(free_port())
+    if gpu:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dev = torch.device("cpu")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    ones = torch.ones(1, dtype=torch.int32, device=dev)
+    dist.all_reduce(ones)
+    ranks = [None] * world
+    dist.all_gather_object(ranks, (rank, local_rank))
+    ok = int(ones.item()) == world and sorted(r for r, _ in ranks) == list(range(world))
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "ok": ok, "world": int(ones.item()), "n_gpus": world, "backend": "nccl (RCCL)" if gpu else "gloo",
+                          "ranks": ranks}), flush=True)
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -244,6 +387,8 @@ def main():
     ap.add_argument("--no-loop", action="store_true", help="skip the reference-named loop (filter() with clustering + annealing)")
     ap.add_argument("--no-diffuse", action="store_true", help="skip the diffuse-regime figure (profiling runs: keeps the wide-start frames out of the kernel statistics)")
     ap.add_argument("--no-extras", action="store_true", help="skip config.c5, config.parity_mode and roofline.dense (profiling runs)")
+    ap.add_argument("--launch-check", action="store_true", help="only start the ranks, form the process group (RCCL on GPUs, gloo without) and "
+                                                                "print one JSON line with the world size: tests the launch path, measures nothing")
     ap.add_argument("--sharded", action="store_true", help="use the particle-sharded engine even on one GPU (smoke test)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "peer_c", "peer", "a2a", "a2a_fixed", "allgather"], help="sharded engine: form of the resample exchange")
     ap.add_argument("--eager", action="store_true", help="materialise the resampled particles every frame (three launches per frame)")
@@ -261,12 +406,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "RANK" not in os.environ and args.gpus > 1:
+        # started as a plain `python bench.py --gpus N`: launch the N ranks here (one process per GPU, the contract's
+        # torch.distributed.run command line on a free port) and pass their exit code on; rank 0 prints the one JSON line
+        raise SystemExit(self_launch(args.gpus, launch_check=args.launch_check))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         args.gpus = world
+    if args.launch_check:
+        raise SystemExit(launch_check(rank, local_rank, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -278,8 +429,16 @@ def main():
         if os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", "INFO"):
             del os.environ["NCCL_DEBUG"]
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        if "MASTER_PORT" not in os.environ:  # (--sharded in one process: nobody else needs to know the port)
+            os.environ["MASTER_PORT"] = str(free_port())
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # the communicator really spans `world` ranks: every rank contributes 1 (reported as config.exchange.rccl_world; a
+        # world that is not the one asked for is an error, not a line)
+        ones = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(ones)
+        rccl_world = int(ones.item())
+        if rccl_world != world or dist.get_world_size() != world:
+            raise SystemExit("bench.py: the RCCL world has %d ranks, %d were asked for" % (rccl_world, world))
 
     from midastouch_amd.engine import FilterEngine, PipelinedFilterEngine
     from midastouch_amd.synthetic import make_codebook, make_trajectory
@@ -324,17 +483,10 @@ def main():
 
     # start: init_filter(gt_0, N) - sigma_t = mesh scale / 3, sigma_r = 60 deg (particle_filter.py:124-145) - projected onto
     # the codebook (filter.py:159-160); sharded runs draw every rank's slice from its own seed
-    from midastouch_amd.synthetic import mesh_scale
-    from scipy.spatial.transform import Rotation
+    from midastouch_amd.synthetic import wide_start
 
     def wide_init(seed):
-        g = torch.Generator().manual_seed(seed)
-        tn0 = torch.normal(0.0, mesh_scale(cb.extents) / 3.0, size=(N, 3), generator=g)
-        rn0 = torch.normal(0.0, 60.0, size=(N, 3), generator=g)
-        Tn = torch.zeros((N, 4, 4))
-        Tn[:, :3, :3] = torch.as_tensor(Rotation.from_euler("zyx", rn0.numpy(), degrees=True).as_matrix()).float()
-        Tn[:, :3, 3], Tn[:, 3, 3] = tn0, 1.0
-        eng.set_particles(torch.as_tensor(traj.gt_poses[0])[None] @ Tn)
+        eng.set_particles(torch.as_tensor(wide_start(cb.extents, traj.gt_poses[0], N, seed)))
         eng.project_to_codebook()
 
     wide_init(100 + rank)
@@ -448,7 +600,7 @@ def main():
             loop_rate["floor_N"] = guarded(reference_loop_rate, cb, traj, N, dev, tree, eng.tree3, T=200, floor=N)
     exchange_info = None
     if sharded:
-        exchange_info = {"form": eng.exchange, "peer_mapping": "ok" if eng.exchange in ("peer", "peer_c") else (eng.peer_error or "not tried"),
+        exchange_info = {"rccl_world": rccl_world, "form": eng.exchange, "peer_mapping": "ok" if eng.exchange in ("peer", "peer_c") else (eng.peer_error or "not tried"),
                          "library_owned_rccl_communicator": bool(getattr(eng, "_ccomm", None) is not None), "fallback": exchange_fallback,
                          "status_last_frame": eng.status.cpu().numpy().tolist()}
         if eng.exchange == "a2a_fixed":  # rows beyond the overflow block's capacity would have been lost: must not happen
@@ -567,6 +719,15 @@ def main():
                 frame(fi)
                 fi += 1
             dper = kernel_pass([1, 2])
+            # ... and its whole step, K frames by one call like the headline: the rate of a caller who wants all K scores every frame
+            torch.cuda.synchronize()
+            td0 = time.perf_counter()
+            t0_ = 1 + fi % (T - 1)
+            nd = min(args.steps, T - t0_)
+            eng.run(odoms[t0_:t0_ + nd], codes[t0_:t0_ + nd], gts[t0_:t0_ + nd])
+            torch.cuda.synchronize()
+            out["config"]["dense_steps_per_sec"] = nd / (time.perf_counter() - td0)
+            fi += nd
             eng.sparse_scores = True
             d_ms = dper["particle_update"]
             out["roofline"]["dense"] = {"kernel": "frame_front with the codebook stream (all K rows)", "kernel_ms": d_ms,
@@ -585,6 +746,9 @@ def main():
         out["config"]["parity_mode"] = guarded(parity_mode_rate, cb, traj, N, dev, tree, eng.tree3)
         if N == 100_000 and K == 50_000 and D == 512:  # beside the headline workload only
             out["config"]["c5"] = guarded(config5_rate, dev)
+            out["config"]["c1"] = guarded(config1_rates, dev)
+            out["config"]["c3_single_gpu"] = guarded(big_config_rates, dev, "c3")
+            out["config"]["c4_single_gpu"] = guarded(big_config_rates, dev, "c4")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cb, traj, N)
         if not sharded and not args.eager and args.resample == "weighted_random":

@@ -49,6 +49,13 @@ int midas_ctx_create(int device, void* hip_stream, midas_ctx** out);
 int midas_ctx_destroy(midas_ctx* ctx);
 int midas_ctx_set_stream(midas_ctx* ctx, void* hip_stream);
 int midas_sync(midas_ctx* ctx); /* hipStreamSynchronize */
+/* The library's scratch (per-call work arrays: DBSCAN's cell tables, selection histograms, the batch step's score panels) is a
+ * bump allocator over library-owned chunks that GROWS when a call needs more than any call before it - a hipMalloc in the middle
+ * of a run (milliseconds: the cold frame of a loop whose 50th frame is the first to cluster).  A caller that knows its capacity
+ * reserves once, up front: afterwards no call below that need allocates (MIDAS_SCRATCH_LOG=1 reports every allocation).
+ * Synchronises the context's stream when it has to replace chunks.  No counterpart in the reference (torch's caching allocator
+ * plays this role for modules/particle_filter.py's temporaries). */
+int midas_scratch_reserve(midas_ctx* ctx, int64_t bytes);
 const char* midas_strerror(int code);
 const char* midas_last_error(const midas_ctx* ctx);
 const char* midas_version(void);

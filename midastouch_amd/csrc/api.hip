@@ -129,7 +129,40 @@ MIDAS_EXPORT int midas_ctx_create(int device, void* hip_stream, midas_ctx** out)
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
     if (const char* ov = getenv("MIDAS_OVERLAP")) ctx->overlap = atoi(ov) != 0;
+    // every translation unit's code object is loaded now, not by the first frame that happens to need it (midas_internal.hpp)
+    const char* lazy = getenv("MIDAS_LAZY_MODULES");
+    if (!(lazy && lazy[0] == '1')) {
+        int (*const warm[])() = {warm_score, warm_particles, warm_resample, warm_cluster, warm_topn, warm_selfsim, warm_loop,
+                                 warm_dbscan, warm_dbscan_nd, warm_index_build, warm_mt19937};
+        for (auto w : warm)
+            if (w() != 0) { (void)hipGetLastError(); }  // not fatal: the unit then loads at its first launch, as before
+    }
     *out = ctx;
+    return MIDAS_OK;
+}
+
+MIDAS_EXPORT int midas_scratch_reserve(midas_ctx* ctx, int64_t bytes) {
+    if (!ctx || bytes < 0) return MIDAS_ERR_INVALID;
+    MIDAS_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ScratchState* s = scratch_of(ctx);
+    size_t have = 0;
+    for (const auto& c : s->chunks) have = c.cap > have ? c.cap : have;
+    const size_t want = ((size_t)bytes + 255) & ~(size_t)255;
+    if (s->chunks.size() == 1 && have >= want) return MIDAS_OK;
+    if (s->chunks.size() >= 1 && have >= want && s->chunks[0].cap == have) return MIDAS_OK;  // the first chunk already holds it
+    // one chunk that holds everything, in front of the others (a call takes the first chunk its request fits): nothing in
+    // flight may still use the old ones when they are freed
+    MIDAS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->side) MIDAS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->side));
+    void* p = nullptr;
+    const size_t cap = want > have ? want : have;
+    if (hipMalloc(&p, cap) != hipSuccess) return midas_set_error(ctx, MIDAS_ERR_NOMEM, "hipMalloc(scratch reserve)", "out of device memory");
+    for (auto& c : s->chunks) (void)hipFree(c.p);
+    s->chunks.clear();
+    s->chunks.push_back({p, cap});
+    s->cur = 0; s->used = 0; s->total = 0;
+    static const bool log = getenv("MIDAS_SCRATCH_LOG") != nullptr;
+    if (log) fprintf(stderr, "[midas] scratch: reserved one chunk of %zu bytes\n", cap);
     return MIDAS_OK;
 }
 
@@ -1249,34 +1282,52 @@ MIDAS_EXPORT int midas_selfsim_topn(midas_ctx* ctx, const midas_codebook* cb, in
     if (stream_env && stream_env[0] == '1') rinv = nullptr;
     if (!ctx->side) MIDAS_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
     hipEvent_t ev_gemm[2] = {nullptr, nullptr}, ev_sel[2] = {nullptr, nullptr};
-    for (int k = 0; k < nbuf; ++k) {
-        MIDAS_HIP_CHECK(ctx, hipEventCreateWithFlags(&ev_gemm[k], hipEventDisableTiming));
-        MIDAS_HIP_CHECK(ctx, hipEventCreateWithFlags(&ev_sel[k], hipEventDisableTiming));
-    }
     hipStream_t main_stream = ctx->stream;
+    // every exit goes through `finish`: the side stream is joined behind the main stream again (the scratch panels may be handed
+    // to the next API call) and the events are destroyed, whatever failed on the way
+    auto finish = [&](int code) {
+        ctx->stream = main_stream;
+        hipEvent_t join = nullptr;
+        if (hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess) {
+            if (hipEventRecord(join, ctx->side) == hipSuccess) (void)hipStreamWaitEvent(main_stream, join, 0);
+            (void)hipEventDestroy(join);
+        }
+        for (int k = 0; k < 2; ++k) {
+            if (ev_gemm[k]) (void)hipEventDestroy(ev_gemm[k]);
+            if (ev_sel[k]) (void)hipEventDestroy(ev_sel[k]);
+        }
+        return code;
+    };
+#define TOPN_CHECK(expr)                                                                                              \
+    do {                                                                                                              \
+        hipError_t _e = (expr);                                                                                       \
+        if (_e != hipSuccess) return finish(midas_set_error(ctx, MIDAS_ERR_HIP, #expr, hipGetErrorString(_e)));       \
+    } while (0)
+    for (int k = 0; k < nbuf; ++k) {
+        TOPN_CHECK(hipEventCreateWithFlags(&ev_gemm[k], hipEventDisableTiming));
+        TOPN_CHECK(hipEventCreateWithFlags(&ev_sel[k], hipEventDisableTiming));
+    }
     // the side stream starts behind whatever the main stream holds (the caller's inputs)
-    MIDAS_HIP_CHECK(ctx, hipEventRecord(ev_sel[0], main_stream));
-    MIDAS_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ev_sel[0], 0));
-    rc = MIDAS_OK;
-    for (int64_t p = 0; p < npanels && rc == MIDAS_OK; ++p) {
+    TOPN_CHECK(hipEventRecord(ev_sel[0], main_stream));
+    TOPN_CHECK(hipStreamWaitEvent(ctx->side, ev_sel[0], 0));
+    for (int64_t p = 0; p < npanels; ++p) {
         const int k = (int)(p % nbuf);
         const int64_t i0 = p * R, rows = K - i0 < R ? K - i0 : R;
         float* pan = (float*)panel + (size_t)k * R * ldo;
-        if (p >= nbuf) MIDAS_HIP_CHECK(ctx, hipStreamWaitEvent(main_stream, ev_sel[k], 0));  // the panel's previous tenant has been consumed
+        if (p >= nbuf) TOPN_CHECK(hipStreamWaitEvent(main_stream, ev_sel[k], 0));  // the panel's previous tenant has been consumed
         rc = launch_selfsim_panel(ctx, cb, i0, rows, pan, ldo);
-        if (rc) break;
-        MIDAS_HIP_CHECK(ctx, hipEventRecord(ev_gemm[k], main_stream));
-        MIDAS_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ev_gemm[k], 0));
+        if (rc) return finish(rc);
+        TOPN_CHECK(hipEventRecord(ev_gemm[k], main_stream));
+        TOPN_CHECK(hipStreamWaitEvent(ctx->side, ev_gemm[k], 0));
         ctx->stream = ctx->side;  // the launcher enqueues on ctx->stream
         rc = launch_topn_pose_error_dots(ctx, (int32_t)rows, K, pan, ldo, cb->norms, rinv, i0, n, feat_dev, d, err_dev + i0,
                                          idx_dev ? idx_dev + i0 * n : nullptr);
         ctx->stream = main_stream;
-        if (rc) break;
-        MIDAS_HIP_CHECK(ctx, hipEventRecord(ev_sel[k], ctx->side));
+        if (rc) return finish(rc);
+        TOPN_CHECK(hipEventRecord(ev_sel[k], ctx->side));
     }
-    for (int k = 0; k < nbuf; ++k) (void)hipStreamWaitEvent(main_stream, ev_sel[k], 0);  // the results are ordered behind the main stream again
-    for (int k = 0; k < nbuf; ++k) { (void)hipEventDestroy(ev_gemm[k]); (void)hipEventDestroy(ev_sel[k]); }
-    return rc;
+#undef TOPN_CHECK
+    return finish(MIDAS_OK);  // the results are ordered behind the main stream again
 }
 
 #ifdef MIDAS_DEBUG_CLOCKS

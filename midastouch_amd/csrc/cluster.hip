@@ -302,4 +302,6 @@ int launch_cluster_centers(midas_ctx* ctx, int64_t N, const float* poses, const 
     return MIDAS_OK;
 }
 
+MIDAS_WARM_TU(cluster, k_cluster_moments)
+
 }  // namespace midas

@@ -595,4 +595,6 @@ int launch_dbscan(midas_ctx* ctx, int64_t cap, const int32_t* n_dev, const float
     return MIDAS_OK;
 }
 
+MIDAS_WARM_TU(dbscan, k_db_setup)
+
 }  // namespace midas

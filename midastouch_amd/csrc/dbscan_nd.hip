@@ -193,4 +193,6 @@ int launch_dbscan_points(midas_ctx* ctx, int64_t N, int32_t dim, const double* p
     }
 }
 
+MIDAS_WARM_TU(dbscan_nd, k_dbn_jump)
+
 }  // namespace midas

@@ -288,4 +288,6 @@ int build_vertex_lists_device(midas_ctx* ctx, midas_tree* t6, const midas_tree* 
     return build_vertex_screen(ctx, t6);
 }
 
+MIDAS_WARM_TU(index_build, k_vertex_screen)
+
 }  // namespace midas

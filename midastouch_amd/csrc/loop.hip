@@ -1003,7 +1003,10 @@ __global__ __launch_bounds__(256) void k_loop_resample(LoopResampleArgs a) {
             L[10] = (double)np; L[11] = a.ctl_d[LOOP_D_VAR]; L[12] = a.ctl_d[LOOP_D_S]; L[13] = (double)a.ctl_i[LOOP_I_RAW];
             // (with min_samples = n / 5 a frame has at most five clusters + the noise label; the row holds eight: bit 8 says
             // the centres of a frame with more present labels are truncated here - the engine's own arrays hold them all)
+            // L[15] = THIS frame's condition bits: the word is cleared once the row holds it (it used to stay set, and every
+            // later row repeated the first overflow)
             L[14] = (double)a.ctl_i[LOOP_I_NCL]; L[15] = (double)(a.ctl_i[LOOP_I_ERR] | (np > 8 ? 8 : 0));
+            a.ctl_i[LOOP_I_ERR] = 0;
             for (int c = 0; c < 8 && c < np; ++c) {
                 for (int k = 0; k < 16; ++k) L[16 + c * 19 + k] = (double)a.cluster_poses[c * 16 + k];
                 for (int k = 0; k < 3; ++k) L[16 + c * 19 + 16 + k] = (double)a.cluster_stds[c * 3 + k];
@@ -1219,5 +1222,7 @@ int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree*
     }
     return MIDAS_OK;
 }
+
+MIDAS_WARM_TU(loop, k_loop_xe)
 
 }  // namespace midas

@@ -133,6 +133,22 @@ int midas_set_error(midas_ctx* ctx, int code, const char* what, const char* deta
         if (!(cond)) return midas_set_error((ctx), MIDAS_ERR_INVALID, #cond, "invalid argument"); \
     } while (0)
 
+// Code objects load lazily, per translation unit, at the first launch of one of its kernels (tens of ms for the large ones, in
+// the middle of whatever frame happens to be the first to need them: the "cold frame" of a run).  Every unit exports a function
+// that makes the runtime load it now - hipFuncGetAttributes resolves a kernel without launching it - and midas_ctx_create calls
+// them all (MIDAS_LAZY_MODULES=1 keeps the lazy behaviour).
+#define MIDAS_WARM_TU(name, kernel)                                                          \
+    int warm_##name() {                                                                      \
+        hipFuncAttributes attr;                                                              \
+        return (int)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&kernel));     \
+    }
+#define MIDAS_WARM_DECL(name) int warm_##name();
+namespace midas {
+MIDAS_WARM_DECL(score) MIDAS_WARM_DECL(particles) MIDAS_WARM_DECL(resample) MIDAS_WARM_DECL(cluster) MIDAS_WARM_DECL(topn)
+MIDAS_WARM_DECL(selfsim) MIDAS_WARM_DECL(loop) MIDAS_WARM_DECL(dbscan) MIDAS_WARM_DECL(dbscan_nd) MIDAS_WARM_DECL(index_build)
+MIDAS_WARM_DECL(mt19937)
+}  // namespace midas
+
 // scratch carve-out (stream-ordered reuse; one stream per context)
 int midas_scratch(midas_ctx* ctx, size_t bytes, void** out);
 

@@ -136,4 +136,6 @@ int launch_mt_rand64(midas_ctx* ctx, uint32_t* state, int64_t skip_words, int64_
     return MIDAS_OK;
 }
 
+MIDAS_WARM_TU(mt19937, k_mt_seed)
+
 }  // namespace midas

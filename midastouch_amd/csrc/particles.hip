@@ -2554,4 +2554,6 @@ int launch_reduce_partials(midas_ctx* ctx, int np, const double* pmax, const dou
     return MIDAS_OK;
 }
 
+MIDAS_WARM_TU(particles, k_propagate)
+
 }  // namespace midas

@@ -1914,4 +1914,6 @@ int launch_step_tail(midas_ctx* ctx, const StepTailArgs& a, int prof_slot_base) 
     return MIDAS_OK;
 }
 
+MIDAS_WARM_TU(resample, k_gather_f64)
+
 }  // namespace midas

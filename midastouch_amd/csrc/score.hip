@@ -284,4 +284,6 @@ int launch_score_batch(midas_ctx* ctx, const midas_codebook* cb, int32_t B, cons
     return MIDAS_OK;
 }
 
+MIDAS_WARM_TU(score, k_codes_prepare)
+
 }  // namespace midas

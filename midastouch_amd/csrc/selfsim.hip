@@ -170,4 +170,6 @@ int launch_selfsim_panel(midas_ctx* ctx, const midas_codebook* cb, int64_t i0, i
     return MIDAS_OK;
 }
 
+MIDAS_WARM_TU(selfsim, k_selfsim_mfma)
+
 }  // namespace midas

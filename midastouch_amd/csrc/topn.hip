@@ -287,4 +287,6 @@ int launch_topn_pose_error_dots(midas_ctx* ctx, int32_t B, int64_t K, const floa
     return MIDAS_OK;
 }
 
+MIDAS_WARM_TU(topn, k_topn_rinv)
+
 }  // namespace midas

@@ -240,7 +240,6 @@ class PipelinedFilterEngine(FilterEngine):
         self._had_gt = False
         self._rmse_frame = torch.zeros(3, **f64)
         self._rmse_last = self._rmse_frame   # where the latest frame left {rmse_t, rmse_r, clock}: _rmse_frame or a row of the run log
-        self._log = None                     # per-frame log of run(): kept between calls (every row is written by its frame)
         # prediction lists of the sparse scoring (include/midas_hip.h score_list_dev): the rows a frame used are scored for
         # the next frame by streaming workgroups of its front launch.  MIDAS_SCORE_LIST=0: every row by its first particle.
         import os
@@ -298,10 +297,12 @@ class PipelinedFilterEngine(FilterEngine):
 
     def step(self, odom, code, gt=None, tn=None, rot=None, u=None, u32=-1.0, multiplier: float = 1.0):
         stream = getattr(self, "torch_stream", None)
+        own_u = False  # u generated here (a fresh tensor nobody else holds): kept for the folded frame without a copy
         if stream is not None and u is None and self.mode == _lib.RESAMPLE_MULTINOMIAL:
             if tn is not None:
                 stream.skip_normal(3 * self.N).skip_normal(3 * self.N)
             u = stream.rand64(self.N)
+            own_u = True
         odom, code, gt, tn, rot, u = self._operands(odom, code, gt, tn, rot, u)
         cur, nxt = self._cur, self._cur ^ 1
         fold = self._pending and not self._flushed
@@ -332,7 +333,8 @@ class PipelinedFilterEngine(FilterEngine):
         self.ctx.bind_current_stream()
         self.ctx.check(self.ctx.lib.midas_lazy_step(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h, C.byref(a)))
         # this frame's resample draws, consumed by the next step or by flush()
-        self._draw = (None if u is None else (u if stream is not None else u.clone()), float(u32), self.step_count)
+        # (a caller's tensor is copied: it may be mutated before the next step() / flush() consumes it)
+        self._draw = (None if u is None else (u if own_u else u.clone()), float(u32), self.step_count)
         self._rmse_last = self._rmse_frame
         self._had_gt = gt is not None
         self._pending, self._flushed, self._cur = True, False, nxt
@@ -372,11 +374,9 @@ class PipelinedFilterEngine(FilterEngine):
         if self.sparse_scores:
             a.score_stamps, a.score_epoch = _ptr(self._stamps), self._next_epoch(T)
             a.score_list = _ptr(self._score_list)
-        log = None
-        if gts is not None:  # no fill, no copy afterwards: launches of their own in front of / behind the frames
-            if self._log is None or self._log.shape[0] < T:
-                self._log = torch.empty((max(T, 256), 3), dtype=torch.float64, device=d)
-            log = self._log[:T]
+        # a FRESH tensor per call (caching allocator: no launch, no fill - every row is written by its frame): the log belongs
+        # to the caller and stays valid across later run() / step() calls; the engine keeps a reference for `rmse`
+        log = torch.empty((T, 3), dtype=torch.float64, device=d) if gts is not None else None
         self._keep = (odoms, codes, gts, log)
         self.ctx.bind_current_stream()
         self.ctx.check(self.ctx.lib.midas_lazy_run(self.ctx.h, self.codebook.h, self.tree6.h, self.tree3.h, C.byref(a), T, _ptr(log)))

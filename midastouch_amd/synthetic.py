@@ -219,3 +219,19 @@ def make_trajectory(cb: SyntheticCodebook, T: int = 200, seed: int = 2000,
     codes = (codes / np.linalg.norm(codes, axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
     return SyntheticTrajectory(gt.astype(np.float32), meas.astype(np.float32),
                                odoms.astype(np.float32), codes, gt_idx)
+
+
+def wide_start(extents, gt0, N: int, seed: int) -> np.ndarray:
+    """`particle_filter.init_filter(gt_0, N)` of the reference (modules/particle_filter.py:124-145): gt_0 composed with
+    N(0, mesh scale / 3) translations and N(0, 60 deg) "zyx" Euler angles - the wide start SURVEY.md 8(d) prescribes for
+    the measurement (the caller projects it onto the codebook, filter/filter.py:159-160).  (N,4,4) float32; draws from a
+    torch CPU generator seeded with `seed`, translations first, as the reference draws them."""
+    import torch
+
+    g = torch.Generator().manual_seed(int(seed))
+    tn0 = torch.normal(0.0, mesh_scale(extents) / 3.0, size=(N, 3), generator=g)
+    rn0 = torch.normal(0.0, 60.0, size=(N, 3), generator=g)
+    Tn = torch.zeros((N, 4, 4))
+    Tn[:, :3, :3] = torch.as_tensor(Rotation.from_euler("zyx", rn0.numpy(), degrees=True).as_matrix()).float()
+    Tn[:, :3, 3], Tn[:, 3, 3] = tn0, 1.0
+    return (torch.as_tensor(np.asarray(gt0, dtype=np.float32))[None] @ Tn).numpy()

@@ -54,6 +54,64 @@ def _check_frame(eng, oracle, cb, code, seed, step, sample=512):
     return mism_lib
 
 
+def _check_propagate(oracle, prev_poses, prop, odom, N, seed, step, sample=2048):
+    """The motion model of the frame on a sample: the oracle's fixed-order compose with the frame's Philox normals, bit for bit."""
+    pick = np.random.default_rng(1000 + step).choice(N, sample, replace=False)
+    tn, rot = oracle.philox_noise(N, seed, step, np.float32(2e-4), np.float32(0.5))
+    assert np.array_equal(oracle.propagate(prev_poses[pick], odom, tn[pick], rot[pick]), prop[pick])
+
+
+@pytest.mark.parametrize("variant", ["FilterEngine", "PipelinedFilterEngine", "run"])
+def test_config2_full_size(dev, oracle, variant):
+    """c2 - the HEADLINE config - at its exact size (BASELINE.json configs[1]: 004_sugar_box, N = 100 000 particles, 50 000 x 512
+    codebook) from the bench's start (reference init_filter(gt_0, N) projected onto the codebook: modules/particle_filter.py:
+    129-145, filter/filter.py:159-160), six frames, every frame against the oracle: motion model and NN / prune decisions on a
+    brute-force sample, scores of all K rows, weights, blocked CDF, Philox draws, resample indices and gathers exact.  `run` is
+    the path bench.py times: midas_lazy_run (T frames by one C call, prediction lists of the sparse scoring on) - the flushed
+    particle set after calls of 1, 2 and 3 frames.  The mismatch counts bench.py's parity_probe reports are asserted here:
+    0 against the spec exponential (in _check_frame), <= 2 per frame and <= 3 in all against libm's."""
+    from midastouch_amd import engine as E
+    from midastouch_amd.synthetic import make_codebook, make_trajectory, wide_start
+    N, K, D, seed = 100_000, 50_000, 512, 4000
+    cb = make_codebook("004_sugar_box", K=K, D=D, seed=1001)
+    traj = make_trajectory(cb, T=8, seed=2001)
+    eng = getattr(E, "PipelinedFilterEngine" if variant == "run" else variant)(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=seed, device=dev)
+    assert eng.sparse_scores
+    eng.set_particles(torch.as_tensor(wide_start(cb.extents, traj.gt_poses[0], N, 100)))
+    eng.project_to_codebook()
+    proj = eng.poses.cpu().numpy()
+    # the projection itself (filter.py:159-160): every particle sits on its nearest codebook pose
+    pick = np.random.default_rng(7).choice(N, 512, replace=False)
+    start = wide_start(cb.extents, traj.gt_poses[0], N, 100)
+    assert np.array_equal(cb.poses[oracle.nn6(oracle.R3_SE3(start[pick]), oracle.R3_SE3(cb.poses))[0]], proj[pick])
+    od, co, gt = (torch.as_tensor(a).to(dev) for a in (traj.odoms, traj.codes, traj.gt_poses))
+    total, t = 0, 1
+    if variant == "run":
+        assert eng._score_list is not None  # prediction lists on
+        for chunk in (1, 2, 3):
+            prev = eng.poses.cpu().numpy() if chunk == 1 else None  # (reading the set materialises it: flush)
+            log = eng.run(od[t:t + chunk], co[t:t + chunk], gt[t:t + chunk])
+            t += chunk
+            last = t - 1
+            if prev is not None:
+                _check_propagate(oracle, prev, eng.poses_prop.cpu().numpy(), traj.odoms[last], N, seed, last - 1)
+            total += _check_frame(eng, oracle, cb, traj.codes[last], seed, last - 1)
+            rt, _ = oracle.particle_rmse(eng.poses_prop.cpu().numpy(), traj.gt_poses[last])
+            assert float(log[-1, 0]) == pytest.approx(rt, rel=1e-9) and float(eng.rmse[0]) == pytest.approx(rt, rel=1e-9)
+        assert eng.step_count == 6
+    else:
+        for t in range(1, 7):
+            prev = eng.poses.cpu().numpy()
+            eng.step(od[t], co[t], gt=gt[t])
+            _check_propagate(oracle, prev, eng.poses_prop.cpu().numpy(), traj.odoms[t], N, seed, t - 1)
+            total += _check_frame(eng, oracle, cb, traj.codes[t], seed, t - 1)
+            rt, _ = oracle.particle_rmse(eng.poses_prop.cpu().numpy(), traj.gt_poses[t])
+            assert float(eng.rmse[0]) == pytest.approx(rt, rel=1e-9)
+    assert total <= 3
+    tele = eng.telemetry.cpu().numpy()
+    assert tele[0] >= 0 and tele[1] >= 0
+
+
 @pytest.mark.parametrize("engine", ["FilterEngine", "PipelinedFilterEngine"])
 def test_config3_one_million_particles(dev, oracle, engine):
     """c3 on one GPU: N = 1 M particles, 50k x 512 codebook (what each of 8 GPUs holds replicated)."""

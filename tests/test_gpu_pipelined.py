@@ -207,7 +207,10 @@ def test_run_equals_stepping(dev):
     log1 = b.run(odoms[4:11], codes[4:11], gts[4:11])          # 7 frames (odd)
     assert torch.equal(b.rmse, rm[1]) and torch.equal(log1[-1, :2], rm[1])
     assert (log1[1:, 2] > log1[:-1, 2]).all()  # device clock at the end of each frame
+    keep1 = log1.clone()
     log2 = b.run(odoms[11:1 + T], codes[11:1 + T], gts[11:1 + T])  # even
+    torch.cuda.synchronize()
+    assert torch.equal(log1, keep1) and log1.data_ptr() != log2.data_ptr()  # an earlier run's log stays valid (a fresh tensor per call)
     for t in range(1 + T, 1 + T + 4):
         b.step(odoms[t], codes[t], gt=gts[t])
     assert b.step_count == a.step_count
