@@ -616,7 +616,8 @@ int midas_tail_resample(midas_ctx* ctx, const midas_tail_resample_args* args);
 #define MIDAS_LOOP_I_NPRES 11  /* rows of cluster_poses_dev / cluster_stds_dev: labels present, ascending */
 #define MIDAS_LOOP_I_FRAME 12  /* frames completed */
 #define MIDAS_LOOP_I_NAN 13    /* NaN among the scores */
-#define MIDAS_LOOP_I_ERR 14    /* bit 0: more than MIDAS_LOOP_MAX_CLUSTERS - 1 clusters, bit 1: DBSCAN grid limit */
+#define MIDAS_LOOP_I_ERR 14    /* conditions of the CURRENT frame (cleared once its log row holds them): bit 0 / 1: more than
+                                * MIDAS_LOOP_MAX_CLUSTERS - 1 clusters (decide / DBSCAN), bit 2: live count above the launches' bound */
 /* ctl_d (16 x float64) */
 #define MIDAS_LOOP_D_S 0        /* softmax denominator (1 when raw) */
 #define MIDAS_LOOP_D_VARPREV 1  /* particle_var (float32 value) */
@@ -681,8 +682,9 @@ int midas_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* 
                     const midas_loop_args* args, int32_t phases);
 /* cluster_particles(method="euclidean") alone (particle_filter.py:208-217): labels_dev[i] = DBSCAN label of pose i's
  * translation, eps as given, min_samples < 0 -> N / 5.  Exact float64 predicate |dx|^2 <= eps^2, clusters numbered by their
- * first core point, border points to the smallest adjacent cluster - what sklearn's DBSCAN returns.
- * ncl_dev: 2 x int32 out {number of clusters, limit flag}. */
+ * first core point, border points to the smallest adjacent cluster - what sklearn's DBSCAN returns.  Any extent (dense cell grid
+ * up to 128 cells of 0.577 eps per axis, a hash table of the occupied cells beyond) and any number of clusters.
+ * ncl_dev: 2 x int32 out {number of clusters, flag: non-zero only for non-finite coordinates / more than 2^21 cells per axis}. */
 int midas_dbscan(midas_ctx* ctx, int64_t N, const float* poses_dev, double eps, int64_t min_samples, int32_t* labels_dev,
                  int32_t* ncl_dev);
 /* cluster_particles(method="logmap") (particle_filter.py:218-223): DBSCAN of N points of `dim` (2 .. 6) float64 coordinates

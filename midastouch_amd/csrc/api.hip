@@ -1243,7 +1243,7 @@ MIDAS_EXPORT int midas_dbscan(midas_ctx* ctx, int64_t N, const float* poses_dev,
     MIDAS_ENTER(ctx);
     MIDAS_REQUIRE(ctx, N > 0 && N < ((int64_t)1 << 31) && poses_dev && labels_dev && ncl_dev && eps > 0.0);
     MIDAS_HIP_CHECK(ctx, hipMemsetAsync(ncl_dev, 0, 2 * sizeof(int32_t), ctx->stream));
-    return launch_dbscan(ctx, N, nullptr, poses_dev, eps, min_samples, labels_dev, ncl_dev, ncl_dev + 1);
+    return launch_dbscan(ctx, N, nullptr, poses_dev, eps, min_samples, labels_dev, ncl_dev, ncl_dev + 1, 0);
 }
 
 MIDAS_EXPORT int midas_dbscan_points(midas_ctx* ctx, int64_t N, int32_t dim, const double* points_dev, double eps, int64_t min_samples,

@@ -17,6 +17,12 @@
 //     smaller, so a root is the smallest particle index of its cluster);
 //   * numbering as sklearn's scan does: clusters in the order of their first core point; a border point takes the
 //     smallest number among the clusters whose core points reach it.
+//   * extent: a cloud of up to 128 cells per axis (0.74 m at eps = 1e-2) indexes its cells directly; a larger one (a wide
+//     init_filter start on a big object, a caller's small eps) keeps them in a hash table of the occupied cells (64-bit key =
+//     the three cell coordinates, open addressing, 2^21 slots) - same algorithm, the 125 neighbour cells looked up by key.  No
+//     extent limit short of 2^21 cells per axis; round 3 fell back to the host's sklearn there;
+//   * any number of clusters: up to 62 are ranked in LDS, more by a prefix sum over the root flags (midas_dbscan; the loop
+//     step keeps its 62-cluster arrays - min_samples = N / 5 allows about five).
 // Predicate (sklearn's KD-tree on float64 copies): ((dx*dx) + dy*dy) + dz*dz <= eps*eps, accumulated in that order.
 // Pinned by fixture G9 (labels written by the reference's own cluster_particles) through the oracle's O(N^2) restatement.
 #include <cmath>
@@ -29,7 +35,10 @@ namespace midas {
 
 constexpr int DB_MAXDIM = 128;                     // cells per axis
 constexpr int DB_MAXCELLS = DB_MAXDIM * DB_MAXDIM * DB_MAXDIM;
-constexpr int DB_MAXROOTS = LOOP_MAX_CLUSTERS - 1;  // labels -1 .. 62
+constexpr int DB_MAXROOTS = LOOP_MAX_CLUSTERS - 1;  // labels -1 .. 62: what the LDS ranking (and the loop step's cluster arrays) hold
+constexpr int DB_HASH_BITS = 21;                    // cell coordinates of the hashed form: 0 .. 2^21 - 1 per axis
+constexpr unsigned long long DB_EMPTY = ~0ull;
+static_assert(DB_MAXCELLS == (1 << DB_HASH_BITS), "the hash table has as many slots as the dense grid has cells");
 constexpr double DB_CELL = 0.577;                   // cell side / eps, below 1 / sqrt(3)
 
 struct DbGrid {         // written by k_db_setup
@@ -42,6 +51,7 @@ struct DbGrid {         // written by k_db_setup
     int32_t nroots;
     int32_t err;
     int32_t nwork;      // points whose core test needs distances
+    int32_t hashed;     // 1: the cells are the slots of the hash table (cloud wider than DB_MAXDIM cells in some axis)
 };
 
 struct DbArgs {
@@ -64,6 +74,9 @@ struct DbArgs {
     int32_t* parent;        // [N] by particle (core points only)
     int32_t* roots;         // [DB_MAXROOTS + 1]
     int32_t* work;          // [N] sorted positions whose core test needs distances
+    unsigned long long* hkeys;  // [DB_MAXCELLS] hashed form: key of the cell in this slot (DB_EMPTY: free)
+    int32_t* rank;          // [N + 1] more than DB_MAXROOTS clusters: root flag by particle, then its exclusive prefix sum
+    int32_t max_clusters;   // 0: any number; otherwise the clusters beyond that many stay unnumbered (err |= 2)
     int32_t* labels;        // [N] out
     int32_t* ncl_out;       // out: number of clusters
     int32_t* err_out;       // nullable: |= 2 on a limit
@@ -119,15 +132,22 @@ __global__ __launch_bounds__(64) void k_db_setup(DbArgs a, int nblocks) {
     g.ox = lo[0]; g.oy = lo[1]; g.oz = lo[2];
     int dims[3];
     int err = 0;
+    int hashed = 0;
     for (int d = 0; d < 3; ++d) {
         const double ext = (double)hi[d] - (double)lo[d];
         double c = n > 0 ? floor(ext / g.h) + 1.0 : 1.0;
         if (!(c >= 1.0)) c = 1.0;                      // NaN extents
-        if (c > (double)DB_MAXDIM) { c = DB_MAXDIM; err = 1; }
+        if (c > (double)DB_MAXDIM) hashed = 1;
+        if (c > (double)(1 << DB_HASH_BITS)) { c = (double)(1 << DB_HASH_BITS); err = 1; }  // (6 km at eps = 1e-2, or infinite coordinates)
         dims[d] = (int)c;
     }
+    if (hashed && n > DB_MAXCELLS / 2) { hashed = 0; err = 1; }  // the table is sized for a load of one half
+    if (!hashed)
+        for (int d = 0; d < 3; ++d)
+            if (dims[d] > DB_MAXDIM) dims[d] = DB_MAXDIM;  // (only with err set: clamped as before)
     g.dx = dims[0]; g.dy = dims[1]; g.dz = dims[2];
-    g.ncells = g.dx * g.dy * g.dz;
+    g.ncells = hashed ? DB_MAXCELLS : g.dx * g.dy * g.dz;
+    g.hashed = hashed;
     g.n = (int32_t)n;
     g.ms = a.min_samples < 0 ? (int32_t)(n / 5) : (int32_t)a.min_samples;
     g.nroots = 0;
@@ -168,14 +188,44 @@ __device__ __forceinline__ void db_box_bounds(const DbArgs& a, int c2, const flo
     maxd2 = gmax[0] * gmax[0]; maxd2 += gmax[1] * gmax[1]; maxd2 += gmax[2] * gmax[2];
 }
 
-__device__ __forceinline__ int db_cell_of(const DbGrid& g, float x, float y, float z, int& cx, int& cy, int& cz) {
-    cx = (int)floor(((double)x - g.ox) / g.h);
-    cy = (int)floor(((double)y - g.oy) / g.h);
-    cz = (int)floor(((double)z - g.oz) / g.h);
-    cx = cx < 0 ? 0 : cx >= g.dx ? g.dx - 1 : cx;
-    cy = cy < 0 ? 0 : cy >= g.dy ? g.dy - 1 : cy;
-    cz = cz < 0 ? 0 : cz >= g.dz ? g.dz - 1 : cz;
-    return (cz * g.dy + cy) * g.dx + cx;
+__device__ __forceinline__ void db_cell_coords(const DbGrid& g, float x, float y, float z, int& cx, int& cy, int& cz) {
+    // (clamped as doubles: a coordinate at infinity must not reach the int conversion)
+    const double hi_x = (double)(g.dx - 1), hi_y = (double)(g.dy - 1), hi_z = (double)(g.dz - 1);
+    double fx = floor(((double)x - g.ox) / g.h), fy = floor(((double)y - g.oy) / g.h), fz = floor(((double)z - g.oz) / g.h);
+    fx = !(fx >= 0.0) ? 0.0 : fx > hi_x ? hi_x : fx;
+    fy = !(fy >= 0.0) ? 0.0 : fy > hi_y ? hi_y : fy;
+    fz = !(fz >= 0.0) ? 0.0 : fz > hi_z ? hi_z : fz;
+    cx = (int)fx; cy = (int)fy; cz = (int)fz;
+}
+__device__ __forceinline__ unsigned long long db_key64(int cx, int cy, int cz) {
+    return (unsigned long long)cx | ((unsigned long long)cy << DB_HASH_BITS) | ((unsigned long long)cz << (2 * DB_HASH_BITS));
+}
+__device__ __forceinline__ unsigned db_hash(unsigned long long k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return (unsigned)k & (unsigned)(DB_MAXCELLS - 1);
+}
+// slot of the cell with this key, inserted if absent (k_db_count only)
+__device__ __forceinline__ int db_hash_insert(unsigned long long* hkeys, unsigned long long key) {
+    unsigned s = db_hash(key);
+    while (true) {
+        const unsigned long long cur = __hip_atomic_load(&hkeys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == key) return (int)s;
+        if (cur == DB_EMPTY) {
+            const unsigned long long old = atomicCAS(&hkeys[s], DB_EMPTY, key);
+            if (old == DB_EMPTY || old == key) return (int)s;
+        }
+        s = (s + 1) & (unsigned)(DB_MAXCELLS - 1);
+    }
+}
+// slot of the cell with this key or -1 (after k_db_count: the table is read-only)
+__device__ __forceinline__ int db_hash_find(const unsigned long long* hkeys, unsigned long long key) {
+    unsigned s = db_hash(key);
+    while (true) {
+        const unsigned long long cur = hkeys[s];
+        if (cur == key) return (int)s;
+        if (cur == DB_EMPTY) return -1;
+        s = (s + 1) & (unsigned)(DB_MAXCELLS - 1);
+    }
 }
 
 // ---- one atomic per distinct cell of a wave ----------------------------------------------------------------------------
@@ -218,6 +268,12 @@ __device__ __forceinline__ void db_cell_min(int32_t* arr, int c, int32_t val, bo
     if ((todo >> lane) & 1ull) atomicMin(&arr[c], val);
 }
 
+// the hashed form's table starts empty (a no-op for a cloud the dense grid holds)
+__global__ __launch_bounds__(256) void k_db_hclear(DbArgs a) {
+    if (!a.grid->hashed) return;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < DB_MAXCELLS; i += (int64_t)gridDim.x * 256) a.hkeys[i] = DB_EMPTY;
+}
+
 __global__ __launch_bounds__(256) void k_db_count(DbArgs a) {
     const DbGrid g = *a.grid;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -226,7 +282,8 @@ __global__ __launch_bounds__(256) void k_db_count(DbArgs a) {
     if (in) {
         const float* P = a.poses + i * 16;
         int cx, cy, cz;
-        c = db_cell_of(g, P[3], P[7], P[11], cx, cy, cz);
+        db_cell_coords(g, P[3], P[7], P[11], cx, cy, cz);
+        c = g.hashed ? db_hash_insert(a.hkeys, db_key64(cx, cy, cz)) : (cz * g.dy + cy) * g.dx + cx;
         a.cid[i] = c;
     }
     (void)db_cell_fetch_inc(a.cell_count, c, in);
@@ -333,12 +390,25 @@ __device__ __forceinline__ bool db_within(const float4& p, const float4& q, doub
 
 // walks the 5 x 5 x 5 cells around cell c (own cell included when `own`); f(cell) returns true to stop
 template <typename F>
-__device__ __forceinline__ void db_for_cells(const DbGrid& g, int c, bool own, F f) {
-    const int cx = c % g.dx, cy = (c / g.dx) % g.dy, cz = c / (g.dx * g.dy);
+__device__ __forceinline__ void db_for_cells(const DbGrid& g, const unsigned long long* __restrict__ hkeys, int c, bool own, F f) {
+    int cx, cy, cz;
+    if (g.hashed) {
+        const unsigned long long k = hkeys[c];
+        const unsigned m = (1u << DB_HASH_BITS) - 1u;
+        cx = (int)((unsigned)k & m); cy = (int)((unsigned)(k >> DB_HASH_BITS) & m); cz = (int)((unsigned)(k >> (2 * DB_HASH_BITS)) & m);
+    } else {
+        cx = c % g.dx; cy = (c / g.dx) % g.dy; cz = c / (g.dx * g.dy);
+    }
     for (int z = cz - 2 < 0 ? 0 : cz - 2; z <= (cz + 2 >= g.dz ? g.dz - 1 : cz + 2); ++z)
         for (int y = cy - 2 < 0 ? 0 : cy - 2; y <= (cy + 2 >= g.dy ? g.dy - 1 : cy + 2); ++y)
             for (int x = cx - 2 < 0 ? 0 : cx - 2; x <= (cx + 2 >= g.dx ? g.dx - 1 : cx + 2); ++x) {
-                const int c2 = (z * g.dy + y) * g.dx + x;
+                int c2;
+                if (g.hashed) {
+                    if (x == cx && y == cy && z == cz) c2 = c;
+                    else if ((c2 = db_hash_find(hkeys, db_key64(x, y, z))) < 0) continue;  // nobody lives there
+                } else {
+                    c2 = (z * g.dy + y) * g.dx + x;
+                }
                 if (c2 == c && !own) continue;
                 if (f(c2)) return;
             }
@@ -361,7 +431,7 @@ __global__ __launch_bounds__(256) void k_db_core(DbArgs a) {
         state = cnt >= g.ms ? 1 : 0;
         if (!state) {
             int lower = cnt, upper = cnt;  // the own cell: all of it within eps
-            db_for_cells(g, c, false, [&](int c2) {
+            db_for_cells(g, a.hkeys, c, false, [&](int c2) {
                 const int pop = a.cell_start[c2 + 1] - a.cell_start[c2];
                 if (pop == 0) return false;
                 double mind2, maxd2;
@@ -391,7 +461,7 @@ __global__ __launch_bounds__(256) void k_db_core_count(DbArgs a) {
         const float4 me = a.s_pt[p];
         const int c = __float_as_int(me.w);
         int cnt = a.cell_start[c + 1] - a.cell_start[c];
-        db_for_cells(g, c, false, [&](int c2) {
+        db_for_cells(g, a.hkeys, c, false, [&](int c2) {
             const int e = a.cell_start[c2 + 1], b0 = a.cell_start[c2];
             if (e == b0) return false;
             double mind2, maxd2;
@@ -453,7 +523,7 @@ __global__ __launch_bounds__(256) void k_db_link(DbArgs a) {
     const float4 me = a.s_pt[p];
     const int c = __float_as_int(me.w);
     const int32_t orig = a.s_orig[p];
-    db_for_cells(g, c, false, [&](int c2) {
+    db_for_cells(g, a.hkeys, c, false, [&](int c2) {
         const int32_t rep2 = a.cell_rep[c2];
         if (rep2 == 0x7fffffff) return false;  // no core point there
         if (db_find(a.parent, rep2) == db_find(a.parent, orig)) return false;
@@ -468,18 +538,64 @@ __global__ __launch_bounds__(256) void k_db_link(DbArgs a) {
     });
 }
 
-// flatten; the roots (a cluster's first core point in index order) are collected
+// flatten; the roots (a cluster's first core point in index order) are collected (the first DB_MAXROOTS in a list for the LDS
+// ranking; all of them as flags by particle index for the general ranking)
 __global__ __launch_bounds__(256) void k_db_roots(DbArgs a) {
     DbGrid* gp = a.grid;
     const DbGrid g = *gp;
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= g.n || !a.s_core[p]) return;
+    if (p >= g.n) return;
     const int32_t orig = a.s_orig[p];
-    const int32_t r = db_find(a.parent, orig);
-    a.parent[orig] = r;  // the unions are complete: values only ever move towards the root, a plain store is safe
-    if (r == orig) {
-        const int slot = atomicAdd(&gp->nroots, 1);
-        if (slot < DB_MAXROOTS) a.roots[slot] = orig;
+    int flag = 0;
+    if (a.s_core[p]) {
+        const int32_t r = db_find(a.parent, orig);
+        a.parent[orig] = r;  // the unions are complete: values only ever move towards the root, a plain store is safe
+        if (r == orig) {
+            const int slot = atomicAdd(&gp->nroots, 1);
+            if (slot < DB_MAXROOTS) a.roots[slot] = orig;
+            flag = 1;
+        }
+    }
+    a.rank[orig] = flag;
+}
+
+// more clusters than the LDS ranking holds: rank[i] := number of roots among the particles before i (one workgroup; a no-op
+// otherwise)
+__global__ __launch_bounds__(1024) void k_db_rank(DbArgs a) {
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    const DbGrid g = *a.grid;
+    if (g.nroots <= DB_MAXROOTS || (a.max_clusters > 0 && a.max_clusters <= DB_MAXROOTS)) return;
+    const int t = threadIdx.x;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < g.n; base += 1024 * 8) {
+        int v[8], mine = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = base + t * 8 + j;
+            v[j] = i < g.n ? a.rank[i] : 0;
+            mine += v[j];
+        }
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int x = __shfl_up(incl, o);
+            if ((t & 63) >= o) incl += x;
+        }
+        if ((t & 63) == 63) s_w[t >> 6] = incl;
+        __syncthreads();
+        int run = s_carry + incl - mine;
+        for (int w = 0; w < (t >> 6); ++w) run += s_w[w];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = base + t * 8 + j;
+            if (i < g.n) a.rank[i] = run;
+            run += v[j];
+        }
+        __syncthreads();
+        if (t == 1023) s_carry = run;
+        __syncthreads();
     }
 }
 
@@ -489,10 +605,13 @@ __global__ __launch_bounds__(256) void k_db_number(DbArgs a) {
     DbGrid* gp = a.grid;
     const DbGrid g = *gp;
     int nr = g.nroots;
-    const bool over = nr > DB_MAXROOTS;
+    // general = ranked through the prefix sum; otherwise the first DB_MAXROOTS roots are ranked here and the clusters beyond
+    // that limit (the loop step's arrays) stay unnumbered
+    const bool general = nr > DB_MAXROOTS && !(a.max_clusters > 0 && a.max_clusters <= DB_MAXROOTS);
+    const bool over = !general && nr > DB_MAXROOTS;
     nr = over ? DB_MAXROOTS : nr;
     const int t = threadIdx.x;
-    if (t < nr) {  // rank sort of the few roots
+    if (!general && t < nr) {  // rank sort of the few roots
         const int32_t v = a.roots[t];
         int rank = 0;
         for (int j = 0; j < nr; ++j) rank += a.roots[j] < v ? 1 : 0;
@@ -508,7 +627,9 @@ __global__ __launch_bounds__(256) void k_db_number(DbArgs a) {
         const int32_t orig = a.s_orig[p];
         const int32_t r = db_find(a.parent, orig);
         int num = -1;
-        for (int j = 0; j < nr; ++j) num = s_roots[j] == r ? j : num;
+        if (general) num = a.rank[r];
+        else
+            for (int j = 0; j < nr; ++j) num = s_roots[j] == r ? j : num;
         a.labels[orig] = num;
         const int c = __float_as_int(a.s_pt[p].w);
         if (a.cell_rep[c] == orig) a.cell_num[c] = num;
@@ -527,7 +648,7 @@ __global__ __launch_bounds__(256) void k_db_border(DbArgs a) {
         const float4 me = a.s_pt[p];
         const int c = __float_as_int(me.w);
         int best = 0x7fffffff;
-        db_for_cells(g, c, true, [&](int c2) {
+        db_for_cells(g, a.hkeys, c, true, [&](int c2) {
             const int num = a.cell_num[c2];
             if (num < 0 || num >= best) return false;
             if (c2 == c) { best = num; return false; }  // a core point of the own cell is within eps
@@ -550,12 +671,12 @@ __global__ __launch_bounds__(256) void k_db_border(DbArgs a) {
 }
 
 int launch_dbscan(midas_ctx* ctx, int64_t cap, const int32_t* n_dev, const float* poses, double eps, int64_t min_samples,
-                  int32_t* labels_out, int32_t* ncl_out, int32_t* err_out) {
+                  int32_t* labels_out, int32_t* ncl_out, int32_t* err_out, int32_t max_clusters) {
     if (cap <= 0) return MIDAS_OK;
     hipStream_t st = ctx->stream;
     DbArgs a;
     a.N = cap; a.n_dev = n_dev; a.poses = poses; a.eps = eps; a.r2 = eps * eps; a.min_samples = min_samples;
-    a.labels = labels_out; a.ncl_out = ncl_out; a.err_out = err_out;
+    a.labels = labels_out; a.ncl_out = ncl_out; a.err_out = err_out; a.max_clusters = max_clusters;
     const int nbb = (int)(ceil_div(cap, 256) < 256 ? ceil_div(cap, 256) : 256);
     int rc;
     void* p;
@@ -576,11 +697,14 @@ int launch_dbscan(midas_ctx* ctx, int64_t cap, const int32_t* n_dev, const float
     DB_SCRATCH(parent, int32_t, cap);
     DB_SCRATCH(roots, int32_t, DB_MAXROOTS + 1);
     DB_SCRATCH(work, int32_t, cap);
+    DB_SCRATCH(hkeys, unsigned long long, DB_MAXCELLS);
+    DB_SCRATCH(rank, int32_t, cap + 1);
 #undef DB_SCRATCH
     const unsigned gp = (unsigned)ceil_div(cap, 256);
     MIDAS_HIP_CHECK(ctx, hipMemsetAsync(a.cell_count, 0, (size_t)DB_MAXCELLS * sizeof(int32_t), st));
     hipLaunchKernelGGL(k_db_bounds, dim3(nbb), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_db_setup, dim3(1), dim3(64), 0, st, a, nbb);
+    hipLaunchKernelGGL(k_db_hclear, dim3(1024), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_db_count, dim3(gp), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_db_scan, dim3(1), dim3(1024), 0, st, a);
     hipLaunchKernelGGL(k_db_scatter, dim3(gp), dim3(256), 0, st, a);
@@ -589,6 +713,7 @@ int launch_dbscan(midas_ctx* ctx, int64_t cap, const int32_t* n_dev, const float
     hipLaunchKernelGGL(k_db_clique, dim3(gp), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_db_link, dim3(gp), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_db_roots, dim3(gp), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_db_rank, dim3(1), dim3(1024), 0, st, a);
     hipLaunchKernelGGL(k_db_number, dim3(gp < 1024 ? gp : 1024), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_db_border, dim3(gp), dim3(256), 0, st, a);
     DB_LAUNCH_CHECK(ctx);

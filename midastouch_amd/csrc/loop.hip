@@ -1172,7 +1172,7 @@ int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree*
     }
     if (phases & MIDAS_LOOP_DBSCAN) {
         if ((rc = launch_dbscan(ctx, cap, s.ctl_i_dev + LOOP_I_N, s.poses_prop_dev, s.eps, -1, s.labels_dev,
-                                s.ctl_i_dev + LOOP_I_NCL, s.ctl_i_dev + LOOP_I_ERR)))
+                                s.ctl_i_dev + LOOP_I_NCL, s.ctl_i_dev + LOOP_I_ERR, LOOP_MAX_CLUSTERS - 1)))  // (the frame's cluster arrays hold that many)
             return rc;
     }
     if (phases & MIDAS_LOOP_ANNEAL) {

@@ -405,7 +405,7 @@ int launch_anneal_select(midas_ctx* ctx, int64_t N, const double* w, int32_t mod
 // ncl_out[0] = number of clusters; err_out (nullable) |= 2 when the grid / cluster limits were exceeded
 int launch_dbscan_points(midas_ctx* ctx, int64_t N, int32_t dim, const double* pts, double eps, int64_t min_samples, int32_t* labels, int32_t* info);
 int launch_dbscan(midas_ctx* ctx, int64_t cap, const int32_t* n_dev, const float* poses, double eps, int64_t min_samples,
-                  int32_t* labels_out, int32_t* ncl_out, int32_t* err_out);
+                  int32_t* labels_out, int32_t* ncl_out, int32_t* err_out, int32_t max_clusters);  // max_clusters 0: any number
 
 // mt19937.hip - torch's CPU generator stream on the device
 int launch_mt_seed(midas_ctx* ctx, uint64_t seed, uint32_t* state);

@@ -830,7 +830,9 @@ __global__ __launch_bounds__(256) void k_tail_b(TailBArgs a) {
                 while (h2 > l2) {
                     const int64_t mid = l2 + ((h2 - l2) >> 1);
                     const double c = bp + a.lp[mid];
-                    if (upper ? (c <= tt) : (c < tt)) l2 = mid + 1; else h2 = mid;
+                    // (a negative total - raw weights of a negative cosine - turns the division-free comparison round)
+                    const bool lft = total < 0.0 ? (upper ? (c >= tt) : (c > tt)) : (upper ? (c <= tt) : (c < tt));
+                    if (lft) l2 = mid + 1; else h2 = mid;
                 }
                 if (l2 >= b_hi) l2 = b_hi - 1;
                 // exact fix-up
@@ -1059,7 +1061,9 @@ __global__ __launch_bounds__(256) void k_tail_b2(TailB2Args a) {
             }
             const double tt = tq * total;
             // "still left of the answer": cumulative value < tt (multinomial, lower bound) / <= tt (systematic, upper bound)
-            auto left = [&](double c) { return upper ? (c <= tt) : (c < tt); };
+            // (a negative total - raw weights of a negative cosine - turns the division-free comparison round: resample_search.hpp)
+            const bool neg = total < 0.0;
+            auto left = [&](double c) { return neg ? (upper ? (c >= tt) : (c > tt)) : (upper ? (c <= tt) : (c < tt)); };
             auto left_exact = [&](double c) { return upper ? (c <= tq) : (c < tq); };
             // cumulative e*valid at the end of table entry j
             auto tab = [&](int j) {

@@ -14,8 +14,13 @@ namespace midas {
 // left(c) = c < tq (multinomial, lower bound) or c <= tq (systematic, upper bound).
 MD int64_t search_in_block(const double* __restrict__ lp, const double* __restrict__ gend, const double* __restrict__ ggend,
                            int b, int64_t N, int64_t one_slot, double bp, double total, double tq, bool upper) {
+    // (total < 0: raw weights - the softmax is skipped when every particle has the same score, particle_filter.py:459-468 -
+    // of a negative cosine; p = w / sum(w) is positive again (:238) and dividing by the negative total turns the comparison
+    // round.  Without the turn the division-free probes point the wrong way and the exact walk below crosses the whole block
+    // one dependent load at a time: 100 - 400 us frames of a lost, collapsed cloud at N = 1000, found with the c1 trajectory.)
     const double tt = tq * total;
-    auto left = [&](double c) { return upper ? (c <= tt) : (c < tt); };
+    const bool neg = total < 0.0;
+    auto left = [&](double c) { return neg ? (upper ? (c >= tt) : (c > tt)) : (upper ? (c <= tt) : (c < tt)); };
     auto left_exact = [&](double c) { return upper ? (c <= tq) : (c < tq); };
     const int64_t b_lo = (int64_t)b << 12, b_hi = b_lo + SCAN_BLOCK < N ? b_lo + SCAN_BLOCK : N;
     // Three levels, one 128-byte line each (16 prefix values fetched together with eight aligned 16-byte loads,

@@ -109,21 +109,22 @@ int launch_score(midas_ctx* ctx, const midas_codebook* cb, int32_t B, const doub
 // Accumulation order (the spec the oracle restates, mo_score_batch_f32): for c, for s in 0..3, for g in
 // 0..3: acc = fmaf(C[k][16c+4g+s], E[b][16c+4g+s], acc).  Epilogue: float64 division by the norms.
 // HBM: K*D*4 bytes once (102 MB at c2) vs B times for the GEMV loop; MFMA: 2*K*D*B flop.
+// Round 4: persistent workgroups, one per CU, sixteen waves each (four per SIMD); the 64 codes sit in LDS whole (132 KB at
+// D = 512), staged once per workgroup.  The schedule is static and balanced in units of one N-tile (16 rows x 16 codes x D):
+// with G = ceil(K / 16) row groups and S = 4 x grid SIMDs, the first floor(G / S) S groups go whole (four tiles, the row
+// pieces fetched once) to SIMD g mod S, wave slot (g / S) mod 4; the G mod S groups left over are cut into their four
+// tiles and dealt round-robin, one tile a turn (K = 50 000: 3125 groups on 1024 SIMDs = three whole groups per SIMD and 53
+// groups left: as whole groups they would give 53 SIMDs a fourth round - 27.3 us at the matrix rate; as 212 single tiles the
+// longest SIMD has 13 tiles - 22.2 us).  Round 3 had 196 workgroups of 256 rows on 256 CUs, two 1 KB row pieces in flight per
+// wave (47 us, 70 TFLOP/s); a wave now keeps MF_PF = 4 + 4 pieces in flight and twelve to sixteen waves per CU are live.
 constexpr int MF_ROWS_PER_WAVE = 16;
-#ifndef MIDAS_MF_WAVES
-#define MIDAS_MF_WAVES 16
-#endif
-#ifndef MIDAS_MF_DC
-#define MIDAS_MF_DC 512
-#endif
-constexpr int MF_WAVES = MIDAS_MF_WAVES;   // waves per workgroup: they share one staged copy of the codes
+constexpr int MF_WAVES = 12;   // waves per workgroup: three slots on each of the CU's four SIMDs (170 registers a wave)
 constexpr int MF_CODES = 64;   // codes per pass (4 N-tiles)
-constexpr int MF_DC = MIDAS_MF_DC;         // D-chunk staged in LDS
 constexpr int MF_PAD = 4;      // floats of padding per staged code row (bank spread)
 #ifndef MIDAS_MF_PF
-#define MIDAS_MF_PF 2
+#define MIDAS_MF_PF 8
 #endif
-constexpr int MF_PF = MIDAS_MF_PF;         // row pieces in flight per lane and queue
+constexpr int MF_PF = MIDAS_MF_PF;         // row pieces in flight per lane and queue (two queues)
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
@@ -159,101 +160,200 @@ __global__ __launch_bounds__(256) void k_codes_prepare(const double* __restrict_
     if (real && s == 0) { const double n = __builtin_sqrt(acc); norms[b] = n < COS_EPS ? COS_EPS : n; }
 }
 
-__global__ __launch_bounds__(64 * MF_WAVES) void k_score_mfma(const float* __restrict__ emb, const double* __restrict__ norms,
-                                                     const float* __restrict__ codes32, const double* __restrict__ code_norms,
-                                                     double* __restrict__ out, int64_t K, int D, int B, int b0) {
-    extern __shared__ __attribute__((aligned(16))) float s_e[];  // [MF_CODES][dc + MF_PAD]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 4, i = lane & 15;
-    const int64_t row0 = ((int64_t)blockIdx.x * MF_WAVES + wave) * MF_ROWS_PER_WAVE;
-    const int nb = B - b0 < MF_CODES ? B - b0 : MF_CODES;  // codes of this pass
-    f32x4 acc[4];
+// one unit of the schedule: rows [row0, row0 + 16) x the NT N-tiles starting at tile t0, over the whole D.
+// begin() sends the first burst of row pieces and the epilogue's norms on their way (the kernel calls it for a wave's first unit
+// BEFORE the codes are staged: the two latencies overlap), run() multiplies, finish() divides and stores.
+// (eb / ld: the staged codes in LDS, or - CODES_LDS false, D too large for the CU's LDS - the float32 code rows in memory)
+#ifndef MIDAS_MF_DBG
+#define MIDAS_MF_DBG 0  // profiling builds only (tools/ab_score.sh): 1 no row fetches, 2 no LDS reads, 4 no epilogue - wrong scores
+#endif
+template <int NT, bool CODES_LDS>
+struct MfUnit {
+    f32x4 acc[NT];
+    float4 qa[MF_PF], qb[MF_PF];
+    double nr[4], cn[NT];
+    const float* arow;
+    int64_t row0;
+    int t0, nc;
+
+    MD float4 piece(int c) const {
+        if (MIDAS_MF_DBG & 1) { float v = (float)c; asm volatile("" : "+v"(v)); return make_float4(v, v, v, v); }
+        return *reinterpret_cast<const float4*>(arow + 16 * (c < nc ? c : nc - 1));
+    }
+    MD void begin(const float* __restrict__ emb, const double* __restrict__ norms, const double* __restrict__ code_norms, int64_t K,
+                  int D, int b0, int nb, int64_t row0_, int t0_) {
+        const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
+        row0 = row0_; t0 = t0_; nc = D / 16;
+        const int64_t row = row0 + i < K ? row0 + i : K - 1;  // clamp: surplus rows are computed and dropped
+        arow = emb + row * (int64_t)D + 4 * g;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int64_t row = row0 + i < K ? row0 + i : K - 1;  // clamp: surplus rows are computed and dropped
-    const float* arow = emb + row * (int64_t)D;
-    for (int d0 = 0; d0 < D; d0 += MF_DC) {
-        const int dc = D - d0 < MF_DC ? D - d0 : MF_DC;
-        const int ld = dc + MF_PAD;
-        __syncthreads();
-        // stage this D-chunk of the 64 codes: eight 16-byte pieces per thread and round trip (a rolled copy loop waits
-        // for every load before it issues the next one)
-        const int q4 = dc / 4, total = MF_CODES * q4;
-        for (int base = 0; base < total; base += 8 * 64 * MF_WAVES) {
-            float4 v[8];
-            int off[8];
+        for (int p = 0; p < MF_PF; ++p) qa[p] = piece(p);
+        // the epilogue's divisors travel now (fetched in the epilogue they were a round trip at the end of every unit)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int idx = base + k * 64 * MF_WAVES + (int)threadIdx.x;
-                const int ic = idx < total ? idx : total - 1;
-                const int b = ic / q4, d = (ic - b * q4) * 4;
-                off[k] = idx < total ? b * ld + d : -1;
-                v[k] = *reinterpret_cast<const float4*>(&codes32[(int64_t)(b0 + b) * D + d0 + d]);
-            }
+        for (int r = 0; r < 4; ++r) { const int64_t k = row0 + 4 * g + r; nr[r] = norms[k < K ? k : K - 1]; }
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (off[k] >= 0) *reinterpret_cast<float4*>(&s_e[off[k]]) = v[k];
+        for (int t = 0; t < NT; ++t) { const int b = 16 * (t0 + t) + i; cn[t] = code_norms[b0 + (b < nb ? b : 0)]; }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    MD void step(const float* __restrict__ eb, int ld, const float4& a, int c) {
+        float4 e[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (MIDAS_MF_DBG & 2) { float v = (float)(c + t); asm volatile("" : "+v"(v)); e[t] = make_float4(v, v, v, v); }
+            else e[t] = *reinterpret_cast<const float4*>(eb + 16 * t * ld + 16 * c);
         }
-        __syncthreads();
-        // The row pieces travel MF_PF steps ahead of the multiplies.  Two register queues alternate: a piece is fetched
-        // into the queue that is NOT being multiplied from - fetched into the registers the MFMAs of the step still read,
-        // the compiler parks it in a temporary and waits for it on the spot (s_waitcnt vmcnt(0) in every step).
-        auto piece = [&](int c) {
-            const int cc = c < dc ? c : dc - 16;
-            return *reinterpret_cast<const float4*>(arow + d0 + cc + 4 * g);
-        };
-        auto step = [&](const float4& a, int c) {
-            const float* eb = reinterpret_cast<const float*>(__builtin_assume_aligned(s_e, 16));
-            float4 e[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) e[t] = *reinterpret_cast<const float4*>(&eb[(16 * t + i) * ld + c + 4 * g]);
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, e[t].x, acc[t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, e[t].x, acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, e[t].y, acc[t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, e[t].y, acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, e[t].z, acc[t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, e[t].z, acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, e[t].w, acc[t], 0, 0, 0);
+    }
+    MD void run(const float* __restrict__ codes, int ld) {
+        const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
+        const float* eb = codes + (16 * t0 + i) * ld + 4 * g;
+        int c0 = 0;
+        // Whole rounds of 2 MF_PF steps, straight-line code (a condition around a step makes the compiler's wait counting give
+        // up at the merge: s_waitcnt vmcnt(0) once per round).  The row pieces travel MF_PF .. 2 MF_PF steps ahead of the
+        // multiplies in two register queues that alternate (fetched into the registers the MFMAs of a step still read, a piece
+        // is parked in a temporary and waited for on the spot); the pieces of the next half round leave as one burst: a lane's
+        // pieces are 64 bytes apart, so the wave asks for MF_PF x 64 contiguous bytes of each of its 16 rows at once.
+        // Instruction order pinned with sched_group_barrier: the burst, then per step the codes' LDS reads and the multiplies.
+        for (; c0 + 2 * MF_PF <= nc; c0 += 2 * MF_PF) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, e[t].w, acc[t], 0, 0, 0);
-        };
-        float4 qa[MF_PF], qb[MF_PF];
+            for (int p = 0; p < MF_PF; ++p) qb[p] = piece(c0 + p + MF_PF);
 #pragma unroll
-        for (int p = 0; p < MF_PF; ++p) qa[p] = piece(16 * p);
-        for (int c0 = 0; c0 < dc; c0 += 32 * MF_PF) {
+            for (int p = 0; p < MF_PF; ++p) step(eb, ld, qa[p], c0 + p);
+            if constexpr (CODES_LDS) {
+                __builtin_amdgcn_sched_group_barrier(0x020, MF_PF, 0);
 #pragma unroll
-            for (int p = 0; p < MF_PF; ++p) {
-                const int c = c0 + 16 * p;
-                qb[p] = piece(c + 16 * MF_PF);
-                if (c < dc) step(qa[p], c);  // wave-uniform
+                for (int p = 0; p < MF_PF; ++p) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
+                }
             }
 #pragma unroll
-            for (int p = 0; p < MF_PF; ++p) {
-                const int c = c0 + 16 * (MF_PF + p);
-                qa[p] = piece(c + 16 * MF_PF);
-                if (c < dc) step(qb[p], c);
+            for (int p = 0; p < MF_PF; ++p) qa[p] = piece(c0 + p + 2 * MF_PF);
+#pragma unroll
+            for (int p = 0; p < MF_PF; ++p) step(eb, ld, qb[p], c0 + MF_PF + p);
+            if constexpr (CODES_LDS) {
+                __builtin_amdgcn_sched_group_barrier(0x020, MF_PF, 0);
+#pragma unroll
+                for (int p = 0; p < MF_PF; ++p) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
+                }
             }
+        }
+        if (c0 < nc) {  // D / 16 not a multiple of 2 MF_PF: the last, partial round (wave-uniform conditions)
+#pragma unroll
+            for (int p = 0; p < MF_PF; ++p) {
+                qb[p] = piece(c0 + p + MF_PF);
+                if (c0 + p < nc) step(eb, ld, qa[p], c0 + p);
+            }
+#pragma unroll
+            for (int p = 0; p < MF_PF; ++p)
+                if (c0 + MF_PF + p < nc) step(eb, ld, qb[p], c0 + MF_PF + p);
         }
     }
     // D[row = 4g + r][code = i] in register r of lane (g, i)
+    MD void finish(double* __restrict__ out, int64_t K, int b0, int nb) {
+        const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
+        if (MIDAS_MF_DBG & 4) {
+            float sum = 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int b = 16 * t + i;
-        if (b < nb) {
-            const double ne = code_norms[b0 + b];
-            const int64_t k0 = row0 + 4 * g;  // the lane's four rows are consecutive: one 32-byte run of the code's scores
-            double* o = out + (int64_t)(b0 + b) * K + k0;
-            if (k0 + 3 < K && ((uintptr_t)o & 15) == 0) {
-                double2 lo, hi;
-                lo.x = (double)acc[t][0] / (ne * norms[k0]); lo.y = (double)acc[t][1] / (ne * norms[k0 + 1]);
-                hi.x = (double)acc[t][2] / (ne * norms[k0 + 2]); hi.y = (double)acc[t][3] / (ne * norms[k0 + 3]);
-                reinterpret_cast<double2*>(o)[0] = lo;
-                reinterpret_cast<double2*>(o)[1] = hi;
-            } else {
+            for (int t = 0; t < NT; ++t) sum += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+            if (sum == 12345.678f) out[0] = (double)sum;
+            return;
+        }
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (k0 + r < K) o[r] = (double)acc[t][r] / (ne * norms[k0 + r]);
+        for (int t = 0; t < NT; ++t) {
+            const int b = 16 * (t0 + t) + i;
+            if (b < nb) {
+                const double ne = cn[t];
+                const int64_t k0 = row0 + 4 * g;  // the lane's four rows are consecutive: one 32-byte run of the code's scores
+                double* o = out + (int64_t)(b0 + b) * K + k0;
+                if (k0 + 3 < K && ((uintptr_t)o & 15) == 0) {
+                    double2 lo, hi;
+                    lo.x = (double)acc[t][0] / (ne * nr[0]); lo.y = (double)acc[t][1] / (ne * nr[1]);
+                    hi.x = (double)acc[t][2] / (ne * nr[2]); hi.y = (double)acc[t][3] / (ne * nr[3]);
+                    reinterpret_cast<double2*>(o)[0] = lo;
+                    reinterpret_cast<double2*>(o)[1] = hi;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (k0 + r < K) o[r] = (double)acc[t][r] / (ne * nr[r]);
+                }
             }
         }
+    }
+};
+
+template <bool CODES_LDS>
+__global__ __launch_bounds__(64 * MF_WAVES) void k_score_mfma(const float* __restrict__ emb, const double* __restrict__ norms,
+                                                     const float* __restrict__ codes32, const double* __restrict__ code_norms,
+                                                     double* __restrict__ out, int64_t K, int D, int B, int b0) {
+    extern __shared__ __attribute__((aligned(16))) float s_e[];  // [MF_CODES][D + MF_PAD]
+    const int wave = threadIdx.x >> 6;
+    const int nb = B - b0 < MF_CODES ? B - b0 : MF_CODES;  // codes of this pass
+    const int ld = CODES_LDS ? D + MF_PAD : D;
+    const float* eb = CODES_LDS ? s_e : codes32 + (int64_t)b0 * D;
+    // ---- the schedule (see above): this wave = slot `slot` of SIMD `simd` ----
+    constexpr int SL = MF_WAVES / 4;
+    const int64_t S = (int64_t)gridDim.x * 4, simd = (int64_t)blockIdx.x * 4 + (wave & 3);
+    const int slot = wave >> 2;
+    const int64_t G = (K + MF_ROWS_PER_WAVE - 1) / MF_ROWS_PER_WAVE;
+    const int64_t rounds = G / S, Gw = rounds * S;   // whole groups: `rounds` per SIMD
+    // the wave's first whole group starts its fetches before the codes are staged
+    MfUnit<4, CODES_LDS> u4;
+    const bool first4 = slot < rounds;
+    if (first4) u4.begin(emb, norms, code_norms, K, D, b0, nb, ((int64_t)slot * S + simd) * MF_ROWS_PER_WAVE, 0);
+    if (CODES_LDS) {
+        // stage the 64 codes (padded with zero rows by k_codes_prepare): six 16-byte pieces per thread and round trip, the loads
+        // unconditional (clamped index) so that a round's six are in flight together
+        const int q4 = D / 4, total = MF_CODES * q4;
+        constexpr int SB = 6, NT_ = 64 * MF_WAVES;
+        for (int base = 0; base < total; base += SB * NT_) {
+            float4 v[SB];
+#pragma unroll
+            for (int k = 0; k < SB; ++k) {
+                const int idx = base + k * NT_ + (int)threadIdx.x;
+                const int ic = idx < total ? idx : total - 1;
+                const int b = ic / q4, d = (ic - b * q4) * 4;
+                v[k] = *reinterpret_cast<const float4*>(&codes32[(int64_t)(b0 + b) * D + d]);
+            }
+#pragma unroll
+            for (int k = 0; k < SB; ++k)  // (pinned here: the compiler otherwise sinks each load into its store's condition)
+                asm volatile("" : "+v"(v[k].x), "+v"(v[k].y), "+v"(v[k].z), "+v"(v[k].w));
+            float4* s4 = reinterpret_cast<float4*>(s_e);  // rows of ld / 4 sixteen-byte pieces (D and the pad are multiples of 4)
+            const int ldq = ld >> 2;
+#pragma unroll
+            for (int k = 0; k < SB; ++k) {
+                const int idx = base + k * NT_ + (int)threadIdx.x;
+                const int ic = idx < total ? idx : total - 1;
+                const int b = ic / q4, dq = ic - b * q4;
+                if (idx < total) s4[b * ldq + dq] = v[k];
+            }
+        }
+        __syncthreads();
+    }
+    __builtin_amdgcn_s_setprio(1);
+    for (int64_t r = slot; r < rounds; r += SL) {
+        if (r != slot) u4.begin(emb, norms, code_norms, K, D, b0, nb, (r * S + simd) * MF_ROWS_PER_WAVE, 0);
+        u4.run(eb, ld);
+        u4.finish(out, K, b0, nb);
+    }
+    // the groups left over, one N-tile a turn: tile-unit q = 4 (group - Gw) + tile goes to SIMD q mod S, slot (rounds + q / S) mod SL
+    const int64_t Q = 4 * (G - Gw);
+    for (int64_t q = simd; q < Q; q += S) {
+        if ((int)((rounds + q / S) % SL) != slot) continue;
+        MfUnit<1, CODES_LDS> u1;
+        u1.begin(emb, norms, code_norms, K, D, b0, nb, (Gw + (q >> 2)) * MF_ROWS_PER_WAVE, (int)(q & 3));
+        u1.run(eb, ld);
+        u1.finish(out, K, b0, nb);
     }
 }
 
@@ -261,6 +361,10 @@ int launch_score_batch(midas_ctx* ctx, const midas_codebook* cb, int32_t B, cons
     if (cb->dtype != MIDAS_F32 || cb->D % 16 != 0 || (uintptr_t)cb->emb % 16 != 0)
         return midas_set_error(ctx, MIDAS_ERR_INVALID, "midas_score_batch", "needs float32 embeddings with D % 16 == 0");
     const int D = cb->D;
+    // the 64 staged codes fit the CU's 160 KB of LDS up to D = 636; beyond (D = 1024) the waves read the float32 code rows from
+    // memory (256 KB: cache-resident) - the same arithmetic, slower
+    const bool codes_lds = (size_t)MF_CODES * (D + MF_PAD) * sizeof(float) <= 160 * 1024;
+    const size_t lds = codes_lds ? (size_t)MF_CODES * (D + MF_PAD) * sizeof(float) : 0;
     const int Bpad = (int)ceil_div(B, MF_CODES) * MF_CODES;
     void *cn, *c32;
     int rc = midas_scratch(ctx, (size_t)B * sizeof(double), &cn);
@@ -268,17 +372,24 @@ int launch_score_batch(midas_ctx* ctx, const midas_codebook* cb, int32_t B, cons
     if ((rc = midas_scratch(ctx, (size_t)Bpad * D * sizeof(float), &c32))) return rc;
     hipLaunchKernelGGL(k_codes_prepare, dim3((unsigned)ceil_div(Bpad, 16)), dim3(256), 0, ctx->stream, codes, (float*)c32,
                        (double*)cn, B, Bpad, D);
-    const int dc = D < MF_DC ? D : MF_DC;
-    const size_t lds = (size_t)MF_CODES * (dc + MF_PAD) * sizeof(float);
     static bool attr_set = false;
+    static int ncu = 256;
     if (!attr_set) {
-        MIDAS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_score_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MIDAS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_score_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
         attr_set = true;
     }
-    const unsigned grid = (unsigned)ceil_div(cb->K, MF_ROWS_PER_WAVE * MF_WAVES);
+    // one persistent workgroup per CU (fewer when the codebook has fewer row groups than that many SIMDs)
+    const int64_t G = ceil_div(cb->K, MF_ROWS_PER_WAVE);
+    const unsigned grid = (unsigned)(G < (int64_t)ncu * 4 ? ceil_div(G, 4) : ncu);
     for (int b0 = 0; b0 < B; b0 += MF_CODES) {
-        hipLaunchKernelGGL(k_score_mfma, dim3(grid), dim3(64 * MF_WAVES), lds, ctx->stream, (const float*)cb->emb, cb->norms,
-                           (const float*)c32, (const double*)cn, scores, cb->K, D, B, b0);
+        if (codes_lds)
+            hipLaunchKernelGGL(k_score_mfma<true>, dim3(grid), dim3(64 * MF_WAVES), lds, ctx->stream, (const float*)cb->emb, cb->norms,
+                               (const float*)c32, (const double*)cn, scores, cb->K, D, B, b0);
+        else
+            hipLaunchKernelGGL(k_score_mfma<false>, dim3(grid), dim3(64 * MF_WAVES), 0, ctx->stream, (const float*)cb->emb, cb->norms,
+                               (const float*)c32, (const double*)cn, scores, cb->K, D, B, b0);
     }
     MIDAS_HIP_CHECK(ctx, hipGetLastError());
     return MIDAS_OK;

@@ -297,12 +297,15 @@ class PipelinedFilterEngine(FilterEngine):
 
     def step(self, odom, code, gt=None, tn=None, rot=None, u=None, u32=-1.0, multiplier: float = 1.0):
         stream = getattr(self, "torch_stream", None)
-        own_u = False  # u generated here (a fresh tensor nobody else holds): kept for the folded frame without a copy
+        own_u, u_event = False, None  # own_u: generated here (a buffer nobody else holds): kept for the folded frame without a copy
         if stream is not None and u is None and self.mode == _lib.RESAMPLE_MULTINOMIAL:
             if tn is not None:
                 stream.skip_normal(3 * self.N).skip_normal(3 * self.N)
-            u = stream.rand64(self.N)
+            # this frame's draws are consumed by the NEXT launch (the folded resample) or by flush(): generated beside this
+            # frame's kernels on the generator's own stream, waited for where they are read
+            u, u_event = stream.rand64_async(self.N)
             own_u = True
+        self._wait_draws()
         odom, code, gt, tn, rot, u = self._operands(odom, code, gt, tn, rot, u)
         cur, nxt = self._cur, self._cur ^ 1
         fold = self._pending and not self._flushed
@@ -335,6 +338,7 @@ class PipelinedFilterEngine(FilterEngine):
         # this frame's resample draws, consumed by the next step or by flush()
         # (a caller's tensor is copied: it may be mutated before the next step() / flush() consumes it)
         self._draw = (None if u is None else (u if own_u else u.clone()), float(u32), self.step_count)
+        self._draw_event = u_event
         self._rmse_last = self._rmse_frame
         self._had_gt = gt is not None
         self._pending, self._flushed, self._cur = True, False, nxt
@@ -361,6 +365,7 @@ class PipelinedFilterEngine(FilterEngine):
         a.resample_prev = int(fold)
         a.poses_in = _ptr(self._poses)
         a.hint_in = _ptr(self._hint) if self.use_hint else None
+        self._wait_draws()
         pu, pu32, pstep = self._draw
         if pu is not None:
             raise MidasError("run() continues with device draws: the pending frame was stepped with host uniforms - flush() first")
@@ -389,10 +394,18 @@ class PipelinedFilterEngine(FilterEngine):
         self._cur = nxt if T % 2 else cur
         return log
 
+    def _wait_draws(self):
+        """The pending frame's draws may still be in flight on the generator's stream (TorchCpuStream): order this stream behind them."""
+        ev = getattr(self, "_draw_event", None)
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            self._draw_event = None
+
     def flush(self):
         """Materialise the latest frame's resample (poses, weights, weights_res, hint, ridx, status, rmse)."""
         if not self._pending or self._flushed:
             return
+        self._wait_draws()
         cur = self._cur
         u, u32, stp = self._draw
         a = LazyFlushArgs()

@@ -193,21 +193,18 @@ class particle_filter:
     # ---------------------------------------------------------------------------------------------
     def cluster_particles(self, _particles: Particles, method: str = "euclidean", eps: float = 1e-2) -> Particles:
         """DBSCAN labels of the particles, min_samples = N / 5 (:208-228).  "euclidean" (what the loop uses, filter.py:183)
-        runs on the device (midas_dbscan: exact float64 predicate on a uniform grid, clusters numbered by their first core
-        point like sklearn's scan) - the reference's host call takes seconds to minutes at 100k particles; "logmap" clusters
+        runs on the device (midas_dbscan: exact float64 predicate on a uniform grid - dense up to 128 cells per axis, a hash
+        table of the occupied cells beyond -, clusters numbered by their first core point like sklearn's scan) - the reference's host call takes seconds to minutes at 100k particles; "logmap" clusters
         the 6-d SE(3) logarithms on the device too (midas_dbscan_points: all pairs, the same predicate and numbering)."""
         particles = copy.copy(_particles)
         if method == "euclidean":
+            # any extent (a hash table of the occupied cells takes over from the dense grid beyond 128 cells per axis) and any
+            # number of clusters: there is no host fallback.  The flag is set only for coordinates at infinity / beyond 2^21
+            # cells per axis (6 km at eps = 1e-2), where no cell structure applies.
             labels, info = ops.dbscan(particles.poses, eps)
             if int(info[1].item()) != 0:
-                # the device grid (128 cells of side 0.577 eps per axis, 62 clusters) does not hold this cloud at this eps: its
-                # labels are not sklearn's.  Say so and do what the reference does (sklearn on the host, :215-217).
-                import warnings
-                from sklearn.cluster import DBSCAN
-                warnings.warn(f"cluster_particles: the cloud exceeds the device DBSCAN's grid at eps={eps} "
-                              f"(extent > {128 * 0.577 * eps:.3g} m or more than 62 clusters); clustering on the host like the reference")
-                data = particles.poses[:, :3, 3].cpu().numpy()
-                labels = torch.as_tensor(DBSCAN(eps=eps, min_samples=int(len(particles) / 5)).fit(data).labels_, device=particles.poses.device)
+                raise ops.MidasError(f"cluster_particles: particle translations are not finite or span more than 2^21 cells of "
+                                     f"{0.577 * eps:.3g} m; DBSCAN labels undefined")
             particles.labels = labels.to(torch.int64)
             return particles
         if method != "logmap":
@@ -228,7 +225,7 @@ class particle_filter:
         "quat_avg" (what filter.py:185 asks for) is Markley's quaternion mean (modules/pose.py:112-147) on the device:
         one pass over the particles accumulates every cluster's moments, a small kernel solves the symmetric 4x4
         eigenproblem the reference handed to the removed Tensor.eig (midas_cluster_centers, csrc/cluster.hip).
-        "logmap" averages rotation vectors with torch ops.
+        "logmap" (pose.log_map_averaged, modules/pose.py:101-109): mean of the SE(3) logarithms, all clusters in one matrix product.
         """
         particles = copy.copy(_particles)
         poses, labels = particles.poses, particles.labels
@@ -236,19 +233,11 @@ class particle_filter:
         if method == "quat_avg":  # K9: every cluster in one pass over the particles (ops.cluster_centers)
             cluster_poses, cluster_stds, _ = ops.cluster_centers(poses, particles.weights, labels, uniq)
             return cluster_poses, cluster_stds
-        from .pose import logmap_average_pose
+        from .pose import logmap_cluster_centers
 
-        weights = particles.weights.float()
-        cluster_stds = torch.zeros((uniq.shape[0], 3), device=uniq.device)
-        cluster_poses = torch.zeros((uniq.shape[0], 4, 4), device=uniq.device)
-        for i, label in enumerate(uniq):
-            sel = labels == label
-            tp, tw = poses[sel, :, :], weights[sel]
-            if torch.isclose(tw.max() - tw.min(), torch.tensor([0.0], device=tw.device, dtype=tw.dtype)):
-                tw = torch.ones_like(tw)
-            cluster_poses[i] = logmap_average_pose(tp, tw)
-            cluster_stds[i, :] = torch.sqrt(torch.sum(((tp[:, :3, 3] - cluster_poses[i, :3, 3]) ** 2 * tw[:, None]) / tw.sum(), dim=0))
-        return cluster_poses, cluster_stds
+        # "logmap" (the signature's default): every cluster at once - one pass of SE(3) logarithms, one float64 matrix product
+        # for all the clusters' sums, the exponentials batched (pose.py: logmap_cluster_centers)
+        return logmap_cluster_centers(poses, particles.weights, labels)
 
     def _anneal_plan(self, n: int, var, floor: int):
         """The rule of :413-447 as a plan (mode, k): 1 = drop the k particles of smallest weight, 2 = duplicate the k of

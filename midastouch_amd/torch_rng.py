@@ -24,18 +24,43 @@ def normal_words(numel: int) -> int:
 
 
 class TorchCpuStream:
-    def __init__(self, seed: int, device=None):
+    """`overlap=True` (default): the generator runs on a stream and a library context of its own - its single-workgroup block
+    recurrence (one CU, ~30 us for a frame's 2 N words at N = 100k) then runs BESIDE the frame kernels of the caller's stream
+    instead of in front of them.  `rand64()` orders the result behind the caller's stream as before; `rand64_async()` returns
+    (tensor, event) and leaves the wait to the consumer (the pipelined engine: the draws of frame t are consumed by frame
+    t + 1's launch).  The output buffers rotate (3): a buffer is rewritten two calls later, after the side stream has waited
+    for the caller's stream as of THAT call - whoever consumed it was enqueued before."""
+
+    def __init__(self, seed: int, device=None, overlap: bool = True):
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.ctx = _lib.context(dev)
-        self.device = self.ctx.device
+        self.device = _lib.context(dev).device
+        self.overlap = bool(overlap)
+        if self.overlap:
+            self.side = torch.cuda.Stream(self.device)
+            with torch.cuda.stream(self.side):
+                self.ctx = _lib.Context(self.device)  # bound to the side stream for good (never re-bound)
+        else:
+            self.side = None
+            self.ctx = _lib.context(dev)
         self.state = torch.zeros(626, dtype=torch.int32, device=self.device)
         self.pending_skip = 0
+        self._bufs, self._turn = [None, None, None], 0
         self.manual_seed(seed)
+
+    def _enter(self):
+        """Orders the generator's stream behind the caller's current stream (state, buffers and seeds are shared with it)."""
+        if self.side is None:
+            self.ctx.bind_current_stream()
+            return
+        self.side.wait_stream(torch.cuda.current_stream(self.device))
+
+    def _call(self, name, *args):
+        self.ctx.check(getattr(self.ctx.lib, name)(self.ctx.h, *args))
 
     def manual_seed(self, seed: int):
         """torch.manual_seed(seed) for this stream."""
-        self.ctx.bind_current_stream()
-        self.ctx.call("midas_mt19937_seed", int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(self.state))
+        self._enter()
+        self._call("midas_mt19937_seed", int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(self.state))
         self.pending_skip = 0
         return self
 
@@ -48,11 +73,33 @@ class TorchCpuStream:
         """Step over what torch.normal(mean, std, size) with `numel` float32 values takes."""
         return self.skip_words(normal_words(numel))
 
+    def rand64_async(self, N: int, out: torch.Tensor | None = None):
+        """The next N values of torch.rand(N, dtype=torch.float64), enqueued on the generator's stream: (tensor, event or None).
+        The consumer waits for the event on its stream before it reads the tensor (None: same stream, already ordered)."""
+        N = int(N)
+        if out is None:
+            i = self._turn
+            self._turn = (i + 1) % 3
+            if self._bufs[i] is None or self._bufs[i].numel() != N:
+                self._bufs[i] = torch.empty(N, dtype=torch.float64, device=self.device)
+            out = self._bufs[i]
+        self._enter()
+        self._call("midas_mt19937_rand64", _ptr(self.state), self.pending_skip, N, _ptr(out))
+        self.pending_skip = 0
+        if self.side is None:
+            return out, None
+        ev = torch.cuda.Event()
+        ev.record(self.side)
+        return out, ev
+
     def rand64(self, N: int, out: torch.Tensor | None = None) -> torch.Tensor:
-        """The next N values of torch.rand(N, dtype=torch.float64) (== the draws of torch.multinomial(w64, N, True))."""
+        """The next N values of torch.rand(N, dtype=torch.float64) (== the draws of torch.multinomial(w64, N, True)), ordered
+        behind the caller's current stream; a fresh tensor unless `out` is given."""
         if out is None:
             out = torch.empty(int(N), dtype=torch.float64, device=self.device)
-        self.ctx.bind_current_stream()
-        self.ctx.call("midas_mt19937_rand64", _ptr(self.state), self.pending_skip, int(N), _ptr(out))
-        self.pending_skip = 0
-        return out
+            if self.side is not None:
+                out.record_stream(self.side)  # written on the generator's stream: the allocator must know
+        u, ev = self.rand64_async(N, out)
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+        return u

@@ -83,3 +83,64 @@ def test_class_surface_and_empty_label():
     c, s, cnt = ops.cluster_centers(parts.poses, parts.weights, parts.labels, torch.tensor([-1, 1, 7], device=dev))
     assert cnt.cpu().tolist() == [400, 800, 0]
     assert torch.isnan(c[2]).all() and torch.isnan(s[2]).all() and not torch.isnan(c[:2]).any()
+
+
+def _se3_log_np(P):
+    """theseus SE3.log_map restated with scipy / numpy float64: xi = [V^-1 t, omega] (published formulas; th.SE3 itself is not
+    installed here - SURVEY 8(c) lists it among the unpinned third-party pieces)."""
+    R, t = P[:, :3, :3].astype(np.float64), P[:, :3, 3].astype(np.float64)
+    om = Rotation.from_matrix(R).as_rotvec()
+    out = np.zeros((len(P), 6))
+    for k in range(len(P)):
+        th = np.linalg.norm(om[k])
+        W = np.array([[0, -om[k, 2], om[k, 1]], [om[k, 2], 0, -om[k, 0]], [-om[k, 1], om[k, 0], 0]])
+        if th > 1e-6:
+            Vinv = np.eye(3) - 0.5 * W + (1 - th * np.cos(th / 2) / (2 * np.sin(th / 2))) / th**2 * W @ W
+        else:
+            Vinv = np.eye(3) - 0.5 * W + W @ W / 12.0
+        out[k, :3], out[k, 3:] = Vinv @ t[k], om[k]
+    return out
+
+
+def _se3_exp_np(xi):
+    u, om = xi[:3], xi[3:]
+    th = np.linalg.norm(om)
+    W = np.array([[0, -om[2], om[1]], [om[2], 0, -om[0]], [-om[1], om[0], 0]])
+    A, B, C = (np.sin(th) / th, (1 - np.cos(th)) / th**2, (th - np.sin(th)) / th**3) if th > 1e-8 else (1.0, 0.5, 1.0 / 6.0)
+    T = np.eye(4)
+    T[:3, :3] = np.eye(3) + A * W + B * W @ W
+    T[:3, 3] = (np.eye(3) + B * W + C * W @ W) @ u
+    return T
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_per", [[500], [300, 900, 41], [2000, 17, 600, 5, 1200]])
+def test_logmap_centres_all_clusters_at_once(n_per):
+    """get_cluster_centers(method="logmap") - the reference signature's DEFAULT (modules/particle_filter.py:153-206 with
+    pose.log_map_averaged, modules/pose.py:101-109) - against a per-cluster float64 restatement of the reference's loop with
+    scipy's rotation logarithm: weighted mean of the SE(3) logarithms mapped back with exp, the cluster's float32 weights
+    flattened to 1 where isclose(max - min, 0) (:178-184), the spread around the centre's translation (:195-204).  Also: the
+    single-cluster helper gives the same pose, and the result does not depend on the run (fixed reduction order)."""
+    from midastouch_amd.particle_filter import Particles, particle_filter
+    from midastouch_amd.pose import logmap_average_pose
+    dev = torch.device("cuda", 0)
+    poses, w, labels = _clustered(n_per, seed=21, flat=1 if len(n_per) > 1 else None)
+    parts = Particles(torch.as_tensor(poses).to(dev), torch.as_tensor(w).to(dev), torch.as_tensor(labels).to(dev))
+    pf = particle_filter.__new__(particle_filter)
+    cp, cs = pf.get_cluster_centers(parts)  # method="logmap" is the default
+    assert cp.shape == (len(n_per), 4, 4) and cs.shape == (len(n_per), 3) and cp.dtype == torch.float32
+    xi = _se3_log_np(poses)
+    w32 = w.astype(np.float32)
+    for i, lab in enumerate(np.unique(labels)):
+        m = labels == lab
+        tw = w32[m].astype(np.float64)
+        if np.isclose(np.float32(w32[m].max() - w32[m].min()), 0.0):
+            tw = np.ones_like(tw)
+        ref = _se3_exp_np((xi[m] * tw[:, None]).sum(0) / tw.sum())
+        std = np.sqrt((((poses[m, :3, 3].astype(np.float64) - ref[:3, 3]) ** 2) * tw[:, None]).sum(0) / tw.sum())
+        assert np.abs(cp[i].cpu().numpy() - ref).max() < 5e-6, (i, lab)
+        np.testing.assert_allclose(cs[i].cpu().numpy(), std, rtol=2e-4, atol=1e-8)
+        one = logmap_average_pose(parts.poses[torch.as_tensor(m).to(dev)], torch.as_tensor(tw).to(dev))
+        assert np.abs(one.cpu().numpy() - ref).max() < 5e-6
+    cp2, cs2 = pf.get_cluster_centers(parts, method="logmap")
+    assert torch.equal(cp, cp2) and torch.equal(cs, cs2)

@@ -37,7 +37,8 @@ def test_dbscan_matches_reference_fixture(dev, golden):
         assert info.cpu().tolist() == [int(ref.max()) + 1, 0]
 
 
-@pytest.mark.parametrize("case", ["blobs_small_ms", "many_clusters", "chain", "spread20k", "dense", "single", "converged24k", "two_scales"])
+@pytest.mark.parametrize("case", ["blobs_small_ms", "many_clusters", "chain", "spread20k", "dense", "single", "converged24k", "two_scales",
+                                  "wide_hashed", "wide_sparse_hashed", "clusters150", "clusters150_hashed"])
 def test_dbscan_matches_oracle(dev, oracle, case):
     from midastouch_amd import ops
     rng = np.random.default_rng(hash(case) % 1000)
@@ -64,13 +65,46 @@ def test_dbscan_matches_oracle(dev, oracle, case):
     elif case == "two_scales":  # a tight core, a halo around eps (boxes cut by the ball: exact tests) and far noise
         X = np.concatenate([rng.normal(0, 0.001, (6000, 3)), rng.normal(0, 0.006, (6000, 3)), rng.uniform(-0.05, 0.05, (3000, 3))])
         X = X[rng.permutation(len(X))]
+    elif case == "wide_hashed":  # 3 m across at eps = 1e-2: 520 cells per axis - the hash table of occupied cells, not the dense grid
+        cen = rng.uniform(-1.5, 1.5, (6, 3))
+        X = np.concatenate([rng.normal(c, 0.004, (1500, 3)) for c in cen] + [rng.uniform(-1.5, 1.5, (1000, 3))])
+        X = X[rng.permutation(len(X))]
+        ms = 200
+    elif case == "wide_sparse_hashed":  # the wide init_filter start of a big object: nothing clusters, every point its own cell
+        X = rng.normal(0, 0.9, (8000, 3))
+    elif case in ("clusters150", "clusters150_hashed"):  # more clusters than the LDS ranking holds (62): the prefix-sum ranking
+        span = 0.3 if case == "clusters150" else 2.0
+        cen = rng.uniform(-span, span, (150, 3))
+        X = np.concatenate([rng.normal(c, 0.0015, (40, 3)) for c in cen] + [rng.uniform(-span, span, (500, 3))])
+        X = X[rng.permutation(len(X))]
+        ms = 10
     else:
         X = np.zeros((1, 3))
     X = X.astype(np.float32)
     ref, ncl = oracle.dbscan(X, eps, len(X) // 5 if ms < 0 else ms)
+    if case.startswith("clusters150"):
+        assert ncl > 100
+    if case.endswith("hashed"):
+        assert np.ptp(X, axis=0).max() > 128 * 0.577 * eps
     lab, info = ops.dbscan(_poses_of(X, dev), eps, ms)
     assert info.cpu().tolist() == [ncl, 0]
     assert np.array_equal(lab.cpu().numpy(), ref), case
+
+
+def test_cluster_particles_wide_cloud_stays_on_the_device(dev, oracle, recwarn):
+    """particle_filter.cluster_particles on a cloud wider than the dense grid (the regime right after a wide init_filter start
+    on a large object; round 3 warned and called sklearn on the host there): the reference's labels, no warning, no host path."""
+    from midastouch_amd.config import load_config
+    from midastouch_amd.particle_filter import Particles, particle_filter
+    rng = np.random.default_rng(5)
+    X = np.concatenate([rng.normal([0.9, -0.4, 0.2], 0.003, (1200, 3)), rng.normal([-0.8, 0.5, 0.0], 0.003, (1100, 3)),
+                        rng.uniform(-1.0, 1.0, (1700, 3))]).astype(np.float32)
+    X = X[rng.permutation(len(X))]
+    pf = particle_filter(load_config(), np.zeros((8, 3)), 1.0, downsample=1, device=dev)
+    out = pf.cluster_particles(Particles(_poses_of(X, dev)))
+    ref, ncl = oracle.dbscan(X, 1e-2, len(X) // 5)
+    assert ncl == 2 and np.array_equal(out.labels.cpu().numpy(), ref)
+    assert not [w for w in recwarn.list if "cluster_particles" in str(w.message)]
 
 
 @pytest.mark.parametrize("case", ["blobs6", "chain6", "noise6", "border6", "three3", "single"])

@@ -188,6 +188,45 @@ def test_step_isclose_guard_and_raw_weights(dev, oracle, softmax):
         poses = ref["poses"]
 
 
+@pytest.mark.parametrize("engine", ["FilterEngine", "PipelinedFilterEngine"])
+@pytest.mark.parametrize("mode", ["weighted_random", "low_var"])
+def test_step_negative_raw_weights(dev, oracle, engine, mode):
+    """Raw weights of a NEGATIVE cosine: every particle scores the same (identical rows: the isclose guard skips the softmax,
+    particle_filter.py:459-468), the tactile code points away from them, so w = x * mask <= 0 and sum(w) < 0 - the reference
+    resamples with p = w / sum(w) >= 0 (:238).  A lost filter whose cloud has collapsed onto one entry is in this state; the
+    division-free probes of the device's search have to turn their comparison round (resample_search.hpp) - the exact walk
+    kept the indices right before, at hundreds of microseconds a frame.  Indices, weights and poses against the oracle, and
+    the frame must not take the walk's time."""
+    from midastouch_amd import engine as E
+    N, K, D = 9000, 800, 128
+    cb, traj, scale = _setup(N, K, D, seed=5)
+    emb = np.abs(cb.embeddings)
+    emb[:] = emb[0]
+    ofl = oracle.OracleFilter(cb.poses, emb, cb.mesh_vertices)
+    eng = getattr(E, engine)(cb.poses, emb, cb.mesh_vertices, N, seed=4200, resample=mode, device=dev)
+    rng = np.random.default_rng(10)
+    poses = cb.poses[rng.integers(0, K, N)]
+    eng.set_particles(torch.as_tensor(poses))
+    code = -np.abs(traj.codes[1])
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for t in range(1, 5):
+        tn, rot = oracle.philox_noise(N, 4200, t - 1, np.float32(2e-4), np.float32(0.5))
+        if mode == "weighted_random":
+            u, u32 = oracle.philox_uniform64(N, 4200, t - 1), None
+        else:
+            u, u32 = None, oracle.philox_uniform32(4200, t - 1)
+        ref = ofl.step(poses, traj.odoms[t], code, tn, rot, u=u, mode=mode, u32=u32)
+        assert ref["status"] == 0 and ref["weights"].max() <= 0.0 and ref["weights"].min() < 0.0
+        ev[0].record()
+        eng.step(torch.as_tensor(traj.odoms[t]).to(dev), torch.as_tensor(code).to(dev))
+        eng.flush() if hasattr(eng, "flush") else None
+        ev[1].record()
+        _compare_step(eng, ref, t)
+        if t > 1:  # (the first frame loads kernels)
+            assert ev[0].elapsed_time(ev[1]) < 1.0, "the search walked instead of probing"
+        poses = ref["poses"]
+
+
 def test_step_unfused_path_odd_dimension(dev, oracle):
     """D = 96 has no fused-front instantiation: separate scoring and particle-update launches, legacy tail
     (midas_filter_step falls back by itself); same parity bar."""
