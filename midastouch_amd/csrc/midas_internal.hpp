@@ -293,6 +293,10 @@ struct ParticleUpdateArgs {
     LazyResample rs;                          // fused front only
     SparseScore sp;                           // stamps != nullptr: only the rows that are some particle's nearest entry are scored
     PeerInboxSrc inbox;                       // rows != nullptr: particles come from the rank's inbox (unpack folded in; forms without folded resample)
+    // presorted form of the folded resample (k_presort_search / k_presort_group in front of the launch): the waves take their
+    // particles in an order that puts slots with the same nearest-entry hint side by side, and find the slot's source ready
+    const int32_t* pre_order = nullptr;       // [batch x N] rank -> slot
+    const int32_t* pre_src = nullptr;         // [batch x N] rank -> source particle of that slot (what lazy_source returns)
 };
 int particle_update_blocks(int64_t N);
 bool index_build_on_host();  // MIDAS_HOST_INDEX=1: the host builders of round 1 (checkers of the device builders)

@@ -1730,9 +1730,19 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
             a.rs.key_base = o;
             a.rs.traj = traj;
         }
+        if (a.pre_order) { a.pre_order += o; a.pre_src += o; }
     }
-    const int64_t n = wave * 64 + lane;
-    const bool live = n < a.N;
+    // presorted (wave-uniform): lane `rank` of the launch works on slot order[rank] - slots that start from the same codebook
+    // entry sit side by side, so the list records a wave's lanes ask for are mostly the SAME addresses (one look-up, one line)
+    const bool presorted = a.pre_order != nullptr;
+    const int64_t rank = wave * 64 + lane;
+    const bool live = rank < a.N;
+    int64_t n = rank;
+    int32_t src_pre = 0;
+    if (presorted) {
+        n = a.pre_order[live ? rank : 0];
+        src_pre = a.pre_src[live ? rank : 0];
+    }
     if (wave == 0 && lane == 0) {
         if (a.status_reset) { a.status_reset[0] = 0; a.status_reset[1] = 0; }
         if (a.flags_reset) { a.flags_reset[0] = 0.0; a.flags_reset[1] = 0.0; }
@@ -1763,15 +1773,20 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
 #pragma unroll
         for (int i = 0; i < 16; ++i) O[i] = a.odom16[i];
         __builtin_amdgcn_sched_barrier(0);
-        const LazyRecords rec = lazy_records_load(a.rs);
+        LazyRecords rec;
+        if (!presorted) rec = lazy_records_load(a.rs);
         __builtin_amdgcn_sched_barrier(0);
         if (live) noise_odom(n, n + a.slot_base, O, a.tn, a.rot, a.std_t, a.std_r, a.seed, a.step, NO);
-        lazy_tables_wave(a.rs, rec, rs_lds);
+        if (!presorted) lazy_tables_wave(a.rs, rec, rs_lds);
     }
     if (rs_lds && live) {
-        // ablate 8 (profiling): no search, own slot
-        src = (ablate & 8) ? n : lazy_source(a.rs, rs_lds, n, a.N, WT ? LAZY_WAVE_LD : 256);
-        if (a.rs.ridx_out) a.rs.ridx_out[n] = (int32_t)src;
+        if (presorted) {
+            src = src_pre;  // (ridx_out was written by the presort)
+        } else {
+            // ablate 8 (profiling): no search, own slot
+            src = (ablate & 8) ? n : lazy_source(a.rs, rs_lds, n, a.N, WT ? LAZY_WAVE_LD : 256);
+            if (a.rs.ridx_out) a.rs.ridx_out[n] = (int32_t)src;
+        }
     }
     const float* pose_src = rs_lds ? a.rs.poses_prev : a.poses_in;
     // the sharded frame with the unpack folded in (midas_shard_run): the particle of slot n is row n of this rank's inbox, stored
@@ -2367,6 +2382,134 @@ int launch_particle_update(midas_ctx* ctx, const midas_tree* t6, const midas_tre
 }
 
 // fused front: returns MIDAS_ERR_UNSUPPORTED-like 1 when the codebook layout has no fused instantiation
+// =================================================================================================
+// presort: the folded resample's sources, and an execution order that groups the slots by their hint
+// =================================================================================================
+// A particle wave's list scans start from the hinted entry's neighbour and vertex lists.  In slot order a wave's 64 particles start
+// from ~50 different entries (c5, frames 20 - 70: the set sits on 200 - 600 entries per trajectory, the multinomial draws scatter
+// them over the slots), so every list record a wave touches is a look-up and a line of its own; in an order that keeps equal hints
+// together it is 3 - 5 entries per wave: the lanes ask for the SAME addresses.  The hint of slot n is nn_prev[src(n)] - known once
+// the resample search is done - so the search moves out of the front into k_presort_search (one lane per slot, the front's own
+// functions: same sources), and k_presort_group builds the order per chunk of 16384 slots in one workgroup: an LDS hash table of
+// the chunk's hints (count per hint, first come first served), an exclusive scan of the counts, a scatter.  The order inside a
+// group is whatever the LDS atomics made it; nothing depends on it (a particle's arithmetic does not know its lane).
+constexpr int PS_CHUNK = 16384, PS_THREADS = 1024, PS_PER = PS_CHUNK / PS_THREADS, PS_TAB = 8192;
+
+MD void presort_offset_traj(ParticleUpdateArgs& a, int traj) {
+    if (!traj) return;
+    const int64_t b = traj, o = b * a.N, ts = b * a.rs.tstride;
+    a.rs.e += ts; a.rs.x_raw += ts; a.rs.lp += ts; a.rs.lp_raw += ts; a.rs.gend += ts; a.rs.gend_raw += ts;
+    a.rs.ggend += ts; a.rs.ggend_raw += ts; a.rs.bsum_e += ts; a.rs.btot += ts; a.rs.btot_raw += ts; a.rs.bmax += ts; a.rs.bmin += ts;
+    a.rs.poses_prev += o * 16; a.rs.nn_prev += o; a.rs.status_prev += 2 * b;
+    if (a.rs.ridx_out) a.rs.ridx_out += o;
+    if (a.rs.u) a.rs.u += o;
+    a.rs.key_base = o;
+    a.rs.traj = traj;
+}
+
+// slot n -> src[n] (= lazy_source, what the front computes for itself otherwise), hint[n] = nn_prev[src]; one-wave workgroups
+__global__ __launch_bounds__(64) void k_presort_search(ParticleUpdateArgs a, int32_t* __restrict__ src_out, int32_t* __restrict__ hint_out) {
+    __shared__ double s_rs[LAZY_WAVE_LDS];
+    const int traj = (int)blockIdx.y, lane = threadIdx.x;
+    const int64_t o = (int64_t)traj * a.N;
+    presort_offset_traj(a, traj);
+    const LazyRecords rec = lazy_records_load(a.rs);
+    lazy_tables_wave(a.rs, rec, s_rs);
+    const int64_t n = (int64_t)blockIdx.x * 64 + lane;
+    if (n >= a.N) return;
+    const int64_t src = lazy_source(a.rs, s_rs, n, a.N, LAZY_WAVE_LD);
+    if (a.rs.ridx_out) a.rs.ridx_out[n] = (int32_t)src;
+    src_out[o + n] = (int32_t)src;
+    hint_out[o + n] = a.rs.nn_prev[src];
+}
+
+// chunk c of trajectory b: order[o + base + pos] = slot, srcr[o + base + pos] = its source, equal hints adjacent
+__global__ __launch_bounds__(PS_THREADS) void k_presort_group(int64_t N, const int32_t* __restrict__ src, const int32_t* __restrict__ hint,
+                                                              int32_t* __restrict__ order, int32_t* __restrict__ srcr) {
+    __shared__ int s_key[PS_TAB];
+    __shared__ int s_cnt[PS_TAB];
+    __shared__ int s_w[PS_THREADS / 64];
+    __shared__ int s_fail;
+    const int t = threadIdx.x;
+    const int64_t o = (int64_t)blockIdx.y * N, base = (int64_t)blockIdx.x * PS_CHUNK;
+    const int64_t end = base + PS_CHUNK < N ? base + PS_CHUNK : N;
+    for (int i = t; i < PS_TAB; i += PS_THREADS) { s_key[i] = -2; s_cnt[i] = 0; }
+    if (t == 0) s_fail = 0;
+    __syncthreads();
+    int slot[PS_PER], rk[PS_PER], sv[PS_PER];
+    int32_t hv[PS_PER];
+#pragma unroll
+    for (int j = 0; j < PS_PER; ++j) {  // the chunk's hints and sources: coalesced, all in flight together
+        const int64_t n = base + (int64_t)j * PS_THREADS + t;
+        const int64_t nc = n < end ? n : end - 1;
+        hv[j] = hint[o + nc];
+        sv[j] = src[o + nc];
+    }
+#pragma unroll
+    for (int j = 0; j < PS_PER; ++j) {
+        const int64_t n = base + (int64_t)j * PS_THREADS + t;
+        slot[j] = -1; rk[j] = 0;
+        if (n < end) {
+            const int key = hv[j] < 0 ? -1 : hv[j];
+            unsigned h = ((unsigned)key * 2654435761u) >> 19;  // 13 bits
+            for (int probe = 0; probe < 64; ++probe) {
+                const int old = atomicCAS(&s_key[h], -2, key);
+                if (old == -2 || old == key) { slot[j] = (int)h; rk[j] = atomicAdd(&s_cnt[h], 1); break; }
+                h = (h + 1) & (PS_TAB - 1);
+            }
+            if (slot[j] < 0) s_fail = 1;  // more distinct hints than the table takes: slot order for this chunk
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the PS_TAB counts: eight per thread
+    constexpr int E = PS_TAB / PS_THREADS;
+    int v[E], mine = 0;
+#pragma unroll
+    for (int k = 0; k < E; ++k) { v[k] = s_cnt[t * E + k]; mine += v[k]; }
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int x = __shfl_up(incl, d);
+        if ((t & 63) >= d) incl += x;
+    }
+    if ((t & 63) == 63) s_w[t >> 6] = incl;
+    __syncthreads();
+    int run = incl - mine;
+    for (int w = 0; w < (t >> 6); ++w) run += s_w[w];
+    const bool fail = s_fail != 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < E; ++k) { s_cnt[t * E + k] = run; run += v[k]; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PS_PER; ++j) {
+        const int64_t n = base + (int64_t)j * PS_THREADS + t;
+        if (n < end) {
+            const int64_t pos = fail ? n - base : (int64_t)(s_cnt[slot[j]] + rk[j]);
+            order[o + base + pos] = (int32_t)n;
+            srcr[o + base + pos] = sv[j];
+        }
+    }
+}
+
+// the two launches in front of a frame front with folded resample and per-wave tables; fills a.pre_order / a.pre_src
+static int launch_presort(midas_ctx* ctx, ParticleUpdateArgs& a) {
+    void *p_src, *p_hint, *p_order, *p_srcr;
+    const size_t bytes = (size_t)a.batch * (size_t)a.N * sizeof(int32_t);
+    int rc;
+    if ((rc = midas_scratch(ctx, bytes, &p_src))) return rc;
+    if ((rc = midas_scratch(ctx, bytes, &p_hint))) return rc;
+    if ((rc = midas_scratch(ctx, bytes, &p_order))) return rc;
+    if ((rc = midas_scratch(ctx, bytes, &p_srcr))) return rc;
+    hipLaunchKernelGGL(k_presort_search, dim3((unsigned)ceil_div(a.N, 64), (unsigned)a.batch), dim3(64), 0, ctx->stream, a, (int32_t*)p_src, (int32_t*)p_hint);
+    hipLaunchKernelGGL(k_presort_group, dim3((unsigned)ceil_div(a.N, PS_CHUNK), (unsigned)a.batch), dim3(PS_THREADS), 0, ctx->stream, a.N,
+                       (const int32_t*)p_src, (const int32_t*)p_hint, (int32_t*)p_order, (int32_t*)p_srcr);
+    MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    a.pre_order = (const int32_t*)p_order;
+    a.pre_src = (const int32_t*)p_srcr;
+    return MIDAS_OK;
+}
+
 int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t3, const ParticleUpdateArgs& a_in,
                        const midas_codebook* cb, const double* code, double* scores, bool* launched) {
     *launched = false;
@@ -2447,6 +2590,17 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
     const int fw = a.batch > 1 ? 1 : (a.rs.enabled && !wave_tables) ? 4 : fw_env == 1 || fw_env == 4 ? fw_env : (a.sp.stamps ? 1 : 4);
     const int n_pu_fw = (nwaves + fw - 1) / fw;
     if (!use_list) { a.sp.pred_tag = 0; a.sp.list = nullptr; }
+    // presort (see k_presort_search): MIDAS_PRESORT=1.  OFF by default - measured (profiles/r04_c5_presort.txt): at c5 the sorted
+    // waves do start from 3 - 5 entries instead of 50 and the best frames' front drops from ~250 to 150 us, but a hard entry's
+    // particles now sit in the SAME waves: their cooperative continuations (one owner's list per pass) queue up inside a wave
+    // instead of spreading over the launch, the front swings between 180 and 480 us, and the two extra launches cost 53 us
+    // (362 against 314 us per batch frame); at c2 the launches cost more than the front's whole list phase (14.5k against 23.7k steps/s).
+    // What the order needs to pay off is a scan that serves all the wave's owners of one entry from ONE fetch of its records.
+    static const int presort_env = getenv("MIDAS_PRESORT") ? atoi(getenv("MIDAS_PRESORT")) : 0;
+    if (wave_tables && fw == 1 && !a.inbox.rows && !a.ablate && !a.n_live && presort_env == 1) {
+        const int rc = launch_presort(ctx, a);
+        if (rc) return rc;
+    }
     const unsigned grid_fw = (unsigned)(n_pu_fw + (a.sp.stamps ? (use_list ? (list_wgs_env + fw - 1) / fw : 0) : ceil_div(cb->K, 4 * fw)));
     // profiling instantiations (MIDAS_ABLATE != 0; D = 512, one-wave workgroups): phase clocks, scan statistics, ablation switches
     if (a.ablate && cb->D == 512 && fw == 1) {
