@@ -286,7 +286,7 @@ def parity_mode_rate(cb, traj, N, dev, tree, mesh_tree, steps=100):
     dt = time.perf_counter() - t0
     return {"steps_per_sec": steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
             "draws": "resample: device replica of torch's CPU mt19937 under torch.manual_seed(3000) (torch.rand(N, float64) stream, "
-                     "generated on the stream before each frame); motion noise: device Philox",
+                     "generated on the generator's own stream beside each frame's kernels); motion noise: device Philox",
             "status": eng.status.cpu().numpy().tolist()}
 
 
@@ -688,9 +688,9 @@ def main():
         achieved = needed / (groups[dom] * 1e-3) / 1e9
         survey = ab[dom] / (groups[dom] * 1e-3) / 1e9
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (PMC counters
-        # cannot be read from inside the process): profiles/r03_traffic.json, tools/pmc_traffic.sh
+        # cannot be read from inside the process): profiles/r04_traffic.json, tools/pmc_traffic.sh
         traffic, traffic_src = None, None
-        for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(REPO, "profiles", name)))
                 traffic, traffic_src = tj["kernels"][dom]["hbm_bytes"], "profiles/" + name

@@ -1698,7 +1698,8 @@ MD int64_t lazy_source(const LazyResample& rs, const double* rs_lds, int64_t n, 
 // where two waves per SIMD are all the launch needs, N <= 131072 in one-wave workgroups)
 // STATS (profiling instantiations only, chosen by MIDAS_ABLATE != 0): per-wave phase clocks, scan statistics and the ablation
 // switches; the production instantiations read no clock and test no switch
-template <bool WT = false, bool SCREEN = false, bool PREF = false, bool STATS = false>
+// PRES: the presorted form (pre_order / pre_src, batch kernels only) is compiled in; elsewhere the arguments are ignored
+template <bool WT = false, bool SCREEN = false, bool PREF = false, bool STATS = false, bool PRES = false>
 MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, ParticleUpdateArgs a, int64_t wave,
                              int nwaves, int traj, double* s_cd, double* rs_lds = nullptr) {
     const int lane = threadIdx.x & 63;
@@ -1734,7 +1735,7 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
     }
     // presorted (wave-uniform): lane `rank` of the launch works on slot order[rank] - slots that start from the same codebook
     // entry sit side by side, so the list records a wave's lanes ask for are mostly the SAME addresses (one look-up, one line)
-    const bool presorted = a.pre_order != nullptr;
+    const bool presorted = PRES && a.pre_order != nullptr;
     const int64_t rank = wave * 64 + lane;
     const bool live = rank < a.N;
     int64_t n = rank;
@@ -1985,7 +1986,7 @@ __global__ __launch_bounds__(64 * FW, (!SCR && FW == 1) ? MIDAS_BATCH_OCC : 1) v
             // one-wave workgroups = the small-set regime (see launch_frame_front): screened scans
             constexpr bool SCREEN = FW == 1 && MIDAS_SCREEN && SCR;
             const int traj = (int)by;
-            if (LAZY == 2) particle_update_wave<true, SCREEN, PREF, STATS>(t6, t3, a, wave, nwaves, traj, s_cd[w], s_rs + w * LAZY_WAVE_LDS);
+            if (LAZY == 2) particle_update_wave<true, SCREEN, PREF, STATS, !SCR && !STATS>(t6, t3, a, wave, nwaves, traj, s_cd[w], s_rs + w * LAZY_WAVE_LDS);
             else particle_update_wave<false, SCREEN, PREF, STATS>(t6, t3, a, wave, nwaves, traj, s_cd[w], LAZY ? s_rs : nullptr);
         }
     } else if (a.sp.list) {  // prediction list: the rows the previous frame used, four per wave-instruction
@@ -2594,10 +2595,13 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
     // waves do start from 3 - 5 entries instead of 50 and the best frames' front drops from ~250 to 150 us, but a hard entry's
     // particles now sit in the SAME waves: their cooperative continuations (one owner's list per pass) queue up inside a wave
     // instead of spreading over the launch, the front swings between 180 and 480 us, and the two extra launches cost 53 us
-    // (362 against 314 us per batch frame); at c2 the launches cost more than the front's whole list phase (14.5k against 23.7k steps/s).
+    // (362 against 314 us per batch frame); at c2 (tried with a build that had it there too) the launches cost more than the front's
+    // whole list phase (14.5k against 23.7k steps/s).
     // What the order needs to pay off is a scan that serves all the wave's owners of one entry from ONE fetch of its records.
+    // (compiled into the batch kernels only - SCR = false: in the single-trajectory front the two branches cost 2 us of a 27 us kernel
+    // even when not taken)
     static const int presort_env = getenv("MIDAS_PRESORT") ? atoi(getenv("MIDAS_PRESORT")) : 0;
-    if (wave_tables && fw == 1 && !a.inbox.rows && !a.ablate && !a.n_live && presort_env == 1) {
+    if (wave_tables && fw == 1 && a.batch > 1 && !a.inbox.rows && !a.ablate && !a.n_live && presort_env == 1) {
         const int rc = launch_presort(ctx, a);
         if (rc) return rc;
     }

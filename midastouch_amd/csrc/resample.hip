@@ -10,6 +10,10 @@
 #include "resample_search.hpp"
 #include "tail_block.hpp"
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "the peer-mapped route kernel's completion protocol relies on gfx942 / gfx950 write-through store acknowledgement (see k_shard_route_*)"
+#endif
+
 namespace midas {
 
 constexpr double ISCLOSE_ATOL = 1e-8;  // torch.isclose default atol (particle_filter.py:460-463)
@@ -1457,7 +1461,9 @@ __global__ __launch_bounds__(256) void k_shard_route(ShardRouteArgs a) {
         peer_rows_store(s_stage[w], s_dst[w], __popcll(mm));
         if (a.own_inbox) {
             // The barrier waits for every wave's outstanding stores (s_waitcnt vmcnt(0) in front of s_barrier), and the row
-            // stores are system-scope write-through stores: acknowledged = performed at the destination.  So the count needs
+            // stores are system-scope write-through stores: acknowledged = performed at the destination.  (That is a property of
+            // gfx942 / gfx950's memory system, not of the programming model - which would want a release on every workgroup's
+            // add: the build refuses any other target, below.)  So the count needs
             // no release of its own (a release fence here is a write-back of the XCD's whole L2 per workgroup: measured,
             // +7 us per launch); the workgroup that sees the full count publishes with a system-scope release store.
             __syncthreads();

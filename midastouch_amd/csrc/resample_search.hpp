@@ -18,9 +18,11 @@ MD int64_t search_in_block(const double* __restrict__ lp, const double* __restri
     // of a negative cosine; p = w / sum(w) is positive again (:238) and dividing by the negative total turns the comparison
     // round.  Without the turn the division-free probes point the wrong way and the exact walk below crosses the whole block
     // one dependent load at a time: 100 - 400 us frames of a lost, collapsed cloud at N = 1000, found with the c1 trajectory.)
-    const double tt = tq * total;
-    const bool neg = total < 0.0;
-    auto left = [&](double c) { return neg ? (upper ? (c >= tt) : (c > tt)) : (upper ? (c <= tt) : (c < tt)); };
+    // The turn costs nothing per probe: with sg = -1 for a negative total, sg (bp + v) = fma(sg, v, sg bp) is the same sum with
+    // the sign flipped (rounding is symmetric; for sg = 1 it IS bp + v), compared against sg tq total on the usual side.
+    const double sg = total < 0.0 ? -1.0 : 1.0;
+    const double tt = sg * (tq * total), sbp = sg * bp;
+    auto left = [&](double v_) { const double c = fma_(sg, v_, sbp); return upper ? (c <= tt) : (c < tt); };  // v_ = block-local prefix
     auto left_exact = [&](double c) { return upper ? (c <= tq) : (c < tq); };
     const int64_t b_lo = (int64_t)b << 12, b_hi = b_lo + SCAN_BLOCK < N ? b_lo + SCAN_BLOCK : N;
     // Three levels, one 128-byte line each (16 prefix values fetched together with eight aligned 16-byte loads,
@@ -36,14 +38,14 @@ MD int64_t search_in_block(const double* __restrict__ lp, const double* __restri
     fetch16(ggend + (int64_t)b * 16);
     int g = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) g += (j < n_groups && left(bp + v[j])) ? 1 : 0;
+    for (int j = 0; j < 16; ++j) g += (j < n_groups && left(v[j])) ? 1 : 0;
     g = g < n_groups ? g : n_groups - 1;
     const int64_t c0 = (b_lo >> 4) + 16 * g;
     fetch16(gend + c0);
     const int n_in_group = n_chunks - 16 * g < 16 ? n_chunks - 16 * g : 16;
     int c = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) c += (j < n_in_group && left(bp + v[j])) ? 1 : 0;
+    for (int j = 0; j < 16; ++j) c += (j < n_in_group && left(v[j])) ? 1 : 0;
     c = c < n_in_group ? c : n_in_group - 1;
     const int64_t s0 = (c0 + c) << 4;
     double v_prev = lp[s0 > b_lo ? s0 - 1 : b_lo];  // the slot before the chunk (same block)
@@ -53,7 +55,7 @@ MD int64_t search_in_block(const double* __restrict__ lp, const double* __restri
     asm volatile("" : "+v"(v_prev));
     int pos = 0;
 #pragma unroll
-    for (int j = 0; j < SCAN_CHUNK; ++j) pos += (s0 + j < b_hi && left(bp + v[j])) ? 1 : 0;
+    for (int j = 0; j < SCAN_CHUNK; ++j) pos += (s0 + j < b_hi && left(v[j])) ? 1 : 0;
     int64_t l2 = s0 + pos;
     // exact fix-up: the predicate on cdf_i is monotone in i; the two neighbours of the boundary are normally in
     // registers, otherwise walk (inside the block: its end is exact)
