@@ -297,6 +297,8 @@ struct ParticleUpdateArgs {
     // particles in an order that puts slots with the same nearest-entry hint side by side, and find the slot's source ready
     const int32_t* pre_order = nullptr;       // [batch x N] rank -> slot
     const int32_t* pre_src = nullptr;         // [batch x N] rank -> source particle of that slot (what lazy_source returns)
+    double* pre_rmse_terms = nullptr;         // [batch x N x 2] with gt16: the particles' rmse terms BY SLOT - the per-wave sums the tail
+                                              // reads are formed from them in slot order (k_rmse_parts), as the unsorted launch forms them
 };
 int particle_update_blocks(int64_t N);
 bool index_build_on_host();  // MIDAS_HOST_INDEX=1: the host builders of round 1 (checkers of the device builders)

@@ -1655,7 +1655,10 @@ MD void lazy_tables_wave(const LazyResample& rs, const LazyRecords& r, double* r
 
 // Per-lane part: the source particle of slot n (what k_tail_b2 writes to ridx[n]).
 // ld = stride of the table block: 256 (lazy_tables, one block per workgroup) or LAZY_WAVE_LD (lazy_tables_wave)
-MD int64_t lazy_source(const LazyResample& rs, const double* rs_lds, int64_t n, int64_t N, int ld = 256) {
+// gend_lds / lp_lds (both or gend_lds alone): the caller's LDS copies of the chunk-end / per-slot tables
+template <typename GT = const double*, typename LT = const double*>
+MD int64_t lazy_source(const LazyResample& rs, const double* rs_lds, int64_t n, int64_t N, int ld = 256, GT gend_lds = nullptr,
+                       LT lp_lds = nullptr) {
     const double* s_bp = rs_lds;
     const double* s_end = rs_lds + ld;
     const double total = rs_lds[2 * ld];
@@ -1684,7 +1687,10 @@ MD int64_t lazy_source(const LazyResample& rs, const double* rs_lds, int64_t n, 
         if (left_exact(s_end[mid])) lo = mid + 1; else hi = mid;
     }
     if (lo >= rs.nb) return N - 1;
-    return search_in_block(lp, gend, apply ? rs.ggend : rs.ggend_raw, lo, N, N - 1, s_bp[lo], total, tq, upper);
+    if constexpr (__is_same(LT, lds_cdp))
+        return search_in_block_t<lds_cdp, GT>(lp_lds, gend, apply ? rs.ggend : rs.ggend_raw, lo, N, N - 1, s_bp[lo], total, tq, upper, gend_lds);
+    else
+        return search_in_block_t<const double*, GT>(lp, gend, apply ? rs.ggend : rs.ggend_raw, lo, N, N - 1, s_bp[lo], total, tq, upper, gend_lds);
 }
 
 // =================================================================================================
@@ -1731,7 +1737,7 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
             a.rs.key_base = o;
             a.rs.traj = traj;
         }
-        if (a.pre_order) { a.pre_order += o; a.pre_src += o; }
+        if (a.pre_order) { a.pre_order += o; a.pre_src += o; if (a.pre_rmse_terms) a.pre_rmse_terms += 2 * o; }
     }
     // presorted (wave-uniform): lane `rank` of the launch works on slot order[rank] - slots that start from the same codebook
     // entry sit side by side, so the list records a wave's lanes ask for are mostly the SAME addresses (one look-up, one line)
@@ -1912,9 +1918,15 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
         if (lane == 0) { a.part_max[wave] = mx; a.part_min[wave] = mn; }
     }
     if (a.gt16) {
-        et2 = wave_sum(et2);
-        ang2 = wave_sum(ang2);
-        if (lane == 0) { a.part_rmse[2 * wave] = et2; a.part_rmse[2 * wave + 1] = ang2; }
+        if (presorted && a.pre_rmse_terms) {
+            // a presorted wave holds other slots than 64 wave .. 64 wave + 63: its sum would be a different (and, the order inside
+            // a group being what the LDS atomics made it, run-dependent) grouping of the same terms.  The terms go out by slot.
+            if (live) reinterpret_cast<double2*>(a.pre_rmse_terms)[n] = make_double2(et2, ang2);
+        } else {
+            et2 = wave_sum(et2);
+            ang2 = wave_sum(ang2);
+            if (lane == 0) { a.part_rmse[2 * wave] = et2; a.part_rmse[2 * wave + 1] = ang2; }
+        }
     }
     if (STATS && a.telemetry && (ablate & 4) && lane == 0) {
         // MIDAS_ABLATE=4: per-wave scan statistics and phase clocks, plain stores into the wave's own 16 slots
@@ -2394,7 +2406,9 @@ int launch_particle_update(midas_ctx* ctx, const midas_tree* t6, const midas_tre
 // functions: same sources), and k_presort_group builds the order per chunk of 16384 slots in one workgroup: an LDS hash table of
 // the chunk's hints (count per hint, first come first served), an exclusive scan of the counts, a scatter.  The order inside a
 // group is whatever the LDS atomics made it; nothing depends on it (a particle's arithmetic does not know its lane).
-constexpr int PS_CHUNK = 16384, PS_THREADS = 1024, PS_PER = PS_CHUNK / PS_THREADS, PS_TAB = 8192;
+constexpr int PS_CHUNK = 4096, PS_THREADS = 1024, PS_PER = PS_CHUNK / PS_THREADS, PS_TAB = 4096;  // (chunks of 16384 slots in one workgroup
+// a trajectory: 18 us of serialised LDS atomics on 64 of the 256 CUs)
+constexpr int PS_GEND_MAX = 2048;  // chunk ends the search kernel stages in LDS (N <= 32768); beyond, the two line fetches
 
 MD void presort_offset_traj(ParticleUpdateArgs& a, int traj) {
     if (!traj) return;
@@ -2408,25 +2422,41 @@ MD void presort_offset_traj(ParticleUpdateArgs& a, int traj) {
     a.rs.traj = traj;
 }
 
-// slot n -> src[n] (= lazy_source, what the front computes for itself otherwise), hint[n] = nn_prev[src]; one-wave workgroups
-__global__ __launch_bounds__(64) void k_presort_search(ParticleUpdateArgs a, int32_t* __restrict__ src_out, int32_t* __restrict__ hint_out) {
-    __shared__ double s_rs[LAZY_WAVE_LDS];
-    const int traj = (int)blockIdx.y, lane = threadIdx.x;
+// slot n -> src[n] (= lazy_source, what the front computes for itself otherwise), hint[n] = nn_prev[src].  Four waves a workgroup:
+// every wave builds the block tables for itself (lazy_tables_wave), then the four copy the trajectory's chunk-end table (the
+// softmax or the raw variant, as the guard decided) into LDS - N = 10 000: 5 KB - and a lane finds its chunk there; the scattered
+// fetches of a search drop from 25 sixteen-byte pieces to 9 (this kernel is bound by the vector cache's look-up rate: 35 -> 15 us).
+__global__ __launch_bounds__(256) void k_presort_search(ParticleUpdateArgs a, int32_t* __restrict__ src_out, int32_t* __restrict__ hint_out) {
+    __shared__ double s_rs[4][LAZY_WAVE_LDS];
+    __shared__ double s_gend[PS_GEND_MAX];
+    const int traj = (int)blockIdx.y, t = threadIdx.x, w = t >> 6, lane = t & 63;
     const int64_t o = (int64_t)traj * a.N;
     presort_offset_traj(a, traj);
     const LazyRecords rec = lazy_records_load(a.rs);
-    lazy_tables_wave(a.rs, rec, s_rs);
-    const int64_t n = (int64_t)blockIdx.x * 64 + lane;
+    lazy_tables_wave(a.rs, rec, s_rs[w]);
+    const bool staged = a.rs.ng <= PS_GEND_MAX;
+    if (staged) {
+        const bool apply = s_rs[w][2 * LAZY_WAVE_LD + 2] != 0.0;  // (every wave computes the same guard)
+        const double* __restrict__ g = apply ? a.rs.gend : a.rs.gend_raw;
+        for (int i = t; i < a.rs.ng; i += 256) s_gend[i] = g[i];
+        __syncthreads();
+    }
+    const int64_t n = (int64_t)blockIdx.x * 256 + t;
     if (n >= a.N) return;
-    const int64_t src = lazy_source(a.rs, s_rs, n, a.N, LAZY_WAVE_LD);
+    const int64_t src = staged ? lazy_source<lds_cdp>(a.rs, s_rs[w], n, a.N, LAZY_WAVE_LD, (lds_cdp)s_gend)
+                               : lazy_source(a.rs, s_rs[w], n, a.N, LAZY_WAVE_LD);
     if (a.rs.ridx_out) a.rs.ridx_out[n] = (int32_t)src;
     src_out[o + n] = (int32_t)src;
     hint_out[o + n] = a.rs.nn_prev[src];
+    (void)lane;
 }
 
 // chunk c of trajectory b: order[o + base + pos] = slot, srcr[o + base + pos] = its source, equal hints adjacent
+// deal > 0: the grouped sequence is dealt to the chunk's waves in runs of `deal` slots (wave w takes runs w, w + W, ...): a wave
+// then holds 64 / deal entries' particles instead of one entry's - the particles of a hard entry (whose cooperative
+// continuations serve one owner per pass) spread over many waves again, while `deal` lanes still ask for the same records.
 __global__ __launch_bounds__(PS_THREADS) void k_presort_group(int64_t N, const int32_t* __restrict__ src, const int32_t* __restrict__ hint,
-                                                              int32_t* __restrict__ order, int32_t* __restrict__ srcr) {
+                                                              int32_t* __restrict__ order, int32_t* __restrict__ srcr, int deal) {
     __shared__ int s_key[PS_TAB];
     __shared__ int s_cnt[PS_TAB];
     __shared__ int s_w[PS_THREADS / 64];
@@ -2452,7 +2482,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_presort_group(int64_t N, const i
         slot[j] = -1; rk[j] = 0;
         if (n < end) {
             const int key = hv[j] < 0 ? -1 : hv[j];
-            unsigned h = ((unsigned)key * 2654435761u) >> 19;  // 13 bits
+            unsigned h = ((unsigned)key * 2654435761u) >> 20;  // 12 bits
             for (int probe = 0; probe < 64; ++probe) {
                 const int old = atomicCAS(&s_key[h], -2, key);
                 if (old == -2 || old == key) { slot[j] = (int)h; rk[j] = atomicAdd(&s_cnt[h], 1); break; }
@@ -2486,11 +2516,122 @@ __global__ __launch_bounds__(PS_THREADS) void k_presort_group(int64_t N, const i
     for (int j = 0; j < PS_PER; ++j) {
         const int64_t n = base + (int64_t)j * PS_THREADS + t;
         if (n < end) {
-            const int64_t pos = fail ? n - base : (int64_t)(s_cnt[slot[j]] + rk[j]);
+            int64_t pos = fail ? n - base : (int64_t)(s_cnt[slot[j]] + rk[j]);
+            const int64_t W = (end - base) >> 6;  // whole waves of the chunk; the ragged rest keeps its place
+            if (deal > 0 && !fail && pos < (W << 6)) {
+                const int64_t q = pos / deal, within = pos - q * deal;
+                pos = ((q % W) << 6) + (q / W) * deal + within;
+            }
             order[o + base + pos] = (int32_t)n;
             srcr[o + base + pos] = sv[j];
         }
     }
+}
+
+// Both steps in ONE kernel for trajectories of up to PS_LP_MAX particles (c5: 10 000): a workgroup stages the trajectory's whole
+// per-slot prefix table (80 KB) and its chunk-end table in LDS - coalesced - and every level of its slots' searches reads LDS;
+// the only scattered fetch left is the hint nn_prev[src].  (The two-kernel form is bound by the vector cache's look-up rate on
+// the searches' line fetches: 26 + 11 us at c5; this one is a launch less and ~12 us.)  Same sources, same grouping.
+constexpr int PS_LP_MAX = 10240;
+struct PresortLds {  // dynamic LDS of k_presort_fused
+    double lp[PS_LP_MAX];
+    double gend[PS_LP_MAX / SCAN_CHUNK];
+    double rs[PS_THREADS / 64][LAZY_WAVE_LDS];
+    int key[PS_TAB];
+    int cnt[PS_TAB];
+    int w[PS_THREADS / 64];
+    int fail;
+};
+__global__ __launch_bounds__(PS_THREADS) void k_presort_fused(ParticleUpdateArgs a, int32_t* __restrict__ order, int32_t* __restrict__ srcr, int deal) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ps_raw[];
+    PresortLds& L = *reinterpret_cast<PresortLds*>(ps_raw);
+    const int traj = (int)blockIdx.y, t = threadIdx.x, wv = t >> 6;
+    const int64_t N = a.N, o = (int64_t)traj * N, base = (int64_t)blockIdx.x * PS_CHUNK;
+    const int64_t end = base + PS_CHUNK < N ? base + PS_CHUNK : N;
+    presort_offset_traj(a, traj);
+    const LazyRecords rec = lazy_records_load(a.rs);
+    lazy_tables_wave(a.rs, rec, L.rs[wv]);
+    {
+        const bool apply = L.rs[wv][2 * LAZY_WAVE_LD + 2] != 0.0;  // (every wave computes the same guard)
+        const double2* __restrict__ lsrc = reinterpret_cast<const double2*>(apply ? a.rs.lp : a.rs.lp_raw);  // padded to 16 values (tables_of)
+        const int n2 = (int)((N + 1) >> 1);
+        for (int i = t; i < n2; i += PS_THREADS) reinterpret_cast<double2*>(L.lp)[i] = lsrc[i];
+        const double* __restrict__ g = apply ? a.rs.gend : a.rs.gend_raw;
+        for (int i = t; i < a.rs.ng; i += PS_THREADS) L.gend[i] = g[i];
+        for (int i = t; i < PS_TAB; i += PS_THREADS) { L.key[i] = -2; L.cnt[i] = 0; }
+        if (t == 0) L.fail = 0;
+    }
+    __syncthreads();
+    int slot[PS_PER], rk[PS_PER], sv[PS_PER];
+    int32_t hv[PS_PER];
+#pragma unroll
+    for (int j = 0; j < PS_PER; ++j) {
+        const int64_t n = base + (int64_t)j * PS_THREADS + t;
+        sv[j] = 0; hv[j] = -1;
+        if (n < end) {
+            const int64_t src = lazy_source<lds_cdp, lds_cdp>(a.rs, L.rs[wv], n, N, LAZY_WAVE_LD, (lds_cdp)L.gend, (lds_cdp)L.lp);
+            if (a.rs.ridx_out) a.rs.ridx_out[n] = (int32_t)src;
+            sv[j] = (int)src;
+            hv[j] = a.rs.nn_prev[src];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PS_PER; ++j) {
+        const int64_t n = base + (int64_t)j * PS_THREADS + t;
+        slot[j] = -1; rk[j] = 0;
+        if (n < end) {
+            const int key = hv[j] < 0 ? -1 : hv[j];
+            unsigned h = ((unsigned)key * 2654435761u) >> 20;  // 12 bits
+            for (int probe = 0; probe < 64; ++probe) {
+                const int old = atomicCAS(&L.key[h], -2, key);
+                if (old == -2 || old == key) { slot[j] = (int)h; rk[j] = atomicAdd(&L.cnt[h], 1); break; }
+                h = (h + 1) & (PS_TAB - 1);
+            }
+            if (slot[j] < 0) L.fail = 1;
+        }
+    }
+    __syncthreads();
+    constexpr int E = PS_TAB / PS_THREADS;
+    int v[E], mine = 0;
+#pragma unroll
+    for (int k = 0; k < E; ++k) { v[k] = L.cnt[t * E + k]; mine += v[k]; }
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int x = __shfl_up(incl, d);
+        if ((t & 63) >= d) incl += x;
+    }
+    if ((t & 63) == 63) L.w[t >> 6] = incl;
+    __syncthreads();
+    int run = incl - mine;
+    for (int w = 0; w < (t >> 6); ++w) run += L.w[w];
+    const bool fail = L.fail != 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < E; ++k) { L.cnt[t * E + k] = run; run += v[k]; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PS_PER; ++j) {
+        const int64_t n = base + (int64_t)j * PS_THREADS + t;
+        if (n < end) {
+            int64_t pos = fail ? n - base : (int64_t)(L.cnt[slot[j]] + rk[j]);
+            const int64_t W = (end - base) >> 6;
+            if (deal > 0 && !fail && pos < (W << 6)) {
+                const int64_t q = pos / deal, within = pos - q * deal;
+                pos = ((q % W) << 6) + (q / W) * deal + within;
+            }
+            order[o + base + pos] = (int32_t)n;
+            srcr[o + base + pos] = sv[j];
+        }
+    }
+}
+
+// per-wave rmse sums in SLOT order from the presorted front's per-slot terms: exactly what an unsorted wave leaves in part_rmse
+__global__ __launch_bounds__(64) void k_rmse_parts(int64_t N, int nwaves, const double* __restrict__ terms, double* __restrict__ part_rmse) {
+    const int64_t b = blockIdx.y, n = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const double2 v = n < N ? reinterpret_cast<const double2*>(terms + 2 * b * N)[n] : make_double2(0.0, 0.0);
+    const double p = wave_sum(v.x), q = wave_sum(v.y);
+    if (threadIdx.x == 0) { part_rmse[2 * (b * nwaves + blockIdx.x)] = p; part_rmse[2 * (b * nwaves + blockIdx.x) + 1] = q; }
 }
 
 // the two launches in front of a frame front with folded resample and per-wave tables; fills a.pre_order / a.pre_src
@@ -2502,12 +2643,30 @@ static int launch_presort(midas_ctx* ctx, ParticleUpdateArgs& a) {
     if ((rc = midas_scratch(ctx, bytes, &p_hint))) return rc;
     if ((rc = midas_scratch(ctx, bytes, &p_order))) return rc;
     if ((rc = midas_scratch(ctx, bytes, &p_srcr))) return rc;
-    hipLaunchKernelGGL(k_presort_search, dim3((unsigned)ceil_div(a.N, 64), (unsigned)a.batch), dim3(64), 0, ctx->stream, a, (int32_t*)p_src, (int32_t*)p_hint);
-    hipLaunchKernelGGL(k_presort_group, dim3((unsigned)ceil_div(a.N, PS_CHUNK), (unsigned)a.batch), dim3(PS_THREADS), 0, ctx->stream, a.N,
-                       (const int32_t*)p_src, (const int32_t*)p_hint, (int32_t*)p_order, (int32_t*)p_srcr);
+    static const int run_env = getenv("MIDAS_PRESORT_RUN") ? atoi(getenv("MIDAS_PRESORT_RUN")) : 8;
+    const int run = (run_env == 1 || run_env == 2 || run_env == 4 || run_env == 8 || run_env == 16 || run_env == 32) ? run_env : 0;  // divisors of 64; else none
+    static const bool fused_env = !(getenv("MIDAS_PRESORT_FUSED") && getenv("MIDAS_PRESORT_FUSED")[0] == '0');
+    if (fused_env && a.N <= PS_LP_MAX) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            MIDAS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_presort_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PresortLds)));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_presort_fused, dim3((unsigned)ceil_div(a.N, PS_CHUNK), (unsigned)a.batch), dim3(PS_THREADS), sizeof(PresortLds), ctx->stream,
+                           a, (int32_t*)p_order, (int32_t*)p_srcr, run);
+    } else {
+        hipLaunchKernelGGL(k_presort_search, dim3((unsigned)ceil_div(a.N, 256), (unsigned)a.batch), dim3(256), 0, ctx->stream, a, (int32_t*)p_src, (int32_t*)p_hint);
+        hipLaunchKernelGGL(k_presort_group, dim3((unsigned)ceil_div(a.N, PS_CHUNK), (unsigned)a.batch), dim3(PS_THREADS), 0, ctx->stream, a.N,
+                           (const int32_t*)p_src, (const int32_t*)p_hint, (int32_t*)p_order, (int32_t*)p_srcr, run);
+    }
     MIDAS_HIP_CHECK(ctx, hipGetLastError());
     a.pre_order = (const int32_t*)p_order;
     a.pre_src = (const int32_t*)p_srcr;
+    if (a.gt16) {
+        void* p_terms;
+        if ((rc = midas_scratch(ctx, (size_t)a.batch * (size_t)a.N * 2 * sizeof(double), &p_terms))) return rc;
+        a.pre_rmse_terms = (double*)p_terms;
+    }
     return MIDAS_OK;
 }
 
@@ -2591,17 +2750,16 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
     const int fw = a.batch > 1 ? 1 : (a.rs.enabled && !wave_tables) ? 4 : fw_env == 1 || fw_env == 4 ? fw_env : (a.sp.stamps ? 1 : 4);
     const int n_pu_fw = (nwaves + fw - 1) / fw;
     if (!use_list) { a.sp.pred_tag = 0; a.sp.list = nullptr; }
-    // presort (see k_presort_search): MIDAS_PRESORT=1.  OFF by default - measured (profiles/r04_c5_presort.txt): at c5 the sorted
-    // waves do start from 3 - 5 entries instead of 50 and the best frames' front drops from ~250 to 150 us, but a hard entry's
-    // particles now sit in the SAME waves: their cooperative continuations (one owner's list per pass) queue up inside a wave
-    // instead of spreading over the launch, the front swings between 180 and 480 us, and the two extra launches cost 53 us
-    // (362 against 314 us per batch frame); at c2 (tried with a build that had it there too) the launches cost more than the front's
-    // whole list phase (14.5k against 23.7k steps/s).
-    // What the order needs to pay off is a scan that serves all the wave's owners of one entry from ONE fetch of its records.
-    // (compiled into the batch kernels only - SCR = false: in the single-trajectory front the two branches cost 2 us of a 27 us kernel
-    // even when not taken)
-    static const int presort_env = getenv("MIDAS_PRESORT") ? atoi(getenv("MIDAS_PRESORT")) : 0;
-    if (wave_tables && fw == 1 && a.batch > 1 && !a.inbox.rows && !a.ablate && !a.n_live && presort_env == 1) {
+    // presort (see k_presort_search): the batch step (grid.y trajectories), on by default, MIDAS_PRESORT=0 switches it off.
+    // Measured at c5 (profiles/r04_c5_presort.txt): grouped and dealt to the waves in runs of 8 (MIDAS_PRESORT_RUN), 298 / 287 us per
+    // batch frame against 313 / 303 without - the front itself drops from ~290 to ~237 us, the two launches in front of it cost
+    // 53 us (the search they moved out of the front included).  Grouped WITHOUT the deal (a wave = one entry's particles) it loses:
+    // a hard entry's particles then share waves, their cooperative continuations (one owner's list per pass) queue up inside a
+    // wave instead of spreading over the launch, and the front swings between 180 and 480 us (362 / 331 us).  Compiled into the
+    // batch kernels only (SCR = false): tried in the single-trajectory front too, the two launches cost c2 more than the front's
+    // whole list phase (14.5k against 23.7k steps/s) and the untaken branches 2 us.
+    static const int presort_env = getenv("MIDAS_PRESORT") ? atoi(getenv("MIDAS_PRESORT")) : 1;
+    if (wave_tables && fw == 1 && a.batch > 1 && !a.inbox.rows && !a.ablate && !a.n_live && presort_env != 0) {
         const int rc = launch_presort(ctx, a);
         if (rc) return rc;
     }
@@ -2656,6 +2814,9 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
     }
 #undef MIDAS_FRONT
 #undef MIDAS_FRONT_L
+    if (a.pre_rmse_terms)  // presorted launch with rmse: the per-wave sums the tail reads, formed in slot order
+        hipLaunchKernelGGL(k_rmse_parts, dim3((unsigned)nwaves, (unsigned)a.batch), dim3(64), 0, ctx->stream, a.N, nwaves,
+                           (const double*)a.pre_rmse_terms, a.part_rmse);
     MIDAS_HIP_CHECK(ctx, hipGetLastError());
     *launched = true;
     return MIDAS_OK;

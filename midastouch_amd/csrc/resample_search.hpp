@@ -12,8 +12,14 @@ namespace midas {
 // chosen on the exact predicate (its end value is not left of the draw, the previous block's is), so the answer lies
 // inside it.  Returns the first slot i of the block with not left(cdf_i), cdf_i = (bp + lp_i) / total, where
 // left(c) = c < tq (multinomial, lower bound) or c <= tq (systematic, upper bound).
-MD int64_t search_in_block(const double* __restrict__ lp, const double* __restrict__ gend, const double* __restrict__ ggend,
-                           int b, int64_t N, int64_t one_slot, double bp, double total, double tq, bool upper) {
+// gend_lds (nullable): the caller's copy of the WHOLE chunk-end table in LDS - the chunk is then found by a binary search there
+// (same predicate, same chunk) instead of the two line fetches; only the chunk's own line comes from memory.
+// LPT / GT: `const double*` (tables in memory) or lds_cdp (the caller's copies in LDS, typed as such: through a generic pointer the
+// reads would be flat instructions).
+typedef const __attribute__((address_space(3))) double* lds_cdp;
+template <typename LPT, typename GT>
+MD int64_t search_in_block_t(LPT lp, const double* __restrict__ gend, const double* __restrict__ ggend,
+                             int b, int64_t N, int64_t one_slot, double bp, double total, double tq, bool upper, GT gend_lds) {
     // (total < 0: raw weights - the softmax is skipped when every particle has the same score, particle_filter.py:459-468 -
     // of a negative cosine; p = w / sum(w) is positive again (:238) and dividing by the negative total turns the comparison
     // round.  Without the turn the division-free probes point the wrong way and the exact walk below crosses the whole block
@@ -34,22 +40,38 @@ MD int64_t search_in_block(const double* __restrict__ lp, const double* __restri
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const double2 w = p2[j]; v[2 * j] = w.x; v[2 * j + 1] = w.y; }
     };
+    auto fetch16_lds = [&](lds_cdp p) {
+#pragma unroll
+        for (int j = 0; j < SCAN_CHUNK; ++j) v[j] = p[j];
+    };
+    constexpr bool LP_LDS = __is_same(LPT, lds_cdp);
     const int n_chunks = (int)((b_hi - b_lo + SCAN_CHUNK - 1) >> 4), n_groups = (n_chunks + 15) >> 4;
-    fetch16(ggend + (int64_t)b * 16);
-    int g = 0;
+    int64_t cidx;  // the chunk: first one of the block whose end value is not left of the draw (the block's last at the latest)
+    if (gend_lds) {
+        int lo = (int)(b_lo >> 4), hi = lo + n_chunks - 1;  // (the last chunk needs no probe)
+        while (lo < hi) {
+            const int mid = lo + ((hi - lo) >> 1);
+            if (left(gend_lds[mid])) lo = mid + 1; else hi = mid;
+        }
+        cidx = lo;
+    } else {
+        fetch16(ggend + (int64_t)b * 16);
+        int g = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) g += (j < n_groups && left(v[j])) ? 1 : 0;
-    g = g < n_groups ? g : n_groups - 1;
-    const int64_t c0 = (b_lo >> 4) + 16 * g;
-    fetch16(gend + c0);
-    const int n_in_group = n_chunks - 16 * g < 16 ? n_chunks - 16 * g : 16;
-    int c = 0;
+        for (int j = 0; j < 16; ++j) g += (j < n_groups && left(v[j])) ? 1 : 0;
+        g = g < n_groups ? g : n_groups - 1;
+        const int64_t c0 = (b_lo >> 4) + 16 * g;
+        fetch16(gend + c0);
+        const int n_in_group = n_chunks - 16 * g < 16 ? n_chunks - 16 * g : 16;
+        int c = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) c += (j < n_in_group && left(v[j])) ? 1 : 0;
-    c = c < n_in_group ? c : n_in_group - 1;
-    const int64_t s0 = (c0 + c) << 4;
+        for (int j = 0; j < 16; ++j) c += (j < n_in_group && left(v[j])) ? 1 : 0;
+        c = c < n_in_group ? c : n_in_group - 1;
+        cidx = c0 + c;
+    }
+    const int64_t s0 = cidx << 4;
     double v_prev = lp[s0 > b_lo ? s0 - 1 : b_lo];  // the slot before the chunk (same block)
-    fetch16(lp + s0);
+    if constexpr (LP_LDS) fetch16_lds(lp + s0); else fetch16(lp + s0);
     // pinned to the chunk's round trip: left to itself the compiler sinks this load into the fix-up branch below, where it
     // is a dependent round trip of its own
     asm volatile("" : "+v"(v_prev));
@@ -80,6 +102,11 @@ MD int64_t search_in_block(const double* __restrict__ lp, const double* __restri
         }
     }
     return l2;
+}
+
+MD int64_t search_in_block(const double* __restrict__ lp, const double* __restrict__ gend, const double* __restrict__ ggend,
+                           int b, int64_t N, int64_t one_slot, double bp, double total, double tq, bool upper) {
+    return search_in_block_t<const double*, const double*>(lp, gend, ggend, b, N, one_slot, bp, total, tq, upper, (const double*)nullptr);
 }
 
 }  // namespace midas
