@@ -74,3 +74,32 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "libmidas_oracle" not in src and "midas_oracle.c" not in src.replace("oracle/midas_oracle.c", ""), f
+
+
+@pytest.mark.gpu
+def test_scratch_reserve_then_no_growth(capfd):
+    """midas_scratch_reserve: one chunk that holds what a later call asks for (a DBSCAN call's cell tables: ~90 MB) - the call then
+    allocates nothing (MIDAS_SCRATCH_LOG reports every allocation on stderr); reserving less than is held is a no-op."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import subprocess
+    import sys
+    code = (
+        "import torch, numpy as np\n"
+        "from midastouch_amd import _lib, ops\n"
+        "dev = torch.device('cuda', 0)\n"
+        "ctx = _lib.context(dev)\n"
+        "ctx.call('midas_scratch_reserve', 160 << 20)\n"
+        "print('RESERVED', flush=True)\n"
+        "import sys; sys.stderr.write('MARK\\n'); sys.stderr.flush()\n"
+        "P = torch.eye(4, device=dev)[None].repeat(5000, 1, 1).contiguous(); P[:, :3, 3] = torch.randn(5000, 3, device=dev) * 0.01\n"
+        "lab, info = ops.dbscan(P, 1e-2)\n"
+        "ctx.call('midas_scratch_reserve', 1 << 20)\n"
+        "torch.cuda.synchronize(); print('DONE', int(info[0]))\n")
+    env = dict(os.environ, MIDAS_SCRATCH_LOG="1", PYTHONPATH=REPO)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "DONE" in r.stdout
+    before, after = r.stderr.split("MARK")
+    assert "reserved one chunk" in before and "[midas] scratch" not in after, r.stderr

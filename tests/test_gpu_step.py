@@ -316,14 +316,16 @@ def test_batch_engine_matches_oracle_per_trajectory(dev, oracle, dense, monkeypa
 
 
 @pytest.mark.parametrize("mode", ["weighted_random", "low_var"])
-@pytest.mark.parametrize("read_every", [1, 3, 100])
-def test_pipelined_batch_engine_equals_batch_engine(dev, mode, read_every):
+@pytest.mark.parametrize("read_every,N", [(1, 9000), (3, 9000), (100, 9000), (3, 11000)])
+def test_pipelined_batch_engine_equals_batch_engine(dev, mode, read_every, N):
     """midas_lazy_step_batch (every trajectory's resample folded into the next frame's front kernel, trajectory = grid.y) against
     midas_filter_step_batch, which the test above pins to the oracle: NN indices, propagated poses and rmse every frame, the
-    materialised particle set whenever it is read - bit-identical, device draws and host uniforms."""
+    materialised particle set whenever it is read - bit-identical, device draws and host uniforms.  The pipelined batch step runs
+    PRESORTED (sources + hint-grouped execution order in front of the front kernel): N = 9000 through the one-kernel form with the
+    tables in LDS, N = 11 000 (beyond its 10 240 slots) through the two-kernel form; the rmse is formed in slot order either way."""
     from midastouch_amd.engine import BatchFilterEngine, PipelinedBatchFilterEngine
     from midastouch_amd.synthetic import make_trajectory
-    B, N, K, D = 4, 9000, 3000, 256   # three summation blocks per trajectory, ragged
+    B, K, D = 4, 3000, 256   # three summation blocks per trajectory, ragged
     cb, traj, scale = _setup(N, K, D, seed=6, obj="cotter-pin")
     trajs = [make_trajectory(cb, T=12, seed=2300 + b) for b in range(B)]
     rng = np.random.default_rng(5)
