@@ -118,11 +118,14 @@ int launch_score(midas_ctx* ctx, const midas_codebook* cb, int32_t B, const doub
 // longest SIMD has 13 tiles - 22.2 us).  Round 3 had 196 workgroups of 256 rows on 256 CUs, two 1 KB row pieces in flight per
 // wave (47 us, 70 TFLOP/s); a wave now keeps MF_PF = 4 + 4 pieces in flight and twelve to sixteen waves per CU are live.
 constexpr int MF_ROWS_PER_WAVE = 16;
-constexpr int MF_WAVES = 12;   // waves per workgroup: three slots on each of the CU's four SIMDs (170 registers a wave)
+#ifndef MIDAS_MF_WAVES
+#define MIDAS_MF_WAVES 12
+#endif
+constexpr int MF_WAVES = MIDAS_MF_WAVES;   // waves per workgroup: three slots on each of the CU's four SIMDs (170 registers a wave); 16: a fourth slot for the tile-units
 constexpr int MF_CODES = 64;   // codes per pass (4 N-tiles)
 constexpr int MF_PAD = 4;      // floats of padding per staged code row (bank spread)
 #ifndef MIDAS_MF_PF
-#define MIDAS_MF_PF 8
+#define MIDAS_MF_PF 4
 #endif
 constexpr int MF_PF = MIDAS_MF_PF;         // row pieces in flight per lane and queue (two queues)
 
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256) void k_codes_prepare(const double* __restrict_
 // BEFORE the codes are staged: the two latencies overlap), run() multiplies, finish() divides and stores.
 // (eb / ld: the staged codes in LDS, or - CODES_LDS false, D too large for the CU's LDS - the float32 code rows in memory)
 #ifndef MIDAS_MF_DBG
-#define MIDAS_MF_DBG 0  // profiling builds only (tools/ab_score.sh): 1 no row fetches, 2 no LDS reads, 4 no epilogue - wrong scores
+#define MIDAS_MF_DBG 0  // profiling builds only (tools/ab_score.sh): 1 no row fetches, 2 no LDS reads, 4 no epilogue, 8 fetch-shape probe - wrong scores
 #endif
 template <int NT, bool CODES_LDS>
 struct MfUnit {
@@ -173,17 +176,25 @@ struct MfUnit {
     float4 qa[MF_PF], qb[MF_PF];
     double nr[4], cn[NT];
     const float* arow;
-    int64_t row0;
+    const float* arow_base;  // (MIDAS_MF_DBG & 8 only)
+    int64_t row0, K_;
     int t0, nc;
 
     MD float4 piece(int c) const {
         if (MIDAS_MF_DBG & 1) { float v = (float)c; asm volatile("" : "+v"(v)); return make_float4(v, v, v, v); }
+        if (MIDAS_MF_DBG & 8) {  // fetch-shape probe (wrong operands): a load = 4 rows x 256 contiguous bytes, as the GEMV stream reads
+            const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
+            const int cc = c < nc ? c : nc - 1;
+            const int64_t r = row0 + 4 * (cc & 3) + g;
+            return *reinterpret_cast<const float4*>(arow_base + (r < K_ ? r : K_ - 1) * (int64_t)(16 * nc) + 64 * (cc >> 2) + 4 * i);
+        }
         return *reinterpret_cast<const float4*>(arow + 16 * (c < nc ? c : nc - 1));
     }
     MD void begin(const float* __restrict__ emb, const double* __restrict__ norms, const double* __restrict__ code_norms, int64_t K,
                   int D, int b0, int nb, int64_t row0_, int t0_) {
         const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
         row0 = row0_; t0 = t0_; nc = D / 16;
+        arow_base = emb; K_ = K;
         const int64_t row = row0 + i < K ? row0 + i : K - 1;  // clamp: surplus rows are computed and dropped
         arow = emb + row * (int64_t)D + 4 * g;
 #pragma unroll
@@ -196,13 +207,16 @@ struct MfUnit {
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    MD void step(const float* __restrict__ eb, int ld, const float4& a, int c) {
-        float4 e[NT];
+    // the codes' operands of step c: four 16-byte LDS reads (one per N-tile)
+    MD void load_e(float4 (&e)[NT], const float* __restrict__ eb, int ld, int c) const {
+        const int cc = c < nc ? c : nc - 1;  // (the step behind the last one re-reads it: unconditional reads, nobody uses them)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            if (MIDAS_MF_DBG & 2) { float v = (float)(c + t); asm volatile("" : "+v"(v)); e[t] = make_float4(v, v, v, v); }
-            else e[t] = *reinterpret_cast<const float4*>(eb + 16 * t * ld + 16 * c);
+            if (MIDAS_MF_DBG & 2) { float v = (float)(cc + t); asm volatile("" : "+v"(v)); e[t] = make_float4(v, v, v, v); }
+            else e[t] = *reinterpret_cast<const float4*>(eb + 16 * t * ld + 16 * cc);
         }
+    }
+    MD void mul(const float4& a, const float4 (&e)[NT]) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, e[t].x, acc[t], 0, 0, 0);
 #pragma unroll
@@ -219,14 +233,25 @@ struct MfUnit {
         // Whole rounds of 2 MF_PF steps, straight-line code (a condition around a step makes the compiler's wait counting give
         // up at the merge: s_waitcnt vmcnt(0) once per round).  The row pieces travel MF_PF .. 2 MF_PF steps ahead of the
         // multiplies in two register queues that alternate (fetched into the registers the MFMAs of a step still read, a piece
-        // is parked in a temporary and waited for on the spot); the pieces of the next half round leave as one burst: a lane's
-        // pieces are 64 bytes apart, so the wave asks for MF_PF x 64 contiguous bytes of each of its 16 rows at once.
-        // Instruction order pinned with sched_group_barrier: the burst, then per step the codes' LDS reads and the multiplies.
+        // is parked in a temporary and waited for on the spot); the pieces of the next half round leave as one burst.
+        // The codes' LDS reads run ONE STEP ahead of the multiplies, in two register sets that alternate (phase stamps of the
+        // form that read a step's operands in front of its own multiplies: the matrix pipe serves the oldest wave first, so one
+        // wave at a time runs and its LDS latency - ~200 cycles a step against 512 cycles of multiplies - is exposed: 9.8 us a
+        // unit against 6.6 at the matrix rate).  Instruction order pinned with sched_group_barrier: per step the NEXT step's
+        // reads, then this step's multiplies; the burst in front of a half round.
+        float4 e0[NT], e1[NT];
+        load_e(e0, eb, ld, 0);
+        static_assert(MF_PF % 2 == 0, "the two operand sets alternate step by step");
         for (; c0 + 2 * MF_PF <= nc; c0 += 2 * MF_PF) {
 #pragma unroll
             for (int p = 0; p < MF_PF; ++p) qb[p] = piece(c0 + p + MF_PF);
 #pragma unroll
-            for (int p = 0; p < MF_PF; ++p) step(eb, ld, qa[p], c0 + p);
+            for (int p = 0; p < MF_PF; p += 2) {
+                load_e(e1, eb, ld, c0 + p + 1);
+                mul(qa[p], e0);
+                load_e(e0, eb, ld, c0 + p + 2);
+                mul(qa[p + 1], e1);
+            }
             if constexpr (CODES_LDS) {
                 __builtin_amdgcn_sched_group_barrier(0x020, MF_PF, 0);
 #pragma unroll
@@ -238,7 +263,12 @@ struct MfUnit {
 #pragma unroll
             for (int p = 0; p < MF_PF; ++p) qa[p] = piece(c0 + p + 2 * MF_PF);
 #pragma unroll
-            for (int p = 0; p < MF_PF; ++p) step(eb, ld, qb[p], c0 + MF_PF + p);
+            for (int p = 0; p < MF_PF; p += 2) {
+                load_e(e1, eb, ld, c0 + MF_PF + p + 1);
+                mul(qb[p], e0);
+                load_e(e0, eb, ld, c0 + MF_PF + p + 2);
+                mul(qb[p + 1], e1);
+            }
             if constexpr (CODES_LDS) {
                 __builtin_amdgcn_sched_group_barrier(0x020, MF_PF, 0);
 #pragma unroll
@@ -248,15 +278,15 @@ struct MfUnit {
                 }
             }
         }
-        if (c0 < nc) {  // D / 16 not a multiple of 2 MF_PF: the last, partial round (wave-uniform conditions)
+        if (c0 < nc) {  // D / 16 not a multiple of 2 MF_PF: the last, partial round (wave-uniform conditions; operands read in place)
 #pragma unroll
             for (int p = 0; p < MF_PF; ++p) {
                 qb[p] = piece(c0 + p + MF_PF);
-                if (c0 + p < nc) step(eb, ld, qa[p], c0 + p);
+                if (c0 + p < nc) { load_e(e0, eb, ld, c0 + p); mul(qa[p], e0); }
             }
 #pragma unroll
             for (int p = 0; p < MF_PF; ++p)
-                if (c0 + MF_PF + p < nc) step(eb, ld, qb[p], c0 + MF_PF + p);
+                if (c0 + MF_PF + p < nc) { load_e(e0, eb, ld, c0 + MF_PF + p); mul(qb[p], e0); }
         }
     }
     // D[row = 4g + r][code = i] in register r of lane (g, i)
@@ -292,6 +322,16 @@ struct MfUnit {
     }
 };
 
+#if MIDAS_MF_DBG & 16  // profiling build: wall-clock stamps (100 MHz) of every wave's phases, tools/mf_clocks.py
+__device__ long long g_mf_clk[256 * MF_WAVES * 8];
+extern "C" __attribute__((visibility("default"))) int midas_debug_mf_clocks(long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mf_clk), (size_t)n * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+#define MF_STAMP(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) g_mf_clk[(blockIdx.x * MF_WAVES + (threadIdx.x >> 6)) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define MF_STAMP(k)
+#endif
+
 template <bool CODES_LDS>
 __global__ __launch_bounds__(64 * MF_WAVES) void k_score_mfma(const float* __restrict__ emb, const double* __restrict__ norms,
                                                      const float* __restrict__ codes32, const double* __restrict__ code_norms,
@@ -307,31 +347,55 @@ __global__ __launch_bounds__(64 * MF_WAVES) void k_score_mfma(const float* __res
     const int slot = wave >> 2;
     const int64_t G = (K + MF_ROWS_PER_WAVE - 1) / MF_ROWS_PER_WAVE;
     const int64_t rounds = G / S, Gw = rounds * S;   // whole groups: `rounds` per SIMD
-    // the wave's first whole group starts its fetches before the codes are staged
+    // The wave's leftover tile-unit, if it has one (one N-tile a turn: tile-unit q = 4 (group - Gw) + tile, to
+    // the slot that gets the matrix pipe LAST - the pipe serves the oldest wave first - and runs there FIRST: a tile-unit is a
+    // chain of fetches with little to multiply, 10 us that ended 6 us behind everything else when it ran after the wave's group).
+    const int64_t Q = 4 * (G - Gw);
+    MF_STAMP(0);
+    float4 stage[CODES_LDS ? 11 : 1];
+    const int q4 = D / 4, total = MF_CODES * q4;
+    constexpr int NT_ = 64 * MF_WAVES;
+    if (CODES_LDS) {
+        // The 64 codes (padded with zero rows by k_codes_prepare) are requested FIRST: loads come back in order, so the first
+        // burst of row pieces (memory) in front of them made the staging wait for it (6.8 us to the barrier); behind them
+        // it travels while the codes are written to LDS.  Eleven 16-byte pieces per thread at D = 512 (more rounds beyond).
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const int idx = k * NT_ + (int)threadIdx.x;
+            const int ic = idx < total ? idx : total - 1;
+            const int b = ic / q4, d = (ic - b * q4) * 4;
+            stage[k] = *reinterpret_cast<const float4*>(&codes32[(int64_t)(b0 + b) * D + d]);
+        }
+    }
     MfUnit<4, CODES_LDS> u4;
     const bool first4 = slot < rounds;
     if (first4) u4.begin(emb, norms, code_norms, K, D, b0, nb, ((int64_t)slot * S + simd) * MF_ROWS_PER_WAVE, 0);
     if (CODES_LDS) {
-        // stage the 64 codes (padded with zero rows by k_codes_prepare): six 16-byte pieces per thread and round trip, the loads
-        // unconditional (clamped index) so that a round's six are in flight together
-        const int q4 = D / 4, total = MF_CODES * q4;
-        constexpr int SB = 6, NT_ = 64 * MF_WAVES;
-        for (int base = 0; base < total; base += SB * NT_) {
-            float4 v[SB];
+        float4* s4 = reinterpret_cast<float4*>(s_e);  // rows of ld / 4 sixteen-byte pieces (D and the pad are multiples of 4)
+        const int ldq = ld >> 2;
 #pragma unroll
-            for (int k = 0; k < SB; ++k) {
+        for (int k = 0; k < 11; ++k)  // (pinned here: the compiler otherwise sinks each load into its store's condition)
+            asm volatile("" : "+v"(stage[k].x), "+v"(stage[k].y), "+v"(stage[k].z), "+v"(stage[k].w));
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const int idx = k * NT_ + (int)threadIdx.x;
+            const int ic = idx < total ? idx : total - 1;
+            const int b = ic / q4, dq = ic - b * q4;
+            if (idx < total) s4[b * ldq + dq] = stage[k];
+        }
+        for (int base = 11 * NT_; base < total; base += 6 * NT_) {  // D > 528: the rest, six pieces a round
+            float4 v[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
                 const int idx = base + k * NT_ + (int)threadIdx.x;
                 const int ic = idx < total ? idx : total - 1;
                 const int b = ic / q4, d = (ic - b * q4) * 4;
                 v[k] = *reinterpret_cast<const float4*>(&codes32[(int64_t)(b0 + b) * D + d]);
             }
 #pragma unroll
-            for (int k = 0; k < SB; ++k)  // (pinned here: the compiler otherwise sinks each load into its store's condition)
-                asm volatile("" : "+v"(v[k].x), "+v"(v[k].y), "+v"(v[k].z), "+v"(v[k].w));
-            float4* s4 = reinterpret_cast<float4*>(s_e);  // rows of ld / 4 sixteen-byte pieces (D and the pad are multiples of 4)
-            const int ldq = ld >> 2;
+            for (int k = 0; k < 6; ++k) asm volatile("" : "+v"(v[k].x), "+v"(v[k].y), "+v"(v[k].z), "+v"(v[k].w));
 #pragma unroll
-            for (int k = 0; k < SB; ++k) {
+            for (int k = 0; k < 6; ++k) {
                 const int idx = base + k * NT_ + (int)threadIdx.x;
                 const int ic = idx < total ? idx : total - 1;
                 const int b = ic / q4, dq = ic - b * q4;
@@ -340,21 +404,25 @@ __global__ __launch_bounds__(64 * MF_WAVES) void k_score_mfma(const float* __res
         }
         __syncthreads();
     }
+    MF_STAMP(1);
     __builtin_amdgcn_s_setprio(1);
-    for (int64_t r = slot; r < rounds; r += SL) {
-        if (r != slot) u4.begin(emb, norms, code_norms, K, D, b0, nb, (r * S + simd) * MF_ROWS_PER_WAVE, 0);
-        u4.run(eb, ld);
-        u4.finish(out, K, b0, nb);
-    }
-    // the groups left over, one N-tile a turn: tile-unit q = 4 (group - Gw) + tile goes to SIMD q mod S, slot (rounds + q / S) mod SL
-    const int64_t Q = 4 * (G - Gw);
-    for (int64_t q = simd; q < Q; q += S) {
-        if ((int)((rounds + q / S) % SL) != slot) continue;
+    // (dealt CU by CU first - tile-unit q to CU q mod grid, SIMD (q / grid) mod 4 - so that 212 of them are one extra tile on 212
+    // different CUs, not four on each of 53)
+    for (int64_t q = (int64_t)blockIdx.x + (int64_t)gridDim.x * (wave & 3); q < Q; q += S) {
+        if (SL - 1 - (int)((q / S) % SL) != slot) continue;
         MfUnit<1, CODES_LDS> u1;
         u1.begin(emb, norms, code_norms, K, D, b0, nb, (Gw + (q >> 2)) * MF_ROWS_PER_WAVE, (int)(q & 3));
         u1.run(eb, ld);
         u1.finish(out, K, b0, nb);
     }
+    for (int64_t r = slot; r < rounds; r += SL) {
+        if (r != slot) u4.begin(emb, norms, code_norms, K, D, b0, nb, (r * S + simd) * MF_ROWS_PER_WAVE, 0);
+        u4.run(eb, ld);
+        MF_STAMP(2);
+        u4.finish(out, K, b0, nb);
+        MF_STAMP(3);
+    }
+    MF_STAMP(4);
 }
 
 int launch_score_batch(midas_ctx* ctx, const midas_codebook* cb, int32_t B, const double* codes, double* scores) {
