@@ -25,7 +25,7 @@ def normal_words(numel: int) -> int:
 
 class TorchCpuStream:
     """`overlap=True` (default): the generator runs on a stream and a library context of its own - its single-workgroup block
-    recurrence (one CU, ~30 us for a frame's 2 N words at N = 100k) then runs BESIDE the frame kernels of the caller's stream
+    recurrence (one CU, ~100 us for a frame's 2 N words at N = 100k: 321 blocks of 624 words at 310 ns) then runs BESIDE the frame kernels of the caller's stream
     instead of in front of them.  `rand64()` orders the result behind the caller's stream as before; `rand64_async()` returns
     (tensor, event) and leaves the wait to the consumer (the pipelined engine: the draws of frame t are consumed by frame
     t + 1's launch).  The output buffers rotate (3): a buffer is rewritten two calls later, after the side stream has waited
