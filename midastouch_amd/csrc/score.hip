@@ -402,7 +402,9 @@ __global__ __launch_bounds__(64 * MF_WAVES) void k_score_mfma(const float* __res
                 if (idx < total) s4[b * ldq + dq] = v[k];
             }
         }
-        __syncthreads();
+        // the barrier orders the LDS writes only: __syncthreads() would also drain the wave's loads (s_waitcnt vmcnt(0) in front of
+        // s_barrier) - the first burst of row pieces and the divisors, which are meant to travel across it (3 us of the 5 to here)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     MF_STAMP(1);
     __builtin_amdgcn_s_setprio(1);
