@@ -628,7 +628,7 @@ def main():
                    "arith": "f32 poses/NN, f64 scores/weights/CDF", "last_status": status,
                    "scoring": ("sparse: the particle kernels score only the codebook rows that are some particle's nearest entry "
                                "(same arithmetic, same scores); %d distinct rows in the last frame" % int(torch.unique(eng.nn_idx).numel()))
-                   if getattr(eng, "sparse_scores", False) else "dense: all K rows every frame",
+                   if getattr(eng, "sparse_scores", getattr(getattr(eng, "backend", None), "_sparse", False)) else "dense: all K rows every frame",
                    "init": "init_filter(gt_0, N) (sigma_t = mesh scale / 3, sigma_r = 60 deg) projected onto the codebook",
                    "timed_region": ("K steps by one midas_shard_run call (library-owned RCCL communicator)" if sharded and eng.exchange == "peer_c" and eng._ccomm is not None
                                     else "K steps by one midas_lazy_run call" if hasattr(eng, "run") and not sharded and not args.eager else "K step() calls"),
