@@ -75,7 +75,8 @@ int midas_score(midas_ctx* ctx, const midas_codebook* cb, int32_t B, const doubl
 /* Batched form for B concurrent trajectories (BASELINE config 5): one pass over the codebook on the matrix
  * cores (v_mfma_f32_16x16x4_f32).  The codes are rounded to float32 (they are float32 network outputs) and
  * the dot products are float32 fma chains in a fixed order, then divided by the float64 norms:
- * scores agree with midas_score to ~1e-7.  Needs float32 embeddings and D % 16 == 0. */
+ * scores agree with midas_score to ~1e-7.  Needs float32 embeddings and D % 16 == 0.  The 64 codes of a pass sit in LDS whole
+ * up to D = 636 (one persistent workgroup per CU); beyond, the waves read the float32 code rows from memory - same arithmetic. */
 int midas_score_batch(midas_ctx* ctx, const midas_codebook* cb, int32_t B, const double* codes_dev,
                       double* scores_dev);
 
@@ -149,7 +150,10 @@ int midas_prune(midas_ctx* ctx, int64_t N, double* w_dev, const double* dist_dev
  * fixed seed" needs neither a host generator nor a per-frame upload of uniforms.
  * midas_mt19937_seed: the state of torch.manual_seed(seed) (low 32 bits, as at::mt19937 takes them).
  * midas_mt19937_rand64: discards skip_words 32-bit outputs, then writes the next N float64 uniforms
- * ((hi << 32 | lo) & (2^53 - 1)) * 2^-53 to out_dev (NULL with N == 0: skip only), and leaves the state advanced. */
+ * ((hi << 32 | lo) & (2^53 - 1)) * 2^-53 to out_dev (NULL with N == 0: skip only), and leaves the state advanced.
+ * One workgroup walks the 624-word blocks (one barrier a block, ~310 ns), a second kernel tempers and converts; the call uses
+ * (2 N + 1872) x 4 bytes of the context's scratch.  A caller that wants it beside other work gives it a context / stream of its
+ * own (midastouch_amd/torch_rng.py does). */
 int midas_mt19937_seed(midas_ctx* ctx, uint64_t seed, uint32_t* state_dev);
 int midas_mt19937_rand64(midas_ctx* ctx, uint32_t* state_dev, int64_t skip_words, int64_t N, double* out_dev);
 
@@ -350,7 +354,11 @@ int midas_lazy_flush(midas_ctx* ctx, const midas_lazy_flush_args* args);
  * midas_lazy_tables_doubles(N) doubles, 128-byte aligned.  Draws are keyed per trajectory as in midas_filter_step_batch
  * (Philox key = trajectory * N + slot; the systematic offset's key = seed + trajectory), so every trajectory is bit-identical
  * to a single-trajectory run of the batch step.  Needs score stamps (sparse scoring), a float32 codebook with D in
- * {128, 256, 512, 1024}, 16 <= N <= 262144. */
+ * {128, 256, 512, 1024}, 16 <= N <= 262144.
+ * The batch step runs PRESORTED by default (MIDAS_PRESORT=0: off): in front of the front kernel the folded resample's sources are
+ * computed and the slots of every trajectory are put in an execution order that keeps equal nearest-entry hints together (dealt
+ * to the waves in runs of MIDAS_PRESORT_RUN = 8 slots); the particles' arithmetic and every output are unchanged (a particle
+ * does not know its lane), the rmse partial sums are formed in slot order. */
 int64_t midas_lazy_tables_doubles(int64_t N);
 int midas_lazy_step_batch(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
                           const midas_lazy_args* args, int32_t B);
