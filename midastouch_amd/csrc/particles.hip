@@ -2636,11 +2636,9 @@ __global__ __launch_bounds__(64) void k_rmse_parts(int64_t N, int nwaves, const 
 
 // the two launches in front of a frame front with folded resample and per-wave tables; fills a.pre_order / a.pre_src
 static int launch_presort(midas_ctx* ctx, ParticleUpdateArgs& a) {
-    void *p_src, *p_hint, *p_order, *p_srcr;
+    void *p_src = nullptr, *p_hint = nullptr, *p_order, *p_srcr;
     const size_t bytes = (size_t)a.batch * (size_t)a.N * sizeof(int32_t);
     int rc;
-    if ((rc = midas_scratch(ctx, bytes, &p_src))) return rc;
-    if ((rc = midas_scratch(ctx, bytes, &p_hint))) return rc;
     if ((rc = midas_scratch(ctx, bytes, &p_order))) return rc;
     if ((rc = midas_scratch(ctx, bytes, &p_srcr))) return rc;
     static const int run_env = getenv("MIDAS_PRESORT_RUN") ? atoi(getenv("MIDAS_PRESORT_RUN")) : 8;
@@ -2655,6 +2653,8 @@ static int launch_presort(midas_ctx* ctx, ParticleUpdateArgs& a) {
         hipLaunchKernelGGL(k_presort_fused, dim3((unsigned)ceil_div(a.N, PS_CHUNK), (unsigned)a.batch), dim3(PS_THREADS), sizeof(PresortLds), ctx->stream,
                            a, (int32_t*)p_order, (int32_t*)p_srcr, run);
     } else {
+        if ((rc = midas_scratch(ctx, bytes, &p_src))) return rc;  // (the two-kernel form hands sources and hints over through memory)
+        if ((rc = midas_scratch(ctx, bytes, &p_hint))) return rc;
         hipLaunchKernelGGL(k_presort_search, dim3((unsigned)ceil_div(a.N, 256), (unsigned)a.batch), dim3(256), 0, ctx->stream, a, (int32_t*)p_src, (int32_t*)p_hint);
         hipLaunchKernelGGL(k_presort_group, dim3((unsigned)ceil_div(a.N, PS_CHUNK), (unsigned)a.batch), dim3(PS_THREADS), 0, ctx->stream, a.N,
                            (const int32_t*)p_src, (const int32_t*)p_hint, (int32_t*)p_order, (int32_t*)p_srcr, run);
