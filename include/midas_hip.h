@@ -307,7 +307,20 @@ typedef struct midas_lazy_args {
                                         * zeroes the stamps.  Same scores as without (which rows are scored by whom is all
                                         * that changes); replaces nothing in the reference - it gathers all N rows every frame
                                         * (tactile_tree/tactile_tree.py:54-58) */
+    uint8_t* guide_dev;                /* NULL or midas_lazy_guide_bytes(N) bytes, 16-byte aligned (single trajectory; ignored by the
+                                        * batch form): guide tables of the summation blocks, written by the frame's tail next to
+                                        * tables_dev and read by the NEXT frame's folded resample.  Per 4096-slot block `bins`
+                                        * equal bins over its masked total W (edge k = fl(k * (W / bins))), a 16-bit entry each:
+                                        * min(number of the block's `unit`-slot pieces whose last prefix value lies left of edge k,
+                                        * pieces of the block - 1) - the piece a draw falling into bin k starts its search from
+                                        * (layout: softmax variant | raw-score variant, each ceil(N/4096) rows of `stride`
+                                        * entries; midas_lazy_guide_layout).  One entry pair and 8 - 16 prefix values replace the
+                                        * three 128-byte table lines of a draw's search; a hint only - the exact comparison on
+                                        * (BP + lp_i) / total decides the index as without it (torch.multinomial's lower bound,
+                                        * modules/particle_filter.py:245) */
 } midas_lazy_args;
+int64_t midas_lazy_guide_bytes(int64_t N);
+int midas_lazy_guide_layout(int32_t* bins_out, int32_t* unit_out, int32_t* stride_out);
 int midas_lazy_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
                     const midas_lazy_args* args);
 /* The prediction list from scratch, for a particle set that did not come out of a frame (after the projection onto the

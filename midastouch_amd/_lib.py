@@ -93,6 +93,7 @@ class LazyArgs(C.Structure):
         ("std_t", C.c_float), ("std_r", C.c_float), ("seed", C.c_uint64), ("step", C.c_uint64),
         ("prune_thr", C.c_double), ("softmax", C.c_int32), ("telemetry", C.c_void_p),
         ("score_stamps", C.c_void_p), ("score_epoch", C.c_uint32), ("rmse", C.c_void_p), ("score_list", C.c_void_p),
+        ("guide", C.c_void_p),
     ]
 
 
@@ -225,6 +226,8 @@ SIGNATURES = {
     "midas_lazy_run": (C.c_int, [_P, _P, _P, _P, C.POINTER(LazyArgs), _I32, _P]),
     "midas_lazy_flush": (C.c_int, [_P, C.POINTER(LazyFlushArgs)]),
     "midas_lazy_tables_doubles": (C.c_int64, [_I64]),
+    "midas_lazy_guide_bytes": (C.c_int64, [_I64]),
+    "midas_lazy_guide_layout": (C.c_int, [_P, _P, _P]),
     "midas_lazy_step_batch": (C.c_int, [_P, _P, _P, _P, C.POINTER(LazyArgs), _I32]),
     "midas_lazy_flush_batch": (C.c_int, [_P, C.POINTER(LazyFlushArgs), _I32]),
     "midas_loop_step": (C.c_int, [_P, _P, _P, _P, C.POINTER(LoopArgs), _I32]),

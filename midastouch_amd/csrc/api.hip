@@ -701,7 +701,14 @@ static int lazy_step_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_
     MIDAS_REQUIRE(ctx, (s.tn_dev == nullptr) == (s.rot_dev == nullptr));
     MIDAS_REQUIRE(ctx, s.resample_mode == MIDAS_RESAMPLE_MULTINOMIAL || s.resample_mode == MIDAS_RESAMPLE_SYSTEMATIC);
     const int64_t N = s.N;
-    const TailTables tb = tables_of(s.tables_dev, N);
+    TailTables tb = tables_of(s.tables_dev, N);
+    // guide tables of the summation blocks (GUIDE_BINS, midas_internal.hpp): softmax variant | raw variant; read by the fronts that
+    // build their resample tables per wave (up to 64 blocks), not written for larger sets
+    if (s.guide_dev && B == 1 && ceil_div(N, SCAN_BLOCK) <= 64) {
+        MIDAS_REQUIRE(ctx, (uintptr_t)s.guide_dev % 16 == 0);
+        tb.guide = reinterpret_cast<guide_t*>(s.guide_dev);
+        tb.guide_raw = tb.guide + ceil_div(N, SCAN_BLOCK) * GUIDE_STRIDE;
+    }
     ParticleUpdateArgs pa;
     pa.N = N;
     pa.batch = B;
@@ -746,6 +753,7 @@ static int lazy_step_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_
         r.enabled = true;
         r.e = tb.e; r.x_raw = tb.x_raw; r.lp = tb.lp; r.lp_raw = tb.lp_raw; r.gend = tb.gend; r.gend_raw = tb.gend_raw;
         r.ggend = tb.ggend; r.ggend_raw = tb.ggend_raw;
+        r.guide = tb.guide; r.guide_raw = tb.guide_raw;
         r.bsum_e = tb.bsum_e; r.btot = tb.btot; r.btot_raw = tb.btot_raw; r.bmax = tb.bmax; r.bmin = tb.bmin;
         r.poses_prev = s.poses_prop_prev_dev; r.nn_prev = s.nn_idx_prev_dev; r.status_prev = s.status_prev_dev;
         r.ridx_out = s.ridx_dev;
@@ -851,6 +859,13 @@ MIDAS_EXPORT int midas_score_list_seed(midas_ctx* ctx, int64_t K, uint32_t* scor
 
 // ---- pipelined batch (config 5): B trajectories, grid.y, one table block per trajectory -------------------------------
 MIDAS_EXPORT int64_t midas_lazy_tables_doubles(int64_t N) { return N > 0 ? tables_doubles(N) : 0; }
+MIDAS_EXPORT int midas_lazy_guide_layout(int32_t* bins_out, int32_t* unit_out, int32_t* stride_out) {
+    if (bins_out) *bins_out = GUIDE_BINS;
+    if (unit_out) *unit_out = GUIDE_UNIT;
+    if (stride_out) *stride_out = GUIDE_STRIDE;
+    return MIDAS_OK;
+}
+MIDAS_EXPORT int64_t midas_lazy_guide_bytes(int64_t N) { return N > 0 ? 2 * ceil_div(N, SCAN_BLOCK) * (int64_t)GUIDE_STRIDE * (int64_t)sizeof(guide_t) : 0; }
 
 MIDAS_EXPORT int midas_lazy_step_batch(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
                                        const midas_lazy_args* args, int32_t B) {

@@ -171,6 +171,24 @@ enum : int {
 constexpr int SCAN_CHUNK = 16;
 constexpr int SCAN_TPB = 256;
 constexpr int SCAN_BLOCK = SCAN_CHUNK * SCAN_TPB;  // 4096 values per block
+// Guide table of a summation block (single-trajectory pipelined step, optional): GUIDE_BINS equal bins over the block's masked
+// total W, edge k at fl(k * (W / GUIDE_BINS)) (a power of two: the bin width is exact).  The block's slots are taken in units of
+// GUIDE_UNIT (16: the chunks of the summation spec; 8 / 4: halves / quarters of them); entry k = min(number of the block's unit
+// ends < edge k, units of the block - 1), entry GUIDE_BINS = units of the block - 1.  A draw whose block-local target lies in
+// bin k finds its slot in unit entry[k] .. entry[k + 1]: one entry pair and GUIDE_UNIT (or twice that) prefix values instead of
+// the group-end, chunk-end and slot lines of search_in_block (a hint: the exact fix-up behind it decides).
+#ifndef MIDAS_GUIDE_BINS
+#define MIDAS_GUIDE_BINS 2048
+#endif
+#ifndef MIDAS_GUIDE_UNIT
+#define MIDAS_GUIDE_UNIT 8
+#endif
+typedef uint16_t guide_t;
+constexpr int GUIDE_BINS = MIDAS_GUIDE_BINS, GUIDE_STRIDE = GUIDE_BINS + 16, GUIDE_UNIT = MIDAS_GUIDE_UNIT;  // (stride in entries)
+constexpr double GUIDE_WIDTH = 1.0 / GUIDE_BINS;
+constexpr int TAIL_GUIDE_LDS = GUIDE_BINS / 2 + 8;  // 32-bit words of LDS the tail's guide pass takes: the edge histogram (16-bit counters) + 4 wave totals
+static_assert((GUIDE_BINS & (GUIDE_BINS - 1)) == 0 && GUIDE_BINS >= 2048, "bins: a power of two, eight or more per chunk");
+static_assert(GUIDE_UNIT == 16 || GUIDE_UNIT == 8 || GUIDE_UNIT == 4, "units: whole chunks, halves or quarters");
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
@@ -200,6 +218,7 @@ struct LazyResample {
     bool enabled = false;
     const double *e, *x_raw, *lp, *lp_raw, *gend, *gend_raw;       // [N] x4, [ng] x2
     const double *ggend, *ggend_raw;                                // [16 nb] x2
+    const guide_t *guide = nullptr, *guide_raw = nullptr;           // nullable [nb x GUIDE_STRIDE] x2 (see GUIDE_BINS)
     const double *bsum_e, *btot, *btot_raw, *bmax, *bmin;           // [nb] each
     const float* poses_prev;                                         // [N x 16] propagated poses of the previous frame
     const int32_t* nn_prev;                                          // [N]
@@ -358,6 +377,7 @@ struct TailTables {
     double *e, *x_raw, *lp, *lp_raw, *gend, *gend_raw;       // [N] x4, [ceil(N/16)] x2
     double *bsum_e, *btot, *btot_raw, *bmax, *bmin;           // [ceil(N/4096)] each
     double *ggend, *ggend_raw;                                // [16 ceil(N/4096)]: block-local prefix at the end of each 256-slot group
+    guide_t *guide = nullptr, *guide_raw = nullptr;           // nullable [ceil(N/4096) x GUIDE_STRIDE] each (see GUIDE_BINS)
 };
 int launch_tail_a2(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,
                    int32_t softmax, const TailTables& tb, int32_t* status, int batch = 1, int64_t score_stride = 0,

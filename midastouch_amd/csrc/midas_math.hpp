@@ -325,5 +325,17 @@ MD int wave_isum_dpp(int v) {
     u += dpp_move<0x143, 0xc>(0u, u);
     return (int)(uint32_t)__builtin_amdgcn_readlane((int)u, 63);
 }
+// inclusive prefix sum over the wave's lanes: row shifts by 1, 2, 4, 8 (lanes shifted in from outside the row add zero), then the
+// totals of the rows below by the two row broadcasts
+MD int wave_iscan_dpp(int v) {
+    uint32_t u = (uint32_t)v;
+    u += dpp_move<0x111>(0u, u);
+    u += dpp_move<0x112>(0u, u);
+    u += dpp_move<0x114>(0u, u);
+    u += dpp_move<0x118>(0u, u);
+    u += dpp_move<0x142, 0xa>(0u, u);
+    u += dpp_move<0x143, 0xc>(0u, u);
+    return (int)u;
+}
 
 }  // namespace midas

@@ -1612,8 +1612,8 @@ MD void lazy_tables(const LazyResample& rs, double* rs_lds) {
 // the motion model runs between the loads and their use: no workgroup barrier, no serial LDS loop - the sequential block
 // prefix is a left fold over lane values read with v_readlane (the same additions in the same order as lazy_tables).
 // Layout of the wave's block (LAZY_WAVE_LDS doubles): [0, 64) block prefix | [64, 128) block ends | 128 total | 130 apply |
-// 131 status of the previous frame.
-constexpr int LAZY_WAVE_LD = 64, LAZY_WAVE_LDS = 2 * LAZY_WAVE_LD + 4;
+// 131 status of the previous frame | [132, 196) block totals (the guide table's bin width, GUIDE_BINS).
+constexpr int LAZY_WAVE_LD = 64, LAZY_WAVE_LDS = 3 * LAZY_WAVE_LD + 4;
 struct LazyRecords { double bt, btr, bx, bn; int32_t status; };
 MD LazyRecords lazy_records_load(const LazyResample& rs) {
     const int lane = threadIdx.x & 63;
@@ -1642,6 +1642,7 @@ MD void lazy_tables_wave(const LazyResample& rs, const LazyRecords& r, double* r
     if (in) {
         rs_lds[lane] = bp;
         rs_lds[LAZY_WAVE_LD + lane] = (lane == rs.nb - 1) ? 1.0 : (bp + w) / total;
+        rs_lds[2 * LAZY_WAVE_LD + 4 + lane] = w;
     }
     if (lane == 0) {
         rs_lds[2 * LAZY_WAVE_LD] = total;
@@ -1687,10 +1688,14 @@ MD int64_t lazy_source(const LazyResample& rs, const double* rs_lds, int64_t n, 
         if (left_exact(s_end[mid])) lo = mid + 1; else hi = mid;
     }
     if (lo >= rs.nb) return N - 1;
-    if constexpr (__is_same(LT, lds_cdp))
+    if constexpr (__is_same(LT, lds_cdp)) {
         return search_in_block_t<lds_cdp, GT>(lp_lds, gend, apply ? rs.ggend : rs.ggend_raw, lo, N, N - 1, s_bp[lo], total, tq, upper, gend_lds);
-    else
-        return search_in_block_t<const double*, GT>(lp, gend, apply ? rs.ggend : rs.ggend_raw, lo, N, N - 1, s_bp[lo], total, tq, upper, gend_lds);
+    } else {
+        // guide table of the block (per-wave tables only: they keep the block totals): the unit from one entry pair
+        const guide_t* guide = ld == LAZY_WAVE_LD ? (apply ? rs.guide : rs.guide_raw) : nullptr;
+        return search_in_block_t<const double*, GT>(lp, gend, apply ? rs.ggend : rs.ggend_raw, lo, N, N - 1, s_bp[lo], total, tq, upper, gend_lds,
+                                                    guide, guide ? rs_lds[2 * LAZY_WAVE_LD + 4 + lo] : 0.0);
+    }
 }
 
 // =================================================================================================

@@ -579,6 +579,7 @@ __global__ __launch_bounds__(256) void k_tail_a2d(int64_t N, const double* __res
                                                   ScorePredict pr = ScorePredict(), bool rmse_raw = false) {
     __shared__ double s_gtot[32];
     __shared__ double s_red[24];
+    __shared__ uint32_t s_gh[TAIL_GUIDE_LDS];
     if ((int)blockIdx.x >= nb_tail) {  // (single trajectory only: the launcher adds these workgroups when pr.stamps is set)
         predict_scan(pr, (int)blockIdx.x - nb_tail);
         return;
@@ -589,10 +590,11 @@ __global__ __launch_bounds__(256) void k_tail_a2d(int64_t N, const double* __res
         tb.e += ts; tb.x_raw += ts; tb.lp += ts; tb.lp_raw += ts; tb.gend += ts; tb.gend_raw += ts; tb.ggend += ts; tb.ggend_raw += ts;
         tb.bsum_e += ts; tb.btot += ts; tb.btot_raw += ts; tb.bmax += ts; tb.bmin += ts;
         if (part_rmse) { part_rmse += 2 * b * nrm; rmse_out += 3 * b; }
+        tb.guide = nullptr; tb.guide_raw = nullptr;  // (single trajectory only)
     }
     int kept = 0;
     bool nan = false;
-    tail_a_direct(N, (int)blockIdx.x, scores, nn_idx, valid, softmax, tb, padded, s_gtot, s_red, kept, nan);
+    tail_a_direct(N, (int)blockIdx.x, scores, nn_idx, valid, softmax, tb, padded, s_gtot, s_red, kept, nan, tb.guide ? s_gh : nullptr);
     const int t = threadIdx.x;
     if (t == 0) {
         if (nan) atomicOr(&status[0], 2);

@@ -78,12 +78,18 @@ MD double block_total(const double* v, double* s_gtot) {
 // written in whole 16-value chunks (the layouts are padded to multiples of 16, values past N are never read).
 // padded: the per-slot tables hold a multiple of 16 values, so the chunk that straddles N is stored whole too.  Needs N >= 16.
 // s_gtot: 32 doubles (two reductions in flight), s_red: 24 doubles of LDS.  kept_out (every thread): valid slots of the block; nan_out: some masked
-// weight of the block is NaN.
+// weight of the block is NaN.  s_gh (nullable, TAIL_GUIDE_LDS words of LDS; with tb.guide / tb.guide_raw): the block's guide table is written too.
 MD void tail_a_direct(int64_t N, int blk, const double* __restrict__ scores, const int32_t* __restrict__ nn_idx,
                       const uint8_t* __restrict__ valid, int32_t softmax, const TailTables& tb, bool padded, double* s_gtot,
-                      double* s_red, int& kept_out, bool& nan_out) {
+                      double* s_red, int& kept_out, bool& nan_out, uint32_t* s_gh = nullptr) {
     const int t = threadIdx.x;
     TA_CLK(0);
+    auto guide_clear = [&]() {  // the guide pass's histogram (each thread its own counters)
+        uint4* h4 = reinterpret_cast<uint4*>(s_gh) + t * (GUIDE_BINS / SCAN_TPB / 8);
+#pragma unroll
+        for (int i = 0; i < GUIDE_BINS / SCAN_TPB / 8; ++i) h4[i] = make_uint4(0u, 0u, 0u, 0u);
+    };
+    if (s_gh) guide_clear();  // (in the shadow of the index loads; the scans' barriers stand between this and the first count)
     const int64_t bbase = (int64_t)blk * SCAN_BLOCK, base = bbase + (int64_t)t * SCAN_CHUNK;
     // Sixteen contiguous slots from ONE address (the loads share it and travel together; a clamped index per slot would
     // cost an address register pair each).  A chunk that would run past N starts at N - 16 instead and is shifted below.
@@ -163,7 +169,7 @@ MD void tail_a_direct(int64_t N, int blk, const double* __restrict__ scores, con
     // one variant, in place: val[j] of the own chunk -> sums, prefix, tables (val is consumed)
     bool extrema_read = false;
     auto variant = [&](double* val, double* __restrict__ lp_out, double* __restrict__ gend_out,
-                       double* __restrict__ ggend_out, double& W_all, double& W_masked, bool& vnan) {
+                       double* __restrict__ ggend_out, double& W_all, double& W_masked, bool& vnan, guide_t* __restrict__ guide_out) {
 #pragma unroll
         for (int j = 0; j < SCAN_CHUNK; ++j) val[j] = base + j < N ? val[j] : 0.0;
         W_all = block_total(val, s_gtot);
@@ -178,6 +184,66 @@ MD void tail_a_direct(int64_t N, int blk, const double* __restrict__ scores, con
         if (base < N) gend_out[(bbase >> 4) + t] = val[SCAN_CHUNK - 1];              // block-local prefix at the chunk end
         if ((t & 15) == 15) ggend_out[(bbase >> 8) + (t >> 4)] = val[SCAN_CHUNK - 1];  // ... at the end of each 256-slot group
         store_chunk(lp_out, val);
+        if (s_gh && guide_out) {
+            // guide table (GUIDE_BINS / GUIDE_UNIT, midas_internal.hpp): entry k = number of unit ends left of edge k.  Every thread
+            // finds, for the units of its chunk, the first edge beyond the unit's end, k_u = min{k : fl(k q) > end_u} (estimate
+            // through the reciprocal, settled on the edges themselves) and counts it into a histogram over the edges in LDS (16-bit
+            // counters, two to a word); the entries are the histogram's running sum: each thread sums its GUIDE_BINS / 256
+            // consecutive counters, the threads' totals are scanned across the workgroup, and the thread's entries leave in whole
+            // 16-byte pieces.  (Runs of entries written unit by unit - scattered 2-byte stores, to memory or LDS - cost the kernel
+            // 1.2 us; ends that do not rise - raw weights of mixed sign, NaN - give entries that are valid unit numbers and no
+            // more: the table is a hint.)
+            constexpr int UPC = SCAN_CHUNK / GUIDE_UNIT;  // units per chunk
+            constexpr int EPT = GUIDE_BINS / SCAN_TPB;    // entries per thread
+            static_assert(EPT % 8 == 0, "a thread's entries are whole 16-byte pieces");
+            const double q = W_masked * GUIDE_WIDTH, rq = (double)GUIDE_BINS * __builtin_amdgcn_rcp(W_masked);
+            const int64_t left_n = N - bbase;
+            const int nch = left_n >= SCAN_BLOCK ? SCAN_TPB : (int)((left_n + SCAN_CHUNK - 1) >> 4);
+            uint4* h4 = reinterpret_cast<uint4*>(s_gh) + t * (EPT / 8);
+            int ku[UPC];
+#pragma unroll
+            for (int j = 0; j < UPC; ++j) {
+                const double end_u = val[GUIDE_UNIT * (j + 1) - 1], kf = end_u * rq;
+                int k = kf > 0.0 ? (kf < (double)GUIDE_BINS ? (int)kf + 1 : GUIDE_BINS) : 0;
+                if (k > 0 && (double)(k - 1) * q > end_u) --k;
+                if (k < GUIDE_BINS && (double)k * q <= end_u) ++k;
+                ku[j] = k;
+            }
+            if (t < nch) {
+#pragma unroll
+                for (int j = 0; j < UPC; ++j)  // (an end at or beyond the last edge is left of no edge that has an entry)
+                    if (ku[j] < GUIDE_BINS) atomicAdd(&s_gh[ku[j] >> 1], 1u << (16 * (ku[j] & 1)));
+            }
+            __syncthreads();
+            unsigned c[EPT];
+#pragma unroll
+            for (int i = 0; i < EPT / 8; ++i) {
+                const uint4 w = h4[i];
+                c[8 * i + 0] = w.x & 0xFFFFu; c[8 * i + 1] = w.x >> 16; c[8 * i + 2] = w.y & 0xFFFFu; c[8 * i + 3] = w.y >> 16;
+                c[8 * i + 4] = w.z & 0xFFFFu; c[8 * i + 5] = w.z >> 16; c[8 * i + 6] = w.w & 0xFFFFu; c[8 * i + 7] = w.w >> 16;
+            }
+            guide_clear();  // (for the other variant's pass, if there is one: its scans' barriers stand in between)
+#pragma unroll
+            for (int i = 1; i < EPT; ++i) c[i] += c[i - 1];
+            const int incl = wave_iscan_dpp((int)c[EPT - 1]);
+            int* s_wt = reinterpret_cast<int*>(s_gh + GUIDE_BINS / 2);
+            if ((t & 63) == 63) s_wt[t >> 6] = incl;
+            __syncthreads();
+            unsigned basec = (unsigned)incl - c[EPT - 1];
+            for (int w = 0; w < (t >> 6); ++w) basec += (unsigned)s_wt[w];
+            const unsigned maxu = (unsigned)(nch * UPC - 1);
+            guide_t* g = guide_out + (int64_t)blk * GUIDE_STRIDE;
+            uint4* dst4 = reinterpret_cast<uint4*>(g + t * EPT);
+            auto ent = [&](int i) { const unsigned e = basec + c[i]; return e < maxu ? e : maxu; };
+#pragma unroll
+            for (int i = 0; i < EPT / 8; ++i) {
+                uint4 w;
+                w.x = ent(8 * i + 0) | (ent(8 * i + 1) << 16); w.y = ent(8 * i + 2) | (ent(8 * i + 3) << 16);
+                w.z = ent(8 * i + 4) | (ent(8 * i + 5) << 16); w.w = ent(8 * i + 6) | (ent(8 * i + 7) << 16);
+                dst4[i] = w;
+            }
+            if (t == 0) g[GUIDE_BINS] = (guide_t)maxu;
+        }
     };
     double Wa = 0.0, Wm = 0.0;
     if (need_soft) {
@@ -191,7 +257,7 @@ MD void tail_a_direct(int64_t N, int blk, const double* __restrict__ scores, con
         TA_CLK(4);
         store_chunk(tb.e, v);
         TA_CLK(5);
-        variant(v, tb.lp, tb.gend, tb.ggend, Wa, Wm, nan);
+        variant(v, tb.lp, tb.gend, tb.ggend, Wa, Wm, nan, tb.guide);
         TA_CLK(6);
         if (t == 0) { tb.bsum_e[blk] = Wa; tb.btot[blk] = Wm; }
     }
@@ -204,7 +270,7 @@ MD void tail_a_direct(int64_t N, int blk, const double* __restrict__ scores, con
         }
         store_chunk(tb.x_raw, v);
         bool nan_raw = false;
-        variant(v, tb.lp_raw, tb.gend_raw, tb.ggend_raw, Wa, Wm, nan_raw);
+        variant(v, tb.lp_raw, tb.gend_raw, tb.ggend_raw, Wa, Wm, nan_raw, tb.guide_raw);
         if (t == 0) tb.btot_raw[blk] = Wm;
         if (!need_soft) nan = nan_raw;  // with the softmax on, x NaN <=> e NaN: counted once
     } else if (t == 0) {

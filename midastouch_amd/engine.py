@@ -13,6 +13,7 @@ Two random-draw modes:
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -94,14 +95,13 @@ class FilterEngine:
         self.rmse = torch.zeros(2, dtype=torch.float64, device=self.device)
         # 16 cumulative counters ([0], [1] = tree-search fallbacks); with MIDAS_ABLATE=4 (profiling) the kernel
         # also keeps 16 statistics slots per wave behind them
-        import os
         extra = 16 * ((N + 15) // 16) if int(os.environ.get("MIDAS_ABLATE", "0")) & 4 else 0
         self.telemetry = torch.zeros(16 + extra, dtype=torch.int64, device=self.device)
         self.step_count = 0
         self.use_hint = True
         # sparse scoring: only the rows that are some particle's nearest entry are scored, by the particle kernels
         # themselves (stamps of the frame that last scored a row; include/midas_hip.h score_stamps_dev).  Same scores.
-        import os as _os
+        _os = os
         self.sparse_scores = self.codebook.emb.dtype == torch.float32 and self.D in (128, 256, 512, 1024) and \
             _os.environ.get("MIDAS_DENSE_SCORES", "0") != "1"
         self._stamps = torch.zeros(self.K, dtype=torch.int32, device=self.device)
@@ -233,6 +233,9 @@ class PipelinedFilterEngine(FilterEngine):
         self._valid = torch.zeros(N, dtype=torch.uint8, device=dev)
         ng, nb = (N + 15) // 16, (N + 4095) // 4096
         self._tables = torch.zeros(4 * (-(-N // 16) * 16) + 2 * (-(-ng // 16) * 16) + 37 * nb, **f64)
+        # guide tables of the folded resample's search (midas_lazy_args.guide_dev; MIDAS_GUIDE=0: the three-line search alone)
+        self._guide = (torch.zeros(int(self.ctx.lib.midas_lazy_guide_bytes(N)), dtype=torch.uint8, device=dev)
+                       if os.environ.get("MIDAS_GUIDE", "1") != "0" and nb <= 64 else None)
         self._scores = torch.zeros(self.K, **f64)
         self._part_rmse = torch.zeros(2 * ((N + 63) // 64), **f64)
         self._cur = 0
@@ -242,7 +245,6 @@ class PipelinedFilterEngine(FilterEngine):
         self._rmse_last = self._rmse_frame   # where the latest frame left {rmse_t, rmse_r, clock}: _rmse_frame or a row of the run log
         # prediction lists of the sparse scoring (include/midas_hip.h score_list_dev): the rows a frame used are scored for
         # the next frame by streaming workgroups of its front launch.  MIDAS_SCORE_LIST=0: every row by its first particle.
-        import os
         self._score_list = torch.zeros(2 + 2 * self.K, dtype=torch.int32, device=dev) \
             if self.sparse_scores and os.environ.get("MIDAS_SCORE_LIST", "1") != "0" and N >= 16 else None
 
@@ -314,6 +316,7 @@ class PipelinedFilterEngine(FilterEngine):
         a.poses_prop_prev, a.nn_idx_prev, a.status_prev = _ptr(self._prop[cur]), _ptr(self._nn[cur]), _ptr(self._st[cur])
         a.poses_prop, a.nn_idx, a.valid, a.status = _ptr(self._prop[nxt]), _ptr(self._nn[nxt]), _ptr(self._valid), _ptr(self._st[nxt])
         a.tables, a.scores = _ptr(self._tables), _ptr(self._scores)
+        a.guide = _ptr(self._guide) if self._guide is not None else None
         a.part_rmse = _ptr(self._part_rmse) if gt is not None else None
         a.resample_prev = int(fold)
         a.poses_in = _ptr(self._poses)
@@ -361,6 +364,7 @@ class PipelinedFilterEngine(FilterEngine):
         a.poses_prop_prev, a.nn_idx_prev, a.status_prev = _ptr(self._prop[cur]), _ptr(self._nn[cur]), _ptr(self._st[cur])
         a.poses_prop, a.nn_idx, a.valid, a.status = _ptr(self._prop[nxt]), _ptr(self._nn[nxt]), _ptr(self._valid), _ptr(self._st[nxt])
         a.tables, a.scores = _ptr(self._tables), _ptr(self._scores)
+        a.guide = _ptr(self._guide) if self._guide is not None else None
         a.part_rmse = _ptr(self._part_rmse) if gts is not None else None
         a.resample_prev = int(fold)
         a.poses_in = _ptr(self._poses)
@@ -461,13 +465,12 @@ class BatchFilterEngine:
         self.ridx = torch.zeros((B, N), dtype=torch.int32, device=d)
         self.status = torch.zeros((B, 2), dtype=torch.int32, device=d)
         self.rmse = torch.zeros((B, 2), dtype=torch.float64, device=d)
-        import os
         extra = 16 * B * ((N + 63) // 64) if int(os.environ.get("MIDAS_ABLATE", "0")) & 4 else 0  # per-wave statistics (profiling)
         self.telemetry = torch.zeros(16 + extra, dtype=torch.int64, device=d)
         self.step_count = 0
         # sparse scoring per trajectory (B x K stamps): the particle waves score the rows their trajectory needs with the
         # float64 arithmetic of the single-trajectory step; MIDAS_DENSE_SCORES=1 keeps the matrix-core pass over all rows
-        import os as _os
+        _os = os
         self.sparse_scores = self.codebook.emb.dtype == torch.float32 and self.codebook.D in (128, 256, 512, 1024) and \
             _os.environ.get("MIDAS_DENSE_SCORES", "0") != "1"
         self._stamps = torch.zeros((B, self.codebook.K), dtype=torch.int32, device=d) if self.sparse_scores else None

@@ -32,11 +32,12 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert lib.midas_strerror(0) == b"ok" and lib.midas_strerror(-1) == b"invalid argument"
 
 
-def test_step_args_struct_matches_header():
-    """Field order of the ctypes mirror of midas_step_args follows the header."""
+@pytest.mark.parametrize("cname,mirror", [("midas_step_args", "StepArgs"), ("midas_lazy_args", "LazyArgs")])
+def test_args_structs_match_header(cname, mirror):
+    """Field order of the ctypes mirrors of midas_step_args / midas_lazy_args follows the header."""
     from midastouch_amd import _lib
     text = open(os.path.join(REPO, "include", "midas_hip.h")).read()
-    body = text[text.index("typedef struct midas_step_args {"):text.index("} midas_step_args;")]
+    body = text[text.index("typedef struct %s {" % cname):text.index("} %s;" % cname)]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = []
     for decl in body.split("{", 1)[1].split(";"):
@@ -47,9 +48,9 @@ def test_step_args_struct_matches_header():
         first = names[0].split()[-1]
         fields.append(first)
         fields.extend(n.strip() for n in names[1:])
-    mirror = [f[0] for f in _lib.StepArgs._fields_]
+    got = [f[0] for f in getattr(_lib, mirror)._fields_]
     norm = [f.replace("_dev", "") for f in fields]
-    assert norm == mirror
+    assert norm == got
 
 
 def test_no_cpu_fallback():
