@@ -1633,16 +1633,31 @@ MD void lazy_tables_wave(const LazyResample& rs, const LazyRecords& r, double* r
     if (__any(nan)) { mx = NAN; mn = NAN; }
     const bool apply = rs.softmax && !(__builtin_fabs(mx - mn) <= LAZY_ISCLOSE_ATOL);
     const double w = in ? (apply ? r.bt : r.btr) : 0.0;
+    // The sequential prefix of the block totals: the totals go through LDS (every lane reads the same eight values a round -
+    // broadcast reads, all requested before the first addition) and every lane runs the same chain of additions, keeping the
+    // value it passes at its own block.  Blocks past nb hold +0.0: adding them changes nothing (the sum never is -0.0).
+    // (v_readlane with the block number in a scalar register cost two hazards and a branch per block: 1.4 us of a wave's life)
+    double* s_wb = rs_lds + 2 * LAZY_WAVE_LD + 4;
+    s_wb[lane] = w;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     double acc = 0.0, bp = 0.0;
-    for (int i = 0; i < rs.nb; ++i) {
-        bp = lane == i ? acc : bp;
-        acc = acc + rl_f64(w, i);
+    for (int i0 = 0; i0 < rs.nb; i0 += 8) {
+        double wv[8];
+        const double2* p2 = reinterpret_cast<const double2*>(s_wb + i0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const double2 t = p2[j]; wv[2 * j] = t.x; wv[2 * j + 1] = t.y; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bp = lane == i0 + j ? acc : bp;
+            acc = acc + wv[j];
+        }
     }
     const double total = acc;
     if (in) {
         rs_lds[lane] = bp;
         rs_lds[LAZY_WAVE_LD + lane] = (lane == rs.nb - 1) ? 1.0 : (bp + w) / total;
-        rs_lds[2 * LAZY_WAVE_LD + 4 + lane] = w;
     }
     if (lane == 0) {
         rs_lds[2 * LAZY_WAVE_LD] = total;
@@ -1984,7 +1999,7 @@ __global__ __launch_bounds__(64 * FW, (!SCR && FW == 1) ? MIDAS_BATCH_OCC : 1) v
                                                          double* __restrict__ scores, int64_t K) {
     static_assert(LAZY != 1 || FW == 4, "the workgroup-level tables take 256 threads");
     __shared__ double s_cd[FW][KD_MAX_LEVELS * 64];
-    __shared__ double s_rs[LAZY == 1 ? 3 * LAZY_MAX_BLOCKS + 8 : LAZY == 2 ? FW * LAZY_WAVE_LDS : 8];
+    __shared__ alignas(16) double s_rs[LAZY == 1 ? 3 * LAZY_MAX_BLOCKS + 8 : LAZY == 2 ? FW * LAZY_WAVE_LDS : 8];
     const int w = threadIdx.x >> 6;
     // A batch of trajectories (grid.y): workgroups go to the eight XCDs round robin by linear id, so with the plain
     // (x = wave, y = trajectory) reading every XCD's L2 holds the neighbour and vertex lists of ALL trajectories.  Read
@@ -2432,7 +2447,7 @@ MD void presort_offset_traj(ParticleUpdateArgs& a, int traj) {
 // softmax or the raw variant, as the guard decided) into LDS - N = 10 000: 5 KB - and a lane finds its chunk there; the scattered
 // fetches of a search drop from 25 sixteen-byte pieces to 9 (this kernel is bound by the vector cache's look-up rate: 35 -> 15 us).
 __global__ __launch_bounds__(256) void k_presort_search(ParticleUpdateArgs a, int32_t* __restrict__ src_out, int32_t* __restrict__ hint_out) {
-    __shared__ double s_rs[4][LAZY_WAVE_LDS];
+    __shared__ alignas(16) double s_rs[4][LAZY_WAVE_LDS];
     __shared__ double s_gend[PS_GEND_MAX];
     const int traj = (int)blockIdx.y, t = threadIdx.x, w = t >> 6, lane = t & 63;
     const int64_t o = (int64_t)traj * a.N;
