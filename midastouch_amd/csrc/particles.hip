@@ -1359,10 +1359,10 @@ MD void store_pose(float* p, const float* P) {
     for (int i = 0; i < 4; ++i) v[i] = make_float4(P[i * 4 + 0], P[i * 4 + 1], P[i * 4 + 2], P[i * 4 + 3]);
 }
 
-// the part of the motion model that does not depend on the particle's pose: NO = O @ Tn(noise of slot n)
-MD void noise_odom(int64_t n, int64_t n_global, const float* O, const float* tn_arr, const float* rot_arr, float std_t,
-                   float std_r, uint64_t seed, uint64_t step, float* NO) {
-    float tn[3], rot[3];
+// the part of the motion model that does not depend on the particle's pose: NO = O @ Tn(noise of slot n) - in two halves (the draws;
+// the noise transform and the product), so that a caller may put a round trip of its own under each
+MD void noise_draws(int64_t n, int64_t n_global, const float* tn_arr, const float* rot_arr, float std_t, float std_r, uint64_t seed,
+                    uint64_t step, float* tn, float* rot) {
     if (tn_arr) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) { tn[j] = tn_arr[n * 3 + j]; rot[j] = rot_arr[n * 3 + j]; }
@@ -1376,9 +1376,17 @@ MD void noise_odom(int64_t n, int64_t n_global, const float* O, const float* tn_
 #pragma unroll
         for (int j = 0; j < 3; ++j) { tn[j] = z[j] * std_t; rot[j] = z[3 + j] * std_r; }
     }
+}
+MD void noise_apply(const float* O, const float* tn, const float* rot, float* NO) {
     float Tn[16];
     noise_transform(tn, rot, Tn);
     mat4_mul(O, Tn, NO);
+}
+MD void noise_odom(int64_t n, int64_t n_global, const float* O, const float* tn_arr, const float* rot_arr, float std_t,
+                   float std_r, uint64_t seed, uint64_t step, float* NO) {
+    float tn[3], rot[3];
+    noise_draws(n, n_global, tn_arr, rot_arr, std_t, std_r, seed, step, tn, rot);
+    noise_apply(O, tn, rot, NO);
 }
 
 MD void propagate_one(int64_t n, int64_t n_global, const float* P, const float* O, const float* tn_arr,
@@ -1672,9 +1680,11 @@ MD void lazy_tables_wave(const LazyResample& rs, const LazyRecords& r, double* r
 // Per-lane part: the source particle of slot n (what k_tail_b2 writes to ridx[n]).
 // ld = stride of the table block: 256 (lazy_tables, one block per workgroup) or LAZY_WAVE_LD (lazy_tables_wave)
 // gend_lds / lp_lds (both or gend_lds alone): the caller's LDS copies of the chunk-end / per-slot tables
-template <typename GT = const double*, typename LT = const double*>
+// mid: arithmetic of the caller's that does not depend on the search, run once while the guide entries travel (NoMid: none; a lane
+// that leaves the search before that point has not run it - the caller looks at its own flag)
+template <typename GT = const double*, typename LT = const double*, typename MID = NoMid>
 MD int64_t lazy_source(const LazyResample& rs, const double* rs_lds, int64_t n, int64_t N, int ld = 256, GT gend_lds = nullptr,
-                       LT lp_lds = nullptr) {
+                       LT lp_lds = nullptr, MID mid = MID()) {
     const double* s_bp = rs_lds;
     const double* s_end = rs_lds + ld;
     const double total = rs_lds[2 * ld];
@@ -1708,8 +1718,8 @@ MD int64_t lazy_source(const LazyResample& rs, const double* rs_lds, int64_t n, 
     } else {
         // guide table of the block (per-wave tables only: they keep the block totals): the unit from one entry pair
         const guide_t* guide = ld == LAZY_WAVE_LD ? (apply ? rs.guide : rs.guide_raw) : nullptr;
-        return search_in_block_t<const double*, GT>(lp, gend, apply ? rs.ggend : rs.ggend_raw, lo, N, N - 1, s_bp[lo], total, tq, upper, gend_lds,
-                                                    guide, guide ? rs_lds[2 * LAZY_WAVE_LD + 4 + lo] : 0.0);
+        return search_in_block_t<const double*, GT, MID>(lp, gend, apply ? rs.ggend : rs.ggend_raw, lo, N, N - 1, s_bp[lo], total, tq, upper, gend_lds,
+                                                         guide, guide ? rs_lds[2 * LAZY_WAVE_LD + 4 + lo] : 0.0, mid);
     }
 }
 
@@ -1803,15 +1813,24 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
         LazyRecords rec;
         if (!presorted) rec = lazy_records_load(a.rs);
         __builtin_amdgcn_sched_barrier(0);
-        if (live) noise_odom(n, n + a.slot_base, O, a.tn, a.rot, a.std_t, a.std_r, a.seed, a.step, NO);
+        // (the draws under the records' round trip; the noise transform and O @ Tn under the guide entries' - see lazy_source)
+        float tnv[3] = {0.f, 0.f, 0.f}, rotv[3] = {0.f, 0.f, 0.f};
+        bool no_done = false;
+        if (live) noise_draws(n, n + a.slot_base, a.tn, a.rot, a.std_t, a.std_r, a.seed, a.step, tnv, rotv);
         if (!presorted) lazy_tables_wave(a.rs, rec, rs_lds);
+        auto mid = [&]() { noise_apply(O, tnv, rotv, NO); no_done = true; };
+        if (rs_lds && live && !presorted && !(ablate & 8)) {
+            src = lazy_source(a.rs, rs_lds, n, a.N, LAZY_WAVE_LD, (const double*)nullptr, (const double*)nullptr, mid);
+            if (a.rs.ridx_out) a.rs.ridx_out[n] = (int32_t)src;
+        }
+        if (live && !no_done) mid();
     }
     if (rs_lds && live) {
         if (presorted) {
             src = src_pre;  // (ridx_out was written by the presort)
-        } else {
+        } else if (!WT) {
             // ablate 8 (profiling): no search, own slot
-            src = (ablate & 8) ? n : lazy_source(a.rs, rs_lds, n, a.N, WT ? LAZY_WAVE_LD : 256);
+            src = (ablate & 8) ? n : lazy_source(a.rs, rs_lds, n, a.N, 256);
             if (a.rs.ridx_out) a.rs.ridx_out[n] = (int32_t)src;
         }
     }

@@ -512,14 +512,21 @@ __global__ __launch_bounds__(256) void k_tail_a2(int64_t N, const double* __rest
 // codebook's spacing per frame, so most of the rows it needs were needed the frame before: they are then scored by
 // balanced, coalesced streaming waves instead of by whichever particle wave touches them first (in the frames after a
 // wide start a wave claimed up to 64 rows = 16 rounds of cold 8 KB fetches, and the kernel ends with its slowest wave).
-constexpr int PREDICT_PER_THREAD = 4;
-MD void predict_scan(const ScorePredict& pr, int blk) {
-    const int lane = threadIdx.x & 63;
+constexpr int PREDICT_PER_THREAD = 16;
+// One workgroup lists the rows of its 256 x PREDICT_PER_THREAD stamps that carry this frame's epoch: counts per thread, a prefix
+// over the wave (DPP), the waves' totals through LDS, ONE bump of the list's counter per workgroup.  (One bump per wave with four
+// stamps a thread was 196 serialised read-modify-writes of one address whenever most waves had rows to list - the frames after
+// a wide start, 10^4 rows in use: 3 - 5 us of the tail kernel there.)  s_wt: 8 ints of LDS.
+MD void predict_scan(const ScorePredict& pr, int blk, int* s_wt) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t k0 = ((int64_t)blk * 256 + threadIdx.x) * PREDICT_PER_THREAD;
     uint32_t st[PREDICT_PER_THREAD];
     if (k0 + PREDICT_PER_THREAD <= pr.K) {
-        const uint4 v = *reinterpret_cast<const uint4*>(pr.stamps + k0);
-        st[0] = v.x; st[1] = v.y; st[2] = v.z; st[3] = v.w;
+#pragma unroll
+        for (int q = 0; q < PREDICT_PER_THREAD / 4; ++q) {
+            const uint4 v = reinterpret_cast<const uint4*>(pr.stamps + k0)[q];
+            st[4 * q] = v.x; st[4 * q + 1] = v.y; st[4 * q + 2] = v.z; st[4 * q + 3] = v.w;
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < PREDICT_PER_THREAD; ++j) st[j] = k0 + j < pr.K ? pr.stamps[k0 + j] : 0u;
@@ -527,19 +534,15 @@ MD void predict_scan(const ScorePredict& pr, int blk) {
     int n = 0;
 #pragma unroll
     for (int j = 0; j < PREDICT_PER_THREAD; ++j) n += (k0 + j < pr.K && st[j] == pr.epoch) ? 1 : 0;
-    // exclusive prefix of n over the wave, one counter bump per wave
-    int incl = n;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
-    }
-    const int total = __shfl(incl, 63);
-    if (total == 0) return;
-    int base = 0;
-    if (lane == 63) base = atomicAdd(pr.count, total);
-    base = __shfl(base, 63);
-    int pos = base + incl - n;
+    const int incl = wave_iscan_dpp(n);
+    if (lane == 63) s_wt[w] = incl;
+    __syncthreads();
+    const int t0 = s_wt[0], t1 = s_wt[1], t2 = s_wt[2], t3 = s_wt[3];
+    const int total = t0 + t1 + t2 + t3;
+    if (total == 0) return;  // (uniform over the workgroup)
+    if (threadIdx.x == 0) s_wt[4] = atomicAdd(pr.count, total);
+    __syncthreads();
+    int pos = s_wt[4] + (w > 0 ? t0 : 0) + (w > 1 ? t1 : 0) + (w > 2 ? t2 : 0) + incl - n;
 #pragma unroll
     for (int j = 0; j < PREDICT_PER_THREAD; ++j)
         if (k0 + j < pr.K && st[j] == pr.epoch) {
@@ -561,7 +564,10 @@ __global__ __launch_bounds__(256) void k_predict_mark(int64_t N, const int32_t* 
     const int32_t r = idx[n];
     if (r >= 0 && r < K) stamps[r] = epoch;  // every marker of a row stores the same value
 }
-__global__ __launch_bounds__(256) void k_predict_scan(ScorePredict pr) { predict_scan(pr, (int)blockIdx.x); }
+__global__ __launch_bounds__(256) void k_predict_scan(ScorePredict pr) {
+    __shared__ int s_wt[8];
+    predict_scan(pr, (int)blockIdx.x, s_wt);
+}
 
 int launch_predict_seed(midas_ctx* ctx, int64_t N, const int32_t* idx, const ScorePredict& pr) {
     MIDAS_HIP_CHECK(ctx, hipMemsetAsync(pr.count, 0, sizeof(int32_t), ctx->stream));
@@ -581,7 +587,7 @@ __global__ __launch_bounds__(256) void k_tail_a2d(int64_t N, const double* __res
     __shared__ double s_red[24];
     __shared__ uint32_t s_gh[TAIL_GUIDE_LDS];
     if ((int)blockIdx.x >= nb_tail) {  // (single trajectory only: the launcher adds these workgroups when pr.stamps is set)
-        predict_scan(pr, (int)blockIdx.x - nb_tail);
+        predict_scan(pr, (int)blockIdx.x - nb_tail, reinterpret_cast<int*>(s_red));
         return;
     }
     if (blockIdx.y) {  // pipelined batch: trajectory blockIdx.y - its own table block (tables_of layout), scores, arrays, rmse triple

@@ -21,12 +21,13 @@ namespace midas {
 // midas_internal.hpp) - the bin of the draw's block-local target names a unit of GUIDE_UNIT slots, or two neighbouring units
 // whose slots are fetched together; the group-end and chunk-end lines are read only where a bin spans more (runs of pruned
 // particles) or the totals are not positive.  Which slots the search starts from changes nothing in the result: the fix-up is
-// exact.  Measured at N = 100k (rocprofv3 means): front 29.4 -> 26.5 us, the tail's guide pass + 0.5 - 0.9 us.
+// exact.  mid: see lazy_source (particles.hip).  Measured at N = 100k (rocprofv3 means): front 29.4 -> 26.5 us, the tail's guide pass + 0.5 - 0.9 us.
 typedef const __attribute__((address_space(3))) double* lds_cdp;
-template <typename LPT, typename GT>
+struct NoMid { MD void operator()() const {} };
+template <typename LPT, typename GT, typename MID = NoMid>
 MD int64_t search_in_block_t(LPT lp, const double* __restrict__ gend, const double* __restrict__ ggend,
                              int b, int64_t N, int64_t one_slot, double bp, double total, double tq, bool upper, GT gend_lds,
-                             const guide_t* __restrict__ guide = nullptr, double Wb = 0.0) {
+                             const guide_t* __restrict__ guide = nullptr, double Wb = 0.0, MID mid = MID()) {
     // (total < 0: raw weights - the softmax is skipped when every particle has the same score, particle_filter.py:459-468 -
     // of a negative cosine; p = w / sum(w) is positive again (:238) and dividing by the negative total turns the comparison
     // round.  Without the turn the division-free probes point the wrong way and the exact walk below crosses the whole block
@@ -110,6 +111,10 @@ MD int64_t search_in_block_t(LPT lp, const double* __restrict__ gend, const doub
             if (k < GUIDE_BINS - 1 && x >= (double)(k + 1) * q) ++k;
             const guide_t* g = guide + (int64_t)b * GUIDE_STRIDE + k;
             const int uA = g[0], uB = g[1];
+            // the caller's independent arithmetic, under the entries' round trip
+            __builtin_amdgcn_sched_barrier(0);
+            mid();
+            __builtin_amdgcn_sched_barrier(0);
             if (uB >= uA && uB - uA <= 1 && (int64_t)uB * GUIDE_UNIT < b_hi - b_lo)
                 return finish(std::integral_constant<int, GUIDE_UNIT>(), b_lo + (int64_t)uA * GUIDE_UNIT, uB != uA);
         }
