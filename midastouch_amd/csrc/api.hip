@@ -702,9 +702,8 @@ static int lazy_step_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_
     MIDAS_REQUIRE(ctx, s.resample_mode == MIDAS_RESAMPLE_MULTINOMIAL || s.resample_mode == MIDAS_RESAMPLE_SYSTEMATIC);
     const int64_t N = s.N;
     TailTables tb = tables_of(s.tables_dev, N);
-    // guide tables of the summation blocks (GUIDE_BINS, midas_internal.hpp): softmax variant | raw variant; read by the fronts that
-    // build their resample tables per wave (up to 64 blocks), not written for larger sets
-    if (s.guide_dev && B == 1 && ceil_div(N, SCAN_BLOCK) <= 64) {
+    // guide tables of the summation blocks (GUIDE_BINS, midas_internal.hpp): softmax variant | raw variant
+    if (s.guide_dev && B == 1) {
         MIDAS_REQUIRE(ctx, (uintptr_t)s.guide_dev % 16 == 0);
         tb.guide = reinterpret_cast<guide_t*>(s.guide_dev);
         tb.guide_raw = tb.guide + ceil_div(N, SCAN_BLOCK) * GUIDE_STRIDE;

@@ -1572,7 +1572,9 @@ __global__ __launch_bounds__(256) void k_rmse_final(int64_t N, int nb, const dou
 // ---- resample of the previous frame as a prologue of the particle update (LazyResample) -------------------------
 // Workgroup part: guard, sequential block prefix, exact cdf at the block ends into LDS (every thread of the
 // 256-thread workgroup takes part).  rs_lds: [0, nb) block prefix | [256, 256+nb) block ends | 512: total, 513: S,
-// 514: apply.  Same arithmetic as k_tail_b / k_tail_b2.
+// 514: apply | [516, 516+nb) block sums of e | [LAZY_WG_W, +nb) block totals (the guide tables' bin width).  Same arithmetic as
+// k_tail_b / k_tail_b2.
+constexpr int LAZY_WG_W = 3 * LAZY_MAX_BLOCKS + 8, LAZY_WG_LDS = 4 * LAZY_MAX_BLOCKS + 8;
 constexpr double LAZY_ISCLOSE_ATOL = 1e-8;
 MD void lazy_tables(const LazyResample& rs, double* rs_lds) {
     __shared__ double s_ex[12];
@@ -1612,6 +1614,7 @@ MD void lazy_tables(const LazyResample& rs, double* rs_lds) {
     // the block's last slot (same additions in the same order); the last block ends at N-1, forced to 1
     const double wb = in ? s_w[t] : 0.0;
     __syncthreads();
+    if (in) rs_lds[LAZY_WG_W + t] = wb;
     if (in) s_w[t] = (t == rs.nb - 1) ? 1.0 : (s_bp[t] + wb) / total;
     __syncthreads();
 }
@@ -1716,10 +1719,10 @@ MD int64_t lazy_source(const LazyResample& rs, const double* rs_lds, int64_t n, 
     if constexpr (__is_same(LT, lds_cdp)) {
         return search_in_block_t<lds_cdp, GT>(lp_lds, gend, apply ? rs.ggend : rs.ggend_raw, lo, N, N - 1, s_bp[lo], total, tq, upper, gend_lds);
     } else {
-        // guide table of the block (per-wave tables only: they keep the block totals): the unit from one entry pair
-        const guide_t* guide = ld == LAZY_WAVE_LD ? (apply ? rs.guide : rs.guide_raw) : nullptr;
+        // guide table of the block: the unit from one entry pair (the block totals sit behind the tables, per wave or per workgroup)
+        const guide_t* guide = apply ? rs.guide : rs.guide_raw;
         return search_in_block_t<const double*, GT, MID>(lp, gend, apply ? rs.ggend : rs.ggend_raw, lo, N, N - 1, s_bp[lo], total, tq, upper, gend_lds,
-                                                         guide, guide ? rs_lds[2 * LAZY_WAVE_LD + 4 + lo] : 0.0, mid);
+                                                         guide, guide ? rs_lds[(ld == LAZY_WAVE_LD ? 2 * LAZY_WAVE_LD + 4 : LAZY_WG_W) + lo] : 0.0, mid);
     }
 }
 
@@ -2018,7 +2021,7 @@ __global__ __launch_bounds__(64 * FW, (!SCR && FW == 1) ? MIDAS_BATCH_OCC : 1) v
                                                          double* __restrict__ scores, int64_t K) {
     static_assert(LAZY != 1 || FW == 4, "the workgroup-level tables take 256 threads");
     __shared__ double s_cd[FW][KD_MAX_LEVELS * 64];
-    __shared__ alignas(16) double s_rs[LAZY == 1 ? 3 * LAZY_MAX_BLOCKS + 8 : LAZY == 2 ? FW * LAZY_WAVE_LDS : 8];
+    __shared__ alignas(16) double s_rs[LAZY == 1 ? LAZY_WG_LDS : LAZY == 2 ? FW * LAZY_WAVE_LDS : 8];
     const int w = threadIdx.x >> 6;
     // A batch of trajectories (grid.y): workgroups go to the eight XCDs round robin by linear id, so with the plain
     // (x = wave, y = trajectory) reading every XCD's L2 holds the neighbour and vertex lists of ALL trajectories.  Read
@@ -2118,7 +2121,7 @@ template <typename T, int NJ, bool LAZY>
 __global__ __launch_bounds__(256) void k_frame_front_a(ParticleUpdateArgs a, int n_pu, int nwaves, PuFeat* __restrict__ feat,
                                                        const T* __restrict__ emb, const double* __restrict__ norms,
                                                        const double* __restrict__ code, double* __restrict__ scores, int64_t K) {
-    __shared__ double s_rs[LAZY ? 3 * LAZY_MAX_BLOCKS + 8 : 8];
+    __shared__ double s_rs[LAZY ? LAZY_WG_LDS : 8];
     const int w = threadIdx.x >> 6;
     if ((int)blockIdx.x < n_pu) {
         if (LAZY) lazy_tables(a.rs, s_rs);

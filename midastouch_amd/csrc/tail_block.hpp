@@ -89,7 +89,10 @@ MD void tail_a_direct(int64_t N, int blk, const double* __restrict__ scores, con
 #pragma unroll
         for (int i = 0; i < GUIDE_BINS / SCAN_TPB / 8; ++i) h4[i] = make_uint4(0u, 0u, 0u, 0u);
     };
-    if (s_gh) guide_clear();  // (in the shadow of the index loads; the scans' barriers stand between this and the first count)
+    if (s_gh) {  // (in the shadow of the index loads; the scans' barriers stand between this and the first count)
+        guide_clear();
+        if (t == 0) s_gh[GUIDE_BINS / 2 + 5] = 0u;  // "some weight of the block is negative"
+    }
     const int64_t bbase = (int64_t)blk * SCAN_BLOCK, base = bbase + (int64_t)t * SCAN_CHUNK;
     // Sixteen contiguous slots from ONE address (the loads share it and travel together; a clamped index per slot would
     // cost an address register pair each).  A chunk that would run past N starts at N - 16 instead and is shifted below.
@@ -174,11 +177,13 @@ MD void tail_a_direct(int64_t N, int blk, const double* __restrict__ scores, con
         for (int j = 0; j < SCAN_CHUNK; ++j) val[j] = base + j < N ? val[j] : 0.0;
         W_all = block_total(val, s_gtot);
         if (!extrema_read) { block_extrema(); extrema_read = true; }  // behind block_total's barrier
+        bool negw = false;
         // (the scan's group totals go to the second half of s_gtot: no barrier between the two reductions)
 #pragma unroll
         for (int j = 0; j < SCAN_CHUNK; ++j) {
             val[j] = val[j] * ((okbits >> j) & 1u ? 1.0 : 0.0);  // okbits is clear on out-of-range slots
             vnan |= val[j] != val[j];
+            negw |= val[j] < 0.0;
         }
         W_masked = block_scan(val, val, s_gtot + 16);
         if (base < N) gend_out[(bbase >> 4) + t] = val[SCAN_CHUNK - 1];              // block-local prefix at the chunk end
@@ -214,7 +219,12 @@ MD void tail_a_direct(int64_t N, int blk, const double* __restrict__ scores, con
                 for (int j = 0; j < UPC; ++j)  // (an end at or beyond the last edge is left of no edge that has an entry)
                     if (ku[j] < GUIDE_BINS) atomicAdd(&s_gh[ku[j] >> 1], 1u << (16 * (ku[j] & 1)));
             }
+            // raw scores of mixed sign (the reference's sampler refuses them: torch.multinomial raises on a negative probability)
+            // give prefix values that do not rise: where a search starts would then decide which of several crossings it
+            // returns.  Such a block's table says "no guide" (entries beyond every unit: the front falls back to the table lines).
+            if (negw) atomicOr(&s_gh[GUIDE_BINS / 2 + 5], 1u);
             __syncthreads();
+            const bool no_guide = s_gh[GUIDE_BINS / 2 + 5] != 0u;
             unsigned c[EPT];
 #pragma unroll
             for (int i = 0; i < EPT / 8; ++i) {
@@ -231,10 +241,11 @@ MD void tail_a_direct(int64_t N, int blk, const double* __restrict__ scores, con
             __syncthreads();
             unsigned basec = (unsigned)incl - c[EPT - 1];
             for (int w = 0; w < (t >> 6); ++w) basec += (unsigned)s_wt[w];
-            const unsigned maxu = (unsigned)(nch * UPC - 1);
+            if (t == 0) s_gh[GUIDE_BINS / 2 + 5] = 0u;  // (every thread has read it: behind the barrier before this one)
+            const unsigned maxu = no_guide ? 0xFFFFu : (unsigned)(nch * UPC - 1);
             guide_t* g = guide_out + (int64_t)blk * GUIDE_STRIDE;
             uint4* dst4 = reinterpret_cast<uint4*>(g + t * EPT);
-            auto ent = [&](int i) { const unsigned e = basec + c[i]; return e < maxu ? e : maxu; };
+            auto ent = [&](int i) { const unsigned e = basec + c[i]; return no_guide ? 0xFFFFu : (e < maxu ? e : maxu); };
 #pragma unroll
             for (int i = 0; i < EPT / 8; ++i) {
                 uint4 w;

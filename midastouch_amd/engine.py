@@ -235,7 +235,7 @@ class PipelinedFilterEngine(FilterEngine):
         self._tables = torch.zeros(4 * (-(-N // 16) * 16) + 2 * (-(-ng // 16) * 16) + 37 * nb, **f64)
         # guide tables of the folded resample's search (midas_lazy_args.guide_dev; MIDAS_GUIDE=0: the three-line search alone)
         self._guide = (torch.zeros(int(self.ctx.lib.midas_lazy_guide_bytes(N)), dtype=torch.uint8, device=dev)
-                       if os.environ.get("MIDAS_GUIDE", "1") != "0" and nb <= 64 else None)
+                       if os.environ.get("MIDAS_GUIDE", "1") != "0" else None)
         self._scores = torch.zeros(self.K, **f64)
         self._part_rmse = torch.zeros(2 * ((N + 63) // 64), **f64)
         self._cur = 0

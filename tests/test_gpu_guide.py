@@ -44,7 +44,8 @@ def _tables(eng):
     ngp = -(-ng // 16) * 16
     t = eng._tables.cpu().numpy()
     o = 4 * Np + 2 * ngp + 32 * nb
-    return dict(lp=t[2 * Np:3 * Np], lp_raw=t[3 * Np:4 * Np], btot=t[o + nb:o + 2 * nb], btot_raw=t[o + 2 * nb:o + 3 * nb], nb=nb)
+    return dict(lp=t[2 * Np:3 * Np], lp_raw=t[3 * Np:4 * Np], x_raw=t[Np:2 * Np], btot=t[o + nb:o + 2 * nb], btot_raw=t[o + 2 * nb:o + 3 * nb],
+                nb=nb, valid=eng._valid.cpu().numpy())
 
 
 def _expected_guide(lp, W, N, blk, bins, unit):
@@ -71,6 +72,7 @@ def test_guide_table_matches_its_definition(dev, N, softmax, sig_t):
     assert eng._guide is not None and eng._guide.numel() == 2 * (-(-N // 4096)) * stride * 2
     eng.set_particles(torch.as_tensor(cb.poses[np.random.default_rng(3).integers(0, K, N)]))
     od, co = torch.as_tensor(traj.odoms).to(dev), torch.as_tensor(traj.codes).to(dev)
+    saw_negative = False
     for t in range(1, 7):
         eng.step(od[t], co[t])
         torch.cuda.synchronize()
@@ -84,7 +86,13 @@ def test_guide_table_matches_its_definition(dev, N, softmax, sig_t):
             if not (W[blk] > 0 and np.isfinite(W[blk])):
                 continue  # (such a block's table is not read)
             want = _expected_guide(lp, W[blk], N, blk, bins, unit)
+            if not softmax:  # raw scores: a block with a negative weight has no guide (its prefix values do not rise)
+                w = (tb["x_raw"][:N] * tb["valid"])[blk * 4096:(blk + 1) * 4096]
+                if (w < 0).any():
+                    want = np.full(bins + 1, 0xFFFF)
+                    saw_negative = True
             assert np.array_equal(g[var, blk, : bins + 1], want), f"frame {t} block {blk}"
+    assert not (softmax and saw_negative)
 
 
 @pytest.mark.parametrize("N,K,softmax,mode,sig_t", [
@@ -94,6 +102,8 @@ def test_guide_table_matches_its_definition(dev, N, softmax, sig_t):
     (5000, 3000, False, "weighted_random", 2e-4),   # raw scores as weights
     (20_000, 3000, True, "weighted_random", 3e-3),  # most particles pruned: bins that span many units fall back to the table lines
     (100_000, 5000, True, "weighted_random", 2e-4),
+    (300_000, 5000, True, "weighted_random", 2e-4),  # more than 64 blocks: the fronts with workgroup-level resample tables
+    (300_000, 5000, True, "low_var", 2e-4),
 ])
 def test_same_results_with_and_without_the_guide(dev, monkeypatch, N, K, softmax, mode, sig_t):
     from midastouch_amd.engine import PipelinedFilterEngine
