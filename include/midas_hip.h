@@ -312,7 +312,9 @@ typedef struct midas_lazy_args {
                                         * tables_dev and read by the NEXT frame's folded resample.  Per 4096-slot block `bins`
                                         * equal bins over its masked total W (edge k = fl(k * (W / bins))), a 16-bit entry each:
                                         * min(number of the block's `unit`-slot pieces whose last prefix value lies left of edge k,
-                                        * pieces of the block - 1) - the piece a draw falling into bin k starts its search from
+                                        * pieces of the block - 1) - the piece a draw falling into bin k starts its search from;
+                                        * 0xFFFF in every entry of a block that holds a negative weight (raw scores of mixed sign:
+                                        * its prefix values do not rise; the front searches such a block through the table lines)
                                         * (layout: softmax variant | raw-score variant, each ceil(N/4096) rows of `stride`
                                         * entries; midas_lazy_guide_layout).  One entry pair and 8 - 16 prefix values replace the
                                         * three 128-byte table lines of a draw's search; a hint only - the exact comparison on
