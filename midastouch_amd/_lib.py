@@ -7,6 +7,7 @@ memory (`tensor.data_ptr()`) and of the HIP stream the kernels are enqueued on.
 from __future__ import annotations
 
 import ctypes as C
+import sys
 import os
 import subprocess
 
@@ -363,7 +364,9 @@ class Context:
             self.lib.midas_ctx_destroy(self.h)
             self.h = None
 
-    def __del__(self):  # pragma: no cover
+    def __del__(self, _finalizing=sys.is_finalizing):  # pragma: no cover  # (bound at import: module globals are gone by then)
+        if _finalizing():  # the process is going away: the HIP runtime may be gone already (its calls would abort, not raise)
+            return
         try:
             self.close()
         except Exception:

@@ -33,6 +33,7 @@ backend is HIP-only (`HipShardBackend`); tests may inject another one.  There is
 from __future__ import annotations
 
 import ctypes as C
+import sys
 import os
 
 import torch
@@ -656,7 +657,9 @@ class ShardedFilterEngine:
             except Exception:
                 pass
 
-    def __del__(self):
+    def __del__(self, _finalizing=sys.is_finalizing):  # (bound at import: module globals are gone by then)
+        if _finalizing():  # the process is going away: the HIP runtime may be gone already (its calls would abort, not raise)
+            return
         try:
             self.close()
         except Exception:

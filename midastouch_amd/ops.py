@@ -6,6 +6,7 @@ cites the reference arithmetic it replaces (paths relative to /root/reference/mi
 from __future__ import annotations
 
 import ctypes as C
+import sys
 
 import torch
 
@@ -66,7 +67,9 @@ class Codebook:
         self.ctx.call("midas_score_batch", self.h, codes.shape[0], _ptr(codes), _ptr(out))
         return out
 
-    def __del__(self):  # pragma: no cover
+    def __del__(self, _finalizing=sys.is_finalizing):  # pragma: no cover  # (bound at import: module globals are gone by then)
+        if _finalizing():  # the process is going away: the HIP runtime may be gone already (its calls would abort, not raise)
+            return
         try:
             if self.h:
                 self.ctx.lib.midas_codebook_destroy(self.h)
@@ -110,7 +113,9 @@ class Tree:
         self.ctx.call("midas_tree_export", self.h, code, C.c_void_p(out.ctypes.data), out.nbytes)
         return out
 
-    def __del__(self):  # pragma: no cover
+    def __del__(self, _finalizing=sys.is_finalizing):  # pragma: no cover  # (bound at import: module globals are gone by then)
+        if _finalizing():  # the process is going away: the HIP runtime may be gone already (its calls would abort, not raise)
+            return
         try:
             if self.h:
                 self.ctx.lib.midas_tree_destroy(self.h)
