@@ -2584,12 +2584,13 @@ struct PresortLds {  // dynamic LDS of k_presort_fused
     int w[PS_THREADS / 64];
     int fail;
 };
-__global__ __launch_bounds__(PS_THREADS) void k_presort_fused(ParticleUpdateArgs a, int32_t* __restrict__ order, int32_t* __restrict__ srcr, int deal) {
+__global__ __launch_bounds__(PS_THREADS) void k_presort_fused(ParticleUpdateArgs a, int32_t* __restrict__ order, int32_t* __restrict__ srcr, int deal, int chunk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ps_raw[];
     PresortLds& L = *reinterpret_cast<PresortLds*>(ps_raw);
     const int traj = (int)blockIdx.y, t = threadIdx.x, wv = t >> 6;
-    const int64_t N = a.N, o = (int64_t)traj * N, base = (int64_t)blockIdx.x * PS_CHUNK;
-    const int64_t end = base + PS_CHUNK < N ? base + PS_CHUNK : N;
+    // chunk (<= PS_CHUNK, whole waves): slots per workgroup - the launcher cuts a trajectory into as many chunks as fill the CUs
+    const int64_t N = a.N, o = (int64_t)traj * N, base = (int64_t)blockIdx.x * chunk;
+    const int64_t end = base + chunk < N ? base + chunk : N;
     presort_offset_traj(a, traj);
     const LazyRecords rec = lazy_records_load(a.rs);
     lazy_tables_wave(a.rs, rec, L.rs[wv]);
@@ -2692,8 +2693,22 @@ static int launch_presort(midas_ctx* ctx, ParticleUpdateArgs& a) {
             MIDAS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_presort_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PresortLds)));
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_presort_fused, dim3((unsigned)ceil_div(a.N, PS_CHUNK), (unsigned)a.batch), dim3(PS_THREADS), sizeof(PresortLds), ctx->stream,
-                           a, (int32_t*)p_order, (int32_t*)p_srcr, run);
+        // One workgroup per CU is all the kernel's LDS allows, and a workgroup's life is a chain of round trips whatever its share: as many
+        // chunks per trajectory as fill the chip (c5: 64 trajectories x 4 chunks of 2560 slots on 256 CUs instead of 3 of 4096 -
+        // 285 / 270 -> 277 / 266 us per batch frame; 5 or 8 chunks - a second round of workgroups - lose: 290 / 285), whole waves each
+        static int ncu = 0;
+        if (!ncu) {
+            hipDeviceProp_t prop;
+            ncu = (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        }
+        static const int chunk_env = getenv("MIDAS_PRESORT_CHUNK") ? atoi(getenv("MIDAS_PRESORT_CHUNK")) : 0;
+        int64_t nch = ceil_div(a.N, PS_CHUNK);
+        if (ncu / a.batch > nch) nch = ncu / a.batch;
+        int64_t chunk = ceil_div(ceil_div(a.N, nch), 64) * 64;
+        if (chunk < 1024) chunk = 1024;  // (a chunk groups its own slots only: small ones share few list records)
+        if (chunk_env >= 64 && chunk_env <= PS_CHUNK && chunk_env % 64 == 0) chunk = chunk_env;
+        hipLaunchKernelGGL(k_presort_fused, dim3((unsigned)ceil_div(a.N, chunk), (unsigned)a.batch), dim3(PS_THREADS), sizeof(PresortLds), ctx->stream,
+                           a, (int32_t*)p_order, (int32_t*)p_srcr, run, (int)chunk);
     } else {
         if ((rc = midas_scratch(ctx, bytes, &p_src))) return rc;  // (the two-kernel form hands sources and hints over through memory)
         if ((rc = midas_scratch(ctx, bytes, &p_hint))) return rc;
