@@ -473,6 +473,8 @@ def main():
 
     def frames(i0, n):
         """n consecutive frames starting at trajectory position i0; one C-ABI call where the engine has one"""
+        if n <= 0:  # (--warmup 0)
+            return None
         t0_ = 1 + i0 % (T - 1)
         can_run = hasattr(eng, "run") and (not sharded or (eng.exchange == "peer_c" and eng._ccomm is not None))
         if can_run and not args.eager and t0_ + n <= T:
