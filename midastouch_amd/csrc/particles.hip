@@ -2768,7 +2768,9 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
     // (re-measured after the single kernel's second pass - per-wave tables, one-wave workgroups, screened scans: pipelined,
     // split / single at N = 6k 29.6k / 27.5k steps/s, 8k 29.0k / 27.9k, 12k 28.3k / 28.5k, 20k 25.8k / 27.1k, 65k 21.0k / 22.9k:
     // the two-kernel form now pays up to ~10 000 particles instead of 65 536; the loop step (live count) keeps it: 126 / 138 us)
-    const bool split_front = a.batch <= 1 && !a.inbox.rows && (split_env >= 2 || (split_env == 1 && ((a.rs.enabled && a.N <= 10240) || a.N <= 2048 || (a.n_live && a.N <= 16384))));
+    // (round 4, with the guide tables in the folded search: the single kernel wins from N = 1000 up - pipelined, split / single at
+    // N = 1k 27.4 / 26.4 us a step, 3k 28.8 / 26.8, 8k 28.7 / 26.7, 12k 27.0 / 27.1, 20k 27.5 / 27.5 - so the pipelined form splits no more)
+    const bool split_front = a.batch <= 1 && !a.inbox.rows && (split_env >= 2 || (split_env == 1 && ((a.rs.enabled && a.N <= 512) || (!a.rs.enabled && a.N <= 2048) || (a.n_live && a.N <= 16384))));
     const int lpp = split_env == 3 ? 2 : 4;
     if (split_front && !(a.ablate & 7)) {
         a.sp.pred_tag = 0; a.sp.list = nullptr;  // (next_count stays: the tail appends whatever form the front had)

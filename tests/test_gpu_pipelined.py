@@ -69,6 +69,29 @@ def test_pipelined_parity_device_draws(dev, oracle, mode, read_every):
     assert np.array_equal(eng.poses.cpu().numpy(), poses)  # final materialisation
 
 
+def test_pipelined_small_set_two_kernel_front(dev, oracle):
+    """N <= 512 in the pipelined form still takes the two-kernel front (resample prologue + feature, then four lanes per particle for
+    the list scans: launch_frame_front's rule; larger sets run the single kernel since the folded search has its guide tables)."""
+    from midastouch_amd.engine import PipelinedFilterEngine
+    N, K, D = 384, 3000, 256
+    cb, traj = _setup(N, K, D, 17)
+    ofl = oracle.OracleFilter(cb.poses, cb.embeddings, cb.mesh_vertices)
+    eng = PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=5100, device=dev)
+    poses = cb.poses[np.random.default_rng(21).integers(0, K, N)]
+    eng.set_particles(torch.as_tensor(poses))
+    for t in range(1, 10):
+        tn, rot = oracle.philox_noise(N, 5100, t - 1, np.float32(2e-4), np.float32(0.5))
+        ref = ofl.step(poses, traj.odoms[t], traj.codes[t], tn, rot, u=oracle.philox_uniform64(N, 5100, t - 1))
+        eng.step(torch.as_tensor(traj.odoms[t]).to(dev), torch.as_tensor(traj.codes[t]).to(dev))
+        assert np.array_equal(eng.poses_prop.cpu().numpy(), ref["poses_prop"]), f"frame {t}"
+        assert np.array_equal(eng.nn_idx.cpu().numpy(), ref["nn_idx"]), f"frame {t}"
+        if t % 3 == 0:
+            assert np.array_equal(eng.ridx.cpu().numpy(), ref["ridx"]), f"frame {t}"
+            assert np.array_equal(eng.poses.cpu().numpy(), ref["poses"]), f"frame {t}"
+        poses = ref["poses"]
+    assert np.array_equal(eng.ridx.cpu().numpy(), ref["ridx"])
+
+
 def test_pipelined_parity_host_draws(dev, oracle):
     """Parity mode: the reference's host draws; the uniforms of frame t are consumed by the NEXT call."""
     from midastouch_amd.engine import PipelinedFilterEngine
