@@ -53,6 +53,23 @@ def test_args_structs_match_header(cname, mirror):
     assert norm == got
 
 
+def test_guide_layout_query_needs_no_device():
+    """midas_lazy_guide_layout / midas_lazy_guide_bytes are pure size queries (a binding sizes guide_dev with them before any device work)."""
+    import ctypes
+    from midastouch_amd import _lib
+    lib = _lib.load()
+    b, u, s = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    lib.midas_lazy_guide_layout.restype = ctypes.c_int
+    assert lib.midas_lazy_guide_layout(ctypes.byref(b), ctypes.byref(u), ctypes.byref(s)) == 0
+    assert b.value >= 2048 and b.value & (b.value - 1) == 0 and u.value in (4, 8, 16) and s.value >= b.value + 1 and s.value % 8 == 0
+    lib.midas_lazy_guide_bytes.restype = ctypes.c_int64
+    lib.midas_lazy_guide_bytes.argtypes = [ctypes.c_int64]
+    for N in (1, 4096, 4097, 100_000, 1 << 20):
+        nb = -(-N // 4096)
+        assert lib.midas_lazy_guide_bytes(N) == 2 * nb * s.value * 2  # two variants, 16-bit entries
+    assert lib.midas_lazy_guide_bytes(0) == 0
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
