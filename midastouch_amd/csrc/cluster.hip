@@ -53,11 +53,7 @@ MD void quat_of(const float* P, double* q) {
     q[0] = sg * x / n; q[1] = sg * y / n; q[2] = sg * z / n; q[3] = sg * w / n;
 }
 
-MD double cl_wsum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+MD double cl_wsum(double v) { return wave_sum_ordered(v); }  // (the xor butterfly 32 .. 1 of the spec, by register moves: midas_math.hpp)
 MD double cl_wmax(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v, o); v = t > v ? t : v; }

@@ -37,11 +37,7 @@ constexpr int SORT_CHUNK = 2048;  // (key, index) pairs sorted per workgroup in 
 __device__ const int kSelShift[SEL_PASSES] = {53, 42, 31, 20, 9, 0};
 __device__ const int kSelWidth[SEL_PASSES] = {11, 11, 11, 11, 11, 9};
 
-MD double lw_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+MD double lw_sum(double v) { return wave_sum_ordered(v); }  // (the xor butterfly 32 .. 1 of the spec, by register moves: midas_math.hpp)
 MD int lw_isum(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -325,6 +325,37 @@ MD int wave_isum_dpp(int v) {
     u += dpp_move<0x143, 0xc>(0u, u);
     return (int)(uint32_t)__builtin_amdgcn_readlane((int)u, 63);
 }
+// ---- floating-point sums in the shuffle butterflies' ORDER, without the shuffles ------------------------------------------------
+// `for (o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o)` is part of the arithmetic spec (the oracle restates it); each `__shfl_xor` of a
+// double is two trips through the LDS crossbar.  The same additions with register moves only:
+//   o = 32, 16: v_permlane32_swap / v_permlane16_swap (gfx950) of the value with itself - the two results are {own row | own row}
+//     and {partner row | partner row} in some order, so their sum is own + partner on every lane (addition commutes bit for bit);
+//   o = 8: row_ror:8 IS lane ^ 8 inside a 16-lane row; after it the row's values repeat with period 8, and then a rotation by
+//     4 reads a lane with the same value as lane ^ 4 ((i +- 4) mod 8 = (i mod 8) ^ 4); likewise 2 and 1.
+// quarter_sum_ordered: the last four steps alone (score_body.hpp's 16-lane tree).  midas_debug_wave_sum compares both forms bit for bit.
+MD double double_of(uint32_t lo, uint32_t hi) { return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo)); }
+MD double quarter_sum_ordered(double v) {
+    v += dpp_move<0x128>(v);
+    v += dpp_move<0x124>(v);
+    v += dpp_move<0x122>(v);
+    v += dpp_move<0x121>(v);
+    return v;
+}
+MD double wave_sum_ordered(double v) {
+    {
+        const uint64_t b = (uint64_t)__double_as_longlong(v);
+        const auto l = __builtin_amdgcn_permlane32_swap((uint32_t)b, (uint32_t)b, false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap((uint32_t)(b >> 32), (uint32_t)(b >> 32), false, false);
+        v = double_of(l[0], h[0]) + double_of(l[1], h[1]);
+    }
+    {
+        const uint64_t b = (uint64_t)__double_as_longlong(v);
+        const auto l = __builtin_amdgcn_permlane16_swap((uint32_t)b, (uint32_t)b, false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap((uint32_t)(b >> 32), (uint32_t)(b >> 32), false, false);
+        v = double_of(l[0], h[0]) + double_of(l[1], h[1]);
+    }
+    return quarter_sum_ordered(v);
+}
 // inclusive prefix sum over the wave's lanes: row shifts by 1, 2, 4, 8 (lanes shifted in from outside the row add zero), then the
 // totals of the rows below by the two row broadcasts
 MD int wave_iscan_dpp(int v) {

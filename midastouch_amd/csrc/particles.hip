@@ -1519,11 +1519,7 @@ MD void rmse_terms(const float* P, const float* G, double& et2, double& ang2) {
     ang2 = (double)ang * (double)ang;
 }
 
-MD double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+MD double wave_sum(double v) { return wave_sum_ordered(v); }  // (the xor butterfly 32 .. 1 of the spec, by register moves: midas_math.hpp)
 MD double wave_max(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o); v = t > v ? t : v; }

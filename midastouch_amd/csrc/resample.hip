@@ -18,11 +18,30 @@ namespace midas {
 
 constexpr double ISCLOSE_ATOL = 1e-8;  // torch.isclose default atol (particle_filter.py:460-463)
 
-MD double wsum(double v) {
+MD double wsum_shuffles(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+MD double wsum(double v) { return wave_sum_ordered(v); }  // (the same additions in the same order: midas_math.hpp)
+// self-check of the register-move sums against the shuffle butterflies: 64 doubles in, per lane {shuffle wave sum, ordered wave
+// sum, shuffle quarter sum, ordered quarter sum} out (256 doubles)
+__global__ __launch_bounds__(64) void k_debug_wave_sum(const double* __restrict__ in, double* __restrict__ out) {
+    const int l = threadIdx.x;
+    const double v = in[l];
+    double q = v;
+    q += __shfl_xor(q, 8); q += __shfl_xor(q, 4); q += __shfl_xor(q, 2); q += __shfl_xor(q, 1);
+    out[4 * l] = wsum_shuffles(v);
+    out[4 * l + 1] = wave_sum_ordered(v);
+    out[4 * l + 2] = q;
+    out[4 * l + 3] = quarter_sum_ordered(v);
+}
+}  // namespace midas
+extern "C" __attribute__((visibility("default"))) int midas_debug_wave_sum(const double* in64_dev, double* out256_dev) {
+    hipLaunchKernelGGL(midas::k_debug_wave_sum, dim3(1), dim3(64), 0, nullptr, in64_dev, out256_dev);
+    return hipDeviceSynchronize() == hipSuccess ? 0 : -1;
+}
+namespace midas {
 MD double wmax(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o); v = t > v ? t : v; }

@@ -8,13 +8,7 @@ namespace midas {
 
 constexpr double COS_EPS = 1e-8;
 
-MD double quarter_reduce(double v) {
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 1);
-    return v;
-}
+MD double quarter_reduce(double v) { return quarter_sum_ordered(v); }  // (xor 8, 4, 2, 1 inside the 16-lane row, by register moves: midas_math.hpp)
 
 template <typename T>
 struct Vec4;
