@@ -38,11 +38,7 @@ __device__ const int kSelShift[SEL_PASSES] = {53, 42, 31, 20, 9, 0};
 __device__ const int kSelWidth[SEL_PASSES] = {11, 11, 11, 11, 11, 9};
 
 MD double lw_sum(double v) { return wave_sum_ordered(v); }  // (the xor butterfly 32 .. 1 of the spec, by register moves: midas_math.hpp)
-MD int lw_isum(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+MD int lw_isum(int v) { return wave_isum_dpp(v); }  // (integer: any order; DPP moves instead of six LDS-crossbar trips)
 
 // Order-preserving 64-bit key of a weight: a < b <=> key(a) < key(b); -0.0 == +0.0; NaN above everything (torch.topk
 // treats NaN as the largest value).
