@@ -2535,12 +2535,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_presort_group(int64_t N, const i
     int v[E], mine = 0;
 #pragma unroll
     for (int k = 0; k < E; ++k) { v[k] = s_cnt[t * E + k]; mine += v[k]; }
-    int incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int x = __shfl_up(incl, d);
-        if ((t & 63) >= d) incl += x;
-    }
+    const int incl = wave_iscan_dpp(mine);  // (DPP row shifts and broadcasts: midas_math.hpp)
     if ((t & 63) == 63) s_w[t >> 6] = incl;
     __syncthreads();
     int run = incl - mine;
@@ -2634,12 +2629,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_presort_fused(ParticleUpdateArgs
     int v[E], mine = 0;
 #pragma unroll
     for (int k = 0; k < E; ++k) { v[k] = L.cnt[t * E + k]; mine += v[k]; }
-    int incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int x = __shfl_up(incl, d);
-        if ((t & 63) >= d) incl += x;
-    }
+    const int incl = wave_iscan_dpp(mine);  // (DPP row shifts and broadcasts: midas_math.hpp)
     if ((t & 63) == 63) L.w[t >> 6] = incl;
     __syncthreads();
     int run = incl - mine;
