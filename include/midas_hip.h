@@ -470,6 +470,10 @@ typedef struct midas_shard_route_args {
      * (system-scope stores over xGMI, sixteen adjacent lanes per row: one whole 128-byte line).  Every slot of the filter has exactly one owner, so after a barrier across the ranks each inbox
      * holds its N rows (midas_shard_unpack_peer).  NULL: the forms above. */
     void* const* peers_dev;
+    /* NULL or the shard's guide tables (midas_lazy_guide_bytes(N) bytes, 16-byte aligned; layout and meaning as
+     * midas_lazy_args.guide_dev), written by the shard's tail next to tables_dev: the owner-side search of a draw then starts
+     * from one entry pair instead of two table lines.  Same indices either way. */
+    const uint8_t* guide_dev;
 } midas_shard_route_args;
 int midas_shard_route_count(midas_ctx* ctx, const midas_shard_route_args* args);
 int midas_shard_route_pack(midas_ctx* ctx, const midas_shard_route_args* args);
@@ -564,6 +568,8 @@ typedef struct midas_shard_step_args {
     int32_t* hint_out_dev;          /* N out */
     int32_t* score_list_dev;        /* NULL or 2 + 2 K int32, zero-initialised: prediction lists of the sparse scoring, as in
                                      * midas_lazy_args (front.score_epoch then advances by TWO per frame; midas_shard_run does) */
+    uint8_t* guide_dev;             /* NULL or midas_lazy_guide_bytes(front.N) bytes, 16-byte aligned: the shard's guide tables, written
+                                     * by the LOCAL phase's tail and read by the ROUTE phase's searches (midas_shard_route_args.guide_dev) */
 } midas_shard_step_args;
 int midas_shard_step(midas_ctx* ctx, midas_comm* comm, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
                      const midas_shard_step_args* args, int32_t phases);

@@ -124,6 +124,7 @@ class ShardRouteArgs(C.Structure):
         ("counts", C.c_void_p), ("send", C.c_void_p), ("weights", C.c_void_p),
         ("fixed_cap", C.c_int64), ("ovf_cap", C.c_int64), ("ovf", C.c_void_p), ("self_rows", C.c_void_p),
         ("peers", C.c_void_p),
+        ("guide", C.c_void_p),
     ]
 
 
@@ -138,7 +139,7 @@ class ShardStepArgs(C.Structure):
         ("counts", C.c_void_p), ("weights", C.c_void_p), ("rmse", C.c_void_p),
         ("peers", C.c_void_p), ("inbox", C.c_void_p), ("flag_offset", C.c_int64), ("frame_tag", C.c_uint64),
         ("ridx", C.c_void_p), ("poses_out", C.c_void_p), ("weights_out", C.c_void_p), ("hint_out", C.c_void_p),
-        ("score_list", C.c_void_p),
+        ("score_list", C.c_void_p), ("guide", C.c_void_p),
     ]
 
 

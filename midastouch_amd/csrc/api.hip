@@ -1005,7 +1005,13 @@ static int shard_route(midas_ctx* ctx, const midas_shard_route_args* args, bool 
     MIDAS_REQUIRE(ctx, !pack || s.peers_dev || s.fixed_cap == 0 || (s.fixed_cap > 0 && s.ovf_cap > 0 && s.ovf_dev && (uintptr_t)s.ovf_dev % 8 == 0 && s.self_dev && (uintptr_t)s.self_dev % 8 == 0 &&
                                                      s.G * s.fixed_cap < ((int64_t)1 << 31)));
     MIDAS_REQUIRE(ctx, s.resample_mode == MIDAS_RESAMPLE_MULTINOMIAL || s.resample_mode == MIDAS_RESAMPLE_SYSTEMATIC);
-    return launch_shard_route(ctx, s, shard_tables_of(const_cast<double*>(s.tables_dev), s.N), pack, sync);
+    TailTables tb = shard_tables_of(const_cast<double*>(s.tables_dev), s.N);
+    if (s.guide_dev) {  // (read only by the peer-mapped form's searches; the table layout of midas_lazy_args.guide_dev)
+        MIDAS_REQUIRE(ctx, (uintptr_t)s.guide_dev % 16 == 0);
+        tb.guide = reinterpret_cast<guide_t*>(const_cast<uint8_t*>(s.guide_dev));
+        tb.guide_raw = tb.guide + ceil_div(s.N, SCAN_BLOCK) * GUIDE_STRIDE;
+    }
+    return launch_shard_route(ctx, s, tb, pack, sync);
 }
 
 MIDAS_EXPORT int midas_shard_route_count(midas_ctx* ctx, const midas_shard_route_args* args) {
@@ -1132,8 +1138,14 @@ static int shard_step_impl(midas_ctx* ctx, midas_comm* comm, const midas_codeboo
         }
         if ((rc = shard_front_impl(ctx, cb, tree6, tree3, &s.front, &prm, s.score_list_dev, &predict, from_inbox ? &src : nullptr))) return rc;
         MIDAS_REQUIRE(ctx, (uintptr_t)s.tables_dev % 128 == 0);
+        TailTables tbs = shard_tables_of(s.tables_dev, N);
+        if (s.guide_dev) {
+            MIDAS_REQUIRE(ctx, (uintptr_t)s.guide_dev % 16 == 0);
+            tbs.guide = reinterpret_cast<guide_t*>(s.guide_dev);
+            tbs.guide_raw = tbs.guide + nb * GUIDE_STRIDE;
+        }
         if ((rc = launch_shard_tail_a(ctx, N, s.front.scores_dev, s.front.nn_idx_dev, s.front.valid_dev, s.softmax,
-                                      shard_tables_of(s.tables_dev, N), s.r1_dev, s.front.status_dev, (const double*)prm,
+                                      tbs, s.r1_dev, s.front.status_dev, (const double*)prm,
                                       predict.stamps ? &predict : nullptr)))
             return rc;
     }
@@ -1153,6 +1165,7 @@ static int shard_step_impl(midas_ctx* ctx, midas_comm* comm, const midas_codeboo
         r.softmax = s.softmax; r.resample_mode = s.resample_mode; r.u_all_dev = s.u_all_dev; r.u32 = s.u32;
         r.seed = s.front.seed; r.step = s.front.step;
         r.counts_dev = s.counts_dev; r.weights_dev = s.weights_dev; r.peers_dev = s.peers_dev;
+        r.guide_dev = s.guide_dev;
         // without FLAG the route kernel's last workgroup publishes this rank's flag and waits for every rank's: when the kernel
         // ends the inbox is complete (one polling wave; the word behind the 64 flags is its workgroup counter)
         const PeerRouteSync sync{(const char*)s.inbox_dev, s.flag_offset, s.frame_tag};

@@ -1319,6 +1319,7 @@ struct ShardRouteArgs {
     long long flag_off = 0;
     unsigned long long tag = 0;
     unsigned* done = nullptr;  // workgroups finished, zero between launches (reset by the last one)
+    const guide_t *guide = nullptr, *guide_raw = nullptr;  // the shard's guide tables (GUIDE_BINS, midas_internal.hpp) or null
 };
 
 // (sys_store8 / sys_load8 / pack2: peer_row.hpp - the rows of the peer-mapped form are 128-byte lines written by sixteen lanes)
@@ -1388,7 +1389,10 @@ __global__ __launch_bounds__(256) void k_shard_route(ShardRouteArgs a) {
 #pragma unroll
         for (int k = 0; k < TB_MAX_BLOCKS / 256; ++k) {
             const int b = k * 256 + t;
-            if (b < nb_all) s_end[b] = (b == nb_all - 1) ? 1.0 : (s_bp[b] + wv[k]) / total;
+            if (b < nb_all) {
+                s_end[b] = (b == nb_all - 1) ? 1.0 : (s_bp[b] + wv[k]) / total;
+                s_se[b] = wv[k];  // (the sums of e are summed up: the array now holds the block totals, the guide tables' bin width)
+            }
         }
         __syncthreads();
     }
@@ -1467,8 +1471,9 @@ __global__ __launch_bounds__(256) void k_shard_route(ShardRouteArgs a) {
             if (!usable) src = i - (int64_t)a.rank * N;  // the resampler keeps the particles
             else if (past) src = N - 1;
             else
-                src = search_in_block(apply ? a.lp : a.lp_raw, apply ? a.gend : a.gend_raw, apply ? a.ggend : a.ggend_raw,
-                                      b - a.rank * a.nb, N, a.rank == a.G - 1 ? N - 1 : -1, s_bp[b], total, tq, upper);
+                src = search_in_block_t<const double*, const double*>(apply ? a.lp : a.lp_raw, apply ? a.gend : a.gend_raw, apply ? a.ggend : a.ggend_raw,
+                                                                      b - a.rank * a.nb, N, a.rank == a.G - 1 ? N - 1 : -1, s_bp[b], total, tq, upper,
+                                                                      (const double*)nullptr, apply ? a.guide : a.guide_raw, s_se[b]);
             const float4* ps = reinterpret_cast<const float4*>(a.poses_prop + src * 16);
             const float4 r0 = ps[0], r1 = ps[1], r2 = ps[2], r3 = ps[3];
             const double wgt = (ev[src] / S) * (a.valid[src] ? 1.0 : 0.0);
@@ -1793,6 +1798,8 @@ int launch_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores, const i
         LAUNCH_CHECK(ctx);
         return MIDAS_OK;
     }
+    if (tb.guide)  // (this form of the tail writes no guide tables: "no guide" in every entry, see tail_block.hpp)
+        MIDAS_HIP_CHECK(ctx, hipMemsetAsync(tb.guide, 0xFF, (size_t)2 * nb * GUIDE_STRIDE * sizeof(guide_t), ctx->stream));
     hipLaunchKernelGGL(k_tail_a2, dim3((unsigned)nb), dim3(256), 0, ctx->stream, N, scores, nn_idx, valid, softmax, tb.e, tb.x_raw,
                        tb.lp, tb.lp_raw, tb.gend, tb.gend_raw, tb.ggend, tb.ggend_raw, r1, r1 + nb, r1 + 2 * nb, r1 + 3 * nb, r1 + 4 * nb,
                        status, r1 + 5 * nb, 0);
@@ -1871,6 +1878,7 @@ int launch_shard_route(midas_ctx* ctx, const midas_shard_route_args& r, const Ta
     ShardRouteArgs a;
     a.N = r.N; a.G = r.G; a.rank = r.rank; a.nb = nb; a.r1_all = r.r1_all_dev;
     a.e = tb.e; a.x_raw = tb.x_raw; a.lp = tb.lp; a.lp_raw = tb.lp_raw; a.gend = tb.gend; a.gend_raw = tb.gend_raw;
+    a.guide = tb.guide; a.guide_raw = tb.guide_raw;
     a.ggend = tb.ggend; a.ggend_raw = tb.ggend_raw;
     a.valid = r.valid_dev; a.nn_idx = r.nn_idx_dev; a.poses_prop = r.poses_prop_dev;
     a.status = r.status_dev; a.rmse_out = r.rmse_dev; a.n_total = (double)r.G * (double)r.N;

@@ -251,6 +251,10 @@ class HipShardBackend:
                 st._score_list = torch.zeros(2 + 2 * self.codebook.K, dtype=torch.int32, device=st.poses.device)
             a.score_list = _ptr(st._score_list)
         a.softmax, a.tables, a.r1, a.r1_all = int(softmax), _ptr(st.tables), _ptr(st.r1), _ptr(r1_all)
+        if getattr(st, "_guide", None) is None and os.environ.get("MIDAS_GUIDE", "1") != "0":
+            # guide tables of the owner-side searches (include/midas_hip.h guide_dev): written by the shard's tail, read by its route kernel
+            st._guide = torch.zeros(int(self.ctx.lib.midas_lazy_guide_bytes(st.N)), dtype=torch.uint8, device=st.poses.device)
+        a.guide = _ptr(getattr(st, "_guide", None))
         a.G, a.rank, a.resample_mode = world, rank, mode
         a.u_all, a.u32 = _ptr(u_all), float(u32)
         a.counts, a.weights = _ptr(st.counts), _ptr(st.weights)
