@@ -137,6 +137,18 @@ MIDAS_EXPORT int midas_ctx_create(int device, void* hip_stream, midas_ctx** out)
         for (auto w : warm)
             if (w() != 0) { (void)hipGetLastError(); }  // not fatal: the unit then loads at its first launch, as before
     }
+    // hand-over records of the grouped tail (4 KB per 4096 particles; without them the tail takes its one-workgroup-per-block form)
+    {
+        void* p = nullptr;
+        const int blocks = midas::TAIL_GROUP_MAX_BLOCKS;
+        if (hipMalloc(&p, (size_t)blocks * midas::TAIL_GROUP_BLOCK_BYTES) == hipSuccess && hipMemset(p, 0, (size_t)blocks * midas::TAIL_GROUP_BLOCK_BYTES) == hipSuccess) {
+            ctx->tail_rec = (unsigned long long*)p;
+            ctx->tail_rec_blocks = blocks;
+        } else {
+            if (p) (void)hipFree(p);
+            (void)hipGetLastError();
+        }
+    }
     *out = ctx;
     return MIDAS_OK;
 }
@@ -173,6 +185,7 @@ MIDAS_EXPORT int midas_ctx_destroy(midas_ctx* ctx) {
     ScratchState* s = scratch_of(ctx);
     for (auto& c : s->chunks) (void)hipFree(c.p);
     delete s;
+    if (ctx->tail_rec) (void)hipFree(ctx->tail_rec);
     if (ctx->ev_ready)
         for (auto& e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

@@ -91,6 +91,11 @@ struct midas_ctx {
     // update (created on first use, non-blocking, forked from / joined into `stream` by the two events)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // hand-over records of the grouped tail (tail_group.hpp): [tail_rec_blocks x TG_BLOCK_WORDS] words, zeroed at allocation
+    // (midas_ctx_create); tail_tag numbers its launches (a record is current when its pairs carry the launch's key)
+    unsigned long long* tail_rec = nullptr;
+    int tail_rec_blocks = 0;
+    uint32_t tail_tag = 0;
 };
 
 struct midas_codebook {
@@ -189,6 +194,11 @@ constexpr double GUIDE_WIDTH = 1.0 / GUIDE_BINS;
 constexpr int TAIL_GUIDE_LDS = GUIDE_BINS / 2 + 8;  // 32-bit words of LDS the tail's guide pass takes: the edge histogram (16-bit counters) + 4 wave totals
 static_assert((GUIDE_BINS & (GUIDE_BINS - 1)) == 0 && GUIDE_BINS >= 2048, "bins: a power of two, eight or more per chunk");
 static_assert(GUIDE_UNIT == 16 || GUIDE_UNIT == 8 || GUIDE_UNIT == 4, "units: whole chunks, halves or quarters");
+
+// grouped tail (tail_group.hpp): one wave per 256-slot group while the whole grid is resident - up to this many 4096-slot blocks
+// (128 four-wave workgroups a 32 blocks: 512 workgroups on 256 CUs); larger sets keep one workgroup per block (they fill the chip)
+constexpr int TAIL_GROUP_MAX_BLOCKS = 128;
+constexpr size_t TAIL_GROUP_BLOCK_BYTES = 2 * 16 * 16 * 8;  // TG_ROUNDS x 16 groups x one 128-byte record
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -9,6 +9,7 @@
 #include "peer_row.hpp"
 #include "resample_search.hpp"
 #include "tail_block.hpp"
+#include "tail_group.hpp"
 
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
 #error "the peer-mapped route kernel's completion protocol relies on gfx942 / gfx950 write-through store acknowledgement (see k_shard_route_*)"
@@ -650,6 +651,47 @@ __global__ __launch_bounds__(256) void k_tail_a2d(int64_t N, const double* __res
             rmse_out[2] = (double)wall_clock64() * 0.01;  // device wall clock (100 MHz) in us: where this frame ended
         }
     }
+}
+
+// The tail with one WAVE per 256-slot group (tail_group.hpp): workgroups [0, nwg) hold four groups each, workgroup nwg (when
+// rmse_out is set) adds up the front's rmse sums as k_tail_a2d's block 0 does, the workgroups behind it list the next frame's rows.
+__global__ __launch_bounds__(256) void k_tail_a3(TailGroupArgs a, int ngroups, int nwg, const double* __restrict__ part_rmse, int nrm,
+                                                 double* __restrict__ rmse_out, bool rmse_raw, ScorePredict pr) {
+    __shared__ double s_E[4][2 * TG_GROUP / GUIDE_UNIT];
+    __shared__ double s_red[24];
+    int b = (int)blockIdx.x;
+    const int t = threadIdx.x;
+    if (b < nwg) {
+        const int G = 4 * b + (t >> 6);
+        if (G < ngroups) tail_group_wave(a, G, s_E[t >> 6]);
+        return;
+    }
+    b -= nwg;
+    if (rmse_out) {
+        if (b == 0) {  // the frame's rmse from the front kernel's per-wave sums (same order as k_tail_b2 / k_tail_a2d)
+            double p = 0.0, q = 0.0;
+            for (int k = t; k < nrm; k += 256) { p += part_rmse[2 * k]; q += part_rmse[2 * k + 1]; }
+            p = wsum(p);
+            q = wsum(q);
+            if ((t & 63) == 0) { s_red[t >> 6] = p; s_red[4 + (t >> 6)] = q; }
+            __syncthreads();
+            if (t == 0) {
+                p = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+                q = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+                if (rmse_raw) {
+                    rmse_out[0] = p;
+                    rmse_out[1] = q;
+                } else {
+                    rmse_out[0] = __builtin_sqrt(p / (double)a.N);
+                    rmse_out[1] = __builtin_sqrt(q / (double)a.N);
+                    rmse_out[2] = (double)wall_clock64() * 0.01;  // device wall clock (100 MHz) in us
+                }
+            }
+            return;
+        }
+        b -= 1;
+    }
+    predict_scan(pr, b, reinterpret_cast<int*>(s_red));
 }
 
 constexpr int TB_MAX_BLOCKS = 1024;  // 4 M particles (per GPU in the fused step, in total in the sharded step)
@@ -1649,6 +1691,30 @@ __global__ void k_peer_probe_check(const char* inbox, int G, int nonce, int32_t*
 // ------------------------------------------------------------------------------------------------
 #define LAUNCH_CHECK(ctx) MIDAS_HIP_CHECK(ctx, hipGetLastError())
 
+// The grouped form needs the hand-over records, the whole grid resident and whole 16-byte pieces of the per-slot arrays.
+static bool tail_grouped_ok(midas_ctx* ctx, int64_t N, const int32_t* nn_idx, const uint8_t* valid, const TailTables& tb) {
+    const char* env = getenv("MIDAS_TAIL_GROUPED");  // (read per launch: the tests compare both forms in one process)
+    const bool on = !(env && env[0] == '0');
+    if (!on || !ctx->tail_rec || N < SCAN_CHUNK || ceil_div(N, SCAN_BLOCK) > ctx->tail_rec_blocks) return false;
+    const uintptr_t al = (uintptr_t)nn_idx | (uintptr_t)tb.e | (uintptr_t)tb.x_raw | (uintptr_t)tb.lp | (uintptr_t)tb.lp_raw;
+    return (al & 15) == 0 && ((uintptr_t)valid & 3) == 0;
+}
+static int launch_tail_a3(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid, int32_t softmax,
+                          const TailTables& tb, bool padded, int32_t* status, double* flags_out, const double* part_rmse, double* rmse_out,
+                          bool rmse_raw, const ScorePredict* predict) {
+    TailGroupArgs a;
+    a.N = N; a.scores = scores; a.nn_idx = nn_idx; a.valid = valid; a.softmax = softmax; a.tb = tb; a.padded = padded;
+    a.status = status; a.flags_out = flags_out; a.rec = ctx->tail_rec;
+    if (++ctx->tail_tag == 0) ctx->tail_tag = 1;
+    a.tag = ctx->tail_tag;
+    const int ngroups = (int)ceil_div(N, TG_GROUP), nwg = (ngroups + 3) / 4;
+    const int nscan = predict ? (int)ceil_div(predict->K, 256 * PREDICT_PER_THREAD) : 0;
+    hipLaunchKernelGGL(k_tail_a3, dim3((unsigned)(nwg + (rmse_out ? 1 : 0) + nscan)), dim3(256), 0, ctx->stream, a, ngroups, nwg, part_rmse,
+                       particle_update_blocks(N), rmse_out, rmse_raw, predict ? *predict : ScorePredict());
+    LAUNCH_CHECK(ctx);
+    return MIDAS_OK;
+}
+
 int launch_shard_unpack_peer(midas_ctx* ctx, int64_t N, const void* inbox, int32_t* ridx, float* poses_out, double* weights_out,
                              int32_t* hint_out) {
     hipLaunchKernelGGL(k_shard_unpack_peer, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, N, (const char*)inbox, ridx,
@@ -1790,6 +1856,9 @@ int launch_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores, const i
     if (direct && N >= SCAN_CHUNK) {  // the shard's per-slot tables are padded (shard_tables_of, api.hip)
         TailTables t = tb;
         t.bsum_e = r1; t.btot = r1 + nb; t.btot_raw = r1 + 2 * nb; t.bmax = r1 + 3 * nb; t.bmin = r1 + 4 * nb;
+        if (tail_grouped_ok(ctx, N, nn_idx, valid, t))
+            return launch_tail_a3(ctx, N, scores, nn_idx, valid, softmax, t, true, status, r1 + 5 * nb, part_rmse,
+                                  part_rmse ? r1 + 5 * nb + 2 : (double*)nullptr, true, with_list ? predict : nullptr);
         const int nscan = with_list ? (int)ceil_div(predict->K, 256 * PREDICT_PER_THREAD) : 0;
         // part_rmse: the front's per-wave sums are added up here (block 0) into r1[5 nb + 2 ..] instead of by a kernel of their own
         hipLaunchKernelGGL(k_tail_a2d, dim3((unsigned)(nb + nscan)), dim3(256), 0, ctx->stream, N, scores, nn_idx, valid, softmax, t, true,
@@ -1831,6 +1900,9 @@ int launch_tail_a2(midas_ctx* ctx, int64_t N, const double* scores, const int32_
     static const bool direct = !(getenv("MIDAS_TAIL_DIRECT") && atoi(getenv("MIDAS_TAIL_DIRECT")) == 0);
     const bool with_list = predict && predict->stamps && predict->list && batch <= 1;
     if (with_list && !(direct && N >= SCAN_CHUNK)) return midas_set_error(ctx, MIDAS_ERR_INVALID, "score_list", "the prediction list needs the direct tail kernel (N >= 16)");
+    if (direct && batch <= 1 && tail_grouped_ok(ctx, N, nn_idx, valid, tb))
+        return launch_tail_a3(ctx, N, scores, nn_idx, valid, softmax, tb, padded_tables, status, nullptr, part_rmse,
+                              part_rmse ? rmse_out : (double*)nullptr, false, with_list ? predict : nullptr);
     if (direct && (batch <= 1 || tstride > 0) && N >= SCAN_CHUNK) {
         const int nscan = with_list ? (int)ceil_div(predict->K, 256 * PREDICT_PER_THREAD) : 0;
         hipLaunchKernelGGL(k_tail_a2d, dim3((unsigned)(nb + nscan), (unsigned)(batch > 1 ? batch : 1)), dim3(256), 0, ctx->stream, N, scores, nn_idx,
