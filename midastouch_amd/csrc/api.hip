@@ -1373,6 +1373,9 @@ MIDAS_EXPORT int midas_selfsim_topn(midas_ctx* ctx, const midas_codebook* cb, in
 #ifdef MIDAS_DEBUG_CLOCKS
 MIDAS_EXPORT int midas_debug_tb2_clocks(long long* out16) { return midas::debug_tb2_clocks(out16); }
 MIDAS_EXPORT int midas_debug_ta_clocks(long long* out16) { return midas::debug_ta_clocks(out16); }
+MIDAS_EXPORT int midas_debug_tg_clocks(long long* io64, int reset) { return midas::debug_tg_clocks(io64, reset); }
+MIDAS_EXPORT int midas_debug_tg_waves(long long* out4096) { return midas::debug_tg_waves(out4096); }
+MIDAS_EXPORT int midas_debug_ff_clocks(long long* io8192, int reset) { return midas::debug_ff_clocks(io8192, reset); }
 #endif
 
 // ---- profiling -----------------------------------------------------------------------------------

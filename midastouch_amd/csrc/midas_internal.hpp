@@ -412,6 +412,9 @@ int launch_shard_unpack_peer_wait(midas_ctx* ctx, int64_t N, const void* inbox, 
                                   int32_t* hint_out, int G, int64_t flag_off, uint64_t tag, int32_t* status, void* const* peers, int rank);
 int debug_tb2_clocks(long long* out16);
 int debug_ta_clocks(long long* out16);
+int debug_tg_clocks(long long* io64, int reset);
+int debug_tg_waves(long long* out4096);
+int debug_ff_clocks(long long* io8192, int reset);
 int launch_tail_a(midas_ctx* ctx, int64_t N, const double* x, const uint8_t* valid, int np, int pstride,
                   const double* pmax_all, const double* pmin_all, int32_t softmax, double* e_io, double* lp_out,
                   double* block_sums_e, double* block_totals_em, double* flags_out, int32_t* flag, int32_t* status,

@@ -2010,12 +2010,21 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
 #ifndef MIDAS_BATCH_OCC
 #define MIDAS_BATCH_OCC 1  // waves per SIMD the batch form (SCR = false) is compiled for (1 = no register cap)
 #endif
+#ifdef MIDAS_DEBUG_CLOCKS  // wall-clock span of the front's particle waves [0, 1] and of its scoring waves [2, 3] (tools/tg_clocks.py)
+__device__ long long g_ff_clk[16384];  // per frame parity and workgroup: start, end
+#define FF_T0 const long long ff_t0_ = wall_clock64()
+#define FF_END do { if (threadIdx.x == 0 && blockIdx.x < 4096) { long long* c_ = g_ff_clk + (a.step & 1) * 8192; c_[2 * blockIdx.x] = ff_t0_; c_[2 * blockIdx.x + 1] = wall_clock64(); } } while (0)
+#else
+#define FF_T0 do { } while (0)
+#define FF_END do { } while (0)
+#endif
 template <typename T, int NJ, int LAZY, int FW, bool SCR = true, bool PREF = false, bool STATS = false>
 __global__ __launch_bounds__(64 * FW, (!SCR && FW == 1) ? MIDAS_BATCH_OCC : 1) void k_frame_front(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a,
                                                          int n_pu, int nwaves, const T* __restrict__ emb,
                                                          const double* __restrict__ norms, const double* __restrict__ code,
                                                          double* __restrict__ scores, int64_t K) {
     static_assert(LAZY != 1 || FW == 4, "the workgroup-level tables take 256 threads");
+    FF_T0;
     __shared__ double s_cd[FW][KD_MAX_LEVELS * 64];
     __shared__ alignas(16) double s_rs[LAZY == 1 ? LAZY_WG_LDS : LAZY == 2 ? FW * LAZY_WAVE_LDS : 8];
     const int w = threadIdx.x >> 6;
@@ -2049,6 +2058,7 @@ __global__ __launch_bounds__(64 * FW, (!SCR && FW == 1) ? MIDAS_BATCH_OCC : 1) v
     } else {
         score_wave<T, NJ, 0>(emb, norms, code, scores, K, (int64_t)(bx - n_pu) * FW + w);
     }
+    FF_END;
 }
 
 // =================================================================================================
@@ -2918,6 +2928,15 @@ int launch_reduce_partials(midas_ctx* ctx, int np, const double* pmax, const dou
     return MIDAS_OK;
 }
 
+#ifdef MIDAS_DEBUG_CLOCKS
+int debug_ff_clocks(long long* io8192, int reset) {
+    if (reset) {
+        static long long zero[16384];
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_ff_clk), zero, sizeof(zero)) == hipSuccess ? 0 : 1;
+    }
+    return hipMemcpyFromSymbol(io8192, HIP_SYMBOL(g_ff_clk), 16384 * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 MIDAS_WARM_TU(particles, k_propagate)
 
 }  // namespace midas

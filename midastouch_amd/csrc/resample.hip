@@ -17,6 +17,10 @@
 
 namespace midas {
 
+#ifdef MIDAS_DEBUG_CLOCKS
+__device__ long long g_tg_clk[64];
+__device__ long long g_tg_w[8192];
+#endif
 constexpr double ISCLOSE_ATOL = 1e-8;  // torch.isclose default atol (particle_filter.py:460-463)
 
 MD double wsum_shuffles(double v) {
@@ -662,13 +666,14 @@ __global__ __launch_bounds__(256) void k_tail_a3(TailGroupArgs a, int ngroups, i
     int b = (int)blockIdx.x;
     const int t = threadIdx.x;
     if (b < nwg) {
-        const int G = 4 * b + (t >> 6);
-        if (G < ngroups) tail_group_wave(a, G, s_E[t >> 6]);
+        const int wv = __builtin_amdgcn_readfirstlane(t >> 6), G = 4 * b + wv;  // (wave-uniform: the group's own conditions are scalar branches)
+        if (G < ngroups) tail_group_wave(a, G, s_E[wv]);
         return;
     }
     b -= nwg;
     if (rmse_out) {
         if (b == 0) {  // the frame's rmse from the front kernel's per-wave sums (same order as k_tail_b2 / k_tail_a2d)
+            TG_SPAN(2048, wall_clock64());
             double p = 0.0, q = 0.0;
             for (int k = t; k < nrm; k += 256) { p += part_rmse[2 * k]; q += part_rmse[2 * k + 1]; }
             p = wsum(p);
@@ -687,6 +692,7 @@ __global__ __launch_bounds__(256) void k_tail_a3(TailGroupArgs a, int ngroups, i
                     rmse_out[2] = (double)wall_clock64() * 0.01;  // device wall clock (100 MHz) in us
                 }
             }
+            TG_SPAN(2049, wall_clock64());
             return;
         }
         b -= 1;
@@ -1891,6 +1897,17 @@ int launch_tail_resample(midas_ctx* ctx, const midas_tail_resample_args& r) {
 #ifdef MIDAS_DEBUG_CLOCKS
 int debug_tb2_clocks(long long* out16) { return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_tb2_clk), 16 * sizeof(long long)) == hipSuccess ? 0 : 1; }
 int debug_ta_clocks(long long* out16) { return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ta_clk), 16 * sizeof(long long)) == hipSuccess ? 0 : 1; }
+// stamps of the grouped tail: out64 = two waves' phases, out_w (4096) = start / end per group wave [2 G, 2 G + 1], rmse workgroup
+// [2048, 2049], list workgroups [2050 + 2 b, ..]; reset: all zero
+int debug_tg_clocks(long long* io64, int reset) {
+    if (reset) {
+        static long long zero[8192];
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tg_w), zero, sizeof(zero));
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_tg_clk), zero, 64 * sizeof(long long)) == hipSuccess ? 0 : 1;
+    }
+    return hipMemcpyFromSymbol(io64, HIP_SYMBOL(g_tg_clk), 64 * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+int debug_tg_waves(long long* out8192) { return hipMemcpyFromSymbol(out8192, HIP_SYMBOL(g_tg_w), 8192 * sizeof(long long)) == hipSuccess ? 0 : 1; }
 #endif
 
 int launch_tail_a2(midas_ctx* ctx, int64_t N, const double* scores, const int32_t* nn_idx, const uint8_t* valid,

@@ -17,6 +17,20 @@
 
 namespace midas {
 
+#ifdef MIDAS_DEBUG_CLOCKS  // wall-clock stamps (100 MHz) of the grouped tail, kept in registers and stored when the wave ends: tools/tg_clocks.py
+extern __device__ long long g_tg_clk[64];
+extern __device__ long long g_tg_w[8192];  // per launch parity and wave / workgroup: start, end
+#define TG_CLK(k) do { tg_clk_[k] = wall_clock64(); } while (0)
+#define TG_CLK_ARG , long long* tg_clk_
+#define TG_CLK_PASS , tg_clk_
+#define TG_SPAN(slot, t_) do { if ((threadIdx.x & 63) == 0 && (slot) < 4096) g_tg_w[(a.tag & 1) * 4096 + (slot)] = (t_); } while (0)
+#else
+#define TG_CLK(k) do { } while (0)
+#define TG_CLK_ARG
+#define TG_CLK_PASS
+#define TG_SPAN(slot, t_) do { } while (0)
+#endif
+
 constexpr int TG_GROUP = 256;        // slots of a wave: one group of the summation spec
 constexpr int TG_VALUES = 5;         // record: masked total, unmasked total, max x, min x, {kept | flags}
 constexpr int TG_REC_WORDS = 16;     // one 128-byte line per (block, round, group)
@@ -51,6 +65,30 @@ MD double shfl_d(double v, int l) {
     return double_of((uint32_t)__shfl((int)(uint32_t)b, l), (uint32_t)__shfl((int)(uint32_t)(b >> 32), l));
 }
 
+// agent-scope (sc1: past the non-coherent caches) 16-byte store / five 16-byte loads of a record
+typedef unsigned int tg_u32x4 __attribute__((ext_vector_type(4)));
+MD void tg_store16(unsigned long long* p, uint64_t lo, uint64_t hi) {
+    tg_u32x4 v;
+    v.x = (unsigned)lo; v.y = (unsigned)(lo >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+MD void tg_load80(const unsigned long long* p, uint64_t* w) {
+    tg_u32x4 v0, v1, v2, v3, v4;
+    asm volatile("global_load_dwordx4 %0, %5, off sc1\n\t"
+                 "global_load_dwordx4 %1, %5, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %5, off offset:32 sc1\n\t"
+                 "global_load_dwordx4 %3, %5, off offset:48 sc1\n\t"
+                 "global_load_dwordx4 %4, %5, off offset:64 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4) : "v"(p) : "memory");
+    const tg_u32x4 v[5] = {v0, v1, v2, v3, v4};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        w[2 * i] = (uint64_t)v[i].x | ((uint64_t)v[i].y << 32);
+        w[2 * i + 1] = (uint64_t)v[i].z | ((uint64_t)v[i].w << 32);
+    }
+}
+
 struct TGBlock {
     double W, Wa, mx, mn;  // block totals (masked, unmasked), block extrema of x (NaN when some x is)
     int kept;
@@ -61,7 +99,7 @@ struct TGBlock {
 // g* : the group's extrema / kept count / "some x is NaN" (published with round 0, ignored in round 1).
 MD TGBlock tg_variant(const TailGroupArgs& a, int G, int round, const double* v, unsigned ok4, double gmx, double gmn, int gkept,
                       bool gxnan, double* __restrict__ lp_out, double* __restrict__ gend_out, double* __restrict__ ggend_out,
-                      guide_t* __restrict__ guide_out, double* s_E) {
+                      guide_t* __restrict__ guide_out, double* s_E TG_CLK_ARG) {
     const int lane = threadIdx.x & 63, c = lane >> 2, k = lane & 3;
     const int blk = G >> 4, g = G & 15;
     const int64_t N = a.N, bbase = (int64_t)blk * SCAN_BLOCK, s0 = (int64_t)G * TG_GROUP + 4 * lane;
@@ -99,15 +137,14 @@ MD TGBlock tg_variant(const TailGroupArgs& a, int G, int round, const double* v,
         acca = acca + readlane_d(enda, 4 * J + 3);
     }
     const double tm = accm, ta = acca;  // (uniform)
-    // publish the group's record
+    TG_CLK(4 + 6 * round);
+    // publish the group's record: five 16-byte pairs {v, v ^ key}, one store each (lanes 0 .. 4)
     unsigned long long* rec_b = a.rec + ((size_t)blk * TG_ROUNDS + round) * 16 * TG_REC_WORDS;
     {
         const uint64_t meta = (uint64_t)(unsigned)gkept | ((uint64_t)(gxnan ? 1 : 0) << 16) | ((uint64_t)(vnan ? 1 : 0) << 17) | ((uint64_t)(negw ? 1 : 0) << 18);
-        const int i = lane >> 1;
-        uint64_t w = i == 0 ? (uint64_t)__double_as_longlong(tm) : i == 1 ? (uint64_t)__double_as_longlong(ta)
-                   : i == 2 ? (uint64_t)__double_as_longlong(gmx) : i == 3 ? (uint64_t)__double_as_longlong(gmn) : meta;
-        if (lane & 1) w ^= tg_key(a.tag, round, i);
-        if (lane < 2 * TG_VALUES) __hip_atomic_store(rec_b + g * TG_REC_WORDS + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t v0 = lane == 0 ? (uint64_t)__double_as_longlong(tm) : lane == 1 ? (uint64_t)__double_as_longlong(ta)
+                          : lane == 2 ? (uint64_t)__double_as_longlong(gmx) : lane == 3 ? (uint64_t)__double_as_longlong(gmn) : meta;
+        if (lane < TG_VALUES) tg_store16(rec_b + g * TG_REC_WORDS + 2 * lane, v0, v0 ^ tg_key(a.tag, round, lane));
     }
     // read the block's records (lane j: group j) until all of them are this launch's
     uint64_t w[2 * TG_VALUES];
@@ -116,40 +153,43 @@ MD TGBlock tg_variant(const TailGroupArgs& a, int G, int round, const double* v,
         const unsigned long long* rp = rec_b + (lane < ngb ? lane : 0) * TG_REC_WORDS;
         const long long t0 = wall_clock64();
         for (;;) {
-#pragma unroll
-            for (int i = 0; i < 2 * TG_VALUES; ++i) w[i] = __hip_atomic_load(rp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tg_load80(rp, w);
             bool ok = true;
 #pragma unroll
             for (int i = 0; i < TG_VALUES; ++i) ok &= (w[2 * i] ^ w[2 * i + 1]) == tg_key(a.tag, round, i);
             if (__all((ok || lane >= ngb) ? 1 : 0)) break;
-            __builtin_amdgcn_s_sleep(1);
             if (wall_clock64() - t0 > TG_WAIT_TICKS) { late = true; break; }
         }
     }
-    // block level: the sixteen group totals in order (groups past N add +0.0, as their slots would)
-    const double vtm = __longlong_as_double((long long)w[0]), vta = __longlong_as_double((long long)w[2]);
-    const double vmx = __longlong_as_double((long long)w[4]), vmn = __longlong_as_double((long long)w[6]);
-    const unsigned vmeta = (unsigned)w[8];
-    double GP = 0.0, GPn = 0.0, W = 0.0, Wa = 0.0, mx = -INFINITY, mn = INFINITY;
-    int kept = 0;
-    unsigned flags = 0;
+    TG_CLK(5 + 6 * round);
+    // block level: the sixteen group totals in order (groups past N add +0.0, as their slots would); extrema, kept count and flags
+    // are order-free: reduced inside row 0 (lanes 0 .. 15 hold the records)
+    const bool have = lane < ngb;
+    const double vtm = have ? __longlong_as_double((long long)w[0]) : 0.0, vta = have ? __longlong_as_double((long long)w[2]) : 0.0;
+    double mx = have ? __longlong_as_double((long long)w[4]) : -INFINITY, mn = have ? __longlong_as_double((long long)w[6]) : INFINITY;
+    uint32_t kp = have ? ((uint32_t)w[8] & 0xFFFFu) : 0u, fl = have ? ((uint32_t)w[8] >> 16) : 0u;
+#define MIDAS_ROW_REDUCE(v, OP)                                                     \
+    { auto t_ = dpp_move<0xB1>(v); v = OP(v, t_); } { auto t_ = dpp_move<0x4E>(v); v = OP(v, t_); } \
+    { auto t_ = dpp_move<0x141>(v); v = OP(v, t_); } { auto t_ = dpp_move<0x140>(v); v = OP(v, t_); }
+    MIDAS_ROW_REDUCE(mx, dpp_max_)
+    MIDAS_ROW_REDUCE(mn, dpp_min_)
+#undef MIDAS_ROW_REDUCE
+    kp += dpp_move<0xB1>(kp, kp); kp += dpp_move<0x4E>(kp, kp); kp += dpp_move<0x141>(kp, kp); kp += dpp_move<0x140>(kp, kp);
+    fl |= dpp_move<0xB1>(fl, fl); fl |= dpp_move<0x4E>(fl, fl); fl |= dpp_move<0x141>(fl, fl); fl |= dpp_move<0x140>(fl, fl);
+    mx = readlane_d(mx, 0);
+    mn = readlane_d(mn, 0);
+    const int kept = __builtin_amdgcn_readlane((int)kp, 0);
+    const unsigned flags = (unsigned)__builtin_amdgcn_readlane((int)fl, 0);
+    double GP = 0.0, GPn = 0.0, W = 0.0, Wa = 0.0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        double tj = 0.0, aj = 0.0;
-        if (j < ngb) {
-            tj = readlane_d(vtm, j);
-            aj = readlane_d(vta, j);
-            const double xj = readlane_d(vmx, j), nj = readlane_d(vmn, j);
-            mx = xj > mx ? xj : mx;
-            mn = nj < mn ? nj : mn;
-            const unsigned mj = (unsigned)__builtin_amdgcn_readlane((int)vmeta, j);
-            kept += (int)(mj & 0xFFFFu);
-            flags |= mj >> 16;
-        }
-        if (j == g) GP = W;
-        W = W + tj;
-        Wa = Wa + aj;
-        if (j == g) GPn = W;
+        GP = j == g ? W : GP;
+        W = W + readlane_d(vtm, j);
+        GPn = j == g ? W : GPn;
+    }
+    if (g == 0) {  // (the block's unmasked total is written by the first group's wave alone)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) Wa = Wa + readlane_d(vta, j);
     }
     if (flags & 1u) { mx = NAN; mn = NAN; }  // torch.max / torch.min propagate NaN
     const bool b_vnan = (flags & 2u) != 0, b_negw = (flags & 4u) != 0;
@@ -170,6 +210,7 @@ MD TGBlock tg_variant(const TailGroupArgs& a, int G, int round, const double* v,
     if (k == 3 && (int64_t)G * TG_GROUP + 16 * c < N) gend_out[(int64_t)G * 16 + c] = out[3];
     if (lane == 63) ggend_out[(int64_t)blk * 16 + g] = out[3];
     if (g == ngb - 1 && lane > g && lane < 16) ggend_out[(int64_t)blk * 16 + lane] = readlane_d(out[3], 63);  // groups without a slot: the block's total
+    TG_CLK(6 + 6 * round);
     if (guide_out) {
         // Guide table (midas_internal.hpp GUIDE_BINS): entry k = min(number of the block's unit ends < edge k, units - 1).  The ends rise
         // (no negative weight), so group g's ends lie in [GP_g, GP_g+1] and the entries of the edges in (GP_g, GP_g+1] are decided by
@@ -187,39 +228,57 @@ MD TGBlock tg_variant(const TailGroupArgs& a, int G, int round, const double* v,
             for (int kk = k0 + lane; kk < k1; kk += 64) gt[kk] = (guide_t)0xFFFFu;
         } else {
             const double q = W * GUIDE_WIDTH, rq = (double)GUIDE_BINS * __builtin_amdgcn_rcp(W);
-            auto first_beyond = [&](double x) {  // min{k : fl(k q) > x}, GUIDE_BINS when there is none (uniform)
+            auto first_beyond = [&](double x) {  // min{k : fl(k q) > x}, GUIDE_BINS when there is none: the estimate through the reciprocal is within one
                 const double kf = x * rq;
                 int kk = kf > 0.0 ? (kf < (double)GUIDE_BINS ? (int)kf + 1 : GUIDE_BINS) : 0;
-                while (kk > 0 && (double)(kk - 1) * q > x) --kk;
-                while (kk < GUIDE_BINS && (double)kk * q <= x) ++kk;
-                return kk;
+                if (kk > 0 && (double)(kk - 1) * q > x) --kk;
+                if (kk < GUIDE_BINS && (double)kk * q <= x) ++kk;
+                return __builtin_amdgcn_readfirstlane(kk);
             };
             const int k_lo = g == 0 ? 0 : first_beyond(GP), k_hi = g == ngb - 1 ? GUIDE_BINS : first_beyond(GPn);
             int nu = UPC * (nch - 16 * g);
             nu = nu > UPG ? UPG : nu;
-            // unit u's end sits in the last value of lane (u + 1) * GUIDE_UNIT / 4 - 1
-            const double E = shfl_d(out[3], ((lane & (UPG - 1)) + 1) * (GUIDE_UNIT / 4) - 1);
-            if (lane < UPG) s_E[lane] = E;
+            // unit u's end is the last value of lane (u + 1) * GUIDE_UNIT / 4 - 1
+            constexpr int LPU = GUIDE_UNIT / 4;  // lanes per unit
+            if ((lane & (LPU - 1)) == LPU - 1) s_E[lane / LPU] = out[3];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const unsigned below = (unsigned)(UPG * g);
-            for (int kb = k_lo; kb < k_hi; kb += 256) {
-                int lo[4];
-                double edge[4];
+            // lower bound over the UPG ends: the first three levels compare against ends every lane can hold (read off their lanes),
+            // the rest are dependent LDS reads
+            constexpr int Q = UPG / 8;  // ends Q - 1, 2 Q - 1, .. , 8 Q - 1
+            double eq[8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { lo[i] = 0; edge[i] = (double)(kb + lane + 64 * i) * q; }
+            for (int i = 0; i < 8; ++i) eq[i] = readlane_d(out[3], (i + 1) * Q * LPU - 1);
+            constexpr int BPL = 4;  // bins a lane and pass (a group's share is 128 bins when the weights are even)
+            for (int kb = k_lo; kb < k_hi; kb += 64 * BPL) {
+                int lo[BPL];
+                double edge[BPL];
 #pragma unroll
-                for (int step = UPG; step > 0; step >>= 1) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int idx = lo[i] + step;
-                        const double e = s_E[(idx - 1) & (2 * UPG - 1)];
-                        lo[i] = (idx <= nu && e < edge[i]) ? idx : lo[i];
-                    }
+                for (int i = 0; i < BPL; ++i) {
+                    edge[i] = (double)(kb + lane + 64 * i) * q;
+                    // (branch-free on purpose: bitwise conditions, every read issued - a short-circuit form serialises the LDS reads)
+                    int l = ((8 * Q <= nu) & (eq[7] < edge[i])) ? 8 * Q : 0;  // (only with every unit below the edge)
+                    const bool h4 = (l == 0) & (4 * Q <= nu) & (eq[3] < edge[i]);
+                    l = h4 ? 4 * Q : l;
+                    const double e2 = h4 ? eq[5] : eq[1];
+                    const bool h2 = (l < 8 * Q) & (l + 2 * Q <= nu) & (e2 < edge[i]);
+                    l = h2 ? l + 2 * Q : l;
+                    const double e1 = h4 ? (h2 ? eq[6] : eq[4]) : (h2 ? eq[2] : eq[0]);
+                    l = ((l < 8 * Q) & (l + Q <= nu) & (e1 < edge[i])) ? l + Q : l;
+                    lo[i] = l;
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int step = Q / 2; step > 0; step >>= 1) {
+                    double e[BPL];
+#pragma unroll
+                    for (int i = 0; i < BPL; ++i) e[i] = s_E[(lo[i] + step - 1) & (2 * UPG - 1)];
+#pragma unroll
+                    for (int i = 0; i < BPL; ++i) lo[i] += ((lo[i] + step <= nu) & (e[i] < edge[i])) ? step : 0;
+                }
+#pragma unroll
+                for (int i = 0; i < BPL; ++i) {
                     const int kk = kb + lane + 64 * i;
                     const unsigned e = below + (unsigned)lo[i];
                     if (kk < k_hi) gt[kk] = (guide_t)(e < maxu ? e : maxu);
@@ -228,6 +287,7 @@ MD TGBlock tg_variant(const TailGroupArgs& a, int G, int round, const double* v,
         }
         if (g == ngb - 1 && lane == 0) gt[GUIDE_BINS] = (guide_t)maxu;
     }
+    TG_CLK(7 + 6 * round);
     TGBlock r;
     r.W = W; r.Wa = Wa; r.mx = mx; r.mn = mn; r.kept = kept; r.vnan = b_vnan; r.late = late;
     return r;
@@ -239,6 +299,10 @@ MD void tail_group_wave(const TailGroupArgs& a, int G, double* s_E) {
     const int blk = G >> 4, g = G & 15;
     const int64_t N = a.N, s0 = (int64_t)G * TG_GROUP + 4 * lane;
     const TailTables& tb = a.tb;
+#ifdef MIDAS_DEBUG_CLOCKS
+    long long tg_clk_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    TG_CLK(0);
     int32_t nn[4] = {0, 0, 0, 0};
     unsigned ok4 = 0, in4 = 0;
     if (s0 + 4 <= N) {
@@ -259,6 +323,7 @@ MD void tail_group_wave(const TailGroupArgs& a, int G, double* s_E) {
     double x[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) x[j] = a.scores[nn[j]];
+    TG_CLK(1);
     double mx = -INFINITY, mn = INFINITY;
     bool xnan = false;
 #pragma unroll
@@ -273,6 +338,7 @@ MD void tail_group_wave(const TailGroupArgs& a, int G, double* s_E) {
     mn = wave_min_dpp(mn);
     const int gkept = wave_isum_dpp(__popc(ok4));
     const bool gxnan = __any(xnan ? 1 : 0) != 0;
+    TG_CLK(2);
     const int64_t npad = (N + SCAN_CHUNK - 1) & ~(int64_t)(SCAN_CHUNK - 1);
     auto store4 = [&](double* __restrict__ o, const double* val) {
         if (s0 + 4 <= N || (a.padded && s0 < npad)) {
@@ -292,10 +358,11 @@ MD void tail_group_wave(const TailGroupArgs& a, int G, double* s_E) {
         double e[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) e[j] = exp_spec(x[j] - 1.0);
+        TG_CLK(3);
         store4(tb.e, e);
 #pragma unroll
         for (int j = 0; j < 4; ++j) e[j] = (in4 >> j) & 1u ? e[j] : 0.0;
-        r0 = tg_variant(a, G, 0, e, ok4, mx, mn, gkept, gxnan, tb.lp, tb.gend, tb.ggend, tb.guide, s_E);
+        r0 = tg_variant(a, G, 0, e, ok4, mx, mn, gkept, gxnan, tb.lp, tb.gend, tb.ggend, tb.guide, s_E TG_CLK_PASS);
         close = __builtin_fabs(r0.mx - r0.mn) <= TAIL_ISCLOSE_ATOL;  // false on NaN
         late |= r0.late;
         nan = r0.vnan;
@@ -304,7 +371,7 @@ MD void tail_group_wave(const TailGroupArgs& a, int G, double* s_E) {
     const bool need_raw = !need_soft || close;  // rare with the softmax on: every particle of the block shares one score
     if (need_raw) {
         store4(tb.x_raw, x);
-        const TGBlock r1 = tg_variant(a, G, need_soft ? 1 : 0, x, ok4, mx, mn, gkept, gxnan, tb.lp_raw, tb.gend_raw, tb.ggend_raw, tb.guide_raw, s_E);
+        const TGBlock r1 = tg_variant(a, G, need_soft ? 1 : 0, x, ok4, mx, mn, gkept, gxnan, tb.lp_raw, tb.gend_raw, tb.ggend_raw, tb.guide_raw, s_E TG_CLK_PASS);
         late |= r1.late;
         if (!need_soft) { r0 = r1; nan = r1.vnan; }  // with the softmax on, x NaN <=> e NaN: counted once
         if (g == 0 && lane == 0) tb.btot_raw[blk] = r1.W;
@@ -322,6 +389,12 @@ MD void tail_group_wave(const TailGroupArgs& a, int G, double* s_E) {
         }
     }
     if (late && lane == 0) atomicOr(&a.status[0], 16);
+#ifdef MIDAS_DEBUG_CLOCKS
+    TG_SPAN(2 * G, tg_clk_[0]);
+    TG_SPAN(2 * G + 1, wall_clock64());
+    if (lane == 0 && (G == 0 || G == 200))
+        for (int i = 0; i < 8; ++i) g_tg_clk[(G ? 24 : 8) + i] = tg_clk_[i];
+#endif
 }
 
 }  // namespace midas
