@@ -56,6 +56,12 @@ int midas_sync(midas_ctx* ctx); /* hipStreamSynchronize */
  * Synchronises the context's stream when it has to replace chunks.  No counterpart in the reference (torch's caching allocator
  * plays this role for modules/particle_filter.py's temporaries). */
 int midas_scratch_reserve(midas_ctx* ctx, int64_t bytes);
+/* Self-test of the float64 sums whose ORDER is part of the arithmetic spec (the wave's xor butterfly 32 .. 1 and the 16-lane row's
+ * 8 .. 1: get_similarity's dot products and the CDF's block sums, modules/particle_filter.py:449-469, :237-252, restated in
+ * oracle/midas_oracle.c): the kernels form them with register moves (csrc/midas_math.hpp); this entry returns, for 64 doubles in,
+ * per lane {butterfly wave sum, register-move wave sum, butterfly row sum, register-move row sum} (256 doubles out), enqueued on the
+ * context's stream.  tests/test_gpu_sums.py compares the pairs bit for bit. */
+int midas_selftest_wave_sums(midas_ctx* ctx, const double* in64_dev, double* out256_dev);
 const char* midas_strerror(int code);
 const char* midas_last_error(const midas_ctx* ctx);
 const char* midas_version(void);
@@ -646,7 +652,9 @@ int midas_tail_resample(midas_ctx* ctx, const midas_tail_resample_args* args);
 #define MIDAS_LOOP_I_FRAME 12  /* frames completed */
 #define MIDAS_LOOP_I_NAN 13    /* NaN among the scores */
 #define MIDAS_LOOP_I_ERR 14    /* conditions of the CURRENT frame (cleared once its log row holds them): bit 0 / 1: more than
-                                * MIDAS_LOOP_MAX_CLUSTERS - 1 clusters (decide / DBSCAN), bit 2: live count above the launches' bound */
+                                * MIDAS_LOOP_MAX_CLUSTERS - 1 clusters (decide / DBSCAN), bit 2: live count above the launches' bound (particles were
+                                * not processed), bit 5: DBSCAN saw non-finite translations or more than 2^21 cells per axis, bit 6: a
+                                * cloud wider than 128 cells per axis with more than 2^20 particles (bits 5 / 6: labels undefined) */
 /* ctl_d (16 x float64) */
 #define MIDAS_LOOP_D_S 0        /* softmax denominator (1 when raw) */
 #define MIDAS_LOOP_D_VARPREV 1  /* particle_var (float32 value) */
@@ -713,7 +721,8 @@ int midas_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* 
  * translation, eps as given, min_samples < 0 -> N / 5.  Exact float64 predicate |dx|^2 <= eps^2, clusters numbered by their
  * first core point, border points to the smallest adjacent cluster - what sklearn's DBSCAN returns.  Any extent (dense cell grid
  * up to 128 cells of 0.577 eps per axis, a hash table of the occupied cells beyond) and any number of clusters.
- * ncl_dev: 2 x int32 out {number of clusters, flag: non-zero only for non-finite coordinates / more than 2^21 cells per axis}. */
+ * ncl_dev: 2 x int32 out {number of clusters, flag: 32 = non-finite coordinates / more than 2^21 cells per axis, 64 = a cloud wider
+ * than 128 cells per axis with more than 2^20 points (the hash table of occupied cells holds 2^21 slots): labels undefined}. */
 int midas_dbscan(midas_ctx* ctx, int64_t N, const float* poses_dev, double eps, int64_t min_samples, int32_t* labels_dev,
                  int32_t* ncl_dev);
 /* cluster_particles(method="logmap") (particle_filter.py:218-223): DBSCAN of N points of `dim` (2 .. 6) float64 coordinates

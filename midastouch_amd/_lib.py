@@ -189,6 +189,7 @@ SIGNATURES = {
     "midas_ctx_destroy": (C.c_int, [_P]),
     "midas_ctx_set_stream": (C.c_int, [_P, _P]),
     "midas_sync": (C.c_int, [_P]),
+    "midas_selftest_wave_sums": (C.c_int, [_P, _P, _P]),
     "midas_scratch_reserve": (C.c_int, [_P, C.c_int64]),
     "midas_strerror": (C.c_char_p, [C.c_int]),
     "midas_last_error": (C.c_char_p, [_P]),

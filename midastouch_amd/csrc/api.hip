@@ -1370,6 +1370,12 @@ MIDAS_EXPORT int midas_selfsim_topn(midas_ctx* ctx, const midas_codebook* cb, in
     return finish(MIDAS_OK);  // the results are ordered behind the main stream again
 }
 
+MIDAS_EXPORT int midas_selftest_wave_sums(midas_ctx* ctx, const double* in64_dev, double* out256_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, in64_dev && out256_dev);
+    return midas::launch_selftest_wave_sums(ctx, in64_dev, out256_dev);
+}
+
 #ifdef MIDAS_DEBUG_CLOCKS
 MIDAS_EXPORT int midas_debug_tb2_clocks(long long* out16) { return midas::debug_tb2_clocks(out16); }
 MIDAS_EXPORT int midas_debug_ta_clocks(long long* out16) { return midas::debug_ta_clocks(out16); }

@@ -79,7 +79,7 @@ struct DbArgs {
     int32_t max_clusters;   // 0: any number; otherwise the clusters beyond that many stay unnumbered (err |= 2)
     int32_t* labels;        // [N] out
     int32_t* ncl_out;       // out: number of clusters
-    int32_t* err_out;       // nullable: |= 2 on a limit
+    int32_t* err_out;       // nullable: |= 2 cluster limit, |= 32 non-finite coordinates / more than 2^21 cells per axis, |= 64 wide cloud of more than 2^20 points
 };
 
 __device__ __forceinline__ int64_t db_n(const DbArgs& a) {
@@ -138,10 +138,10 @@ __global__ __launch_bounds__(64) void k_db_setup(DbArgs a, int nblocks) {
         double c = n > 0 ? floor(ext / g.h) + 1.0 : 1.0;
         if (!(c >= 1.0)) c = 1.0;                      // NaN extents
         if (c > (double)DB_MAXDIM) hashed = 1;
-        if (c > (double)(1 << DB_HASH_BITS)) { c = (double)(1 << DB_HASH_BITS); err = 1; }  // (6 km at eps = 1e-2, or infinite coordinates)
+        if (c > (double)(1 << DB_HASH_BITS)) { c = (double)(1 << DB_HASH_BITS); err |= 1; }  // (6 km at eps = 1e-2, or infinite coordinates)
         dims[d] = (int)c;
     }
-    if (hashed && n > DB_MAXCELLS / 2) { hashed = 0; err = 1; }  // the table is sized for a load of one half
+    if (hashed && n > DB_MAXCELLS / 2) { hashed = 0; err |= 2; }  // the table is sized for a load of one half (err 2: a wide cloud of more than 2^20 points)
     if (!hashed)
         for (int d = 0; d < 3; ++d)
             if (dims[d] > DB_MAXDIM) dims[d] = DB_MAXDIM;  // (only with err set: clamped as before)
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256) void k_db_number(DbArgs a) {
     __syncthreads();
     if (blockIdx.x == 0 && t == 0) {
         *a.ncl_out = nr;
-        if (a.err_out && (over || g.err)) *a.err_out |= 2;
+        if (a.err_out && (over || g.err)) *a.err_out |= (over ? 2 : 0) | (g.err & 1 ? 32 : 0) | (g.err & 2 ? 64 : 0);  // cluster limit | extent / non-finite | hash capacity
     }
     for (int64_t p = (int64_t)blockIdx.x * 256 + t; p < g.n; p += (int64_t)gridDim.x * 256) {
         if (!a.s_core[p]) continue;

@@ -410,6 +410,7 @@ int launch_peer_probe(midas_ctx* ctx, void* const* peers, const void* inbox, int
 int launch_peer_flag_write(midas_ctx* ctx, void* const* peers, int G, int rank, int64_t flag_off, uint64_t tag);
 int launch_shard_unpack_peer_wait(midas_ctx* ctx, int64_t N, const void* inbox, int32_t* ridx, float* poses_out, double* weights_out,
                                   int32_t* hint_out, int G, int64_t flag_off, uint64_t tag, int32_t* status, void* const* peers, int rank);
+int launch_selftest_wave_sums(midas_ctx* ctx, const double* in64, double* out256);
 int debug_tb2_clocks(long long* out16);
 int debug_ta_clocks(long long* out16);
 int debug_tg_clocks(long long* io64, int reset);

@@ -332,7 +332,7 @@ MD int wave_isum_dpp(int v) {
 //     and {partner row | partner row} in some order, so their sum is own + partner on every lane (addition commutes bit for bit);
 //   o = 8: row_ror:8 IS lane ^ 8 inside a 16-lane row; after it the row's values repeat with period 8, and then a rotation by
 //     4 reads a lane with the same value as lane ^ 4 ((i +- 4) mod 8 = (i mod 8) ^ 4); likewise 2 and 1.
-// quarter_sum_ordered: the last four steps alone (score_body.hpp's 16-lane tree).  midas_debug_wave_sum compares both forms bit for bit.
+// quarter_sum_ordered: the last four steps alone (score_body.hpp's 16-lane tree).  midas_selftest_wave_sums compares both forms bit for bit.
 MD double double_of(uint32_t lo, uint32_t hi) { return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo)); }
 MD double quarter_sum_ordered(double v) {
     v += dpp_move<0x128>(v);

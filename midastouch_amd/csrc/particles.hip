@@ -2684,19 +2684,23 @@ static int launch_presort(midas_ctx* ctx, ParticleUpdateArgs& a) {
     const int run = (run_env == 1 || run_env == 2 || run_env == 4 || run_env == 8 || run_env == 16 || run_env == 32) ? run_env : 0;  // divisors of 64; else none
     static const bool fused_env = !(getenv("MIDAS_PRESORT_FUSED") && getenv("MIDAS_PRESORT_FUSED")[0] == '0');
     if (fused_env && a.N <= PS_LP_MAX) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        // per device: the dynamic-LDS limit of the kernel and the CU count (a second GPU's context must not inherit the first's)
+        constexpr int MAXDEV = 64;
+        static bool attr_set[MAXDEV] = {};
+        static int ncu_dev[MAXDEV] = {};
+        const int di = ctx->device >= 0 && ctx->device < MAXDEV ? ctx->device : 0;
+        if (!attr_set[di] || ctx->device != di) {
             MIDAS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_presort_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PresortLds)));
-            attr_set = true;
+            attr_set[di] = true;
         }
         // One workgroup per CU is all the kernel's LDS allows, and a workgroup's life is a chain of round trips whatever its share: as many
         // chunks per trajectory as fill the chip (c5: 64 trajectories x 4 chunks of 2560 slots on 256 CUs instead of 3 of 4096 -
         // 285 / 270 -> 277 / 266 us per batch frame; 5 or 8 chunks - a second round of workgroups - lose: 290 / 285), whole waves each
-        static int ncu = 0;
-        if (!ncu) {
+        if (!ncu_dev[di] || ctx->device != di) {
             hipDeviceProp_t prop;
-            ncu = (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+            ncu_dev[di] = (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
         }
+        const int ncu = ncu_dev[di];
         static const int chunk_env = getenv("MIDAS_PRESORT_CHUNK") ? atoi(getenv("MIDAS_PRESORT_CHUNK")) : 0;
         int64_t nch = ceil_div(a.N, PS_CHUNK);
         if (ncu / a.batch > nch) nch = ncu / a.batch;

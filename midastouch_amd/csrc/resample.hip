@@ -41,12 +41,11 @@ __global__ __launch_bounds__(64) void k_debug_wave_sum(const double* __restrict_
     out[4 * l + 2] = q;
     out[4 * l + 3] = quarter_sum_ordered(v);
 }
-}  // namespace midas
-extern "C" __attribute__((visibility("default"))) int midas_debug_wave_sum(const double* in64_dev, double* out256_dev) {
-    hipLaunchKernelGGL(midas::k_debug_wave_sum, dim3(1), dim3(64), 0, nullptr, in64_dev, out256_dev);
-    return hipDeviceSynchronize() == hipSuccess ? 0 : -1;
+int launch_selftest_wave_sums(midas_ctx* ctx, const double* in64, double* out256) {
+    hipLaunchKernelGGL(k_debug_wave_sum, dim3(1), dim3(64), 0, ctx->stream, in64, out256);
+    MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    return MIDAS_OK;
 }
-namespace midas {
 MD double wmax(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o); v = t > v ? t : v; }
@@ -1927,6 +1926,10 @@ int launch_tail_a2(midas_ctx* ctx, int64_t N, const double* scores, const int32_
                            part_rmse ? rmse_out : (double*)nullptr, score_stride, tstride, nb, with_list ? *predict : ScorePredict());
         LAUNCH_CHECK(ctx);
         return MIDAS_OK;
+    }
+    if (tb.guide && batch <= 1) {  // (this form of the tail writes no guide tables: "no guide" in every entry, see tail_block.hpp)
+        MIDAS_HIP_CHECK(ctx, hipMemsetAsync(tb.guide, 0xFF, (size_t)nb * GUIDE_STRIDE * sizeof(guide_t), ctx->stream));
+        if (tb.guide_raw) MIDAS_HIP_CHECK(ctx, hipMemsetAsync(tb.guide_raw, 0xFF, (size_t)nb * GUIDE_STRIDE * sizeof(guide_t), ctx->stream));
     }
     hipLaunchKernelGGL(k_tail_a2, dim3((unsigned)nb, (unsigned)(batch > 1 ? batch : 1)), dim3(256), 0, ctx->stream, N, scores, nn_idx, valid, softmax, tb.e, tb.x_raw,
                        tb.lp, tb.lp_raw, tb.gend, tb.gend_raw, tb.ggend, tb.ggend_raw, tb.bsum_e, tb.btot, tb.btot_raw, tb.bmax, tb.bmin,

@@ -262,33 +262,43 @@ class LoopEngine:
             self._n_host = None if self.cluster else self._n_host
 
     # ---- results --------------------------------------------------------------------------------------------------
-    def read_log(self, first: int = 0, last: int = None):
+    def read_log(self, first: int = 0, last: int = None, strict: bool = True):
         """Per-frame records of frames [first, last) as a list of dicts (one read-back): frame, n (before annealing),
-        n_after, rmse_t, rmse_r, kept, drifted, status, mode, k, clusters, var, cluster_poses (C,4,4), cluster_stds (C,3)."""
+        n_after, rmse_t, rmse_r, kept, drifted, status, mode, k, clusters, var, cluster_poses (C,4,4), cluster_stds (C,3), err.
+        Conditions that leave a frame's particles or labels UNDEFINED (err bit 2: the live count exceeded the bound the launches
+        were sized for; bits 5 / 6: DBSCAN's cell structure did not apply) raise MidasError once every row is parsed (the records
+        are attached to the exception as `.records`); strict=False reports them as warnings like the benign ones (cluster limits)."""
         last = self.step_count if last is None else min(last, self.step_count)
         first = max(first, last - self.log_frames)
         rows = self._log.cpu().numpy()
-        out = []
+        out, fatal = [], []
+        import warnings
         for f in range(first, last):
             L = rows[f % self.log_frames]
             npres = int(L[10])
             cl = L[16:16 + 19 * min(npres, 8)].reshape(-1, 19)
             err = int(L[15])
-            # condition bits of THIS frame (the device clears the word once the row holds it); reported, never raised: the
-            # records of the run stay readable and the caller decides (`err` in the record)
+            # condition bits of THIS frame (the device clears the word once the row holds it)
             if err & (1 | 2):
-                import warnings
                 warnings.warn(f"frame {f}: more than {_lib.LOOP_MAX_CLUSTERS - 2} clusters in one frame - the labels beyond that limit, and the "
                               "annealing driven by them, are not the reference's (min_samples = n / 5 allows about five)")
             if err & 8:
-                import warnings
                 warnings.warn(f"frame {f}: {npres} cluster labels present, the log row keeps the centres of the first 8")
             if err & 4:
-                import warnings
-                warnings.warn(f"frame {f}: the live particle count exceeded the bound the launches were sized for; "
-                              "the particles beyond it were not processed in this frame")
+                fatal.append(f"frame {f}: the live particle count exceeded the bound the launches were sized for; "
+                             "the particles beyond it were not processed in this frame")
+            if err & 32:
+                fatal.append(f"frame {f}: DBSCAN saw non-finite particle translations or a cloud of more than 2^21 cells per axis; labels undefined")
+            if err & 64:
+                fatal.append(f"frame {f}: DBSCAN on a cloud wider than 128 cells per axis with more than 2^20 particles (hash table capacity); labels undefined")
             out.append(dict(frame=f, n=int(L[1]), n_after=int(L[2]), rmse_t=float(L[3]), rmse_r=float(L[4]), kept=int(L[5]),
                             drifted=bool(L[6]), status=int(L[7]), mode=int(L[8]), k=int(L[9]), clusters=npres, var=float(L[11]),
                             S=float(L[12]), raw=bool(L[13]), ncl=int(L[14]), err=int(L[15]),
                             cluster_poses=cl[:, :16].reshape(-1, 4, 4).astype(np.float32), cluster_stds=cl[:, 16:].astype(np.float32)))
+        if fatal and strict:
+            e = MidasError("; ".join(fatal))
+            e.records = out
+            raise e
+        for msg in fatal:
+            warnings.warn(msg)
         return out

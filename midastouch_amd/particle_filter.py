@@ -199,12 +199,16 @@ class particle_filter:
         particles = copy.copy(_particles)
         if method == "euclidean":
             # any extent (a hash table of the occupied cells takes over from the dense grid beyond 128 cells per axis) and any
-            # number of clusters: there is no host fallback.  The flag is set only for coordinates at infinity / beyond 2^21
-            # cells per axis (6 km at eps = 1e-2), where no cell structure applies.
+            # number of clusters: there is no host fallback.  Flag 32: coordinates at infinity / beyond 2^21 cells per axis (6 km at
+            # eps = 1e-2), where no cell structure applies; flag 64: a wide cloud of more than 2^20 particles (hash table capacity).
             labels, info = ops.dbscan(particles.poses, eps)
-            if int(info[1].item()) != 0:
+            flag = int(info[1].item())
+            if flag & 32:
                 raise ops.MidasError(f"cluster_particles: particle translations are not finite or span more than 2^21 cells of "
                                      f"{0.577 * eps:.3g} m; DBSCAN labels undefined")
+            if flag & 64:
+                raise ops.MidasError(f"cluster_particles: {len(particles)} particles spread over more than 128 cells of {0.577 * eps:.3g} m per axis - the "
+                                     "hash table of occupied cells holds 2^20 particles; cluster a subset, raise eps, or shard the set")
             particles.labels = labels.to(torch.int64)
             return particles
         if method != "logmap":

@@ -75,13 +75,20 @@ class TorchCpuStream:
 
     def rand64_async(self, N: int, out: torch.Tensor | None = None):
         """The next N values of torch.rand(N, dtype=torch.float64), enqueued on the generator's stream: (tensor, event or None).
-        The consumer waits for the event on its stream before it reads the tensor (None: same stream, already ordered)."""
+        The consumer waits for the event on its stream before it reads the tensor (None: same stream, already ordered).
+        Without `out` the tensor is one of THREE rotating internal buffers: ONE consumer, which has enqueued its use of a buffer
+        before the third following call (the engines: one draw per frame, consumed by that frame) - anybody who keeps the
+        tensor longer, or shares the stream object between engines, passes `out` (or calls rand64, which allocates)."""
         N = int(N)
         if out is None:
             i = self._turn
             self._turn = (i + 1) % 3
             if self._bufs[i] is None or self._bufs[i].numel() != N:
+                # (a buffer dropped here may still be being written on the generator's stream: the allocator learns of that stream
+                # at allocation, so the block is not handed out again before the write is done)
                 self._bufs[i] = torch.empty(N, dtype=torch.float64, device=self.device)
+                if self.side is not None:
+                    self._bufs[i].record_stream(self.side)
             out = self._bufs[i]
         self._enter()
         self._call("midas_mt19937_rand64", _ptr(self.state), self.pending_skip, N, _ptr(out))

@@ -24,6 +24,11 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/midas_hip.h but not exported"
+    # ... and nothing else: every midas_* symbol the library exports is declared (a stray debug entry would be a second, unreviewed ABI)
+    import subprocess
+    exported = sorted({ln.split()[-1] for ln in subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout.splitlines()
+                       if ln.split() and ln.split()[-1].startswith("midas_")})
+    assert exported == names, sorted(set(exported) ^ set(names))
     # the python binding table covers exactly the declared surface
     assert sorted(_lib.SIGNATURES) == names
     lib.midas_version.restype = ctypes.c_char_p

@@ -1,7 +1,7 @@
 """The float64 sums over a wave (xor butterfly 32 .. 1) and over a 16-lane row (8 .. 1) are part of the arithmetic spec (the oracle
 restates their order: oracle/midas_oracle.c mo_quarter_tree, the blocked scan).  The kernels form them with register moves
 (v_permlane32_swap / v_permlane16_swap and row rotations, midas_math.hpp) instead of `__shfl_xor` trips through the LDS crossbar:
-this test compares both forms bit for bit on the device (midas_debug_wave_sum), over magnitudes, signs, subnormals, infinities, NaN."""
+this test compares both forms bit for bit on the device (midas_selftest_wave_sums), over magnitudes, signs, subnormals, infinities, NaN."""
 import ctypes
 
 import numpy as np
@@ -16,10 +16,7 @@ def test_register_move_sums_equal_the_shuffle_butterflies():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from midastouch_amd import _lib
-    lib = _lib.load()
-    _lib.context(torch.device("cuda", 0))
-    lib.midas_debug_wave_sum.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-    lib.midas_debug_wave_sum.restype = ctypes.c_int
+    ctx = _lib.context(torch.device("cuda", 0))
     rng = np.random.default_rng(0)
     for trial in range(300):
         kind = trial % 5
@@ -36,7 +33,7 @@ def test_register_move_sums_equal_the_shuffle_butterflies():
             x[rng.integers(0, 64, 3)] = [np.inf, -0.0, np.nan]
         xin = torch.as_tensor(x).cuda()
         out = torch.zeros(256, dtype=torch.float64, device="cuda")
-        assert lib.midas_debug_wave_sum(xin.data_ptr(), out.data_ptr()) == 0
+        ctx.call("midas_selftest_wave_sums", _lib._ptr(xin), _lib._ptr(out))
         o = out.cpu().numpy().reshape(64, 4)
         a, b, c, d = (np.ascontiguousarray(o[:, i]).view(np.uint64) for i in range(4))
         assert np.all((a == b) | (np.isnan(o[:, 0]) & np.isnan(o[:, 1]))), trial
