@@ -51,6 +51,36 @@ PER_PARTICLE_TAIL = 200    # the remaining 200 of the 340 B/particle
 # of which the pipelined front performs, for the previous frame: CDF read 8, resample index write 4, pose gather read 64,
 # label (hint) gather read 4 - the 64-byte write of the gathered pose and the weight gather are what the fusion removes
 PER_PARTICLE_FOLDED = 80
+# ... of which the 64-byte pose read is the SAME read as the propagate's (the fused kernel takes a particle's pose once, through
+# the resample source): the bytes the fused launch has to move per particle are 140 + 80 - 64
+PER_PARTICLE_FUSED_NEEDED = PER_PARTICLE_UPDATE + PER_PARTICLE_FOLDED - 64
+
+
+def cpu_quota() -> int:
+    """CPUs this process may really use: the cgroup's quota (cpu.max) when there is one, else the affinity mask.  The GPU boxes show
+    256 hardware threads under a 16-CPU quota: torch's default 128 intra-op threads then exhaust the quota within one scheduling
+    period and the kernel parks the whole process - enqueueing thread included - for 20 - 40 ms (tools/diag_loop_stall.py: the
+    "one slow frame" of the reference-named loop, once per process, right after init_filter's host-side tensor ops)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(q) // int(per)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
+def spread(vals, scale=1.0):
+    """median / min / max of repeated measurements (one sample cannot tell a regression from a hiccup)"""
+    v = sorted(float(x) * scale for x in vals)
+    return {"median": v[len(v) // 2], "min": v[0], "max": v[-1], "repeats": len(v)}
 
 
 def algorithmic_bytes(N, K, D, B=1):
@@ -105,7 +135,7 @@ def cpu_baseline(cb, traj, N, budget_s=12.0, max_steps=40):
         p = p1[torch.multinomial(w, N, replacement=True).numpy()]
         done2 += 1
     dt2 = time.perf_counter() - t1
-    return {"value": done / dt, "unit": "steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
+    return {"value": done / dt, "unit": "steps/s", "cores": int(torch.get_num_threads()), "cpu_quota": cpu_quota(), "kind": "port",
             "sample": f"{done} frames of the same workload (N={N}, K={cb.K}, D={cb.D}) through the reference-shaped "
                       f"torch-CPU path (gather (N,D) f64 + cosine + softmax + multinomial; scipy cKDTree workers=-1 "
                       f"stands in for pynanoflann n_jobs=16), {dt:.1f} s",
@@ -114,7 +144,7 @@ def cpu_baseline(cb, traj, N, budget_s=12.0, max_steps=40):
                                    f"particle (K x D GEMV instead of the (N,D) gather), same threads, {dt2:.1f} s"}
 
 
-def reference_loop_rate(cb, traj, N, dev, tree, mesh_tree, T=200, floor=1000):
+def reference_loop_rate(cb, traj, N, dev, tree, mesh_tree, T=200, floor=1000, repeats=3):
     """midastouch_amd.filter.filter - the reference's loop body with DBSCAN every 50th frame, cluster centres and annealing
     every frame (filter/filter.py:150-190), N0 = N, device draws - over T frames of the same trajectory: frames / s after the
     two initial frames (whose init_filter runs on the host like the reference's)."""
@@ -131,21 +161,25 @@ def reference_loop_rate(cb, traj, N, dev, tree, mesh_tree, T=200, floor=1000):
     was = gc.isenabled()
     gc.collect()
     gc.disable()
+    runs = []
     try:
-        st = run_filter(cfg, seq, device=dev, floor=floor)
+        for _ in range(repeats):
+            runs.append(run_filter(cfg, seq, device=dev, floor=floor))
     finally:
         if was:
             gc.enable()
+    rates = [len(st["time"][2:]) / sum(st["time"][2:]) for st in runs]
+    st = runs[int(np.argsort(rates)[len(rates) // 2])]  # the run with the median rate is the one described
     steady = st["time"][2:]
-    return {"frames_per_sec": len(steady) / sum(steady), "ms_per_frame": 1e3 * sum(steady) / len(steady), "frames": len(steady),
+    return {"frames_per_sec": len(steady) / sum(steady), "frames_per_sec_runs": spread(rates), "ms_per_frame": 1e3 * sum(steady) / len(steady), "frames": len(steady),
             "N0": N, "floor": floor, "N_final": st["num_particles"][-1], "N_min": min(st["num_particles"]),
             "ms_frame_median": 1e3 * sorted(steady)[len(steady) // 2],
-            "ms_frame_max": 1e3 * max(steady), "slowest_frame": 2 + int(np.argmax(steady)),
+            "ms_frame_max": 1e3 * max(steady), "ms_frame_max_runs": spread([max(r["time"][2:]) for r in runs], 1e3), "slowest_frame": 2 + int(np.argmax(steady)),
             "slowest_frames": [{"frame": 2 + int(i), "ms": 1e3 * steady[int(i)]} for i in np.argsort(steady)[::-1][:3]],
             "rmse_t_mm_final": 1e3 * st["rmse_t"][-1]}
 
 
-def config5_rate(dev, frames=60):
+def config5_rate(dev, frames=60, repeats=3):
     """BASELINE configs[4] (c5): B = 64 trajectories x N = 10 000 particles on the cotter pin's 50k x 512 codebook, pipelined batch
     engine (two launches per batch frame), device draws: us per batch frame from a spread start and from a start near the truth."""
     from midastouch_amd.engine import PipelinedBatchFilterEngine
@@ -168,28 +202,38 @@ def config5_rate(dev, frames=60):
                 d0 = np.linalg.norm(cb.poses[:, :3, 3] - trs[b % 8].gt_poses[0][:3, 3], axis=1)
                 start.append(cb.poses[rng.choice(np.argsort(d0)[:2500], N)])
             start = np.stack(start)
-        eng.set_particles(torch.as_tensor(start))
-        eng.project_to_codebook()
-        for i in range(10):
-            eng.step(od[1 + i % 38], co[1 + i % 38])
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(frames):
-            eng.step(od[1 + (10 + i) % 38], co[1 + (10 + i) % 38])
-        torch.cuda.synchronize()
-        us = (time.perf_counter() - t0) / frames * 1e6
-        out[init] = {"us_per_batch_frame": us, "trajectory_steps_per_sec": B * 1e6 / us}
+        uss = []
+        for rep in range(repeats):
+            eng.set_particles(torch.as_tensor(start))
+            eng.project_to_codebook()
+            for i in range(10):
+                eng.step(od[1 + i % 38], co[1 + i % 38])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(frames):
+                eng.step(od[1 + (10 + i) % 38], co[1 + (10 + i) % 38])
+            torch.cuda.synchronize()
+            uss.append((time.perf_counter() - t0) / frames * 1e6)
+        us = sorted(uss)[len(uss) // 2]
+        out[init] = {"us_per_batch_frame": us, "us_per_batch_frame_runs": spread(uss), "trajectory_steps_per_sec": B * 1e6 / us}
     return out
 
 
-def _timed_run(eng, od, co, T, warm, steps):
-    """steps frames by ONE midas_lazy_run call after `warm` frames (the form the headline is timed in), us per frame"""
-    eng.run(od[1:1 + warm], co[1:1 + warm])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    eng.run(od[1 + warm:1 + warm + steps], co[1 + warm:1 + warm + steps])
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps * 1e6
+def _timed_run(eng, od, co, T, warm, steps, start=None, repeats=1):
+    """steps frames by ONE midas_lazy_run call after `warm` frames (the form the headline is timed in), us per frame; with `start`
+    the run is repeated from that particle set (projected onto the codebook) and the list of all repeats is returned"""
+    uss = []
+    for rep in range(repeats):
+        if start is not None:
+            eng.set_particles(start)
+            eng.project_to_codebook()
+        eng.run(od[1:1 + warm], co[1:1 + warm])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.run(od[1 + warm:1 + warm + steps], co[1 + warm:1 + warm + steps])
+        torch.cuda.synchronize()
+        uss.append((time.perf_counter() - t0) / steps * 1e6)
+    return uss if start is not None else uss[0]
 
 
 def config1_rates(dev, budget_s=4.0):
@@ -207,10 +251,9 @@ def config1_rates(dev, budget_s=4.0):
     od, co = torch.as_tensor(tr.odoms).to(dev), torch.as_tensor(tr.codes).to(dev)
     eng = PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, device=dev)
     start = cb.poses[np.random.default_rng(0).integers(0, K, N)]
-    eng.set_particles(torch.as_tensor(start))
-    eng.project_to_codebook()
-    us = _timed_run(eng, od, co, 262, 40, 200)
-    out = {"workload": "c1: 004_sugar_box, N=1000, K=5000, D=256", "gpu": {"steps_per_sec": 1e6 / us, "us_per_step": us, "steps": 200}}
+    uss = _timed_run(eng, od, co, 262, 40, 200, start=torch.as_tensor(start), repeats=3)
+    us = sorted(uss)[len(uss) // 2]
+    out = {"workload": "c1: 004_sugar_box, N=1000, K=5000, D=256", "gpu": {"steps_per_sec": 1e6 / us, "us_per_step": us, "us_per_step_runs": spread(uss), "steps": 200}}
     nthreads = min(8, os.cpu_count() or 1)  # 1000 particles: more threads only add hand-over time
     was = torch.get_num_threads()
     torch.set_num_threads(nthreads)
@@ -251,14 +294,25 @@ def big_config_rates(dev, which):
     t2 = time.perf_counter()
     d0 = np.linalg.norm(cb.poses[:, :3, 3] - tr.gt_poses[0][:3, 3], axis=1)
     near = np.argsort(d0)[: K // 20]
-    eng.set_particles(torch.as_tensor(cb.poses[np.random.default_rng(4).choice(near, N)]))
-    eng.project_to_codebook()
+    start = torch.as_tensor(cb.poses[np.random.default_rng(4).choice(near, N)])
     od, co = torch.as_tensor(tr.odoms).to(dev), torch.as_tensor(tr.codes).to(dev)
-    us = _timed_run(eng, od, co, 72, 20, 50)
+    uss = _timed_run(eng, od, co, 72, 20, 50, start=start, repeats=3)
+    us = sorted(uss)[len(uss) // 2]
     ab = algorithmic_bytes(N, K, D)["step"]
-    return {"workload": f"{which} total on one GPU: {obj}, N={N}, K={K}, D={D}", "steps_per_sec": 1e6 / us, "us_per_step": us, "steps": 50,
-            "algorithmic_MB_per_step": ab / 1e6, "step_frac_of_hbm_peak_survey_model": ab / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-            "host_codebook_s": t1 - t0, "index_build_s": t2 - t1}
+    out = {"workload": f"{which} total on one GPU: {obj}, N={N}, K={K}, D={D}", "steps_per_sec": 1e6 / us, "us_per_step": us, "us_per_step_runs": spread(uss), "steps": 50,
+           "scoring": "sparse: only the rows some particle's nearest entry points at are read (the codebook stream of SURVEY 8(d)'s byte model does not move: no roofline figure for this form)",
+           "algorithmic_MB_per_step_survey_model": ab / 1e6, "host_codebook_s": t1 - t0, "index_build_s": t2 - t1}
+    if which == "c4":
+        # BASELINE's "bandwidth-bound regime": every one of the 500k rows scored every frame - what a caller with the heat-map on runs
+        # (filter/filter.py:213-215, live_demo.py:107-109): the front kernel streams the whole 1.02 GB codebook beside the particle waves
+        eng.sparse_scores = False
+        usd = _timed_run(eng, od, co, 72, 20, 50, start=start, repeats=3)
+        eng.sparse_scores = True
+        ud = sorted(usd)[len(usd) // 2]
+        out["dense"] = {"us_per_step": ud, "us_per_step_runs": spread(usd), "steps_per_sec": 1e6 / ud, "algorithmic_MB_per_step": ab / 1e6,
+                        "achieved_GBs": ab / (ud * 1e-6) / 1e9, "step_frac_of_hbm_peak": ab / (ud * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                        "note": "all K = 500k rows streamed every frame (K1 GEMV inside the front kernel): SURVEY 8(d) bytes / whole-step time"}
+    return out
 
 
 def parity_mode_rate(cb, traj, N, dev, tree, mesh_tree, steps=100):
@@ -278,13 +332,16 @@ def parity_mode_rate(cb, traj, N, dev, tree, mesh_tree, steps=100):
     T = odoms.shape[0]
     for i in range(20):
         eng.step(odoms[1 + i % (T - 1)], codes[1 + i % (T - 1)])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        eng.step(odoms[1 + (20 + i) % (T - 1)], codes[1 + (20 + i) % (T - 1)])
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {"steps_per_sec": steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
+    dts = []
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            eng.step(odoms[1 + (20 + rep * steps + i) % (T - 1)], codes[1 + (20 + rep * steps + i) % (T - 1)])
+        torch.cuda.synchronize()
+        dts.append(time.perf_counter() - t0)
+    dt = sorted(dts)[1]
+    return {"steps_per_sec": steps / dt, "steps_per_sec_runs": spread([steps / d for d in dts]), "ms_per_step": 1e3 * dt / steps, "steps": steps,
             "draws": "resample: device replica of torch's CPU mt19937 under torch.manual_seed(3000) (torch.rand(N, float64) stream, "
                      "generated on the generator's own stream beside each frame's kernels); motion noise: device Philox",
             "status": eng.status.cpu().numpy().tolist()}
@@ -310,6 +367,26 @@ def parity_probe(eng, N, seed):
     out["note"] = ("last frame of the run, N = %d: resample indices of the device against the oracle's search over the blocked CDF of "
                    "exp(x - 1) * mask with the spec exponential (must be 0) and with libm's exp (SURVEY 7 hard part 2)" % N)
     return out
+
+
+def sharded_one_gpu(steps=20, warmup=5):
+    """The C-side sharded frame (midas_shard_run on a library-owned RCCL communicator, world 1: front, tail, record all-gather,
+    owner-side routing into the peer-mapped inbox, unpack folded into the next front) on this one GPU, in a process of its own
+    (it needs a process group): what `bench.py --sharded` prints, reduced to the figures of the frame."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--sharded", "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-extras",
+           "--no-loop", "--no-profile", "--no-diffuse"]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not line:
+        return {"error": "rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
+    d = json.loads(line[-1])
+    return {"steps_per_sec": d["value"], "us_per_frame": 1e3 * d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"], "exchange": d["config"]["exchange"],
+            "timed_region": d["config"]["timed_region"], "engine": d["config"]["engine"],
+            "note": "particle-sharded engine with one shard: every phase of the multi-GPU frame runs (the all-gather and the inbox stores stay on this GPU)"}
 
 
 def free_port() -> int:
@@ -420,6 +497,9 @@ def main():
         raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # host-side tensor ops (init_filter's draws, the runner's 4x4 products) on as many threads as the cgroup grants, not as the box
+    # shows: see cpu_quota()
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), cpu_quota())))
     dist = None
     if world > 1 or args.sharded:
         import torch.distributed as dist
@@ -680,7 +760,8 @@ def main():
             # SURVEY 8(d)'s model charges all K rows to every frame; the kernel needs the rows some particle's nearest entry
             # points at (measured: telemetry [2] + [3]), so its own byte count is per-particle bytes + those rows
             ab["frame_front"] = ab["score_codebook"] + ab["particle_update"] + folded
-            needed = N * PER_PARTICLE_UPDATE + folded + (rows_prof * row_bytes if sparse else ab["score_codebook"] + K * 24)
+            per_particle = PER_PARTICLE_FUSED_NEEDED if folded else PER_PARTICLE_UPDATE
+            needed = N * per_particle + (rows_prof * row_bytes if sparse else ab["score_codebook"] + K * 24)
             dom = "frame_front"
         else:
             groups = {"score_codebook": per["score_codebook"], "particle_update": per["particle_update"],
@@ -692,7 +773,7 @@ def main():
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (PMC counters
         # cannot be read from inside the process): profiles/r04_traffic.json, tools/pmc_traffic.sh
         traffic, traffic_src = None, None
-        for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(REPO, "profiles", name)))
                 traffic, traffic_src = tj["kernels"][dom]["hbm_bytes"], "profiles/" + name
@@ -701,18 +782,23 @@ def main():
                 pass
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                           "algorithmic_bytes_per_launch": needed, "kernel_ms": groups[dom],
+                           "algorithmic_bytes_per_launch": needed, "needed_bytes": needed,
+                           "survey_8d_bytes_of_the_launch": (N * (PER_PARTICLE_UPDATE + PER_PARTICLE_FOLDED) + ab["score_codebook"] + K * 24) if fused else ab[dom],
+                           "kernel_ms": groups[dom],
                            "rows_scored_per_launch": rows_prof if sparse else float(K),
                            "per_kernel_ms": per, "event_pair_overhead_ms": overhead,
                            "frac_survey_model": survey / HBM_PEAK_GBS, "survey_model_bytes_per_launch": ab[dom],
                            "step_bytes_survey_model": ab["step"],
                            "step_frac_survey_model": ab["step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "note": "achieved = bytes this launch has to move / its HIP-event time: N x (140 update + 80 folded resample) + "
+                           "note": "achieved = bytes this launch has to move / its HIP-event time: N x (140 update + 80 folded resample - 64: the pose is "
+                                   "read once, through the resample source) + "
                                    "rows x (4 D + 32), rows = codebook rows actually scored per frame (sparse scoring: the rows some particle's "
                                    "nearest entry points at, counted by the kernels) - the kernel is bound by the dependent-fetch chain of a "
                                    "particle wave, not by bandwidth (DESIGN.md section 4).  frac_survey_model keeps SURVEY.md 8(d)'s byte model, "
                                    "which charges all K rows of the codebook to every frame although the sparse kernel does not read them; "
-                                   "roofline.dense is the same frame with every row streamed (the K1 GEMV the north-star names)"}
+                                   "roofline.dense is the same frame with every row streamed (the K1 GEMV the north-star names): there SURVEY 8(d)'s "
+                                   "bytes really move, and that is the figure to hold against the HBM roofline; traffic = HBM bytes per launch from the "
+                                   "rocprofv3 --pmc passes of this command committed under profiles/ (counters cannot be read inside the process)"}
         if fused and sparse and not args.no_extras:
             # the dense K1 beside it: every codebook row streamed by the front kernel (horizontal fusion, MIDAS_DENSE_SCORES=1 form) -
             # what a caller with the heat-map on runs every frame (filter/filter.py:213-215); the survey model's bytes are real here
@@ -751,6 +837,7 @@ def main():
             out["config"]["c1"] = guarded(config1_rates, dev)
             out["config"]["c3_single_gpu"] = guarded(big_config_rates, dev, "c3")
             out["config"]["c4_single_gpu"] = guarded(big_config_rates, dev, "c4")
+            out["config"]["sharded_one_gpu"] = guarded(sharded_one_gpu)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cb, traj, N)
         if not sharded and not args.eager and args.resample == "weighted_random":

@@ -232,6 +232,7 @@ def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str
                                  "host_enqueue": float(np.average(motion_time)) if motion_time else 0.0}
     filter_stats["frames"] = records
     filter_stats["frame_idx"] = frame_idx
+    filter_stats["host_time"] = motion_time  # seconds the host spent on each iteration (enqueueing; waiting too when somebody looks at every frame)
     if results_path is not None:
         save_filter_stats(filter_stats, results_path)
     return filter_stats

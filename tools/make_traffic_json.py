@@ -15,7 +15,7 @@ for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=T
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 GROUPS = {"k_frame_front<float, 8, 2,": "frame_front", "k_frame_front<float, 8, 1,": "frame_front", "k_frame_front<float, 8, 0,": "frame_front_plain",
-          "8, true>": "frame_front", "8, false>": "frame_front_plain", "k_tail_a2": "tail_a", "k_tail_b2": "tail_b", "k_score_reg<float, 8, 0>": "score_codebook",
+          "8, true>": "frame_front", "8, false>": "frame_front_plain", "k_tail_a3": "tail_a", "k_tail_a2": "tail_a", "k_tail_b2": "tail_b", "k_score_reg<float, 8, 0>": "score_codebook",
           "k_particle_update": "particle_update", "k_tail_a(": "tail_a_legacy", "k_tail_b(": "tail_b_legacy"}
 res = {}
 for kname, cs in acc.items():
