@@ -741,13 +741,7 @@ MD bool nn6_hint_scan_screened(const TreeView<Kd6>& tv, const float* q, int32_t&
 // (c5: 353 -> 376 us per batch frame with the screen, c2's front 32.2 -> 30.8 us).
 // Scans records [0, NN_SOLO) of entry h's list (record 0 = the entry itself); the first batch is fetched
 // together with the entry so that r = |q - F_h| costs no round trip of its own.
-// MIDAS_NN_HOPS > 0: a lane whose first batch holds an entry closer than the hinted one (and no certificate yet) starts
-// over from THAT entry's list, up to MIDAS_NN_HOPS times - the certificate's radius is |q - pivot| + best, so a closer
-// pivot needs fewer records (the answer is the exact nearest entry whatever the pivot); `h` returns the pivot the
-// cooperative continuation must go on with.
-#ifndef MIDAS_NN_HOPS
-#define MIDAS_NN_HOPS 0
-#endif
+// (measured and dropped: a greedy hop to a closer entry's list - no effect, hints are rarely stale)
 MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t& h, float& best, int64_t& bi, int* n_scanned,
                       float* r_out = nullptr) {
     const Nbr6* nb = tv.nbrs + (size_t)h * NBR_REC;
@@ -755,7 +749,6 @@ MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t& h, float
     int scanned = 0;
     int b32 = h;  // record 0 overwrites the incoming candidate; list indices are int32
     bool certified = false;
-    int hops = 0;
     int32_t tw = tv.twin[h];  // pivot switch across the angle-pi cut (see nn6_hint_scan_screened); once
 #pragma unroll 1
     for (int s0 = 0; s0 < NN_SOLO && !certified; s0 += NN_BATCH) {
@@ -766,12 +759,6 @@ MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t& h, float
             nb = tv.nbrs + (size_t)h * NBR_REC;
             s0 = 0;
             scanned = 0;
-        }
-        if (MIDAS_NN_HOPS > 0 && s0 == NN_BATCH && hops < MIDAS_NN_HOPS && b32 != h) {  // a closer pivot: its list from the start
-            h = b32;
-            nb = tv.nbrs + (size_t)h * NBR_REC;
-            s0 = 0;
-            ++hops;
         }
         Nbr6 e[NN_BATCH];
 #pragma unroll
@@ -907,12 +894,7 @@ MD void row_best(float& d, int& i) {
 #ifndef MIDAS_COOP_CHUNK
 #define MIDAS_COOP_CHUNK 64
 #endif
-#ifndef MIDAS_COOP_LDS
-#define MIDAS_COOP_LDS 0  // measured: no change on c5 (305 against 304 us) - the scalar steps run beside other waves' vector work
-#endif
-#ifndef MIDAS_COOP_PIECES
-#define MIDAS_COOP_PIECES 0
-#endif
+// (measured and dropped: piece-contiguous fetches of the group, DESIGN.md notebook "MIDAS_COOP_PIECES")
 constexpr int COOP_G = MIDAS_COOP_G, COOP_L = 64 / COOP_G, COOP_CHUNK = MIDAS_COOP_CHUNK, COOP_STEPS = COOP_CHUNK / COOP_L;
 static_assert(COOP_G == 4 || COOP_G == 8 || COOP_G == 16, "owners per pass");
 static_assert(COOP_STEPS >= 1 && COOP_STEPS * COOP_L == COOP_CHUNK, "a chunk is whole steps of the group");
@@ -934,7 +916,7 @@ MD void group_best(float& d, int& i) {
 
 template <bool SCREEN = false>
 MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_lane, float& best, int64_t& bi, bool need,
-                 bool& done, int* own_lds = nullptr) {
+                 bool& done) {
     const int lane = threadIdx.x & 63, grp = lane / COOP_L, j = lane % COOP_L;
     int nrec = NN_SOLO;  // next record of this lane's list (owners only)
     // pass after pass: every open owner gets its next 64 records, COOP_G owners per instruction stream
@@ -943,29 +925,14 @@ MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_
         unsigned long long todo = __ballot(open_lane);
         if (!todo) break;
         const int my_rank = (int)__builtin_popcountll(todo & ((1ull << lane) - 1ull));  // rank among this pass's owners
-        const int n_own = (int)__builtin_popcountll(todo);
-        // own_lds (64 ints of the wave's LDS): the owners' lane numbers in rank order, written once per round, so a pass
-        // reads its group's owner with one LDS load instead of COOP_G scalar find-first-set / clear steps
-        if (MIDAS_COOP_LDS && own_lds) {
-            if (open_lane) own_lds[my_rank] = lane;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
         int served = 0;
-        while ((MIDAS_COOP_LDS && own_lds) ? served < n_own : todo != 0) {
+        while (todo != 0) {
             int mine = -1;
-            if (MIDAS_COOP_LDS && own_lds) {
-                const int slot = served + grp;
-                const int v = own_lds[slot < 63 ? slot : 63];
-                mine = slot < n_own ? v : -1;
-            } else {
 #pragma unroll
-                for (int k = 0; k < COOP_G; ++k) {
-                    const int o = todo ? (int)__builtin_ctzll(todo) : -1;
-                    todo &= todo - 1;  // 0 & anything stays 0
-                    mine = grp == k ? o : mine;
-                }
+            for (int k = 0; k < COOP_G; ++k) {  // (the owners' lane numbers through LDS instead of these scalar steps: no change, dropped)
+                const int o = todo ? (int)__builtin_ctzll(todo) : -1;
+                todo &= todo - 1;  // 0 & anything stays 0
+                mine = grp == k ? o : mine;
             }
             const int src = mine >= 0 ? mine : lane;
             float qq[6];
@@ -1025,36 +992,6 @@ MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_
                 take(pick<COOP_STEPS>(P, k), nb4[2 * pick<COOP_STEPS>(sc, k) + 1], true);
             }
             rho_last = hl.w;  // of this lane's last record: the group's last lane holds the chunk's last (when the chunk is whole)
-            } else if (MIDAS_COOP_PIECES) {
-            // piece-contiguous fetch: the 2 COOP_L 16-byte pieces of a step's COOP_L records are read by the group as two
-            // runs of COOP_L consecutive pieces (lane j: pieces j and COOP_L + j), so a load instruction touches each line
-            // once and whole; lane pairs then swap one piece: the even lane keeps record j/2 of the step's first half (its
-            // own first piece + the neighbour's), the odd lane record j/2 of the second half.  Same records, same
-            // distances, same (distance, index) minimum - only which lane evaluates which record changes.
-            const float4* __restrict__ nb4 = reinterpret_cast<const float4*>(tv.nbrs + (size_t)hh * NBR_REC);
-            const int odd = j & 1;
-            float4 pa[COOP_STEPS], pb[COOP_STEPS];
-#pragma unroll
-            for (int m = 0; m < COOP_STEPS; ++m) {
-                const int ra = first + COOP_L * m + (j >> 1), rb = ra + COOP_L / 2;
-                pa[m] = nb4[2 * (ra <= NBR_M ? ra : NBR_M) + odd];
-                pb[m] = nb4[2 * (rb <= NBR_M ? rb : NBR_M) + odd];
-            }
-#pragma unroll
-            for (int m = 0; m < COOP_STEPS; ++m) {
-                const float4 give = odd ? pa[m] : pb[m];
-                float4 got;
-                got.x = __uint_as_float(dpp_u32<DPP_XOR1>(__float_as_uint(give.x)));
-                got.y = __uint_as_float(dpp_u32<DPP_XOR1>(__float_as_uint(give.y)));
-                got.z = __uint_as_float(dpp_u32<DPP_XOR1>(__float_as_uint(give.z)));
-                got.w = __uint_as_float(dpp_u32<DPP_XOR1>(__float_as_uint(give.w)));
-                const float4 lo = odd ? got : pa[m], hi = odd ? pb[m] : got;
-                const float dm = full_from(qq, part4(qq, lo), hi);  // == dist2(qq, record), bit for bit
-                const int im = __float_as_int(hi.z);
-                const bool in = first + COOP_L * m + (j >> 1) + (odd ? COOP_L / 2 : 0) <= NBR_M;
-                if (in && (dm < d || (dm == d && im < id))) { d = dm; id = im; }  // NaN never wins
-                rho_last = in ? hi.w : rho_last;
-            }
             } else {
             const Nbr6* nb = tv.nbrs + (size_t)hh * NBR_REC;
             Nbr6 e[COOP_STEPS];
@@ -1335,7 +1272,7 @@ MD bool nn6_wave(const TreeView<Kd6>& tv, const float* q, bool live, int32_t hin
         done = SCREEN ? nn6_hint_scan_screened(tv, q, hint, best, bi, n_scanned, &r_lane)
                       : nn6_hint_scan(tv, q, hint, best, bi, n_scanned, &r_lane);
     if (t_solo) *t_solo = clock64();
-    nn6_coop<SCREEN>(tv, q, hint, r_lane, best, bi, hinted && !done, done, reinterpret_cast<int*>(cd));  // the rest, whole wave per lane
+    nn6_coop<SCREEN>(tv, q, hint, r_lane, best, bi, hinted && !done, done);  // the rest, whole wave per lane
     wave_search<Kd6, false, STATS>(tv, q, best, bi, !done, cd, n_leaves, n_nodes);
     idx = (int32_t)bi;
     d2 = best;
@@ -1983,19 +1920,10 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
 #undef MIDAS_TICK
 }
 
-#ifndef MIDAS_XCD_TRAJ
-#define MIDAS_XCD_TRAJ 0  // measured: 371 against 319 us per c5 batch frame with the affinity
-#endif
 template <bool STATS>
 __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a) {
     __shared__ double s_cd[KD_MAX_LEVELS * 64];  // child-distance columns, reused by both searches
-    unsigned bx = blockIdx.x, by = blockIdx.y;
-    if (MIDAS_XCD_TRAJ && gridDim.y > 1 && (gridDim.y & 7u) == 0) {  // XCD c serves the trajectories c mod 8 (see k_frame_front)
-        const unsigned L = by * gridDim.x + bx, c = L & 7u, s = L >> 3;
-        by = c + 8u * (s / gridDim.x);
-        bx = s % gridDim.x;
-    }
-    particle_update_wave<false, false, false, STATS>(t6, t3, a, bx, gridDim.x, by, s_cd);
+    particle_update_wave<false, false, false, STATS>(t6, t3, a, blockIdx.x, gridDim.x, blockIdx.y, s_cd);
 }
 
 // Front kernel of the fused single-trajectory step: the particle update (latency-bound: dependent scattered
@@ -2028,16 +1956,9 @@ __global__ __launch_bounds__(64 * FW, (!SCR && FW == 1) ? MIDAS_BATCH_OCC : 1) v
     __shared__ double s_cd[FW][KD_MAX_LEVELS * 64];
     __shared__ alignas(16) double s_rs[LAZY == 1 ? LAZY_WG_LDS : LAZY == 2 ? FW * LAZY_WAVE_LDS : 8];
     const int w = threadIdx.x >> 6;
-    // A batch of trajectories (grid.y): workgroups go to the eight XCDs round robin by linear id, so with the plain
-    // (x = wave, y = trajectory) reading every XCD's L2 holds the neighbour and vertex lists of ALL trajectories.  Read
-    // instead as: XCD c serves the trajectories t = c mod 8 - its L2 then only sees an eighth of the batch's lists
-    // (placement is a matter of speed only: any (trajectory, wave) pair is served exactly once either way).
-    unsigned bx = blockIdx.x, by = blockIdx.y;
-    if (MIDAS_XCD_TRAJ && !SCR && gridDim.y > 1 && (gridDim.y & 7u) == 0 && n_pu == (int)gridDim.x) {
-        const unsigned L = by * gridDim.x + bx, c = L & 7u, s = L >> 3;
-        by = c + 8u * (s / gridDim.x);
-        bx = s % gridDim.x;
-    }
+    // (a batch's trajectories bound to XCDs - XCD c serving the trajectories c mod 8 so that its L2 sees an eighth of the batch's
+    // lists - was measured and dropped: 371 against 319 us per c5 batch frame)
+    const unsigned bx = blockIdx.x, by = blockIdx.y;
     if ((int)bx < n_pu) {
         if (LAZY == 1) lazy_tables(a.rs, s_rs);
         const int64_t wave = (int64_t)bx * FW + w;

@@ -123,7 +123,7 @@ constexpr int MF_ROWS_PER_WAVE = 16;
 #endif
 constexpr int MF_WAVES = MIDAS_MF_WAVES;   // waves per workgroup: three slots on each of the CU's four SIMDs (170 registers a wave); 16: a fourth slot for the tile-units
 constexpr int MF_CODES = 64;   // codes per pass (4 N-tiles)
-constexpr int MF_PAD = 4;      // floats of padding per staged code row (bank spread)
+
 #ifndef MIDAS_MF_PF
 #define MIDAS_MF_PF 4
 #endif
@@ -170,6 +170,9 @@ __global__ __launch_bounds__(256) void k_codes_prepare(const double* __restrict_
 #ifndef MIDAS_MF_DBG
 #define MIDAS_MF_DBG 0  // profiling builds only (tools/ab_score.sh): 1 no row fetches, 2 no LDS reads, 4 no epilogue, 8 fetch-shape probe - wrong scores
 #endif
+// staged piece idx = (t nc + c) 64 + 16 g + i (see k_score_mfma): the code and the first column it holds
+MD int mf_code_of(int idx, int nc) { return 16 * ((idx >> 6) / nc) + (idx & 15); }
+MD int mf_d_of(int idx, int nc) { return 16 * ((idx >> 6) % nc) + 4 * ((idx >> 4) & 3); }
 template <int NT, bool CODES_LDS>
 struct MfUnit {
     f32x4 acc[NT];
@@ -213,6 +216,7 @@ struct MfUnit {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             if (MIDAS_MF_DBG & 2) { float v = (float)(cc + t); asm volatile("" : "+v"(v)); e[t] = make_float4(v, v, v, v); }
+            else if (CODES_LDS) e[t] = *reinterpret_cast<const float4*>(eb + (t * nc + cc) * 256);  // (operand order: see k_score_mfma's staging)
             else e[t] = *reinterpret_cast<const float4*>(eb + 16 * t * ld + 16 * cc);
         }
     }
@@ -228,7 +232,7 @@ struct MfUnit {
     }
     MD void run(const float* __restrict__ codes, int ld) {
         const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
-        const float* eb = codes + (16 * t0 + i) * ld + 4 * g;
+        const float* eb = CODES_LDS ? codes + (t0 * nc * 64 + lane) * 4 : codes + (16 * t0 + i) * ld + 4 * g;
         int c0 = 0;
         // Whole rounds of 2 MF_PF steps, straight-line code (a condition around a step makes the compiler's wait counting give
         // up at the merge: s_waitcnt vmcnt(0) once per round).  The row pieces travel MF_PF .. 2 MF_PF steps ahead of the
@@ -336,10 +340,15 @@ template <bool CODES_LDS>
 __global__ __launch_bounds__(64 * MF_WAVES) void k_score_mfma(const float* __restrict__ emb, const double* __restrict__ norms,
                                                      const float* __restrict__ codes32, const double* __restrict__ code_norms,
                                                      double* __restrict__ out, int64_t K, int D, int B, int b0) {
-    extern __shared__ __attribute__((aligned(16))) float s_e[];  // [MF_CODES][D + MF_PAD]
+    // The 64 codes in LDS in the ORDER THE OPERAND READS TAKE THEM: sixteen-byte piece ((t nc + c) 64 + 16 g + i) = code 16 t + i,
+    // columns 16 c + 4 g .. + 3 (t: N-tile, c: step of 16 columns, lane (g, i) of the wave) - a step's operand read of one N-tile is
+    // 64 consecutive pieces, lane l the l-th: no bank is asked twice (rows of D + 4 floats put lanes (g, i) and (g + 1, i - 1) on one
+    // bank: 1.65 M conflict cycles against 3.56 M LDS cycles per launch, profiles/r04_d_pmc_score_mfma.txt), and the staging store of
+    // piece idx goes to piece idx - conflict-free as well.
+    extern __shared__ __attribute__((aligned(16))) float s_e[];  // [4 N-tiles][D / 16 steps][64 lanes] x 4 floats
     const int wave = threadIdx.x >> 6;
     const int nb = B - b0 < MF_CODES ? B - b0 : MF_CODES;  // codes of this pass
-    const int ld = CODES_LDS ? D + MF_PAD : D;
+    const int ld = D;
     const float* eb = CODES_LDS ? s_e : codes32 + (int64_t)b0 * D;
     // ---- the schedule (see above): this wave = slot `slot` of SIMD `simd` ----
     constexpr int SL = MF_WAVES / 4;
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(64 * MF_WAVES) void k_score_mfma(const float* __res
     const int64_t Q = 4 * (G - Gw);
     MF_STAMP(0);
     float4 stage[CODES_LDS ? 11 : 1];
-    const int q4 = D / 4, total = MF_CODES * q4;
+    const int q4 = D / 4, total = MF_CODES * q4, ncq = D / 16;
     constexpr int NT_ = 64 * MF_WAVES;
     if (CODES_LDS) {
         // The 64 codes (padded with zero rows by k_codes_prepare) are requested FIRST: loads come back in order, so the first
@@ -363,7 +372,7 @@ __global__ __launch_bounds__(64 * MF_WAVES) void k_score_mfma(const float* __res
         for (int k = 0; k < 11; ++k) {
             const int idx = k * NT_ + (int)threadIdx.x;
             const int ic = idx < total ? idx : total - 1;
-            const int b = ic / q4, d = (ic - b * q4) * 4;
+            const int b = mf_code_of(ic, ncq), d = mf_d_of(ic, ncq);
             stage[k] = *reinterpret_cast<const float4*>(&codes32[(int64_t)(b0 + b) * D + d]);
         }
     }
@@ -371,17 +380,14 @@ __global__ __launch_bounds__(64 * MF_WAVES) void k_score_mfma(const float* __res
     const bool first4 = slot < rounds;
     if (first4) u4.begin(emb, norms, code_norms, K, D, b0, nb, ((int64_t)slot * S + simd) * MF_ROWS_PER_WAVE, 0);
     if (CODES_LDS) {
-        float4* s4 = reinterpret_cast<float4*>(s_e);  // rows of ld / 4 sixteen-byte pieces (D and the pad are multiples of 4)
-        const int ldq = ld >> 2;
+        float4* s4 = reinterpret_cast<float4*>(s_e);
 #pragma unroll
         for (int k = 0; k < 11; ++k)  // (pinned here: the compiler otherwise sinks each load into its store's condition)
             asm volatile("" : "+v"(stage[k].x), "+v"(stage[k].y), "+v"(stage[k].z), "+v"(stage[k].w));
 #pragma unroll
         for (int k = 0; k < 11; ++k) {
             const int idx = k * NT_ + (int)threadIdx.x;
-            const int ic = idx < total ? idx : total - 1;
-            const int b = ic / q4, dq = ic - b * q4;
-            if (idx < total) s4[b * ldq + dq] = stage[k];
+            if (idx < total) s4[idx] = stage[k];
         }
         for (int base = 11 * NT_; base < total; base += 6 * NT_) {  // D > 528: the rest, six pieces a round
             float4 v[6];
@@ -389,7 +395,7 @@ __global__ __launch_bounds__(64 * MF_WAVES) void k_score_mfma(const float* __res
             for (int k = 0; k < 6; ++k) {
                 const int idx = base + k * NT_ + (int)threadIdx.x;
                 const int ic = idx < total ? idx : total - 1;
-                const int b = ic / q4, d = (ic - b * q4) * 4;
+                const int b = mf_code_of(ic, ncq), d = mf_d_of(ic, ncq);
                 v[k] = *reinterpret_cast<const float4*>(&codes32[(int64_t)(b0 + b) * D + d]);
             }
 #pragma unroll
@@ -397,9 +403,7 @@ __global__ __launch_bounds__(64 * MF_WAVES) void k_score_mfma(const float* __res
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 const int idx = base + k * NT_ + (int)threadIdx.x;
-                const int ic = idx < total ? idx : total - 1;
-                const int b = ic / q4, dq = ic - b * q4;
-                if (idx < total) s4[b * ldq + dq] = v[k];
+                if (idx < total) s4[idx] = v[k];
             }
         }
         // the barrier orders the LDS writes only: __syncthreads() would also drain the wave's loads (s_waitcnt vmcnt(0) in front of
@@ -431,10 +435,10 @@ int launch_score_batch(midas_ctx* ctx, const midas_codebook* cb, int32_t B, cons
     if (cb->dtype != MIDAS_F32 || cb->D % 16 != 0 || (uintptr_t)cb->emb % 16 != 0)
         return midas_set_error(ctx, MIDAS_ERR_INVALID, "midas_score_batch", "needs float32 embeddings with D % 16 == 0");
     const int D = cb->D;
-    // the 64 staged codes fit the CU's 160 KB of LDS up to D = 636; beyond (D = 1024) the waves read the float32 code rows from
+    // the 64 staged codes fit the CU's 160 KB of LDS up to D = 640; beyond (D = 1024) the waves read the float32 code rows from
     // memory (256 KB: cache-resident) - the same arithmetic, slower
-    const bool codes_lds = (size_t)MF_CODES * (D + MF_PAD) * sizeof(float) <= 160 * 1024;
-    const size_t lds = codes_lds ? (size_t)MF_CODES * (D + MF_PAD) * sizeof(float) : 0;
+    const bool codes_lds = (size_t)MF_CODES * D * sizeof(float) <= 160 * 1024;
+    const size_t lds = codes_lds ? (size_t)MF_CODES * D * sizeof(float) : 0;
     const int Bpad = (int)ceil_div(B, MF_CODES) * MF_CODES;
     void *cn, *c32;
     int rc = midas_scratch(ctx, (size_t)B * sizeof(double), &cn);
