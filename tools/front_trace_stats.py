@@ -8,7 +8,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 steps = int(sys.argv[2])
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 out = {}
-for pat, key in (("k_frame_front<float, 8, 2,", "frame_front_pipelined"), ("k_tail_a2d", "tail_a2d")):
+for pat, key in (("k_frame_front<float, 8, 2,", "frame_front_pipelined"), ("k_tail_a3", "tail_a3"), ("k_tail_a2d", "tail_a2d")):
     d = np.array([(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if pat in r["Kernel_Name"]])
     if len(d) == 0:
         continue
