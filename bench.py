@@ -218,33 +218,39 @@ def config5_rate(dev, frames=60, repeats=3):
         out[init] = {"us_per_batch_frame": us, "us_per_batch_frame_runs": spread(uss), "trajectory_steps_per_sec": B * 1e6 / us}
         if init == "near":
             near_start = start
-    # the same batch frame with ALL K rows scored for all 64 codes on the matrix cores (k_score_mfma: the B x K x D contraction the
+    # the batch frame with ALL K rows scored for all 64 codes on the matrix cores (k_score_mfma: the B x K x D contraction the
     # north-star names, on a side stream beside the particle update; a caller who wants every trajectory's heat-map every frame -
-    # filter/live_demo.py:104-109): 3.28 GFLOP and 128 MB per batch frame on top of the particle work
-    was = os.environ.get("MIDAS_DENSE_SCORES")
-    os.environ["MIDAS_DENSE_SCORES"] = "1"
+    # filter/live_demo.py:104-109): 3.28 GFLOP and 128 MB per batch frame on top of the particle work.  The eager batch engine
+    # (three launches per batch frame: the pipelined one needs the sparse scores)
     try:
-        engd = PipelinedBatchFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, B, N, device=dev)
-    finally:
-        if was is None:
-            del os.environ["MIDAS_DENSE_SCORES"]
-        else:
-            os.environ["MIDAS_DENSE_SCORES"] = was
-    uss = []
-    for rep in range(repeats):
-        engd.set_particles(torch.as_tensor(near_start))
-        engd.project_to_codebook()
-        for i in range(10):
-            engd.step(od[1 + i % 38], co[1 + i % 38])
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(frames):
-            engd.step(od[1 + (10 + i) % 38], co[1 + (10 + i) % 38])
-        torch.cuda.synchronize()
-        uss.append((time.perf_counter() - t0) / frames * 1e6)
-    us = sorted(uss)[len(uss) // 2]
-    out["near_dense_mfma"] = {"us_per_batch_frame": us, "us_per_batch_frame_runs": spread(uss), "trajectory_steps_per_sec": B * 1e6 / us,
-                              "scoring": "dense: midas_score_batch (k_score_mfma, f32 MFMA 16x16x4) over all K rows for the 64 codes every batch frame, sparse scoring off"}
+        from midastouch_amd.engine import BatchFilterEngine
+        was = os.environ.get("MIDAS_DENSE_SCORES")
+        os.environ["MIDAS_DENSE_SCORES"] = "1"
+        try:
+            engd = BatchFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, B, N, device=dev)
+        finally:
+            if was is None:
+                del os.environ["MIDAS_DENSE_SCORES"]
+            else:
+                os.environ["MIDAS_DENSE_SCORES"] = was
+        uss = []
+        for rep in range(repeats):
+            engd.set_particles(torch.as_tensor(near_start))
+            engd.project_to_codebook()
+            for i in range(10):
+                engd.step(od[1 + i % 38], co[1 + i % 38])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(frames):
+                engd.step(od[1 + (10 + i) % 38], co[1 + (10 + i) % 38])
+            torch.cuda.synchronize()
+            uss.append((time.perf_counter() - t0) / frames * 1e6)
+        us = sorted(uss)[len(uss) // 2]
+        out["near_dense_mfma"] = {"us_per_batch_frame": us, "us_per_batch_frame_runs": spread(uss), "trajectory_steps_per_sec": B * 1e6 / us,
+                                  "engine": "BatchFilterEngine (eager: the resampled sets are materialised every frame)",
+                                  "scoring": "dense: midas_score_batch (k_score_mfma, f32 MFMA 16x16x4) over all K rows for the 64 codes every batch frame, sparse scoring off"}
+    except Exception as e:  # noqa: BLE001
+        out["near_dense_mfma"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 

@@ -149,12 +149,6 @@ MIDAS_EXPORT int midas_ctx_create(int device, void* hip_stream, midas_ctx** out)
             (void)hipGetLastError();
         }
     }
-    {
-        void* p = nullptr;
-        const size_t bytes = (size_t)midas::CLAIM_MAX_WAVES * (1 + midas::CLAIM_Q) * sizeof(unsigned long long);
-        if (hipMalloc(&p, bytes) == hipSuccess && hipMemset(p, 0, bytes) == hipSuccess) ctx->claim_buf = (unsigned long long*)p;
-        else { if (p) (void)hipFree(p); (void)hipGetLastError(); }
-    }
     *out = ctx;
     return MIDAS_OK;
 }
@@ -192,7 +186,6 @@ MIDAS_EXPORT int midas_ctx_destroy(midas_ctx* ctx) {
     for (auto& c : s->chunks) (void)hipFree(c.p);
     delete s;
     if (ctx->tail_rec) (void)hipFree(ctx->tail_rec);
-    if (ctx->claim_buf) (void)hipFree(ctx->claim_buf);
     if (ctx->ev_ready)
         for (auto& e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

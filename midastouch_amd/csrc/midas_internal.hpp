@@ -96,9 +96,6 @@ struct midas_ctx {
     unsigned long long* tail_rec = nullptr;
     int tail_rec_blocks = 0;
     uint32_t tail_tag = 0;
-    // claim hand-over buffers of the front kernel (SparseScore::claim_pub / claim_rows), tagged per launch like the records above
-    unsigned long long* claim_buf = nullptr;   // [CLAIM_MAX_WAVES x (1 + CLAIM_Q)]
-    uint32_t claim_tag = 0;
 };
 
 struct midas_codebook {
@@ -268,19 +265,7 @@ struct SparseScore {
     // a wide start); the particle waves then only mark the rows they use (for the next frame's list) and score nothing
     int32_t dense_thr = 0;
     int64_t K = 0;
-    // claim hand-over (single-trajectory front with streaming waves, fixed particle count; score_body.hpp hand_over_claims): a
-    // particle wave that is the first of the frame on up to CLAIM_Q rows does not score them itself - the kernel would end with
-    // such waves - but leaves them in its own segment of claim_rows and publishes the count in claim_pub[wave]; the first
-    // claim_scorers streaming waves of the launch pick them up (drain_claims).  Entries are {value | launch tag << 32}.
-    unsigned long long* claim_pub = nullptr;   // [nwaves]
-    unsigned long long* claim_rows = nullptr;  // [nwaves x CLAIM_Q]
-    uint32_t claim_tag = 0;
-    int32_t claim_scorers = 0;
-    int32_t* claim_status = nullptr;           // |= 16 when a particle wave's count did not arrive within the bound
 };
-constexpr int CLAIM_Q = 8;            // rows a particle wave may hand over (more: it scores them itself, as without the hand-over)
-constexpr int CLAIM_WAVES = 16;       // particle waves a scorer wave looks after
-constexpr int CLAIM_MAX_WAVES = 16384;  // capacity of the context's hand-over buffers: 2^20 particles
 // what the tail kernel needs to build the next frame's list: rows whose stamp is `epoch` (claimed or confirmed in this
 // frame) are appended to `list` and re-stamped epoch + 1, the next frame's pred_tag (its epoch is epoch + 2)
 struct ScorePredict {

@@ -1834,12 +1834,9 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
         for (int j = 0; j < (PRE ? 1 + MESH_BATCH : 1); ++j) pre[j] = vs[j];
     }
     RowClaim claim{false, 0u};
-    const int hand_wave = a.sp.claim_pub && traj == 0 ? (int)wave : -1;  // claim hand-over to the launch's scorer waves (SparseScore::claim_pub)
     if (a.sp.stamps && !(ablate & 16)) {  // ablate 16 (profiling): nobody scores
         claim = claim_rows_issue(a.sp, live, bi, MIDAS_CLAIM_HASH ? reinterpret_cast<int*>(s_cd) : nullptr);
-        if (!MIDAS_CLAIM_DEFER) st_rows = score_claimed_rows_nj(a.sp, claim, bi, dense_scores, hand_wave);
-    } else if (hand_wave >= 0 && lane == 0) {
-        claim_store(a.sp.claim_pub + hand_wave, 0u, a.sp.claim_tag);  // (a scorer waits for every wave's count)
+        if (!MIDAS_CLAIM_DEFER) st_rows = score_claimed_rows_nj(a.sp, claim, bi, dense_scores);
     }
     MIDAS_TICK(9);
     // prune: valid <=> some mesh vertex within sqrt(t2) of the particle
@@ -1870,7 +1867,7 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
         if (lane == 0 && m) atomicAdd(&a.telemetry[1], (unsigned long long)__popcll(m));
     }
     if (mv >= 0) ok = mv == 1;
-    if (MIDAS_CLAIM_DEFER && a.sp.stamps && !(ablate & 16)) st_rows = score_claimed_rows_nj(a.sp, claim, bi, dense_scores, hand_wave);
+    if (MIDAS_CLAIM_DEFER && a.sp.stamps && !(ablate & 16)) st_rows = score_claimed_rows_nj(a.sp, claim, bi, dense_scores);
     if (a.telemetry && st_rows && lane == 0) atomicAdd(&a.telemetry[2], (unsigned long long)st_rows);  // rows scored by particle waves
     MIDAS_TICK(6);
     if (live) {
@@ -1978,9 +1975,7 @@ __global__ __launch_bounds__(64 * FW, (!SCR && FW == 1) ? MIDAS_BATCH_OCC : 1) v
             if (a.sp.dense_thr > 0 && c > a.sp.dense_thr) atomicAdd(&a.telemetry[3], (unsigned long long)a.sp.K);  // all of them
             else if (c > 0) atomicAdd(&a.telemetry[3], (unsigned long long)(c < a.sp.list_cap ? c : a.sp.list_cap));
         }
-        const int sw = (int)(bx - n_pu) * FW + w;
-        score_list_wave<NJ>(a.sp, sw, ((int)gridDim.x - n_pu) * FW);
-        if (a.sp.claim_pub && sw < a.sp.claim_scorers) drain_claims<NJ>(a.sp, sw, nwaves, reinterpret_cast<int*>(s_cd[w]));
+        score_list_wave<NJ>(a.sp, (int)(bx - n_pu) * FW + w, ((int)gridDim.x - n_pu) * FW);
     } else {
         score_wave<T, NJ, 0>(emb, norms, code, scores, K, (int64_t)(bx - n_pu) * FW + w);
     }
@@ -2749,19 +2744,6 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
         if (rc) return rc;
     }
     const unsigned grid_fw = (unsigned)(n_pu_fw + (a.sp.stamps ? (use_list ? (list_wgs_env + fw - 1) / fw : 0) : ceil_div(cb->K, 4 * fw)));
-    // claim hand-over (SparseScore::claim_pub): one-wave particle workgroups beside streaming waves, fixed particle count
-    {
-        const char* ho = getenv("MIDAS_CLAIM_HANDOVER");  // 0: every wave scores the rows it is first on itself (read per launch: the tests compare both)
-        const int scorers = (int)ceil_div(nwaves, CLAIM_WAVES);
-        if (use_list && fw == 1 && a.batch <= 1 && !a.n_live && ctx->claim_buf && nwaves <= CLAIM_MAX_WAVES && scorers <= list_wgs_env && !(ho && ho[0] == '0')) {
-            a.sp.claim_pub = ctx->claim_buf;
-            a.sp.claim_rows = ctx->claim_buf + CLAIM_MAX_WAVES;
-            if (++ctx->claim_tag == 0) ctx->claim_tag = 1;
-            a.sp.claim_tag = ctx->claim_tag;
-            a.sp.claim_scorers = scorers;
-            a.sp.claim_status = a.status_reset;
-        }
-    }
     // profiling instantiations (MIDAS_ABLATE != 0; D = 512, one-wave workgroups): phase clocks, scan statistics, ablation switches
     if (a.ablate && cb->D == 512 && fw == 1) {
         bool done = true;

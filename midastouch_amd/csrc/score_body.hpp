@@ -157,21 +157,11 @@ MD void score_rows4(const SparseScore& sp, int32_t mine) {
 // the frame's scoring mode (uniform; see SparseScore::dense_thr): read early by the particle waves, it is a round trip
 MD bool scores_dense(const SparseScore& sp) { return sp.list != nullptr && sp.dense_thr > 0 && *sp.list_count > sp.dense_thr; }
 
-// agent-scope 8-byte store / load (past the non-coherent caches: the scorer waves run on other CUs of the same launch)
-MD void claim_store(unsigned long long* p, uint32_t v, uint32_t tag) {
-    __hip_atomic_store(p, (unsigned long long)v | ((unsigned long long)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-MD unsigned long long claim_load(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// wave_id >= 0 with sp.claim_pub set: the claimed rows (up to CLAIM_Q) are handed to the launch's scorer waves instead of being
-// scored here, and the wave's count is published whatever it is (a scorer waits for every wave it looks after)
 template <int NJ>
-MD int score_claimed_rows(const SparseScore& sp, const RowClaim& c, int32_t row, bool dense = false, int wave_id = -1) {  // returns the rows this wave claimed
+MD int score_claimed_rows(const SparseScore& sp, const RowClaim& c, int32_t row, bool dense = false) {  // returns the rows this wave scored
     const int lane = threadIdx.x & 63, qd = lane >> 4;
-    const bool hand = wave_id >= 0 && sp.claim_pub != nullptr;
     if (dense) {  // every row is being scored by the streaming waves: mark the rows in use, claim nothing
         if (c.leader && c.old != sp.epoch) sp.stamps[row] = sp.epoch;
-        if (hand && lane == 0) claim_store(sp.claim_pub + wave_id, 0u, sp.claim_tag);
         return 0;
     }
     // (after the first waves of a frame nearly every needed row carries the epoch already)
@@ -191,12 +181,6 @@ MD int score_claimed_rows(const SparseScore& sp, const RowClaim& c, int32_t row,
 #endif
     unsigned long long m = __ballot(claim);
     const int nrows = (int)__builtin_popcountll(m);
-    if (hand) {
-        const bool over = nrows > CLAIM_Q;
-        if (!over && claim) claim_store(sp.claim_rows + (size_t)wave_id * CLAIM_Q + __builtin_popcountll(m & ((1ull << lane) - 1ull)), (uint32_t)row, sp.claim_tag);
-        if (lane == 0) claim_store(sp.claim_pub + wave_id, over ? 0u : (uint32_t)nrows, sp.claim_tag);
-        if (!over) return nrows;
-    }
     while (m) {
         int32_t mine = -1;
 #pragma unroll
@@ -213,62 +197,12 @@ MD int score_claimed_rows(const SparseScore& sp, const RowClaim& c, int32_t row,
     return nrows;
 }
 
-MD int score_claimed_rows_nj(const SparseScore& sp, const RowClaim& c, int32_t row, bool dense = false, int wave_id = -1) {
+MD int score_claimed_rows_nj(const SparseScore& sp, const RowClaim& c, int32_t row, bool dense = false) {
     switch (sp.nj) {
-        case 8: return score_claimed_rows<8>(sp, c, row, dense, wave_id);
-        case 4: return score_claimed_rows<4>(sp, c, row, dense, wave_id);
-        case 2: return score_claimed_rows<2>(sp, c, row, dense, wave_id);
-        default: return score_claimed_rows<16>(sp, c, row, dense, wave_id);
-    }
-}
-
-// Scorer wave s of the launch (one of the first sp.claim_scorers streaming waves): looks after the particle waves
-// [CLAIM_WAVES s, CLAIM_WAVES (s + 1)) - waits for each one's published count (lanes 0 .. CLAIM_WAVES - 1 poll, a look every ~0.2 us),
-// fetches the rows of those that have reported (all 64 lanes: two entries each), packs them through LDS and scores them four at a
-// time in score_wave's layout - the same arithmetic, so the scores are the ones the particle waves would have written.
-// lds: CLAIM_WAVES x CLAIM_Q ints of the wave's own.  Bounded (0.2 s): a count that never arrives leaves bit 16 in the status.
-template <int NJ>
-MD void drain_claims(const SparseScore& sp, int s, int nwaves, int* lds) {
-    static_assert(CLAIM_WAVES * CLAIM_Q == 128, "two entries a lane");
-    const int lane = threadIdx.x & 63, qd = lane >> 4;
-    const int w = CLAIM_WAVES * s + lane;
-    bool pend = lane < CLAIM_WAVES && w < nwaves;
-    const long long t0 = wall_clock64();
-    while (__any(pend ? 1 : 0)) {
-        const unsigned long long v = pend ? claim_load(sp.claim_pub + w) : 0ull;
-        const bool ready = pend && (uint32_t)(v >> 32) == sp.claim_tag;
-        pend = pend && !ready;
-        const int n = ready ? (int)(uint32_t)v : 0;
-        if (__any(n > 0 ? 1 : 0)) {
-            // lane l: entries 2 (l & 3), 2 (l & 3) + 1 of particle wave CLAIM_WAVES s + (l >> 2)
-            const int nw = __shfl(n, lane >> 2), j0 = 2 * (lane & 3);
-            const unsigned long long* rp = sp.claim_rows + (size_t)(CLAIM_WAVES * s + (lane >> 2)) * CLAIM_Q + j0;
-            const bool h0 = j0 < nw, h1 = j0 + 1 < nw;
-            unsigned long long e0 = 0, e1 = 0;
-            for (int tries = 0; tries < 100000; ++tries) {  // (the rows were stored before the count, but nothing orders the two: look until they carry the tag)
-                e0 = h0 ? claim_load(rp) : 0ull;
-                e1 = h1 ? claim_load(rp + 1) : 0ull;
-                const bool ok = (!h0 || (uint32_t)(e0 >> 32) == sp.claim_tag) && (!h1 || (uint32_t)(e1 >> 32) == sp.claim_tag);
-                if (__all(ok ? 1 : 0)) break;
-            }
-            const int cnt = (h0 ? 1 : 0) + (h1 ? 1 : 0);
-            const int incl = wave_iscan_dpp(cnt), total = __builtin_amdgcn_readlane(incl, 63);
-            if (h0) lds[incl - cnt] = (int)(uint32_t)e0;
-            if (h1) lds[incl - cnt + 1] = (int)(uint32_t)e1;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int i = 0; i < total; i += 4) score_rows4<NJ>(sp, i + qd < total ? lds[i + qd] : -1);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        } else if (__any(pend ? 1 : 0)) {
-            __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t0 > 20000000ll) {
-                if (lane == 0 && sp.claim_status) atomicOr(sp.claim_status, 16);
-                break;
-            }
-        }
+        case 8: return score_claimed_rows<8>(sp, c, row, dense);
+        case 4: return score_claimed_rows<4>(sp, c, row, dense);
+        case 2: return score_claimed_rows<2>(sp, c, row, dense);
+        default: return score_claimed_rows<16>(sp, c, row, dense);
     }
 }
 
