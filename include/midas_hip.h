@@ -342,7 +342,10 @@ int midas_score_list_seed(midas_ctx* ctx, int64_t K, uint32_t* score_stamps_dev,
  * assignment, frame 1 the swapped one, ...) and folds the resample of the frame before it; rmse_log_dev (NULL or 3 T
  * doubles) receives every frame's {rmse_t, rmse_r, device wall clock in us at the end of the frame}.  The reference's loop body is called once per sensor frame
  * (filter/filter.py:131-233); replaying a recorded sequence needs no host turn-around between frames.  After the call the
- * latest frame's buffers are first's (poses_prop, nn_idx, status) when T is even, its *_prev ones when T is odd. */
+ * latest frame's buffers are first's (poses_prop, nn_idx, status) when T is even, its *_prev ones when T is odd.
+ * The frame's tail numbers its launches (the waves of a summation block hand their totals to each other through records that
+ * carry the launch's number, csrc/tail_group.hpp): the calls of the step family (midas_filter_step, midas_lazy_step / _run,
+ * midas_shard_*) must be ISSUED, not replayed from a captured hipGraph - a replay would repeat a number. */
 int midas_lazy_run(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
                    const midas_lazy_args* first, int32_t T, double* rmse_log_dev);
 
