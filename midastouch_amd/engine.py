@@ -47,6 +47,8 @@ def operand(t, name: str, dtype, shape, device):
     (what the TCN emits before its .double()) and strided views are converted; a wrong element count raises."""
     if t is None:
         return None
+    if isinstance(t, torch.Tensor) and t.dtype == dtype and t.device == device and t.shape == tuple(shape) and t.is_contiguous():
+        return t  # (already what the kernels read: the common case of a run() fed from device tensors)
     t = torch.as_tensor(t)
     n = 1
     for s_ in shape:
@@ -359,30 +361,38 @@ class PipelinedFilterEngine(FilterEngine):
         gts = operand(gts, "gt poses", torch.float32, (T, 4, 4), d)
         cur, nxt = self._cur, self._cur ^ 1
         fold = self._pending and not self._flushed
-        a = LazyArgs()
-        a.N = self.N
-        a.poses_prop_prev, a.nn_idx_prev, a.status_prev = _ptr(self._prop[cur]), _ptr(self._nn[cur]), _ptr(self._st[cur])
-        a.poses_prop, a.nn_idx, a.valid, a.status = _ptr(self._prop[nxt]), _ptr(self._nn[nxt]), _ptr(self._valid), _ptr(self._st[nxt])
-        a.tables, a.scores = _ptr(self._tables), _ptr(self._scores)
-        a.guide = _ptr(self._guide) if self._guide is not None else None
+        # the argument block with every pointer that does not change from call to call, one per buffer parity, built once (the
+        # timed region of a caller starts before this call: what is set up here is time the device idles)
+        cache = self.__dict__.setdefault("_run_args", {})
+        a = cache.get(cur)
+        if a is None:
+            a = LazyArgs()
+            a.N = self.N
+            a.poses_prop_prev, a.nn_idx_prev, a.status_prev = _ptr(self._prop[cur]), _ptr(self._nn[cur]), _ptr(self._st[cur])
+            a.poses_prop, a.nn_idx, a.valid, a.status = _ptr(self._prop[nxt]), _ptr(self._nn[nxt]), _ptr(self._valid), _ptr(self._st[nxt])
+            a.tables, a.scores = _ptr(self._tables), _ptr(self._scores)
+            a.guide = _ptr(self._guide) if self._guide is not None else None
+            a.poses_in = _ptr(self._poses)
+            a.telemetry = _ptr(self.telemetry)
+            a.ridx = None
+            a.u_prev = None
+            cache[cur] = a
         a.part_rmse = _ptr(self._part_rmse) if gts is not None else None
         a.resample_prev = int(fold)
-        a.poses_in = _ptr(self._poses)
         a.hint_in = _ptr(self._hint) if self.use_hint else None
         self._wait_draws()
         pu, pu32, pstep = self._draw
         if pu is not None:
             raise MidasError("run() continues with device draws: the pending frame was stepped with host uniforms - flush() first")
-        a.resample_mode, a.u_prev, a.u32_prev, a.step_prev = self.mode, None, float(pu32), int(pstep)
-        a.ridx = None
+        a.resample_mode, a.u32_prev, a.step_prev = self.mode, float(pu32), int(pstep)
         a.odom16, a.code, a.gt16 = _ptr(odoms), _ptr(codes), _ptr(gts)
         a.std_t, a.std_r = self.sig_t, self.sig_r
         a.seed, a.step = self.seed, self.step_count
         a.prune_thr, a.softmax = self.pen_max, int(self.softmax)
-        a.telemetry = _ptr(self.telemetry)
-        if self.sparse_scores:
-            a.score_stamps, a.score_epoch = _ptr(self._stamps), self._next_epoch(T)
-            a.score_list = _ptr(self._score_list)
+        if self.sparse_scores:  # (a caller may switch the scoring form between calls)
+            a.score_stamps, a.score_epoch, a.score_list = _ptr(self._stamps), self._next_epoch(T), _ptr(self._score_list)
+        else:
+            a.score_stamps, a.score_epoch, a.score_list = None, 0, None
         # a FRESH tensor per call (caching allocator: no launch, no fill - every row is written by its frame): the log belongs
         # to the caller and stays valid across later run() / step() calls; the engine keeps a reference for `rmse`
         log = torch.empty((T, 3), dtype=torch.float64, device=d) if gts is not None else None
