@@ -878,11 +878,9 @@ MD void row_best(float& d, int& i) {
 // in the next pass with its next 64 records, until its list is exhausted (then: the list's outer radius, the twin).
 // A wave of c2 has ~10 open owners (up to ~20): with four per pass (16-lane rows) that was three to five dependent
 // round trips, with eight it is two or three.
-// 1: the stamps are requested before the prune and looked at after it.  Measured: slower (front 34 -> 45 us) - the particle
-// waves run in lock step, so with the look deferred nearly every wave still finds the old stamps and exchanges.
-#ifndef MIDAS_CLAIM_DEFER
-#define MIDAS_CLAIM_DEFER 0
-#endif
+// (Looking at the stamps only after the prune was measured twice - round 3: front 34 -> 45 us, round 5 with the prediction
+// list: 29.7k -> 29.2k steps/s - the particle waves run in lock step, so with the look deferred nearly every wave still
+// finds the old stamps and exchanges.  The claim is looked at where it is issued.)
 #ifndef MIDAS_CLAIM_HASH
 #define MIDAS_CLAIM_HASH 1  // leaders of the row claims through an LDS hash table (score_body.hpp claim_rows_issue); 0: ballot rounds
 #endif
@@ -1836,7 +1834,7 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
     RowClaim claim{false, 0u};
     if (a.sp.stamps && !(ablate & 16)) {  // ablate 16 (profiling): nobody scores
         claim = claim_rows_issue(a.sp, live, bi, MIDAS_CLAIM_HASH ? reinterpret_cast<int*>(s_cd) : nullptr);
-        if (!MIDAS_CLAIM_DEFER) st_rows = score_claimed_rows_nj(a.sp, claim, bi, dense_scores);
+        st_rows = score_claimed_rows_nj(a.sp, claim, bi, dense_scores);
     }
     MIDAS_TICK(9);
     // prune: valid <=> some mesh vertex within sqrt(t2) of the particle
@@ -1867,7 +1865,6 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
         if (lane == 0 && m) atomicAdd(&a.telemetry[1], (unsigned long long)__popcll(m));
     }
     if (mv >= 0) ok = mv == 1;
-    if (MIDAS_CLAIM_DEFER && a.sp.stamps && !(ablate & 16)) st_rows = score_claimed_rows_nj(a.sp, claim, bi, dense_scores);
     if (a.telemetry && st_rows && lane == 0) atomicAdd(&a.telemetry[2], (unsigned long long)st_rows);  // rows scored by particle waves
     MIDAS_TICK(6);
     if (live) {
@@ -2177,10 +2174,8 @@ __global__ __launch_bounds__(256, MIDAS_NNP_OCC) void k_particle_nn_prune(TreeVi
     RowClaim claim{false, 0u};
     if (a.sp.stamps) {
         claim = claim_rows_issue(a.sp, owner && live, nn, MIDAS_CLAIM_HASH ? reinterpret_cast<int*>(s_cd[w]) : nullptr);
-        if (!MIDAS_CLAIM_DEFER) {
-            const int nr = score_claimed_rows_nj(a.sp, claim, nn);
-            if (a.telemetry && nr && lane == 0) atomicAdd(&a.telemetry[2], (unsigned long long)nr);
-        }
+        const int nr = score_claimed_rows_nj(a.sp, claim, nn);
+        if (a.telemetry && nr && lane == 0) atomicAdd(&a.telemetry[2], (unsigned long long)nr);
     }
     if (a.vlist) {
         Point3 ph;
@@ -2217,7 +2212,6 @@ __global__ __launch_bounds__(256, MIDAS_NNP_OCC) void k_particle_nn_prune(TreeVi
         a.nn_idx[p] = nn;
         a.valid[p] = ok ? 1 : 0;
     }
-    if (MIDAS_CLAIM_DEFER && a.sp.stamps) score_claimed_rows_nj(a.sp, claim, nn);
 }
 
 // =================================================================================================
