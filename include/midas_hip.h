@@ -307,10 +307,11 @@ typedef struct midas_lazy_args {
     int32_t* score_list_dev;           /* NULL or 2 + 2 K int32, zero-initialised by the caller: prediction lists of the sparse
                                         * scoring (single trajectory).  [0], [1] = the two lists' lengths, then two lists of K
                                         * rows.  The frame with score_epoch e scores list (e >> 1) & 1 - the rows the frame
-                                        * before it used, stamped e - 1 by that frame's tail - with streaming workgroups of its
-                                        * front launch, and its own tail writes the other list.  With a list the caller advances
-                                        * score_epoch by TWO per frame (midas_lazy_run does) and zeroes the two lengths whenever it
-                                        * zeroes the stamps.  Same scores as without (which rows are scored by whom is all
+                                        * before it used, stamped e - 1 by that frame's tail, and the rows that frame had on its
+                                        * list without using them (one second chance; bits 31:30 of their stamp count it) - with streaming
+                                        * workgroups of its front launch, and its own tail writes the other list.  With a list
+                                        * the caller advances score_epoch by TWO per frame (midas_lazy_run does), keeps it below
+                                        * 0x3FFFFFF0 and zeroes the two lengths whenever it zeroes the stamps.  Same scores as without (which rows are scored by whom is all
                                         * that changes); replaces nothing in the reference - it gathers all N rows every frame
                                         * (tactile_tree/tactile_tree.py:54-58) */
     uint8_t* guide_dev;                /* NULL or midas_lazy_guide_bytes(N) bytes, 16-byte aligned (single trajectory; ignored by the

@@ -693,7 +693,7 @@ MIDAS_EXPORT int midas_lazy_run(midas_ctx* ctx, const midas_codebook* cb, const 
         a.step += 1;
         if (a.score_stamps_dev) {  // never 0; two per frame with a prediction list (the tag between two epochs marks its rows)
             const uint32_t inc = a.score_list_dev ? 2u : 1u;
-            MIDAS_REQUIRE(ctx, a.score_epoch < 0xFFFFFFF0u - inc);  // the caller restarts the epochs (and zeroes the stamps) long before
+            MIDAS_REQUIRE(ctx, a.score_epoch < (a.score_list_dev ? MIDAS_EPOCH_LIMIT : 0xFFFFFFF0u) - inc);  // the caller restarts the epochs (and zeroes the stamps) long before
             a.score_epoch += inc;
         }
         a.odom16_dev += 16;
@@ -749,6 +749,7 @@ static int lazy_step_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_
     if (s.score_stamps_dev && s.score_epoch) { pa.sp.stamps = s.score_stamps_dev; pa.sp.epoch = s.score_epoch; }
     ScorePredict predict;
     if (pa.sp.stamps && s.score_list_dev && B == 1 && s.score_epoch >= 2 && N >= SCAN_CHUNK) {
+        MIDAS_REQUIRE(ctx, s.score_epoch < MIDAS_EPOCH_LIMIT);  // (bit 31 of a stamp flags a listed row's second chance)
         const int par = (int)((s.score_epoch >> 1) & 1u);
         int32_t* base = s.score_list_dev;
         pa.sp.pred_tag = s.score_epoch - 1u;
@@ -860,7 +861,7 @@ static int lazy_flush_impl(midas_ctx* ctx, const midas_lazy_flush_args& s, int32
 MIDAS_EXPORT int midas_score_list_seed(midas_ctx* ctx, int64_t K, uint32_t* score_stamps_dev, uint32_t score_epoch, int32_t* score_list_dev,
                                        int64_t N, const int32_t* nn_idx_dev) {
     MIDAS_ENTER(ctx);
-    MIDAS_REQUIRE(ctx, K > 0 && score_stamps_dev && score_epoch >= 2 && score_epoch < 0xFFFFFFF0u && score_list_dev && N > 0 && nn_idx_dev);
+    MIDAS_REQUIRE(ctx, K > 0 && score_stamps_dev && score_epoch >= 2 && score_epoch < MIDAS_EPOCH_LIMIT && score_list_dev && N > 0 && nn_idx_dev);
     const int par = (int)((score_epoch >> 1) & 1u);
     ScorePredict pr;
     pr.stamps = score_stamps_dev; pr.epoch = score_epoch; pr.K = K;
@@ -949,7 +950,7 @@ static int shard_front_impl(midas_ctx* ctx, const midas_codebook* cb, const mida
     pa.part_rmse = (double*)prm;
     if (inbox) pa.inbox = *inbox;
     if (!s.scores_ready && s.score_stamps_dev && s.score_epoch) { pa.sp.stamps = s.score_stamps_dev; pa.sp.epoch = s.score_epoch; }
-    if (pa.sp.stamps && score_list && predict_out && s.score_epoch >= 2 && s.N >= SCAN_CHUNK && cb) {
+    if (pa.sp.stamps && score_list && predict_out && s.score_epoch >= 2 && s.score_epoch < MIDAS_EPOCH_LIMIT && s.N >= SCAN_CHUNK && cb) {
         const int par = (int)((s.score_epoch >> 1) & 1u);
         pa.sp.pred_tag = s.score_epoch - 1u;
         pa.sp.list_count = score_list + par;
@@ -1226,7 +1227,7 @@ MIDAS_EXPORT int midas_shard_run(midas_ctx* ctx, midas_comm* comm, const midas_c
         a.frame_tag += 1;
         a.u32 = -1.0f;
         if (a.front.score_stamps_dev) {
-            MIDAS_REQUIRE(ctx, a.front.score_epoch < 0xFFFFFFF0u - 2u);
+            MIDAS_REQUIRE(ctx, a.front.score_epoch < MIDAS_EPOCH_LIMIT - 2u);
             a.front.score_epoch += a.score_list_dev ? 2u : 1u;
         }
         a.front.odom16_dev += 16;

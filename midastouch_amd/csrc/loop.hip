@@ -156,22 +156,41 @@ __global__ __launch_bounds__(256) void k_loop_weights(int32_t* __restrict__ ctl_
     __shared__ double s_sum[LAZY_MAX_BLOCKS];
     __shared__ double s_mx[4], s_mn[4], sa[4], sb[4];
     __shared__ int s_k[4], s_f[4];
-    const int64_t n = ctl_i[LOOP_I_N];
     const int blk = blockIdx.x, t = threadIdx.x;
     const int64_t bbase = (int64_t)blk * SCAN_BLOCK;
+    // Everything this workgroup reads leaves before the live count is looked at (k_loop_xe: the control block is a trip of its
+    // own): the block results of every LAUNCHED block (the ones behind the live count hold stale values and are masked below),
+    // and the slots' numerators / masks on indices bounded by the launches' cap.
+    const int nbl = (int)gridDim.x;  // (<= LAZY_MAX_BLOCKS = the workgroup's threads: one entry a thread)
+    const int tb = t < nbl ? t : nbl - 1;
+    const double pre_sum = bsum[tb], pre_max = bmax[tb], pre_min = bmin[tb];
+    const int pre_kept = bkept[tb], pre_nan = bnan[tb];
+    double pe[SCAN_CHUNK], px[SCAN_CHUNK];
+    uint8_t pv[SCAN_CHUNK];
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) {
+        const int64_t i = bbase + (int64_t)j * 256 + t, ic = i < grid_n ? i : grid_n - 1;
+        pe[j] = e[ic]; px[j] = x[ic]; pv[j] = valid[ic];
+    }
+    double rm_p = 0.0, rm_q = 0.0;  // block 0: the first 256 waves' rmse partials (all of them for sets up to 16 384)
+    if (blk == 0 && part_rmse) {
+        const int nwl = (int)(((int64_t)grid_n + 63) / 64), kc = t < nwl ? t : nwl - 1;
+        rm_p = part_rmse[2 * kc]; rm_q = part_rmse[2 * kc + 1];
+    }
+    const int64_t n = ctl_i[LOOP_I_N];
     if (bbase >= n && blk != 0) return;
-    const int nb = (int)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    int nb = (int)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    nb = nb < nbl ? nb : nbl;  // (more alive than the launches were sized for: flagged below, the frame is undefined)
     double mx = -INFINITY, mn = INFINITY;
     int kept = 0, f = 0;
     bool anynan = false;
-    for (int i = t; i < nb; i += 256) {
-        s_sum[i] = bsum[i];
-        const double a = bmax[i], c = bmin[i];
-        anynan |= a != a;
-        mx = a > mx ? a : mx;
-        mn = c < mn ? c : mn;
-        kept += bkept[i];
-        f |= bnan[i];
+    if (t < nb && t < nbl) {
+        s_sum[t] = pre_sum;
+        anynan |= pre_max != pre_max;
+        mx = pre_max > mx ? pre_max : mx;
+        mn = pre_min < mn ? pre_min : mn;
+        kept += pre_kept;
+        f |= pre_nan;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -197,12 +216,12 @@ __global__ __launch_bounds__(256) void k_loop_weights(int32_t* __restrict__ ctl_
     const bool applied = softmax != 0 && !close;
     const double Sd = applied ? S : 1.0;
     const bool drifted = kept == 0 && n > 0;
-#pragma unroll 4
+#pragma unroll
     for (int j = 0; j < SCAN_CHUNK; ++j) {
         const int64_t i = bbase + (int64_t)j * 256 + t;
         if (i < n) {
-            const double num = applied ? e[i] : x[i];
-            w_out[i] = num / Sd * (valid[i] ? 1.0 : 0.0);
+            const double num = applied ? pe[j] : px[j];
+            w_out[i] = num / Sd * (pv[j] ? 1.0 : 0.0);
             src[i] = (int32_t)i;  // until an ANNEAL phase says otherwise the annealed set is the particle set itself
             if (drifted) {
                 const float4* s4 = reinterpret_cast<const float4*>(cb_poses + (size_t)nn_idx[i] * 16);
@@ -215,7 +234,8 @@ __global__ __launch_bounds__(256) void k_loop_weights(int32_t* __restrict__ ctl_
     double p = 0.0, q = 0.0;
     if (part_rmse) {
         const int nw = (int)((n + 63) / 64);
-        for (int k = t; k < nw; k += 256) { p += part_rmse[2 * k]; q += part_rmse[2 * k + 1]; }
+        if (t < nw) { p += rm_p; q += rm_q; }
+        for (int k = t + 256; k < nw; k += 256) { p += part_rmse[2 * k]; q += part_rmse[2 * k + 1]; }
         p = lw_sum(p);
         q = lw_sum(q);
         if ((t & 63) == 0) { sa[t >> 6] = p; sb[t >> 6] = q; }

@@ -267,7 +267,18 @@ struct SparseScore {
     int64_t K = 0;
 };
 // what the tail kernel needs to build the next frame's list: rows whose stamp is `epoch` (claimed or confirmed in this
-// frame) are appended to `list` and re-stamped epoch + 1, the next frame's pred_tag (its epoch is epoch + 2)
+// frame) are appended to `list` and re-stamped epoch + 1, the next frame's pred_tag (its epoch is epoch + 2).
+// Second chance (round 5): a row that was on this frame's list but that nobody needed (stamp still epoch - 1) is listed ONCE
+// more, stamped (epoch + 1) | PRED_SECOND - in the frames after a wide start half of the rows a frame needs and the frame before
+// did not were in use two frames back (the cloud's fringe flickers: tools/diag_flicker.py), and every such row was a claim: a
+// stamp exchange and a cold 2 KB fetch inside a particle wave.  Epochs stay below 2^30 (MIDAS_EPOCH_LIMIT), bits 31:30 count the
+// frames a listed row went unused (MIDAS_PRED_CHANCES of them are allowed).
+#ifndef MIDAS_PRED_CHANCES
+#define MIDAS_PRED_CHANCES 3  // further frames a listed row stays on the list unused (0 .. 3)
+#endif
+constexpr uint32_t PRED_SECOND = 0xC0000000u;  // bits 31:30 of a listed row's stamp: frames it has been listed without being used
+constexpr uint32_t PRED_AGE1 = 0x40000000u;
+constexpr uint32_t MIDAS_EPOCH_LIMIT = 0x3FFFFFF0u;
 struct ScorePredict {
     uint32_t* stamps = nullptr;
     uint32_t epoch = 0;

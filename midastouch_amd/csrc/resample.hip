@@ -554,9 +554,14 @@ MD void predict_scan(const ScorePredict& pr, int blk, int* s_wt) {
 #pragma unroll
         for (int j = 0; j < PREDICT_PER_THREAD; ++j) st[j] = k0 + j < pr.K ? pr.stamps[k0 + j] : 0u;
     }
+    // listed: the rows this frame used (stamp = epoch) and the rows that were on this frame's list unused (stamp = epoch - 1, the
+    // frame's pred_tag: their second chance, ScorePredict); a second chance that was not taken (bit 31 set) is dropped
+    const uint32_t unused = pr.epoch - 1u;
+    // keep(st): the row goes on the next list
+    auto keep = [&](uint32_t v) { return v == pr.epoch || ((v & ~PRED_SECOND) == unused && (v >> 30) < (uint32_t)MIDAS_PRED_CHANCES); };
     int n = 0;
 #pragma unroll
-    for (int j = 0; j < PREDICT_PER_THREAD; ++j) n += (k0 + j < pr.K && st[j] == pr.epoch) ? 1 : 0;
+    for (int j = 0; j < PREDICT_PER_THREAD; ++j) n += (k0 + j < pr.K && keep(st[j])) ? 1 : 0;
     const int incl = wave_iscan_dpp(n);
     if (lane == 63) s_wt[w] = incl;
     __syncthreads();
@@ -568,12 +573,12 @@ MD void predict_scan(const ScorePredict& pr, int blk, int* s_wt) {
     int pos = s_wt[4] + (w > 0 ? t0 : 0) + (w > 1 ? t1 : 0) + (w > 2 ? t2 : 0) + incl - n;
 #pragma unroll
     for (int j = 0; j < PREDICT_PER_THREAD; ++j)
-        if (k0 + j < pr.K && st[j] == pr.epoch) {
+        if (k0 + j < pr.K && keep(st[j])) {
             // (distinct rows, counter zeroed by the front: pos < K; a row that would not fit simply stays unlisted and untagged -
             // its first particle of the next frame claims it)
             if (pos < pr.K) {
                 pr.list[pos] = (int32_t)(k0 + j);
-                pr.stamps[k0 + j] = pr.epoch + 1u;
+                pr.stamps[k0 + j] = st[j] == pr.epoch ? pr.epoch + 1u : ((pr.epoch + 1u) | ((st[j] & PRED_SECOND) + PRED_AGE1));
             }
             ++pos;
         }

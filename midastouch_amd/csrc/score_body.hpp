@@ -169,14 +169,14 @@ MD int score_claimed_rows(const SparseScore& sp, const RowClaim& c, int32_t row,
     // Prediction list (sp.pred_tag != 0): the tail of the previous frame stamped the rows that frame used with pred_tag and
     // listed them; streaming waves of THIS launch score the list (score_list_wave), so a leader that finds the tag only
     // confirms the row is in use again (a plain store: every confirmer writes the same value) and nobody claims it.
-    const bool predicted = sp.pred_tag != 0u && c.old == sp.pred_tag;
+    const bool predicted = sp.pred_tag != 0u && (c.old & ~PRED_SECOND) == sp.pred_tag;  // (listed: used last frame, or its second chance)
     if (c.leader && predicted) sp.stamps[row] = sp.epoch;
 #if defined(MIDAS_CLAIM_PLAIN) && MIDAS_CLAIM_PLAIN
     if (c.leader && c.old != sp.epoch && !predicted) { sp.stamps[row] = sp.epoch; claim = true; }  // profiling: no exchange, duplicates allowed
 #else
     if (c.leader && c.old != sp.epoch && !predicted) {
         const uint32_t was = atomicExch(&sp.stamps[row], sp.epoch);
-        claim = was != sp.epoch && !(sp.pred_tag != 0u && was == sp.pred_tag);
+        claim = was != sp.epoch && !(sp.pred_tag != 0u && (was & ~PRED_SECOND) == sp.pred_tag);
     }
 #endif
     unsigned long long m = __ballot(claim);

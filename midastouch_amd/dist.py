@@ -266,7 +266,7 @@ class HipShardBackend:
     def next_epochs(self, st, n=1) -> int:
         """First of n consecutive sparse-scoring epochs of this shard's stamps, spaced by two (the value between two epochs
         tags the rows of the prediction list); restart + zeroed stamps and list lengths long before a wrap."""
-        if st._epoch + 2 * n >= 0x7FFFFFF0:
+        if st._epoch + 2 * n >= 0x3FFFFFF0:  # (bits 31:30 of a stamp are the listed rows' age: csrc/midas_internal.hpp)
             st._stamps.zero_()
             st._score_list[:2].zero_()
             st._epoch = 0

@@ -21,7 +21,7 @@ from . import _lib, ops
 from ._lib import LazyArgs, LazyFlushArgs, MidasError, StepArgs, _ptr
 
 
-EPOCH_LIMIT = 0x7FFFFFF0
+EPOCH_LIMIT = 0x3FFFFFF0  # (bits 31:30 of a stamp count the frames a listed row went unused: csrc/midas_internal.hpp)
 
 
 def advance_epoch(eng, n: int = 1) -> int:

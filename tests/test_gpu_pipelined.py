@@ -242,6 +242,27 @@ def test_run_equals_stepping(dev):
     assert torch.isfinite(log2).all() and log2.shape == (T - 10, 3)
 
 
+PRED_CHANCES = 3  # csrc/midas_internal.hpp MIDAS_PRED_CHANCES: frames a listed row stays on the list without being used
+
+
+def _check_list(listed, used, history, what):
+    """The list a frame's tail leaves: every row the frame used, plus rows one of the PRED_CHANCES frames before it used (a listed
+    row that goes unused stays listed that many frames); nothing else, nothing twice.  history: the earlier frames' used rows."""
+    ls = set(listed.tolist())
+    assert len(ls) == listed.numel(), f"{what}: a row is listed twice"
+    us = set(used.tolist())
+    assert us <= ls, f"{what}: {len(us - ls)} rows in use are not on the list"
+    extra = ls - us
+    recent = set()
+    for h in history[-PRED_CHANCES:]:
+        recent |= set(h.tolist())
+    if len(history) >= 1:
+        assert extra <= recent, f"{what}: {len(extra - recent)} listed rows were not in use in this or the {PRED_CHANCES} frames before"
+    if len(history) > PRED_CHANCES:  # a row last used PRED_CHANCES + 1 frames ago has used up its chances
+        old = set(history[-PRED_CHANCES - 1].tolist()) - recent - us
+        assert not (old & ls), f"{what}: {len(old & ls)} rows are still listed {PRED_CHANCES + 1} frames after their last use"
+
+
 @pytest.mark.parametrize("N", [20000, 300000])
 def test_prediction_list_same_results(dev, oracle, monkeypatch, N):
     """Sparse scoring with the prediction list (the rows a frame used are scored for the next one by streaming workgroups,
@@ -262,6 +283,7 @@ def test_prediction_list_same_results(dev, oracle, monkeypatch, N):
     assert engs["list"]._score_list is not None and engs["nolist"]._score_list is None
     ofl = oracle.OracleFilter(cb.poses, cb.embeddings, cb.mesh_vertices) if N <= 20000 else None
     poses = start
+    history = []
     od, co = torch.as_tensor(traj.odoms).to(dev), torch.as_tensor(traj.codes).to(dev)
     for t in range(1, 8):
         for e in engs.values():
@@ -273,7 +295,9 @@ def test_prediction_list_same_results(dev, oracle, monkeypatch, N):
         if t >= 2:  # from the second frame on the list is non-empty and most of the rows in use were on it
             par = (a._epoch >> 1) & 1
             n_listed = int(a._score_list[par ^ 1].item())  # written by this frame's tail for the next frame
-            assert n_listed == used.numel(), f"frame {t}: the list holds {n_listed} rows, {used.numel()} are in use"
+            listed = a._score_list[2 + (par ^ 1) * K: 2 + (par ^ 1) * K + n_listed].long()
+            _check_list(listed, used, history, f"frame {t}")
+        history.append(used)
         if t % 3 == 0 or ofl is not None:
             assert np.array_equal(a.ridx.cpu().numpy(), b.ridx.cpu().numpy()), f"frame {t}"
             assert np.array_equal(a.weights.cpu().numpy(), b.weights.cpu().numpy()), f"frame {t}"
@@ -365,9 +389,10 @@ def test_dense_switch_of_the_prediction_list_same_results(dev, monkeypatch):
     for tag in ("dense", "list"):
         engs[tag] = PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=seed, device=dev)
         engs[tag].set_particles(torch.as_tensor(start))
-        engs[tag].project_to_codebook()
+        seeded = engs[tag].project_to_codebook()
     tele0 = int(engs["dense"].telemetry[3].item())
     saw_dense = saw_list = False
+    history = [torch.unique(torch.as_tensor(seeded)).long().to(dev)]  # (the projection's rows: seeded onto the first list)
     for t in range(1, 9):
         rows_before = int(engs["dense"].telemetry[3].item())
         monkeypatch.setenv("MIDAS_DENSE_ROWS", "1000" if t <= 4 else "100000")  # four dense frames, then back to the list
@@ -380,7 +405,10 @@ def test_dense_switch_of_the_prediction_list_same_results(dev, monkeypatch):
         assert torch.equal(a._scores[used], b._scores[used]), t
         assert torch.equal(a.ridx, b.ridx) and torch.equal(a.weights, b.weights), t
         par = (a._epoch >> 1) & 1
-        assert int(a._score_list[par ^ 1].item()) == used.numel(), t   # the next frame's list: the rows in use, whatever the mode
+        n_listed = int(a._score_list[par ^ 1].item())
+        # the next frame's list: the rows in use (+ second chances), whatever the mode
+        _check_list(a._score_list[2 + (par ^ 1) * K: 2 + (par ^ 1) * K + n_listed].long(), used, history, f"frame {t}")
+        history.append(used)
         scored = int(a.telemetry[3].item()) - rows_before
         saw_dense |= scored == K
         saw_list |= 0 < scored < K
