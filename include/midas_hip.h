@@ -186,7 +186,7 @@ int midas_rmse(midas_ctx* ctx, int64_t N, const float* poses_dev, const float* g
 
 /* ---- cluster centres (K9) -------------------------------------------------------------------- */
 /* particle_filter.get_cluster_centers(method="quat_avg") (modules/particle_filter.py:153-206) with pose.xyz_quat_averaged
- * (modules/pose.py:112-147; its removed Tensor.eig is a symmetric 4x4 eigenproblem, solved here by Jacobi in float64).
+ * (modules/pose.py:112-147; its removed Tensor.eig is a symmetric 4x4 eigenproblem; its top eigenvector is found here by repeated squaring in float64).
  * For each of the C label values: members = particles carrying it; weights taken as float32 (:161) and flattened to 1
  * when isclose(max - min, 0) (:178-184); centre rotation = principal eigenvector of sum w q q^T / sum w over sign-fixed
  * unit quaternions, centre translation = weighted mean; std = sqrt(sum w (t - centre)^2 / sum w) per axis.

@@ -6,7 +6,7 @@
 // sign-fixed quaternions (qw >= 0), the translation the weighted mean, the spread sqrt(sum w (t - mean)^2 / sum w).
 // The reference walks the clusters in a Python loop of ~25 small torch ops each; here one pass over the particles
 // accumulates every cluster's moments (both the weighted and the flattened set, the choice needs the cluster's
-// extrema) and one small kernel finishes each cluster (4x4 symmetric eigenproblem by cyclic Jacobi in float64).
+// extrema) and one small kernel finishes each cluster (4x4 symmetric eigenproblem: the top eigenvector by repeated squaring in float64, cluster_rot.hpp).
 //
 // Summation order (deterministic): per particle wave a shuffle tree, per 256-thread block the four waves in order,
 // then the blocks in order.
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void k_loop_cluster_finish(const int32_t* __re
 }
 
 // rot: LOOP_MAX_CLUSTERS x 10 doubles - the moment matrices whose eigenproblem the annealing kernel's second workgroup solves
-// (the decision only needs the translation spreads: the float64 Jacobi, 15 us on one thread, runs beside the selection)
+// (the decision only needs the translation spreads: the eigenvector runs beside the selection)
 int launch_loop_cluster(midas_ctx* ctx, int64_t cap, const int32_t* ctl_i, const float* poses, const double* w64,
                         const int32_t* labels, double* part, float* centers, float* stds, int64_t* counts, double* rot) {
     hipLaunchKernelGGL(k_loop_cluster_moments, dim3((unsigned)ceil_div(cap, 256)), dim3(256), 0, ctx->stream, ctl_i, poses, w64,

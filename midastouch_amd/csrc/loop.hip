@@ -320,7 +320,7 @@ MD void loop_decide(int32_t* __restrict__ ctl_i, double* __restrict__ ctl_d, con
     k_out = k;
 }
 
-// Second workgroup of the annealing kernels: the rotation of every present cluster's centre (float64 Jacobi on the moment
+// Second workgroup of the annealing kernels: the rotation of every present cluster's centre (top eigenvector of the moment
 // matrix k_loop_cluster_finish left in `rot`), written into the compact row loop_decide gives the cluster - the selection
 // does not wait for it.  Lane c < 8 of one wave takes cluster slot c.
 MD void loop_rotations(const int32_t* __restrict__ ctl_i, const int64_t* __restrict__ counts_all, const double* __restrict__ rot,
