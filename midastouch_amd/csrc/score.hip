@@ -446,14 +446,19 @@ int launch_score_batch(midas_ctx* ctx, const midas_codebook* cb, int32_t B, cons
     if ((rc = midas_scratch(ctx, (size_t)Bpad * D * sizeof(float), &c32))) return rc;
     hipLaunchKernelGGL(k_codes_prepare, dim3((unsigned)ceil_div(Bpad, 16)), dim3(256), 0, ctx->stream, codes, (float*)c32,
                        (double*)cn, B, Bpad, D);
-    static bool attr_set = false;
-    static int ncu = 256;
-    if (!attr_set) {
+    // per device (the same rule as launch_presort, particles.hip): a second GPU's context must not inherit the first one's
+    // dynamic-LDS limit and CU count
+    constexpr int MAXDEV = 64;
+    static bool attr_set[MAXDEV] = {};
+    static int ncu_dev[MAXDEV] = {};
+    const int di = ctx->device >= 0 && ctx->device < MAXDEV ? ctx->device : 0;
+    if (!attr_set[di] || ctx->device != di) {
         MIDAS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_score_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-        attr_set = true;
+        ncu_dev[di] = (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        attr_set[di] = true;
     }
+    const int ncu = ncu_dev[di];
     // one persistent workgroup per CU (fewer when the codebook has fewer row groups than that many SIMDs)
     const int64_t G = ceil_div(cb->K, MF_ROWS_PER_WAVE);
     const unsigned grid = (unsigned)(G < (int64_t)ncu * 4 ? ceil_div(G, 4) : ncu);
