@@ -881,6 +881,9 @@ MD void row_best(float& d, int& i) {
 // (Looking at the stamps only after the prune was measured twice - round 3: front 34 -> 45 us, round 5 with the prediction
 // list: 29.7k -> 29.2k steps/s - the particle waves run in lock step, so with the look deferred nearly every wave still
 // finds the old stamps and exchanges.  The claim is looked at where it is issued.)
+#ifndef MIDAS_SCORE_ROUNDS
+#define MIDAS_SCORE_ROUNDS 2  // quads of codebook rows a scoring wave of the fused front streams (dense scoring)
+#endif
 #ifndef MIDAS_CLAIM_HASH
 #define MIDAS_CLAIM_HASH 1  // leaders of the row claims through an LDS hash table (score_body.hpp claim_rows_issue); 0: ballot rounds
 #endif
@@ -1932,6 +1935,9 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
 // LAZY 2: the same with the tables built per wave (nb <= 64), which also frees the workgroup size: FW = waves per
 // workgroup.  With FW = 1 the 1563 particle waves of c2 spread 6 - 7 per CU; workgroups of four land 4 or 8 on a CU.
 // SCR = false (batch of trajectories, grid.y): whole-record list scans - the screen costs the batch step more than it saves
+#ifndef MIDAS_FRONT_OCC
+#define MIDAS_FRONT_OCC 1  // waves per SIMD the single-trajectory forms are compiled for (1 = no register cap: 234 registers, two waves)
+#endif
 #ifndef MIDAS_BATCH_OCC
 #define MIDAS_BATCH_OCC 1  // waves per SIMD the batch form (SCR = false) is compiled for (1 = no register cap)
 #endif
@@ -1944,7 +1950,7 @@ __device__ long long g_ff_clk[16384];  // per frame parity and workgroup: start,
 #define FF_END do { } while (0)
 #endif
 template <typename T, int NJ, int LAZY, int FW, bool SCR = true, bool PREF = false, bool STATS = false>
-__global__ __launch_bounds__(64 * FW, (!SCR && FW == 1) ? MIDAS_BATCH_OCC : 1) void k_frame_front(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a,
+__global__ __launch_bounds__(64 * FW, (!SCR && FW == 1) ? MIDAS_BATCH_OCC : MIDAS_FRONT_OCC) void k_frame_front(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a,
                                                          int n_pu, int nwaves, const T* __restrict__ emb,
                                                          const double* __restrict__ norms, const double* __restrict__ code,
                                                          double* __restrict__ scores, int64_t K) {
@@ -1974,7 +1980,10 @@ __global__ __launch_bounds__(64 * FW, (!SCR && FW == 1) ? MIDAS_BATCH_OCC : 1) v
         }
         score_list_wave<NJ>(a.sp, (int)(bx - n_pu) * FW + w, ((int)gridDim.x - n_pu) * FW);
     } else {
-        score_wave<T, NJ, 0>(emb, norms, code, scores, K, (int64_t)(bx - n_pu) * FW + w);
+        // all K rows (the dense K1 beside the particle waves): MIDAS_SCORE_ROUNDS consecutive quads of rows a wave, requested
+        // together (score_wave_multi, score_body.hpp)
+        const int64_t w0 = ((int64_t)(bx - n_pu) * FW + w) * MIDAS_SCORE_ROUNDS;
+        if (w0 * 4 < K) score_wave_multi<T, NJ, MIDAS_SCORE_ROUNDS>(emb, norms, code, scores, K, w0);
     }
     FF_END;
 }
@@ -2737,7 +2746,7 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
         const int rc = launch_presort(ctx, a);
         if (rc) return rc;
     }
-    const unsigned grid_fw = (unsigned)(n_pu_fw + (a.sp.stamps ? (use_list ? (list_wgs_env + fw - 1) / fw : 0) : ceil_div(cb->K, 4 * fw)));
+    const unsigned grid_fw = (unsigned)(n_pu_fw + (a.sp.stamps ? (use_list ? (list_wgs_env + fw - 1) / fw : 0) : ceil_div(cb->K, 4 * fw * MIDAS_SCORE_ROUNDS)));
     // profiling instantiations (MIDAS_ABLATE != 0; D = 512, one-wave workgroups): phase clocks, scan statistics, ablation switches
     if (a.ablate && cb->D == 512 && fw == 1) {
         bool done = true;

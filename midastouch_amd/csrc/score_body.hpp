@@ -73,6 +73,59 @@ MD void score_wave(const T* __restrict__ emb, const double* __restrict__ norms, 
     }
 }
 
+// R consecutive quads of rows by one wave (MODE 0), the R x NJ row pieces requested together.  The scoring waves of the fused
+// front with one quad each were 125 k one-wave workgroups for c4's 500 k rows; with two quads a wave the dense frame of c4 takes
+// 215 us instead of 228 (four or six: no further gain, six spills).  What the fused stream loses against k_score_reg alone
+// (172 us) is the particle waves' phase: ~2 TB/s of scattered requests during the launch's first 25 - 30 us leave the stream
+// little of the memory system; register caps that give the stream more wave slots in that phase (three / four waves a SIMD)
+// change nothing for it and cost the particle waves 5 / 16 %.  Same arithmetic per row as score_wave (same lane ownership, same
+// summation order): bit-identical scores.
+template <typename T, int NJ, int R>
+MD void score_wave_multi(const T* __restrict__ emb, const double* __restrict__ norms, const double* __restrict__ code,
+                         double* __restrict__ out, int64_t K, int64_t wave0) {
+    constexpr int D = NJ * 64;
+    const int lane = threadIdx.x & 63;
+    const int s = lane & 15;
+    using V = typename Vec4<T>::type;
+    V v[R][NJ];
+    double nr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = (wave0 + r) * 4 + (lane >> 4);
+        const T* p = emb + (row < K ? row : 0) * (int64_t)D + s * 4;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) v[r][j] = *reinterpret_cast<const V*>(p + j * 64);
+        nr[r] = norms[row < K ? row : 0];  // (travels with the rows)
+    }
+    double e[NJ * 4];
+    double ne2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const double2* p = reinterpret_cast<const double2*>(code + j * 64 + s * 4);
+        double2 a = p[0], b = p[1];
+        e[j * 4 + 0] = a.x; e[j * 4 + 1] = a.y; e[j * 4 + 2] = b.x; e[j * 4 + 3] = b.y;
+    }
+#pragma unroll
+    for (int i = 0; i < NJ * 4; ++i) ne2 = fma_(e[i], e[i], ne2);
+    ne2 = quarter_reduce(ne2);
+    double ne = __builtin_sqrt(ne2);
+    ne = ne < COS_EPS ? COS_EPS : ne;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = (wave0 + r) * 4 + (lane >> 4);
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            acc = fma_((double)v[r][j].x, e[j * 4 + 0], acc);
+            acc = fma_((double)v[r][j].y, e[j * 4 + 1], acc);
+            acc = fma_((double)v[r][j].z, e[j * 4 + 2], acc);
+            acc = fma_((double)v[r][j].w, e[j * 4 + 3], acc);
+        }
+        acc = quarter_reduce(acc);
+        if (row < K && s == 0) out[row] = acc / (ne * nr[r]);
+    }
+}
+
 // ---- sparse scoring inside the particle kernels ----------------------------------------------------------------
 // cos(code, C_k) is only ever read at k = nearest entry of some particle (modules/particle_filter.py:449-457 scores the
 // gathered rows; the dense pass over all K rows is this implementation's restructuring of it).  Once the cloud has
