@@ -1978,7 +1978,8 @@ __global__ __launch_bounds__(64 * FW, (!SCR && FW == 1) ? MIDAS_BATCH_OCC : MIDA
             if (a.sp.dense_thr > 0 && c > a.sp.dense_thr) atomicAdd(&a.telemetry[3], (unsigned long long)a.sp.K);  // all of them
             else if (c > 0) atomicAdd(&a.telemetry[3], (unsigned long long)(c < a.sp.list_cap ? c : a.sp.list_cap));
         }
-        score_list_wave<NJ>(a.sp, (int)(bx - n_pu) * FW + w, ((int)gridDim.x - n_pu) * FW);
+        if (!(STATS && (a.ablate & 64)))  // ablate 64 (profiling): the list is not scored - what its stream costs the particle waves
+            score_list_wave<NJ>(a.sp, (int)(bx - n_pu) * FW + w, ((int)gridDim.x - n_pu) * FW);
     } else {
         // all K rows (the dense K1 beside the particle waves): MIDAS_SCORE_ROUNDS consecutive quads of rows a wave, requested
         // together (score_wave_multi, score_body.hpp)
