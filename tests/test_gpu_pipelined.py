@@ -413,3 +413,34 @@ def test_dense_switch_of_the_prediction_list_same_results(dev, monkeypatch):
         saw_dense |= scored == K
         saw_list |= 0 < scored < K
     assert saw_dense and saw_list, (saw_dense, saw_list, int(engs["dense"].telemetry[3].item()) - tele0)
+
+
+@pytest.mark.parametrize("N,K,D", [(20000, 5003, 512), (300000, 3001, 256), (600, 1030, 512)])
+def test_dense_front_scores_every_row(dev, oracle, monkeypatch, N, K, D):
+    """MIDAS_DENSE_SCORES=1: the front launch streams ALL K rows beside the particle waves (the K1 GEMV of SURVEY 8(a), two
+    quads of rows per scoring wave - score_wave_multi) instead of scoring only the rows in use.  Every one of the K scores equals
+    the oracle's bit for bit (K not a multiple of the eight rows a scoring wave takes: the ragged end), and the particle sets are
+    those of the sparse engine.  N = 20000: one-wave workgroups with per-wave tables; 300000: four-wave workgroups; 600: the
+    two-kernel front (its scoring workgroups keep one quad per wave)."""
+    from midastouch_amd.engine import PipelinedFilterEngine
+    cb, traj = _setup(N, K, D, 13)
+    start = cb.poses[np.random.default_rng(8).integers(0, K, N)]
+    engs = {}
+    for tag, env in (("dense", "1"), ("sparse", "0")):
+        monkeypatch.setenv("MIDAS_DENSE_SCORES", env)
+        engs[tag] = PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=77, device=dev)
+        engs[tag].set_particles(torch.as_tensor(start))
+    assert not engs["dense"].sparse_scores and engs["sparse"].sparse_scores
+    od, co = torch.as_tensor(traj.odoms).to(dev), torch.as_tensor(traj.codes).to(dev)
+    for t in range(1, 6):
+        for e in engs.values():
+            e.step(od[t], co[t])
+        a, b = engs["dense"], engs["sparse"]
+        ref = oracle.score_codebook(cb.embeddings, traj.codes[t])
+        a.flush()
+        assert np.array_equal(a._scores.cpu().numpy(), ref), f"frame {t}: {int((a._scores.cpu().numpy() != ref).sum())} of {K} scores differ"
+        assert torch.equal(a.nn_idx, b.nn_idx) and torch.equal(a.ridx, b.ridx) and torch.equal(a.weights, b.weights), f"frame {t}"
+    for e in engs.values():
+        e.run(od[6:12], co[6:12])
+    assert torch.equal(engs["dense"].ridx, engs["sparse"].ridx) and torch.equal(engs["dense"].poses, engs["sparse"].poses)
+    assert np.array_equal(engs["dense"]._scores.cpu().numpy(), oracle.score_codebook(cb.embeddings, traj.codes[11]))
