@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from midastouch_amd.engine import PipelinedFilterEngine
 from midastouch_amd.synthetic import make_codebook, make_trajectory
 dev = torch.device("cuda", 0)
-N, K, D = 1_000_000, 50_000, 512
+N, K, D = int(os.environ.get("C3_N", 1_000_000)), 50_000, 512
 cb = make_codebook("035_power_drill", K=K, D=D, seed=1003)
 tr = make_trajectory(cb, T=72, seed=2003)
 eng = PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, device=dev)
@@ -20,4 +20,4 @@ torch.cuda.synchronize()
 t0 = time.perf_counter()
 eng.run(od[21:61], co[21:61])
 torch.cuda.synchronize()
-print("c3 total on one GPU: %.1f us per frame" % ((time.perf_counter() - t0) / 40 * 1e6))
+print("c3 total on one GPU (N = %d): %.1f us per frame" % (N, (time.perf_counter() - t0) / 40 * 1e6))
