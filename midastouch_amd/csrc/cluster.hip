@@ -13,6 +13,7 @@
 #include "midas_internal.hpp"
 #include "midas_math.hpp"
 #include "cluster_rot.hpp"
+#include "loop_weights.hpp"
 
 namespace midas {
 
@@ -65,22 +66,33 @@ MD double cl_wmin(double v) {
     return v;
 }
 
-// part[(block * C + c) * CL_MOM + m]; label_value(c) = the label cluster slot c stands for
-template <typename LabelT, typename LV>
-MD void cluster_moments_body(int64_t N, const float* __restrict__ poses, const double* __restrict__ w64,
-                             const float* __restrict__ w32, const LabelT* __restrict__ labels, int C, LV label_value,
-                             double* __restrict__ part, double (*s_w)[CL_MOM]) {
-    const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
-    const int64_t n = (int64_t)blockIdx.x * 256 + t;
-    const bool live = n < N;
-    const int64_t nc = live ? n : N - 1;
-    float P[16];
+// part[(block * C + c) * CL_MOM + m]; label_value(c) = the label cluster slot c stands for.  In two steps: what a particle
+// contributes (pose rows, label, float32-rounded weight) and the accumulation, so that the loop step can compute the weight in
+// the same launch (k_loop_weights_moments).
+struct MomIn {
+    float P[12];
+    int64_t lab;
+    double w;
+};
+template <typename LabelT>
+MD MomIn moments_load(int64_t nc, const float* __restrict__ poses, const double* __restrict__ w64, const float* __restrict__ w32,
+                      const LabelT* __restrict__ labels) {
+    MomIn in;
     const float4* p4 = reinterpret_cast<const float4*>(poses + nc * 16);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { const float4 r = p4[i]; P[4 * i] = r.x; P[4 * i + 1] = r.y; P[4 * i + 2] = r.z; P[4 * i + 3] = r.w; }
-    const int64_t lab = (int64_t)labels[nc];
+    for (int i = 0; i < 3; ++i) { const float4 r = p4[i]; in.P[4 * i] = r.x; in.P[4 * i + 1] = r.y; in.P[4 * i + 2] = r.z; in.P[4 * i + 3] = r.w; }
+    in.lab = (int64_t)labels[nc];
     // particles.weights.float() (:161): the reference averages with float32 weights
-    const double w = w64 ? (double)(float)w64[nc] : (double)w32[nc];
+    in.w = w64 ? (double)(float)w64[nc] : w32 ? (double)w32[nc] : 0.0;  // (neither: the caller computes the weight itself)
+    return in;
+}
+
+template <typename LV>
+MD void moments_accumulate(bool live, const MomIn& in, int C, LV label_value, double* __restrict__ part, double (*s_w)[CL_MOM]) {
+    const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
+    const float* P = in.P;
+    const int64_t lab = in.lab;
+    const double w = in.w;
     double q[4];
     quat_of(P, q);
     const double tx = P[3], ty = P[7], tz = P[11];
@@ -123,6 +135,16 @@ MD void cluster_moments_body(int64_t N, const float* __restrict__ poses, const d
     }
 }
 
+template <typename LabelT, typename LV>
+MD void cluster_moments_body(int64_t N, const float* __restrict__ poses, const double* __restrict__ w64,
+                             const float* __restrict__ w32, const LabelT* __restrict__ labels, int C, LV label_value,
+                             double* __restrict__ part, double (*s_w)[CL_MOM]) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = n < N;
+    const MomIn in = moments_load(live ? n : N - 1, poses, w64, w32, labels);
+    moments_accumulate(live, in, C, label_value, part, s_w);
+}
+
 __global__ __launch_bounds__(256) void k_cluster_moments(int64_t N, const float* __restrict__ poses, const double* __restrict__ w64,
                                                          const float* __restrict__ w32, const int64_t* __restrict__ labels, int C,
                                                          const int64_t* __restrict__ label_values, double* __restrict__ part) {
@@ -141,6 +163,47 @@ __global__ __launch_bounds__(256) void k_loop_cluster_moments(const int32_t* __r
     C = C > LOOP_MAX_CLUSTERS ? LOOP_MAX_CLUSTERS : C;
     if ((int64_t)blockIdx.x * 256 >= n) return;
     cluster_moments_body(n, poses, w64, (const float*)nullptr, labels, C, [](int c) { return (int64_t)(c - 1); }, part, s_w);
+}
+
+// The same with the frame's weights computed at its head (loop_weights.hpp: k_loop_weights' arithmetic, one particle a thread):
+// S and the guard from k_loop_xe's block results by every workgroup for itself, the particle's weight stored and used at once,
+// the first workgroup finalises the control block.  One launch less per frame (~5 us of a 90 us frame at N ~ 10^4), and the
+// moments need not read the weights back.  Everything a thread reads is requested before the live count is looked at.
+__global__ __launch_bounds__(256) void k_loop_weights_moments(LoopWeightsArgs a, const int32_t* __restrict__ labels,
+                                                              double* __restrict__ part) {
+    __shared__ double s_w[4][CL_MOM];
+    __shared__ double s_sum[LAZY_MAX_BLOCKS];
+    __shared__ double s_red[8], s_ab[8];
+    __shared__ int s_ired[8];
+    const int t = threadIdx.x;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + t, ic = idx < a.grid_n ? idx : a.grid_n - 1;
+    const LoopWeightsPre pre = loop_weights_prefetch(a, blockIdx.x == 0);
+    const double e_i = a.e[ic], x_i = a.x[ic];
+    const uint8_t v_i = a.valid[ic];
+    const int32_t nn_i = a.nn_idx[ic];
+    MomIn in = moments_load(ic, a.poses_prop, (const double*)nullptr, (const float*)nullptr, labels);  // (w: below)
+    const int64_t n = a.ctl_i[LOOP_I_N];
+    int C = a.ctl_i[LOOP_I_NCL] + 1;
+    C = C > LOOP_MAX_CLUSTERS ? LOOP_MAX_CLUSTERS : C;
+    if ((int64_t)blockIdx.x * 256 >= n && blockIdx.x != 0) return;
+    const LoopWeightsHead h = loop_weights_head(a, pre, n, s_sum, s_red, s_ired);
+    const bool live = idx < n;
+    double w = 0.0;
+    if (live) {
+        w = loop_weight_store(a, h, idx, e_i, x_i, v_i);
+        if (h.drifted) {  // every particle back onto its codebook pose; the moments are taken of the re-projected set
+            const float4* s4 = reinterpret_cast<const float4*>(a.cb_poses + (size_t)nn_i * 16);
+            float4* d4 = reinterpret_cast<float4*>(a.poses_prop + (size_t)idx * 16);
+            const float4 r0 = s4[0], r1 = s4[1], r2 = s4[2], r3 = s4[3];
+            d4[0] = r0; d4[1] = r1; d4[2] = r2; d4[3] = r3;
+            in.P[0] = r0.x; in.P[1] = r0.y; in.P[2] = r0.z; in.P[3] = r0.w;
+            in.P[4] = r1.x; in.P[5] = r1.y; in.P[6] = r1.z; in.P[7] = r1.w;
+            in.P[8] = r2.x; in.P[9] = r2.y; in.P[10] = r2.z; in.P[11] = r2.w;
+        }
+    }
+    in.w = (double)(float)w;  // particles.weights.float() (:161)
+    if ((int64_t)blockIdx.x * 256 < n) moments_accumulate(live, in, C, [](int c) { return (int64_t)(c - 1); }, part, s_w);
+    if (blockIdx.x == 0) loop_weights_finalise(a, h, pre, s_ab);
 }
 
 // one 64-thread workgroup per cluster: blocks summed in order, then the closed forms
@@ -274,9 +337,13 @@ __global__ __launch_bounds__(256) void k_loop_cluster_finish(const int32_t* __re
 // rot: LOOP_MAX_CLUSTERS x 10 doubles - the moment matrices whose eigenproblem the annealing kernel's second workgroup solves
 // (the decision only needs the translation spreads: the eigenvector runs beside the selection)
 int launch_loop_cluster(midas_ctx* ctx, int64_t cap, const int32_t* ctl_i, const float* poses, const double* w64,
-                        const int32_t* labels, double* part, float* centers, float* stds, int64_t* counts, double* rot) {
-    hipLaunchKernelGGL(k_loop_cluster_moments, dim3((unsigned)ceil_div(cap, 256)), dim3(256), 0, ctx->stream, ctl_i, poses, w64,
-                       labels, part);
+                        const int32_t* labels, double* part, float* centers, float* stds, int64_t* counts, double* rot,
+                        const LoopWeightsArgs* weights) {
+    if (weights)
+        hipLaunchKernelGGL(k_loop_weights_moments, dim3((unsigned)ceil_div(cap, 256)), dim3(256), 0, ctx->stream, *weights, labels, part);
+    else
+        hipLaunchKernelGGL(k_loop_cluster_moments, dim3((unsigned)ceil_div(cap, 256)), dim3(256), 0, ctx->stream, ctl_i, poses, w64,
+                           labels, part);
     hipLaunchKernelGGL(k_loop_cluster_finish, dim3(LOOP_MAX_CLUSTERS), dim3(256), 0, ctx->stream, ctl_i, (const double*)part, centers,
                        stds, counts, rot);
     MIDAS_HIP_CHECK(ctx, hipGetLastError());

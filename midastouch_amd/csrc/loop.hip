@@ -25,12 +25,12 @@
 #include "midas_math.hpp"
 #include "cluster_rot.hpp"
 #include "tail_block.hpp"
+#include "loop_weights.hpp"
 
 namespace midas {
 
 #define LAUNCH_CHECK(ctx) MIDAS_HIP_CHECK(ctx, hipGetLastError())
 
-constexpr double LOOP_ISCLOSE_ATOL = 1e-8;  // torch.isclose default atol (particle_filter.py:460-463)
 constexpr int SEL_PASSES = 6;
 constexpr int SEL_BINS = 2048;
 constexpr int SORT_CHUNK = 2048;  // (key, index) pairs sorted per workgroup in LDS
@@ -143,123 +143,42 @@ __global__ __launch_bounds__(256) void k_loop_xe(const int32_t* __restrict__ ctl
 }
 
 // S = blocks summed in order; guard; w = (e or x) / S * valid; every particle back onto its codebook pose when all of them
-// were pruned (filter.py:176-179); block 0 finalises the control block and the rmse.
-__global__ __launch_bounds__(256) void k_loop_weights(int32_t* __restrict__ ctl_i, double* __restrict__ ctl_d, int32_t grid_n,
-                                                      const double* __restrict__ bsum, const double* __restrict__ bmax,
-                                                      const double* __restrict__ bmin, const int32_t* __restrict__ bkept,
-                                                      const int32_t* __restrict__ bnan, const double* __restrict__ x,
-                                                      const double* __restrict__ e, const uint8_t* __restrict__ valid,
-                                                      const int32_t* __restrict__ nn_idx, const float* __restrict__ cb_poses,
-                                                      float* __restrict__ poses_prop, double* __restrict__ w_out,
-                                                      int32_t* __restrict__ src, const double* __restrict__ part_rmse,
-                                                      int32_t softmax) {
+// were pruned (filter.py:176-179); block 0 finalises the control block and the rmse.  (The arithmetic lives in loop_weights.hpp:
+// frames whose cluster moments follow in the same call have it at the head of that launch instead, cluster.hip.)
+__global__ __launch_bounds__(256) void k_loop_weights(LoopWeightsArgs a) {
     __shared__ double s_sum[LAZY_MAX_BLOCKS];
-    __shared__ double s_mx[4], s_mn[4], sa[4], sb[4];
-    __shared__ int s_k[4], s_f[4];
+    __shared__ double s_red[8], s_ab[8];
+    __shared__ int s_ired[8];
     const int blk = blockIdx.x, t = threadIdx.x;
     const int64_t bbase = (int64_t)blk * SCAN_BLOCK;
-    // Everything this workgroup reads leaves before the live count is looked at (k_loop_xe: the control block is a trip of its
-    // own): the block results of every LAUNCHED block (the ones behind the live count hold stale values and are masked below),
-    // and the slots' numerators / masks on indices bounded by the launches' cap.
-    const int nbl = (int)gridDim.x;  // (<= LAZY_MAX_BLOCKS = the workgroup's threads: one entry a thread)
-    const int tb = t < nbl ? t : nbl - 1;
-    const double pre_sum = bsum[tb], pre_max = bmax[tb], pre_min = bmin[tb];
-    const int pre_kept = bkept[tb], pre_nan = bnan[tb];
+    // Everything this workgroup reads leaves before the live count is looked at (the control block is a trip of its own): the block
+    // results of every LAUNCHED block (the ones behind the live count hold stale values and are masked), and the slots'
+    // numerators / masks on indices bounded by the launches' cap.
+    const LoopWeightsPre pre = loop_weights_prefetch(a, blk == 0);
     double pe[SCAN_CHUNK], px[SCAN_CHUNK];
     uint8_t pv[SCAN_CHUNK];
 #pragma unroll
     for (int j = 0; j < SCAN_CHUNK; ++j) {
-        const int64_t i = bbase + (int64_t)j * 256 + t, ic = i < grid_n ? i : grid_n - 1;
-        pe[j] = e[ic]; px[j] = x[ic]; pv[j] = valid[ic];
+        const int64_t i = bbase + (int64_t)j * 256 + t, ic = i < a.grid_n ? i : a.grid_n - 1;
+        pe[j] = a.e[ic]; px[j] = a.x[ic]; pv[j] = a.valid[ic];
     }
-    double rm_p = 0.0, rm_q = 0.0;  // block 0: the first 256 waves' rmse partials (all of them for sets up to 16 384)
-    if (blk == 0 && part_rmse) {
-        const int nwl = (int)(((int64_t)grid_n + 63) / 64), kc = t < nwl ? t : nwl - 1;
-        rm_p = part_rmse[2 * kc]; rm_q = part_rmse[2 * kc + 1];
-    }
-    const int64_t n = ctl_i[LOOP_I_N];
+    const int64_t n = a.ctl_i[LOOP_I_N];
     if (bbase >= n && blk != 0) return;
-    int nb = (int)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
-    nb = nb < nbl ? nb : nbl;  // (more alive than the launches were sized for: flagged below, the frame is undefined)
-    double mx = -INFINITY, mn = INFINITY;
-    int kept = 0, f = 0;
-    bool anynan = false;
-    if (t < nb && t < nbl) {
-        s_sum[t] = pre_sum;
-        anynan |= pre_max != pre_max;
-        mx = pre_max > mx ? pre_max : mx;
-        mn = pre_min < mn ? pre_min : mn;
-        kept += pre_kept;
-        f |= pre_nan;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double a = __shfl_xor(mx, o), c = __shfl_xor(mn, o);
-        mx = a > mx ? a : mx;
-        mn = c < mn ? c : mn;
-    }
-    kept = lw_isum(kept);
-    f = __any(f != 0 || anynan) ? 1 : 0;
-    if ((t & 63) == 0) { s_mx[t >> 6] = mx; s_mn[t >> 6] = mn; s_k[t >> 6] = kept; s_f[t >> 6] = f; }
-    __syncthreads();
-    mx = s_mx[0]; mn = s_mn[0]; kept = s_k[0]; f = s_f[0];
-    for (int w = 1; w < 4; ++w) {
-        mx = s_mx[w] > mx ? s_mx[w] : mx;
-        mn = s_mn[w] < mn ? s_mn[w] : mn;
-        kept += s_k[w];
-        f |= s_f[w];
-    }
-    if (f) { mx = NAN; mn = NAN; }
-    double S = 0.0;
-    for (int i = 0; i < nb; ++i) S = S + s_sum[i];
-    const bool close = __builtin_fabs(mx - mn) <= LOOP_ISCLOSE_ATOL;  // false on NaN
-    const bool applied = softmax != 0 && !close;
-    const double Sd = applied ? S : 1.0;
-    const bool drifted = kept == 0 && n > 0;
+    const LoopWeightsHead h = loop_weights_head(a, pre, n, s_sum, s_red, s_ired);
 #pragma unroll
     for (int j = 0; j < SCAN_CHUNK; ++j) {
         const int64_t i = bbase + (int64_t)j * 256 + t;
         if (i < n) {
-            const double num = applied ? pe[j] : px[j];
-            w_out[i] = num / Sd * (pv[j] ? 1.0 : 0.0);
-            src[i] = (int32_t)i;  // until an ANNEAL phase says otherwise the annealed set is the particle set itself
-            if (drifted) {
-                const float4* s4 = reinterpret_cast<const float4*>(cb_poses + (size_t)nn_idx[i] * 16);
-                float4* d4 = reinterpret_cast<float4*>(poses_prop + (size_t)i * 16);
+            loop_weight_store(a, h, i, pe[j], px[j], pv[j]);
+            if (h.drifted) {
+                const float4* s4 = reinterpret_cast<const float4*>(a.cb_poses + (size_t)a.nn_idx[i] * 16);
+                float4* d4 = reinterpret_cast<float4*>(a.poses_prop + (size_t)i * 16);
                 d4[0] = s4[0]; d4[1] = s4[1]; d4[2] = s4[2]; d4[3] = s4[3];
             }
         }
     }
     if (blk != 0) return;
-    double p = 0.0, q = 0.0;
-    if (part_rmse) {
-        const int nw = (int)((n + 63) / 64);
-        if (t < nw) { p += rm_p; q += rm_q; }
-        for (int k = t + 256; k < nw; k += 256) { p += part_rmse[2 * k]; q += part_rmse[2 * k + 1]; }
-        p = lw_sum(p);
-        q = lw_sum(q);
-        if ((t & 63) == 0) { sa[t >> 6] = p; sb[t >> 6] = q; }
-    }
-    __syncthreads();
-    if (t == 0) {
-        if (part_rmse) {
-            p = (sa[0] + sa[1]) + (sa[2] + sa[3]);
-            q = (sb[0] + sb[1]) + (sb[2] + sb[3]);
-            ctl_d[LOOP_D_RMSE_T] = __builtin_sqrt(p / (double)n);
-            ctl_d[LOOP_D_RMSE_R] = __builtin_sqrt(q / (double)n);
-        }
-        ctl_d[LOOP_D_S] = Sd;
-        ctl_d[LOOP_D_XMAX] = mx;
-        ctl_d[LOOP_D_XMIN] = mn;
-        ctl_i[LOOP_I_KEPT] = kept;
-        ctl_i[LOOP_I_DRIFT] = drifted ? 1 : 0;
-        ctl_i[LOOP_I_RAW] = applied ? 0 : 1;
-        ctl_i[LOOP_I_NAN] = f;
-        if (n > grid_n) ctl_i[LOOP_I_ERR] |= 4;  // the launches were sized for fewer particles than are alive
-        ctl_i[LOOP_I_NSET] = (int32_t)n;
-        ctl_i[LOOP_I_MODE] = 0;
-        ctl_i[LOOP_I_K] = 0;
-    }
+    loop_weights_finalise(a, h, pre, s_ab);
 }
 
 // ---- ANNEAL ---------------------------------------------------------------------------------------------------------
@@ -1133,6 +1052,8 @@ int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree*
     const unsigned nbcap = (unsigned)ceil_div(cap, SCAN_BLOCK);
     int rc;
     hipStream_t st = ctx->stream;
+    LoopWeightsArgs wa{};
+    bool weights_merged = false;
     if (phases & MIDAS_LOOP_FRONT) {
         ParticleUpdateArgs pa;
         pa.N = cap;
@@ -1175,11 +1096,17 @@ int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree*
         hipLaunchKernelGGL(k_loop_xe, dim3(nbcap), dim3(256), 0, st, (const int32_t*)s.ctl_i_dev, (const double*)s.scores_dev,
                            (const int32_t*)s.nn_idx_dev, (const uint8_t*)s.valid_dev, s.softmax, s.unit_weights, s.x_dev, s.e_dev, bsum, bmax, bmin,
                            bkept, bnan);
-        hipLaunchKernelGGL(k_loop_weights, dim3(nbcap), dim3(256), 0, st, s.ctl_i_dev, s.ctl_d_dev, (int32_t)(cap < (1 << 30) ? cap : (1 << 30)), (const double*)bsum,
-                           (const double*)bmax, (const double*)bmin, (const int32_t*)bkept, (const int32_t*)bnan,
-                           (const double*)s.x_dev, (const double*)s.e_dev, (const uint8_t*)s.valid_dev,
-                           (const int32_t*)s.nn_idx_dev, s.cb_poses_dev, s.poses_prop_dev, s.weights_dev, s.src_dev,
-                           (const double*)(pa.gt16 ? s.part_rmse_dev : nullptr), s.softmax);
+        wa.ctl_i = s.ctl_i_dev; wa.ctl_d = s.ctl_d_dev; wa.grid_n = (int32_t)(cap < (1 << 30) ? cap : (1 << 30)); wa.nbl = (int32_t)nbcap;
+        wa.bsum = bsum; wa.bmax = bmax; wa.bmin = bmin; wa.bkept = bkept; wa.bnan = bnan;
+        wa.x = (const double*)s.x_dev; wa.e = (const double*)s.e_dev; wa.valid = (const uint8_t*)s.valid_dev;
+        wa.nn_idx = (const int32_t*)s.nn_idx_dev; wa.cb_poses = s.cb_poses_dev; wa.poses_prop = s.poses_prop_dev;
+        wa.w_out = s.weights_dev; wa.src = s.src_dev; wa.part_rmse = (const double*)(pa.gt16 ? s.part_rmse_dev : nullptr);
+        wa.softmax = s.softmax;
+        // the weights at the head of the cluster-moment launch when that launch follows in this call with nothing in between
+        // (DBSCAN reads the re-projected poses: frames that cluster keep the launch of their own)
+        static const bool merge_env = !(getenv("MIDAS_LOOP_MERGE") && atoi(getenv("MIDAS_LOOP_MERGE")) == 0);
+        weights_merged = merge_env && (phases & MIDAS_LOOP_ANNEAL) && !(phases & MIDAS_LOOP_DBSCAN);
+        if (!weights_merged) hipLaunchKernelGGL(k_loop_weights, dim3(nbcap), dim3(256), 0, st, wa);
         LAUNCH_CHECK(ctx);
     }
     if (phases & MIDAS_LOOP_DBSCAN) {
@@ -1197,7 +1124,7 @@ int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree*
         SelectScratch ss;
         if ((rc = select_scratch(ctx, cap, ss))) return rc;
         if ((rc = launch_loop_cluster(ctx, cap, s.ctl_i_dev, s.poses_prop_dev, s.weights_dev, s.labels_dev, (double*)part, (float*)cen,
-                                      (float*)sd, (int64_t*)cnt, (double*)rot)))
+                                      (float*)sd, (int64_t*)cnt, (double*)rot, weights_merged ? &wa : nullptr)))
             return rc;
         if (s.anneal_small && cap <= LOOP_SMALL_MAX) {
             hipLaunchKernelGGL(k_loop_anneal_small<true>, dim3(2), dim3(1024), 0, st, s.ctl_i_dev, s.ctl_d_dev, (const float*)cen, (const float*)sd,

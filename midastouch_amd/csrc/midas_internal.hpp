@@ -443,8 +443,10 @@ int launch_cluster_centers(midas_ctx* ctx, int64_t N, const float* poses, const 
                            const int64_t* labels, int32_t C, const int64_t* label_values, float* centers, float* stds,
                            int64_t* counts);
 
+struct LoopWeightsArgs;  // loop_weights.hpp
 int launch_loop_cluster(midas_ctx* ctx, int64_t cap, const int32_t* ctl_i, const float* poses, const double* w64,
-                        const int32_t* labels, double* part, float* centers, float* stds, int64_t* counts, double* rot);
+                        const int32_t* labels, double* part, float* centers, float* stds, int64_t* counts, double* rot,
+                        const LoopWeightsArgs* weights = nullptr);  // weights: computed at the head of the moment launch (loop.hip)
 
 // loop.hip / dbscan.hip - the reference's whole loop body on a variable-size particle set (midas_loop_step)
 int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* t6, const midas_tree* t3,

@@ -2080,8 +2080,7 @@ static_assert(NN_SOLO == 32 && MESH_SOLO == 16, "the group scans fetch 32 / 16 r
 #define MIDAS_NNP_OCC 2  // the two-kernel form only serves small sets now (<= 10 240 particles, the loop step): registers over occupancy
 #endif
 template <int LPP>
-__global__ __launch_bounds__(256, MIDAS_NNP_OCC) void k_particle_nn_prune(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a,
-                                                                          const PuFeat* __restrict__ feat) {
+MD void particle_nn_prune_wg(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, ParticleUpdateArgs a, const PuFeat* __restrict__ feat) {
     static_assert(LPP == 4 || LPP == 2, "lanes per particle");
     // quad_perm selectors inside a group of LPP lanes: broadcast of its first / last lane
     constexpr int BC_FIRST = LPP == 4 ? 0x00 : 0xA0, BC_LAST = LPP == 4 ? 0xFF : 0xF5;
@@ -2225,6 +2224,23 @@ __global__ __launch_bounds__(256, MIDAS_NNP_OCC) void k_particle_nn_prune(TreeVi
         a.nn_idx[p] = nn;
         a.valid[p] = ok ? 1 : 0;
     }
+}
+
+template <int LPP>
+__global__ __launch_bounds__(256, MIDAS_NNP_OCC) void k_particle_nn_prune(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a,
+                                                                          const PuFeat* __restrict__ feat) {
+    particle_nn_prune_wg<LPP>(t6, t3, a, feat);
+}
+
+// Both parts in ONE launch for the loop step's small sets (no folded resample, sparse scoring: no streaming workgroups): a
+// workgroup's first wave is part A for the 64 particles the workgroup's four waves then search with four lanes each.  Part A is
+// a chain of round trips that one wave per 64 particles carries as well as four waves per 256 did; what goes is a launch
+// boundary (~4 us of a frame of 85) and the first touch of the hand-over records by another launch.
+__global__ __launch_bounds__(256, MIDAS_NNP_OCC) void k_front_small(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a, int nwaves,
+                                                                    PuFeat* __restrict__ feat) {
+    if (threadIdx.x < 64 && (int)blockIdx.x < nwaves) particle_front_wave(a, (int64_t)blockIdx.x, nullptr, feat);
+    __syncthreads();  // (drains the first wave's stores of the hand-over records: the other waves read them through the L2)
+    particle_nn_prune_wg<4>(t6, t3, a, feat);
 }
 
 // =================================================================================================
@@ -2705,6 +2721,14 @@ int launch_frame_front(midas_ctx* ctx, const midas_tree* t6, const midas_tree* t
         void* feat;
         int rc = midas_scratch(ctx, (size_t)a.N * sizeof(PuFeat), &feat);
         if (rc) return rc;
+        static const bool small_env = !(getenv("MIDAS_FRONT_SMALL") && atoi(getenv("MIDAS_FRONT_SMALL")) == 0);
+        if (small_env && !a.rs.enabled && a.sp.stamps && lpp == 4) {  // (no streaming workgroups beside part A: grid == n_pu)
+            hipLaunchKernelGGL(k_front_small, dim3((unsigned)ceil_div(a.N, 64)), dim3(256), 0, ctx->stream, view_of<Kd6>(t6), view_of<Kd3>(t3),
+                               a, nwaves, (PuFeat*)feat);
+            MIDAS_HIP_CHECK(ctx, hipGetLastError());
+            *launched = true;
+            return MIDAS_OK;
+        }
 #define MIDAS_FRONT_A(NJ)                                                                                            \
     if (a.rs.enabled)                                                                                                \
         hipLaunchKernelGGL((k_frame_front_a<float, NJ, true>), dim3(grid), dim3(256), 0, ctx->stream, a, n_pu, nwaves,  \
