@@ -6,6 +6,13 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from midastouch_amd.config import load_config
 from midastouch_amd.filter import filter as run_filter, synthetic_sequence
+from midastouch_amd import loop_engine
+if os.environ.get("MAX_AHEAD"):  # experiment: frames the host may run ahead of the device's last report
+    _init = loop_engine.LoopEngine.__init__
+    def _patched(self, *a, **k):
+        _init(self, *a, **k)
+        self.max_ahead = int(os.environ["MAX_AHEAD"])
+    loop_engine.LoopEngine.__init__ = _patched
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 floor = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 cfg = load_config([f"expt.params.num_particles={N}", "expt.codebook_size=50000", "tcn.model.output_dim=512"])
