@@ -1939,7 +1939,7 @@ __global__ __launch_bounds__(64) void k_particle_update(TreeView<Kd6> t6, TreeVi
 #define MIDAS_FRONT_OCC 1  // waves per SIMD the single-trajectory forms are compiled for (1 = no register cap: 234 registers, two waves)
 #endif
 #ifndef MIDAS_FRONT4_OCC
-#define MIDAS_FRONT4_OCC 4  // ... and the four-wave workgroups of sets beyond 131 072 particles: several rounds of waves, four a SIMD (c3, N = 1 M: 190 -> 181 us; 3: no gain)
+#define MIDAS_FRONT4_OCC 4  // ... and the four-wave workgroups with workgroup-level tables = sets beyond 131 072 particles: several rounds of waves, four a SIMD (c3, N = 1 M: 190 -> 181 us; 3: no gain).  NOT the four-wave form of the dense front at smaller N (per-wave tables): one round of waves, the cap cost it 4 us of 29
 #endif
 #ifndef MIDAS_BATCH_OCC
 #define MIDAS_BATCH_OCC 1  // waves per SIMD the batch form (SCR = false) is compiled for (1 = no register cap)
@@ -1953,7 +1953,7 @@ __device__ long long g_ff_clk[16384];  // per frame parity and workgroup: start,
 #define FF_END do { } while (0)
 #endif
 template <typename T, int NJ, int LAZY, int FW, bool SCR = true, bool PREF = false, bool STATS = false>
-__global__ __launch_bounds__(64 * FW, (!SCR && FW == 1) ? MIDAS_BATCH_OCC : FW == 4 ? MIDAS_FRONT4_OCC : MIDAS_FRONT_OCC) void k_frame_front(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a,
+__global__ __launch_bounds__(64 * FW, (!SCR && FW == 1) ? MIDAS_BATCH_OCC : (FW == 4 && LAZY == 1) ? MIDAS_FRONT4_OCC : MIDAS_FRONT_OCC) void k_frame_front(TreeView<Kd6> t6, TreeView<Kd3> t3, ParticleUpdateArgs a,
                                                          int n_pu, int nwaves, const T* __restrict__ emb,
                                                          const double* __restrict__ norms, const double* __restrict__ code,
                                                          double* __restrict__ scores, int64_t K) {
