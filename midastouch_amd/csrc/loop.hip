@@ -5,15 +5,17 @@
 // (ctl_i[LOOP_I_N]); every kernel is launched over the capacity of the arrays and reads the live count itself, so a frame
 // needs no host round trip:
 //
-//   FRONT     k_frame_front (particles.hip, live count from the control block) -> k_loop_xe (scores gathered, softmax
-//             numerators, per-block sums in the spec order) -> k_loop_weights (S, isclose guard, masked weights, drift
-//             re-projection, rmse)
+//   FRONT     k_frame_front (particles.hip, live count from the control block; sets up to 16 384: k_front_small) ->
+//             k_loop_xe (scores gathered, softmax numerators, per-block sums in the spec order) -> k_loop_weights (S,
+//             isclose guard, masked weights, drift re-projection, rmse; loop_weights.hpp - in frames without DBSCAN this
+//             work sits at the head of the cluster-moment launch instead, k_loop_weights_moments in cluster.hip)
 //   DBSCAN    dbscan.hip
-//   ANNEAL    k_loop_cluster_* (cluster.hip) -> k_loop_decide (labels present, var = mean(stds), the annealing rule in
-//             float32 as torch evaluates it) -> k_loop_select x 6 (radix select of the k-th smallest / largest weight,
-//             11-bit digits of the order-preserving 64-bit key) -> k_loop_compact_count / k_loop_compact (the annealed set
-//             as an index list: survivors in their order, or everybody + the k best) -> k_loop_sort_chunks /
-//             k_loop_sort_rank (the duplicates in topk's output order: weight descending, index ascending)
+//   ANNEAL    k_loop_cluster_* (cluster.hip) -> sets up to 16 384: k_loop_anneal_small (decision + selection by one
+//             workgroup, the centres' rotations by a second); larger: k_loop_decide (labels present, var = mean(stds),
+//             the annealing rule in float32 as torch evaluates it) -> k_loop_select x 6 (radix select of the k-th smallest
+//             / largest weight, 11-bit digits of the order-preserving 64-bit key) -> k_loop_compact_count / k_loop_compact
+//             (the annealed set as an index list: survivors in their order, or everybody + the k best) ->
+//             k_loop_sort_chunks / k_loop_sort_rank (the duplicates in topk's output order: weight descending, index ascending)
 //   RESAMPLE  k_loop_scan (blocked prefix sums of (e * valid)[src]) -> k_loop_resample (n_set draws, exact inverse
 //             search on cdf_i = (BP_b + lp_i) / total, gathers through src)
 //
