@@ -21,8 +21,8 @@ _LIB_PATH = os.path.join(_HERE, "libmidas_oracle.so")
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (a few hundred ms)."""
-    src = os.path.join(_HERE, "midas_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("midas_oracle.c", "aten_topk.c")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.run(["make", "-C", _HERE, "-B", "-s"], check=True)
     return _LIB_PATH
 
@@ -394,15 +394,44 @@ def cluster_var(stds):
     return np.float32(s / np.float32(flat.shape[0]))
 
 
+def aten_topk(values, k: int, largest: bool = True, sorted: bool = True, return_fallbacks: bool = False):
+    """`torch.topk(values, k, largest=..., sorted=...).indices` of a 1-d float64 tensor ON THE CPU, ties included:
+    oracle/aten_topk.c restates ATen's `topk_impl_loop` over libstdc++'s partial_sort / nth_element / sort
+    (particle_filter.py:433-441 is the caller).  Pinned against torch.topk by tests/test_aten_topk.py."""
+    v = _f64(values).ravel()
+    out = np.empty(int(k), dtype=np.int64)
+    fb = C.c_int64(0)
+    rc = lib().mo_aten_topk(_p(v), C.c_int64(v.shape[0]), C.c_int64(int(k)), C.c_int(int(bool(largest))), C.c_int(int(bool(sorted))),
+                            _p(out), None, C.byref(fb))
+    if rc != 0:
+        raise ValueError("aten_topk: k out of range")
+    return (out, fb.value) if return_fallbacks else out
+
+
+def aten_topk_killer(n: int, nth: int = 0, for_sort: bool = False):
+    """A permutation of 0..n-1 (float64) on which the median-of-three partition of nth_element (at position `nth`) or of
+    sort degenerates until the depth limit is spent (McIlroy's adversary played against the restatement)."""
+    out = np.empty(int(n), dtype=np.float64)
+    if lib().mo_aten_topk_killer(C.c_int64(int(n)), C.c_int64(int(nth)), C.c_int(int(bool(for_sort))), _p(out)) != 0:
+        raise MemoryError
+    return out
+
+
 class Annealer:
     """particle_filter.annealing (particle_filter.py:405-447) on index sets.
 
     `step(weights, var, floor)` returns the index array (into the current particles) of the
     particles that survive, with duplicates appended for growth - same order as the reference
     (`Particles.remove` keeps the original order, `add` appends in topk order).
+
+    ties: which members of a tie `torch.topk` takes (and in which order it lists them) is the one thing the values do not
+    decide.  "index" = smaller index first (torch's CUDA kernel, the device's default rule); "aten_cpu" = what ATen's CPU
+    kernel does (`aten_topk`: the reference as it runs on the CPU, i.e. what the G13 fixture holds).
     """
 
-    def __init__(self):
+    def __init__(self, ties: str = "index"):
+        assert ties in ("index", "aten_cpu")
+        self.ties = ties
         self.particle_var = float("inf")
         self.init_particles = None
 
@@ -426,7 +455,7 @@ class Annealer:
             num_remove = min(int(np.float32(one - ratio) * np.float32(n)), abs(n - floor), n // 3)
             if not num_remove:
                 return keep
-            order = np.argsort(w, kind="stable")[:num_remove]
+            order = np.argsort(w, kind="stable")[:num_remove] if self.ties == "index" else aten_topk(w, num_remove, largest=False)
             mask = np.ones(n, dtype=bool)
             mask[order] = False
             return keep[mask]
@@ -434,7 +463,7 @@ class Annealer:
             num_increase = min(int(np.float32(ratio - one) * np.float32(n)), n // 3)
             if num_increase + n > self.init_particles:
                 return keep
-            order = np.argsort(-w, kind="stable")[:num_increase]
+            order = np.argsort(-w, kind="stable")[:num_increase] if self.ties == "index" else aten_topk(w, num_increase, largest=True)
             return np.concatenate([keep, order])
         return keep
 
@@ -453,9 +482,9 @@ class OracleLoop:
                  travel on are e / S * mask with S the blocked sum of e over the N particles BEFORE annealing."""
 
     def __init__(self, cb_poses, cb_embeddings, mesh_verts, pen_max=0.002, floor=1000, eps=1e-2, softmax=True, cluster=True,
-                 cluster_every=50):
+                 cluster_every=50, ties="index"):
         self.f = OracleFilter(cb_poses, cb_embeddings, mesh_verts, pen_max)
-        self.annealer = Annealer()
+        self.annealer = Annealer(ties)
         self.floor, self.eps, self.softmax, self.cluster = int(floor), float(eps), bool(softmax), bool(cluster)
         self.cluster_every = int(cluster_every)
         self.count = 0

@@ -66,6 +66,7 @@ def run(pfm, cluster: bool, name: str, init_ratio: float):
     out = {"N0": N0, "K": K, "D": D, "T": T, "cb_seed": CB_SEED, "traj_seed": TRAJ_SEED, "poses0": poses.copy(),
            "cluster": np.bool_(cluster), "cb_sha": np.str_(sha(cb.embeddings.astype(np.float32)))}
     oracle_ann = orc.Annealer()
+    aten_ann = orc.Annealer(ties="aten_cpu")  # the restatement of ATen's CPU top-k: must make the reference's choice in EVERY frame
     ties = 0
     for t in range(1, T + 1):
         N = poses.shape[0]
@@ -108,6 +109,7 @@ def run(pfm, cluster: bool, name: str, init_ratio: float):
             keep = shadow.annealing(marker, var).labels.numpy().astype(np.int64)
             assert len(keep) == len(parts) and torch.equal(parts.poses, torch.tensor(prop)[keep])
             spec_keep = oracle_ann.step(w_pruned, np.float32(var.item()))
+            assert np.array_equal(aten_ann.step(w_pruned, np.float32(var.item())), keep), f"frame {t}: aten_topk restatement differs from torch.topk"
             tie = not np.array_equal(spec_keep, keep)
             if tie:  # the two choices must differ only among equal weights
                 assert len(spec_keep) == len(keep) and np.array_equal(np.sort(w_pruned[spec_keep]), np.sort(w_pruned[keep])), t
