@@ -718,6 +718,11 @@ typedef struct midas_loop_args {
                                     * grid_n particles (annealing grows the set by at most n / 3 per frame, so a count seen L frames
                                     * ago bounds today's by (4/3)^L); ctl_i[ERR] |= 4 if the bound was wrong */
     int32_t anneal_small;          /* 1: grid_n <= 16384 - one workgroup runs decide + select + compaction + sort (same results) */
+    int32_t topk_ties;             /* MIDAS_TOPK_TIES_INDEX (0): ties of annealing's torch.topk go to the smaller index (torch's CUDA
+                                    * kernel; the fast radix select).  MIDAS_TOPK_TIES_ATEN_CPU (1): the members - and for duplicates
+                                    * the order - ATen's CPU kernel picks (std::partial_sort when k * 64 <= n, else std::nth_element +
+                                    * std::sort, walked move for move by one wave: topk_aten.hip), i.e. what the reference keeps when it
+                                    * runs on the CPU under a fixed seed (modules/particle_filter.py:433-441) */
 } midas_loop_args;
 int midas_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
                     const midas_loop_args* args, int32_t phases);
@@ -741,6 +746,14 @@ int midas_dbscan_points(midas_ctx* ctx, int64_t N, int32_t dim, const double* po
  * smallest weight, in their order (n_set = N - k); mode 2: all N followed by the k of largest weight, largest first
  * (n_set = N + k; src_dev holds N + k entries).  Ties go to the smaller index.  0 <= k <= N / 3.  weights_dev: N float64. */
 int midas_anneal_select(midas_ctx* ctx, int64_t N, const double* weights_dev, int32_t mode, int64_t k, int32_t* src_dev);
+/* The same with the tie rule chosen (modules/particle_filter.py:433-441, `torch.topk(particles.weights, k, largest=...)`):
+ * ties = MIDAS_TOPK_TIES_INDEX is midas_anneal_select; MIDAS_TOPK_TIES_ATEN_CPU returns exactly the set (mode 1) / the list
+ * (mode 2) torch.topk returns on the CPU, whichever members of a tie that is.  info_dev: NULL or 1 int32 the call ADDS the
+ * number of depth-limit fallbacks to (heap select inside nth_element, heap sort inside sort; tests). */
+#define MIDAS_TOPK_TIES_INDEX 0
+#define MIDAS_TOPK_TIES_ATEN_CPU 1
+int midas_anneal_select_ties(midas_ctx* ctx, int64_t N, const double* weights_dev, int32_t mode, int64_t k, int32_t ties,
+                             int32_t* src_dev, int32_t* info_dev);
 
 /* B concurrent trajectories against one codebook (BASELINE config 5, "throughput mode"): every per-trajectory
  * array of `args` carries a leading batch dimension, contiguous - poses (B,N,16), weights (B,N), hints (B,N),

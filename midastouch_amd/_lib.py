@@ -171,12 +171,13 @@ class LoopArgs(C.Structure):
         ("softmax", C.c_int32), ("resample_mode", C.c_int32), ("floor", C.c_int32), ("eps", C.c_double),
         ("unit_weights", C.c_int32), ("telemetry", C.c_void_p),
         ("score_stamps", C.c_void_p), ("score_epoch", C.c_uint32),
-        ("host_mirror", C.c_void_p), ("grid_n", C.c_int64), ("anneal_small", C.c_int32),
+        ("host_mirror", C.c_void_p), ("grid_n", C.c_int64), ("anneal_small", C.c_int32), ("topk_ties", C.c_int32),
     ]
 
 
 # phases of midas_loop_step and the control-block indices (include/midas_hip.h MIDAS_LOOP_*)
 LOOP_FRONT, LOOP_DBSCAN, LOOP_ANNEAL, LOOP_RESAMPLE = 1, 2, 4, 8
+TOPK_TIES_INDEX, TOPK_TIES_ATEN_CPU = 0, 1  # whom annealing's torch.topk takes inside a tie (include/midas_hip.h)
 LOOP_MAX_CLUSTERS, LOOP_LOG_DOUBLES = 64, 168
 (LOOP_I_N, LOOP_I_NSET, LOOP_I_MODE, LOOP_I_K, LOOP_I_INIT, LOOP_I_VARSET, LOOP_I_KEPT, LOOP_I_DRIFT, LOOP_I_STATUS,
  LOOP_I_RAW, LOOP_I_NCL, LOOP_I_NPRES, LOOP_I_FRAME, LOOP_I_NAN, LOOP_I_ERR) = range(15)
@@ -237,6 +238,7 @@ SIGNATURES = {
     "midas_dbscan": (C.c_int, [_P, _I64, _P, _D, _I64, _P, _P]),
     "midas_dbscan_points": (C.c_int, [_P, _I64, C.c_int32, _P, _D, _I64, _P, _P]),
     "midas_anneal_select": (C.c_int, [_P, _I64, _P, _I32, _I64, _P]),
+    "midas_anneal_select_ties": (C.c_int, [_P, _I64, _P, _I32, _I64, _I32, _P, _P]),
     "midas_shard_front": (C.c_int, [_P, _P, _P, _P, C.POINTER(ShardFrontArgs)]),
     "midas_shard_tail_a": (C.c_int, [_P, _I64, _P, _P, _P, _I32, _P, _P, _P]),
     "midas_shard_tail_fin": (C.c_int, [_P, _I64, _P, _P, _P, _P, _I32, _P, _I32, _I64, _I32, _P, _P]),

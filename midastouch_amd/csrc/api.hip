@@ -133,7 +133,7 @@ MIDAS_EXPORT int midas_ctx_create(int device, void* hip_stream, midas_ctx** out)
     const char* lazy = getenv("MIDAS_LAZY_MODULES");
     if (!(lazy && lazy[0] == '1')) {
         int (*const warm[])() = {warm_score, warm_particles, warm_resample, warm_cluster, warm_topn, warm_selfsim, warm_loop,
-                                 warm_dbscan, warm_dbscan_nd, warm_index_build, warm_mt19937};
+                                 warm_dbscan, warm_dbscan_nd, warm_index_build, warm_mt19937, warm_topk_aten};
         for (auto w : warm)
             if (w() != 0) { (void)hipGetLastError(); }  // not fatal: the unit then loads at its first launch, as before
     }
@@ -1276,7 +1276,15 @@ MIDAS_EXPORT int midas_anneal_select(midas_ctx* ctx, int64_t N, const double* we
     MIDAS_ENTER(ctx);
     MIDAS_REQUIRE(ctx, N > 0 && ceil_div(N, SCAN_BLOCK) <= LAZY_MAX_BLOCKS && weights_dev && src_dev && (mode == 1 || mode == 2) &&
                            k >= 0 && k <= N / 3);
-    return launch_anneal_select(ctx, N, weights_dev, k == 0 ? 0 : mode, k, src_dev);
+    return launch_anneal_select(ctx, N, weights_dev, k == 0 ? 0 : mode, k, MIDAS_TOPK_TIES_INDEX, src_dev, nullptr);
+}
+
+MIDAS_EXPORT int midas_anneal_select_ties(midas_ctx* ctx, int64_t N, const double* weights_dev, int32_t mode, int64_t k, int32_t ties,
+                                          int32_t* src_dev, int32_t* info_dev) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, N > 0 && ceil_div(N, SCAN_BLOCK) <= LAZY_MAX_BLOCKS && weights_dev && src_dev && (mode == 1 || mode == 2) &&
+                           k >= 0 && k <= N / 3 && (ties == MIDAS_TOPK_TIES_INDEX || ties == MIDAS_TOPK_TIES_ATEN_CPU));
+    return launch_anneal_select(ctx, N, weights_dev, k == 0 ? 0 : mode, k, ties, src_dev, info_dev);
 }
 
 MIDAS_EXPORT int midas_dbscan(midas_ctx* ctx, int64_t N, const float* poses_dev, double eps, int64_t min_samples,

@@ -20,7 +20,8 @@
 //             search on cdf_i = (BP_b + lp_i) / total, gathers through src)
 //
 // Spec (oracle/oracle.py OracleLoop): identical to midas_filter_step where the two overlap; ties of the top-k selection go
-// to the smaller index.
+// to the smaller index (torch's CUDA rule), or - midas_loop_args.topk_ties = MIDAS_TOPK_TIES_ATEN_CPU, the mode that replays a
+// seeded run of the reference - to the members ATen's CPU kernel takes (topk_aten.hip).
 #include <cstdlib>
 
 #include "midas_internal.hpp"
@@ -1051,13 +1052,14 @@ __global__ __launch_bounds__(256) void k_loop_identity(int32_t n, int32_t* __res
     if (i < n) src[i] = i;
 }
 
-int launch_anneal_select(midas_ctx* ctx, int64_t N, const double* w, int32_t mode, int64_t k, int32_t* src) {
+int launch_anneal_select(midas_ctx* ctx, int64_t N, const double* w, int32_t mode, int64_t k, int32_t ties, int32_t* src, int32_t* info) {
     void* ctl;
     int rc;
     if ((rc = midas_scratch(ctx, 32 * sizeof(int32_t), &ctl))) return rc;
     SelectScratch ss;
     if ((rc = select_scratch(ctx, N, ss))) return rc;
     hipLaunchKernelGGL(k_anneal_plan, dim3(1), dim3(256), 0, ctx->stream, (int32_t*)ctl, ss.hist, ss.state, (int32_t)N, mode, (int32_t)k);
+    if (ties == MIDAS_TOPK_TIES_ATEN_CPU) return launch_topk_aten(ctx, N, (const int32_t*)ctl, w, src, info);
     const char* small = getenv("MIDAS_ANNEAL_SMALL");  // tests: the single-workgroup path on the same plan
     if (N <= LOOP_SMALL_MAX && small && atoi(small)) {
         hipLaunchKernelGGL(k_loop_identity, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, (int32_t)N, src);
@@ -1151,7 +1153,11 @@ int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree*
         if ((rc = launch_loop_cluster(ctx, cap, s.ctl_i_dev, s.poses_prop_dev, s.weights_dev, s.labels_dev, (double*)part, (float*)cen,
                                       (float*)sd, (int64_t*)cnt, (double*)rot, weights_merged ? &wa : nullptr)))
             return rc;
-        if (s.anneal_small && cap <= LOOP_SMALL_MAX) {
+        if (s.topk_ties == MIDAS_TOPK_TIES_ATEN_CPU) {  // the reference's CPU tie choices (topk_aten.hip); the decision as always
+            hipLaunchKernelGGL(k_loop_decide, dim3(2), dim3(256), 0, st, s.ctl_i_dev, s.ctl_d_dev, (const float*)cen, (const float*)sd,
+                               (const int64_t*)cnt, s.cluster_poses_dev, s.cluster_stds_dev, ss.hist, ss.state, s.floor, (const double*)rot);
+            if ((rc = launch_topk_aten(ctx, cap, s.ctl_i_dev, s.weights_dev, s.src_dev, nullptr))) return rc;
+        } else if (s.anneal_small && cap <= LOOP_SMALL_MAX) {
             hipLaunchKernelGGL(k_loop_anneal_small<true>, dim3(2), dim3(1024), 0, st, s.ctl_i_dev, s.ctl_d_dev, (const float*)cen, (const float*)sd,
                                (const int64_t*)cnt, s.cluster_poses_dev, s.cluster_stds_dev, s.floor, (const double*)s.weights_dev, s.src_dev,
                                (const double*)rot);

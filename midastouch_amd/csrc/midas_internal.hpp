@@ -151,7 +151,7 @@ int midas_set_error(midas_ctx* ctx, int code, const char* what, const char* deta
 namespace midas {
 MIDAS_WARM_DECL(score) MIDAS_WARM_DECL(particles) MIDAS_WARM_DECL(resample) MIDAS_WARM_DECL(cluster) MIDAS_WARM_DECL(topn)
 MIDAS_WARM_DECL(selfsim) MIDAS_WARM_DECL(loop) MIDAS_WARM_DECL(dbscan) MIDAS_WARM_DECL(dbscan_nd) MIDAS_WARM_DECL(index_build)
-MIDAS_WARM_DECL(mt19937)
+MIDAS_WARM_DECL(mt19937) MIDAS_WARM_DECL(topk_aten)
 }  // namespace midas
 
 // scratch carve-out (stream-ordered reuse; one stream per context)
@@ -453,7 +453,8 @@ int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree*
                      const midas_loop_args& a, int32_t phases);
 // src[0 .. n_set): the annealed particle set as indices - mode 1: the N particles minus the k of smallest weight, in
 // order; mode 2: all N followed by the k of largest weight, best first; ties to the smaller index
-int launch_anneal_select(midas_ctx* ctx, int64_t N, const double* w, int32_t mode, int64_t k, int32_t* src);
+int launch_anneal_select(midas_ctx* ctx, int64_t N, const double* w, int32_t mode, int64_t k, int32_t ties, int32_t* src, int32_t* info);
+int launch_topk_aten(midas_ctx* ctx, int64_t cap, const int32_t* ci, const double* w, int32_t* src, int32_t* info);
 // labels_out[i] in [-1, ncl) for the n = *n_dev (or N when n_dev is null) poses; min_samples < 0 -> n / 5 (cluster_particles);
 // ncl_out[0] = number of clusters; err_out (nullable) |= 2 when the grid / cluster limits were exceeded
 int launch_dbscan_points(midas_ctx* ctx, int64_t N, int32_t dim, const double* pts, double eps, int64_t min_samples, int32_t* labels, int32_t* info);

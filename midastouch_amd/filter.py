@@ -104,7 +104,8 @@ def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str
     draws="device" (default): Philox streams on the device, frames are enqueued back to back.  draws="host": the
     reference's own random streams - torch.normal tn, rot and the resampler's torch.rand on the CPU generator, in its
     order - which needs the particle count on the host twice per frame (bit-parity with the reference under
-    torch.manual_seed, at the price of those read-backs and of the host generator).
+    torch.manual_seed, at the price of those read-backs and of the host generator); annealing's top-k then also resolves its
+    ties the way torch.topk does on the CPU (LoopEngine(topk_ties="aten_cpu")), so the particle SET is the reference's too.
     pace="fixed" steps one frame per iteration; pace="wallclock" reproduces `idx = int(frame_rate * total_time)`
     (:134-135: slow iterations skip frames, fast ones repeat) and therefore waits for every frame.
     The defaults are `filter/filter.py`'s; `filter_real(...)` presets the real-data script's variations
@@ -132,7 +133,7 @@ def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str
         pf._mesh_tree = seq.mesh_tree
     eng = LoopEngine(codebook, None, pf.mesh_kdtree, init_particles, sig_t=pf.motion_noise["sig_t"], sig_r=pf.motion_noise["sig_r"],
                      pen_max=pf.pen_max, seed=seed, softmax=softmax, floor=floor, cluster=cluster, log_frames=max(traj_size + 8, 64),
-                     device=device)
+                     device=device, topk_ties="aten_cpu" if draws == "host" else "index")
     # odom = inv(meas[prev]) @ meas[idx] (:154): the inverses in one call, and - frame after frame in fixed pace - the
     # products too (a 4x4 product per frame through the BLAS library costs more device time than the whole frame's kernels)
     inv_meas = torch.linalg.inv(meas_p)

@@ -12,7 +12,9 @@ results (rmse, N, cluster centres ...) go to a device log that is read once, whe
 Draws: device Philox streams keyed by (seed, frame) by default; `tn` / `rot` / `u` take the host draws of the reference
 (torch CPU generator, its order: tn, rot, then the resampler's uniforms) - the host then has to know the particle count,
 i.e. `n` (one small read-back per frame), and may split the frame with `phases` to draw the uniforms once the annealed
-size is known, as the reference does.
+size is known, as the reference does.  Such a replay also wants `topk_ties="aten_cpu"`: inside a tie (the normal case:
+particles on one codebook entry share a weight) annealing's `torch.topk` keeps whomever ATen's CPU kernel happens to reach,
+and the device then walks that kernel's algorithm (topk_aten.hip) instead of its own radix select (ties by index).
 """
 from __future__ import annotations
 
@@ -33,7 +35,8 @@ ALL_PHASES = _lib.LOOP_FRONT | _lib.LOOP_DBSCAN | _lib.LOOP_ANNEAL | _lib.LOOP_R
 class LoopEngine:
     def __init__(self, cb_poses, cb_embeddings, mesh_vertices, num_particles: int, *, sig_t=2e-4, sig_r=0.5, pen_max=0.002,
                  seed=4000, softmax=True, resample="weighted_random", floor: int = 1000, eps: float = 1e-2, cluster: bool = True,
-                 cluster_every: int = 50, log_frames: int = 4096, device=None):
+                 cluster_every: int = 50, log_frames: int = 4096, device=None,
+                 topk_ties: str = "index"):
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.ctx = _lib.context(dev)
         self.device = d = self.ctx.device
@@ -52,6 +55,9 @@ class LoopEngine:
         self.sig_t, self.sig_r, self.pen_max = float(sig_t), float(sig_r), float(pen_max)
         self.seed, self.softmax, self.floor, self.eps = int(seed), bool(softmax), int(floor), float(eps)
         self.cluster, self.cluster_every = bool(cluster), max(int(cluster_every), 1)
+        # whom annealing's torch.topk takes inside a tie: "index" (torch's CUDA rule, the radix select) or "aten_cpu" (the
+        # reference as it runs on the CPU - the rule of a seeded replay; topk_aten.hip)
+        self.topk_ties = {"index": _lib.TOPK_TIES_INDEX, "aten_cpu": _lib.TOPK_TIES_ATEN_CPU}[topk_ties]
         self.mode = {"weighted_random": _lib.RESAMPLE_MULTINOMIAL, "low_var": _lib.RESAMPLE_SYSTEMATIC,
                      "low_var_batch": _lib.RESAMPLE_SYSTEMATIC}[resample]
         self.cap = cap = int(num_particles)
@@ -246,6 +252,7 @@ class LoopEngine:
         a.host_mirror = C.c_void_p(self._mirror.data_ptr())
         a.grid_n = self._grid_n
         a.anneal_small = int(self._grid_n <= 16384)
+        a.topk_ties = self.topk_ties
         a.telemetry = _ptr(self.telemetry)
         if self.sparse_scores and phases & _lib.LOOP_FRONT:
             from .engine import advance_epoch

@@ -301,13 +301,16 @@ def dbscan_points(points: torch.Tensor, eps: float = 1e-2, min_samples: int = -1
     return labels, info
 
 
-def anneal_select(weights: torch.Tensor, mode: int, k: int) -> torch.Tensor:
+def anneal_select(weights: torch.Tensor, mode: int, k: int, ties: str = "index", info: torch.Tensor = None) -> torch.Tensor:
     """Index list of the annealed particle set (particle_filter.py:421-446): mode 1 = without the k smallest weights (order
-    kept), mode 2 = everybody followed by the k largest (largest first); ties to the smaller index."""
+    kept), mode 2 = everybody followed by the k largest (largest first).  ties: "index" = to the smaller index (torch's CUDA
+    kernel), "aten_cpu" = the members / the order `torch.topk` returns on the CPU (topk_aten.hip).  info: optional int32[1]
+    the call adds its depth-limit fallbacks to."""
     w = weights.double().contiguous()
     n = w.shape[0]
     src = torch.empty(n + (k if mode == 2 else 0), dtype=torch.int32, device=w.device)
-    _ctx(w).call("midas_anneal_select", n, _ptr(w), int(mode), int(k), _ptr(src))
+    rule = {"index": _lib.TOPK_TIES_INDEX, "aten_cpu": _lib.TOPK_TIES_ATEN_CPU}[ties]
+    _ctx(w).call("midas_anneal_select_ties", n, _ptr(w), int(mode), int(k), rule, _ptr(src), _ptr(info))
     return src[:n - k] if mode == 1 else src
 
 

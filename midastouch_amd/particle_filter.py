@@ -108,6 +108,7 @@ class particle_filter:
 
         self.motion_noise = {"mu": 0, "sig_r": _noise("noise_r"), "sig_t": _noise("noise_t")}
         self.particle_var = torch.tensor([float("inf")])
+        self.topk_ties = "index"  # annealing(): whom torch.topk takes inside a tie ("aten_cpu": as the reference on the CPU)
         self.init_noise = [self.mesh_diagonal() / 3.0 * noise, 180.0 / 3.0 * noise]  # (:124-127)
 
     # ---------------------------------------------------------------------------------------------
@@ -263,15 +264,15 @@ class particle_filter:
         return None
 
     def annealing(self, _particles: Particles, var, floor: int = 1000) -> Particles:
-        """Adapt the particle count to the cluster spread (:405-447).  The selection runs on the device
-        (midas_anneal_select: radix select of the k-th weight, compaction of the survivors in their order or the k best
-        appended best-first; ties to the smaller index, as torch.topk resolves them on CUDA) and comes back as one index
-        list the three arrays are gathered through."""
+        """Adapt the particle count to the cluster spread (:405-447).  The selection runs on the device and comes back as one
+        index list the three arrays are gathered through.  `self.topk_ties`: "index" (default) - radix select of the k-th
+        weight, ties to the smaller index, as torch.topk resolves them on CUDA; "aten_cpu" (set by seed_device_stream, the
+        mode that replays the reference's CPU run) - the members and the order torch.topk returns on the CPU (topk_aten.hip)."""
         particles = copy.copy(_particles)
         plan = self._anneal_plan(len(particles.weights), var, floor)
         if plan is None:
             return particles
-        src = ops.anneal_select(particles.weights, *plan)
+        src = ops.anneal_select(particles.weights, *plan, ties=self.topk_ties)
         self.last_anneal_indices = src
         particles.poses = ops.gather_rows(particles.poses, src)
         particles.weights = ops.gather_rows(particles.weights, src)
@@ -283,9 +284,11 @@ class particle_filter:
         """torch.manual_seed(seed) for the resampler's draws, kept on the device: `resampler("weighted_random")` then takes
         the uniforms torch.multinomial would consume (modules/particle_filter.py:245) from the device replica of torch's
         CPU generator (midastouch_amd/torch_rng.py) - the reference's indices bit for bit, nothing generated on the host.
-        `seed=None` returns to the host generator."""
+        `seed=None` returns to the host generator.  A seeded run replays the reference on the CPU, so `annealing` then
+        also takes torch.topk's CPU choice inside a tie (`topk_ties`)."""
         from .torch_rng import TorchCpuStream
         self.torch_stream = None if seed is None else TorchCpuStream(seed, self.device)
+        self.topk_ties = "index" if seed is None else "aten_cpu"
         return self.torch_stream
 
     def resampler(self, _particles: Particles, resample: str = "weighted_random") -> Particles:

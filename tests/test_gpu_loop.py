@@ -295,9 +295,10 @@ def test_loop_engine_free_running_vs_oracle(dev, oracle, N0, mode, cluster):
 
 def test_loop_engine_replays_reference_loop_trace(dev, golden, oracle):
     """G13 (the reference's loop body with DBSCAN + annealing, N0 = 4096, 64 frames) with the reference's host draws in
-    its order - tn, rot, then, once the annealed size is known, the resampler's uniforms (the frame is split there).  Every
-    frame starts from the trace's own state; frames whose top-k the reference decided inside a tie follow the index
-    rule and are compared with the oracle under that rule, all others with the reference's digests too."""
+    its order - tn, rot, then, once the annealed size is known, the resampler's uniforms (the frame is split there) - and
+    `topk_ties="aten_cpu"`: annealing's torch.topk decides 60 of the 64 frames inside a tie, and the device keeps the
+    particles the reference kept - the kept-set and resample-index digests the REFERENCE wrote hold in ALL 64 frames, the run
+    carries on from its own state through the oracle's loop under the same rule (no teacher forcing of the choice)."""
     from midastouch_amd import _lib
     from midastouch_amd.loop_engine import LoopEngine
     from midastouch_amd.synthetic import make_codebook, make_trajectory
@@ -305,11 +306,53 @@ def test_loop_engine_replays_reference_loop_trace(dev, golden, oracle):
     cb = make_codebook(K=int(g["K"]), D=int(g["D"]), seed=int(g["cb_seed"]), mesh_points=20000)
     T, N0 = int(g["T"]), int(g["N0"])
     traj = make_trajectory(cb, T=T + 1, seed=int(g["traj_seed"]))
+    loop = oracle.OracleLoop(cb.poses, cb.embeddings, cb.mesh_vertices, ties="aten_cpu")
+    eng = LoopEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N0, device=dev, topk_ties="aten_cpu")
+    poses, labels = g["poses0"], np.zeros(N0, dtype=np.int64)
+    tie_frames = 0
+    for t in range(1, T + 1):
+        n = poses.shape[0]
+        eng.set_particles(torch.as_tensor(poses), torch.as_tensor(labels), reset_annealing=False)
+        eng.set_annealing_state(float(loop.annealer.particle_var), loop.annealer.init_particles or 0)
+        eng.step_count = t - 1
+        torch.manual_seed(3000 + t)
+        tn = torch.normal(mean=0.0, std=2e-4, size=(n, 3))
+        rot = torch.normal(mean=0.0, std=0.5, size=(n, 3))
+        dbs = (t - 1) % 50 == 0
+        eng.step(torch.as_tensor(traj.odoms[t]), torch.as_tensor(traj.codes[t]), gt=torch.as_tensor(traj.gt_poses[t]), tn=tn, rot=rot,
+                 dbscan=dbs, phases=_lib.LOOP_FRONT | _lib.LOOP_DBSCAN | _lib.LOOP_ANNEAL)
+        n2 = int(eng.ctl_i[_lib.LOOP_I_NSET].item())
+        u = torch.rand(n2, dtype=torch.float64)
+        eng.step(None, None, u=u, phases=_lib.LOOP_RESAMPLE)
+        ref = loop.step(poses, labels, traj.odoms[t], traj.codes[t], tn.numpy(), rot.numpy(), gt=traj.gt_poses[t], u=u.numpy())
+        assert ref["N"] == n2 == int(g[f"N2_{t}"])
+        fv = eng.frame_view()
+        _compare_frame(fv, ref, t, dbs)
+        # the reference's own digests, tie or not
+        assert sha(fv["src"].cpu().numpy().astype(np.int32)) == str(g[f"keep_{t}_sha"]), f"frame {t}: kept set is not the reference's"
+        assert sha(fv["ridx"].cpu().numpy().astype(np.int32)) == str(g[f"ridx_{t}_sha"]), f"frame {t}: resample indices are not the reference's"
+        if bool(g[f"tie_{t}"]):
+            assert np.array_equal(fv["src"].cpu().numpy(), g[f"keep_{t}"])
+            tie_frames += 1
+        poses, labels = ref["poses"], ref["labels"]
+    assert tie_frames == 60  # the fixture's count: the index rule would have left the reference's set in every one of them
+
+
+def test_loop_engine_index_rule_on_reference_loop_trace(dev, golden, oracle):
+    """The default rule (ties by index: torch's CUDA kernel, the radix select) on G13's first tie frames: identical to the
+    oracle under that rule, and the kept set differs from the reference's CPU choice only inside the tie."""
+    from midastouch_amd import _lib
+    from midastouch_amd.loop_engine import LoopEngine
+    from midastouch_amd.synthetic import make_codebook, make_trajectory
+    g = golden("g13_loop_trace")
+    cb = make_codebook(K=int(g["K"]), D=int(g["D"]), seed=int(g["cb_seed"]), mesh_points=20000)
+    N0 = int(g["N0"])
+    traj = make_trajectory(cb, T=int(g["T"]) + 1, seed=int(g["traj_seed"]))
     loop = oracle.OracleLoop(cb.poses, cb.embeddings, cb.mesh_vertices)
     eng = LoopEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N0, device=dev)
     poses, labels = g["poses0"], np.zeros(N0, dtype=np.int64)
-    exact_frames = 0
-    for t in range(1, T + 1):
+    seen = 0
+    for t in range(1, 9):
         n = poses.shape[0]
         eng.set_particles(torch.as_tensor(poses), torch.as_tensor(labels), reset_annealing=False)
         eng.set_annealing_state(float(loop.annealer.particle_var), loop.annealer.init_particles or 0)
@@ -326,19 +369,18 @@ def test_loop_engine_replays_reference_loop_trace(dev, golden, oracle):
         tie = bool(g[f"tie_{t}"])
         by_index = copy.deepcopy(loop)
         ref_idx = by_index.step(poses, labels, traj.odoms[t], traj.codes[t], tn.numpy(), rot.numpy(), gt=traj.gt_poses[t], u=u.numpy())
-        assert ref_idx["N"] == n2 == int(g[f"N2_{t}"])
         fv = eng.frame_view()
         _compare_frame(fv, ref_idx, t, dbs)
-        if not tie:  # no tie: the reference's own digests
-            assert sha(fv["src"].cpu().numpy().astype(np.int32)) == str(g[f"keep_{t}_sha"])
-            assert sha(fv["ridx"].cpu().numpy().astype(np.int32)) == str(g[f"ridx_{t}_sha"])
-            exact_frames += 1
+        if tie:
+            w = fv["weights"].cpu().numpy()
+            mine, theirs = fv["src"].cpu().numpy(), g[f"keep_{t}"]
+            assert not np.array_equal(mine, theirs) and np.array_equal(np.sort(w[mine]), np.sort(w[theirs]))
+            seen += 1
         # carry on from the reference's own choice
         ref = loop.step(poses, labels, traj.odoms[t], traj.codes[t], tn.numpy(), rot.numpy(), gt=traj.gt_poses[t], u=u.numpy(),
                         keep_override=g[f"keep_{t}"] if tie else None)
-        assert sha(ref["ridx"].astype(np.int32)) == str(g[f"ridx_{t}_sha"])
         poses, labels = ref["poses"], ref["labels"]
-    assert exact_frames >= 3
+    assert seen >= 3
 
 
 def test_filter_runner_host_draws_matches_oracle_loop(dev, oracle):
@@ -356,7 +398,7 @@ def test_filter_runner_host_draws_matches_oracle_loop(dev, oracle):
     cb_poses, emb = seq.codebook.poses.cpu().numpy(), seq.codebook.embeddings.cpu().numpy()
     gt, meas, codes = seq.gt_p.cpu().numpy(), seq.meas_p.cpu().numpy(), seq.codes.cpu().numpy()
     pf = particle_filter(cfg, seq.mesh_vertices, cfg.expt.params.noise_ratio, downsample=1, device=dev)
-    loop = oracle.OracleLoop(cb_poses, emb, seq.mesh_vertices, floor=300)
+    loop = oracle.OracleLoop(cb_poses, emb, seq.mesh_vertices, floor=300, ties="aten_cpu")  # draws="host" replays the CPU run
     inv = torch.linalg.inv(seq.meas_p).cpu().numpy()
     torch.manual_seed(5)
     prev, poses, labels = 0, None, None
