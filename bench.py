@@ -20,8 +20,8 @@ HIP event per step gives `config.ms_per_step_median / _p95`.
 Single GPU: the pipelined engine - the resample + gather of frame t runs as a prologue of frame t+1's front kernel
 (a per-slot dependence), so every timed step performs one resample (the previous frame's), one propagate / NN /
 prune, one codebook scoring and one softmax / CDF pass and leaves its rmse: the same work per step, two launches instead
-of three, the resampled poses never written to HBM.  The last frame's particle set is materialised after the timed region
-(`eng.status`).  Beside the headline (the fixed-N step of SURVEY.md 8(d)) `config` carries the rates a caller sees who
+of three, the resampled poses never written to HBM.  The K-th frame's resample (nobody's prologue yet) is materialised
+by `eng.flush()` INSIDE the timed region: `value` contains K complete resamples.  Beside the headline (the fixed-N step of SURVEY.md 8(d)) `config` carries the rates a caller sees who
 wants more per frame: `steps_per_sec_materialised_every_frame` (the particle set read after every frame, three launches)
 and `reference_loop_frames_per_sec` (midastouch_amd.filter.filter: the reference's loop with DBSCAN every 50th frame,
 cluster centres and annealing every frame on the device-side particle count, N0 = N).
@@ -568,7 +568,7 @@ def main():
     tree = None
     if not sharded:
         # pipelined: the resample of frame t runs inside the front kernel of frame t+1 (two launches per frame); the
-        # particle set is materialised when it is read - here once, after the timed region (eng.status below)
+        # particle set is materialised when it is read - here once, by the flush at the end of the timed region
         from midastouch_amd.tactile_tree import tactile_tree
         tree = tactile_tree(torch.as_tensor(cb.poses), torch.as_tensor(cb.cam_poses), torch.as_tensor(cb.embeddings))
         tree.to_device(dev)  # one codebook index, shared by the engine and by the reference-named loop below
@@ -662,8 +662,17 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     timed_inputs = frames_inputs(args.warmup, args.steps)
+    lazy_ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if not sharded and not args.eager else None
     t0 = time.perf_counter()
+    if lazy_ev:
+        lazy_ev[0].record()
     run_log = frames(args.warmup, args.steps, timed_inputs)  # (a view of the engine's log buffer: copied below, outside the timed region)
+    if lazy_ev:
+        # the pipelined engine folds frame t's resample into frame t + 1's front: the K-th frame's search + gather would be left
+        # for whoever reads the set.  It is materialised INSIDE the timed region, so `value` holds K complete resamples - the work
+        # the reference's step does (particle_filter.py:245-249); the K frames without it: config.steps_per_sec_last_resample_pending
+        lazy_ev[1].record()
+        eng.flush()
     t_enqueued = time.perf_counter() - t0
     torch.cuda.synchronize()
     if dist is not None:
@@ -682,6 +691,9 @@ def main():
         td = eng.telemetry.cpu().numpy()[:4].astype(np.int64) - tele_before[:4].astype(np.int64)
         rows_timed = {"by_particle_waves_per_frame": float(td[2]) / args.steps, "off_prediction_list_per_frame": float(td[3]) / args.steps}
     ms_per_step = dt / args.steps * 1e3
+    lazy_rate = args.steps / (lazy_ev[0].elapsed_time(lazy_ev[1]) * 1e-3) if lazy_ev else None  # (device time of the K frames, events on the engine's stream)
+    if hasattr(eng, "check"):
+        eng.check()
     status = eng.status.cpu().numpy().tolist()
     # the same engine with the resampled particle set materialised (read) after every frame: three launches per frame
     eager_rate = None
@@ -757,6 +769,7 @@ def main():
                    "timed_region": ("K steps by one midas_shard_run call (library-owned RCCL communicator)" if sharded and eng.exchange == "peer_c" and eng._ccomm is not None
                                     else "K steps by one midas_lazy_run call" if hasattr(eng, "run") and not sharded and not args.eager else "K step() calls"),
                    "steps_per_sec_materialised_every_frame": eager_rate,
+                   "steps_per_sec_last_resample_pending": lazy_rate,
                    "reference_loop_frames_per_sec": loop_rate,
                    "per_step": step_stats, "per_step_in_timed_call": run_stats, "diffuse_regime": diffuse, "exchange": exchange_info,
                    "rows_scored_in_timed_region": rows_timed,
@@ -815,7 +828,7 @@ def main():
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (PMC counters
         # cannot be read from inside the process): profiles/r04_traffic.json, tools/pmc_traffic.sh
         traffic, traffic_src = None, None
-        for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for name in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(REPO, "profiles", name)))
                 traffic, traffic_src = tj["kernels"][dom]["hbm_bytes"], "profiles/" + name
@@ -840,7 +853,10 @@ def main():
                                    "which charges all K rows of the codebook to every frame although the sparse kernel does not read them; "
                                    "roofline.dense is the same frame with every row streamed (the K1 GEMV the north-star names): there SURVEY 8(d)'s "
                                    "bytes really move, and that is the figure to hold against the HBM roofline; traffic = HBM bytes per launch from the "
-                                   "rocprofv3 --pmc passes of this command committed under profiles/ (counters cannot be read inside the process)"}
+                                   "rocprofv3 --pmc passes of this command committed under profiles/ (counters cannot be read inside the process).  "
+                                   "needed_bytes / rows_scored_per_launch describe the CONVERGED regime of this profiling pass (frames behind the timed "
+                                   "window, a few hundred rows in use); the timed window itself, right after the wide start, scored "
+                                   "config.rows_scored_in_timed_region rows per frame - two regimes, do not mix them"}
         if fused and sparse and not args.no_extras:
             # the dense K1 beside it: every codebook row streamed by the front kernel (horizontal fusion, MIDAS_DENSE_SCORES=1 form) -
             # what a caller with the heat-map on runs every frame (filter/filter.py:213-215); the survey model's bytes are real here

@@ -275,7 +275,12 @@ typedef struct midas_lazy_args {
     float* poses_prop_dev;             /* N x 16 out */
     int32_t* nn_idx_dev;               /* N out */
     uint8_t* valid_dev;                /* N out */
-    int32_t* status_dev;               /* 2 out: [0] = 2 on NaN weights, [1] = particles kept by the prune */
+    int32_t* status_dev;               /* 2 out: [0] = 2 on NaN weights, [1] = particles kept by the prune.  [0] bit 4 (value 16): a wave
+                                        * of the grouped tail (one wave per 256 slots, the waves of a 4096-slot block hand their sums to
+                                        * each other) did not see its block's records within 0.2 s - the frame's tables are UNDEFINED.
+                                        * The form is only taken while the whole grid is resident on the device (queried occupancy), so
+                                        * this means foreign work held the compute units; MIDAS_TAIL_GROUPED=0 selects the form without
+                                        * waits.  midastouch_amd's engines raise on it (`check()`) */
     double* tables_dev;                /* 128-byte aligned, 4 N16 + 2 G16 + 37 ceil(N/4096) doubles with N16 = N and G16 = ceil(N/16),
                                         * each rounded up to a multiple of 16: on entry the previous frame's softmax /
                                         * CDF tables (read when resample_prev), on exit this frame's */
@@ -308,7 +313,8 @@ typedef struct midas_lazy_args {
                                         * scoring (single trajectory).  [0], [1] = the two lists' lengths, then two lists of K
                                         * rows.  The frame with score_epoch e scores list (e >> 1) & 1 - the rows the frame
                                         * before it used, stamped e - 1 by that frame's tail, and the rows that frame had on its
-                                        * list without using them (one second chance; bits 31:30 of their stamp count it) - with streaming
+                                        * list without using them (a listed row stays up to THREE further frames unused - compile knob MIDAS_PRED_CHANCES, 0 .. 3;
+                                        * its stamp is (e + 1) | age << 30, bits 31:30 = frames listed without use) - with streaming
                                         * workgroups of its front launch, and its own tail writes the other list.  With a list
                                         * the caller advances score_epoch by TWO per frame (midas_lazy_run does), keeps it below
                                         * 0x3FFFFFF0 and zeroes the two lengths whenever it zeroes the stamps.  Same scores as without (which rows are scored by whom is all

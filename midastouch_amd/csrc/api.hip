@@ -141,7 +141,9 @@ MIDAS_EXPORT int midas_ctx_create(int device, void* hip_stream, midas_ctx** out)
     {
         void* p = nullptr;
         const int blocks = midas::TAIL_GROUP_MAX_BLOCKS;
-        if (hipMalloc(&p, (size_t)blocks * midas::TAIL_GROUP_BLOCK_BYTES) == hipSuccess && hipMemset(p, 0, (size_t)blocks * midas::TAIL_GROUP_BLOCK_BYTES) == hipSuccess) {
+        // (hipMemset is not ordered against a non-blocking caller stream: the device is drained before anybody can launch on the records)
+        if (hipMalloc(&p, (size_t)blocks * midas::TAIL_GROUP_BLOCK_BYTES) == hipSuccess && hipMemset(p, 0, (size_t)blocks * midas::TAIL_GROUP_BLOCK_BYTES) == hipSuccess &&
+            hipDeviceSynchronize() == hipSuccess) {
             ctx->tail_rec = (unsigned long long*)p;
             ctx->tail_rec_blocks = blocks;
         } else {
@@ -676,6 +678,11 @@ MIDAS_EXPORT int midas_lazy_run(midas_ctx* ctx, const midas_codebook* cb, const 
                            !first->rot_dev && !first->u_prev_dev);
     MIDAS_REQUIRE(ctx, !rmse_log_dev || (first->gt16_dev && first->part_rmse_dev));
     midas_lazy_args a = *first;
+    if (a.score_stamps_dev) {  // every epoch of the run is checked BEFORE anything is enqueued (the last frame uses first + inc (T - 1));
+                               // the caller restarts the epochs (and zeroes the stamps) long before the limit
+        const uint64_t inc = a.score_list_dev ? 2u : 1u;
+        MIDAS_REQUIRE(ctx, (uint64_t)a.score_epoch + inc * (uint64_t)(T - 1) < (a.score_list_dev ? (uint64_t)MIDAS_EPOCH_LIMIT : 0xFFFFFFF0ull));
+    }
     for (int32_t f = 0; f < T; ++f) {
         int rc = f ? scratch_reset(ctx) : MIDAS_OK;  // frames are ordered on the stream: each may reuse the scratch
         if (rc) return rc;
@@ -692,9 +699,7 @@ MIDAS_EXPORT int midas_lazy_run(midas_ctx* ctx, const midas_codebook* cb, const 
         a.step_prev = a.step;
         a.step += 1;
         if (a.score_stamps_dev) {  // never 0; two per frame with a prediction list (the tag between two epochs marks its rows)
-            const uint32_t inc = a.score_list_dev ? 2u : 1u;
-            MIDAS_REQUIRE(ctx, a.score_epoch < (a.score_list_dev ? MIDAS_EPOCH_LIMIT : 0xFFFFFFF0u) - inc);  // the caller restarts the epochs (and zeroes the stamps) long before
-            a.score_epoch += inc;
+            a.score_epoch += a.score_list_dev ? 2u : 1u;  // (range checked above, for the whole run)
         }
         a.odom16_dev += 16;
         a.code_dev += cb->D;
@@ -950,7 +955,10 @@ static int shard_front_impl(midas_ctx* ctx, const midas_codebook* cb, const mida
     pa.part_rmse = (double*)prm;
     if (inbox) pa.inbox = *inbox;
     if (!s.scores_ready && s.score_stamps_dev && s.score_epoch) { pa.sp.stamps = s.score_stamps_dev; pa.sp.epoch = s.score_epoch; }
-    if (pa.sp.stamps && score_list && predict_out && s.score_epoch >= 2 && s.score_epoch < MIDAS_EPOCH_LIMIT && s.N >= SCAN_CHUNK && cb) {
+    // (an epoch at the limit is an error here as in lazy_step_impl - bits 31:30 of a stamp are a listed row's age -, not a frame
+    // that silently runs without its list)
+    MIDAS_REQUIRE(ctx, !(pa.sp.stamps && score_list && predict_out) || s.score_epoch < MIDAS_EPOCH_LIMIT);
+    if (pa.sp.stamps && score_list && predict_out && s.score_epoch >= 2 && s.N >= SCAN_CHUNK && cb) {
         const int par = (int)((s.score_epoch >> 1) & 1u);
         pa.sp.pred_tag = s.score_epoch - 1u;
         pa.sp.list_count = score_list + par;
@@ -1211,6 +1219,8 @@ MIDAS_EXPORT int midas_shard_run(midas_ctx* ctx, midas_comm* comm, const midas_c
     MIDAS_REQUIRE(ctx, first != nullptr && comm != nullptr && cb != nullptr && T >= 1);
     MIDAS_REQUIRE(ctx, !first->front.tn_dev && !first->front.rot_dev && !first->u_all_dev && !first->front.scores_ready);
     midas_shard_step_args a = *first;
+    if (a.front.score_stamps_dev)  // every epoch of the run checked before anything is enqueued (see midas_lazy_run)
+        MIDAS_REQUIRE(ctx, (uint64_t)a.front.score_epoch + (a.score_list_dev ? 2ull : 1ull) * (uint64_t)(T - 1) < (uint64_t)MIDAS_EPOCH_LIMIT);
     // The unpack of every frame but the last is folded into the NEXT frame's front: the rows other ranks stored into this rank's
     // inbox are read there, behind the same flag wait (MIDAS_SHARD_FOLD=0: every frame unpacks into the particle arrays).
     // Safe with one inbox: a peer stores the rows of frame f + 1 behind its record all_gather of frame f + 1, which completes only
@@ -1226,10 +1236,7 @@ MIDAS_EXPORT int midas_shard_run(midas_ctx* ctx, midas_comm* comm, const midas_c
         a.front.step += 1;
         a.frame_tag += 1;
         a.u32 = -1.0f;
-        if (a.front.score_stamps_dev) {
-            MIDAS_REQUIRE(ctx, a.front.score_epoch < MIDAS_EPOCH_LIMIT - 2u);
-            a.front.score_epoch += a.score_list_dev ? 2u : 1u;
-        }
+        if (a.front.score_stamps_dev) a.front.score_epoch += a.score_list_dev ? 2u : 1u;
         a.front.odom16_dev += 16;
         a.front.code_dev += cb->D;
         if (a.front.gt16_dev) a.front.gt16_dev += 16;

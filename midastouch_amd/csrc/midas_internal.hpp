@@ -268,8 +268,8 @@ struct SparseScore {
 };
 // what the tail kernel needs to build the next frame's list: rows whose stamp is `epoch` (claimed or confirmed in this
 // frame) are appended to `list` and re-stamped epoch + 1, the next frame's pred_tag (its epoch is epoch + 2).
-// Second chance (round 5): a row that was on this frame's list but that nobody needed (stamp still epoch - 1) is listed ONCE
-// more, stamped (epoch + 1) | PRED_SECOND - in the frames after a wide start half of the rows a frame needs and the frame before
+// Further chances (round 5): a row that was on this frame's list but that nobody needed (stamp still epoch - 1, whatever its age
+// bits) is listed again, up to MIDAS_PRED_CHANCES (3) frames in a row, stamped (epoch + 1) | age << 30 - in the frames after a wide start half of the rows a frame needs and the frame before
 // did not were in use two frames back (the cloud's fringe flickers: tools/diag_flicker.py), and every such row was a claim: a
 // stamp exchange and a cold 2 KB fetch inside a particle wave.  Epochs stay below 2^30 (MIDAS_EPOCH_LIMIT), bits 31:30 count the
 // frames a listed row went unused (MIDAS_PRED_CHANCES of them are allowed).

@@ -1134,7 +1134,10 @@ MD void mesh_coop(const MeshRec* __restrict__ vlist, int32_t h, const double* tq
             for (int c0 = 1 + MESH_SOLO + 64; c0 <= MESH_M && r1 < 0; c0 += 64) {
                 const int s = c0 + lane;
                 bool hit = false;
-                float rho = INFINITY;
+                // (lanes past the end of the list decide nothing: with +inf here they "stopped" the scan, and a list that was
+                // merely EXHAUSTED - a dense mesh, the particle 2 mm off its entry - read as "provably too far" instead of going
+                // to the tree search; two particles in 640 000 at c5, found by the exhaustive check of round 6)
+                float rho = -INFINITY;
                 if (s <= MESH_M) {
                     const MeshRec r = v1[s];
                     Point3 p;

@@ -1702,10 +1702,26 @@ __global__ void k_peer_probe_check(const char* inbox, int G, int nonce, int32_t*
 #define LAUNCH_CHECK(ctx) MIDAS_HIP_CHECK(ctx, hipGetLastError())
 
 // The grouped form needs the hand-over records, the whole grid resident and whole 16-byte pieces of the per-slot arrays.
-static bool tail_grouped_ok(midas_ctx* ctx, int64_t N, const int32_t* nn_idx, const uint8_t* valid, const TailTables& tb) {
+// Resident = the launch's workgroups (four-wave group workgroups + the rmse workgroup + `extra` list workgroups) fit the DEVICE's
+// compute units at the kernel's occupancy - queried, not assumed (a partitioned or smaller part takes the one-workgroup-per-block
+// form earlier); the waves wait for each other, so a grid that cannot all start must not take this form.
+static int tail_resident_workgroups(midas_ctx* ctx) {
+    static int cap_dev[64] = {};
+    const int di = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+    if (!cap_dev[di] || ctx->device != di) {
+        hipDeviceProp_t prop;
+        const int ncu = (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 0;
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_tail_a3, 256, 0) != hipSuccess) { occ = 0; (void)hipGetLastError(); }
+        cap_dev[di] = ncu * occ > 0 ? ncu * occ : -1;
+    }
+    return cap_dev[di];
+}
+static bool tail_grouped_ok(midas_ctx* ctx, int64_t N, const int32_t* nn_idx, const uint8_t* valid, const TailTables& tb, int extra) {
     const char* env = getenv("MIDAS_TAIL_GROUPED");  // (read per launch: the tests compare both forms in one process)
     const bool on = !(env && env[0] == '0');
     if (!on || !ctx->tail_rec || N < SCAN_CHUNK || ceil_div(N, SCAN_BLOCK) > ctx->tail_rec_blocks) return false;
+    if ((ceil_div(N, TG_GROUP) + 3) / 4 + 1 + extra > tail_resident_workgroups(ctx)) return false;
     const uintptr_t al = (uintptr_t)nn_idx | (uintptr_t)tb.e | (uintptr_t)tb.x_raw | (uintptr_t)tb.lp | (uintptr_t)tb.lp_raw;
     return (al & 15) == 0 && ((uintptr_t)valid & 3) == 0;
 }
@@ -1866,7 +1882,7 @@ int launch_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores, const i
     if (direct && N >= SCAN_CHUNK) {  // the shard's per-slot tables are padded (shard_tables_of, api.hip)
         TailTables t = tb;
         t.bsum_e = r1; t.btot = r1 + nb; t.btot_raw = r1 + 2 * nb; t.bmax = r1 + 3 * nb; t.bmin = r1 + 4 * nb;
-        if (tail_grouped_ok(ctx, N, nn_idx, valid, t))
+        if (tail_grouped_ok(ctx, N, nn_idx, valid, t, with_list ? (int)ceil_div(predict->K, 256 * PREDICT_PER_THREAD) : 0))
             return launch_tail_a3(ctx, N, scores, nn_idx, valid, softmax, t, true, status, r1 + 5 * nb, part_rmse,
                                   part_rmse ? r1 + 5 * nb + 2 : (double*)nullptr, true, with_list ? predict : nullptr);
         const int nscan = with_list ? (int)ceil_div(predict->K, 256 * PREDICT_PER_THREAD) : 0;
@@ -1921,7 +1937,7 @@ int launch_tail_a2(midas_ctx* ctx, int64_t N, const double* scores, const int32_
     static const bool direct = !(getenv("MIDAS_TAIL_DIRECT") && atoi(getenv("MIDAS_TAIL_DIRECT")) == 0);
     const bool with_list = predict && predict->stamps && predict->list && batch <= 1;
     if (with_list && !(direct && N >= SCAN_CHUNK)) return midas_set_error(ctx, MIDAS_ERR_INVALID, "score_list", "the prediction list needs the direct tail kernel (N >= 16)");
-    if (direct && batch <= 1 && tail_grouped_ok(ctx, N, nn_idx, valid, tb))
+    if (direct && batch <= 1 && tail_grouped_ok(ctx, N, nn_idx, valid, tb, with_list ? (int)ceil_div(predict->K, 256 * PREDICT_PER_THREAD) : 0))
         return launch_tail_a3(ctx, N, scores, nn_idx, valid, softmax, tb, padded_tables, status, nullptr, part_rmse,
                               part_rmse ? rmse_out : (double*)nullptr, false, with_list ? predict : nullptr);
     if (direct && (batch <= 1 || tstride > 0) && N >= SCAN_CHUNK) {

@@ -250,6 +250,14 @@ class PipelinedFilterEngine(FilterEngine):
         self._score_list = torch.zeros(2 + 2 * self.K, dtype=torch.int32, device=dev) \
             if self.sparse_scores and os.environ.get("MIDAS_SCORE_LIST", "1") != "0" and N >= 16 else None
 
+    def check(self):
+        """Raises if a frame's tail reported its tables undefined (status bit 4, value 16: a wave of the grouped tail waited
+        0.2 s for its block's records - include/midas_hip.h, midas_lazy_args.status_dev).  One small read-back."""
+        st = torch.stack([self._st[0][0], self._st[1][0]]).cpu()
+        if int(st[0]) & 16 or int(st[1]) & 16:
+            raise MidasError("grouped tail: a wave did not receive its block's records in time - the frame's CDF tables are undefined "
+                             "(foreign work on the device?); MIDAS_TAIL_GROUPED=0 selects the form without waits")
+
     # the latest frame's own outputs
     @property
     def status(self):
@@ -363,9 +371,13 @@ class PipelinedFilterEngine(FilterEngine):
         fold = self._pending and not self._flushed
         # the argument block with every pointer that does not change from call to call, one per buffer parity, built once (the
         # timed region of a caller starts before this call: what is set up here is time the device idles)
+        # (keyed on the buffers' addresses: a caller that rebinds one - `eng.poses = t`, `eng.telemetry = ...` - gets a fresh block)
+        bufs = (self._prop[cur], self._nn[cur], self._st[cur], self._prop[nxt], self._nn[nxt], self._valid, self._st[nxt], self._tables,
+                self._scores, self._guide, self._poses, self.telemetry)
+        sig = tuple(0 if b is None else b.data_ptr() for b in bufs)
         cache = self.__dict__.setdefault("_run_args", {})
-        a = cache.get(cur)
-        if a is None:
+        a, have = cache.get(cur, (None, None))
+        if have != sig:
             a = LazyArgs()
             a.N = self.N
             a.poses_prop_prev, a.nn_idx_prev, a.status_prev = _ptr(self._prop[cur]), _ptr(self._nn[cur]), _ptr(self._st[cur])
@@ -376,7 +388,7 @@ class PipelinedFilterEngine(FilterEngine):
             a.telemetry = _ptr(self.telemetry)
             a.ridx = None
             a.u_prev = None
-            cache[cur] = a
+            cache[cur] = (a, sig)
         a.part_rmse = _ptr(self._part_rmse) if gts is not None else None
         a.resample_prev = int(fold)
         a.hint_in = _ptr(self._hint) if self.use_hint else None

@@ -309,3 +309,98 @@ def test_config5_batch_full_size(dev, oracle, engine):
     w = eng.weights.cpu().numpy()
     assert np.array_equal(st[:, 1], (w != 0).sum(1))
     assert np.isfinite(w).all()
+
+
+# ---- every particle of a frame by brute force (no sampling) -------------------------------------------------------------
+def _brute_force_all(oracle, prop, cb_feat, verts, threads=None):
+    """oracle.nn6 / oracle.nn3_dist over ALL rows of `prop`, the rows split across host threads (the C loops release the GIL)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    threads = threads or max(1, min(16, len(os.sched_getaffinity(0))))
+    feat = oracle.R3_SE3(prop)
+    cuts = np.linspace(0, prop.shape[0], threads + 1).astype(int)
+    with ThreadPoolExecutor(threads) as ex:
+        nn = list(ex.map(lambda i: oracle.nn6(feat[cuts[i]:cuts[i + 1]], cb_feat)[0], range(threads)))
+        d3 = list(ex.map(lambda i: oracle.nn3_dist(prop[cuts[i]:cuts[i + 1]], verts), range(threads)))
+    return np.concatenate(nn), np.concatenate(d3)
+
+
+def test_config2_every_particle_by_brute_force(dev, oracle):
+    """c2 at full size, NO sampling: the device's 1-NN (neighbour-list scan with certificate, tree fallback) and prune decisions of
+    ALL 100 000 particles against the brute-force scan of the 50 000 entries / of every mesh vertex - in the first frame after
+    the wide start (stale hints, the cloud over the whole object: the hardest frame for the certificate) and in a converged one.
+    Reference: tactile_tree.SE3_NN (tactile_tree/tactile_tree.py:50-58), remove_invalid_particles (particle_filter.py:386-391)."""
+    from midastouch_amd.engine import PipelinedFilterEngine
+    from midastouch_amd.synthetic import make_codebook, make_trajectory, wide_start
+    N, K, D, seed = 100_000, 50_000, 512, 4000
+    cb = make_codebook("004_sugar_box", K=K, D=D, seed=1001)
+    traj = make_trajectory(cb, T=14, seed=2001)
+    eng = PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=seed, device=dev)
+    eng.set_particles(torch.as_tensor(wide_start(cb.extents, traj.gt_poses[0], N, 100)))
+    eng.project_to_codebook()
+    cb_feat = oracle.R3_SE3(cb.poses)
+    od, co, gt = (torch.as_tensor(a).to(dev) for a in (traj.odoms, traj.codes, traj.gt_poses))
+    for t in (1, 12):
+        if t > 2:
+            eng.run(od[2:t], co[2:t], gt[2:t])
+        eng.step(od[t], co[t], gt=gt[t])
+        prop = eng.poses_prop.cpu().numpy()
+        nn, d3 = _brute_force_all(oracle, prop, cb_feat, cb.mesh_vertices)
+        assert np.array_equal(eng.nn_idx.cpu().numpy(), nn), f"frame {t}: {int((eng.nn_idx.cpu().numpy() != nn).sum())} of {N} NN indices differ"
+        assert np.array_equal(eng.weights.cpu().numpy() != 0, ~(d3 > 0.002)), f"frame {t}: prune decisions"
+    eng.check()
+
+
+def test_config5_every_particle_by_brute_force(dev, oracle):
+    """c5 at full size, NO sampling: NN and prune decisions of all 64 x 10 000 particles of one batch frame by brute force."""
+    from midastouch_amd.engine import BatchFilterEngine
+    from midastouch_amd.synthetic import make_codebook, make_trajectory
+    B, N, K, D, seed = 64, 10_000, 50_000, 512, 4200
+    cb = make_codebook("cotter-pin", K=K, D=D, seed=1005)
+    trajs = [make_trajectory(cb, T=4, seed=2200 + b) for b in range(8)]
+    eng = BatchFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, B, N, sig_t=1e-4, sig_r=0.5, seed=seed, device=dev)
+    rng = np.random.default_rng(1)
+    start = []
+    for b in range(B):
+        d0 = np.linalg.norm(cb.poses[:, :3, 3] - trajs[b % 8].gt_poses[0][:3, 3], axis=1)
+        start.append(cb.poses[rng.choice(np.argsort(d0)[:2500], N)])
+    eng.set_particles(torch.as_tensor(np.stack(start)))
+    for t in (1, 2):
+        odoms = torch.as_tensor(np.stack([trajs[b % 8].odoms[t] for b in range(B)])).to(dev)
+        codes = torch.as_tensor(np.stack([trajs[b % 8].codes[t] for b in range(B)])).to(dev)
+        eng.step(odoms, codes, None)
+    prop = eng.poses_prop.cpu().numpy().reshape(B * N, 4, 4)
+    nn, d3 = _brute_force_all(oracle, prop, oracle.R3_SE3(cb.poses), cb.mesh_vertices)
+    got = eng.nn_idx.cpu().numpy().reshape(-1)
+    assert np.array_equal(got, nn), f"{int((got != nn).sum())} of {B * N} NN indices differ"
+    assert np.array_equal(eng.weights.cpu().numpy().reshape(-1) != 0, ~(d3 > 0.002))
+
+
+@pytest.mark.parametrize("engine", ["FilterEngine", "PipelinedFilterEngine"])
+def test_prune_exhausted_vertex_list_goes_to_the_tree(dev, oracle, engine):
+    """The case the exhaustive c5 check found (two particles of 640 000 pruned that the reference keeps): on the cotter pin's
+    dense mesh a particle 2 - 4 mm off its nearest entry walks that entry's whole vertex list (256 records) without a vertex
+    within 2 mm and without reaching a record that is provably too far - the list is EXHAUSTED, which decides nothing, and the
+    3-d tree has the answer.  Every decision against brute force; the tree search must have been taken."""
+    from midastouch_amd import engine as E
+    from midastouch_amd.synthetic import make_codebook, make_trajectory
+    N, K, D, seed = 30_000, 5_000, 256, 77
+    cb = make_codebook("cotter-pin", K=K, D=D, seed=1005)
+    traj = make_trajectory(cb, T=3, seed=2200)
+    eng = getattr(E, engine)(cb.poses, cb.embeddings, cb.mesh_vertices, N, sig_t=1e-5, sig_r=0.01, seed=seed, device=dev)
+    rng = np.random.default_rng(3)
+    poses = cb.poses[rng.integers(0, K, N)].copy()
+    off = rng.normal(size=(N, 3))
+    off *= (rng.uniform(0.0015, 0.0045, N) / np.linalg.norm(off, axis=1))[:, None]
+    poses[:, :3, 3] += off.astype(np.float32)
+    eng.set_particles(torch.as_tensor(poses))
+    tele0 = eng.telemetry.cpu().numpy().copy()
+    eye = torch.eye(4)
+    eng.step(eye, torch.as_tensor(traj.codes[1]))
+    prop = eng.poses_prop.cpu().numpy()
+    nn, d3 = _brute_force_all(oracle, prop, oracle.R3_SE3(cb.poses), cb.mesh_vertices)
+    assert np.array_equal(eng.nn_idx.cpu().numpy(), nn)
+    kept = eng.weights.cpu().numpy() != 0
+    assert np.array_equal(kept, ~(d3 > 0.002)), f"{int((kept != ~(d3 > 0.002)).sum())} prune decisions differ"
+    assert 0 < kept.sum() < N
+    assert int(eng.telemetry.cpu().numpy()[1] - tele0[1]) > 0, "no particle needed the tree: the case is not covered"

@@ -343,6 +343,50 @@ def test_epoch_wrap_restarts_stamps_and_lists(dev):
     assert np.array_equal(eng.ridx.cpu().numpy(), ref.ridx.cpu().numpy())
 
 
+@pytest.mark.parametrize("T", [1, 2, 3])
+def test_run_whose_last_epoch_is_the_largest_allowed(dev, T):
+    """advance_epoch lets a run's LAST epoch reach EPOCH_LIMIT - 2; midas_lazy_run checks the whole run's epochs
+    before it enqueues anything (it used to re-check after every frame, the last one included, and returned an error with all T
+    frames already in flight).  The run succeeds, the engine's state follows, the next call restarts the epochs."""
+    from midastouch_amd.engine import EPOCH_LIMIT, PipelinedFilterEngine
+    N, K, D = 6000, 3000, 256
+    cb, traj = _setup(N, K, D, 3)
+    eng = PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=1, device=dev)
+    ref = PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=1, device=dev)
+    rng = np.random.default_rng(2)
+    start = torch.as_tensor(cb.poses[rng.integers(0, K, N)])
+    eng.set_particles(start)
+    ref.set_particles(start)
+    od, co = torch.as_tensor(traj.odoms).to(dev), torch.as_tensor(traj.codes).to(dev)
+    eng._epoch = EPOCH_LIMIT - 2 - 2 * T   # the run's epochs: LIMIT - 2 T, ..., LIMIT - 2
+    eng.run(od[1:1 + T], co[1:1 + T])
+    ref.run(od[1:1 + T], co[1:1 + T])
+    assert eng._epoch == EPOCH_LIMIT - 2 and eng.step_count == T
+    eng.run(od[1 + T:3 + T], co[1 + T:3 + T])
+    ref.run(od[1 + T:3 + T], co[1 + T:3 + T])
+    assert eng._epoch == 4  # restarted
+    eng.check()
+    assert np.array_equal(eng.nn_idx.cpu().numpy(), ref.nn_idx.cpu().numpy())
+    assert np.array_equal(eng.ridx.cpu().numpy(), ref.ridx.cpu().numpy())
+    # one epoch further is refused BEFORE anything is enqueued: the engine's state is untouched
+    eng._epoch = EPOCH_LIMIT - 2
+    a = eng._epoch
+    from midastouch_amd.engine import advance_epoch
+    assert advance_epoch(eng, 1) == 2 and a != eng._epoch  # (the host side restarts by itself ...)
+    from midastouch_amd._lib import MidasError
+    import midastouch_amd.engine as E
+    eng._epoch = EPOCH_LIMIT - 2
+    orig = E.EPOCH_LIMIT
+    try:
+        E.EPOCH_LIMIT = 1 << 31  # ... so the C-side check is reached only with the host's restart disabled
+        steps = eng.step_count
+        with pytest.raises(MidasError):
+            eng.run(od[1:3], co[1:3])
+        assert eng.step_count == steps
+    finally:
+        E.EPOCH_LIMIT = orig
+
+
 def test_prediction_list_seeded_at_projection(dev, monkeypatch):
     """project_to_codebook (filter/filter.py:159-160) knows every particle's nearest entry: the first frame's rows are listed
     there and then (midas_score_list_seed), so the first frame after a wide start scores them with streaming workgroups too.
