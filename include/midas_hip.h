@@ -162,6 +162,21 @@ int midas_prune(midas_ctx* ctx, int64_t N, double* w_dev, const double* dist_dev
  * own (midastouch_amd/torch_rng.py does). */
 int midas_mt19937_seed(midas_ctx* ctx, uint64_t seed, uint32_t* state_dev);
 int midas_mt19937_rand64(midas_ctx* ctx, uint32_t* state_dev, int64_t skip_words, int64_t N, double* out_dev);
+/* The same stream (same reference call: torch.multinomial's draws, modules/particle_filter.py:245) with the call's 2 N words
+ * generated in `pieces` pieces side by side.  mt19937 is linear over GF(2): x[k + J] = XOR of x[k + i] over the exponents i of
+ * t^J mod phi(t) (phi: the generator's characteristic polynomial, degree 19937), so the 624 words that start a piece follow
+ * from MIDAS_MT19937_HIST_WORDS consecutive words generated earlier and one polynomial per piece:
+ *   hist_dev  (in/out) MIDAS_MT19937_HIST_WORDS uint32: on entry the first such words the PREVIOUS call handed out (raw,
+ *             untempered - every call with 2 N >= MIDAS_MT19937_HIST_WORDS leaves them), on exit this call's;
+ *   polys_dev pieces x 624 uint32: bit b of word w of polynomial c = coefficient of t^(32 w + b) of t^(J_c) mod phi, J_c = distance
+ *             in words from hist_dev's first word to the first word of piece c = (words the previous call handed out) + skip_words
+ *             + c x 624 x ceil(ceil(2 N / 624) / pieces)  (host-side set-up: midastouch_amd/mt_jump.py; a wrong table gives wrong
+ *             numbers, nothing else - tests/test_torch_stream.py holds the chunked stream against torch.rand);
+ * polys_dev NULL or pieces <= 0: the sequential walk of midas_mt19937_rand64, which also leaves hist_dev (if given).
+ * state_dev is left as after midas_mt19937_rand64.  Needs 2 N >= MIDAS_MT19937_HIST_WORDS. */
+#define MIDAS_MT19937_HIST_WORDS 20560
+int midas_mt19937_rand64_chunked(midas_ctx* ctx, uint32_t* state_dev, int64_t skip_words, int64_t N, double* out_dev,
+                                 uint32_t* hist_dev, const uint32_t* polys_dev, int32_t pieces);
 
 /* ---- resample  (K6, K7, K8) ------------------------------------------------------------------ */
 /* cdf = blocked_prefix(w) / total, cdf[N-1] = 1 (float64, fixed summation order - DESIGN.md).

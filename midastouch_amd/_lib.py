@@ -177,6 +177,7 @@ class LoopArgs(C.Structure):
 
 # phases of midas_loop_step and the control-block indices (include/midas_hip.h MIDAS_LOOP_*)
 LOOP_FRONT, LOOP_DBSCAN, LOOP_ANNEAL, LOOP_RESAMPLE = 1, 2, 4, 8
+MT19937_HIST_WORDS = 20560  # MIDAS_MT19937_HIST_WORDS
 TOPK_TIES_INDEX, TOPK_TIES_ATEN_CPU = 0, 1  # whom annealing's torch.topk takes inside a tie (include/midas_hip.h)
 LOOP_MAX_CLUSTERS, LOOP_LOG_DOUBLES = 64, 168
 (LOOP_I_N, LOOP_I_NSET, LOOP_I_MODE, LOOP_I_K, LOOP_I_INIT, LOOP_I_VARSET, LOOP_I_KEPT, LOOP_I_DRIFT, LOOP_I_STATUS,
@@ -217,6 +218,7 @@ SIGNATURES = {
     "midas_score_list_seed": (C.c_int, [_P, _I64, _P, C.c_uint32, _P, _I64, _P]),
     "midas_mt19937_seed": (C.c_int, [_P, _U64, _P]),
     "midas_mt19937_rand64": (C.c_int, [_P, _P, _I64, _I64, _P]),
+    "midas_mt19937_rand64_chunked": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _I32]),
     "midas_resample_search": (C.c_int, [_P, _I64, _P, _I64, _I32, _P, _F, _U64, _U64, _P]),
     "midas_gather_rows": (C.c_int, [_P, _I64, _P, _P, _P, _I32]),
     "midas_rmse": (C.c_int, [_P, _I64, _P, _P, _P]),

@@ -401,7 +401,17 @@ MIDAS_EXPORT int midas_mt19937_seed(midas_ctx* ctx, uint64_t seed, uint32_t* sta
 MIDAS_EXPORT int midas_mt19937_rand64(midas_ctx* ctx, uint32_t* state_dev, int64_t skip_words, int64_t N, double* out_dev) {
     MIDAS_ENTER(ctx);
     MIDAS_REQUIRE(ctx, state_dev != nullptr && skip_words >= 0 && N >= 0 && (N == 0 || out_dev != nullptr));
-    return launch_mt_rand64(ctx, state_dev, skip_words, N, out_dev);
+    return launch_mt_rand64(ctx, state_dev, skip_words, N, out_dev, nullptr);
+}
+
+MIDAS_EXPORT int midas_mt19937_rand64_chunked(midas_ctx* ctx, uint32_t* state_dev, int64_t skip_words, int64_t N, double* out_dev,
+                                              uint32_t* hist_dev, const uint32_t* polys_dev, int32_t pieces) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, state_dev != nullptr && skip_words >= 0 && N >= 0 && (N == 0 || out_dev != nullptr));
+    if (!polys_dev || pieces <= 0)  // the sequential walk; leaves the history for a chunked call to follow
+        return launch_mt_rand64(ctx, state_dev, skip_words, N, out_dev, hist_dev);
+    MIDAS_REQUIRE(ctx, hist_dev != nullptr && N > 0 && pieces <= 1024 && 2 * N >= MIDAS_MT19937_HIST_WORDS);
+    return launch_mt_rand64_chunked(ctx, state_dev, N, out_dev, hist_dev, polys_dev, pieces);
 }
 
 MIDAS_EXPORT int midas_resample_search(midas_ctx* ctx, int64_t N, const double* cdf_dev, int64_t M, int32_t mode,

@@ -122,14 +122,127 @@ __global__ __launch_bounds__(MT_THREADS) void k_mt_blocks(uint32_t* __restrict__
     if (c == 0) state[MT_N] = (uint32_t)(e - bl * MT_N);
 }
 
-// 2 N words -> N doubles: (hi << 32 | lo) & (2^53 - 1), times 2^-53 (at::uniform_real_distribution<double>); hi = the first word
+// 2 N words -> N doubles: (hi << 32 | lo) & (2^53 - 1), times 2^-53 (at::uniform_real_distribution<double>); hi = the first word.
+// hist (nullable): the first MT_HIST of the raw words are kept for the next call's jump (k_mt_jump).
+constexpr int MT_DEG = 19937;
+constexpr int MT_HIST = MT_DEG + MT_N - 1;  // x[k + i], k < 624, i < 19937
+static_assert(MT_HIST == MIDAS_MT19937_HIST_WORDS, "include/midas_hip.h");
 __global__ __launch_bounds__(256) void k_mt_emit(const uint32_t* __restrict__ raw, const int32_t* __restrict__ meta, long long N,
-                                                 double* __restrict__ out) {
+                                                 double* __restrict__ out, uint32_t* __restrict__ hist) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
-    const uint32_t* w = raw + meta[0] + 2 * i;
-    const unsigned long long r = (((unsigned long long)mt_temper(w[0]) << 32) | mt_temper(w[1])) & ((1ull << 53) - 1ull);
+    const uint32_t* w = raw + (meta ? meta[0] : 0) + 2 * i;
+    const uint32_t w0 = w[0], w1 = w[1];
+    const unsigned long long r = (((unsigned long long)mt_temper(w0) << 32) | mt_temper(w1)) & ((1ull << 53) - 1ull);
     out[i] = (double)r * 1.1102230246251565e-16;
+    if (hist) {
+        if (2 * i < MT_HIST) hist[2 * i] = w0;
+        if (2 * i + 1 < MT_HIST) hist[2 * i + 1] = w1;
+    }
+}
+
+// ---- chunked generation: G workgroups walk G pieces of a call's words side by side ------------------------------------------
+// mt19937 is linear over GF(2): with phi its characteristic polynomial (degree 19937) and P_J = t^J mod phi,
+//     x[k + J] = XOR over the exponents i of P_J of x[k + i]          (Haramoto et al. 2008; midastouch_amd/mt_jump.py)
+// for every k - so the 624 words that START a piece of this call's output follow from MT_HIST consecutive words of the previous
+// call's output (`hist`, kept by k_mt_emit) and one polynomial per piece (host-side set-up, 624-word bitsets).  A workgroup
+// computes MT_JW consecutive words of one piece's start: the window hist[k0, k0 + 19937 + MT_JW) in LDS (78 KB), a thread walks
+// the set bits of its share of the polynomial (~10^4 taps, 40 per thread) and XORs MT_JW consecutive window words per tap;
+// the threads' partial sums meet in an XOR butterfly.
+constexpr int MT_JW = 16;
+constexpr int MT_JWIN = MT_DEG + MT_JW;  // window words per workgroup
+static_assert(MT_N % MT_JW == 0, "whole workgroups per piece");
+__global__ __launch_bounds__(256) void k_mt_jump(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ polys,
+                                                 uint32_t* __restrict__ starts) {
+    extern __shared__ uint32_t s_win[];  // MT_JWIN words + 4 x MT_JW for the cross-wave step
+    const int t = threadIdx.x, k0 = blockIdx.x * MT_JW, c = blockIdx.y;
+    for (int j = t; j < MT_JWIN; j += 256) s_win[j] = hist[k0 + j];
+    const uint32_t* P = polys + (size_t)c * MT_N;
+    uint32_t pw[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) pw[q] = (t + 256 * q < MT_N) ? P[t + 256 * q] : 0u;
+    __syncthreads();
+    uint32_t acc[MT_JW];
+#pragma unroll
+    for (int m = 0; m < MT_JW; ++m) acc[m] = 0u;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        uint32_t bits = pw[q];
+        const int base = 32 * (t + 256 * q);
+        while (bits) {
+            const int i = base + __builtin_ctz(bits);
+            bits &= bits - 1u;
+            if (i < MT_DEG) {  // (a polynomial has no term beyond: guards the window against a malformed table)
+#pragma unroll
+                for (int m = 0; m < MT_JW; ++m) acc[m] ^= s_win[i + m];
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT_JW; ++m) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc[m] ^= (uint32_t)__shfl_xor((int)acc[m], o);
+    }
+    uint32_t* s_x = s_win + MT_JWIN;
+    if ((t & 63) == 0) {
+#pragma unroll
+        for (int m = 0; m < MT_JW; ++m) s_x[(t >> 6) * MT_JW + m] = acc[m];
+    }
+    __syncthreads();
+    if (t < MT_JW) starts[(size_t)c * MT_N + k0 + t] = (s_x[t] ^ s_x[MT_JW + t]) ^ (s_x[2 * MT_JW + t] ^ s_x[3 * MT_JW + t]);
+}
+
+// Piece c = blocks [c bpc, (c + 1) bpc) of the call's nblocks blocks of 624 words (block 0 starts at the call's first word): its first
+// block is starts[c], the others follow by the block recurrence of k_mt_blocks (same column walk, one barrier a block).  The piece
+// that holds the call's last word leaves the generator's state: that block and the words consumed of it.
+__global__ __launch_bounds__(MT_THREADS) void k_mt_chunks(const uint32_t* __restrict__ starts, long long nwords, int bpc, uint32_t* __restrict__ raw,
+                                                          uint32_t* __restrict__ state) {
+    __shared__ uint32_t s_mt[2][MT_N];
+    const int c = threadIdx.x;
+    const long long nblocks = (nwords + MT_N - 1) / MT_N;
+    const long long fb = (long long)blockIdx.x * bpc;
+    if (fb >= nblocks) return;
+    const long long lb = (fb + bpc < nblocks ? fb + bpc : nblocks) - 1;  // last block of this piece
+    for (int k = c; k < MT_N; k += MT_THREADS) {
+        const uint32_t v = starts[(size_t)blockIdx.x * MT_N + k];
+        s_mt[0][k] = v;
+        raw[fb * MT_N + k] = v;
+    }
+    __syncthreads();
+    int par = 0;
+    uint32_t* r = raw + (fb + 1) * MT_N;
+    for (int done = 0, k = (int)(lb - fb); done < k; ++done, par ^= 1, r += MT_N) {
+        const uint32_t* __restrict__ o = s_mt[par];
+        uint32_t* __restrict__ n = s_mt[par ^ 1];
+        if (c < MT_COLS) {  // (k_mt_blocks' block step, see there)
+            const bool third = c + 2 * MT_COLS < MT_N;
+            const bool last = c + 2 * MT_COLS == MT_N - 1;
+            const int i2 = third ? c + 2 * MT_COLS : 0, i3 = (third && !last) ? c + 2 * MT_COLS + 1 : 0;
+            const uint32_t a0 = o[c], a1 = o[c + 1], far = o[c + MT_M];
+            const uint32_t b0w = o[c + MT_COLS], b1w = o[c + MT_COLS + 1];
+            const uint32_t c0w = o[i2], c1r = o[i3];
+            uint32_t z0 = o[0], z1 = o[1], zm = o[MT_M];
+            asm volatile("" : "+v"(z0), "+v"(z1), "+v"(zm));
+            uint32_t nz = zm ^ mt_twist(z0, z1);
+            asm volatile("" : "+v"(nz));
+            const uint32_t c1w = last ? nz : c1r;
+            const uint32_t n0 = far ^ mt_twist(a0, a1);
+            const uint32_t n1 = n0 ^ mt_twist(b0w, b1w);
+            const uint32_t n2 = n1 ^ mt_twist(c0w, c1w);
+            n[c] = n0;
+            n[c + MT_COLS] = n1;
+            if (third) n[c + 2 * MT_COLS] = n2;
+            r[c] = n0;
+            r[c + MT_COLS] = n1;
+            if (third) r[c + 2 * MT_COLS] = n2;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (lb == nblocks - 1) {
+        const uint32_t* fin = s_mt[par];
+        for (int k = c; k < MT_N; k += MT_THREADS) state[k] = fin[k];
+        if (c == 0) { state[MT_N] = (uint32_t)(nwords - lb * MT_N); state[MT_N + 1] = 0; }
+    }
 }
 
 int launch_mt_seed(midas_ctx* ctx, uint64_t seed, uint32_t* state) {
@@ -138,7 +251,33 @@ int launch_mt_seed(midas_ctx* ctx, uint64_t seed, uint32_t* state) {
     return MIDAS_OK;
 }
 
-int launch_mt_rand64(midas_ctx* ctx, uint32_t* state, int64_t skip_words, int64_t N, double* out) {
+// The chunked form: `polys` = G polynomials of 624 words (t^J_c mod phi, J_c = distance from the first word in `hist` to the first word
+// of piece c - the host knows both), `hist` in/out.  skip_words is part of J_c already: the state is replaced, not advanced.
+int launch_mt_rand64_chunked(midas_ctx* ctx, uint32_t* state, int64_t N, double* out, uint32_t* hist, const uint32_t* polys, int32_t G) {
+    const int64_t nwords = 2 * N, nblocks = ceil_div(nwords, MT_N);
+    const int bpc = (int)ceil_div(nblocks, G);
+    void* p;
+    int rc;
+    if ((rc = midas_scratch(ctx, ((size_t)nblocks + 1) * MT_N * sizeof(uint32_t), &p))) return rc;
+    uint32_t* raw = (uint32_t*)p;
+    if ((rc = midas_scratch(ctx, (size_t)G * MT_N * sizeof(uint32_t), &p))) return rc;
+    uint32_t* starts = (uint32_t*)p;
+    static bool attr_set[64] = {};
+    const int di = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+    const int lds = (MT_JWIN + 4 * MT_JW) * (int)sizeof(uint32_t);
+    if (!attr_set[di] || ctx->device != di) {
+        MIDAS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_mt_jump, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set[di] = true;
+    }
+    hipLaunchKernelGGL(k_mt_jump, dim3(MT_N / MT_JW, (unsigned)G), dim3(256), lds, ctx->stream, (const uint32_t*)hist, polys, starts);
+    hipLaunchKernelGGL(k_mt_chunks, dim3((unsigned)G), dim3(MT_THREADS), 0, ctx->stream, (const uint32_t*)starts, (long long)nwords, bpc, raw, state);
+    hipLaunchKernelGGL(k_mt_emit, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)raw, (const int32_t*)nullptr,
+                       (long long)N, out, hist);
+    MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    return MIDAS_OK;
+}
+
+int launch_mt_rand64(midas_ctx* ctx, uint32_t* state, int64_t skip_words, int64_t N, double* out, uint32_t* hist) {
     if (N == 0 && skip_words == 0) return MIDAS_OK;
     uint32_t* raw = nullptr;
     int32_t* meta = nullptr;
@@ -152,7 +291,9 @@ int launch_mt_rand64(midas_ctx* ctx, uint32_t* state, int64_t skip_words, int64_
         meta = (int32_t*)p;
     }
     hipLaunchKernelGGL(k_mt_blocks, dim3(1), dim3(MT_THREADS), 0, ctx->stream, state, (long long)skip_words, (long long)(2 * N), raw, meta);
-    if (N > 0) hipLaunchKernelGGL(k_mt_emit, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, raw, meta, (long long)N, out);
+    if (N > 0)
+        hipLaunchKernelGGL(k_mt_emit, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)raw, (const int32_t*)meta, (long long)N,
+                           out, 2 * N >= MT_HIST ? hist : (uint32_t*)nullptr);
     MIDAS_HIP_CHECK(ctx, hipGetLastError());
     return MIDAS_OK;
 }

@@ -15,6 +15,14 @@ from . import _lib
 from ._lib import _ptr
 
 
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 def normal_words(numel: int) -> int:
     """32-bit generator outputs one CPU torch.normal of `numel` float32 values consumes (ATen normal_fill: one per value,
     the last 16 drawn again when numel is not a multiple of 16).  Sizes below 16 take ATen's scalar path: not modelled."""
@@ -29,9 +37,15 @@ class TorchCpuStream:
     instead of in front of them.  `rand64()` orders the result behind the caller's stream as before; `rand64_async()` returns
     (tensor, event) and leaves the wait to the consumer (the pipelined engine: the draws of frame t are consumed by frame
     t + 1's launch).  The output buffers rotate (3): a buffer is rewritten two calls later, after the side stream has waited
-    for the caller's stream as of THAT call - whoever consumed it was enqueued before."""
+    for the caller's stream as of THAT call - whoever consumed it was enqueued before.
 
-    def __init__(self, seed: int, device=None, overlap: bool = True):
+    `pieces` (default 8; 0 = always the sequential walk): a call's 2 N words are generated in that many pieces side by side once
+    the previous call has left MIDAS_MT19937_HIST_WORDS of its words on the device - mt19937 is linear over GF(2), the words
+    that start a piece follow from those by one polynomial per piece (mt_jump.py; computed on the host once per distinct
+    (previous size, skip, size), ~10 ms each, checked against a reference generator before use).  Same numbers, bit for bit;
+    321 sequential blocks (100 us at N = 100k) become 41."""
+
+    def __init__(self, seed: int, device=None, overlap: bool = True, pieces: int = 8):
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.device = _lib.context(dev).device
         self.overlap = bool(overlap)
@@ -44,6 +58,10 @@ class TorchCpuStream:
             self.ctx = _lib.context(dev)
         self.state = torch.zeros(626, dtype=torch.int32, device=self.device)
         self.pending_skip = 0
+        self.pieces = int(pieces)
+        self._hist = torch.zeros(_lib.MT19937_HIST_WORDS, dtype=torch.int32, device=self.device)
+        self._hist_words = 0   # words the call that wrote _hist handed out (0: no history)
+        self._polys = {}       # (previous words, skip, words) -> device table of the pieces' polynomials
         self._bufs, self._turn = [None, None, None], 0
         self.manual_seed(seed)
 
@@ -62,6 +80,7 @@ class TorchCpuStream:
         self._enter()
         self._call("midas_mt19937_seed", int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(self.state))
         self.pending_skip = 0
+        self._hist_words = 0
         return self
 
     def skip_words(self, n: int):
@@ -91,13 +110,44 @@ class TorchCpuStream:
                     self._bufs[i].record_stream(self.side)
             out = self._bufs[i]
         self._enter()
-        self._call("midas_mt19937_rand64", _ptr(self.state), self.pending_skip, N, _ptr(out))
+        words = 2 * N
+        polys = None
+        if self.pieces > 0 and self._hist_words and words >= _lib.MT19937_HIST_WORDS:
+            polys = self._piece_polys(self._hist_words, self.pending_skip, words)
+        self._call("midas_mt19937_rand64_chunked", _ptr(self.state), self.pending_skip, N, _ptr(out), _ptr(self._hist), _ptr(polys),
+                   self.pieces if polys is not None else 0)
+        # (a call too short to leave a history, or a pure skip, breaks the chain: the next call walks sequentially)
+        self._hist_words = words if words >= _lib.MT19937_HIST_WORDS else 0
         self.pending_skip = 0
         if self.side is None:
             return out, None
         ev = torch.cuda.Event()
         ev.record(self.side)
         return out, ev
+
+    def _piece_polys(self, prev_words: int, skip: int, words: int):
+        key = (prev_words, skip, words, self.pieces)
+        tab = self._polys.get(key)
+        if tab is None:
+            import numpy as np
+
+            from . import mt_jump
+            nblocks = -(-words // 624)
+            bpc = -(-nblocks // self.pieces)
+            rows = []
+            for c in range(self.pieces):
+                J = prev_words + skip + c * bpc * 624
+                if not mt_jump.check(J):
+                    raise _lib.MidasError(f"mt19937 jump polynomial for distance {J} failed its check against the reference generator")
+                rows.append(mt_jump.jump_words(J))
+            host = torch.from_numpy(np.stack(rows).view(np.int32))
+            if len(self._polys) >= 16:
+                self._polys.clear()
+            # uploaded on the generator's stream (the caller is inside _enter() .. the launch)
+            with torch.cuda.stream(self.side) if self.side is not None else _null():
+                tab = host.to(self.device)
+            self._polys[key] = tab
+        return tab
 
     def rand64(self, N: int, out: torch.Tensor | None = None) -> torch.Tensor:
         """The next N values of torch.rand(N, dtype=torch.float64) (== the draws of torch.multinomial(w64, N, True)), ordered

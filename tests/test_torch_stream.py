@@ -65,6 +65,51 @@ def test_device_stream_equals_torch_rand():
         assert torch.equal(st.skip_normal(3 * N).skip_normal(3 * N).rand64(N).cpu(), u), N
 
 
+def test_jump_polynomials_against_the_reference_generator():
+    """mt_jump: the characteristic polynomial found by Berlekamp-Massey has mt19937's known shape (degree 19937, 135 terms), and
+    x[k + J] = XOR of the taps of t^J mod phi on numpy's mt19937 stream for the distances the chunked generator uses."""
+    from midastouch_amd import mt_jump
+    phi, low = mt_jump.char_poly()
+    assert phi.bit_length() - 1 == 19937 and len(low) + 1 == 135
+    for J in (0, 1, 623, 624, 19936, 19937, 19938, 200_000, 200_000 + 41 * 624, 2 * 33_333 + 7 * 14 * 624, 2_000_000 + 401 * 624):
+        assert mt_jump.check(J, samples=6), J
+    w = mt_jump.jump_words(200_000)
+    assert w.shape == (624,) and w.dtype == np.uint32 and int(w[-1]) >> 1 == 0  # no term at or beyond t^19937
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pieces", [1, 3, 8, 16, 64])
+def test_chunked_device_stream_equals_torch_rand(pieces):
+    """midas_mt19937_rand64_chunked: from the second draw on a call's words are generated in `pieces` pieces side by side (start
+    states by jump polynomials from the previous call's words) - the same stream as torch.rand bit for bit, across changing
+    sizes, the reference's draw order (normals skipped between the resampler's draws), calls too short to chain, and re-seeding."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from midastouch_amd.torch_rng import TorchCpuStream
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(77)
+    st = TorchCpuStream(77, dev, pieces=pieces)
+    chained = 0
+    for n in (100_000, 100_000, 100_000, 50_001, 100_000, 10_280, 10_281, 12_000, 5_000, 100_000, 100_000, 311_000):
+        had = st._hist_words
+        assert torch.equal(st.rand64(n).cpu(), torch.rand(n, dtype=torch.float64)), n
+        chained += 1 if (had and 2 * n >= 20560) else 0
+    assert chained >= 7
+    # the reference's frame: tn, rot (torch.normal, skipped here), then the resampler's N uniforms - three frames
+    N = 33_333
+    for _ in range(3):
+        torch.normal(0.0, 2e-4, size=(N, 3)), torch.normal(0.0, 0.5, size=(N, 3))
+        assert torch.equal(st.skip_normal(3 * N).skip_normal(3 * N).rand64(N).cpu(), torch.rand(N, dtype=torch.float64))
+    st.manual_seed(5)
+    torch.manual_seed(5)
+    for n in (20_000, 20_000, 1_000_000, 1_000_000):
+        assert torch.equal(st.rand64(n).cpu(), torch.rand(n, dtype=torch.float64)), n
+    # the generator's state is torch's: a sequential stream seeded from it continues identically
+    seq = TorchCpuStream(0, dev, pieces=0)
+    seq.state.copy_(st.state)
+    assert torch.equal(seq.rand64(1000).cpu(), torch.rand(1000, dtype=torch.float64))
+
+
 @pytest.mark.gpu
 def test_resampler_on_the_device_stream_matches_reference_digests(golden):
     """G2b (the reference's own resampler at N = 100 000 under torch.manual_seed, tools/gen_goldens_r2.py) through
