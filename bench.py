@@ -378,7 +378,8 @@ def parity_mode_rate(cb, traj, N, dev, tree, mesh_tree, steps=100):
     dt = sorted(dts)[1]
     return {"steps_per_sec": steps / dt, "steps_per_sec_runs": spread([steps / d for d in dts]), "ms_per_step": 1e3 * dt / steps, "steps": steps,
             "draws": "resample: device replica of torch's CPU mt19937 under torch.manual_seed(3000) (torch.rand(N, float64) stream, "
-                     "generated on the generator's own stream beside each frame's kernels); motion noise: device Philox",
+                     "generated on the generator's own stream beside each frame's kernels, a frame's 2 N words in six pieces side by side whose start "
+                     "states follow from the previous frame's words by GF(2) jump polynomials: midastouch_amd/mt_jump.py); motion noise: device Philox",
             "status": eng.status.cpu().numpy().tolist()}
 
 

@@ -146,36 +146,54 @@ __global__ __launch_bounds__(256) void k_mt_emit(const uint32_t* __restrict__ ra
 //     x[k + J] = XOR over the exponents i of P_J of x[k + i]          (Haramoto et al. 2008; midastouch_amd/mt_jump.py)
 // for every k - so the 624 words that START a piece of this call's output follow from MT_HIST consecutive words of the previous
 // call's output (`hist`, kept by k_mt_emit) and one polynomial per piece (host-side set-up, 624-word bitsets).  A workgroup
-// computes MT_JW consecutive words of one piece's start: the window hist[k0, k0 + 19937 + MT_JW) in LDS (78 KB), a thread walks
-// the set bits of its share of the polynomial (~10^4 taps, 40 per thread) and XORs MT_JW consecutive window words per tap;
-// the threads' partial sums meet in an XOR butterfly.
+// computes MT_JW consecutive words of one piece's start from the window hist[k0, k0 + 19936 + MT_JW) in LDS (78 KB, two
+// workgroups a compute unit): ~10^4 terms per polynomial, MT_JW window words each; the partial sums meet in an XOR butterfly.
 constexpr int MT_JW = 16;
-constexpr int MT_JWIN = MT_DEG + MT_JW;  // window words per workgroup
-static_assert(MT_N % MT_JW == 0, "whole workgroups per piece");
+constexpr int MT_JWIN = MT_DEG + MT_JW - 1;  // window words per workgroup: taps i <= 19936, words i .. i + 15
+constexpr int MT_JQ = MT_N / 2;              // 312 groups of 64 exponents
+static_assert(MT_N % MT_JW == 0 && MT_JQ % 4 == 0, "whole workgroups per piece, whole shares per wave");
+// Lane L of a wave takes the exponents i = 64 q + L (bit L & 31 of polynomial word 2 q + (L >> 5)): the lanes that hold a term read
+// window words i + m, m = 0 .. 15, one m at a time - bank (L + m) mod 64, all different: no LDS conflicts (a thread per term with
+// its sixteen consecutive words collided four to five deep, and the kernel took 40 us where this takes 7 for eight pieces).
+// The four waves share the q range; a lane's 78 polynomial words are in registers before the window has arrived.
 __global__ __launch_bounds__(256) void k_mt_jump(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ polys,
                                                  uint32_t* __restrict__ starts) {
-    extern __shared__ uint32_t s_win[];  // MT_JWIN words + 4 x MT_JW for the cross-wave step
-    const int t = threadIdx.x, k0 = blockIdx.x * MT_JW, c = blockIdx.y;
-    for (int j = t; j < MT_JWIN; j += 256) s_win[j] = hist[k0 + j];
-    const uint32_t* P = polys + (size_t)c * MT_N;
-    uint32_t pw[3];
+    extern __shared__ uint32_t s_win[];  // MT_JWIN words (the first 4 x MT_JW reused for the cross-wave step)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, k0 = blockIdx.x * MT_JW, c = blockIdx.y;
+    const uint32_t* P = polys + (size_t)c * MT_N + (lane >> 5);
+    uint32_t pw[MT_JQ / 4];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) pw[q] = (t + 256 * q < MT_N) ? P[t + 256 * q] : 0u;
+    for (int r = 0; r < MT_JQ / 4; ++r) pw[r] = P[2 * (wave + 4 * r)];
+    {   // the window: 16-byte pieces, every load of a thread in flight before its first LDS store (one round trip, not twenty)
+        constexpr int NV = (MT_JWIN + 3) / 4, PER = (NV + 255) / 256;
+        const uint4* src = reinterpret_cast<const uint4*>(hist + k0);  // k0 is a multiple of 16 words
+        uint4 v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int j = t + 256 * u;
+            v[u] = j < NV - 1 ? src[j] : make_uint4(0u, 0u, 0u, 0u);
+        }
+        uint4* dst = reinterpret_cast<uint4*>(s_win);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int j = t + 256 * u;
+            if (j < NV - 1) dst[j] = v[u];
+        }
+        // the last, partial piece word by word (hist ends at MT_HIST: no read beyond it)
+        if (t < MT_JWIN - 4 * (NV - 1)) s_win[4 * (NV - 1) + t] = hist[k0 + 4 * (NV - 1) + t];
+    }
     __syncthreads();
     uint32_t acc[MT_JW];
 #pragma unroll
     for (int m = 0; m < MT_JW; ++m) acc[m] = 0u;
+    const int sh = lane & 31;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        uint32_t bits = pw[q];
-        const int base = 32 * (t + 256 * q);
-        while (bits) {
-            const int i = base + __builtin_ctz(bits);
-            bits &= bits - 1u;
-            if (i < MT_DEG) {  // (a polynomial has no term beyond: guards the window against a malformed table)
+    for (int r = 0; r < MT_JQ / 4; ++r) {  // (fully unrolled: the polynomial words stay in registers)
+        const int i = 64 * (wave + 4 * r) + lane;
+        if (((pw[r] >> sh) & 1u) && i < MT_DEG) {  // (a polynomial has no term at or beyond t^19937: guards the window)
+            const uint32_t* w = s_win + i;
 #pragma unroll
-                for (int m = 0; m < MT_JW; ++m) acc[m] ^= s_win[i + m];
-            }
+            for (int m = 0; m < MT_JW; ++m) acc[m] ^= w[m];
         }
     }
 #pragma unroll
@@ -183,13 +201,13 @@ __global__ __launch_bounds__(256) void k_mt_jump(const uint32_t* __restrict__ hi
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) acc[m] ^= (uint32_t)__shfl_xor((int)acc[m], o);
     }
-    uint32_t* s_x = s_win + MT_JWIN;
-    if ((t & 63) == 0) {
+    __syncthreads();  // every wave is done with the window
+    if (lane == 0) {
 #pragma unroll
-        for (int m = 0; m < MT_JW; ++m) s_x[(t >> 6) * MT_JW + m] = acc[m];
+        for (int m = 0; m < MT_JW; ++m) s_win[wave * MT_JW + m] = acc[m];
     }
     __syncthreads();
-    if (t < MT_JW) starts[(size_t)c * MT_N + k0 + t] = (s_x[t] ^ s_x[MT_JW + t]) ^ (s_x[2 * MT_JW + t] ^ s_x[3 * MT_JW + t]);
+    if (t < MT_JW) starts[(size_t)c * MT_N + k0 + t] = (s_win[t] ^ s_win[MT_JW + t]) ^ (s_win[2 * MT_JW + t] ^ s_win[3 * MT_JW + t]);
 }
 
 // Piece c = blocks [c bpc, (c + 1) bpc) of the call's nblocks blocks of 624 words (block 0 starts at the call's first word): its first
@@ -264,7 +282,7 @@ int launch_mt_rand64_chunked(midas_ctx* ctx, uint32_t* state, int64_t N, double*
     uint32_t* starts = (uint32_t*)p;
     static bool attr_set[64] = {};
     const int di = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
-    const int lds = (MT_JWIN + 4 * MT_JW) * (int)sizeof(uint32_t);
+    const int lds = MT_JWIN * (int)sizeof(uint32_t);
     if (!attr_set[di] || ctx->device != di) {
         MIDAS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_mt_jump, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set[di] = true;

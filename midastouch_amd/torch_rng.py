@@ -39,13 +39,14 @@ class TorchCpuStream:
     t + 1's launch).  The output buffers rotate (3): a buffer is rewritten two calls later, after the side stream has waited
     for the caller's stream as of THAT call - whoever consumed it was enqueued before.
 
-    `pieces` (default 8; 0 = always the sequential walk): a call's 2 N words are generated in that many pieces side by side once
+    `pieces` (default 6; 0 = always the sequential walk): a call's 2 N words are generated in that many pieces side by side once
     the previous call has left MIDAS_MT19937_HIST_WORDS of its words on the device - mt19937 is linear over GF(2), the words
     that start a piece follow from those by one polynomial per piece (mt_jump.py; computed on the host once per distinct
     (previous size, skip, size), ~10 ms each, checked against a reference generator before use).  Same numbers, bit for bit;
-    321 sequential blocks (100 us at N = 100k) become 41."""
+    321 sequential blocks (86 us at N = 100k) become 54: 12 us for the jump, 15 for the blocks, 4 for the conversion - the seeded
+    step at c2 goes from 10.8k to 22.7k frames/s (4 / 6 / 8 / 12 pieces: 21.7 / 22.7 / 21.7 / 21.8k; tools/bench_parity_mode.py)."""
 
-    def __init__(self, seed: int, device=None, overlap: bool = True, pieces: int = 8):
+    def __init__(self, seed: int, device=None, overlap: bool = True, pieces: int = 6):
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.device = _lib.context(dev).device
         self.overlap = bool(overlap)
@@ -81,6 +82,7 @@ class TorchCpuStream:
         self._call("midas_mt19937_seed", int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(self.state))
         self.pending_skip = 0
         self._hist_words = 0
+        self._mark = None
         return self
 
     def skip_words(self, n: int):
@@ -99,6 +101,7 @@ class TorchCpuStream:
         before the third following call (the engines: one draw per frame, consumed by that frame) - anybody who keeps the
         tensor longer, or shares the stream object between engines, passes `out` (or calls rand64, which allocates)."""
         N = int(N)
+        own = out is None
         if out is None:
             i = self._turn
             self._turn = (i + 1) % 3
@@ -109,7 +112,20 @@ class TorchCpuStream:
                 if self.side is not None:
                     self._bufs[i].record_stream(self.side)
             out = self._bufs[i]
-        self._enter()
+        if own and self.side is not None:
+            # A rotating buffer was last handed out three calls ago and, by the contract above, its consumer was enqueued before the
+            # call after that one: the generator waits for the caller's stream as it stood at the PREVIOUS call, not as it stands
+            # now - it may run a whole frame ahead of the kernels that are being enqueued (state and history are its own).
+            cur = torch.cuda.current_stream(self.device)
+            mark = torch.cuda.Event()
+            mark.record(cur)
+            prev, self._mark = getattr(self, "_mark", None), mark
+            if prev is None:
+                self.side.wait_stream(cur)
+            else:
+                self.side.wait_event(prev)
+        else:
+            self._enter()
         words = 2 * N
         polys = None
         if self.pieces > 0 and self._hist_words and words >= _lib.MT19937_HIST_WORDS:
