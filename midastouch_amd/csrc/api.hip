@@ -314,6 +314,7 @@ MIDAS_EXPORT int midas_tree_destroy(midas_tree* t) {
     if (t->twin) (void)hipFree(t->twin);
     if (t->vlist) (void)hipFree(t->vlist);
     if (t->vscr) (void)hipFree(t->vscr);
+    if (t->field.d) (void)hipFree(const_cast<float*>(t->field.d));
     tree_free_host(t);
     delete t;
     return MIDAS_OK;
@@ -550,6 +551,7 @@ static int filter_step_impl(midas_ctx* ctx, const midas_codebook* cb, const mida
     pa.thr = s.prune_thr;
     pa.vlist = (tree6->vlist && tree6->vlist_mesh == tree3) ? (const MeshRec*)tree6->vlist : nullptr;
     pa.vscr = pa.vlist ? (const MeshScr*)tree6->vscr : nullptr;
+    pa.field = tree3->field;
     pa.telemetry = (unsigned long long*)s.telemetry_dev;
     pa.status_reset = s.status_dev;
     pa.part_max = (double*)pmax;
@@ -757,6 +759,7 @@ static int lazy_step_impl(midas_ctx* ctx, const midas_codebook* cb, const midas_
     pa.thr = s.prune_thr;
     pa.vlist = (tree6->vlist && tree6->vlist_mesh == tree3) ? (const MeshRec*)tree6->vlist : nullptr;
     pa.vscr = pa.vlist ? (const MeshScr*)tree6->vscr : nullptr;
+    pa.field = tree3->field;
     pa.telemetry = (unsigned long long*)s.telemetry_dev;
     pa.status_reset = s.status_dev;
     pa.gt16 = (s.gt16_dev && s.part_rmse_dev) ? s.gt16_dev : nullptr;
@@ -958,6 +961,7 @@ static int shard_front_impl(midas_ctx* ctx, const midas_codebook* cb, const mida
     pa.thr = s.prune_thr;
     pa.vlist = (tree6->vlist && tree6->vlist_mesh == tree3) ? (const MeshRec*)tree6->vlist : nullptr;
     pa.vscr = pa.vlist ? (const MeshScr*)tree6->vscr : nullptr;
+    pa.field = tree3->field;
     pa.telemetry = (unsigned long long*)s.telemetry_dev;
     pa.status_reset = s.status_dev;
     pa.flags_reset = s.flags_dev;

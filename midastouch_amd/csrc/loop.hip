@@ -1102,6 +1102,7 @@ int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree*
         pa.thr = s.prune_thr;
         pa.vlist = (t6->vlist && t6->vlist_mesh == t3) ? (const MeshRec*)t6->vlist : nullptr;
         pa.vscr = pa.vlist ? (const MeshScr*)t6->vscr : nullptr;
+        pa.field = t3->field;
         pa.telemetry = (unsigned long long*)s.telemetry_dev;
         pa.gt16 = (s.gt16_dev && s.part_rmse_dev) ? s.gt16_dev : nullptr;
         pa.part_rmse = s.part_rmse_dev;

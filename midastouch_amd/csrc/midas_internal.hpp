@@ -55,6 +55,20 @@ constexpr int MESH_M = 256;
 constexpr int MESH_REC = MESH_M + 1;  // record 0 = header: c = the entry's translation, rho = distance of the
                                       // first vertex NOT in the list
 
+// Distance field of a mesh (dim-3 trees): the exact distance from the CENTRE of every cell of a uniform grid to its nearest mesh
+// vertex, as float32.  The distance to the nearest vertex is 1-Lipschitz, so a particle at distance rho from its cell's centre has
+// d in [v - rho, v + rho]: the prune ("some vertex within thr", modules/particle_filter.py:386-391) is DECIDED for every particle
+// outside a shell of half-width rho (< 0.87 cells) around the threshold surface - by one 4-byte read requested before the
+// nearest-neighbour search - and only the shell goes on to the vertex lists / the tree, which remain the exact decision.
+// A point outside the grid (the vertices' bounding box grown by `expand`) is farther than `expand` from every vertex.
+struct MeshField {
+    const float* d = nullptr;  // [n[2]][n[1]][n[0]]
+    float lo[3] = {0.f, 0.f, 0.f};
+    float h = 0.f, inv_h = 0.f;
+    int32_t n[3] = {0, 0, 0};
+    float expand = 0.f;
+};
+
 template <class KD>
 struct TreeView {
     const typename KD::Box* boxes;  // [(8^(L+1) - 1)/7]
@@ -122,6 +136,7 @@ struct midas_tree {
     void* vscr;      // MeshScr[K * MESH_REC]: float32 screening copy of vlist (nullable)
     const midas_tree* vlist_mesh;  // the mesh tree the lists were built from
     void* host;      // host copy of the tree (dim 3: used to build the lists)
+    midas::MeshField field;  // dim 3: distance field of the vertices (d == nullptr: none); library-owned
 };
 
 // ---- error helpers ----------------------------------------------------------------------------
@@ -322,6 +337,7 @@ struct ParticleUpdateArgs {
     double thr;            // the threshold itself (triangle-inequality tests of the vertex lists)
     const MeshRec* vlist;  // nullable: per-codebook-entry mesh vertex lists
     const MeshScr* vscr = nullptr;  // nullable: their float32 screening copy (only read when vlist is set)
+    MeshField field;                // d != nullptr: the mesh's distance field decides the prune wherever it can (see MeshField)
     double* part_max;      // [nblocks]
     double* part_min;      // [nblocks]
     const float* gt16;     // nullable

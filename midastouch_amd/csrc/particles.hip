@@ -286,6 +286,12 @@ static int upload_tree(midas_ctx* ctx, const HostTree<KD>& h, int64_t K, midas_t
     return MIDAS_OK;
 }
 
+// The distance field of a dim-3 tree's vertices (MeshField): the bounding box grown by FIELD_EXPAND, cubic cells sized so that the
+// grid has at most FIELD_MAX_CELLS of them, every cell's value by the exact search (k_field_build).  MIDAS_MESH_FIELD=0: none.
+constexpr double FIELD_EXPAND = 0.0025;            // m: decides "outside the grid = pruned" for thresholds below it (the reference's is 0.002)
+constexpr int64_t FIELD_MAX_CELLS = (int64_t)1 << 22;  // 16 MB of float32
+static int build_mesh_field(midas_ctx* ctx, midas_tree* t, const double* pts, int64_t K);
+
 int tree_build_impl(midas_ctx* ctx, int32_t dim, int64_t K, const void* points_dev, midas_tree* out) {
     MIDAS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (dim == 6) {
@@ -305,7 +311,9 @@ int tree_build_impl(midas_ctx* ctx, int32_t dim, int64_t K, const void* points_d
     MIDAS_HIP_CHECK(ctx, hipMemcpy(host.data(), points_dev, host.size() * sizeof(double), hipMemcpyDeviceToHost));
     HostTree<Kd3>* h = new HostTree<Kd3>(build_tree<Kd3>(host.data(), K));
     out->host = h;  // kept for attach_mesh (host k-NN over the mesh vertices)
-    return upload_tree<Kd3>(ctx, *h, K, out);
+    int rc = upload_tree<Kd3>(ctx, *h, K, out);
+    if (rc) return rc;
+    return build_mesh_field(ctx, out, host.data(), K);
 }
 
 void tree_free_host(midas_tree* t) {
@@ -1405,6 +1413,56 @@ __global__ __launch_bounds__(64) void k_nn6_stats(TreeView<Kd6> tv, int64_t N, c
     }
 }
 
+// ---- the mesh's distance field (MeshField, midas_internal.hpp) ---------------------------------------------------------------
+// The centre of cell (ix, iy, iz) as ONE float32 expression, used by the builder and by the look-up alike (the stored distance
+// belongs to exactly this point).
+MD float field_centre(const MeshField& f, int axis, int i) { return fmaf_((float)i + 0.5f, f.h, f.lo[axis]); }
+
+// A look-up in two halves: field_fetch requests the cell's value (early: the translation is known once the motion model is done,
+// the answer travels under the nearest-neighbour search), field_decide turns it into 1 (some vertex within thr, certain),
+// 0 (none, certain) or -1 (the shell around the threshold, NaN, no field: the exact path decides).
+struct FieldProbe { float v = 0.f, rho = 0.f; int state = 2; };  // state 0: inside the grid, 1: outside it, 2: unknown
+MD FieldProbe field_fetch(const MeshField& f, const float* tq, bool live) {
+    FieldProbe pr;
+    if (!f.d || !live) return pr;
+    const float gx = (tq[0] - f.lo[0]) * f.inv_h, gy = (tq[1] - f.lo[1]) * f.inv_h, gz = (tq[2] - f.lo[2]) * f.inv_h;
+    if (!(gx == gx && gy == gy && gz == gz)) return pr;  // NaN: unknown
+    if (!(gx >= 0.f && gy >= 0.f && gz >= 0.f && gx < (float)f.n[0] && gy < (float)f.n[1] && gz < (float)f.n[2])) { pr.state = 1; return pr; }
+    const int ix = (int)gx, iy = (int)gy, iz = (int)gz;  // (a value that rounding put into the neighbouring cell is served by that cell: rho says how far its centre is)
+    const float dx = tq[0] - field_centre(f, 0, ix), dy = tq[1] - field_centre(f, 1, iy), dz = tq[2] - field_centre(f, 2, iz);
+    pr.rho = __builtin_sqrtf(fmaf_(dz, dz, fmaf_(dy, dy, dx * dx)));
+    pr.v = f.d[((int64_t)iz * f.n[1] + iy) * f.n[0] + ix];
+    pr.state = 0;
+    return pr;
+}
+MD int field_decide(const MeshField& f, const FieldProbe& pr, double thr) {
+    if (pr.state == 2 || !(thr >= 0.0)) return -1;
+    const float thr_up = __double2float_ru(thr), thr_dn = __double2float_rd(thr);
+    if (pr.state == 1) return f.expand > thr_up * 1.00001f ? 0 : -1;  // outside the grown bounding box: farther than `expand` from every vertex
+    // true distance d, stored v = float(d_centre) (nearest: 6e-8 relative), rho computed to 4e-7 relative on float32 coordinates
+    // that are exact: |d - v| <= rho + 1e-6 (v + rho), and the exact path's comparison is d <= thr up to 1e-16
+    const float slack = 2e-6f * (pr.v + pr.rho + thr_up) + 1e-30f;
+    if (pr.v + pr.rho + slack <= thr_dn) return 1;
+    if (pr.v - pr.rho - slack >= thr_up) return 0;
+    return -1;
+}
+
+// builder: exact distance (float64 search of the 3-d tree, as k_nn3) from every cell centre of a slab of the grid
+__global__ __launch_bounds__(64) void k_field_build(TreeView<Kd3> tv, MeshField f, int64_t c0, int64_t ncells, float* __restrict__ out) {
+    __shared__ double s_cd[KD_MAX_LEVELS * 64];
+    const int64_t n = c0 + (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = n < ncells;
+    double q[3] = {0.0, 0.0, 0.0};
+    if (live) {
+        const int ix = (int)(n % f.n[0]), iy = (int)((n / f.n[0]) % f.n[1]), iz = (int)(n / ((int64_t)f.n[0] * f.n[1]));
+        q[0] = (double)field_centre(f, 0, ix); q[1] = (double)field_centre(f, 1, iy); q[2] = (double)field_centre(f, 2, iz);
+    }
+    double best = INFINITY;
+    int64_t bi = 0;
+    wave_search<Kd3, false>(tv, q, best, bi, live, s_cd);
+    if (live) out[n] = (float)__builtin_sqrt(best);
+}
+
 __global__ __launch_bounds__(64) void k_nn3(TreeView<Kd3> tv, int64_t N, const float* __restrict__ poses,
                                             double* __restrict__ dist) {
     __shared__ double s_cd[KD_MAX_LEVELS * 64];
@@ -1805,6 +1863,9 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
         store_pose(a.poses_prop + n * 16, R);
         se3_feature(R, 0.99f, 0.01f, f);
     }
+    // the prune's distance-field cell is requested now (it needs the translation only): the answer arrives under the search
+    const float tq_f[3] = {R[3], R[7], R[11]};
+    const FieldProbe probe = field_fetch(a.field, tq_f, live && !(ablate & 2));
     MIDAS_TICK(1);
     // nearest codebook entry
     int32_t bi = 0;
@@ -1831,8 +1892,11 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
     // look at the stamps is a round trip of its own)
     // (of the float32 screening copy; without one the float64 list is read after the claim)
     constexpr bool PRE = PREF;
+    // prune, first word: the distance field (1 valid, 0 invalid: certain; -1: the vertex lists / the tree decide)
+    int mv = live ? field_decide(a.field, probe, a.thr) : -1;
+    const bool lists_needed = __ballot(live && mv < 0) != 0;  // (wave-uniform: a wave whose particles are all decided skips the lists)
     MeshScr pre[PRE ? 1 + MESH_BATCH : 1];
-    if (PRE && a.vscr != nullptr) {
+    if (PRE && a.vscr != nullptr && lists_needed) {
         const MeshScr* vs = a.vscr + (size_t)(live ? bi : 0) * MESH_REC;
 #pragma unroll
         for (int j = 0; j < (PRE ? 1 + MESH_BATCH : 1); ++j) pre[j] = vs[j];
@@ -1847,17 +1911,17 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
     double q3[3] = {(double)R[3], (double)R[7], (double)R[11]};
     double best = a.t2;
     int64_t vi = 0;
-    int mv = -1;  // 1 valid, 0 invalid, -1 undecided
     if (ablate & 2) mv = 1;
-    else if (a.vlist) {
+    else if (a.vlist && lists_needed) {
         double lim_lane = 0.0;
+        const bool open = live && mv < 0;  // the lanes the field left undecided
         if (a.vscr) {  // first records, per lane: float32 screening copy, the float64 records only for what it cannot decide
             const float tqf[3] = {R[3], R[7], R[11]};
-            if (live) mv = mesh_screen_check<PRE>(a.vscr, bi, tqf, a.thr, MESH_SOLO, &lim_lane, pre);
+            if (open) mv = mesh_screen_check<PRE>(a.vscr, bi, tqf, a.thr, MESH_SOLO, &lim_lane, pre);
             if (__ballot(mv == -2)) {
                 if (mv == -2) mv = mesh_list_check<false>(a.vlist, bi, q3, a.t2, a.thr, MESH_SOLO, &lim_lane);
             }
-        } else if (live) {
+        } else if (open) {
             mv = mesh_list_check<false>(a.vlist, bi, q3, a.t2, a.thr, MESH_SOLO, &lim_lane);
         }
         MIDAS_TICK(4);
@@ -2104,6 +2168,10 @@ MD void particle_nn_prune_wg(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
     const float4 f0 = fp[0], f1 = fp[1];
     const float q[6] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y};
     int32_t hint = live ? __float_as_int(f1.z) : -1;
+    // the prune's distance-field cell (MeshField) is requested now, under the search: the translation is in the propagated pose
+    const float* pr = a.poses_prop + pc * 16;
+    const float tq_f[3] = {pr[3], pr[7], pr[11]};
+    const FieldProbe probe = field_fetch(a.field, tq_f, live);
     // ---- nearest codebook entry: the solo records of the hinted entry's list ----
     float best = INFINITY, r_lane = 0.f;
     int64_t bi = 0;
@@ -2175,12 +2243,12 @@ MD void particle_nn_prune_wg(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
     const int32_t nn = (int32_t)dpp_u32<BC_FIRST>((uint32_t)(int32_t)bi);
     // ---- prune: header + records 1 .. 16 of the entry's vertex list in one round trip, requested BEFORE the row claim of the
     // sparse scoring so that the claim's look at the stamps (a round trip of its own) runs beside it ----
-    const float* pr = a.poses_prop + pc * 16;
-    const double q3[3] = {(double)pr[3], (double)pr[7], (double)pr[11]};
-    int mv = -1;  // 1 valid, 0 invalid, -1 undecided
+    const double q3[3] = {(double)tq_f[0], (double)tq_f[1], (double)tq_f[2]};
+    int mv = live ? field_decide(a.field, probe, a.thr) : -1;  // 1 valid, 0 invalid (the distance field: certain), -1 undecided
+    const bool lists_needed = __ballot(live && mv < 0) != 0;    // (wave-uniform)
     double lim = 0.0;
     MeshRec hd, e[MESH_PER_LANE];
-    if (a.vlist) {
+    if (a.vlist && lists_needed) {
         const MeshRec* vl = a.vlist + (size_t)(live ? nn : 0) * MESH_REC;
         hd = vl[0];
 #pragma unroll
@@ -2192,7 +2260,7 @@ MD void particle_nn_prune_wg(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
         const int nr = score_claimed_rows_nj(a.sp, claim, nn);
         if (a.telemetry && nr && lane == 0) atomicAdd(&a.telemetry[2], (unsigned long long)nr);
     }
-    if (a.vlist) {
+    if (a.vlist && lists_needed) {
         Point3 ph;
         ph.c[0] = hd.c[0]; ph.c[1] = hd.c[1]; ph.c[2] = hd.c[2];
         const double delta = __builtin_sqrt(dist2(q3, ph)) * (1.0 + 1e-12);
@@ -2208,7 +2276,7 @@ MD void particle_nn_prune_wg(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
         }
         hits |= dpp_u32<DPP_XOR1>(hits); stops |= dpp_u32<DPP_XOR1>(stops);
         if (LPP == 4) { hits |= dpp_u32<DPP_XOR2>(hits); stops |= dpp_u32<DPP_XOR2>(stops); }
-        if (live && (hits | stops)) {  // the first event in record order decides, "provably too far" before "hit"
+        if (live && mv < 0 && (hits | stops)) {  // the first event in record order decides, "provably too far" before "hit"
             const int fh = hits ? __builtin_ctz(hits) : 32, fs = stops ? __builtin_ctz(stops) : 32;
             mv = fh < fs ? 1 : 0;
         }
@@ -2352,6 +2420,53 @@ int launch_nn6_stats(midas_ctx* ctx, const midas_tree* t, int64_t N, const float
     hipLaunchKernelGGL(k_nn6_stats, dim3((unsigned)ceil_div(N, 64)), dim3(64), 0, ctx->stream, view_of<Kd6>(t), N, feat6,
                        hint, leaves, nodes);
     MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    return MIDAS_OK;
+}
+
+static int build_mesh_field(midas_ctx* ctx, midas_tree* t, const double* pts, int64_t K) {
+    const char* env = getenv("MIDAS_MESH_FIELD");
+    if ((env && env[0] == '0') || K <= 0) return MIDAS_OK;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t k = 0; k < K; ++k)
+        for (int d = 0; d < 3; ++d) {
+            const double v = pts[3 * k + d];
+            if (!(v == v) || std::isinf(v)) return MIDAS_OK;  // non-finite vertices: no field (the exact paths deal with them as before)
+            lo[d] = v < lo[d] ? v : lo[d];
+            hi[d] = v > hi[d] ? v : hi[d];
+        }
+    double ext[3], vol = 1.0;
+    for (int d = 0; d < 3; ++d) { ext[d] = (hi[d] - lo[d]) + 2.0 * FIELD_EXPAND * 1.01; vol *= ext[d]; }
+    double h = std::cbrt(vol / (double)FIELD_MAX_CELLS);
+    MeshField f;
+    for (int iter = 0; iter < 8; ++iter) {  // (rounding the counts up can exceed the budget: grow the cells a little)
+        int64_t cells = 1;
+        for (int d = 0; d < 3; ++d) { f.n[d] = (int32_t)std::ceil(ext[d] / h) + 1; cells *= f.n[d]; }
+        if (cells <= FIELD_MAX_CELLS) break;
+        h *= 1.03;
+    }
+    f.h = (float)h;
+    f.inv_h = 1.0f / f.h;
+    // the grid's corner: at or below lo - 1.01 expand as a float32 (a point "outside" must really be beyond the grown box)
+    for (int d = 0; d < 3; ++d) f.lo[d] = std::nextafter((float)(lo[d] - FIELD_EXPAND * 1.01), -INFINITY);
+    // ... and the far faces: n cells of f.h must reach hi + expand (the counts were taken with the double h: check with the float)
+    for (int d = 0; d < 3; ++d)
+        while ((double)f.lo[d] + (double)f.n[d] * (double)f.h < hi[d] + FIELD_EXPAND * 1.005) ++f.n[d];
+    f.expand = (float)FIELD_EXPAND;
+    const int64_t cells = (int64_t)f.n[0] * f.n[1] * f.n[2];
+    float* dev = nullptr;
+    if (hipMalloc((void**)&dev, (size_t)cells * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return MIDAS_OK; }  // no memory: no field
+    f.d = dev;
+    const TreeView<Kd3> tv = view_of<Kd3>(t);
+    const int64_t SLAB = (int64_t)1 << 24;  // cells per launch
+    for (int64_t c0 = 0; c0 < cells; c0 += SLAB) {
+        const int64_t n = cells - c0 < SLAB ? cells - c0 : SLAB;
+        hipLaunchKernelGGL(k_field_build, dim3((unsigned)ceil_div(n, 64)), dim3(64), 0, ctx->stream, tv, f, c0, cells, dev);
+    }
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        (void)hipFree(dev);
+        return midas_set_error(ctx, MIDAS_ERR_HIP, "k_field_build", "building the mesh's distance field failed");
+    }
+    t->field = f;
     return MIDAS_OK;
 }
 
