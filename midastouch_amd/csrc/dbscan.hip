@@ -52,6 +52,7 @@ struct DbGrid {         // written by k_db_setup
     int32_t err;
     int32_t nwork;      // points whose core test needs distances
     int32_t hashed;     // 1: the cells are the slots of the hash table (cloud wider than DB_MAXDIM cells in some axis)
+    int32_t ncore_cells;  // cells that hold a core point (k_db_clique lists them for k_db_link)
 };
 
 struct DbArgs {
@@ -74,6 +75,7 @@ struct DbArgs {
     int32_t* parent;        // [N] by particle (core points only)
     int32_t* roots;         // [DB_MAXROOTS + 1]
     int32_t* work;          // [N] sorted positions whose core test needs distances
+    int32_t* core_cells;    // [N] the cells that hold a core point (at most one per point)
     unsigned long long* hkeys;  // [DB_MAXCELLS] hashed form: key of the cell in this slot (DB_EMPTY: free)
     int32_t* rank;          // [N + 1] more than DB_MAXROOTS clusters: root flag by particle, then its exclusive prefix sum
     int32_t max_clusters;   // 0: any number; otherwise the clusters beyond that many stay unnumbered (err |= 2)
@@ -153,6 +155,7 @@ __global__ __launch_bounds__(64) void k_db_setup(DbArgs a, int nblocks) {
     g.nroots = 0;
     g.err = err;
     g.nwork = 0;
+    g.ncore_cells = 0;
     *a.grid = g;
 }
 
@@ -507,35 +510,84 @@ __device__ __forceinline__ void db_union(int32_t* parent, int32_t x, int32_t y) 
 
 // the core points of a cell are a clique: hang each under the cell's representative
 __global__ __launch_bounds__(256) void k_db_clique(DbArgs a) {
-    const DbGrid g = *a.grid;
+    DbGrid* gp = a.grid;
+    const DbGrid g = *gp;
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= g.n || !a.s_core[p]) return;
     const int c = __float_as_int(a.s_pt[p].w);
     const int32_t orig = a.s_orig[p], rep = a.cell_rep[c];
     if (orig != rep) a.parent[orig] = rep;
+    else a.core_cells[atomicAdd(&gp->ncore_cells, 1)] = c;  // the representative lists its cell (once per cell)
 }
 
-// one partner within eps in a neighbouring cell joins that cell's component
+// Two cells' components join when ONE core point of the one is within eps of ONE core point of the other.  One WAVE per cell
+// that holds core points, against the cells around it with a higher index (a pair is looked at once): the pair's components
+// are compared once, by the wave - not by every core point of the cell (round 5: one thread per core point, 125 cells each,
+// two walks of the union-find per cell: at N = 100 k in a converged cloud 25 M atomic loads of the same few roots, 5.2 ms of
+// the 7.3 ms DBSCAN frame); then the tight boxes of the two cells (wholly beyond eps: nothing; wholly within: joined);
+// then the cell's core points 64 at a time against the other cell's box, and only a point the box does not decide against
+// that cell's core points, 64 at a time, until the first hit.
+__device__ __forceinline__ void db_cell_box(const DbArgs& a, int c, double* lo, double* hi) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        lo[d] = (double)db_unkey(a.cell_box[(size_t)d * DB_MAXCELLS + c]);
+        hi[d] = (double)db_unkey(a.cell_box[(size_t)(3 + d) * DB_MAXCELLS + c]);
+    }
+}
 __global__ __launch_bounds__(256) void k_db_link(DbArgs a) {
     const DbGrid g = *a.grid;
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= g.n || !a.s_core[p]) return;
-    const float4 me = a.s_pt[p];
-    const int c = __float_as_int(me.w);
-    const int32_t orig = a.s_orig[p];
-    db_for_cells(g, a.hkeys, c, false, [&](int c2) {
-        const int32_t rep2 = a.cell_rep[c2];
-        if (rep2 == 0x7fffffff) return false;  // no core point there
-        if (db_find(a.parent, rep2) == db_find(a.parent, orig)) return false;
-        double mind2, maxd2;
-        db_box_bounds(a, c2, me, mind2, maxd2);
-        if (mind2 > a.r2) return false;  // nobody of that cell is within eps
-        if (maxd2 <= a.r2) { db_union(a.parent, orig, rep2); return false; }  // everybody is: so is its core point
-        const int e = a.cell_start[c2 + 1];
-        for (int q = a.cell_start[c2]; q < e; ++q)
-            if (a.s_core[q] && db_within(me, a.s_pt[q], a.r2)) { db_union(a.parent, orig, rep2); break; }
-        return false;
-    });
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * 256) >> 6);
+    for (int ci = wave; ci < g.ncore_cells; ci += nwaves) {
+        const int c = a.core_cells[ci];
+        const int32_t rep = a.cell_rep[c];
+        const int b1 = a.cell_start[c], e1 = a.cell_start[c + 1];
+        double lo1[3], hi1[3];
+        db_cell_box(a, c, lo1, hi1);
+        db_for_cells(g, a.hkeys, c, false, [&](int c2) {  // (wave-uniform: every lane walks the same cells)
+            if (c2 <= c) return false;                    // the pair belongs to the cell with the lower index
+            const int32_t rep2 = a.cell_rep[c2];
+            if (rep2 == 0x7fffffff) return false;         // no core point there
+            if (db_find(a.parent, rep2) == db_find(a.parent, rep)) return false;
+            // the two tight boxes, in the predicate's arithmetic (see db_box_bounds: rounding is monotone through it)
+            double lo2[3], hi2[3], mind2 = 0.0, maxd2 = 0.0;
+            db_cell_box(a, c2, lo2, hi2);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const double ga = lo2[d] - hi1[d], gb = lo1[d] - hi2[d];
+                double gm = ga > gb ? ga : gb;
+                gm = gm > 0.0 ? gm : 0.0;
+                const double fa = hi2[d] - lo1[d], fb = hi1[d] - lo2[d];
+                const double fm = fa > fb ? fa : fb;
+                if (d == 0) { mind2 = gm * gm; maxd2 = fm * fm; } else { mind2 += gm * gm; maxd2 += fm * fm; }
+            }
+            if (mind2 > a.r2) return false;
+            bool linked = maxd2 <= a.r2;  // every pair is within eps: so are two core points
+            const int b2 = a.cell_start[c2], e2 = a.cell_start[c2 + 1];
+            for (int p0 = b1; p0 < e1 && !linked; p0 += 64) {
+                const int p = p0 + lane, pc = p < e1 ? p : e1 - 1;
+                const bool active = p < e1 && a.s_core[pc];
+                const float4 me = a.s_pt[pc];
+                double mn, mx;
+                db_box_bounds(a, c2, me, mn, mx);
+                // (the other cell's box holds its non-core points too: "all of it within eps" still reaches its core points)
+                if (__any(active && mx <= a.r2)) { linked = true; break; }
+                unsigned long long open = __ballot(active && mn <= a.r2);
+                while (open && !linked) {
+                    const int l = (int)__builtin_ctzll(open);
+                    open &= open - 1;
+                    float4 mq;
+                    mq.x = __shfl(me.x, l); mq.y = __shfl(me.y, l); mq.z = __shfl(me.z, l); mq.w = 0.f;
+                    for (int q0 = b2; q0 < e2; q0 += 64) {
+                        const int q = q0 + lane, qc = q < e2 ? q : e2 - 1;
+                        if (__any(q < e2 && a.s_core[qc] && db_within(mq, a.s_pt[qc], a.r2))) { linked = true; break; }
+                    }
+                }
+            }
+            if (linked && lane == 0) db_union(a.parent, rep, rep2);
+            return false;
+        });
+    }
 }
 
 // flatten; the roots (a cluster's first core point in index order) are collected (the first DB_MAXROOTS in a list for the LDS
@@ -697,6 +749,7 @@ int launch_dbscan(midas_ctx* ctx, int64_t cap, const int32_t* n_dev, const float
     DB_SCRATCH(parent, int32_t, cap);
     DB_SCRATCH(roots, int32_t, DB_MAXROOTS + 1);
     DB_SCRATCH(work, int32_t, cap);
+    DB_SCRATCH(core_cells, int32_t, cap);
     DB_SCRATCH(hkeys, unsigned long long, DB_MAXCELLS);
     DB_SCRATCH(rank, int32_t, cap + 1);
 #undef DB_SCRATCH
@@ -711,7 +764,7 @@ int launch_dbscan(midas_ctx* ctx, int64_t cap, const int32_t* n_dev, const float
     hipLaunchKernelGGL(k_db_core, dim3(gp), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_db_core_count, dim3(gp < 2048 ? gp : 2048), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_db_clique, dim3(gp), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_db_link, dim3(gp), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_db_link, dim3(gp < 2048 ? gp : 2048), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_db_roots, dim3(gp), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_db_rank, dim3(1), dim3(1024), 0, st, a);
     hipLaunchKernelGGL(k_db_number, dim3(gp < 1024 ? gp : 1024), dim3(256), 0, st, a);

@@ -749,7 +749,9 @@ MD bool nn6_hint_scan_screened(const TreeView<Kd6>& tv, const float* q, int32_t&
 // (c5: 353 -> 376 us per batch frame with the screen, c2's front 32.2 -> 30.8 us).
 // Scans records [0, NN_SOLO) of entry h's list (record 0 = the entry itself); the first batch is fetched
 // together with the entry so that r = |q - F_h| costs no round trip of its own.
-// (measured and dropped: a greedy hop to a closer entry's list - no effect, hints are rarely stale)
+// (measured and dropped: a greedy hop to a closer entry's list - no effect at c2, hints are rarely stale; none at c5 either (round 6:
+// 278 us per batch frame with and without): there the nearest entry is about as far as the hinted one - the feature's rotation part
+// spreads the entries over five dimensions - so no pivot shortens the proof, 47 of a wave's 64 lanes go on to nn6_coop either way)
 MD bool nn6_hint_scan(const TreeView<Kd6>& tv, const float* q, int32_t& h, float& best, int64_t& bi, int* n_scanned,
                       float* r_out = nullptr) {
     const Nbr6* nb = tv.nbrs + (size_t)h * NBR_REC;
