@@ -78,7 +78,10 @@ MD void score_wave(const T* __restrict__ emb, const double* __restrict__ norms, 
 // 215 us instead of 228 (four or six: no further gain, six spills).  What the fused stream loses against k_score_reg alone
 // (172 us) is the particle waves' phase: ~2 TB/s of scattered requests during the launch's first 25 - 30 us leave the stream
 // little of the memory system; register caps that give the stream more wave slots in that phase (three / four waves a SIMD)
-// change nothing for it and cost the particle waves 5 / 16 %.  Same arithmetic per row as score_wave (same lane ownership, same
+// change nothing for it and cost the particle waves 5 / 16 %.  Round 6 measured the two remaining ideas on c2's dense front (30.0 us):
+// the row pieces as non-temporal loads (so that the stream stops evicting list records from the L2) 33.2 us, the stream's waves at
+// s_setprio 1 / 3: 32.3 / 32.7, both together 34.4 - all slower, none kept (tools/ab_dense_stream.sh, gpurun_out r06_ab_dense).
+// Same arithmetic per row as score_wave (same lane ownership, same
 // summation order): bit-identical scores.
 template <typename T, int NJ, int R>
 MD void score_wave_multi(const T* __restrict__ emb, const double* __restrict__ norms, const double* __restrict__ code,
