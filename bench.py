@@ -840,11 +840,24 @@ def main():
                 break
             except Exception:
                 pass
+        # the same kernel's mean duration in the committed rocprofv3 --kernel-trace of this command (the steady 200-step form):
+        # the HIP-event figure above has an empty event pair's overhead taken off, the trace has nothing taken off
+        traced = {}
+        for tag, key in (("front", "frame_front_pipelined"),):
+            for name in ("r06_front_trace.json", "r05_j_front_trace.json"):
+                try:
+                    traced = {"ms": json.load(open(os.path.join(REPO, "profiles", name)))[key]["mean_us_all_calls"] * 1e-3, "source": "profiles/" + name}
+                    break
+                except Exception:
+                    pass
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                            "algorithmic_bytes_per_launch": needed, "needed_bytes": needed,
                            "survey_8d_bytes_of_the_launch": (N * (PER_PARTICLE_UPDATE + PER_PARTICLE_FOLDED) + ab["score_codebook"] + K * 24) if fused else ab[dom],
                            "kernel_ms": groups[dom],
+                           "kernel_ms_rocprof": traced.get("ms") if dom == "frame_front" else None,
+                           "frac_rocprof": (needed / traced["ms"] / 1e6 / HBM_PEAK_GBS) if (dom == "frame_front" and traced) else None,
+                           "kernel_ms_rocprof_source": traced.get("source") if dom == "frame_front" else None,
                            "rows_scored_per_launch": rows_prof if sparse else float(K),
                            "per_kernel_ms": per, "event_pair_overhead_ms": overhead,
                            "frac_survey_model": survey / HBM_PEAK_GBS, "survey_model_bytes_per_launch": ab[dom],
@@ -881,7 +894,16 @@ def main():
             fi += nd
             eng.sparse_scores = True
             d_ms = dper["particle_update"]
+            dtr = {}
+            for name in ("r06_dense_front_trace.json", "r05_j_dense_front_trace.json"):
+                try:
+                    dtr = {"ms": json.load(open(os.path.join(REPO, "profiles", name)))["frame_front_pipelined"]["mean_us_all_calls"] * 1e-3, "source": "profiles/" + name}
+                    break
+                except Exception:
+                    pass
             out["roofline"]["dense"] = {"kernel": "frame_front with the codebook stream (all K rows)", "kernel_ms": d_ms,
+                                        "kernel_ms_rocprof": dtr.get("ms"), "kernel_ms_rocprof_source": dtr.get("source"),
+                                        "frac_rocprof": (ab["frame_front"] / dtr["ms"] / 1e6 / HBM_PEAK_GBS) if dtr else None,
                                         "algorithmic_bytes_per_launch": ab["frame_front"], "achieved": ab["frame_front"] / (d_ms * 1e-3) / 1e9,
                                         "frac": ab["frame_front"] / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "tail_a_ms": dper["tail_a"],
                                         "score_stream_bytes": ab["score_codebook"]}

@@ -601,9 +601,6 @@ static_assert(NN_SOLO % NN_BATCH == 0 && NBR_M % NN_BATCH == 0 && MESH_SOLO % ME
 #ifndef MIDAS_SCREEN
 #define MIDAS_SCREEN 1
 #endif
-#ifndef MIDAS_TAKE_BRANCHFREE
-#define MIDAS_TAKE_BRANCHFREE 1  // candidate updates of the screened scans as selects (0: the short-circuit form)
-#endif
 MD float part4(const float* q, const float4& lo) {
     const float d0 = q[0] - lo.x, d1 = q[1] - lo.y, d2 = q[2] - lo.z, d3 = q[3] - lo.w;
     float d = d0 * d0;
@@ -672,7 +669,7 @@ MD void nn6_hint_batch(const float4* __restrict__ nb4, int s0, const float* q, i
     const int j1 = m1 ? __builtin_ctz(m1) : NN_BATCH - 1, j2 = m2 ? __builtin_ctz(m2) : NN_BATCH - 1;
     const float4 ha = nb4[2 * (s0 + j1) + 1];
     const float4 hb = nb4[2 * (s0 + j2) + 1];
-#if MIDAS_TAKE_BRANCHFREE
+    // candidate updates as selects (the short-circuit form compiled to exec-mask regions: slower, removed in round 6)
     int b32 = (int)bi;  // list indices are int32
     auto take = [&](float p4, const float4& hi, bool on) {  // no short circuits: selects instead of exec-mask regions
         const float d = full_from(q, p4, hi);
@@ -691,22 +688,6 @@ MD void nn6_hint_batch(const float4* __restrict__ nb4, int s0, const float* q, i
         take(pick<NN_BATCH>(P, j), nb4[2 * (s0 + j) + 1], true);
     }
     bi = b32;
-#else
-    auto take = [&](float p4, const float4& hi) {
-        const float d = full_from(q, p4, hi);
-        const int32_t id = __float_as_int(hi.z);
-        if (d < best || (d == best && (int64_t)id < bi)) { best = d; bi = id; }
-    };
-    if (m1) take(pick<NN_BATCH>(P, j1), ha);
-    if (m2) take(pick<NN_BATCH>(P, j2), hb);
-    if (mask >> (NN_BATCH - 1)) take(P[NN_BATCH - 1], hl);
-    unsigned rest = m2 & (m2 - 1u);
-    while (rest) {  // more than two candidates among the batch's first records
-        const int j = __builtin_ctz(rest);
-        rest &= rest - 1u;
-        take(pick<NN_BATCH>(P, j), nb4[2 * (s0 + j) + 1]);
-    }
-#endif
     // every record behind this batch is at least this far (lower bound of |q - F| with slack for the rounding of r, rho)
     const float g = fmaf_(hl.w - r, 0.9999996f, rslack);
     certified = g > 0.0f && g * g * 0.99997f > best;
@@ -987,11 +968,9 @@ MD void nn6_coop(const TreeView<Kd6>& tv, const float* q, int32_t hint, float r_
             auto take = [&](float p4, const float4& hi, bool on) {
                 const float dm = full_from(qq, p4, hi);
                 const int im = __float_as_int(hi.z);
-                if (MIDAS_TAKE_BRANCHFREE) {
-                    const bool better = on & ((dm < d) | ((dm == d) & (im < id)));  // NaN never wins
-                    d = better ? dm : d;
-                    id = better ? im : id;
-                } else if (on && (dm < d || (dm == d && im < id))) { d = dm; id = im; }
+                const bool better = on & ((dm < d) | ((dm == d) & (im < id)));  // NaN never wins; selects, no branches
+                d = better ? dm : d;
+                id = better ? im : id;
             };
             take(pick<COOP_STEPS>(P, k1), ha, m1 != 0);
             take(pick<COOP_STEPS>(P, k2), hb, m2 != 0);

@@ -51,5 +51,10 @@ python tools/pmc_summary.py gpurun_out/pmc_${T}_score_mfma k_score_mfma > gpurun
 python tools/bench_score_mfma.py > gpurun_out/${T}_score_mfma_shapes.json 2>/dev/null; cat gpurun_out/${T}_score_mfma_shapes.json | cut -c1-400
 python tools/bench_configs.py > gpurun_out/${T}_other_configs.json 2> gpurun_out/${T}_other_configs.err; cat gpurun_out/${T}_other_configs.json | cut -c1-400
 python tools/bench_filter_loop.py > gpurun_out/${T}_filter_loop.jsonl 2>&1; tail -2 gpurun_out/${T}_filter_loop.jsonl | cut -c1-300
+# round 6: the seeded mode (device replica of torch's CPU generator, pieces side by side), the generator's kernels, the loop's and DBSCAN's kernels
+python tools/bench_parity_mode.py 0 6 > gpurun_out/${T}_parity_mode.txt 2>&1; grep pieces gpurun_out/${T}_parity_mode.txt
+tools/prof_stats.sh ${T}_mt19937 120 python tools/bench_mt_pieces.py 0 6 | grep -E "k_mt|rc="
+tools/prof_stats.sh ${T}_loop 300 python tools/prof_loop.py 100000 1000 300 | grep -E "k_loop|k_front_small|rc=" | cut -c1-200
+tools/prof_stats.sh ${T}_dbscan 300 python tools/prof_dbscan_frames.py | grep -E "k_db_|rc=" | cut -c1-160; grep -i slowest gpurun_out/prof_${T}_dbscan/run.log
 # the raw traces are large: only the summaries travel back
 find gpurun_out -name "*kernel_trace.csv" -delete; find gpurun_out -name "*counter_collection.csv" -size +2M -delete
