@@ -289,7 +289,7 @@ static int upload_tree(midas_ctx* ctx, const HostTree<KD>& h, int64_t K, midas_t
 // The distance field of a dim-3 tree's vertices (MeshField): the bounding box grown by FIELD_EXPAND, cubic cells sized so that the
 // grid has at most FIELD_MAX_CELLS of them, every cell's value by the exact search (k_field_build).  MIDAS_MESH_FIELD=0: none.
 constexpr double FIELD_EXPAND = 0.0025;            // m: decides "outside the grid = pruned" for thresholds below it (the reference's is 0.002)
-constexpr int64_t FIELD_MAX_CELLS = (int64_t)1 << 22;  // 16 MB of float32
+constexpr int64_t FIELD_MAX_CELLS = (int64_t)1 << 26;  // 256 MB of float32 (c4's mug: 0.23 mm cells; with 2^22 cells of 0.59 mm the undecided shell held 1700 particles a frame)
 static int build_mesh_field(midas_ctx* ctx, midas_tree* t, const double* pts, int64_t K);
 
 int tree_build_impl(midas_ctx* ctx, int32_t dim, int64_t K, const void* points_dev, midas_tree* out) {
