@@ -100,22 +100,31 @@ MD void tk_heap_select(TkPair* h, int len, TkPair* q, int from, int to) {
     tk_make_heap<LARGEST>(h, len);
     tk_sync();
     const int lane = tk_lane();
-    for (int base = from; base < to; base += 64) {
-        const int x = base + lane;
-        const bool in = x < to;
-        TkPair c = q[in ? x : to - 1];
-        double top = h[0].v;
-        unsigned long long m = __ballot(in && tk_comp<LARGEST>(c.v, top));
-        while (m) {
-            const int b = __builtin_ctzll(m);
-            TkPair val;  // __pop_heap(first, middle, i): value = *i; *i = *first; adjust(first, 0, len, value)
-            val.v = __shfl(c.v, b);
-            val.i = __shfl(c.i, b);
-            val.pad = 0;
-            if (lane == b) q[x] = h[0];
-            tk_adjust_heap<LARGEST>(h, 0, len, val);
-            top = h[0].v;
-            m = __ballot(in && lane > b && tk_comp<LARGEST>(c.v, top));
+    for (int base0 = from; base0 < to; base0 += 256) {
+        TkPair cs[4];  // four tiles of 64 candidates requested together (one round trip instead of four); looked at in order
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int x = base0 + 64 * u + lane;
+            cs[u] = q[x < to ? x : to - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int x = base0 + 64 * u + lane;
+            const bool in = x < to;
+            const TkPair c = cs[u];
+            double top = h[0].v;
+            unsigned long long m = __ballot(in && tk_comp<LARGEST>(c.v, top));
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                TkPair val;  // __pop_heap(first, middle, i): value = *i; *i = *first; adjust(first, 0, len, value)
+                val.v = __shfl(c.v, b);
+                val.i = __shfl(c.i, b);
+                val.pad = 0;
+                if (lane == b) q[x] = h[0];
+                tk_adjust_heap<LARGEST>(h, 0, len, val);
+                top = h[0].v;
+                m = __ballot(in && lane > b && tk_comp<LARGEST>(c.v, top));
+            }
         }
     }
     tk_sync();
