@@ -205,10 +205,14 @@ struct MfUnit {
         // the epilogue's divisors travel now (fetched in the epilogue they were a round trip at the end of every unit)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const int64_t k = row0 + 4 * g + r; nr[r] = norms[k < K ? k : K - 1]; }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { const int b = 16 * (t0 + t) + i; cn[t] = code_norms[b0 + (b < nb ? b : 0)]; }
+        if (code_norms) set_cn(code_norms, b0, nb);  // (nullptr: the norms are being computed by this workgroup - set_cn() behind its barrier)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    MD void set_cn(const double* __restrict__ code_norms, int b0, int nb) {
+        const int i = threadIdx.x & 15;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { const int b = 16 * (t0 + t) + i; cn[t] = code_norms[b0 + (b < nb ? b : 0)]; }
     }
     // the codes' operands of step c: four 16-byte LDS reads (one per N-tile)
     MD void load_e(float4 (&e)[NT], const float* __restrict__ eb, int ld, int c) const {
@@ -336,10 +340,14 @@ extern "C" __attribute__((visibility("default"))) int midas_debug_mf_clocks(long
 #define MF_STAMP(k)
 #endif
 
-template <bool CODES_LDS>
+// FOLD (round 6, with CODES_LDS): the workgroup converts the float64 codes itself while it stages them and forms their norms (the
+// sums of k_codes_prepare in its order: a quarter-wave per code, lane s over the columns s, s + 16, .., then the 16-lane tree) -
+// no k_codes_prepare launch in front, no float32 copy of the codes in memory; codes64 = the caller's B x D float64 codes.
+template <bool CODES_LDS, bool FOLD = false>
 __global__ __launch_bounds__(64 * MF_WAVES) void k_score_mfma(const float* __restrict__ emb, const double* __restrict__ norms,
                                                      const float* __restrict__ codes32, const double* __restrict__ code_norms,
-                                                     double* __restrict__ out, int64_t K, int D, int B, int b0) {
+                                                     double* __restrict__ out, int64_t K, int D, int B, int b0,
+                                                     const double* __restrict__ codes64 = nullptr) {
     // The 64 codes in LDS in the ORDER THE OPERAND READS TAKE THEM: sixteen-byte piece ((t nc + c) 64 + 16 g + i) = code 16 t + i,
     // columns 16 c + 4 g .. + 3 (t: N-tile, c: step of 16 columns, lane (g, i) of the wave) - a step's operand read of one N-tile is
     // 64 consecutive pieces, lane l the l-th: no bank is asked twice (rows of D + 4 floats put lanes (g, i) and (g + 1, i - 1) on one
@@ -361,10 +369,21 @@ __global__ __launch_bounds__(64 * MF_WAVES) void k_score_mfma(const float* __res
     // chain of fetches with little to multiply, 10 us that ended 6 us behind everything else when it ran after the wave's group).
     const int64_t Q = 4 * (G - Gw);
     MF_STAMP(0);
-    float4 stage[CODES_LDS ? 11 : 1];
+    float4 stage[(CODES_LDS && !FOLD) ? 11 : 1];
     const int q4 = D / 4, total = MF_CODES * q4, ncq = D / 16;
     constexpr int NT_ = 64 * MF_WAVES;
-    if (CODES_LDS) {
+    double* s_cn = reinterpret_cast<double*>(s_e + (size_t)MF_CODES * D);  // FOLD: the 64 code norms behind the staged codes
+    constexpr int FOLD_MAXC = 40;  // columns per lane: D <= 640
+    double fv[FOLD ? FOLD_MAXC : 1];
+    constexpr int NQ = NT_ / 16;  // quarter-waves of the workgroup: pass p of the staging gives quarter-wave q the code q + NQ p
+    if constexpr (CODES_LDS && FOLD) {
+        const int qw = (int)threadIdx.x >> 4, s = (int)threadIdx.x & 15;
+        const int b = qw < MF_CODES ? qw : MF_CODES - 1;
+        const double* c = codes64 + (int64_t)(b0 + (b < nb ? b : 0)) * D + s;
+#pragma unroll
+        for (int k = 0; k < FOLD_MAXC; ++k) fv[k] = c[16 * (k < ncq ? k : ncq - 1)];
+    }
+    if constexpr (CODES_LDS && !FOLD) {
         // The 64 codes (padded with zero rows by k_codes_prepare) are requested FIRST: loads come back in order, so the first
         // burst of row pieces (memory) in front of them made the staging wait for it (6.8 us to the barrier); behind them
         // it travels while the codes are written to LDS.  Eleven 16-byte pieces per thread at D = 512 (more rounds beyond).
@@ -378,8 +397,36 @@ __global__ __launch_bounds__(64 * MF_WAVES) void k_score_mfma(const float* __res
     }
     MfUnit<4, CODES_LDS> u4;
     const bool first4 = slot < rounds;
-    if (first4) u4.begin(emb, norms, code_norms, K, D, b0, nb, ((int64_t)slot * S + simd) * MF_ROWS_PER_WAVE, 0);
-    if (CODES_LDS) {
+    if (first4) u4.begin(emb, norms, FOLD ? nullptr : code_norms, K, D, b0, nb, ((int64_t)slot * S + simd) * MF_ROWS_PER_WAVE, 0);
+    if constexpr (CODES_LDS && FOLD) {
+        const int qw0 = (int)threadIdx.x >> 4, s = (int)threadIdx.x & 15;
+#pragma unroll
+        for (int k = 0; k < FOLD_MAXC; ++k) asm volatile("" : "+v"(fv[k]));  // (pinned: requested above, in front of the first row burst)
+        for (int pass = 0; pass * NQ < MF_CODES; ++pass) {
+            const int b = qw0 + NQ * pass;
+            if (b >= MF_CODES) break;  // (with twelve waves: quarter-waves 16 .. 47 have no second code)
+            if (pass >= 1) {
+                const double* c = codes64 + (int64_t)(b0 + (b < nb ? b : 0)) * D + s;
+#pragma unroll
+                for (int k = 0; k < FOLD_MAXC; ++k) fv[k] = c[16 * (k < ncq ? k : ncq - 1)];
+            }
+            const bool real = b < nb;
+            double acc2 = 0.0;
+            // piece ((t nc + k) 64 + 16 g + i) holds code 16 t + i, columns 16 k + 4 g .. + 3: column s + 16 k is component s & 3 of g = s >> 2
+            float* o = s_e + ((size_t)((b >> 4) * ncq) * 64 + 16 * (s >> 2) + (b & 15)) * 4 + (s & 3);
+#pragma unroll
+            for (int k = 0; k < FOLD_MAXC; ++k)
+                if (k < ncq) {
+                    o[(size_t)k * 256] = real ? (float)fv[k] : 0.0f;
+                    acc2 = fma_(fv[k], fv[k], acc2);
+                }
+            acc2 = quarter_reduce(acc2);
+            if (s == 0) { const double n = __builtin_sqrt(acc2); s_cn[b] = real ? (n < COS_EPS ? COS_EPS : n) : 1.0; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (first4) u4.set_cn(s_cn - b0, b0, nb);
+    }
+    if constexpr (CODES_LDS && !FOLD) {
         float4* s4 = reinterpret_cast<float4*>(s_e);
 #pragma unroll
         for (int k = 0; k < 11; ++k)  // (pinned here: the compiler otherwise sinks each load into its store's condition)
@@ -417,12 +464,12 @@ __global__ __launch_bounds__(64 * MF_WAVES) void k_score_mfma(const float* __res
     for (int64_t q = (int64_t)blockIdx.x + (int64_t)gridDim.x * (wave & 3); q < Q; q += S) {
         if (SL - 1 - (int)((q / S) % SL) != slot) continue;
         MfUnit<1, CODES_LDS> u1;
-        u1.begin(emb, norms, code_norms, K, D, b0, nb, (Gw + (q >> 2)) * MF_ROWS_PER_WAVE, (int)(q & 3));
+        u1.begin(emb, norms, FOLD ? (const double*)(s_cn - b0) : code_norms, K, D, b0, nb, (Gw + (q >> 2)) * MF_ROWS_PER_WAVE, (int)(q & 3));
         u1.run(eb, ld);
         u1.finish(out, K, b0, nb);
     }
     for (int64_t r = slot; r < rounds; r += SL) {
-        if (r != slot) u4.begin(emb, norms, code_norms, K, D, b0, nb, (r * S + simd) * MF_ROWS_PER_WAVE, 0);
+        if (r != slot) u4.begin(emb, norms, FOLD ? (const double*)(s_cn - b0) : code_norms, K, D, b0, nb, (r * S + simd) * MF_ROWS_PER_WAVE, 0);
         u4.run(eb, ld);
         MF_STAMP(2);
         u4.finish(out, K, b0, nb);
@@ -438,14 +485,20 @@ int launch_score_batch(midas_ctx* ctx, const midas_codebook* cb, int32_t B, cons
     // the 64 staged codes fit the CU's 160 KB of LDS up to D = 640; beyond (D = 1024) the waves read the float32 code rows from
     // memory (256 KB: cache-resident) - the same arithmetic, slower
     const bool codes_lds = (size_t)MF_CODES * D * sizeof(float) <= 160 * 1024;
-    const size_t lds = codes_lds ? (size_t)MF_CODES * D * sizeof(float) : 0;
+    // folded staging (the workgroups convert the float64 codes and form their norms themselves: no k_codes_prepare launch) where the
+    // 64 norms fit behind the staged codes and a lane's columns fit its registers (D <= 624: D = 128 .. 512)
+    // (K 50k x D 512 x B 64: 52.3 -> 46.6 us per call, 62.7 -> 70.3 TFLOP/s; the k_codes_prepare form stays for D = 640 and D > 640)
+    const bool fold = codes_lds && D <= 624 && (uintptr_t)codes % 8 == 0;
+    const size_t lds = codes_lds ? (size_t)MF_CODES * D * sizeof(float) + (fold ? MF_CODES * sizeof(double) : 0) : 0;
     const int Bpad = (int)ceil_div(B, MF_CODES) * MF_CODES;
-    void *cn, *c32;
-    int rc = midas_scratch(ctx, (size_t)B * sizeof(double), &cn);
-    if (rc) return rc;
-    if ((rc = midas_scratch(ctx, (size_t)Bpad * D * sizeof(float), &c32))) return rc;
-    hipLaunchKernelGGL(k_codes_prepare, dim3((unsigned)ceil_div(Bpad, 16)), dim3(256), 0, ctx->stream, codes, (float*)c32,
-                       (double*)cn, B, Bpad, D);
+    void *cn = nullptr, *c32 = nullptr;
+    int rc;
+    if (!fold) {
+        if ((rc = midas_scratch(ctx, (size_t)B * sizeof(double), &cn))) return rc;
+        if ((rc = midas_scratch(ctx, (size_t)Bpad * D * sizeof(float), &c32))) return rc;
+        hipLaunchKernelGGL(k_codes_prepare, dim3((unsigned)ceil_div(Bpad, 16)), dim3(256), 0, ctx->stream, codes, (float*)c32,
+                           (double*)cn, B, Bpad, D);
+    }
     // per device (the same rule as launch_presort, particles.hip): a second GPU's context must not inherit the first one's
     // dynamic-LDS limit and CU count
     constexpr int MAXDEV = 64;
@@ -454,6 +507,7 @@ int launch_score_batch(midas_ctx* ctx, const midas_codebook* cb, int32_t B, cons
     const int di = ctx->device >= 0 && ctx->device < MAXDEV ? ctx->device : 0;
     if (!attr_set[di] || ctx->device != di) {
         MIDAS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_score_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MIDAS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_score_mfma<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         hipDeviceProp_t prop;
         ncu_dev[di] = (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
         attr_set[di] = true;
@@ -463,12 +517,15 @@ int launch_score_batch(midas_ctx* ctx, const midas_codebook* cb, int32_t B, cons
     const int64_t G = ceil_div(cb->K, MF_ROWS_PER_WAVE);
     const unsigned grid = (unsigned)(G < (int64_t)ncu * 4 ? ceil_div(G, 4) : ncu);
     for (int b0 = 0; b0 < B; b0 += MF_CODES) {
-        if (codes_lds)
+        if (fold)
+            hipLaunchKernelGGL((k_score_mfma<true, true>), dim3(grid), dim3(64 * MF_WAVES), lds, ctx->stream, (const float*)cb->emb, cb->norms,
+                               (const float*)nullptr, (const double*)nullptr, scores, cb->K, D, B, b0, codes);
+        else if (codes_lds)
             hipLaunchKernelGGL(k_score_mfma<true>, dim3(grid), dim3(64 * MF_WAVES), lds, ctx->stream, (const float*)cb->emb, cb->norms,
-                               (const float*)c32, (const double*)cn, scores, cb->K, D, B, b0);
+                               (const float*)c32, (const double*)cn, scores, cb->K, D, B, b0, (const double*)nullptr);
         else
             hipLaunchKernelGGL(k_score_mfma<false>, dim3(grid), dim3(64 * MF_WAVES), 0, ctx->stream, (const float*)cb->emb, cb->norms,
-                               (const float*)c32, (const double*)cn, scores, cb->K, D, B, b0);
+                               (const float*)c32, (const double*)cn, scores, cb->K, D, B, b0, (const double*)nullptr);
     }
     MIDAS_HIP_CHECK(ctx, hipGetLastError());
     return MIDAS_OK;
