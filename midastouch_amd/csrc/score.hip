@@ -209,6 +209,24 @@ struct MfUnit {
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // the NEXT unit of the same tiles: its first burst of row pieces and its divisors leave before this unit's divisions (finish()
+    // reads neither the row pointer nor the piece queue); adopt() makes it the current unit behind them
+    MD void prefetch_next(const float* __restrict__ emb, const double* __restrict__ norms, int64_t K, int D, int64_t row0n, double (&nrn)[4]) {
+        const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
+        const int64_t row = row0n + i < K ? row0n + i : K - 1;
+        arow = emb + row * (int64_t)D + 4 * g;
+#pragma unroll
+        for (int p = 0; p < MF_PF; ++p) qa[p] = piece(p);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int64_t k = row0n + 4 * g + r; nrn[r] = norms[k < K ? k : K - 1]; }
+    }
+    MD void adopt(int64_t row0n, const double (&nrn)[4]) {
+        row0 = row0n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nr[r] = nrn[r];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     MD void set_cn(const double* __restrict__ code_norms, int b0, int nb) {
         const int i = threadIdx.x & 15;
 #pragma unroll
@@ -469,10 +487,14 @@ __global__ __launch_bounds__(64 * MF_WAVES) void k_score_mfma(const float* __res
         u1.finish(out, K, b0, nb);
     }
     for (int64_t r = slot; r < rounds; r += SL) {
-        if (r != slot) u4.begin(emb, norms, FOLD ? (const double*)(s_cn - b0) : code_norms, K, D, b0, nb, (r * S + simd) * MF_ROWS_PER_WAVE, 0);
         u4.run(eb, ld);
         MF_STAMP(2);
+        const bool more = r + SL < rounds;  // (the wave's next unit: same tiles, same code norms)
+        const int64_t row0n = ((r + SL) * S + simd) * MF_ROWS_PER_WAVE;
+        double nrn[4] = {0.0, 0.0, 0.0, 0.0};
+        if (more) u4.prefetch_next(emb, norms, K, D, row0n, nrn);
         u4.finish(out, K, b0, nb);
+        if (more) u4.adopt(row0n, nrn);
         MF_STAMP(3);
     }
     MF_STAMP(4);
