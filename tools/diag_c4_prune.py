@@ -1,6 +1,9 @@
+#!/usr/bin/env python3
+"""c4 on one GPU (N = 100k, K = 500k): per frame the tree searches of the NN / the prune, the rows scored by particle waves / off the list
+(round 6: what the prune fix costs there, and what the distance field takes back; MIDAS_MESH_FIELD=0 for the form without it)."""
 import json, os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from midastouch_amd.engine import PipelinedFilterEngine
 from midastouch_amd.synthetic import make_codebook, make_trajectory
 dev = torch.device("cuda", 0)
