@@ -289,6 +289,7 @@ static int upload_tree(midas_ctx* ctx, const HostTree<KD>& h, int64_t K, midas_t
 // The distance field of a dim-3 tree's vertices (MeshField): the bounding box grown by FIELD_EXPAND, cubic cells sized so that the
 // grid has at most FIELD_MAX_CELLS of them, every cell's value by the exact search (k_field_build).  MIDAS_MESH_FIELD=0: none.
 constexpr double FIELD_EXPAND = 0.0025;            // m: decides "outside the grid = pruned" for thresholds below it (the reference's is 0.002)
+constexpr double FIELD_MIN_CELL = 2.5e-5;          // m: cells no finer than this (shell half-width < 0.022 mm)
 constexpr int64_t FIELD_MAX_CELLS = (int64_t)1 << 26;  // 256 MB of float32 (c4's mug: 0.23 mm cells; with 2^22 cells of 0.59 mm the undecided shell held 1700 particles a frame)
 static int build_mesh_field(midas_ctx* ctx, midas_tree* t, const double* pts, int64_t K);
 
@@ -2418,6 +2419,7 @@ static int build_mesh_field(midas_ctx* ctx, midas_tree* t, const double* pts, in
     double ext[3], vol = 1.0;
     for (int d = 0; d < 3; ++d) { ext[d] = (hi[d] - lo[d]) + 2.0 * FIELD_EXPAND * 1.01; vol *= ext[d]; }
     double h = std::cbrt(vol / (double)FIELD_MAX_CELLS);
+    if (h < FIELD_MIN_CELL) h = FIELD_MIN_CELL;  // (a small mesh does not need the whole budget: the shell is thin enough)
     MeshField f;
     for (int iter = 0; iter < 8; ++iter) {  // (rounding the counts up can exceed the budget: grow the cells a little)
         int64_t cells = 1;

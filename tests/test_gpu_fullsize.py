@@ -404,3 +404,30 @@ def test_prune_exhausted_vertex_list_goes_to_the_tree(dev, oracle, engine):
     assert np.array_equal(kept, ~(d3 > 0.002)), f"{int((kept != ~(d3 > 0.002)).sum())} prune decisions differ"
     assert 0 < kept.sum() < N
     assert int(eng.telemetry.cpu().numpy()[1] - tele0[1]) > 0, "no particle needed the tree: the case is not covered"
+
+
+@pytest.mark.parametrize("pen_max", [0.0005, 0.004])
+def test_prune_thresholds_around_the_fields_reach(dev, oracle, pen_max):
+    """The distance field decides "outside the grid = pruned" only for thresholds below the 2.5 mm the grid was grown by; a larger
+    `pen.max` (0.004) leaves those particles to the lists / the tree, a small one (0.0005) puts the shell inside the grid: the
+    masks are the brute-force masks either way."""
+    from midastouch_amd.engine import FilterEngine
+    from midastouch_amd.synthetic import make_codebook, make_trajectory
+    N, K, D = 20_000, 4_000, 256
+    cb = make_codebook("004_sugar_box", K=K, D=D, seed=1001)
+    traj = make_trajectory(cb, T=3, seed=2001)
+    eng = FilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, sig_t=1e-5, sig_r=0.01, pen_max=pen_max, seed=5, device=dev)
+    rng = np.random.default_rng(8)
+    poses = cb.poses[rng.integers(0, K, N)].copy()
+    off = rng.normal(size=(N, 3))
+    off *= (rng.uniform(0.0, 2.5 * pen_max, N) / np.linalg.norm(off, axis=1))[:, None]
+    off[: N // 10] *= 20.0  # some far outside the grid
+    poses[:, :3, 3] += off.astype(np.float32)
+    eng.set_particles(torch.as_tensor(poses))
+    eng.step(torch.eye(4), torch.as_tensor(traj.codes[1]))
+    prop = eng.poses_prop.cpu().numpy()
+    nn, d3 = _brute_force_all(oracle, prop, oracle.R3_SE3(cb.poses), cb.mesh_vertices)
+    assert np.array_equal(eng.nn_idx.cpu().numpy(), nn)
+    kept = eng.weights.cpu().numpy() != 0
+    assert np.array_equal(kept, ~(d3 > pen_max)), f"{int((kept != ~(d3 > pen_max)).sum())} prune decisions differ"
+    assert 0 < kept.sum() < N
