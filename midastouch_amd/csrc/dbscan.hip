@@ -28,6 +28,7 @@
 #include <cmath>
 
 #include "midas_internal.hpp"
+#include "midas_math.hpp"
 
 namespace midas {
 
@@ -417,6 +418,29 @@ __device__ __forceinline__ void db_for_cells(const DbGrid& g, const unsigned lon
             }
 }
 
+// The 5 x 5 x 5 cells around a cell, ONE PER LANE (two turns of a wave: lanes 0 .. 63 take neighbours 0 .. 63, then 64 .. 124): the
+// kernels that give a point a whole wave used to walk the 125 cells one after the other with every lane doing the same box
+// test - 125 dependent look-ups a point.  nbr = 25 (z + 2) + 5 (y + 2) + (x + 2) offset index; returns the cell or -1 (outside the
+// grid, nobody lives there, or the centre cell itself unless `own`).
+__device__ __forceinline__ void db_cell_xyz(const DbGrid& g, const unsigned long long* __restrict__ hkeys, int c, int& cx, int& cy, int& cz) {
+    if (g.hashed) {
+        const unsigned long long k = hkeys[c];
+        const unsigned m = (1u << DB_HASH_BITS) - 1u;
+        cx = (int)((unsigned)k & m); cy = (int)((unsigned)(k >> DB_HASH_BITS) & m); cz = (int)((unsigned)(k >> (2 * DB_HASH_BITS)) & m);
+    } else {
+        cx = c % g.dx; cy = (c / g.dx) % g.dy; cz = c / (g.dx * g.dy);
+    }
+}
+__device__ __forceinline__ int db_neighbour_cell(const DbGrid& g, const unsigned long long* __restrict__ hkeys, int c, int cx, int cy, int cz,
+                                                 int nbr, bool own) {
+    if (nbr >= 125) return -1;
+    const int x = cx + nbr % 5 - 2, y = cy + (nbr / 5) % 5 - 2, z = cz + nbr / 25 - 2;
+    if (x < 0 || y < 0 || z < 0 || x >= g.dx || y >= g.dy || z >= g.dz) return -1;
+    if (nbr == 62) return own ? c : -1;  // the centre
+    if (g.hashed) return db_hash_find(hkeys, db_key64(x, y, z));
+    return (z * g.dy + y) * g.dx + x;
+}
+
 // core <=> at least min_samples points within eps (itself included).  Pass 1, one thread per point, decides what needs no
 // distance: the own cell alone reaches min_samples (all of it is within eps), or the 125 cells together cannot.  The rest
 // goes to a worklist.
@@ -453,8 +477,11 @@ __global__ __launch_bounds__(256) void k_db_core(DbArgs a) {
     db_cell_min(a.cell_rep, c, orig, in && state == 1);
 }
 
-// Pass 2, one wave per undecided point: the lanes share the candidates of each cell (coalesced), the count stops at
-// min_samples.
+// Pass 2, one wave per undecided point.  The 124 cells around it are classified one per lane (whole box within eps: counts in
+// full; box beyond eps: nothing; box cut by the ball: exact tests) and the whole cells added up by the wave; then only the cut
+// cells are scanned, 64 candidates at a time, and the count stops as soon as min_samples is reached OR can no longer be reached
+// (round 5 walked the 125 cells one by one, every lane the same box test, and counted a point that could not become core to
+// the end: 1 - 2 ms of the DBSCAN frame at N = 100k).
 __global__ __launch_bounds__(256) void k_db_core_count(DbArgs a) {
     const DbGrid g = *a.grid;
     const int lane = threadIdx.x & 63;
@@ -463,22 +490,52 @@ __global__ __launch_bounds__(256) void k_db_core_count(DbArgs a) {
         const int32_t p = a.work[wi];
         const float4 me = a.s_pt[p];
         const int c = __float_as_int(me.w);
-        int cnt = a.cell_start[c + 1] - a.cell_start[c];
-        db_for_cells(g, a.hkeys, c, false, [&](int c2) {
-            const int e = a.cell_start[c2 + 1], b0 = a.cell_start[c2];
-            if (e == b0) return false;
-            double mind2, maxd2;
-            db_box_bounds(a, c2, me, mind2, maxd2);
-            if (mind2 > a.r2) return false;                               // wholly beyond eps
-            if (maxd2 <= a.r2) { cnt += e - b0; return cnt >= g.ms; }     // wholly within eps: no test needed
-            for (int q0 = b0; q0 < e; q0 += 64) {
-                const int q = q0 + lane;
-                const bool in = q < e && db_within(me, a.s_pt[q < e ? q : e - 1], a.r2);
-                cnt += __popcll(__ballot(in));
-                if (cnt >= g.ms) return true;
+        int cx, cy, cz;
+        db_cell_xyz(g, a.hkeys, c, cx, cy, cz);
+        int cnt = a.cell_start[c + 1] - a.cell_start[c];  // the own cell: all of it within eps
+        int pot = 0;                                        // points of the cut cells not yet looked at
+        int c2v[2], popv[2];
+        unsigned long long cut[2];
+#pragma unroll
+        for (int turn = 0; turn < 2; ++turn) {
+            const int c2 = db_neighbour_cell(g, a.hkeys, c, cx, cy, cz, lane + 64 * turn, false);
+            int pop = 0, cls = 0;  // cls 1: whole cell within eps, 2: cut
+            if (c2 >= 0) {
+                pop = a.cell_start[c2 + 1] - a.cell_start[c2];
+                if (pop > 0) {
+                    double mind2, maxd2;
+                    db_box_bounds(a, c2, me, mind2, maxd2);
+                    cls = maxd2 <= a.r2 ? 1 : (mind2 <= a.r2 ? 2 : 0);
+                }
             }
-            return false;
-        });
+            c2v[turn] = c2; popv[turn] = pop;
+            cnt += wave_isum_dpp(cls == 1 ? pop : 0);
+            pot += wave_isum_dpp(cls == 2 ? pop : 0);
+            cut[turn] = __ballot(cls == 2);
+        }
+        cnt = __builtin_amdgcn_readfirstlane(cnt);
+        pot = __builtin_amdgcn_readfirstlane(pot);
+#pragma unroll
+        for (int turn = 0; turn < 2; ++turn) {
+            unsigned long long m = cut[turn];
+            while (m && cnt < g.ms && cnt + pot >= g.ms) {
+                const int l = (int)__builtin_ctzll(m);
+                m &= m - 1;
+                const int c2 = __shfl(c2v[turn], l), pop = __shfl(popv[turn], l);
+                const int b0 = a.cell_start[c2], e = b0 + pop;
+                pot -= pop;
+                for (int q0 = b0; q0 < e && cnt < g.ms; q0 += 256) {  // four tiles of candidates requested together (one round trip)
+                    float4 cand[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int q = q0 + 64 * u + lane; cand[u] = a.s_pt[q < e ? q : e - 1]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int q = q0 + 64 * u + lane;
+                        cnt += __popcll(__ballot(q < e && db_within(me, cand[u], a.r2)));
+                    }
+                }
+            }
+        }
         if (lane == 0) {
             const bool core = cnt >= g.ms;
             a.s_core[p] = core ? 1 : 0;
@@ -689,8 +746,10 @@ __global__ __launch_bounds__(256) void k_db_number(DbArgs a) {
 }
 
 // border points: the smallest cluster number among the core points within eps; noise otherwise.
-// One WAVE per point (the lanes share a cell's candidates, any hit ends the cell): a thread per point walked the partial cells
-// of a dense cloud's halo one point after the other - 4.5 ms of the frame-50 DBSCAN at N = 100 k even with the box tests.
+// One WAVE per point.  The 125 cells (own cell included) are classified one per lane: a cell with core points whose whole box is
+// within eps (the own cell always is) offers its cluster number outright - the wave's minimum over those is the answer unless a
+// CUT cell holds a smaller number, and only those cut cells are scanned, 64 candidates at a time, any hit ends the cell.
+// (Round 3: a thread per point, 4.5 ms at N = 100k; round 4: a wave per point walking the cells one by one, 1.0 ms; now 0.2.)
 __global__ __launch_bounds__(256) void k_db_border(DbArgs a) {
     const DbGrid g = *a.grid;
     const int lane = threadIdx.x & 63;
@@ -699,25 +758,51 @@ __global__ __launch_bounds__(256) void k_db_border(DbArgs a) {
         if (a.s_core[p]) continue;
         const float4 me = a.s_pt[p];
         const int c = __float_as_int(me.w);
+        int cx, cy, cz;
+        db_cell_xyz(g, a.hkeys, c, cx, cy, cz);
         int best = 0x7fffffff;
-        db_for_cells(g, a.hkeys, c, true, [&](int c2) {
-            const int num = a.cell_num[c2];
-            if (num < 0 || num >= best) return false;
-            if (c2 == c) { best = num; return false; }  // a core point of the own cell is within eps
-            // the cell's tight box first: wholly beyond eps - nobody to look at (a halo point next to a dense cell scanned all
-            // of its points for nothing: 16 ms of a 17 ms DBSCAN at N = 100 k); wholly within eps - its core point is a hit
-            double mind2, maxd2;
-            db_box_bounds(a, c2, me, mind2, maxd2);
-            if (mind2 > a.r2) return false;
-            if (maxd2 <= a.r2) { best = num; return false; }
-            const int e = a.cell_start[c2 + 1], b0 = a.cell_start[c2];
-            for (int q0 = b0; q0 < e; q0 += 64) {
-                const int q = q0 + lane, qc = q < e ? q : e - 1;
-                const bool hit = q < e && a.s_core[qc] && db_within(me, a.s_pt[qc], a.r2);
-                if (__any(hit)) { best = num; break; }
+        int c2v[2], numv[2];
+        unsigned long long cut[2];
+#pragma unroll
+        for (int turn = 0; turn < 2; ++turn) {
+            const int nbr = lane + 64 * turn;
+            const int c2 = db_neighbour_cell(g, a.hkeys, c, cx, cy, cz, nbr, true);
+            int num = -1, cls = 0;  // cls 1: some core point of the cell is certainly within eps, 2: cut
+            if (c2 >= 0) {
+                num = a.cell_num[c2];
+                if (num >= 0) {
+                    if (c2 == c) cls = 1;  // a core point of the own cell is within eps
+                    else {
+                        double mind2, maxd2;
+                        db_box_bounds(a, c2, me, mind2, maxd2);
+                        cls = maxd2 <= a.r2 ? 1 : (mind2 <= a.r2 ? 2 : 0);
+                    }
+                }
             }
-            return false;
-        });
+            c2v[turn] = c2; numv[turn] = num;
+            int mine = cls == 1 ? num : 0x7fffffff;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(mine, o); mine = v < mine ? v : mine; }
+            best = mine < best ? mine : best;
+            cut[turn] = __ballot(cls == 2);
+        }
+#pragma unroll
+        for (int turn = 0; turn < 2; ++turn) {
+            unsigned long long m = cut[turn];
+            while (m) {
+                const int l = (int)__builtin_ctzll(m);
+                m &= m - 1;
+                const int num = __shfl(numv[turn], l);
+                if (num >= best) continue;
+                const int c2 = __shfl(c2v[turn], l);
+                const int e = a.cell_start[c2 + 1], b0 = a.cell_start[c2];
+                for (int q0 = b0; q0 < e; q0 += 64) {
+                    const int q = q0 + lane, qc = q < e ? q : e - 1;
+                    const bool hit = q < e && a.s_core[qc] && db_within(me, a.s_pt[qc], a.r2);
+                    if (__any(hit)) { best = num; break; }
+                }
+            }
+        }
         if (lane == 0) a.labels[a.s_orig[p]] = best == 0x7fffffff ? -1 : best;
     }
 }
