@@ -174,6 +174,17 @@ int midas_mt19937_rand64(midas_ctx* ctx, uint32_t* state_dev, int64_t skip_words
  *             numbers, nothing else - tests/test_torch_stream.py holds the chunked stream against torch.rand);
  * polys_dev NULL or pieces <= 0: the sequential walk of midas_mt19937_rand64, which also leaves hist_dev (if given).
  * state_dev is left as after midas_mt19937_rand64.  Needs 2 N >= MIDAS_MT19937_HIST_WORDS. */
+/* torch.normal(mean, std, size) of `numel` float32 values (numel >= 16) from the same stream - the motion noise of
+ * add_noise_to_odom (modules/particle_filter.py:326-335: two calls of 3 N values per frame, in front of the resampler's draws).
+ * ATen turns float32 uniforms ((w & 0xFFFFFF) 2^-24, one generator output each) into normals sixteen at a time (Box-Muller:
+ * radius(u1) cos / sin(theta(u2)), times std plus mean by one fused multiply-add) and draws the last sixteen again when numel is
+ * not a multiple of 16.  radius_dev / cos_dev / sin_dev: the three functions as tables over the 2^24 uniforms (float32[2^24] each),
+ * read off torch.normal itself by the host (midastouch_amd/torch_normal.py) - whatever math library ATen uses on the machine, the
+ * values are torch.normal's bit for bit (tests/test_torch_stream.py).  Consumes numel (+ 16) outputs behind skip_words.
+ * hist_dev / polys_dev / pieces: as midas_mt19937_rand64_chunked (J_c counts this call's words: numel (+ 16)); NULL / 0: sequential. */
+int midas_mt19937_normal32(midas_ctx* ctx, uint32_t* state_dev, int64_t skip_words, int64_t numel, float mean, float std,
+                           const float* radius_dev, const float* cos_dev, const float* sin_dev, float* out_dev, uint32_t* hist_dev,
+                           const uint32_t* polys_dev, int32_t pieces);
 #define MIDAS_MT19937_HIST_WORDS 20560
 int midas_mt19937_rand64_chunked(midas_ctx* ctx, uint32_t* state_dev, int64_t skip_words, int64_t N, double* out_dev,
                                  uint32_t* hist_dev, const uint32_t* polys_dev, int32_t pieces);

@@ -219,6 +219,7 @@ SIGNATURES = {
     "midas_mt19937_seed": (C.c_int, [_P, _U64, _P]),
     "midas_mt19937_rand64": (C.c_int, [_P, _P, _I64, _I64, _P]),
     "midas_mt19937_rand64_chunked": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _I32]),
+    "midas_mt19937_normal32": (C.c_int, [_P, _P, _I64, _I64, _F, _F, _P, _P, _P, _P, _P, _P, _I32]),
     "midas_resample_search": (C.c_int, [_P, _I64, _P, _I64, _I32, _P, _F, _U64, _U64, _P]),
     "midas_gather_rows": (C.c_int, [_P, _I64, _P, _P, _P, _I32]),
     "midas_rmse": (C.c_int, [_P, _I64, _P, _P, _P]),

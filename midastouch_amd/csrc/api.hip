@@ -405,6 +405,17 @@ MIDAS_EXPORT int midas_mt19937_rand64(midas_ctx* ctx, uint32_t* state_dev, int64
     return launch_mt_rand64(ctx, state_dev, skip_words, N, out_dev, nullptr);
 }
 
+MIDAS_EXPORT int midas_mt19937_normal32(midas_ctx* ctx, uint32_t* state_dev, int64_t skip_words, int64_t numel, float mean, float std,
+                                        const float* radius_dev, const float* cos_dev, const float* sin_dev, float* out_dev, uint32_t* hist_dev,
+                                        const uint32_t* polys_dev, int32_t pieces) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, state_dev != nullptr && skip_words >= 0 && numel >= 16 && radius_dev && cos_dev && sin_dev && out_dev);
+    const bool chunked = polys_dev && pieces > 0;
+    MIDAS_REQUIRE(ctx, !chunked || (hist_dev != nullptr && pieces <= 1024 && numel >= MIDAS_MT19937_HIST_WORDS));
+    return launch_mt_normal32(ctx, state_dev, skip_words, numel, mean, std, radius_dev, cos_dev, sin_dev, out_dev, hist_dev,
+                              chunked ? polys_dev : nullptr, chunked ? pieces : 0);
+}
+
 MIDAS_EXPORT int midas_mt19937_rand64_chunked(midas_ctx* ctx, uint32_t* state_dev, int64_t skip_words, int64_t N, double* out_dev,
                                               uint32_t* hist_dev, const uint32_t* polys_dev, int32_t pieces) {
     MIDAS_ENTER(ctx);

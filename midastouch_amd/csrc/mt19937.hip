@@ -269,27 +269,72 @@ int launch_mt_seed(midas_ctx* ctx, uint64_t seed, uint32_t* state) {
     return MIDAS_OK;
 }
 
-// The chunked form: `polys` = G polynomials of 624 words (t^J_c mod phi, J_c = distance from the first word in `hist` to the first word
-// of piece c - the host knows both), `hist` in/out.  skip_words is part of J_c already: the state is replaced, not advanced.
-int launch_mt_rand64_chunked(midas_ctx* ctx, uint32_t* state, int64_t N, double* out, uint32_t* hist, const uint32_t* polys, int32_t G) {
-    const int64_t nwords = 2 * N, nblocks = ceil_div(nwords, MT_N);
-    const int bpc = (int)ceil_div(nblocks, G);
+// torch.normal(mean, std, size) of float32 values from the stream's words (ATen normal_fill, modules/particle_filter.py:326-335):
+// sixteen at a time, u1 = 1 - data[j], u2 = data[j + 8], data[j] = (radius(u1) cos(theta(u2))) std + mean, data[j + 8] = (radius
+// sin) std + mean; when numel is not a multiple of 16 the last sixteen values are drawn AGAIN from sixteen further words.  radius /
+// cos / sin are TABLES over the 2^24 values a float32 uniform takes, read off torch.normal itself on the host
+// (midastouch_amd/torch_normal.py): bit-identical to whatever math library ATen dispatches to.
+constexpr uint32_t MT_U24 = (1u << 24) - 1u;
+__global__ __launch_bounds__(256) void k_mt_normal(const uint32_t* __restrict__ raw, const int32_t* __restrict__ meta, long long numel, long long nwords,
+                                                   const float* __restrict__ R, const float* __restrict__ C, const float* __restrict__ S,
+                                                   float mean, float std, float* __restrict__ out, uint32_t* __restrict__ hist) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t* w = raw + (meta ? meta[0] : 0);
+    if (hist && i < MT_HIST && i < nwords) hist[i] = w[i];
+    if (i >= numel) return;
+    const bool tail = (numel & 15) && i >= numel - 16;        // redrawn from the sixteen words behind the first numel
+    const long long base = tail ? numel : (i & ~15ll);
+    const int j = (int)(tail ? i - (numel - 16) : (i & 15));
+    const uint32_t k1 = mt_temper(w[base + (j & 7)]) & MT_U24, k2 = mt_temper(w[base + 8 + (j & 7)]) & MT_U24;
+    const float n = R[k1] * (j < 8 ? C[k2] : S[k2]);
+    out[i] = __builtin_fmaf(n, std, mean);
+}
+
+// The words of a call: sequential walk (k_mt_blocks; raw + meta offset) or in pieces (k_mt_jump + k_mt_chunks; offset 0, meta null).
+// `polys` = G polynomials of 624 words (t^J_c mod phi, J_c = distance from the first word in `hist` to the first word of piece c - the
+// host knows both); skip_words is part of J_c already: in pieces the state is replaced, not advanced.
+static int mt_words(midas_ctx* ctx, uint32_t* state, int64_t skip_words, int64_t nwords, const uint32_t* hist, const uint32_t* polys, int32_t G,
+                    uint32_t** raw_out, int32_t** meta_out) {
     void* p;
     int rc;
-    if ((rc = midas_scratch(ctx, ((size_t)nblocks + 1) * MT_N * sizeof(uint32_t), &p))) return rc;
-    uint32_t* raw = (uint32_t*)p;
-    if ((rc = midas_scratch(ctx, (size_t)G * MT_N * sizeof(uint32_t), &p))) return rc;
-    uint32_t* starts = (uint32_t*)p;
-    static bool attr_set[64] = {};
-    const int di = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
-    const int lds = MT_JWIN * (int)sizeof(uint32_t);
-    if (!attr_set[di] || ctx->device != di) {
-        MIDAS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_mt_jump, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set[di] = true;
+    *raw_out = nullptr;
+    *meta_out = nullptr;
+    if (polys && G > 0) {
+        const int64_t nblocks = ceil_div(nwords, MT_N);
+        const int bpc = (int)ceil_div(nblocks, G);
+        if ((rc = midas_scratch(ctx, ((size_t)nblocks + 1) * MT_N * sizeof(uint32_t), &p))) return rc;
+        uint32_t* raw = (uint32_t*)p;
+        if ((rc = midas_scratch(ctx, (size_t)G * MT_N * sizeof(uint32_t), &p))) return rc;
+        uint32_t* starts = (uint32_t*)p;
+        static bool attr_set[64] = {};
+        const int di = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+        const int lds = MT_JWIN * (int)sizeof(uint32_t);
+        if (!attr_set[di] || ctx->device != di) {
+            MIDAS_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_mt_jump, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_set[di] = true;
+        }
+        hipLaunchKernelGGL(k_mt_jump, dim3(MT_N / MT_JW, (unsigned)G), dim3(256), lds, ctx->stream, hist, polys, starts);
+        hipLaunchKernelGGL(k_mt_chunks, dim3((unsigned)G), dim3(MT_THREADS), 0, ctx->stream, (const uint32_t*)starts, (long long)nwords, bpc, raw, state);
+        *raw_out = raw;
+        return MIDAS_OK;
     }
-    hipLaunchKernelGGL(k_mt_jump, dim3(MT_N / MT_JW, (unsigned)G), dim3(256), lds, ctx->stream, (const uint32_t*)hist, polys, starts);
-    hipLaunchKernelGGL(k_mt_chunks, dim3((unsigned)G), dim3(MT_THREADS), 0, ctx->stream, (const uint32_t*)starts, (long long)nwords, bpc, raw, state);
-    hipLaunchKernelGGL(k_mt_emit, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)raw, (const int32_t*)nullptr,
+    if (nwords > 0) {
+        // blocks b0 .. bl: at most the words, the rest of the block they start in and of the one they end in
+        if ((rc = midas_scratch(ctx, ((size_t)nwords + 3 * MT_N) * sizeof(uint32_t), &p))) return rc;
+        *raw_out = (uint32_t*)p;
+        if ((rc = midas_scratch(ctx, 64, &p))) return rc;
+        *meta_out = (int32_t*)p;
+    }
+    hipLaunchKernelGGL(k_mt_blocks, dim3(1), dim3(MT_THREADS), 0, ctx->stream, state, (long long)skip_words, (long long)nwords, *raw_out, *meta_out);
+    return MIDAS_OK;
+}
+
+int launch_mt_rand64_chunked(midas_ctx* ctx, uint32_t* state, int64_t N, double* out, uint32_t* hist, const uint32_t* polys, int32_t G) {
+    uint32_t* raw;
+    int32_t* meta;
+    int rc = mt_words(ctx, state, 0, 2 * N, hist, polys, G, &raw, &meta);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_mt_emit, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)raw, (const int32_t*)meta,
                        (long long)N, out, hist);
     MIDAS_HIP_CHECK(ctx, hipGetLastError());
     return MIDAS_OK;
@@ -297,21 +342,28 @@ int launch_mt_rand64_chunked(midas_ctx* ctx, uint32_t* state, int64_t N, double*
 
 int launch_mt_rand64(midas_ctx* ctx, uint32_t* state, int64_t skip_words, int64_t N, double* out, uint32_t* hist) {
     if (N == 0 && skip_words == 0) return MIDAS_OK;
-    uint32_t* raw = nullptr;
-    int32_t* meta = nullptr;
-    if (N > 0) {
-        // blocks b0 .. bl: at most the 2 N words, the rest of the block they start in and of the one they end in
-        void* p;
-        int rc = midas_scratch(ctx, ((size_t)2 * N + 3 * MT_N) * sizeof(uint32_t), &p);
-        if (rc) return rc;
-        raw = (uint32_t*)p;
-        if ((rc = midas_scratch(ctx, 64, &p))) return rc;
-        meta = (int32_t*)p;
-    }
-    hipLaunchKernelGGL(k_mt_blocks, dim3(1), dim3(MT_THREADS), 0, ctx->stream, state, (long long)skip_words, (long long)(2 * N), raw, meta);
+    uint32_t* raw;
+    int32_t* meta;
+    int rc = mt_words(ctx, state, skip_words, 2 * N, nullptr, nullptr, 0, &raw, &meta);
+    if (rc) return rc;
     if (N > 0)
         hipLaunchKernelGGL(k_mt_emit, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)raw, (const int32_t*)meta, (long long)N,
                            out, 2 * N >= MT_HIST ? hist : (uint32_t*)nullptr);
+    MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    return MIDAS_OK;
+}
+
+// numel float32 normals (numel >= 16); polys / G as in mt_words (nullptr / 0: the sequential walk)
+int launch_mt_normal32(midas_ctx* ctx, uint32_t* state, int64_t skip_words, int64_t numel, float mean, float std, const float* R, const float* C,
+                       const float* S, float* out, uint32_t* hist, const uint32_t* polys, int32_t G) {
+    const int64_t nwords = numel + ((numel & 15) ? 16 : 0);
+    uint32_t* raw;
+    int32_t* meta;
+    int rc = mt_words(ctx, state, skip_words, nwords, hist, polys, G, &raw, &meta);
+    if (rc) return rc;
+    const int64_t threads = numel > MT_HIST ? numel : (nwords < MT_HIST ? nwords : MT_HIST);  // (the history's words have a thread each)
+    hipLaunchKernelGGL(k_mt_normal, dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)raw, (const int32_t*)meta,
+                       (long long)numel, (long long)nwords, R, C, S, mean, std, out, nwords >= MT_HIST ? hist : (uint32_t*)nullptr);
     MIDAS_HIP_CHECK(ctx, hipGetLastError());
     return MIDAS_OK;
 }

@@ -127,11 +127,18 @@ class TorchCpuStream:
         else:
             self._enter()
         words = 2 * N
-        polys = None
-        if self.pieces > 0 and self._hist_words and words >= _lib.MT19937_HIST_WORDS:
-            polys = self._piece_polys(self._hist_words, self.pending_skip, words)
+        polys = self._chain_polys(words)
         self._call("midas_mt19937_rand64_chunked", _ptr(self.state), self.pending_skip, N, _ptr(out), _ptr(self._hist), _ptr(polys),
                    self.pieces if polys is not None else 0)
+        return self._drawn(words, out)
+
+    def _chain_polys(self, words: int):
+        """The jump polynomials of a call of `words` words, or None (no history / too short: the sequential walk)."""
+        if self.pieces > 0 and self._hist_words and words >= _lib.MT19937_HIST_WORDS:
+            return self._piece_polys(self._hist_words, self.pending_skip, words)
+        return None
+
+    def _drawn(self, words: int, out):
         # (a call too short to leave a history, or a pure skip, breaks the chain: the next call walks sequentially)
         self._hist_words = words if words >= _lib.MT19937_HIST_WORDS else 0
         self.pending_skip = 0
@@ -140,6 +147,46 @@ class TorchCpuStream:
         ev = torch.cuda.Event()
         ev.record(self.side)
         return out, ev
+
+    def _normal_tables(self):
+        """The three 2^24-entry tables of torch.normal's float32 path on this machine (torch_normal.py), on the device."""
+        tabs = getattr(self, "_ntab", None)
+        if tabs is None:
+            from . import torch_normal
+            with torch.cuda.stream(self.side) if self.side is not None else _null():
+                tabs = tuple(torch.from_numpy(a).to(self.device) for a in torch_normal.host_tables())
+            self._ntab = tabs
+        return tabs
+
+    def normal_async(self, mean: float, std: float, size, out: torch.Tensor | None = None):
+        """torch.normal(mean, std, size=size) of float32 values - the reference's motion-noise draws (particle_filter.py:326-335) -
+        from this stream, enqueued on the generator's stream: (tensor, event or None) as rand64_async.  The result is a fresh tensor
+        unless `out` is given (float32, contiguous, numel elements); at least 16 values (ATen's scalar path below that is not
+        modelled)."""
+        shape = tuple(size) if hasattr(size, "__len__") else (int(size),)
+        numel = 1
+        for d in shape:
+            numel *= int(d)
+        if numel < 16:
+            raise _lib.MidasError("torch.normal of fewer than 16 values uses another code path of ATen: not modelled")
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=self.device)
+            if self.side is not None:
+                out.record_stream(self.side)
+        R, Ct, S = self._normal_tables()
+        self._enter()
+        words = normal_words(numel)
+        polys = self._chain_polys(words) if numel >= _lib.MT19937_HIST_WORDS else None
+        self._call("midas_mt19937_normal32", _ptr(self.state), self.pending_skip, numel, float(mean), float(std), _ptr(R), _ptr(Ct), _ptr(S),
+                   _ptr(out), _ptr(self._hist), _ptr(polys), self.pieces if polys is not None else 0)
+        return self._drawn(words if numel >= _lib.MT19937_HIST_WORDS else 0, out)
+
+    def normal(self, mean: float, std: float, size, out: torch.Tensor | None = None) -> torch.Tensor:
+        """torch.normal(mean, std, size=size) (float32), ordered behind the caller's current stream."""
+        z, ev = self.normal_async(mean, std, size, out)
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+        return z
 
     def _piece_polys(self, prev_words: int, skip: int, words: int):
         key = (prev_words, skip, words, self.pieces)

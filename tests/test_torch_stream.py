@@ -167,3 +167,42 @@ def test_pipelined_engine_on_the_device_stream_equals_host_uniforms():
         if t % 3 == 0:
             assert torch.equal(a.ridx, b.ridx) and torch.equal(a.poses, b.poses), t
     assert torch.equal(a.ridx, b.ridx) and torch.equal(a.weights, b.weights)
+
+
+def test_torch_normal_tables_reproduce_torch_normal():
+    """torch_normal.py: the radius / cos / sin tables read off torch.normal (crafted generator states) reproduce torch.normal under a
+    seed bit for bit - multiples of 16 and not, the reference's (N, 3) shapes, several scales (CPU: numpy emulation of the device
+    kernel's arithmetic, generator words from torch.rand's float32 stream)."""
+    from midastouch_amd import torch_normal as tn
+    R, C, S = tn.host_tables()
+    assert R.shape == C.shape == S.shape == (1 << 24,) and C[0] == 1.0 and S[0] == 0.0 and R[0] == 0.0
+    for seed, numel, std in ((5, 16, 1.0), (7, 48, 0.5), (11, 100, 2e-4), (3000, 300_000, 0.5), (42, 3 * 33_333, 2e-4), (9, 17, 60.0)):
+        torch.manual_seed(seed)
+        ref = torch.normal(0.0, std, size=(numel,)).numpy()
+        nw = numel + (16 if numel % 16 else 0)
+        torch.manual_seed(seed)
+        k = np.round(torch.rand(nw, dtype=torch.float32).numpy().astype(np.float64) * 2.0 ** 24).astype(np.uint64)
+        assert np.array_equal(tn.emulate(k, numel, 0.0, std), ref), (seed, numel, std)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pieces", [0, 6])
+def test_device_normal_equals_torch_normal(pieces):
+    """midas_mt19937_normal32: the reference's motion-noise draws from the device replica of torch's generator - one frame's
+    sequence tn, rot (torch.normal, (N, 3)), then the resampler's N float64 uniforms, frame after frame, bit for bit; sizes that are
+    and are not multiples of 16, below and above the chaining threshold, sequential and in pieces."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from midastouch_amd.torch_rng import TorchCpuStream
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(31)
+    st = TorchCpuStream(31, dev, pieces=pieces)
+    for N in (16, 100, 4096, 33_333, 100_000, 100_000, 100_000, 7_000, 100_000):
+        tn_ref = torch.normal(0.0, 2e-4, size=(N, 3))
+        rot_ref = torch.normal(0.0, 0.5, size=(N, 3))
+        u_ref = torch.rand(N, dtype=torch.float64)
+        assert torch.equal(st.normal(0.0, 2e-4, (N, 3)).cpu(), tn_ref), N
+        assert torch.equal(st.normal(0.0, 0.5, (N, 3)).cpu(), rot_ref), N
+        assert torch.equal(st.rand64(N).cpu(), u_ref), N
+    z = torch.normal(1.5, 3.0, size=(1000,))
+    assert torch.equal(st.normal(1.5, 3.0, 1000).cpu(), z)  # (a mean that is not zero: the fused multiply-add)
