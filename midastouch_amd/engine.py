@@ -298,25 +298,49 @@ class PipelinedFilterEngine(FilterEngine):
             self.ctx.call("midas_score_list_seed", self.K, _ptr(self._stamps), self._next_epoch(), _ptr(self._score_list), self.N, _ptr(idx))
         return idx
 
-    def seed_torch_stream(self, seed):
+    def seed_torch_stream(self, seed, motion: bool = False):
         """Resample draws from the device replica of torch's CPU generator under torch.manual_seed(seed) (torch_rng.py):
         every step() without explicit `u` then resamples with the uniforms torch.multinomial would consume
         (modules/particle_filter.py:245).  With host motion noise (tn, rot given) the stream first steps over the words those
-        two torch.normal calls took, so it stays aligned with a host generator seeded alike.  seed=None: back to Philox."""
+        two torch.normal calls took, so it stays aligned with a host generator seeded alike.
+        motion=True: the motion noise comes from the stream too - `torch.normal(0, sig_t, (N, 3))`, `torch.normal(0, sig_r, (N, 3))`
+        in front of the resampler's uniforms, the reference's order (:326-335, :245) - i.e. EVERY draw of a frame is the one a
+        seeded run of the reference takes, generated on the device (unit normals a frame ahead, scaled where they are used).
+        seed=None: back to Philox."""
         from .torch_rng import TorchCpuStream
         self.torch_stream = None if seed is None else TorchCpuStream(seed, self.device)
+        self.torch_motion = bool(motion) and seed is not None
+        self._unit_noise = None  # (tn, rot, event): unit normals of the NEXT frame, drawn behind this frame's uniforms
         return self.torch_stream
 
     def step(self, odom, code, gt=None, tn=None, rot=None, u=None, u32=-1.0, multiplier: float = 1.0):
         stream = getattr(self, "torch_stream", None)
         own_u, u_event = False, None  # own_u: generated here (a buffer nobody else holds): kept for the folded frame without a copy
         if stream is not None and u is None and self.mode == _lib.RESAMPLE_MULTINOMIAL:
+            stream_motion = False
             if tn is not None:
                 stream.skip_normal(3 * self.N).skip_normal(3 * self.N)
+            elif getattr(self, "torch_motion", False):
+                stream_motion = True
+                # the frame's own normals: std = 1 draws scaled here - fl(n x std) is what ATen's fused multiply-add with mean 0 gives -
+                # so that they can be drawn a frame ahead whatever `multiplier` the caller passes then
+                if self._unit_noise is None:
+                    a, _ = stream.normal_async(0.0, 1.0, (self.N, 3))
+                    b, ev = stream.normal_async(0.0, 1.0, (self.N, 3))
+                    self._unit_noise = (a, b, ev)
+                a, b, ev = self._unit_noise
+                if ev is not None:
+                    torch.cuda.current_stream(self.device).wait_event(ev)
+                mul = max(float(multiplier), 1.0)
+                tn, rot = a * (mul * self.sig_t), b * (mul * self.sig_r)
             # this frame's draws are consumed by the NEXT launch (the folded resample) or by flush(): generated beside this
             # frame's kernels on the generator's own stream, waited for where they are read
             u, u_event = stream.rand64_async(self.N)
             own_u = True
+            if stream_motion:
+                a, _ = stream.normal_async(0.0, 1.0, (self.N, 3))   # the next frame's, behind this frame's uniforms (the stream's order)
+                b, ev = stream.normal_async(0.0, 1.0, (self.N, 3))
+                self._unit_noise = (a, b, ev)
         self._wait_draws()
         odom, code, gt, tn, rot, u = self._operands(odom, code, gt, tn, rot, u)
         cur, nxt = self._cur, self._cur ^ 1

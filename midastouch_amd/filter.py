@@ -106,6 +106,10 @@ def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str
     order - which needs the particle count on the host twice per frame (bit-parity with the reference under
     torch.manual_seed, at the price of those read-backs and of the host generator); annealing's top-k then also resolves its
     ties the way torch.topk does on the CPU (LoopEngine(topk_ties="aten_cpu")), so the particle SET is the reference's too.
+    draws="seeded": the SAME numbers as draws="host" - torch's default CPU generator continued on the device (torch_rng.py:
+    its mt19937 stream, `torch.normal`'s float32 transform as tables read off torch itself, `torch.rand` float64) - without the
+    host generating and uploading 6 N normals and N uniforms a frame; the host-side draws of `init_filter` take the stream
+    over and hand it back, and at the end torch's generator stands where draws="host" leaves it.
     pace="fixed" steps one frame per iteration; pace="wallclock" reproduces `idx = int(frame_rate * total_time)`
     (:134-135: slow iterations skip frames, fast ones repeat) and therefore waits for every frame.
     The defaults are `filter/filter.py`'s; `filter_real(...)` presets the real-data script's variations
@@ -116,8 +120,8 @@ def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str
     from .loop_engine import LoopEngine
 
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    if draws not in ("device", "host"):
-        raise ValueError("draws must be 'device' or 'host'")
+    if draws not in ("device", "host", "seeded"):
+        raise ValueError("draws must be 'device', 'host' or 'seeded'")
     expt_cfg = cfg.expt
     init_particles = int(expt_cfg.params.num_particles)
     noise_ratio = expt_cfg.params.noise_ratio
@@ -133,7 +137,32 @@ def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str
         pf._mesh_tree = seq.mesh_tree
     eng = LoopEngine(codebook, None, pf.mesh_kdtree, init_particles, sig_t=pf.motion_noise["sig_t"], sig_r=pf.motion_noise["sig_r"],
                      pen_max=pf.pen_max, seed=seed, softmax=softmax, floor=floor, cluster=cluster, log_frames=max(traj_size + 8, 64),
-                     device=device, topk_ties="aten_cpu" if draws == "host" else "index")
+                     device=device, topk_ties="aten_cpu" if draws in ("host", "seeded") else "index")
+    stream = None
+    if draws == "seeded":
+        from .torch_rng import TorchCpuStream
+        stream = TorchCpuStream(0, device)
+    on_device = False  # seeded: who holds torch's stream at the moment (False: the host's default generator)
+
+    def stream_to(dev_side: bool):
+        nonlocal on_device
+        if stream is None or on_device == dev_side:
+            return
+        stream.from_host() if dev_side else stream.to_host()
+        on_device = dev_side
+
+    def draw_normal(std, n):  # add_noise_to_odom's torch.normal(mu, std, (n, 3)) (:326-335)
+        if stream is not None and 3 * n >= 16:
+            stream_to(True)
+            return stream.normal(pf.motion_noise["mu"], std, (n, 3))
+        stream_to(False)  # (host mode, or fewer than 16 values: ATen's scalar path, drawn where it is defined)
+        return torch.normal(mean=pf.motion_noise["mu"], std=std, size=(n, 3))
+
+    def draw_uniform(n):  # the resampler's torch.multinomial stream (:245)
+        if stream is not None:
+            stream_to(True)
+            return stream.rand64(n)
+        return torch.rand(n, dtype=torch.float64)
     # odom = inv(meas[prev]) @ meas[idx] (:154): the inverses in one call, and - frame after frame in fixed pace - the
     # products too (a 4x4 product per frame through the BLAS library costs more device time than the whole frame's kernels)
     inv_meas = torch.linalg.inv(meas_p)
@@ -173,6 +202,7 @@ def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str
             start = time.time()
             moving = prev_idx > 0
             if not moving:  # (filter.py:152,156-160) - like the reference, frames seen while prev_idx == 0 re-initialise
+                stream_to(False)  # init_filter draws on the host generator
                 particles = pf.init_filter(gt_p[idx, :], init_particles)
                 eng.set_particles(particles.poses, reset_annealing=count == 0)
                 eng.project_to_codebook()
@@ -181,17 +211,17 @@ def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str
                 odom = step_odoms[prev_idx] if idx == prev_idx + 1 else inv_meas[prev_idx] @ meas_p[idx, :]
             unit = count % max(int(update_freq), 1) != 0  # filter_real.py:205-212: no measurement update on this frame
             kw = dict(gt=gt_p[idx, :], dbscan=cluster and count % 50 == 0, unit_weights=unit, std_override=None if moving else (0.0, 0.0))
-            if draws == "host":
+            if draws in ("host", "seeded"):
                 n = eng.n
                 std_t, std_r = (pf.motion_noise["sig_t"], pf.motion_noise["sig_r"]) if moving else (0.0, 0.0)
                 if moving:  # add_noise_to_odom's draws, its order (:326-335); the initial frames draw inside init_filter
-                    kw["tn"] = torch.normal(mean=pf.motion_noise["mu"], std=std_t, size=(n, 3))
-                    kw["rot"] = torch.normal(mean=pf.motion_noise["mu"], std=std_r, size=(n, 3))
+                    kw["tn"] = draw_normal(std_t, n)
+                    kw["rot"] = draw_normal(std_r, n)
                 else:
                     kw["tn"], kw["rot"] = torch.zeros((n, 3)), torch.zeros((n, 3))
                 eng.step(odom, seq.codes[idx], phases=_lib.LOOP_FRONT | _lib.LOOP_DBSCAN | _lib.LOOP_ANNEAL, **kw)
                 n_set = int(eng.ctl_i[_lib.LOOP_I_NSET].item())
-                eng.step(None, None, u=torch.rand(n_set, dtype=torch.float64), phases=_lib.LOOP_RESAMPLE)  # multinomial's stream
+                eng.step(None, None, u=draw_uniform(n_set), phases=_lib.LOOP_RESAMPLE)  # multinomial's stream
             else:
                 eng.step(odom, seq.codes[idx], **kw)
             ev = torch.cuda.Event(enable_timing=True)
@@ -216,6 +246,7 @@ def filter(cfg, seq: Optional[Sequence] = None, viz=None, device=None, pace: str
             prev_idx = idx
             count += 1
         torch.cuda.synchronize(device)
+        stream_to(False)  # seeded: torch's generator continues where the run's draws ended
     finally:
         gc.unfreeze()  # also when a frame raises: a frozen collector would outlive the run
     records.extend(eng.read_log(len(records), count))

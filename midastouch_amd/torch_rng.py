@@ -85,6 +85,58 @@ class TorchCpuStream:
         self._mark = None
         return self
 
+    # ---- hand-over between torch's host generator and this stream --------------------------------------------------
+    # A caller that draws some numbers on the host (init_filter, particle_filter.py:129-145) and the per-frame ones here keeps
+    # ONE stream: from_host() continues the host generator where it stands, to_host() gives it back.  Layout of the host
+    # state (CPUGeneratorImpl's legacy pod, 5056 bytes): uint64 seed | int32 left | int32 seeded | uint64 next | uint64 state[624] | ..
+    def from_host(self, generator: torch.Generator | None = None):
+        """Continue `generator` (default: torch's default CPU generator) on the device: the next draw here is the number the host
+        generator would have produced next."""
+        import numpy as np
+        b = (torch.get_rng_state() if generator is None else generator.get_state()).numpy()
+        if b.size != 5056:
+            raise _lib.MidasError("unexpected layout of torch's CPU generator state")
+        left = int(np.frombuffer(b[8:12].tobytes(), dtype=np.int32)[0])
+        nxt = int(np.frombuffer(b[16:24].tobytes(), dtype=np.uint64)[0])
+        words = np.frombuffer(b[24:24 + 624 * 8].tobytes(), dtype=np.uint64).astype(np.uint32)
+        # at::mt19937 twists when --left reaches 0: left == 1 means "a new block is due" whatever next says (fresh seeds: left 1, next 0)
+        pos = 624 if left == 1 else nxt
+        host = np.concatenate([words, np.array([pos, 0], dtype=np.uint32)]).view(np.int32)
+        self._enter()
+        with torch.cuda.stream(self.side) if self.side is not None else _null():
+            self.state.copy_(torch.from_numpy(host.copy()), non_blocking=False)
+        self.pending_skip = 0
+        self._hist_words = 0
+        self._mark = None
+        return self
+
+    def to_host(self, generator: torch.Generator | None = None):
+        """Give the stream back: `generator` (default: torch's default CPU generator) continues where this stream stands
+        (pending skips applied).  Synchronises with the generator's stream."""
+        import numpy as np
+        if self.pending_skip:
+            self._enter()
+            self._call("midas_mt19937_rand64_chunked", _ptr(self.state), self.pending_skip, 0, None, None, None, 0)
+            self.pending_skip = 0
+            self._hist_words = 0
+        if self.side is not None:
+            self.side.synchronize()
+        else:
+            torch.cuda.current_stream(self.device).synchronize()
+        st = self.state.cpu().numpy().view(np.uint32)
+        pos = int(st[624])
+        g = torch.default_generator if generator is None else generator
+        b = g.get_state().numpy().copy()
+        if b.size != 5056:
+            raise _lib.MidasError("unexpected layout of torch's CPU generator state")
+        # pos words of the stored block are consumed: next = pos, left = 624 - pos + 1 (the twist happens when --left hits 0)
+        b[8:12] = np.frombuffer(np.int32(624 - pos + 1).tobytes(), dtype=np.uint8)
+        b[12:16] = np.frombuffer(np.int32(1).tobytes(), dtype=np.uint8)
+        b[16:24] = np.frombuffer(np.uint64(pos if pos < 624 else 0).tobytes(), dtype=np.uint8)
+        b[24:24 + 624 * 8] = np.frombuffer(st[:624].astype(np.uint64).tobytes(), dtype=np.uint8)
+        g.set_state(torch.from_numpy(b))
+        return self
+
     def skip_words(self, n: int):
         """Step over n 32-bit outputs (applied with the next draw)."""
         self.pending_skip += int(n)

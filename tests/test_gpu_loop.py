@@ -420,6 +420,29 @@ def test_filter_runner_host_draws_matches_oracle_loop(dev, oracle):
     assert stats["frames"][-1]["n_after"] == poses.shape[0]
 
 
+def test_filter_runner_seeded_draws_equal_host_draws(dev):
+    """filter(draws="seeded"): torch's CPU generator continued on the device - mt19937 words, torch.normal's float32 transform,
+    torch.rand float64, handed over to the host for init_filter and back - gives the run of draws="host" number for number: the
+    same particle counts, rmse and cluster spreads in every frame, and torch's generator stands at the same place afterwards."""
+    from midastouch_amd.config import load_config
+    from midastouch_amd.filter import filter as run_filter, synthetic_sequence
+    N, T = 6000, 30
+    cfg = load_config([f"expt.params.num_particles={N}", "expt.codebook_size=2500"])
+    seq = synthetic_sequence(cfg, dev, T=T)
+    out = {}
+    for mode in ("host", "seeded"):
+        torch.manual_seed(77)
+        st = run_filter(cfg, seq=seq, device=dev, draws=mode, floor=500)
+        out[mode] = (st, torch.rand(8, dtype=torch.float64))
+    a, b = out["host"][0], out["seeded"][0]
+    assert a["num_particles"] == b["num_particles"] and min(a["num_particles"]) < N
+    assert a["rmse_t"] == b["rmse_t"] and a["rmse_r"] == b["rmse_r"]
+    for x, y in zip(a["cluster_stds"], b["cluster_stds"]):
+        assert torch.equal(x, y)
+    assert [f["kept"] for f in a["frames"]] == [f["kept"] for f in b["frames"]]
+    assert torch.equal(out["host"][1], out["seeded"][1]), "torch's generator does not stand where the host-draw run leaves it"
+
+
 def test_filter_runner_device_draws_tracks_and_anneals(dev):
     """filter() with its default device draws: frames are enqueued back to back, the log is read once at the end."""
     from midastouch_amd.config import load_config

@@ -488,3 +488,31 @@ def test_dense_front_scores_every_row(dev, oracle, monkeypatch, N, K, D):
         e.run(od[6:12], co[6:12])
     assert torch.equal(engs["dense"].ridx, engs["sparse"].ridx) and torch.equal(engs["dense"].poses, engs["sparse"].poses)
     assert np.array_equal(engs["dense"]._scores.cpu().numpy(), oracle.score_codebook(cb.embeddings, traj.codes[11]))
+
+
+def test_pipelined_every_draw_from_the_device_replica_of_torchs_stream(dev, oracle):
+    """seed_torch_stream(seed, motion=True): motion noise AND resample draws from the device replica of torch's CPU generator, in
+    the reference's order (tn, rot, then the resampler's uniforms - particle_filter.py:326-335, :245), unit normals drawn a frame
+    ahead: frame after frame identical to the oracle fed with the host generator's own draws under torch.manual_seed."""
+    from midastouch_amd.engine import PipelinedFilterEngine
+    N, K, D = 20_000, 3000, 256
+    cb, traj = _setup(N, K, D, 7)
+    ofl = oracle.OracleFilter(cb.poses, cb.embeddings, cb.mesh_vertices)
+    eng = PipelinedFilterEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N, seed=1, device=dev)
+    rng = np.random.default_rng(12)
+    poses = cb.poses[rng.integers(0, K, N)]
+    eng.set_particles(torch.as_tensor(poses))
+    eng.seed_torch_stream(2024, motion=True)
+    torch.manual_seed(2024)
+    for t in range(1, 9):
+        tn = torch.normal(0.0, 2e-4, size=(N, 3)).numpy()
+        rot = torch.normal(0.0, 0.5, size=(N, 3)).numpy()
+        u = torch.rand(N, dtype=torch.float64).numpy()
+        ref = ofl.step(poses, traj.odoms[t], traj.codes[t], tn, rot, u=u)
+        eng.step(torch.as_tensor(traj.odoms[t]).to(dev), torch.as_tensor(traj.codes[t]).to(dev))
+        assert np.array_equal(eng.poses_prop.cpu().numpy(), ref["poses_prop"]), f"frame {t}: propagated poses"
+        assert np.array_equal(eng.nn_idx.cpu().numpy(), ref["nn_idx"]), f"frame {t}"
+        if t % 3 == 0:
+            assert np.array_equal(eng.ridx.cpu().numpy(), ref["ridx"]), f"frame {t}: resample indices"
+            assert np.array_equal(eng.poses.cpu().numpy(), ref["poses"]), f"frame {t}"
+        poses = ref["poses"]

@@ -206,3 +206,36 @@ def test_device_normal_equals_torch_normal(pieces):
         assert torch.equal(st.rand64(N).cpu(), u_ref), N
     z = torch.normal(1.5, 3.0, size=(1000,))
     assert torch.equal(st.normal(1.5, 3.0, 1000).cpu(), z)  # (a mean that is not zero: the fused multiply-add)
+
+
+@pytest.mark.gpu
+def test_stream_hand_over_between_host_and_device():
+    """from_host / to_host: one torch stream, drawn alternately on the host generator and on the device replica - as a runner does that
+    initialises its particles with host draws (init_filter) and takes the per-frame draws on the device."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from midastouch_amd.torch_rng import TorchCpuStream
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(123)
+    ref = [torch.normal(0.0, 1.0, size=(5000, 3)), torch.rand(777, dtype=torch.float64), torch.normal(0.0, 0.5, size=(100, 3)),
+           torch.rand(3), torch.normal(0.0, 2.0, size=(40_000,)), torch.rand(50_000, dtype=torch.float64), torch.rand(5, dtype=torch.float64)]
+    torch.manual_seed(123)
+    st = TorchCpuStream(0, dev)
+    got = [torch.normal(0.0, 1.0, size=(5000, 3))]                 # host
+    st.from_host()
+    got.append(st.rand64(777).cpu())                               # device
+    got.append(st.normal(0.0, 0.5, (100, 3)).cpu())
+    st.to_host()
+    got.append(torch.rand(3))                                      # host again (float32: one word each)
+    st.from_host()
+    got.append(st.normal(0.0, 2.0, 40_000).cpu())
+    got.append(st.rand64(50_000).cpu())
+    st.to_host()
+    got.append(torch.rand(5, dtype=torch.float64))
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert torch.equal(a, b), i
+    # a freshly seeded host generator (left = 1: the twist is due) hands over as well
+    torch.manual_seed(9)
+    st.from_host()
+    torch.manual_seed(9)
+    assert torch.equal(st.rand64(1000).cpu(), torch.rand(1000, dtype=torch.float64))
