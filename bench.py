@@ -350,7 +350,7 @@ def big_config_rates(dev, which):
     return out
 
 
-def parity_mode_rate(cb, traj, N, dev, tree, mesh_tree, steps=100):
+def parity_mode_rate(cb, traj, N, dev, tree, mesh_tree, steps=100, motion=False):
     """The fixed-seed mode at c2: every frame resamples with the draws torch.multinomial would take from torch's CPU
     generator under torch.manual_seed(3000) (modules/particle_filter.py:245), generated by the device replica of that
     generator (midas_mt19937_rand64) - the mode in which resample indices are bit-exact against the reference's
@@ -362,7 +362,7 @@ def parity_mode_rate(cb, traj, N, dev, tree, mesh_tree, steps=100):
     rng = np.random.default_rng(0)
     eng.set_particles(torch.as_tensor(cb.poses[rng.integers(0, cb.K, N)]))
     eng.project_to_codebook()
-    eng.seed_torch_stream(3000)
+    eng.seed_torch_stream(3000, motion=motion)
     odoms, codes = torch.as_tensor(traj.odoms).to(dev), torch.as_tensor(traj.codes).to(dev)
     T = odoms.shape[0]
     for i in range(20):
@@ -379,7 +379,9 @@ def parity_mode_rate(cb, traj, N, dev, tree, mesh_tree, steps=100):
     return {"steps_per_sec": steps / dt, "steps_per_sec_runs": spread([steps / d for d in dts]), "ms_per_step": 1e3 * dt / steps, "steps": steps,
             "draws": "resample: device replica of torch's CPU mt19937 under torch.manual_seed(3000) (torch.rand(N, float64) stream, "
                      "generated on the generator's own stream beside each frame's kernels, a frame's 2 N words in six pieces side by side whose start "
-                     "states follow from the previous frame's words by GF(2) jump polynomials: midastouch_amd/mt_jump.py); motion noise: device Philox",
+                     "states follow from the previous frame's words by GF(2) jump polynomials: midastouch_amd/mt_jump.py); motion noise: "
+                     + ("the same stream - torch.normal(0, sig, (N, 3)) twice a frame in front of the uniforms, its float32 transform as tables read "
+                        "off torch.normal itself (midastouch_amd/torch_normal.py): every draw of the frame is the reference's" if motion else "device Philox"),
             "status": eng.status.cpu().numpy().tolist()}
 
 
@@ -917,6 +919,7 @@ def main():
                            "step_frac": achieved / HBM_PEAK_GBS}
     if not sharded and not args.no_extras:
         out["config"]["parity_mode"] = guarded(parity_mode_rate, cb, traj, N, dev, tree, eng.tree3)
+        out["config"]["parity_mode_all_draws"] = guarded(parity_mode_rate, cb, traj, N, dev, tree, eng.tree3, 100, True)
         if N == 100_000 and K == 50_000 and D == 512:  # beside the headline workload only
             out["config"]["c5"] = guarded(config5_rate, dev)
             out["config"]["c1"] = guarded(config1_rates, dev)
