@@ -126,8 +126,8 @@ class particle_filter:
         from scipy.spatial.transform import Rotation as R
 
         dev = gt_pose.device
-        tn = torch.normal(mean=0.0, std=self.init_noise[0], size=(N, 3))
-        rotNoise = torch.normal(mean=0.0, std=self.init_noise[1], size=(N, 3))
+        tn = self._normal(0.0, self.init_noise[0], N).cpu()
+        rotNoise = self._normal(0.0, self.init_noise[1], N).cpu()
         Rn = torch.tensor(R.from_euler("zyx", rotNoise, degrees=True).as_matrix())
         Tn = torch.zeros((N, 4, 4), dtype=gt_pose.dtype)
         Tn[:, :3, :3], Tn[:, :3, 3], Tn[:, 3, 3] = Rn, tn, 1
@@ -142,10 +142,25 @@ class particle_filter:
         particles = copy.copy(_particles)
         N = particles.poses.shape[0]
         # same draws, same order, same generator as add_noise_to_odom (:326-335)
-        tn = torch.normal(mean=self.motion_noise["mu"], std=float(multiplier) * self.motion_noise["sig_t"], size=(N, 3))
-        rotNoise = torch.normal(mean=self.motion_noise["mu"], std=float(multiplier) * self.motion_noise["sig_r"], size=(N, 3))
+        tn = self._normal(self.motion_noise["mu"], float(multiplier) * self.motion_noise["sig_t"], N)
+        rotNoise = self._normal(self.motion_noise["mu"], float(multiplier) * self.motion_noise["sig_r"], N)
         particles.poses = ops.propagate(particles.poses, odom, tn, rotNoise)
         return self.check_quats(particles)
+
+    def _normal(self, mean: float, std: float, N: int) -> torch.Tensor:
+        """torch.normal(mean, std, size=(N, 3)) as the reference draws it: on torch's CPU generator, or - after
+        seed_device_stream() - from that generator's replica on the device (the same numbers, torch_rng.py; below 16 values ATen takes
+        another path, which stays on the host: the stream is handed over for that call and taken back)."""
+        stream = getattr(self, "torch_stream", None)
+        if stream is None:
+            return torch.normal(mean=mean, std=std, size=(N, 3))
+        if 3 * N >= 16:
+            return stream.normal(mean, std, (N, 3))
+        g = torch.Generator()
+        stream.to_host(g)
+        z = torch.normal(mean=mean, std=std, size=(N, 3), generator=g)
+        stream.from_host(g)
+        return z
 
     def check_quats(self, particles: Particles) -> Particles:
         """Prune particles whose rotation gives a NaN / zero-norm quaternion (:347-357)."""
@@ -281,10 +296,10 @@ class particle_filter:
 
     # ---------------------------------------------------------------------------------------------
     def seed_device_stream(self, seed: int):
-        """torch.manual_seed(seed) for the resampler's draws, kept on the device: `resampler("weighted_random")` then takes
-        the uniforms torch.multinomial would consume (modules/particle_filter.py:245) from the device replica of torch's
-        CPU generator (midastouch_amd/torch_rng.py) - the reference's indices bit for bit, nothing generated on the host.
-        `seed=None` returns to the host generator.  A seeded run replays the reference on the CPU, so `annealing` then
+        """torch.manual_seed(seed), kept on the device: every draw of the class surface - `init_filter`'s and `motionModel`'s
+        torch.normal calls (:129-130, :326-335), the uniforms `resampler("weighted_random")`'s torch.multinomial would consume (:245) -
+        then comes from the device replica of torch's CPU generator (midastouch_amd/torch_rng.py, torch_normal.py): the numbers of a
+        run of the reference under that seed, bit for bit, nothing generated on the host.  `seed=None` returns to the host generator.  A seeded run replays the reference on the CPU, so `annealing` then
         also takes torch.topk's CPU choice inside a tie (`topk_ties`)."""
         from .torch_rng import TorchCpuStream
         self.torch_stream = None if seed is None else TorchCpuStream(seed, self.device)

@@ -56,6 +56,41 @@ def test_init_filter_matches_reference_golden(dev, setup, golden):
     assert parts.weights.dtype == torch.float32 and float(parts.weights.sum()) == 1024
 
 
+def test_reference_goldens_with_every_draw_on_the_device(dev, setup, golden):
+    """G3 (motionModel) and G8 (init_filter) - outputs the REFERENCE wrote under torch.manual_seed - with `pf.seed_device_stream(seed)`
+    instead of the host generator: the torch.normal draws come from the device replica of torch's stream (mt19937 words + ATen's
+    float32 normal transform as tables, torch_normal.py) and give the reference's poses; and the same poses as the host-drawn run,
+    exactly."""
+    from midastouch_amd.particle_filter import Particles
+    cfg, cb, pf, tree = setup
+    g = golden("g3_motion")
+    try:
+        for tag in ("sim", "mul3"):
+            sig_r, sig_t, mul, seed = g[f"{tag}_params"]
+            pf.motion_noise = {"mu": 0, "sig_r": float(sig_r), "sig_t": float(sig_t)}
+            parts = Particles(torch.as_tensor(g[f"{tag}_poses"]).to(dev))
+            odom = torch.as_tensor(g[f"{tag}_odom"]).to(dev)
+            pf.seed_device_stream(None)
+            torch.manual_seed(int(seed))
+            host = pf.motionModel(parts, odom, multiplier=float(mul)).poses.cpu().numpy()
+            pf.seed_device_stream(int(seed))
+            torch.manual_seed(12345)  # (the host generator is not what is drawn from)
+            out = pf.motionModel(parts, odom, multiplier=float(mul))
+            np.testing.assert_allclose(out.poses.cpu().numpy(), g[f"{tag}_new_poses"], rtol=0, atol=2e-6)
+            assert np.array_equal(out.poses.cpu().numpy(), host)
+        g8 = golden("g8_init")
+        keep = pf.init_noise
+        pf.init_noise = [float(v) for v in g8["init_noise"]]
+        pf.seed_device_stream(int(g8["seed"]))
+        parts = pf.init_filter(torch.as_tensor(g8["gt"]).to(dev), 1024)
+        pf.init_noise = keep
+        np.testing.assert_allclose(parts.poses.cpu().numpy(), g8["poses"], rtol=0, atol=2e-6)
+    finally:
+        pf.seed_device_stream(None)
+        pf.topk_ties = "index"
+        pf.motion_noise = {"mu": 0, "sig_r": 0.5, "sig_t": 2e-4}
+
+
 def test_get_similarity_matches_reference_golden(dev, setup, golden):
     from midastouch_amd.tactile_tree import tactile_tree
     cfg, cb, pf, _ = setup
