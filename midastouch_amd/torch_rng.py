@@ -60,6 +60,7 @@ class TorchCpuStream:
         self.state = torch.zeros(626, dtype=torch.int32, device=self.device)
         self.pending_skip = 0
         self.pieces = int(pieces)
+        self.chain_after = 2  # occurrences of a (previous size, skip, size) pattern before its jump polynomials are computed (1: at once)
         self._hist = torch.zeros(_lib.MT19937_HIST_WORDS, dtype=torch.int32, device=self.device)
         self._hist_words = 0   # words the call that wrote _hist handed out (0: no history)
         self._polys = {}       # (previous words, skip, words) -> device table of the pieces' polynomials
@@ -154,10 +155,12 @@ class TorchCpuStream:
         tensor longer, or shares the stream object between engines, passes `out` (or calls rand64, which allocates)."""
         N = int(N)
         own = out is None
+        fresh = False
         if out is None:
             i = self._turn
             self._turn = (i + 1) % 3
             if self._bufs[i] is None or self._bufs[i].numel() != N:
+                fresh = True  # (see below: a new block may be memory the caller's stream is still using)
                 # (a buffer dropped here may still be being written on the generator's stream: the allocator learns of that stream
                 # at allocation, so the block is not handed out again before the write is done)
                 self._bufs[i] = torch.empty(N, dtype=torch.float64, device=self.device)
@@ -172,7 +175,9 @@ class TorchCpuStream:
             mark = torch.cuda.Event()
             mark.record(cur)
             prev, self._mark = getattr(self, "_mark", None), mark
-            if prev is None:
+            # (a buffer allocated in THIS call is a block the allocator may have taken back from the caller's stream a moment ago -
+            # kernels enqueued there since the previous mark may still read it: the full wait, once per buffer)
+            if prev is None or fresh:
                 self.side.wait_stream(cur)
             else:
                 self.side.wait_event(prev)
@@ -187,7 +192,19 @@ class TorchCpuStream:
     def _chain_polys(self, words: int):
         """The jump polynomials of a call of `words` words, or None (no history / too short: the sequential walk)."""
         if self.pieces > 0 and self._hist_words and words >= _lib.MT19937_HIST_WORDS:
-            return self._piece_polys(self._hist_words, self.pending_skip, words)
+            # the polynomials cost the host ~10 ms each: worth it for a pattern of sizes that REPEATS (a fixed-N engine: the same
+            # three calls every frame), not for a particle count that changes every frame (the annealing loop: 100 ms a frame of
+            # host arithmetic when every call asked for its own set) - a (previous size, skip, size) is served in pieces from its
+            # second occurrence on
+            key = (self._hist_words, self.pending_skip, words, self.pieces)
+            if key in self._polys:
+                return self._polys[key]
+            seen = self.__dict__.setdefault("_seen", {})
+            if len(seen) > 256:
+                seen.clear()
+            seen[key] = seen.get(key, 0) + 1
+            if seen[key] >= self.chain_after:
+                return self._piece_polys(self._hist_words, self.pending_skip, words)
         return None
 
     def _drawn(self, words: int, out):

@@ -89,6 +89,7 @@ def test_chunked_device_stream_equals_torch_rand(pieces):
     dev = torch.device("cuda", 0)
     torch.manual_seed(77)
     st = TorchCpuStream(77, dev, pieces=pieces)
+    st.chain_after = 1  # every call that can be served in pieces is (the default waits for a size pattern to repeat)
     chained = 0
     for n in (100_000, 100_000, 100_000, 50_001, 100_000, 10_280, 10_281, 12_000, 5_000, 100_000, 100_000, 311_000):
         had = st._hist_words
@@ -197,6 +198,7 @@ def test_device_normal_equals_torch_normal(pieces):
     dev = torch.device("cuda", 0)
     torch.manual_seed(31)
     st = TorchCpuStream(31, dev, pieces=pieces)
+    st.chain_after = 1
     for N in (16, 100, 4096, 33_333, 100_000, 100_000, 100_000, 7_000, 100_000):
         tn_ref = torch.normal(0.0, 2e-4, size=(N, 3))
         rot_ref = torch.normal(0.0, 0.5, size=(N, 3))

@@ -20,7 +20,7 @@ cfg = load_config([f"expt.params.num_particles={N}", f"expt.codebook_size={K}", 
 dev = torch.device("cuda", 0)
 seq = synthetic_sequence(cfg, dev, T=T, D=512)
 run_filter(cfg, seq, device=dev, max_frames=20)  # warm-up (library load, allocator)
-for cluster, draws, floor in ((True, "device", 1000), (True, "device", 100000), (False, "device", 1000), (True, "host", 1000)):
+for cluster, draws, floor in ((True, "device", 1000), (True, "device", 100000), (False, "device", 1000), (True, "host", 1000), (True, "seeded", 1000)):
     torch.cuda.synchronize()
     t0 = time.time()
     st = run_filter(cfg, seq, device=dev, cluster=cluster, draws=draws, floor=floor, max_frames=T if draws == "device" else 60)
