@@ -17,19 +17,7 @@
 
 namespace midas {
 
-constexpr int CL_MOM = 36;  // moments per cluster, see the enum
-enum : int {
-    M_SW = 0,      // sum w
-    M_CNT = 1,     // members
-    M_WMAX = 2,    // max w (float32 values)
-    M_WMIN = 3,    // min w
-    M_QQW = 4,     // 10: upper triangle of sum w q q^T, q = (x, y, z, w)
-    M_QQ1 = 14,    // 10: the same with w = 1
-    M_TW = 24,     // 3: sum w t
-    M_T1 = 27,     // 3: sum t
-    M_TTW = 30,    // 3: sum w t^2
-    M_TT1 = 33,    // 3: sum t^2
-};
+// (the moments' layout - CL_MOM, M_* - and the closed forms made of them: cluster_rot.hpp)
 
 // unit quaternion (x, y, z, w) of a rotation matrix, float64, branch on the largest diagonal term (Shepperd)
 MD void quat_of(const float* P, double* q) {
@@ -66,7 +54,8 @@ MD double cl_wmin(double v) {
     return v;
 }
 
-// part[(block * C + c) * CL_MOM + m]; label_value(c) = the label cluster slot c stands for.  In two steps: what a particle
+// part[(c * nbs + block) * CL_MOM + m] (nbs = the launch's blocks: a cluster's partials lie together, whoever sums them can ask
+// for them without knowing how many clusters there are); label_value(c) = the label cluster slot c stands for.  In two steps: what a particle
 // contributes (pose rows, label, float32-rounded weight) and the accumulation, so that the loop step can compute the weight in
 // the same launch (k_loop_weights_moments).
 struct MomIn {
@@ -89,6 +78,7 @@ MD MomIn moments_load(int64_t nc, const float* __restrict__ poses, const double*
 
 template <typename LV>
 MD void moments_accumulate(bool live, const MomIn& in, int C, LV label_value, double* __restrict__ part, double (*s_w)[CL_MOM]) {
+    const size_t nbs = gridDim.x;
     const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
     const float* P = in.P;
     const int64_t lab = in.lab;
@@ -130,7 +120,7 @@ MD void moments_accumulate(bool live, const MomIn& in, int C, LV label_value, do
             if (t == M_WMAX) { r = s_w[0][t]; for (int i = 1; i < 4; ++i) r = s_w[i][t] > r ? s_w[i][t] : r; }
             else if (t == M_WMIN) { r = s_w[0][t]; for (int i = 1; i < 4; ++i) r = s_w[i][t] < r ? s_w[i][t] : r; }
             else r = ((s_w[0][t] + s_w[1][t]) + s_w[2][t]) + s_w[3][t];
-            part[((size_t)blockIdx.x * C + c) * CL_MOM + t] = r;
+            part[((size_t)c * nbs + blockIdx.x) * CL_MOM + t] = r;
         }
     }
 }
@@ -209,7 +199,7 @@ __global__ __launch_bounds__(256) void k_loop_weights_moments(LoopWeightsArgs a,
 // one 64-thread workgroup per cluster: blocks summed in order, then the closed forms
 // rot_out (loop step): the normalised moment matrix goes there (10 doubles per cluster) and the rotation entries of the
 // centre are left to whoever solves it (cluster_rotation_write, beside the annealing); nullptr: solved here
-MD void cluster_finish_body(int nblocks, int C, int c, const double* __restrict__ part, float* __restrict__ centers,
+MD void cluster_finish_body(int nblocks, size_t nbs, int c, const double* __restrict__ part, float* __restrict__ centers,
                             float* __restrict__ stds, int64_t* __restrict__ counts, double* s_m, double* __restrict__ rot_out = nullptr) {
     const int t = threadIdx.x;
     // blocks in order (the sums' order is part of the arithmetic).  The partials of CB blocks are staged in LDS by all 64 threads
@@ -230,7 +220,7 @@ MD void cluster_finish_body(int nblocks, int C, int c, const double* __restrict_
             for (int j = 0; j < LB; ++j) {
                 const int i = i0 + NT * j, ic = i < nb * CL_MOM ? i : nb * CL_MOM - 1;
                 const int b = ic / CL_MOM, m = ic - b * CL_MOM;
-                x[j] = part[((size_t)(b0 + b) * C + c) * CL_MOM + m];
+                x[j] = part[((size_t)c * nbs + (size_t)(b0 + b)) * CL_MOM + m];
             }
 #pragma unroll
             for (int j = 0; j < LB; ++j)
@@ -282,56 +272,27 @@ MD void cluster_finish_body(int nblocks, int C, int c, const double* __restrict_
     }
     __syncthreads();
     if (t != 0) return;
-    if (counts) counts[c] = (int64_t)s_m[M_CNT];
-    float* out = centers + (size_t)c * 16;
-    float* sd = stds + (size_t)c * 3;
-    if (s_m[M_CNT] == 0.0) {  // empty cluster (the caller passed a label nobody carries): NaN like a 0/0 mean
-        for (int i = 0; i < 16; ++i) out[i] = NAN;
-        for (int i = 0; i < 3; ++i) sd[i] = NAN;
-        return;
-    }
-    // torch.isclose(max - min, 0): |d| <= atol (1e-8), in the float32 arithmetic of the reference
-    const float d = (float)s_m[M_WMAX] - (float)s_m[M_WMIN];
-    const bool flat = __builtin_fabsf(d) <= 1e-8f;
-    const int oq = flat ? M_QQ1 : M_QQW, ot = flat ? M_T1 : M_TW, ott = flat ? M_TT1 : M_TTW;
-    const double sw = flat ? s_m[M_CNT] : s_m[M_SW];
-    double A10[10];
-    for (int k = 0; k < 10; ++k) A10[k] = s_m[oq + k] / sw;
-    if (rot_out) {
-        for (int k = 0; k < 10; ++k) rot_out[(size_t)c * 10 + k] = A10[k];
-    } else {
-        cluster_rotation_write(A10, out);
-    }
-    float mean[3];
-    for (int i = 0; i < 3; ++i) mean[i] = (float)(s_m[ot + i] / sw);
-    out[3] = mean[0]; out[7] = mean[1]; out[11] = mean[2];
-    out[12] = 0.f; out[13] = 0.f; out[14] = 0.f; out[15] = 1.f;
-    // sum w (t - m)^2 / sum w with m the float32 centre, from the moments
-    for (int i = 0; i < 3; ++i) {
-        const double m = (double)mean[i];
-        double var = (s_m[ott + i] - 2.0 * m * s_m[ot + i] + m * m * sw) / sw;
-        var = var < 0.0 ? 0.0 : var;
-        sd[i] = (float)__builtin_sqrt(var);
-    }
+    cluster_close(s_m, centers + (size_t)c * 16, stds + (size_t)c * 3, counts ? counts + c : nullptr,
+                  rot_out ? rot_out + (size_t)c * 10 : nullptr);
 }
 
 __global__ __launch_bounds__(64) void k_cluster_finish(int nblocks, int C, const double* __restrict__ part,
                                                        float* __restrict__ centers, float* __restrict__ stds,
                                                        int64_t* __restrict__ counts) {
     __shared__ double s_m[CL_MOM];
-    cluster_finish_body(nblocks, C, blockIdx.x, part, centers, stds, counts, s_m);
+    cluster_finish_body(nblocks, (size_t)nblocks, blockIdx.x, part, centers, stds, counts, s_m);
 }
 
 // loop engine: cluster slot c = blockIdx.x of the LOOP_MAX_CLUSTERS launched; rows of label c - 1
 __global__ __launch_bounds__(256) void k_loop_cluster_finish(const int32_t* __restrict__ ctl_i, const double* __restrict__ part,
                                                             float* __restrict__ centers, float* __restrict__ stds,
-                                                            int64_t* __restrict__ counts, double* __restrict__ rot) {
+                                                            int64_t* __restrict__ counts, double* __restrict__ rot, int32_t nbs) {
     __shared__ double s_m[CL_MOM];
     const int64_t n = ctl_i[LOOP_I_N];
     int C = ctl_i[LOOP_I_NCL] + 1;
     C = C > LOOP_MAX_CLUSTERS ? LOOP_MAX_CLUSTERS : C;
     if ((int)blockIdx.x >= C) return;
-    cluster_finish_body((int)((n + 255) / 256), C, blockIdx.x, part, centers, stds, counts, s_m, rot);
+    cluster_finish_body((int)((n + 255) / 256), (size_t)nbs, blockIdx.x, part, centers, stds, counts, s_m, rot);
 }
 
 // rot: LOOP_MAX_CLUSTERS x 10 doubles - the moment matrices whose eigenproblem the annealing kernel's second workgroup solves
@@ -345,7 +306,7 @@ int launch_loop_cluster(midas_ctx* ctx, int64_t cap, const int32_t* ctl_i, const
         hipLaunchKernelGGL(k_loop_cluster_moments, dim3((unsigned)ceil_div(cap, 256)), dim3(256), 0, ctx->stream, ctl_i, poses, w64,
                            labels, part);
     hipLaunchKernelGGL(k_loop_cluster_finish, dim3(LOOP_MAX_CLUSTERS), dim3(256), 0, ctx->stream, ctl_i, (const double*)part, centers,
-                       stds, counts, rot);
+                       stds, counts, rot, (int32_t)ceil_div(cap, 256));
     MIDAS_HIP_CHECK(ctx, hipGetLastError());
     return MIDAS_OK;
 }

@@ -61,4 +61,54 @@ MD void cluster_rotation_write(const double* A10, float* out) {
     out[8] = (float)(2.0 * (qx * qz - qy * qw)); out[9] = (float)(2.0 * (qy * qz + qx * qw)); out[10] = (float)(1.0 - 2.0 * (qx * qx + qy * qy));
 }
 
+// ---- the moments of a cluster and what is made of them (cluster.hip's finishing kernels)
+constexpr int CL_MOM = 36;  // moments per cluster, see the enum
+enum : int {
+    M_SW = 0,      // sum w
+    M_CNT = 1,     // members
+    M_WMAX = 2,    // max w (float32 values)
+    M_WMIN = 3,    // min w
+    M_QQW = 4,     // 10: upper triangle of sum w q q^T, q = (x, y, z, w)
+    M_QQ1 = 14,    // 10: the same with w = 1
+    M_TW = 24,     // 3: sum w t
+    M_T1 = 27,     // 3: sum t
+    M_TTW = 30,    // 3: sum w t^2
+    M_TT1 = 33,    // 3: sum t^2
+};
+
+// One cluster from its CL_MOM summed moments s_m (one thread): member count, centre row `out` (16 floats), spreads `sd` (3 floats).
+// rot_out (10 doubles; loop step): the normalised moment matrix goes there and the rotation entries of the centre are left to
+// whoever solves it (cluster_rotation_write, beside the annealing); nullptr: solved here.
+MD void cluster_close(const double* s_m, float* out, float* sd, int64_t* count, double* rot_out) {
+    if (count) *count = (int64_t)s_m[M_CNT];
+    if (s_m[M_CNT] == 0.0) {  // empty cluster (the caller passed a label nobody carries): NaN like a 0/0 mean
+        for (int i = 0; i < 16; ++i) out[i] = NAN;
+        for (int i = 0; i < 3; ++i) sd[i] = NAN;
+        return;
+    }
+    // torch.isclose(max - min, 0): |d| <= atol (1e-8), in the float32 arithmetic of the reference
+    const float d = (float)s_m[M_WMAX] - (float)s_m[M_WMIN];
+    const bool flat = __builtin_fabsf(d) <= 1e-8f;
+    const int oq = flat ? M_QQ1 : M_QQW, ot = flat ? M_T1 : M_TW, ott = flat ? M_TT1 : M_TTW;
+    const double sw = flat ? s_m[M_CNT] : s_m[M_SW];
+    double A10[10];
+    for (int k = 0; k < 10; ++k) A10[k] = s_m[oq + k] / sw;
+    if (rot_out) {
+        for (int k = 0; k < 10; ++k) rot_out[k] = A10[k];
+    } else {
+        cluster_rotation_write(A10, out);
+    }
+    float mean[3];
+    for (int i = 0; i < 3; ++i) mean[i] = (float)(s_m[ot + i] / sw);
+    out[3] = mean[0]; out[7] = mean[1]; out[11] = mean[2];
+    out[12] = 0.f; out[13] = 0.f; out[14] = 0.f; out[15] = 1.f;
+    // sum w (t - m)^2 / sum w with m the float32 centre, from the moments
+    for (int i = 0; i < 3; ++i) {
+        const double m = (double)mean[i];
+        double var = (s_m[ott + i] - 2.0 * m * s_m[ot + i] + m * m * sw) / sw;
+        var = var < 0.0 ? 0.0 : var;
+        sd[i] = (float)__builtin_sqrt(var);
+    }
+}
+
 }  // namespace midas

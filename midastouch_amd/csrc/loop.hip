@@ -105,7 +105,9 @@ __global__ __launch_bounds__(256) void k_loop_xe(const int32_t* __restrict__ ctl
 #pragma unroll
         for (int j = 0; j < SCAN_CHUNK; ++j) {
             v[j] = exp_spec(v[j] - 1.0);
-            __builtin_amdgcn_sched_barrier(0);  // one exponential at a time (registers)
+            // four exponentials interleaved (tail_block.hpp's MIDAS_TAIL_EXP_ILP): each is a dependent chain of ~25 fma at ~20 cycles
+            // a step, the workgroup's four waves are alone on their SIMDs - one at a time was 16 x 500 cycles = 3.3 us of this launch
+            if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (base + SCAN_CHUNK <= n) {
@@ -560,15 +562,7 @@ MD void small_scan2(int a, int b, int& ea, int& eb, int& ta, int& tb, int* s_w) 
     eb = pb + ib - b;
 }
 
-template <bool DECIDE>
-__global__ __launch_bounds__(1024) void k_loop_anneal_small(int32_t* __restrict__ ctl_i, double* __restrict__ ctl_d,
-                                                            const float* __restrict__ centers_all, const float* __restrict__ stds_all,
-                                                            const int64_t* __restrict__ counts_all, float* __restrict__ centers_out,
-                                                            float* __restrict__ stds_out, int32_t floor_n,
-                                                            const double* __restrict__ w, int32_t* __restrict__ src,
-                                                            const double* __restrict__ rot) {
 #ifdef MIDAS_ANNEAL_CLOCKS
-    const long long ck0 = wall_clock64();
 #define ACK(i) do { if (threadIdx.x == 0) ctl_d[56 + (i)] += (double)(wall_clock64() - ck0); } while (0)
 #define ctl_d_dbg(d, k) do { (d)[56 + 6] += 1.0; (d)[56 + 8] += (double)(k); } while (0)
 #define ctl_d_pass(d) do { (d)[56 + 15] += 1.0; } while (0)
@@ -577,37 +571,39 @@ __global__ __launch_bounds__(1024) void k_loop_anneal_small(int32_t* __restrict_
 #define ACK(i) do { } while (0)
 #define ctl_d_dbg(d, k) do { } while (0)
 #endif
-    if (DECIDE && blockIdx.x == 1) { loop_rotations(ctl_i, counts_all, rot, centers_out); ACK(7); return; }
+
+// The sixteen weights a thread of the small-set selection owns, as order-preserving keys: particles t, 1024 + t, .., 15 x 1024 + t
+// (indices clamped to the live count).  A wave's load is 64 consecutive values; with sixteen CONSECUTIVE particles per thread
+// every lane was a cache line of its own - 64 tag look-ups per instruction, 16 k of them in the one compute unit this
+// workgroup has: ~5 us that showed as the wait at the first barrier (tools/anneal_clocks.py "minmax end").
+MD void small_keys(const double* __restrict__ w, int n, uint64_t* wkey) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int i = 1024 * j + t;
+        wkey[j] = weight_key(w[i < n ? i : n - 1]);
+    }
+}
+
+// The selection of a small set by all 1024 threads of one workgroup: radix select of the k-th key, compaction in index order, the
+// duplicates in topk's order.  s_w[36 .. 39] = {mode, k, n, 0} (the caller's decision, behind a barrier); wkey: small_keys().
+// s_key / s_idx: LOOP_SMALL_PAIRS entries of LDS each.
+MD void anneal_small_select(int* s_w, const uint64_t* wkey, int32_t* __restrict__ src, int32_t* __restrict__ ctl_i,
+                            double* __restrict__ ctl_d, long long ck0, uint64_t* s_key, int32_t* s_idx) {
     __shared__ uint32_t s_h[SEL_BINS];
-    __shared__ int s_w[40];
-    __shared__ uint64_t s_key[LOOP_SMALL_PAIRS];
-    __shared__ int32_t s_idx[LOOP_SMALL_PAIRS];
     __shared__ uint64_t s_small[64];
     __shared__ uint64_t s_T[1];
     const int t = threadIdx.x;
-    if (t == 0) {
-        int mode = ctl_i[LOOP_I_MODE], k = ctl_i[LOOP_I_K];  // !DECIDE: a plan made by the host (midas_anneal_select)
-        if (DECIDE) loop_decide(ctl_i, ctl_d, centers_all, stds_all, counts_all, centers_out, stds_out, floor_n, mode, k);
-        const int n0 = ctl_i[LOOP_I_N];
-        if (n0 > LOOP_SMALL_MAX) { ctl_i[LOOP_I_ERR] |= 4; mode = 0; }  // the caller's bound was wrong: no annealing, flagged
-        s_w[36] = mode; s_w[37] = k; s_w[38] = n0; s_w[39] = 0;
-    }
-    __syncthreads();
-    ACK(0);
     const int mode = s_w[36], k = s_w[37], n = s_w[38];
     if (!mode) {
         if (n > LOOP_SMALL_MAX && t == 0) { ctl_i[LOOP_I_MODE] = 0; ctl_i[LOOP_I_K] = 0; ctl_i[LOOP_I_NSET] = n; }
         return;  // identity index list: written by k_loop_weights
     }
-    // thread t owns the sixteen consecutive particles [16 t, 16 t + 16): index order = thread order, one block scan compacts
+    // thread t owns the particles 1024 j + t: index order = (row j, wave, lane)
     uint64_t key[16];
-    const int base = 16 * t;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int i = base + j;
-        key[j] = select_key(w, i < n ? i : n - 1, mode);
-    }
-    const int mine_n = n - base < 0 ? 0 : n - base > 16 ? 16 : n - base;  // how many of them exist
+    for (int j = 0; j < 16; ++j) key[j] = mode == 2 ? ~wkey[j] : wkey[j];  // (select_key)
+    const int mine_n = n - t <= 0 ? 0 : (n - t + 1023) >> 10;  // how many of them exist (rows 0 .. mine_n - 1; n <= 16 384)
     ACK(1);
     // ---- radix select: the k-th smallest key T and how many of its equals to take (r)
     // The digits start at the highest bit in which the keys DIFFER (weights of one frame share sign and exponent, often the
@@ -737,30 +733,61 @@ __global__ __launch_bounds__(1024) void k_loop_anneal_small(int32_t* __restrict_
     const uint64_t T = prefix;
     const int r = krem;
     ACK(2);
-    // ---- compaction in index order
-    unsigned lbits = 0, ebits = 0;
+    // ---- compaction in index order: per (row, wave) the counts of keys below / equal to T from ballots, one wave scans the 256
+    // (row, wave) pairs in index order, a lane's place inside its wave's row is the ballot's bits below it
+    {
+        const int lane = t & 63, wv = t >> 6;
+        const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+        int pl[16], pe[16];
+        unsigned lbits = 0, ebits = 0;
+        int2* s_ce = reinterpret_cast<int2*>(s_h);  // 256 (row, wave) counts, then their exclusive prefixes (the histogram is done with)
+        __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        lbits |= (j < mine_n && key[j] < T) ? (1u << j) : 0u;
-        ebits |= (j < mine_n && key[j] == T) ? (1u << j) : 0u;
-    }
-    int lb, eb, tl, te;
-    small_scan2(__popc(lbits), __popc(ebits), lb, eb, tl, te, s_w);
+        for (int j = 0; j < 16; ++j) {
+            const bool isl = j < mine_n && key[j] < T, ise = j < mine_n && key[j] == T;
+            const uint64_t bl = __ballot(isl), be = __ballot(ise);
+            pl[j] = __popcll(bl & below);
+            pe[j] = __popcll(be & below);
+            lbits |= isl ? (1u << j) : 0u;
+            ebits |= ise ? (1u << j) : 0u;
+            if (lane == 0) s_ce[j * 16 + wv] = make_int2(__popcll(bl), __popcll(be));
+        }
+        __syncthreads();
+        if (wv == 0) {
+            const int2 c0 = s_ce[4 * lane], c1 = s_ce[4 * lane + 1], c2 = s_ce[4 * lane + 2], c3 = s_ce[4 * lane + 3];
+            int sl = c0.x + c1.x + c2.x + c3.x, se = c0.y + c1.y + c2.y + c3.y;
+            int il = sl, ie = se;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        if (j < mine_n) {
-            const int i = base + j;
-            const bool isl = (lbits >> j) & 1u, ise = (ebits >> j) & 1u;
-            const bool selected = isl || (ise && eb < r);
-            const int sel_before = lb + (eb < r ? eb : r);
-            if (mode == 1) {
-                if (!selected) src[i - sel_before] = i;
-            } else if (selected) {
-                s_key[sel_before] = key[j];
-                s_idx[sel_before] = i;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int a = __shfl_up(il, o), b = __shfl_up(ie, o);
+                if (lane >= o) { il += a; ie += b; }
             }
-            lb += isl ? 1 : 0;
-            eb += ise ? 1 : 0;
+            int el = il - sl, ee = ie - se;
+            s_ce[4 * lane] = make_int2(el, ee);
+            el += c0.x; ee += c0.y;
+            s_ce[4 * lane + 1] = make_int2(el, ee);
+            el += c1.x; ee += c1.y;
+            s_ce[4 * lane + 2] = make_int2(el, ee);
+            el += c2.x; ee += c2.y;
+            s_ce[4 * lane + 3] = make_int2(el, ee);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j < mine_n) {
+                const int i = 1024 * j + t;
+                const int2 b = s_ce[j * 16 + wv];
+                const int lb = b.x + pl[j], eb = b.y + pe[j];
+                const bool isl = (lbits >> j) & 1u, ise = (ebits >> j) & 1u;
+                const bool selected = isl || (ise && eb < r);
+                const int sel_before = lb + (eb < r ? eb : r);
+                if (mode == 1) {
+                    if (!selected) src[i - sel_before] = i;
+                } else if (selected) {
+                    s_key[sel_before] = key[j];
+                    s_idx[sel_before] = i;
+                }
+            }
         }
     }
     ACK(3);
@@ -806,6 +833,38 @@ __global__ __launch_bounds__(1024) void k_loop_anneal_small(int32_t* __restrict_
     for (int q = t; q < k; q += 1024) src[n + q] = s_idx[q];
     ACK(5);
     if (threadIdx.x == 0) { ctl_d_dbg(ctl_d, k); }
+}
+
+
+template <bool DECIDE>
+__global__ __launch_bounds__(1024) void k_loop_anneal_small(int32_t* __restrict__ ctl_i, double* __restrict__ ctl_d,
+                                                            const float* __restrict__ centers_all, const float* __restrict__ stds_all,
+                                                            const int64_t* __restrict__ counts_all, float* __restrict__ centers_out,
+                                                            float* __restrict__ stds_out, int32_t floor_n,
+                                                            const double* __restrict__ w, int32_t* __restrict__ src,
+                                                            const double* __restrict__ rot) {
+#ifdef MIDAS_ANNEAL_CLOCKS
+    const long long ck0 = wall_clock64();
+#else
+    const long long ck0 = 0;
+#endif
+    if (DECIDE && blockIdx.x == 1) { loop_rotations(ctl_i, counts_all, rot, centers_out); ACK(7); return; }
+    __shared__ int s_w[40];
+    const int t = threadIdx.x;
+    if (t == 0) {
+        int mode = ctl_i[LOOP_I_MODE], k = ctl_i[LOOP_I_K];  // !DECIDE: a plan made by the host (midas_anneal_select)
+        if (DECIDE) loop_decide(ctl_i, ctl_d, centers_all, stds_all, counts_all, centers_out, stds_out, floor_n, mode, k);
+        const int n0 = ctl_i[LOOP_I_N];
+        if (n0 > LOOP_SMALL_MAX) { ctl_i[LOOP_I_ERR] |= 4; mode = 0; }  // the caller's bound was wrong: no annealing, flagged
+        s_w[36] = mode; s_w[37] = k; s_w[38] = n0; s_w[39] = 0;
+    }
+    __syncthreads();
+    ACK(0);
+    __shared__ uint64_t s_key[LOOP_SMALL_PAIRS];
+    __shared__ int32_t s_idx[LOOP_SMALL_PAIRS];
+    uint64_t wkey[16];
+    small_keys(w, s_w[38], wkey);
+    anneal_small_select(s_w, wkey, src, ctl_i, ctl_d, ck0, s_key, s_idx);
 }
 
 // ---- RESAMPLE -------------------------------------------------------------------------------------------------------

@@ -21,21 +21,22 @@ extern __device__ long long g_ta_clk[16];
 // l[j] = GP_g + (TP_c + local_j) (l may be v itself); returns the block total W (identical in every thread).
 // Needs 16 doubles of LDS (s_gtot) and contains one __syncthreads().
 MD double block_scan(const double* v, double* l, double* s_gtot) {
+    const int tid = threadIdx.x;
     __builtin_amdgcn_sched_barrier(0);  // phase walls: work hoisted across them only adds live registers
     double run = 0.0;
 #pragma unroll
     for (int j = 0; j < SCAN_CHUNK; ++j) { run = run + v[j]; l[j] = run; }
     const double T = run;
-    const int c = threadIdx.x & 15;
+    const int c = tid & 15;
     double TP = 0.0;
     // chunk totals of the own 16-lane row, lane by lane (DPP row broadcasts; `__shfl` was an LDS-crossbar trip each), added in order
 #define MIDAS_TP_STEP(J) { const double t_ = row_bcast<J>(T); if (J < c) TP = TP + t_; }
     MIDAS_TP_STEP(0) MIDAS_TP_STEP(1) MIDAS_TP_STEP(2) MIDAS_TP_STEP(3) MIDAS_TP_STEP(4) MIDAS_TP_STEP(5) MIDAS_TP_STEP(6) MIDAS_TP_STEP(7)
     MIDAS_TP_STEP(8) MIDAS_TP_STEP(9) MIDAS_TP_STEP(10) MIDAS_TP_STEP(11) MIDAS_TP_STEP(12) MIDAS_TP_STEP(13) MIDAS_TP_STEP(14) MIDAS_TP_STEP(15)
 #undef MIDAS_TP_STEP
-    if (c == 15) s_gtot[threadIdx.x >> 4] = TP + T;
+    if (c == 15) s_gtot[tid >> 4] = TP + T;
     __syncthreads();
-    const int g = threadIdx.x >> 4;
+    const int g = tid >> 4;
     double GP = 0.0, W = 0.0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {

@@ -17,4 +17,5 @@ cfg = load_config([f"expt.params.num_particles={N}", "expt.codebook_size=50000",
 dev = torch.device("cuda", 0)
 seq = synthetic_sequence(cfg, dev, T=T, D=512)
 st = run_filter(cfg, seq, device=dev, floor=floor)
-print("frames", len(st["time"]), "steady ms/frame", 1e3 * sum(st["time"][2:]) / len(st["time"][2:]), "N", st["num_particles"][::25])
+steady = sorted(st["time"][2:])
+print("frames", len(st["time"]), "steady ms/frame", 1e3 * sum(steady) / len(steady), "median", 1e3 * steady[len(steady) // 2], "N", st["num_particles"][::25])
