@@ -54,3 +54,12 @@ print("  last 32 waves: life", np.round(life[-32:], 1).tolist())
 print("  last 32 waves: prop", dd[-32:, 8].astype(int).tolist())
 print("last frame, wave lifetime us: p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(life, [10, 50, 90, 99, 100])))
 print("[nn tree, prune tree, nn coop lanes, prune coop lanes, nn coop waves, prune coop waves, nn records scanned, -]")
+# the last frame's timeline: when each wave started (100 MHz wall clock, relative to the first) and ended
+tel = eng.telemetry[16:].view(-1, 16).cpu().numpy()[:nw].astype(np.int64)
+start = (tel[:, 1] - tel[:, 1].min()) / 100.0
+end = start + life
+print("last frame, wave START us after the first: p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(start, [10, 50, 90, 99, 100])))
+print("last frame, wave END   us after the first start: p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(end, [10, 50, 90, 99, 100])))
+for lo in range(0, nw, 196):
+    hi = min(nw, lo + 196)
+    print(f"  waves {lo:5d}..{hi:5d}: start mean {start[lo:hi].mean():5.1f} end mean {end[lo:hi].mean():5.1f} end max {end[lo:hi].max():5.1f}")
