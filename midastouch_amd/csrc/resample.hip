@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void k_tail_a2(int64_t N, const double* __rest
 
 // k_tail_a2 in the chunk-per-thread view (tail_block.hpp): every thread reads and writes its own 16-slot chunk from one
 // address, nothing goes through LDS.  Same outputs, 5.5 us instead of 8.0 at N = 100k (two barriers and two LDS round
-// trips fewer on a latency-bound kernel).  Single trajectory, N >= 16; MIDAS_TAIL_DIRECT=0 selects k_tail_a2.
+// trips fewer on a latency-bound kernel).  Single trajectory, N >= 16 (smaller sets: k_tail_a2).
 // Extra workgroups of the tail (blockIdx.x >= nb): the prediction list of the NEXT frame's sparse scoring.  Every row whose
 // stamp is this frame's epoch was somebody's nearest entry in this frame (claimed by its first particle, or confirmed from
 // the previous list): it goes on the list - order is immaterial, one counter bump per wave - and is re-stamped epoch + 1,
@@ -1875,7 +1875,7 @@ int launch_shard_tail_a(midas_ctx* ctx, int64_t N, const double* scores, const i
                         int32_t softmax, const TailTables& tb, double* r1, int32_t* status, const double* part_rmse,
                         const ScorePredict* predict) {
     const int nb = (int)ceil_div(N, SCAN_BLOCK);
-    static const bool direct = !(getenv("MIDAS_TAIL_DIRECT") && atoi(getenv("MIDAS_TAIL_DIRECT")) == 0);
+    constexpr bool direct = true;  // (k_tail_a2, the LDS-staged form, serves N < 16 and the batch without table strides only)
     const bool with_list = predict && predict->stamps && predict->list;
     if ((part_rmse || with_list) && !(direct && N >= SCAN_CHUNK))
         return midas_set_error(ctx, MIDAS_ERR_INVALID, "shard tail", "rmse sums / prediction list in the tail need the direct tail kernel (N >= 16)");
@@ -1934,7 +1934,7 @@ int launch_tail_a2(midas_ctx* ctx, int64_t N, const double* scores, const int32_
                    int32_t softmax, const TailTables& tb, int32_t* status, int batch, int64_t score_stride, bool padded_tables,
                    const double* part_rmse, double* rmse_out, int64_t tstride, const ScorePredict* predict) {
     const int nb = (int)ceil_div(N, SCAN_BLOCK);
-    static const bool direct = !(getenv("MIDAS_TAIL_DIRECT") && atoi(getenv("MIDAS_TAIL_DIRECT")) == 0);
+    constexpr bool direct = true;  // (k_tail_a2, the LDS-staged form, serves N < 16 and the batch without table strides only)
     const bool with_list = predict && predict->stamps && predict->list && batch <= 1;
     if (with_list && !(direct && N >= SCAN_CHUNK)) return midas_set_error(ctx, MIDAS_ERR_INVALID, "score_list", "the prediction list needs the direct tail kernel (N >= 16)");
     if (direct && batch <= 1 && tail_grouped_ok(ctx, N, nn_idx, valid, tb, with_list ? (int)ceil_div(predict->K, 256 * PREDICT_PER_THREAD) : 0))
