@@ -55,6 +55,13 @@ MD uint64_t weight_key(double w) {
 // ---- FRONT, second half ---------------------------------------------------------------------------------------------
 // x = scores[nn], e = exp(x - 1) (or x when the softmax is off); per 4096-slot block the sum of e in the spec order,
 // the extrema of x, the particles the prune kept, NaN among the scores.
+// (round 6) The block's slots are read and written slot-per-lane - a wave's load is 64 consecutive indices, its stores 64
+// consecutive values - and the numerators reach the chunk-per-thread layout the summation spec is written in through LDS
+// (index i at i + i / 16: the chunk reads are spread over the banks).  With sixteen CONSECUTIVE slots per thread every lane of
+// every load and store was a cache line of its own: 64 look-ups an instruction, ~80 instructions a wave - the launch's bound.
+MD int lds_chunk_pos(int i) { return i + (i >> 4); }
+constexpr int LDS_CHUNK_DOUBLES = SCAN_BLOCK + SCAN_BLOCK / 16;
+
 __global__ __launch_bounds__(256) void k_loop_xe(const int32_t* __restrict__ ctl_i, const double* __restrict__ scores,
                                                  const int32_t* __restrict__ nn_idx, const uint8_t* __restrict__ valid,
                                                  int32_t softmax, int32_t unit, double* __restrict__ x_out, double* __restrict__ e_out,
@@ -63,64 +70,56 @@ __global__ __launch_bounds__(256) void k_loop_xe(const int32_t* __restrict__ ctl
     __shared__ double s_gtot[16];
     __shared__ double s_mx[4], s_mn[4];
     __shared__ int s_k[4], s_f[4];
+    __shared__ double s_t[LDS_CHUNK_DOUBLES];
     const int64_t n = ctl_i[LOOP_I_N];
     const int blk = blockIdx.x, t = threadIdx.x;
     const int64_t bbase = (int64_t)blk * SCAN_BLOCK;
     if (bbase >= n) return;
-    const int64_t base = bbase + (int64_t)t * SCAN_CHUNK;
     // batched, unconditional loads on clamped indices (a branch around a load makes hipcc wait for each one in turn)
     double v[SCAN_CHUNK];
     int32_t nn[SCAN_CHUNK];
     unsigned okbits = 0;
 #pragma unroll
-    for (int j = 0; j < SCAN_CHUNK; ++j) {
-        const int64_t ic = base + j < n ? base + j : n - 1;
-        nn[j] = nn_idx[ic];
-        okbits |= valid[ic] != 0 ? (1u << j) : 0u;
+    for (int k = 0; k < SCAN_CHUNK; ++k) {
+        const int64_t i = bbase + (int64_t)k * 256 + t, ic = i < n ? i : n - 1;
+        nn[k] = nn_idx[ic];
+        okbits |= valid[ic] != 0 ? (1u << k) : 0u;
     }
 #pragma unroll
-    for (int j = 0; j < SCAN_CHUNK; ++j) v[j] = unit ? 1.0 : scores[nn[j]];
+    for (int k = 0; k < SCAN_CHUNK; ++k) v[k] = unit ? 1.0 : scores[nn[k]];
     double mx = -INFINITY, mn = INFINITY;
     int kept = 0;
     bool nan = false;
 #pragma unroll
-    for (int j = 0; j < SCAN_CHUNK; ++j) {
-        const bool in = base + j < n;
-        const double xv = v[j];
+    for (int k = 0; k < SCAN_CHUNK; ++k) {
+        const int64_t i = bbase + (int64_t)k * 256 + t;
+        const bool in = i < n;
+        const double xv = v[k];
         mx = in && xv > mx ? xv : mx;
         mn = in && xv < mn ? xv : mn;
-        kept += in && ((okbits >> j) & 1u) ? 1 : 0;
+        kept += in && ((okbits >> k) & 1u) ? 1 : 0;
         nan |= in && xv != xv;
-    }
-    if (base + SCAN_CHUNK <= n) {
-        double2* o2 = reinterpret_cast<double2*>(x_out + base);
-#pragma unroll
-        for (int j = 0; j < SCAN_CHUNK / 2; ++j) o2[j] = make_double2(v[2 * j], v[2 * j + 1]);
-    } else {
-#pragma unroll
-        for (int j = 0; j < SCAN_CHUNK; ++j)
-            if (base + j < n) x_out[base + j] = v[j];
+        if (in) x_out[i] = xv;
     }
     if (softmax) {
 #pragma unroll
-        for (int j = 0; j < SCAN_CHUNK; ++j) {
-            v[j] = exp_spec(v[j] - 1.0);
-            // four exponentials interleaved (tail_block.hpp's MIDAS_TAIL_EXP_ILP): each is a dependent chain of ~25 fma at ~20 cycles
-            // a step, the workgroup's four waves are alone on their SIMDs - one at a time was 16 x 500 cycles = 3.3 us of this launch
-            if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+        for (int k = 0; k < SCAN_CHUNK; ++k) {
+            v[k] = exp_spec(v[k] - 1.0);
+            // four exponentials interleaved: each is a dependent chain of ~25 fma at ~20 cycles a step, and the workgroup's four
+            // waves are alone on their SIMDs
+            if (k % 4 == 3) __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (base + SCAN_CHUNK <= n) {
-        double2* o2 = reinterpret_cast<double2*>(e_out + base);
 #pragma unroll
-        for (int j = 0; j < SCAN_CHUNK / 2; ++j) o2[j] = make_double2(v[2 * j], v[2 * j + 1]);
-    } else {
-#pragma unroll
-        for (int j = 0; j < SCAN_CHUNK; ++j)
-            if (base + j < n) e_out[base + j] = v[j];
+    for (int k = 0; k < SCAN_CHUNK; ++k) {
+        const int il = k * 256 + t;
+        const bool in = bbase + il < n;
+        if (in) e_out[bbase + il] = v[k];
+        s_t[lds_chunk_pos(il)] = in ? v[k] : 0.0;
     }
+    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < SCAN_CHUNK; ++j) v[j] = base + j < n ? v[j] : 0.0;
+    for (int j = 0; j < SCAN_CHUNK; ++j) v[j] = s_t[17 * t + j];  // the own chunk: slots 16 t .. 16 t + 15 of the block
     const double W = block_total(v, s_gtot);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -874,28 +873,40 @@ __global__ __launch_bounds__(256) void k_loop_scan(const int32_t* __restrict__ c
                                                    const int32_t* __restrict__ src, double* __restrict__ lp,
                                                    double* __restrict__ btot, int32_t* __restrict__ bnan) {
     __shared__ double s_gtot[16];
+    __shared__ double s_t[LDS_CHUNK_DOUBLES];  // (k_loop_xe: slot-per-lane in memory, chunk-per-thread for the sums)
     const int64_t n2 = ctl_i[LOOP_I_NSET];
     const int raw = ctl_i[LOOP_I_RAW];
     const int blk = blockIdx.x, t = threadIdx.x;
-    const int64_t base = (int64_t)blk * SCAN_BLOCK + (int64_t)t * SCAN_CHUNK;
-    if ((int64_t)blk * SCAN_BLOCK >= n2) return;
+    const int64_t bbase = (int64_t)blk * SCAN_BLOCK;
+    if (bbase >= n2) return;
     double v[SCAN_CHUNK];
+    int32_t sv[SCAN_CHUNK];
     bool nan = false;
 #pragma unroll
-    for (int j = 0; j < SCAN_CHUNK; ++j) {
-        const int64_t i = base + j;
-        const bool in = i < n2;
-        const int32_t s = src[in ? i : n2 - 1];
-        const double num = raw ? x[s] : e[s];
-        const double m = num * (valid[s] ? 1.0 : 0.0);
-        v[j] = in ? m : 0.0;
-        nan |= in && m != m;
+    for (int k = 0; k < SCAN_CHUNK; ++k) {
+        const int64_t i = bbase + (int64_t)k * 256 + t;
+        sv[k] = src[i < n2 ? i : n2 - 1];
     }
+#pragma unroll
+    for (int k = 0; k < SCAN_CHUNK; ++k) {
+        const bool in = bbase + (int64_t)k * 256 + t < n2;
+        const double num = raw ? x[sv[k]] : e[sv[k]];
+        const double m = num * (valid[sv[k]] ? 1.0 : 0.0);
+        nan |= in && m != m;
+        s_t[lds_chunk_pos(k * 256 + t)] = in ? m : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SCAN_CHUNK; ++j) v[j] = s_t[17 * t + j];
     const double W = block_scan(v, v, s_gtot);
 #pragma unroll
-    for (int j = 0; j < SCAN_CHUNK; ++j)
-        if (base + j < n2) lp[base + j] = v[j];
+    for (int j = 0; j < SCAN_CHUNK; ++j) s_t[17 * t + j] = v[j];
     const int f = __syncthreads_or(nan ? 1 : 0);
+#pragma unroll
+    for (int k = 0; k < SCAN_CHUNK; ++k) {
+        const int64_t i = bbase + (int64_t)k * 256 + t;
+        if (i < n2) lp[i] = s_t[lds_chunk_pos(k * 256 + t)];
+    }
     if (t == 0) { btot[blk] = W; bnan[blk] = f; }
 }
 
