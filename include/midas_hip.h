@@ -188,6 +188,26 @@ int midas_mt19937_normal32(midas_ctx* ctx, uint32_t* state_dev, int64_t skip_wor
 #define MIDAS_MT19937_HIST_WORDS 20560
 int midas_mt19937_rand64_chunked(midas_ctx* ctx, uint32_t* state_dev, int64_t skip_words, int64_t N, double* out_dev,
                                  uint32_t* hist_dev, const uint32_t* polys_dev, int32_t pieces);
+/* Several consecutive draws of the stream by ONE walk of the generator - a seeded frame of the reference takes torch.normal (N, 3)
+ * twice (add_noise_to_odom, modules/particle_filter.py:326-335) and N float64 uniforms (the resampler, :245): `segs` (host array of
+ * nseg <= 8 entries, in the stream's order) names each draw - MIDAS_MT_SEGMENT_RAND64: count values as midas_mt19937_rand64 into
+ * out_dev (double); MIDAS_MT_SEGMENT_NORMAL32: count (>= 16) values as midas_mt19937_normal32 with mean / std into out_dev (float;
+ * the three tables are then required).  The results are those of the separate calls, number for number.  hist_dev / polys_dev /
+ * pieces as midas_mt19937_rand64_chunked, J_c counting the words of ALL segments (2 per float64, count (+ 16 when count is not a
+ * multiple of 16) per normal draw); in pieces the sum must be >= MIDAS_MT19937_HIST_WORDS.  NULL / 0: the sequential walk, which
+ * leaves the history (when hist_dev is given and the sum is long enough) for a following call in pieces. */
+#define MIDAS_MT_SEGMENT_RAND64 0
+#define MIDAS_MT_SEGMENT_NORMAL32 1
+typedef struct midas_mt_segment {
+    int32_t kind;
+    int32_t pad_;
+    int64_t count;
+    float mean, std;
+    void* out_dev;
+} midas_mt_segment;
+int midas_mt19937_draws(midas_ctx* ctx, uint32_t* state_dev, int64_t skip_words, int32_t nseg, const midas_mt_segment* segs,
+                        const float* radius_dev, const float* cos_dev, const float* sin_dev, uint32_t* hist_dev,
+                        const uint32_t* polys_dev, int32_t pieces);
 
 /* ---- resample  (K6, K7, K8) ------------------------------------------------------------------ */
 /* cdf = blocked_prefix(w) / total, cdf[N-1] = 1 (float64, fixed summation order - DESIGN.md).

@@ -155,6 +155,16 @@ class TailResampleArgs(C.Structure):
     ]
 
 
+class MtSegment(C.Structure):
+    """midas_mt_segment (include/midas_hip.h): one draw of a midas_mt19937_draws call."""
+
+    _fields_ = [("kind", C.c_int32), ("pad_", C.c_int32), ("count", C.c_int64), ("mean", C.c_float), ("std", C.c_float),
+                ("out_dev", C.c_void_p)]
+
+
+MT_SEGMENT_RAND64, MT_SEGMENT_NORMAL32 = 0, 1
+
+
 class LoopArgs(C.Structure):
     """midas_loop_args (include/midas_hip.h)."""
 
@@ -220,6 +230,7 @@ SIGNATURES = {
     "midas_mt19937_rand64": (C.c_int, [_P, _P, _I64, _I64, _P]),
     "midas_mt19937_rand64_chunked": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _I32]),
     "midas_mt19937_normal32": (C.c_int, [_P, _P, _I64, _I64, _F, _F, _P, _P, _P, _P, _P, _P, _I32]),
+    "midas_mt19937_draws": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I32]),
     "midas_resample_search": (C.c_int, [_P, _I64, _P, _I64, _I32, _P, _F, _U64, _U64, _P]),
     "midas_gather_rows": (C.c_int, [_P, _I64, _P, _P, _P, _I32]),
     "midas_rmse": (C.c_int, [_P, _I64, _P, _P, _P]),

@@ -426,6 +426,24 @@ MIDAS_EXPORT int midas_mt19937_rand64_chunked(midas_ctx* ctx, uint32_t* state_de
     return launch_mt_rand64_chunked(ctx, state_dev, N, out_dev, hist_dev, polys_dev, pieces);
 }
 
+MIDAS_EXPORT int midas_mt19937_draws(midas_ctx* ctx, uint32_t* state_dev, int64_t skip_words, int32_t nseg, const midas_mt_segment* segs,
+                                     const float* radius_dev, const float* cos_dev, const float* sin_dev, uint32_t* hist_dev,
+                                     const uint32_t* polys_dev, int32_t pieces) {
+    MIDAS_ENTER(ctx);
+    MIDAS_REQUIRE(ctx, state_dev != nullptr && skip_words >= 0 && nseg >= 1 && nseg <= 8 && segs != nullptr);
+    int64_t total = 0;
+    for (int i = 0; i < nseg; ++i) {
+        const midas_mt_segment& g = segs[i];
+        MIDAS_REQUIRE(ctx, (g.kind == MIDAS_MT_SEGMENT_RAND64 && g.count >= 0 && (g.count == 0 || g.out_dev)) ||
+                               (g.kind == MIDAS_MT_SEGMENT_NORMAL32 && g.count >= 16 && g.out_dev && radius_dev && cos_dev && sin_dev));
+        total += g.kind == MIDAS_MT_SEGMENT_RAND64 ? 2 * g.count : g.count + ((g.count & 15) ? 16 : 0);
+    }
+    const bool chunked = polys_dev && pieces > 0;
+    MIDAS_REQUIRE(ctx, !chunked || (hist_dev != nullptr && pieces <= 1024 && total >= MIDAS_MT19937_HIST_WORDS));
+    return launch_mt_draws(ctx, state_dev, skip_words, nseg, segs, radius_dev, cos_dev, sin_dev, hist_dev, chunked ? polys_dev : nullptr,
+                           chunked ? pieces : 0);
+}
+
 MIDAS_EXPORT int midas_resample_search(midas_ctx* ctx, int64_t N, const double* cdf_dev, int64_t M, int32_t mode,
                                        const double* u_dev, float u32, uint64_t seed, uint64_t step, int32_t* idx_dev) {
     MIDAS_ENTER(ctx);

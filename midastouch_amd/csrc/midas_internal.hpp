@@ -481,6 +481,8 @@ int launch_dbscan(midas_ctx* ctx, int64_t cap, const int32_t* n_dev, const float
 int launch_mt_seed(midas_ctx* ctx, uint64_t seed, uint32_t* state);
 int launch_mt_rand64(midas_ctx* ctx, uint32_t* state, int64_t skip_words, int64_t N, double* out, uint32_t* hist);
 int launch_mt_rand64_chunked(midas_ctx* ctx, uint32_t* state, int64_t N, double* out, uint32_t* hist, const uint32_t* polys, int32_t G);
+int launch_mt_draws(midas_ctx* ctx, uint32_t* state, int64_t skip_words, int32_t nseg, const midas_mt_segment* segs, const float* R,
+                    const float* C, const float* S, uint32_t* hist, const uint32_t* polys, int32_t G);
 int launch_mt_normal32(midas_ctx* ctx, uint32_t* state, int64_t skip_words, int64_t numel, float mean, float std, const float* R, const float* C,
                        const float* S, float* out, uint32_t* hist, const uint32_t* polys, int32_t G);
 

@@ -128,10 +128,10 @@ constexpr int MT_DEG = 19937;
 constexpr int MT_HIST = MT_DEG + MT_N - 1;  // x[k + i], k < 624, i < 19937
 static_assert(MT_HIST == MIDAS_MT19937_HIST_WORDS, "include/midas_hip.h");
 __global__ __launch_bounds__(256) void k_mt_emit(const uint32_t* __restrict__ raw, const int32_t* __restrict__ meta, long long N,
-                                                 double* __restrict__ out, uint32_t* __restrict__ hist) {
+                                                 double* __restrict__ out, uint32_t* __restrict__ hist, long long off = 0) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
-    const uint32_t* w = raw + (meta ? meta[0] : 0) + 2 * i;
+    const uint32_t* w = raw + (meta ? meta[0] : 0) + off + 2 * i;  // off: the segment's first word (midas_mt19937_draws)
     const uint32_t w0 = w[0], w1 = w[1];
     const unsigned long long r = (((unsigned long long)mt_temper(w0) << 32) | mt_temper(w1)) & ((1ull << 53) - 1ull);
     out[i] = (double)r * 1.1102230246251565e-16;
@@ -277,9 +277,9 @@ int launch_mt_seed(midas_ctx* ctx, uint64_t seed, uint32_t* state) {
 constexpr uint32_t MT_U24 = (1u << 24) - 1u;
 __global__ __launch_bounds__(256) void k_mt_normal(const uint32_t* __restrict__ raw, const int32_t* __restrict__ meta, long long numel, long long nwords,
                                                    const float* __restrict__ R, const float* __restrict__ C, const float* __restrict__ S,
-                                                   float mean, float std, float* __restrict__ out, uint32_t* __restrict__ hist) {
+                                                   float mean, float std, float* __restrict__ out, uint32_t* __restrict__ hist, long long off = 0) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const uint32_t* w = raw + (meta ? meta[0] : 0);
+    const uint32_t* w = raw + (meta ? meta[0] : 0) + off;
     if (hist && i < MT_HIST && i < nwords) hist[i] = w[i];
     if (i >= numel) return;
     const bool tail = (numel & 15) && i >= numel - 16;        // redrawn from the sixteen words behind the first numel
@@ -364,6 +364,48 @@ int launch_mt_normal32(midas_ctx* ctx, uint32_t* state, int64_t skip_words, int6
     const int64_t threads = numel > MT_HIST ? numel : (nwords < MT_HIST ? nwords : MT_HIST);  // (the history's words have a thread each)
     hipLaunchKernelGGL(k_mt_normal, dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)raw, (const int32_t*)meta,
                        (long long)numel, (long long)nwords, R, C, S, mean, std, out, nwords >= MT_HIST ? hist : (uint32_t*)nullptr);
+    MIDAS_HIP_CHECK(ctx, hipGetLastError());
+    return MIDAS_OK;
+}
+
+// ---- several draws of one frame from ONE walk of the generator -----------------------------------------------------------------
+// A seeded frame of the reference takes torch.normal (N, 3) twice and torch.rand N float64 (particle_filter.py:326-335, :245): as
+// three calls that is three jumps, three walks, three launches' worth of Python.  Here the segments' words are generated together
+// (one jump + one set of pieces over the sum of their words), each segment is then transformed from its place in the raw words; the
+// history the next call's jump reads is copied once.
+__global__ __launch_bounds__(256) void k_mt_hist(const uint32_t* __restrict__ raw, const int32_t* __restrict__ meta, uint32_t* __restrict__ hist) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < MT_HIST) hist[i] = raw[(meta ? meta[0] : 0) + i];
+}
+
+int launch_mt_draws(midas_ctx* ctx, uint32_t* state, int64_t skip_words, int32_t nseg, const midas_mt_segment* segs, const float* R,
+                    const float* C, const float* S, uint32_t* hist, const uint32_t* polys, int32_t G) {
+    int64_t total = 0;
+    for (int i = 0; i < nseg; ++i)
+        total += segs[i].kind == MIDAS_MT_SEGMENT_RAND64 ? 2 * segs[i].count : segs[i].count + ((segs[i].count & 15) ? 16 : 0);
+    uint32_t* raw;
+    int32_t* meta;
+    int rc = mt_words(ctx, state, skip_words, total, hist, polys, G, &raw, &meta);
+    if (rc) return rc;
+    int64_t off = 0;
+    for (int i = 0; i < nseg; ++i) {
+        const int64_t n = segs[i].count;
+        if (segs[i].kind == MIDAS_MT_SEGMENT_RAND64) {
+            if (n > 0)
+                hipLaunchKernelGGL(k_mt_emit, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)raw, (const int32_t*)meta,
+                                   (long long)n, (double*)segs[i].out_dev, (uint32_t*)nullptr, (long long)off);
+            off += 2 * n;
+        } else {
+            const int64_t nw = n + ((n & 15) ? 16 : 0);
+            hipLaunchKernelGGL(k_mt_normal, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)raw, (const int32_t*)meta,
+                               (long long)n, (long long)nw, R, C, S, segs[i].mean, segs[i].std, (float*)segs[i].out_dev, (uint32_t*)nullptr,
+                               (long long)off);
+            off += nw;
+        }
+    }
+    if (hist && total >= MT_HIST)
+        hipLaunchKernelGGL(k_mt_hist, dim3((unsigned)ceil_div((int64_t)MT_HIST, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)raw,
+                           (const int32_t*)meta, hist);
     MIDAS_HIP_CHECK(ctx, hipGetLastError());
     return MIDAS_OK;
 }

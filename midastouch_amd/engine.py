@@ -335,12 +335,15 @@ class PipelinedFilterEngine(FilterEngine):
                 tn, rot = a * (mul * self.sig_t), b * (mul * self.sig_r)
             # this frame's draws are consumed by the NEXT launch (the folded resample) or by flush(): generated beside this
             # frame's kernels on the generator's own stream, waited for where they are read
-            u, u_event = stream.rand64_async(self.N)
             own_u = True
             if stream_motion:
-                a, _ = stream.normal_async(0.0, 1.0, (self.N, 3))   # the next frame's, behind this frame's uniforms (the stream's order)
-                b, ev = stream.normal_async(0.0, 1.0, (self.N, 3))
+                # ... together with the next frame's unit normals, which follow them in the stream: one walk of the generator
+                # (midas_mt19937_draws) instead of three
+                (u, a, b), ev = stream.draws_async([("rand64", self.N), ("normal", 0.0, 1.0, (self.N, 3)), ("normal", 0.0, 1.0, (self.N, 3))])
+                u_event = ev
                 self._unit_noise = (a, b, ev)
+            else:
+                u, u_event = stream.rand64_async(self.N)
         self._wait_draws()
         odom, code, gt, tn, rot, u = self._operands(odom, code, gt, tn, rot, u)
         cur, nxt = self._cur, self._cur ^ 1

@@ -189,14 +189,15 @@ class TorchCpuStream:
                    self.pieces if polys is not None else 0)
         return self._drawn(words, out)
 
-    def _chain_polys(self, words: int):
+    def _chain_polys(self, words: int, pieces: int | None = None):
         """The jump polynomials of a call of `words` words, or None (no history / too short: the sequential walk)."""
-        if self.pieces > 0 and self._hist_words and words >= _lib.MT19937_HIST_WORDS:
+        pieces = self.pieces if pieces is None else pieces
+        if pieces > 0 and self._hist_words and words >= _lib.MT19937_HIST_WORDS:
             # the polynomials cost the host ~10 ms each: worth it for a pattern of sizes that REPEATS (a fixed-N engine: the same
             # three calls every frame), not for a particle count that changes every frame (the annealing loop: 100 ms a frame of
             # host arithmetic when every call asked for its own set) - a (previous size, skip, size) is served in pieces from its
             # second occurrence on
-            key = (self._hist_words, self.pending_skip, words, self.pieces)
+            key = (self._hist_words, self.pending_skip, words, pieces)
             if key in self._polys:
                 return self._polys[key]
             seen = self.__dict__.setdefault("_seen", {})
@@ -204,7 +205,7 @@ class TorchCpuStream:
                 seen.clear()
             seen[key] = seen.get(key, 0) + 1
             if seen[key] >= self.chain_after:
-                return self._piece_polys(self._hist_words, self.pending_skip, words)
+                return self._piece_polys(self._hist_words, self.pending_skip, words, pieces)
         return None
 
     def _drawn(self, words: int, out):
@@ -257,17 +258,67 @@ class TorchCpuStream:
             torch.cuda.current_stream(self.device).wait_event(ev)
         return z
 
-    def _piece_polys(self, prev_words: int, skip: int, words: int):
-        key = (prev_words, skip, words, self.pieces)
+    def draws_async(self, spec):
+        """Several consecutive draws by ONE walk of the generator (midas_mt19937_draws): spec = sequence of ("rand64", N) and
+        ("normal", mean, std, size) in the stream's order - a seeded frame of the reference is normal (N, 3) twice and rand64 N
+        (particle_filter.py:326-335, :245).  Returns ([tensors], event or None): the numbers of the separate calls, fresh tensors,
+        enqueued on the generator's stream behind the caller's current stream."""
+        import ctypes as C
+        outs, segs, words, need_tables = [], [], 0, False
+        for item in spec:
+            if item[0] == "rand64":
+                n = int(item[1])
+                out = torch.empty(n, dtype=torch.float64, device=self.device)
+                segs.append((_lib.MT_SEGMENT_RAND64, n, 0.0, 1.0, out))
+                words += 2 * n
+            elif item[0] == "normal":
+                _, mean, std, size = item
+                shape = tuple(size) if hasattr(size, "__len__") else (int(size),)
+                numel = 1
+                for d in shape:
+                    numel *= int(d)
+                if numel < 16:
+                    raise _lib.MidasError("torch.normal of fewer than 16 values uses another code path of ATen: not modelled")
+                out = torch.empty(shape, dtype=torch.float32, device=self.device)
+                segs.append((_lib.MT_SEGMENT_NORMAL32, numel, float(mean), float(std), out))
+                words += normal_words(numel)
+                need_tables = True
+            else:
+                raise ValueError(f"unknown draw {item[0]!r}")
+            if self.side is not None:
+                out.record_stream(self.side)
+            outs.append(out)
+        R, Ct, S = self._normal_tables() if need_tables else (None, None, None)
+        self._enter()
+        arr = (_lib.MtSegment * len(segs))()
+        for a, (kind, count, mean, std, out) in zip(arr, segs):
+            a.kind, a.count, a.mean, a.std, a.out_dev = kind, count, mean, std, out.data_ptr()
+        pieces = self.pieces_for(words)
+        polys = self._chain_polys(words, pieces)
+        self._call("midas_mt19937_draws", _ptr(self.state), self.pending_skip, len(segs), C.cast(arr, C.c_void_p), _ptr(R), _ptr(Ct), _ptr(S),
+                   _ptr(self._hist), _ptr(polys), pieces if polys is not None else 0)
+        _, ev = self._drawn(words, None)
+        return outs, ev
+
+    def pieces_for(self, words: int) -> int:
+        """Pieces a call of `words` words is cut into: `pieces` for a draw of 2 x 10^5 words (N = 10^5 uniforms), more for longer calls
+        so that a piece stays ~54 blocks of 624 words (the walk of a piece is the sequential part; a jump costs ~2 us a piece)."""
+        if self.pieces <= 0:
+            return 0
+        return max(self.pieces, min(48, -(-words // (54 * 624))))
+
+    def _piece_polys(self, prev_words: int, skip: int, words: int, pieces: int | None = None):
+        pieces = self.pieces if pieces is None else pieces
+        key = (prev_words, skip, words, pieces)
         tab = self._polys.get(key)
         if tab is None:
             import numpy as np
 
             from . import mt_jump
             nblocks = -(-words // 624)
-            bpc = -(-nblocks // self.pieces)
+            bpc = -(-nblocks // pieces)
             rows = []
-            for c in range(self.pieces):
+            for c in range(pieces):
                 J = prev_words + skip + c * bpc * 624
                 if not mt_jump.check(J):
                     raise _lib.MidasError(f"mt19937 jump polynomial for distance {J} failed its check against the reference generator")

@@ -211,6 +211,40 @@ def test_device_normal_equals_torch_normal(pieces):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pieces", [0, 6])
+def test_one_walk_for_the_draws_of_a_frame(pieces):
+    """midas_mt19937_draws: a frame's draws - the resampler's N float64 uniforms and the next frame's two torch.normal (N, 3) - from ONE
+    walk of the generator, in the stream's order; mixed with single calls; sizes that are and are not multiples of 16, below and
+    above the chaining threshold, the same pattern repeated (chained from its second occurrence on)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from midastouch_amd.torch_rng import TorchCpuStream
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(47)
+    st = TorchCpuStream(47, dev, pieces=pieces)
+    for N in (100, 33_333, 100_000, 100_000, 100_000, 100_000, 5_000, 100_000, 100_000):
+        u_ref = torch.rand(N, dtype=torch.float64)
+        a_ref = torch.normal(0.0, 1.0, size=(N, 3))
+        b_ref = torch.normal(0.0, 0.5, size=(N, 3))
+        (u, a, b), ev = st.draws_async([("rand64", N), ("normal", 0.0, 1.0, (N, 3)), ("normal", 0.0, 0.5, (N, 3))])
+        if ev is not None:
+            torch.cuda.current_stream(dev).wait_event(ev)
+        assert torch.equal(u.cpu(), u_ref), N
+        assert torch.equal(a.cpu(), a_ref), N
+        assert torch.equal(b.cpu(), b_ref), N
+        if N == 5_000:  # a single call in between: the chain goes on from its history or starts again
+            assert torch.equal(st.rand64(30_000).cpu(), torch.rand(30_000, dtype=torch.float64))
+    # normal first, uniforms last (the reference's order inside one frame), a mean that is not zero
+    t_ref, r_ref, u_ref = torch.normal(1.0, 2e-4, size=(40_000, 3)), torch.normal(0.0, 0.5, size=(40_000, 3)), torch.rand(40_000, dtype=torch.float64)
+    (t, r, u), ev = st.draws_async([("normal", 1.0, 2e-4, (40_000, 3)), ("normal", 0.0, 0.5, (40_000, 3)), ("rand64", 40_000)])
+    if ev is not None:
+        torch.cuda.current_stream(dev).wait_event(ev)
+    assert torch.equal(t.cpu(), t_ref) and torch.equal(r.cpu(), r_ref) and torch.equal(u.cpu(), u_ref)
+    st.to_host()
+    assert torch.equal(torch.rand(7), torch.rand(7)) is False or True  # (the generator is usable)
+
+
+@pytest.mark.gpu
 def test_stream_hand_over_between_host_and_device():
     """from_host / to_host: one torch stream, drawn alternately on the host generator and on the device replica - as a runner does that
     initialises its particles with host draws (init_filter) and takes the per-frame draws on the device."""

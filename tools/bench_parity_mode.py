@@ -25,6 +25,9 @@ for pieces in [int(a) for a in sys.argv[1:]] or [0, 4, 8, 16]:
     torch_rng.TorchCpuStream.__init__ = init
     r = bench.parity_mode_rate(cb, traj, N, dev, tree, mesh)
     print(f"pieces={pieces}: {r['steps_per_sec']:.0f} steps/s ({r['ms_per_step'] * 1e3:.1f} us/step)  runs {r['steps_per_sec_runs']}", flush=True)
+    if os.environ.get("ALL_DRAWS"):  # every draw of the frame from the stream (motion noise too)
+        r = bench.parity_mode_rate(cb, traj, N, dev, tree, mesh, motion=True)
+        print(f"pieces={pieces}, all draws: {r['steps_per_sec']:.0f} steps/s ({r['ms_per_step'] * 1e3:.1f} us/step)  runs {r['steps_per_sec_runs']}", flush=True)
 # the generator alone
 st = torch_rng.TorchCpuStream.__new__(torch_rng.TorchCpuStream)
 for pieces in (0, 4, 8, 16, 32):
