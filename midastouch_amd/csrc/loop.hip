@@ -66,27 +66,30 @@ __global__ __launch_bounds__(256) void k_loop_xe(const int32_t* __restrict__ ctl
                                                  const int32_t* __restrict__ nn_idx, const uint8_t* __restrict__ valid,
                                                  int32_t softmax, int32_t unit, double* __restrict__ x_out, double* __restrict__ e_out,
                                                  double* __restrict__ bsum, double* __restrict__ bmax, double* __restrict__ bmin,
-                                                 int32_t* __restrict__ bkept, int32_t* __restrict__ bnan) {
+                                                 int32_t* __restrict__ bkept, int32_t* __restrict__ bnan, int32_t cap_n, int64_t K) {
     __shared__ double s_gtot[16];
     __shared__ double s_mx[4], s_mn[4];
     __shared__ int s_k[4], s_f[4];
     __shared__ double s_t[LDS_CHUNK_DOUBLES];
-    const int64_t n = ctl_i[LOOP_I_N];
     const int blk = blockIdx.x, t = threadIdx.x;
     const int64_t bbase = (int64_t)blk * SCAN_BLOCK;
-    if (bbase >= n) return;
-    // batched, unconditional loads on clamped indices (a branch around a load makes hipcc wait for each one in turn)
+    // batched, unconditional loads on clamped indices (a branch around a load makes hipcc wait for each one in turn); clamped to
+    // what the launch was sized for, not to the live count - the control block is a trip of its own, the indices and the scores
+    // travel beside it (a slot behind the live count holds anything: its row number is clamped too, its values are masked)
     double v[SCAN_CHUNK];
     int32_t nn[SCAN_CHUNK];
     unsigned okbits = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_CHUNK; ++k) {
-        const int64_t i = bbase + (int64_t)k * 256 + t, ic = i < n ? i : n - 1;
-        nn[k] = nn_idx[ic];
+        const int64_t i = bbase + (int64_t)k * 256 + t, ic = i < cap_n ? i : cap_n - 1;
+        const int32_t r = nn_idx[ic];
+        nn[k] = r < 0 ? 0 : ((int64_t)r >= K ? (int32_t)(K - 1) : r);
         okbits |= valid[ic] != 0 ? (1u << k) : 0u;
     }
 #pragma unroll
     for (int k = 0; k < SCAN_CHUNK; ++k) v[k] = unit ? 1.0 : scores[nn[k]];
+    const int64_t n = ctl_i[LOOP_I_N];
+    if (bbase >= n) return;
     double mx = -INFINITY, mn = INFINITY;
     int kept = 0;
     bool nan = false;
@@ -603,6 +606,9 @@ MD void anneal_small_select(int* s_w, const uint64_t* wkey, int32_t* __restrict_
 #pragma unroll
     for (int j = 0; j < 16; ++j) key[j] = mode == 2 ? ~wkey[j] : wkey[j];  // (select_key)
     const int mine_n = n - t <= 0 ? 0 : (n - t + 1023) >> 10;  // how many of them exist (rows 0 .. mine_n - 1; n <= 16 384)
+    // rows that hold a particle at all (the same for every thread): the per-row loops below skip the others on a scalar branch - at
+    // n ~ 8k half of what the sixteen waves of this ONE compute unit would issue
+    const int rows = (n + 1023) >> 10;
     ACK(1);
     // ---- radix select: the k-th smallest key T and how many of its equals to take (r)
     // The digits start at the highest bit in which the keys DIFFER (weights of one frame share sign and exponent, often the
@@ -611,7 +617,7 @@ MD void anneal_small_select(int* s_w, const uint64_t* wkey, int32_t* __restrict_
     uint64_t kmin = ~0ull, kmax = 0ull;
 #pragma unroll
     for (int j = 0; j < 16; ++j)
-        if (j < mine_n) { kmin = key[j] < kmin ? key[j] : kmin; kmax = key[j] > kmax ? key[j] : kmax; }
+        if (j < rows && j < mine_n) { kmin = key[j] < kmin ? key[j] : kmin; kmax = key[j] > kmax ? key[j] : kmax; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const uint64_t a = (uint64_t)__shfl_xor((long long)kmin, o), c = (uint64_t)__shfl_xor((long long)kmax, o);
@@ -631,7 +637,8 @@ MD void anneal_small_select(int* s_w, const uint64_t* wkey, int32_t* __restrict_
     {
         int eq = 0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) eq += (j < mine_n && key[j] == kmin) ? 1 : 0;
+        for (int j = 0; j < 16; ++j)
+            if (j < rows) eq += (j < mine_n && key[j] == kmin) ? 1 : 0;
         eq = lw_isum(eq);
         if ((t & 63) == 0 && eq) atomicAdd(&s_w[39], eq);
         __syncthreads();
@@ -656,7 +663,7 @@ MD void anneal_small_select(int* s_w, const uint64_t* wkey, int32_t* __restrict_
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const bool match = top >= 64 || (key[j] >> top) == prefix;
-            if (j < mine_n && match) atomicAdd(&s_h[(uint32_t)(key[j] >> shift) & ((1u << width) - 1u)], 1u);
+            if (j < rows && j < mine_n && match) atomicAdd(&s_h[(uint32_t)(key[j] >> shift) & ((1u << width) - 1u)], 1u);
         }
         __syncthreads();
         ACKD(11);
@@ -691,7 +698,8 @@ MD void anneal_small_select(int* s_w, const uint64_t* wkey, int32_t* __restrict_
             const uint64_t cand = s_T[0];
             int eq = 0;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) eq += (j < mine_n && key[j] == cand) ? 1 : 0;
+            for (int j = 0; j < 16; ++j)
+                if (j < rows) eq += (j < mine_n && key[j] == cand) ? 1 : 0;
             eq = lw_isum(eq);
             if ((t & 63) == 0 && eq) atomicAdd(&s_w[35], eq);
             __syncthreads();
@@ -743,13 +751,18 @@ MD void anneal_small_select(int* s_w, const uint64_t* wkey, int32_t* __restrict_
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const bool isl = j < mine_n && key[j] < T, ise = j < mine_n && key[j] == T;
-            const uint64_t bl = __ballot(isl), be = __ballot(ise);
-            pl[j] = __popcll(bl & below);
-            pe[j] = __popcll(be & below);
-            lbits |= isl ? (1u << j) : 0u;
-            ebits |= ise ? (1u << j) : 0u;
-            if (lane == 0) s_ce[j * 16 + wv] = make_int2(__popcll(bl), __popcll(be));
+            pl[j] = 0; pe[j] = 0;
+            if (j < rows) {
+                const bool isl = j < mine_n && key[j] < T, ise = j < mine_n && key[j] == T;
+                const uint64_t bl = __ballot(isl), be = __ballot(ise);
+                pl[j] = __popcll(bl & below);
+                pe[j] = __popcll(be & below);
+                lbits |= isl ? (1u << j) : 0u;
+                ebits |= ise ? (1u << j) : 0u;
+                if (lane == 0) s_ce[j * 16 + wv] = make_int2(__popcll(bl), __popcll(be));
+            } else if (lane == 0) {
+                s_ce[j * 16 + wv] = make_int2(0, 0);
+            }
         }
         __syncthreads();
         if (wv == 0) {
@@ -773,7 +786,7 @@ MD void anneal_small_select(int* s_w, const uint64_t* wkey, int32_t* __restrict_
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            if (j < mine_n) {
+            if (j < rows && j < mine_n) {
                 const int i = 1024 * j + t;
                 const int2 b = s_ce[j * 16 + wv];
                 const int lb = b.x + pl[j], eb = b.y + pe[j];
@@ -934,12 +947,20 @@ struct LoopResampleArgs {
     const float* cluster_poses;
     const float* cluster_stds;
     int32_t* host_mirror;
+    int32_t cap2;  // slots the prefix array holds (the launch's bound of the annealed set)
 };
 
 // n_set draws over cdf_i = (BP_b + lp_i) / total (last slot 1): lower bound (multinomial) / upper bound (systematic) by
 // bisection on the exact values; the drawn particle's rows are fetched through src.  All-zero or NaN weights: the annealed
 // set goes on unresampled (particle_filter.py:240-241).
 __global__ __launch_bounds__(256) void k_loop_resample(LoopResampleArgs a) {
+#ifdef MIDAS_ANNEAL_CLOCKS  // (phase clocks of workgroup 0, thread 0: tools/anneal_clocks.py)
+    const long long ck0 = wall_clock64();
+    double* ctl_d = a.ctl_d;
+#define RCK(i) do { if (blockIdx.x == 0) ACK(i); } while (0)
+#else
+#define RCK(i) do { } while (0)
+#endif
     __shared__ double s_bp[LAZY_MAX_BLOCKS + 1];
     __shared__ int s_flag;
     // Small sets (softmax weights: the prefix sums do not decrease): the prefix at the end of every 16-slot chunk is staged in LDS
@@ -948,21 +969,53 @@ __global__ __launch_bounds__(256) void k_loop_resample(LoopResampleArgs a) {
     // search finds the same slot in a non-decreasing sequence (the values compared are the same exact quotients).
     constexpr int RS_CHUNKS = 2048;
     __shared__ double s_ce[RS_CHUNKS];
-    const int64_t n2 = a.ctl_i[LOOP_I_NSET];
     const int t = threadIdx.x;
+    // Chunk ends, block totals and NaN flags leave before the control block is looked at (it is a trip of its own): by position,
+    // bounded by what the launch was sized for - what lies behind the live count is not used.
+    constexpr int RS_PRE = RS_CHUNKS / 256;
+    const int64_t nch_cap = ((int64_t)a.cap2 + 15) >> 4;
+    const int nb_cap = (int)(((int64_t)a.cap2 + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    double ce[RS_PRE];
+    const bool pre = nch_cap <= RS_CHUNKS && a.cap2 > 0;
+    if (pre) {
+#pragma unroll
+        for (int k = 0; k < RS_PRE; ++k) {
+            const int64_t p = (int64_t)16 * (t + 256 * k) + 15;
+            ce[k] = a.lp[p < a.cap2 ? p : a.cap2 - 1];
+        }
+    }
+    const int tb = t < nb_cap ? t : nb_cap - 1;  // (nb_cap <= LAZY_MAX_BLOCKS = 256: one block a thread)
+    const double bt_t = a.btot[tb];
+    const int bn_t = a.bnan[tb];
+    const int64_t n2 = a.ctl_i[LOOP_I_NSET];
     const int64_t i = (int64_t)blockIdx.x * 256 + t;
-    if ((int64_t)blockIdx.x * 256 >= n2 && blockIdx.x != 0) return;
+    // The frame's bookkeeping (status, log row, counters, the host's mirror: ~2 us of one thread, loads and stores one after the
+    // other) is done by the LAST workgroup of the launch when that one has no draws of its own - the launches are sized for a
+    // third more than the set can hold, so it normally has none - instead of by the first behind its gathers: the kernel was as
+    // long as workgroup 0.
+    const bool last_idle = (int64_t)(gridDim.x - 1) * 256 >= n2 && gridDim.x > 1;
+    const bool book = last_idle ? blockIdx.x == gridDim.x - 1 : blockIdx.x == 0;
+    if ((int64_t)blockIdx.x * 256 >= n2 && !book) return;
+    RCK(16);
     const int nb = (int)((n2 + SCAN_BLOCK - 1) / SCAN_BLOCK);
     const int64_t nch = (n2 + 15) >> 4;
     const bool two_level = a.ctl_i[LOOP_I_RAW] == 0 && nch <= RS_CHUNKS && n2 > 0;
-    if (two_level)
-        for (int c = t; c < (int)nch; c += 256) { const int64_t p = (int64_t)16 * c + 15; s_ce[c] = a.lp[p < n2 ? p : n2 - 1]; }
-    for (int b = t; b < nb; b += 256) s_bp[b + 1] = a.btot[b];
+    if (two_level) {
+        if (pre) {  // (the chunk that straddles the live count ends at slot n2 - 1)
+#pragma unroll
+            for (int k = 0; k < RS_PRE; ++k) {
+                const int c = t + 256 * k;
+                if (c < (int)nch) s_ce[c] = (int64_t)16 * c + 15 < n2 ? ce[k] : a.lp[n2 - 1];
+            }
+        } else {
+            for (int c = t; c < (int)nch; c += 256) { const int64_t p = (int64_t)16 * c + 15; s_ce[c] = a.lp[p < n2 ? p : n2 - 1]; }
+        }
+    }
+    const int nbl = nb < nb_cap ? nb : nb_cap;  // (more alive than the launch was sized for: flagged elsewhere; stay inside the arrays)
+    if (t < nbl) s_bp[t + 1] = bt_t;
     if (t == 0) s_flag = 0;
     __syncthreads();
-    int f = 0;
-    for (int b = t; b < nb; b += 256) f |= a.bnan[b];
-    if (f) s_flag = 1;
+    if (t < nbl && bn_t) s_flag = 1;
     if (t == 0) {
         double acc = 0.0;
         s_bp[0] = 0.0;
@@ -971,6 +1024,7 @@ __global__ __launch_bounds__(256) void k_loop_resample(LoopResampleArgs a) {
     __syncthreads();
     const double total = s_bp[nb];
     const int status = (s_flag || total != total) ? 2 : (total == 0.0 ? 1 : 0);
+    RCK(17);
     if (i < n2) {
         int64_t pick = i;
         if (!status) {
@@ -985,27 +1039,47 @@ __global__ __launch_bounds__(256) void k_loop_resample(LoopResampleArgs a) {
                 uq = uq >= 1.0 ? uq - 1.0 : uq;
             }
             int64_t lo = 0, hi = n2;
-            if (two_level) {  // the first chunk whose end is not left of the draw, then inside it
+            auto left_exact = [&](int64_t m) {
+                const double c = m == n2 - 1 ? 1.0 : (s_bp[m >> 12] + a.lp[m]) / total;
+                return upper ? c <= uq : c < uq;
+            };
+            if (two_level) {
+                // the first chunk whose end is not left of the draw, then inside it - probed WITHOUT the division (total > 0 here:
+                // bp + v against uq total; a float64 division is ~40 dependent instructions, fifteen probes were 3 of the kernel's
+                // 10 us), then the exact predicate on the two neighbours of the boundary, walking where the two disagree: the
+                // predicate on the quotients is monotone in the slot, so the result is the bisection's (resample_search.hpp does
+                // the same for the large sets)
+                const double tt = uq * total;
+                auto left_fast = [&](int64_t m, double v_) {
+                    if (m >= n2 - 1) return false;
+                    const double c = s_bp[m >> 12] + v_;
+                    return upper ? c <= tt : c < tt;
+                };
                 int cl = 0, ch = (int)nch;
                 while (ch > cl) {
                     const int cm = cl + ((ch - cl) >> 1);
-                    const int64_t p = (int64_t)16 * cm + 15;
-                    const double c = p >= n2 - 1 ? 1.0 : (s_bp[p >> 12] + s_ce[cm]) / total;
-                    const bool left = upper ? c <= uq : c < uq;
-                    if (left) cl = cm + 1; else ch = cm;
+                    if (left_fast((int64_t)16 * cm + 15, s_ce[cm])) cl = cm + 1; else ch = cm;
                 }
                 lo = (int64_t)16 * cl;
                 hi = lo + 16 < n2 ? lo + 16 : n2;
                 if (cl >= (int)nch) lo = hi = n2;
-            }
-            while (hi > lo) {
-                const int64_t mid = lo + ((hi - lo) >> 1);
-                const double c = mid == n2 - 1 ? 1.0 : (s_bp[mid >> 12] + a.lp[mid]) / total;
-                const bool left = upper ? c <= uq : c < uq;
-                if (left) lo = mid + 1; else hi = mid;
+                // (inside the chunk: four dependent probes of one cache line; its sixteen values fetched together - eight 16-byte
+                // loads a lane, every lane a line of its own - made the kernel 1 us slower)
+                while (hi > lo) {
+                    const int64_t mid = lo + ((hi - lo) >> 1);
+                    if (left_fast(mid, a.lp[mid])) lo = mid + 1; else hi = mid;
+                }
+                while (lo > 0 && !left_exact(lo - 1)) --lo;
+                while (lo < n2 && left_exact(lo)) ++lo;
+            } else {
+                while (hi > lo) {
+                    const int64_t mid = lo + ((hi - lo) >> 1);
+                    if (left_exact(mid)) lo = mid + 1; else hi = mid;
+                }
             }
             pick = lo < n2 ? lo : n2 - 1;
         }
+        RCK(18);
         a.ridx[i] = (int32_t)pick;
         const int32_t s = a.src[pick];
         const float4* s4 = reinterpret_cast<const float4*>(a.poses_prop + (size_t)s * 16);
@@ -1015,8 +1089,9 @@ __global__ __launch_bounds__(256) void k_loop_resample(LoopResampleArgs a) {
         a.weights_out[i] = a.w[s];
         a.hint_out[i] = a.nn_idx[s];
         a.labels_out[i] = a.labels[s];
+        RCK(19);
     }
-    if (blockIdx.x == 0 && t == 0) {
+    if (book && t == 0) {
         const int32_t n = a.ctl_i[LOOP_I_N];
         a.ctl_i[LOOP_I_STATUS] = status;
         a.ctl_d[LOOP_D_TOTAL] = total;
@@ -1045,7 +1120,11 @@ __global__ __launch_bounds__(256) void k_loop_resample(LoopResampleArgs a) {
             __hip_atomic_store(&a.host_mirror[1], (int32_t)n2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&a.host_mirror[0], a.ctl_i[LOOP_I_FRAME], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+#ifdef MIDAS_ANNEAL_CLOCKS
+        ctl_d[56 + 22] += 1.0;  // launches
+#endif
     }
+    RCK(20);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
@@ -1193,7 +1272,7 @@ int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree*
         int32_t* bnan = bkept + nbcap;
         hipLaunchKernelGGL(k_loop_xe, dim3(nbcap), dim3(256), 0, st, (const int32_t*)s.ctl_i_dev, (const double*)s.scores_dev,
                            (const int32_t*)s.nn_idx_dev, (const uint8_t*)s.valid_dev, s.softmax, s.unit_weights, s.x_dev, s.e_dev, bsum, bmax, bmin,
-                           bkept, bnan);
+                           bkept, bnan, (int32_t)(cap < (1 << 30) ? cap : (1 << 30)), cb->K);
         wa.ctl_i = s.ctl_i_dev; wa.ctl_d = s.ctl_d_dev; wa.grid_n = (int32_t)(cap < (1 << 30) ? cap : (1 << 30)); wa.nbl = (int32_t)nbcap;
         wa.bsum = bsum; wa.bmax = bmax; wa.bmin = bmin; wa.bkept = bkept; wa.bnan = bnan;
         wa.x = (const double*)s.x_dev; wa.e = (const double*)s.e_dev; wa.valid = (const uint8_t*)s.valid_dev;
@@ -1244,7 +1323,7 @@ int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree*
         const int64_t cap2 = cap + cap / 3 + 1 < s.cap ? cap + cap / 3 + 1 : s.cap;
         const unsigned nb2 = (unsigned)ceil_div(cap2, SCAN_BLOCK);
         void *lp, *bt, *bn;
-        if ((rc = midas_scratch(ctx, (size_t)cap2 * sizeof(double), &lp))) return rc;
+        if ((rc = midas_scratch(ctx, ((size_t)cap2 + SCAN_CHUNK) * sizeof(double), &lp))) return rc;  // (the resample reads whole chunks)
         if ((rc = midas_scratch(ctx, (size_t)nb2 * sizeof(double), &bt))) return rc;
         if ((rc = midas_scratch(ctx, (size_t)nb2 * sizeof(int32_t), &bn))) return rc;
         hipLaunchKernelGGL(k_loop_scan, dim3(nb2), dim3(256), 0, st, (const int32_t*)s.ctl_i_dev, (const double*)s.x_dev,
@@ -1258,6 +1337,7 @@ int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree*
         r.ridx = s.ridx_dev; r.mode = s.resample_mode; r.u = s.u_dev; r.u32 = s.u32; r.seed = s.seed; r.step = s.step;
         r.log = s.log_dev; r.cluster_poses = s.cluster_poses_dev; r.cluster_stds = s.cluster_stds_dev;
         r.host_mirror = s.host_mirror;
+        r.cap2 = (int32_t)(cap2 < (1 << 30) ? cap2 : (1 << 30));
         hipLaunchKernelGGL(k_loop_resample, dim3((unsigned)ceil_div(cap2, 256)), dim3(256), 0, st, r);
         LAUNCH_CHECK(ctx);
     }

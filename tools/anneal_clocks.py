@@ -16,10 +16,15 @@ cfg = load_config(["expt.params.num_particles=100000", "expt.codebook_size=50000
 dev = torch.device("cuda", 0)
 seq = synthetic_sequence(cfg, dev, T=150, D=512)
 run_filter(cfg, seq, device=dev, cluster=True, draws="device", floor=1000, max_frames=150)
-c = engines[-1].ctl_d.cpu().numpy()[56:72]
+c = engines[-1].ctl_d.cpu().numpy()[56:80]
 n2 = max(c[6], 1.0)
 print("launches with mode 2:", int(c[6]), "mean k", c[8] / n2)
 print("cumulative ticks (100 MHz -> us = /100) summed over ALL launches: after decide %.0f, keys %.0f, select %.0f, compaction %.0f | mode-2 only: sort %.0f, write %.0f | rotations block %.0f" % tuple(c[i] / 100 for i in (0, 1, 2, 3, 4, 5, 7)))
 nl = c[0] / 146.0  # launches, from the decide phase's ~1.46 us
 print("per launch (us): minmax end %.1f | per pass: zero %.2f atomics %.2f scan %.2f pick %.2f ; passes per launch %.2f ; finish %.2f" % (
     c[9] / 100 / nl, c[10] / 100 / max(c[15], 1), c[11] / 100 / max(c[15], 1), c[12] / 100 / max(c[15], 1), c[13] / 100 / max(c[15], 1), c[15] / nl, c[14] / 100 / nl))
+# k_loop_resample, workgroup 0 / thread 0, absolute from the kernel's first instruction: prefetch + live count there [16], tables built [17],
+# search done [18], rows gathered and stored [19], end [20]; launches [22]
+nr = max(c[22], 1.0)
+print("k_loop_resample per launch (us): count known %.2f tables %.2f search %.2f rows %.2f end %.2f (launches %d)" % tuple(
+    [c[i] / 100 / nr for i in (16, 17, 18, 19, 20)] + [nr]))
