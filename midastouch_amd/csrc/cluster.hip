@@ -76,8 +76,16 @@ MD MomIn moments_load(int64_t nc, const float* __restrict__ poses, const double*
     return in;
 }
 
+// skip: a cluster NONE of the workgroup's particles belongs to is not summed (34 wave sums and two barriers each: with six
+// clusters alive and one or two of them in a workgroup, 7.5 of the loop launch's 11 us) - its partials are written directly.
+// They are not simply +0.0: the sums are of 0 x (a product of quaternion components, a translation) over every lane, which is -0.0
+// where EVERY lane's factor is negative - the signs are taken once per workgroup (13 of them) - and NaN where some lane's pose
+// is not finite (then nothing is skipped).  Same bits as the sums (tests/test_gpu_knobs.py: MIDAS_MOMENTS_SKIP=0).
 template <typename LV>
-MD void moments_accumulate(bool live, const MomIn& in, int C, LV label_value, double* __restrict__ part, double (*s_w)[CL_MOM]) {
+MD void moments_accumulate(bool live, const MomIn& in, int C, LV label_value, double* __restrict__ part, double (*s_w)[CL_MOM],
+                           bool skip = true) {
+    __shared__ unsigned long long s_mem[4];
+    __shared__ unsigned s_sgn[4];
     const size_t nbs = gridDim.x;
     const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
     const float* P = in.P;
@@ -86,8 +94,51 @@ MD void moments_accumulate(bool live, const MomIn& in, int C, LV label_value, do
     double q[4];
     quat_of(P, q);
     const double tx = P[3], ty = P[7], tz = P[11];
+    unsigned long long wgmask = ~0ull;
+    unsigned sgn = 0;
+    if (skip && C <= 64) {
+        unsigned long long mm = 0;
+        for (int c = 0; c < C; ++c) mm |= __any(live && lab == label_value(c)) ? (1ull << c) : 0ull;
+        unsigned sg = 0;
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = i; j < 4; ++j) {
+                const double qq = q[i] * q[j];
+                sg |= __all(__builtin_signbit(qq) ? 1 : 0) ? (1u << k) : 0u;
+                ++k;
+            }
+        sg |= __all(__builtin_signbit(tx) ? 1 : 0) ? (1u << 10) : 0u;
+        sg |= __all(__builtin_signbit(ty) ? 1 : 0) ? (1u << 11) : 0u;
+        sg |= __all(__builtin_signbit(tz) ? 1 : 0) ? (1u << 12) : 0u;
+        const bool fin = __builtin_isfinite(q[0]) && __builtin_isfinite(q[1]) && __builtin_isfinite(q[2]) && __builtin_isfinite(q[3]) &&
+                         __builtin_isfinite(tx) && __builtin_isfinite(ty) && __builtin_isfinite(tz);
+        sg |= __all(fin ? 1 : 0) ? (1u << 31) : 0u;
+        if (lane == 0) { s_mem[wv] = mm; s_sgn[wv] = sg; }
+        __syncthreads();
+        sgn = s_sgn[0] & s_sgn[1] & s_sgn[2] & s_sgn[3];
+        if ((sgn >> 31) & 1u) wgmask = s_mem[0] | s_mem[1] | s_mem[2] | s_mem[3];  // (something not finite here: 0 x inf is part of the sums)
+    }
     double v[CL_MOM];
     for (int c = 0; c < C; ++c) {
+        if (!((wgmask >> (c & 63)) & 1ull)) {  // (workgroup-uniform)
+            if (t < CL_MOM) {
+                double r = 0.0;
+                if (t == M_WMAX) r = -INFINITY;
+                else if (t == M_WMIN) r = INFINITY;
+                else {
+                    int bit = -1;
+                    if (t >= M_QQW && t < M_QQW + 10) bit = t - M_QQW;
+                    else if (t >= M_QQ1 && t < M_QQ1 + 10) bit = t - M_QQ1;
+                    else if (t >= M_TW && t < M_TW + 3) bit = 10 + t - M_TW;
+                    else if (t >= M_T1 && t < M_T1 + 3) bit = 10 + t - M_T1;
+                    if (bit >= 0 && ((sgn >> bit) & 1u)) r = -0.0;
+                }
+                part[((size_t)c * nbs + blockIdx.x) * CL_MOM + t] = r;
+            }
+            continue;
+        }
         const bool mine = live && lab == label_value(c);
         const double a = mine ? w : 0.0, b = mine ? 1.0 : 0.0;
         v[M_SW] = a; v[M_CNT] = b; v[M_WMAX] = 0.0; v[M_WMIN] = 0.0;
@@ -128,39 +179,47 @@ MD void moments_accumulate(bool live, const MomIn& in, int C, LV label_value, do
 template <typename LabelT, typename LV>
 MD void cluster_moments_body(int64_t N, const float* __restrict__ poses, const double* __restrict__ w64,
                              const float* __restrict__ w32, const LabelT* __restrict__ labels, int C, LV label_value,
-                             double* __restrict__ part, double (*s_w)[CL_MOM]) {
+                             double* __restrict__ part, double (*s_w)[CL_MOM], bool skip) {
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = n < N;
     const MomIn in = moments_load(live ? n : N - 1, poses, w64, w32, labels);
-    moments_accumulate(live, in, C, label_value, part, s_w);
+    moments_accumulate(live, in, C, label_value, part, s_w, skip);
 }
 
 __global__ __launch_bounds__(256) void k_cluster_moments(int64_t N, const float* __restrict__ poses, const double* __restrict__ w64,
                                                          const float* __restrict__ w32, const int64_t* __restrict__ labels, int C,
-                                                         const int64_t* __restrict__ label_values, double* __restrict__ part) {
+                                                         const int64_t* __restrict__ label_values, double* __restrict__ part, bool skip) {
     __shared__ double s_w[4][CL_MOM];
-    cluster_moments_body(N, poses, w64, w32, labels, C, [&](int c) { return label_values[c]; }, part, s_w);
+    cluster_moments_body(N, poses, w64, w32, labels, C, [&](int c) { return label_values[c]; }, part, s_w, skip);
 }
 
 // loop engine: labels are DBSCAN's int32 values in [-1, ncl), cluster slot c stands for label c - 1; the particle count
 // and ncl come from the control block (midas_loop_step)
 __global__ __launch_bounds__(256) void k_loop_cluster_moments(const int32_t* __restrict__ ctl_i, const float* __restrict__ poses,
                                                               const double* __restrict__ w64, const int32_t* __restrict__ labels,
-                                                              double* __restrict__ part) {
+                                                              double* __restrict__ part, bool skip) {
     __shared__ double s_w[4][CL_MOM];
     const int64_t n = ctl_i[LOOP_I_N];
     int C = ctl_i[LOOP_I_NCL] + 1;
     C = C > LOOP_MAX_CLUSTERS ? LOOP_MAX_CLUSTERS : C;
     if ((int64_t)blockIdx.x * 256 >= n) return;
-    cluster_moments_body(n, poses, w64, (const float*)nullptr, labels, C, [](int c) { return (int64_t)(c - 1); }, part, s_w);
+    cluster_moments_body(n, poses, w64, (const float*)nullptr, labels, C, [](int c) { return (int64_t)(c - 1); }, part, s_w, skip);
 }
 
 // The same with the frame's weights computed at its head (loop_weights.hpp: k_loop_weights' arithmetic, one particle a thread):
 // S and the guard from k_loop_xe's block results by every workgroup for itself, the particle's weight stored and used at once,
 // the first workgroup finalises the control block.  One launch less per frame (~5 us of a 90 us frame at N ~ 10^4), and the
 // moments need not read the weights back.  Everything a thread reads is requested before the live count is looked at.
+#ifdef MIDAS_ANNEAL_CLOCKS  // phase clocks of workgroup 0, thread 0 (tools/anneal_clocks.py; slots 24 .. 29 of the profiling block)
+#define WCK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl_d[56 + (i)] += (double)(wall_clock64() - wck0); } while (0)
+#else
+#define WCK(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void k_loop_weights_moments(LoopWeightsArgs a, const int32_t* __restrict__ labels,
-                                                              double* __restrict__ part) {
+                                                              double* __restrict__ part, bool skip) {
+#ifdef MIDAS_ANNEAL_CLOCKS
+    const long long wck0 = wall_clock64();
+#endif
     __shared__ double s_w[4][CL_MOM];
     __shared__ double s_sum[LAZY_MAX_BLOCKS];
     __shared__ double s_red[8], s_ab[8];
@@ -176,7 +235,9 @@ __global__ __launch_bounds__(256) void k_loop_weights_moments(LoopWeightsArgs a,
     int C = a.ctl_i[LOOP_I_NCL] + 1;
     C = C > LOOP_MAX_CLUSTERS ? LOOP_MAX_CLUSTERS : C;
     if ((int64_t)blockIdx.x * 256 >= n && blockIdx.x != 0) return;
+    WCK(24);
     const LoopWeightsHead h = loop_weights_head(a, pre, n, s_sum, s_red, s_ired);
+    WCK(25);
     const bool live = idx < n;
     double w = 0.0;
     if (live) {
@@ -192,8 +253,14 @@ __global__ __launch_bounds__(256) void k_loop_weights_moments(LoopWeightsArgs a,
         }
     }
     in.w = (double)(float)w;  // particles.weights.float() (:161)
-    if ((int64_t)blockIdx.x * 256 < n) moments_accumulate(live, in, C, [](int c) { return (int64_t)(c - 1); }, part, s_w);
+    WCK(26);
+    if ((int64_t)blockIdx.x * 256 < n) moments_accumulate(live, in, C, [](int c) { return (int64_t)(c - 1); }, part, s_w, skip);
+    WCK(27);
     if (blockIdx.x == 0) loop_weights_finalise(a, h, pre, s_ab);
+    WCK(28);
+#ifdef MIDAS_ANNEAL_CLOCKS
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl_d[56 + 29] += 1.0;
+#endif
 }
 
 // one 64-thread workgroup per cluster: blocks summed in order, then the closed forms
@@ -295,16 +362,22 @@ __global__ __launch_bounds__(256) void k_loop_cluster_finish(const int32_t* __re
     cluster_finish_body((int)((n + 255) / 256), (size_t)nbs, blockIdx.x, part, centers, stds, counts, s_m, rot);
 }
 
+static bool moments_skip() {  // MIDAS_MOMENTS_SKIP=0: every cluster summed by every workgroup (the parity test's other side)
+    static const bool on = !(getenv("MIDAS_MOMENTS_SKIP") && atoi(getenv("MIDAS_MOMENTS_SKIP")) == 0);
+    return on;
+}
+
 // rot: LOOP_MAX_CLUSTERS x 10 doubles - the moment matrices whose eigenproblem the annealing kernel's second workgroup solves
 // (the decision only needs the translation spreads: the eigenvector runs beside the selection)
 int launch_loop_cluster(midas_ctx* ctx, int64_t cap, const int32_t* ctl_i, const float* poses, const double* w64,
                         const int32_t* labels, double* part, float* centers, float* stds, int64_t* counts, double* rot,
                         const LoopWeightsArgs* weights) {
     if (weights)
-        hipLaunchKernelGGL(k_loop_weights_moments, dim3((unsigned)ceil_div(cap, 256)), dim3(256), 0, ctx->stream, *weights, labels, part);
+        hipLaunchKernelGGL(k_loop_weights_moments, dim3((unsigned)ceil_div(cap, 256)), dim3(256), 0, ctx->stream, *weights, labels, part,
+                           moments_skip());
     else
         hipLaunchKernelGGL(k_loop_cluster_moments, dim3((unsigned)ceil_div(cap, 256)), dim3(256), 0, ctx->stream, ctl_i, poses, w64,
-                           labels, part);
+                           labels, part, moments_skip());
     hipLaunchKernelGGL(k_loop_cluster_finish, dim3(LOOP_MAX_CLUSTERS), dim3(256), 0, ctx->stream, ctl_i, (const double*)part, centers,
                        stds, counts, rot, (int32_t)ceil_div(cap, 256));
     MIDAS_HIP_CHECK(ctx, hipGetLastError());
@@ -319,7 +392,7 @@ int launch_cluster_centers(midas_ctx* ctx, int64_t N, const float* poses, const 
     int rc = midas_scratch(ctx, (size_t)nb * C * CL_MOM * sizeof(double), &part);
     if (rc) return rc;
     hipLaunchKernelGGL(k_cluster_moments, dim3((unsigned)nb), dim3(256), 0, ctx->stream, N, poses, w64, w32, labels, (int)C,
-                       label_values, (double*)part);
+                       label_values, (double*)part, moments_skip());
     hipLaunchKernelGGL(k_cluster_finish, dim3((unsigned)C), dim3(64), 0, ctx->stream, nb, (int)C, (const double*)part, centers,
                        stds, counts);
     MIDAS_HIP_CHECK(ctx, hipGetLastError());

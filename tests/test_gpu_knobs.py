@@ -32,6 +32,7 @@ SWITCHES = [
     ("MIDAS_NO_VSCR", "1"),          # prune without the float32 screening records
     ("MIDAS_MESH_FIELD", "0"),       # prune without the distance field
     ("MIDAS_LOOP_MERGE", "0"),       # loop: weights and cluster moments as two launches
+    ("MIDAS_MOMENTS_SKIP", "0"),     # cluster moments: every cluster summed by every workgroup, members or not
     ("MIDAS_OVERLAP", "0"),          # no fused front at all: scoring, then the particle update
     ("MIDAS_LAZY_MODULES", "1"),     # kernels loaded on first use
     ("MIDAS_DENSE_SCORES", "1"),     # every codebook row scored by the front's streaming waves

@@ -16,7 +16,7 @@ cfg = load_config(["expt.params.num_particles=100000", "expt.codebook_size=50000
 dev = torch.device("cuda", 0)
 seq = synthetic_sequence(cfg, dev, T=150, D=512)
 run_filter(cfg, seq, device=dev, cluster=True, draws="device", floor=1000, max_frames=150)
-c = engines[-1].ctl_d.cpu().numpy()[56:80]
+c = engines[-1].ctl_d.cpu().numpy()[56:88]
 n2 = max(c[6], 1.0)
 print("launches with mode 2:", int(c[6]), "mean k", c[8] / n2)
 print("cumulative ticks (100 MHz -> us = /100) summed over ALL launches: after decide %.0f, keys %.0f, select %.0f, compaction %.0f | mode-2 only: sort %.0f, write %.0f | rotations block %.0f" % tuple(c[i] / 100 for i in (0, 1, 2, 3, 4, 5, 7)))
@@ -28,3 +28,8 @@ print("per launch (us): minmax end %.1f | per pass: zero %.2f atomics %.2f scan 
 nr = max(c[22], 1.0)
 print("k_loop_resample per launch (us): count known %.2f tables %.2f search %.2f rows %.2f end %.2f (launches %d)" % tuple(
     [c[i] / 100 / nr for i in (16, 17, 18, 19, 20)] + [nr]))
+# k_loop_weights_moments, workgroup 0 / thread 0: everything it reads there [24], S and the guard [25], weight stored [26], moments of
+# every cluster [27], control block + rmse [28]; launches [29]
+nw = max(c[29], 1.0)
+print("k_loop_weights_moments per launch (us): loads %.2f head %.2f weight %.2f moments %.2f finalise %.2f (launches %d)" % tuple(
+    [c[i] / 100 / nw for i in (24, 25, 26, 27, 28)] + [nw]))
