@@ -1770,7 +1770,9 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
     const bool dense_scores = scores_dense(a.sp);  // requested here, looked at after the nearest-neighbour search
     const int ablate = STATS ? a.ablate : 0;
     long long tc[10];  // phase clocks, reported with MIDAS_ABLATE=4
+    long long tp[4] = {0, 0, 0, 0};  // ... and inside the first phase (MIDAS_ABLATE=4 + 128: reported in place of phases 4 .. 7)
 #define MIDAS_TICK(i) do { if (STATS) tc[i] = clock64(); } while (0)
+#define MIDAS_PTICK(i) do { if (STATS) tp[i] = clock64(); } while (0)
     MIDAS_TICK(0);
     const long long wall0 = STATS ? wall_clock64() : 0;  // 100 MHz
     double x = 0.0, et2 = 0.0, ang2 = 0.0;
@@ -1798,12 +1800,14 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
         bool no_done = false;
         if (live) noise_draws(n, n + a.slot_base, a.tn, a.rot, a.std_t, a.std_r, a.seed, a.step, tnv, rotv);
         if (!presorted) lazy_tables_wave(a.rs, rec, rs_lds);
+        MIDAS_PTICK(0);  // records there, tables built (draws done under their trip)
         auto mid = [&]() { noise_apply(O, tnv, rotv, NO); no_done = true; };
         if (rs_lds && live && !presorted && !(ablate & 8)) {
             src = lazy_source(a.rs, rs_lds, n, a.N, LAZY_WAVE_LD, (const double*)nullptr, (const double*)nullptr, mid);
             if (a.rs.ridx_out) a.rs.ridx_out[n] = (int32_t)src;
         }
         if (live && !no_done) mid();
+        MIDAS_PTICK(1);  // source slot known (guide entries, prefix piece)
     }
     if (rs_lds && live) {
         if (presorted) {
@@ -1836,6 +1840,7 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
         }
         if (WT) {
             mat4_mul(P, NO, R);
+            MIDAS_PTICK(2);  // source row there, propagated
         } else {
             float O[16];
 #pragma unroll
@@ -1964,9 +1969,16 @@ MD void particle_update_wave(const TreeView<Kd6>& t6, const TreeView<Kd3>& t3, P
         w[6] += st_scan;
         w[7] += (unsigned long long)(wall_clock64() - wall0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) w[8 + i] += (unsigned long long)(i == 3 ? tc[9] - tc[3] : i == 4 ? tc[5] - tc[9] : tc[i + 1] - tc[i]);  // [3] claim + scoring, [4] prune lists
+        for (int i = 0; i < 8; ++i) {
+            long long d = i == 3 ? tc[9] - tc[3] : i == 4 ? tc[5] - tc[9] : tc[i + 1] - tc[i];  // [3] claim + scoring, [4] prune lists
+            // + 128: the first phase in four pieces instead of phases 4 .. 7: records + tables, source slot, source row + product,
+            // store + feature + field probe
+            if ((ablate & 128) && i >= 4) d = !tp[0] ? 0 : i == 4 ? tp[0] - tc[0] : i == 5 ? tp[1] - tp[0] : i == 6 ? tp[2] - tp[1] : tc[1] - tp[2];  // (frames without a folded resample: nothing)
+            w[8 + i] += (unsigned long long)d;
+        }
     }
 #undef MIDAS_TICK
+#undef MIDAS_PTICK
 }
 
 template <bool STATS>
