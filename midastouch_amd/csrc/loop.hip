@@ -543,12 +543,7 @@ constexpr int LOOP_SMALL_MAX = 16384, LOOP_SMALL_PAIRS = 8192;
 // exclusive prefix over the 1024 threads of (a, b); totals returned in ta / tb.  s_w: 32 ints of LDS.
 MD void small_scan2(int a, int b, int& ea, int& eb, int& ta, int& tb, int* s_w) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    int ia = a, ib = b;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int x = __shfl_up(ia, o), y = __shfl_up(ib, o);
-        if (lane >= o) { ia += x; ib += y; }
-    }
+    const int ia = wave_iscan_dpp(a), ib = wave_iscan_dpp(b);  // (inclusive, by register moves)
     __syncthreads();
     if (lane == 63) { s_w[wv] = ia; s_w[16 + wv] = ib; }
     __syncthreads();
@@ -594,6 +589,8 @@ MD void anneal_small_select(int* s_w, const uint64_t* wkey, int32_t* __restrict_
                             double* __restrict__ ctl_d, long long ck0, uint64_t* s_key, int32_t* s_idx) {
     __shared__ uint32_t s_h[SEL_BINS];
     __shared__ uint64_t s_small[64];
+    __shared__ uint64_t s_ext[32];   // the waves' extrema (an array of its own: no barrier before s_small's other use)
+    __shared__ int2 s_ce[256];       // the compaction's (row, wave) counts (likewise: not the histogram's memory)
     __shared__ uint64_t s_T[1];
     const int t = threadIdx.x;
     const int mode = s_w[36], k = s_w[37], n = s_w[38];
@@ -618,20 +615,19 @@ MD void anneal_small_select(int* s_w, const uint64_t* wkey, int32_t* __restrict_
 #pragma unroll
     for (int j = 0; j < 16; ++j)
         if (j < rows && j < mine_n) { kmin = key[j] < kmin ? key[j] : kmin; kmax = key[j] > kmax ? key[j] : kmax; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint64_t a = (uint64_t)__shfl_xor((long long)kmin, o), c = (uint64_t)__shfl_xor((long long)kmax, o);
-        kmin = a < kmin ? a : kmin;
-        kmax = c > kmax ? c : kmax;
-    }
-    if ((t & 63) == 0) { s_small[t >> 6] = kmin; s_small[16 + (t >> 6)] = kmax; }
+    ACK(30);
+    kmin = wave_umin64_dpp(kmin);  // (register moves: midas_math.hpp)
+    kmax = wave_umax64_dpp(kmax);
+    ACK(31);
+    if ((t & 63) == 0) { s_ext[t >> 6] = kmin; s_ext[16 + (t >> 6)] = kmax; }
     __syncthreads();
+    ACK(32);
 #pragma unroll
     for (int w = 0; w < 16; ++w) {
-        kmin = s_small[w] < kmin ? s_small[w] : kmin;
-        kmax = s_small[16 + w] > kmax ? s_small[16 + w] : kmax;
+        kmin = s_ext[w] < kmin ? s_ext[w] : kmin;
+        kmax = s_ext[16 + w] > kmax ? s_ext[16 + w] : kmax;
     }
-    __syncthreads();  // (s_small is used again below)
+    ACK(33);
     // Enough copies of the smallest key?  (The pruned particles' zeros when particles are dropped, the ~80 particles on the
     // best-scoring entry when the best are duplicated: k is a per cent or two of the set.)  Then T is that key: no pass at all.
     {
@@ -640,6 +636,7 @@ MD void anneal_small_select(int* s_w, const uint64_t* wkey, int32_t* __restrict_
         for (int j = 0; j < 16; ++j)
             if (j < rows) eq += (j < mine_n && key[j] == kmin) ? 1 : 0;
         eq = lw_isum(eq);
+        ACK(34);
         if ((t & 63) == 0 && eq) atomicAdd(&s_w[39], eq);
         __syncthreads();
     }
@@ -747,8 +744,6 @@ MD void anneal_small_select(int* s_w, const uint64_t* wkey, int32_t* __restrict_
         const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
         int pl[16], pe[16];
         unsigned lbits = 0, ebits = 0;
-        int2* s_ce = reinterpret_cast<int2*>(s_h);  // 256 (row, wave) counts, then their exclusive prefixes (the histogram is done with)
-        __syncthreads();
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             pl[j] = 0; pe[j] = 0;
@@ -768,12 +763,7 @@ MD void anneal_small_select(int* s_w, const uint64_t* wkey, int32_t* __restrict_
         if (wv == 0) {
             const int2 c0 = s_ce[4 * lane], c1 = s_ce[4 * lane + 1], c2 = s_ce[4 * lane + 2], c3 = s_ce[4 * lane + 3];
             int sl = c0.x + c1.x + c2.x + c3.x, se = c0.y + c1.y + c2.y + c3.y;
-            int il = sl, ie = se;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int a = __shfl_up(il, o), b = __shfl_up(ie, o);
-                if (lane >= o) { il += a; ie += b; }
-            }
+            const int il = wave_iscan_dpp(sl), ie = wave_iscan_dpp(se);
             int el = il - sl, ee = ie - se;
             s_ce[4 * lane] = make_int2(el, ee);
             el += c0.x; ee += c0.y;
@@ -877,6 +867,9 @@ __global__ __launch_bounds__(1024) void k_loop_anneal_small(int32_t* __restrict_
     uint64_t wkey[16];
     small_keys(w, s_w[38], wkey);
     anneal_small_select(s_w, wkey, src, ctl_i, ctl_d, ck0, s_key, s_idx);
+#ifdef MIDAS_ANNEAL_CLOCKS
+    if (threadIdx.x == 0) ctl_d[56 + 35] += 1.0;  // launches that got here
+#endif
 }
 
 // ---- RESAMPLE -------------------------------------------------------------------------------------------------------

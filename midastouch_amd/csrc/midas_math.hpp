@@ -313,6 +313,27 @@ MD double wave_min_dpp(double v) {
     MIDAS_DPP_REDUCE(v, dpp_min_)
     return wave_bcast63(v);
 }
+// the same for order-preserving 64-bit keys (the small-set selection's extrema: a `__shfl_xor` butterfly of two 64-bit values is
+// 24 trips through the LDS crossbar, one after the other - 1.6 us with sixteen waves on one compute unit)
+template <int CTRL, int ROW_MASK = 0xf>
+MD uint64_t dpp_move(uint64_t b) {
+    const uint32_t lo = dpp_move<CTRL, ROW_MASK>((uint32_t)b, (uint32_t)b), hi = dpp_move<CTRL, ROW_MASK>((uint32_t)(b >> 32), (uint32_t)(b >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+MD uint64_t dpp_umax_(uint64_t a, uint64_t b) { return b > a ? b : a; }
+MD uint64_t dpp_umin_(uint64_t a, uint64_t b) { return b < a ? b : a; }
+MD uint64_t wave_bcast63(uint64_t b) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), 63);
+    return ((uint64_t)hi << 32) | lo;
+}
+MD uint64_t wave_umax64_dpp(uint64_t v) {
+    MIDAS_DPP_REDUCE(v, dpp_umax_)
+    return wave_bcast63(v);
+}
+MD uint64_t wave_umin64_dpp(uint64_t v) {
+    MIDAS_DPP_REDUCE(v, dpp_umin_)
+    return wave_bcast63(v);
+}
 MD int wave_isum_dpp(int v) {
     // (a sum is not idempotent: the mirrors add the OTHER half's total to lanes that all hold their own half's - still every
     // element once; the row broadcasts add whole rows)

@@ -16,7 +16,7 @@ cfg = load_config(["expt.params.num_particles=100000", "expt.codebook_size=50000
 dev = torch.device("cuda", 0)
 seq = synthetic_sequence(cfg, dev, T=150, D=512)
 run_filter(cfg, seq, device=dev, cluster=True, draws="device", floor=1000, max_frames=150)
-c = engines[-1].ctl_d.cpu().numpy()[56:88]
+c = engines[-1].ctl_d.cpu().numpy()[56:96]
 n2 = max(c[6], 1.0)
 print("launches with mode 2:", int(c[6]), "mean k", c[8] / n2)
 print("cumulative ticks (100 MHz -> us = /100) summed over ALL launches: after decide %.0f, keys %.0f, select %.0f, compaction %.0f | mode-2 only: sort %.0f, write %.0f | rotations block %.0f" % tuple(c[i] / 100 for i in (0, 1, 2, 3, 4, 5, 7)))
@@ -33,3 +33,8 @@ print("k_loop_resample per launch (us): count known %.2f tables %.2f search %.2f
 nw = max(c[29], 1.0)
 print("k_loop_weights_moments per launch (us): loads %.2f head %.2f weight %.2f moments %.2f finalise %.2f (launches %d)" % tuple(
     [c[i] / 100 / nw for i in (24, 25, 26, 27, 28)] + [nw]))
+# k_loop_anneal_small, thread 0, absolute: decision [0], keys [1], own extrema [30], wave extrema [31], barrier [32], sixteen waves' extrema [33],
+# equal count [34], ... [9] as above; selection [2], compaction [3]; launches [35]
+na = max(c[35], 1.0)
+print("k_loop_anneal_small per launch (us): decide %.2f keys %.2f own %.2f wave %.2f barrier %.2f all %.2f eq %.2f extrema-phase-end %.2f select %.2f compaction %.2f (launches %d; returns before the keys are not in the later stamps)" % tuple(
+    [c[i] / 100 / na for i in (0, 1, 30, 31, 32, 33, 34, 9, 2, 3)] + [na]))
