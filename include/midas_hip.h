@@ -710,7 +710,8 @@ int midas_tail_resample(midas_ctx* ctx, const midas_tail_resample_args* args);
 #define MIDAS_LOOP_I_ERR 14    /* conditions of the CURRENT frame (cleared once its log row holds them): bit 0 / 1: more than
                                 * MIDAS_LOOP_MAX_CLUSTERS - 1 clusters (decide / DBSCAN), bit 2: live count above the launches' bound (particles were
                                 * not processed), bit 5: DBSCAN saw non-finite translations or more than 2^21 cells per axis, bit 6: a
-                                * cloud wider than 128 cells per axis with more than 2^20 particles (bits 5 / 6: labels undefined) */
+                                * cloud wider than 128 cells per axis with more than 2^20 particles (bits 5 / 6: labels undefined), bit 7: anneal_frozen was
+                                * set and the annealing rule wanted to act (the set was left as it was: not the reference's) */
 /* ctl_d (16 x float64) */
 #define MIDAS_LOOP_D_S 0        /* softmax denominator (1 when raw) */
 #define MIDAS_LOOP_D_VARPREV 1  /* particle_var (float32 value) */
@@ -775,6 +776,12 @@ typedef struct midas_loop_args {
                                     * the order - ATen's CPU kernel picks (std::partial_sort when k * 64 <= n, else std::nth_element +
                                     * std::sort, walked move for move by one wave: topk_aten.hip), i.e. what the reference keeps when it
                                     * runs on the CPU under a fixed seed (modules/particle_filter.py:433-441) */
+    int32_t anneal_frozen;         /* 1: the caller states that annealing cannot change the set - the live count equals `floor` AND the
+                                    * count annealing started from (modules/particle_filter.py:421-446: a removal needs |n - floor| > 0,
+                                    * a duplication k + n <= init_particles; both stay impossible once they are).  The ANNEAL phase then
+                                    * runs its decision only (cluster rows, variance: two small workgroups) and none of the selection's
+                                    * launches; the decision checks the statement and raises ctl_i[ERR] bit 7 if it finds work to do. */
+    int32_t pad2_;
 } midas_loop_args;
 int midas_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree* tree6, const midas_tree* tree3,
                     const midas_loop_args* args, int32_t phases);

@@ -182,6 +182,7 @@ class LoopArgs(C.Structure):
         ("unit_weights", C.c_int32), ("telemetry", C.c_void_p),
         ("score_stamps", C.c_void_p), ("score_epoch", C.c_uint32),
         ("host_mirror", C.c_void_p), ("grid_n", C.c_int64), ("anneal_small", C.c_int32), ("topk_ties", C.c_int32),
+        ("anneal_frozen", C.c_int32), ("pad2_", C.c_int32),
     ]
 
 

@@ -266,7 +266,8 @@ __global__ __launch_bounds__(256) void k_loop_decide(int32_t* __restrict__ ctl_i
                                                      const float* __restrict__ centers_all, const float* __restrict__ stds_all,
                                                      const int64_t* __restrict__ counts_all, float* __restrict__ centers_out,
                                                      float* __restrict__ stds_out, uint32_t* __restrict__ hist,
-                                                     int32_t* __restrict__ sel_state, int32_t floor_n, const double* __restrict__ rot) {
+                                                     int32_t* __restrict__ sel_state, int32_t floor_n, const double* __restrict__ rot,
+                                                     int32_t frozen = 0) {
     if (blockIdx.x == 1) { loop_rotations(ctl_i, counts_all, rot, centers_out); return; }
     const int t = threadIdx.x;
     for (int i = t; i < SEL_PASSES * SEL_BINS; i += 256) hist[i] = 0u;
@@ -275,6 +276,11 @@ __global__ __launch_bounds__(256) void k_loop_decide(int32_t* __restrict__ ctl_i
     if (t != 0) return;
     int mode, k;
     loop_decide(ctl_i, ctl_d, centers_all, stds_all, counts_all, centers_out, stds_out, floor_n, mode, k);
+    if (frozen && mode) {  // the caller said annealing cannot act and no selection was launched: the set stays, the frame says so
+        ctl_i[LOOP_I_ERR] |= 128;
+        ctl_i[LOOP_I_MODE] = 0; ctl_i[LOOP_I_K] = 0; ctl_i[LOOP_I_NSET] = ctl_i[LOOP_I_N];
+        k = 0;
+    }
     sel_state[0] = 0; sel_state[1] = 0; sel_state[2] = k;  // pass 0: empty prefix, rank k
 }
 
@@ -1296,7 +1302,14 @@ int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree*
         if ((rc = launch_loop_cluster(ctx, cap, s.ctl_i_dev, s.poses_prop_dev, s.weights_dev, s.labels_dev, (double*)part, (float*)cen,
                                       (float*)sd, (int64_t*)cnt, (double*)rot, weights_merged ? &wa : nullptr)))
             return rc;
-        if (s.topk_ties == MIDAS_TOPK_TIES_ATEN_CPU) {  // the reference's CPU tie choices (topk_aten.hip); the decision as always
+        if (s.anneal_frozen) {
+            // live count == floor == the count annealing started from: the rule (particle_filter.py:421-446) cannot remove (needs
+            // |n - floor| > 0) or duplicate (needs k + n <= init) - the decision's bookkeeping runs (cluster rows, variance), the ten
+            // launches of the selection, which would each find mode 0 and leave, do not (45 us of a 118 us frame at N = 100k)
+            hipLaunchKernelGGL(k_loop_decide, dim3(2), dim3(256), 0, st, s.ctl_i_dev, s.ctl_d_dev, (const float*)cen, (const float*)sd,
+                               (const int64_t*)cnt, s.cluster_poses_dev, s.cluster_stds_dev, ss.hist, ss.state, s.floor, (const double*)rot, 1);
+            LAUNCH_CHECK(ctx);
+        } else if (s.topk_ties == MIDAS_TOPK_TIES_ATEN_CPU) {  // the reference's CPU tie choices (topk_aten.hip); the decision as always
             hipLaunchKernelGGL(k_loop_decide, dim3(2), dim3(256), 0, st, s.ctl_i_dev, s.ctl_d_dev, (const float*)cen, (const float*)sd,
                                (const int64_t*)cnt, s.cluster_poses_dev, s.cluster_stds_dev, ss.hist, ss.state, s.floor, (const double*)rot);
             if ((rc = launch_topk_aten(ctx, cap, s.ctl_i_dev, s.weights_dev, s.src_dev, nullptr))) return rc;

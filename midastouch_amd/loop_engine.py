@@ -86,6 +86,8 @@ class LoopEngine:
         self._mirror = torch.zeros(2, dtype=torch.int32).pin_memory()
         self._frames_at_reset, self._n_at_reset, self._steps_at_reset, self._grid_n = 0, cap, 0, cap
         self.max_ahead = 1         # frames the host may enqueue ahead of the device's last report (None: no limit)
+        self.allow_frozen = True   # see _frozen()
+        self._init_known = None    # init_particles as the host knows it (None: annealing's first call will take the live count)
         self.step_count = 0        # frames enqueued (Philox counter, log row)
         self._n_host = None        # particle count as last known by the host (None: ask the device)
         self._pending_phases = 0
@@ -116,8 +118,10 @@ class LoopEngine:
             old = self.ctl_i.cpu()
             for k in (_lib.LOOP_I_INIT, _lib.LOOP_I_VARSET, _lib.LOOP_I_FRAME):
                 ci[k] = old[k]
+            self._init_known = int(old[_lib.LOOP_I_INIT]) if int(old[_lib.LOOP_I_VARSET]) else None
         else:
             self.ctl_d.zero_()
+            self._init_known = None
         ci[_lib.LOOP_I_N] = n
         ci[_lib.LOOP_I_NSET] = n
         ci[_lib.LOOP_I_NCL] = ncl
@@ -152,8 +156,19 @@ class LoopEngine:
                 return self.cap
         return min(n, self.cap)
 
+    def _frozen(self) -> bool:
+        """Annealing cannot change the set: the live count equals `floor` and the count annealing starts (started) from
+        (particle_filter.py:421-446: a removal needs |n - floor| > 0, a duplication k + n <= init_particles) - true from a start with
+        n == floor on, for good.  The ANNEAL phase then runs its decision only, not the selection's ten launches; the device checks
+        the statement (log row err bit 7).  `allow_frozen = False` keeps the launches (tests)."""
+        if not (self.cluster and self.allow_frozen):
+            return False
+        n0 = self._n_at_reset
+        return self.floor == n0 and self._init_known in (None, n0)
+
     def set_annealing_state(self, particle_var: float, init_particles: int):
         """particle_filter.particle_var / init_particles (particle_filter.py:413-417) - for restarts and tests."""
+        self._init_known = int(init_particles)
         ci = self.ctl_i.cpu()
         ci[_lib.LOOP_I_VARSET] = 0 if np.isinf(particle_var) else 1
         ci[_lib.LOOP_I_INIT] = int(init_particles)
@@ -252,6 +267,7 @@ class LoopEngine:
         a.host_mirror = C.c_void_p(self._mirror.data_ptr())
         a.grid_n = self._grid_n
         a.anneal_small = int(self._grid_n <= 16384)
+        a.anneal_frozen = int(self._frozen())
         a.topk_ties = self.topk_ties
         a.telemetry = _ptr(self.telemetry)
         if self.sparse_scores and phases & _lib.LOOP_FRONT:
@@ -298,6 +314,9 @@ class LoopEngine:
                 fatal.append(f"frame {f}: DBSCAN saw non-finite particle translations or a cloud of more than 2^21 cells per axis; labels undefined")
             if err & 64:
                 fatal.append(f"frame {f}: DBSCAN on a cloud wider than 128 cells per axis with more than 2^20 particles (hash table capacity); labels undefined")
+            if err & 128:
+                fatal.append(f"frame {f}: the engine stated that annealing could not act (live count == floor == init_particles) and the "
+                             "rule wanted to: the set was left as it was")
             out.append(dict(frame=f, n=int(L[1]), n_after=int(L[2]), rmse_t=float(L[3]), rmse_r=float(L[4]), kept=int(L[5]),
                             drifted=bool(L[6]), status=int(L[7]), mode=int(L[8]), k=int(L[9]), clusters=npres, var=float(L[11]),
                             S=float(L[12]), raw=bool(L[13]), ncl=int(L[14]), err=int(L[15]),

@@ -293,6 +293,53 @@ def test_loop_engine_free_running_vs_oracle(dev, oracle, N0, mode, cluster):
     assert [r["n_after"] for r in log] == sizes and eng.n == sizes[-1]
 
 
+@pytest.mark.parametrize("N0", [6000, 40000])
+def test_loop_engine_frozen_annealing_runs_the_decision_only(dev, oracle, N0):
+    """floor == live count == init_particles: the annealing rule (particle_filter.py:421-446) can neither remove nor duplicate, the
+    engine says so (midas_loop_args.anneal_frozen) and the ANNEAL phase runs its decision without the selection's launches - frame
+    after frame the oracle's loop body (which applies the rule), and identical to an engine that keeps the launches.  A wrong statement
+    is found by the device and read_log() raises."""
+    from midastouch_amd._lib import MidasError
+    from midastouch_amd.loop_engine import LoopEngine
+    from midastouch_amd.synthetic import make_codebook, make_trajectory
+    K, D, T, seed = 3000, 256, 14, 4300
+    cb = make_codebook(K=K, D=D, seed=1014, mesh_points=20000)
+    traj = make_trajectory(cb, T=T + 1, seed=2014)
+    rng = np.random.default_rng(3)
+    loop = oracle.OracleLoop(cb.poses, cb.embeddings, cb.mesh_vertices, cluster=True, cluster_every=5, floor=N0)
+    poses = cb.poses[rng.integers(0, K, N0)]
+    engs = []
+    for allow in (True, False):
+        e = LoopEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N0, seed=seed, floor=N0, cluster_every=5, device=dev)
+        e.allow_frozen = allow
+        e.set_particles(torch.as_tensor(poses))
+        assert e._frozen() is allow
+        engs.append(e)
+    labels = np.zeros(N0, dtype=np.int64)
+    for t in range(T):
+        tn, rot = oracle.philox_noise(N0, seed, t, np.float32(2e-4), np.float32(0.5))
+        ref = loop.step(poses, labels, traj.odoms[t + 1], traj.codes[t + 1], tn, rot, gt=traj.gt_poses[t + 1], mode="weighted_random",
+                        draws=lambda n2: oracle.philox_uniform64(n2, seed, t))
+        assert ref["N"] == N0
+        for e in engs:
+            e.step(torch.as_tensor(traj.odoms[t + 1]), torch.as_tensor(traj.codes[t + 1]), gt=torch.as_tensor(traj.gt_poses[t + 1]))
+            _compare_frame(e.frame_view(), ref, t, t % 5 == 0)
+        poses, labels = ref["poses"], ref["labels"]
+    logs = [e.read_log() for e in engs]
+    for ra, rb in zip(*logs):
+        assert ra["n_after"] == rb["n_after"] == N0 and ra["mode"] == rb["mode"] == 0 and ra["err"] == rb["err"] == 0
+        assert np.array_equal(ra["cluster_poses"], rb["cluster_poses"]) and np.array_equal(ra["cluster_stds"], rb["cluster_stds"])
+    # a wrong statement: the floor below the live count lets the rule remove particles; the device notices
+    bad = LoopEngine(cb.poses, cb.embeddings, cb.mesh_vertices, N0, seed=seed, floor=N0 // 2, cluster_every=5, device=dev)
+    bad.set_particles(torch.as_tensor(cb.poses[rng.integers(0, K, N0)]))
+    assert not bad._frozen()
+    bad._frozen = lambda: True
+    for t in range(8):
+        bad.step(torch.as_tensor(traj.odoms[t + 1]), torch.as_tensor(traj.codes[t + 1]))
+    with pytest.raises(MidasError, match="annealing could not act"):
+        bad.read_log()
+
+
 def test_loop_engine_replays_reference_loop_trace(dev, golden, oracle):
     """G13 (the reference's loop body with DBSCAN + annealing, N0 = 4096, 64 frames) with the reference's host draws in
     its order - tn, rot, then, once the annealed size is known, the resampler's uniforms (the frame is split there) - and
