@@ -275,25 +275,46 @@ MD void cluster_finish_body(int nblocks, size_t nbs, int c, const double* __rest
     constexpr int CB = 128;
     __shared__ double s_part[CB * CL_MOM];
     double r = 0.0;
+    // (eighteen loads in flight per thread before the first LDS store: left as one load and one store per iteration the
+    // compiler waits for each load in turn - 72 dependent trips, slower than the form this replaces)
+    constexpr int LB = 18;
+    const int NT = (int)blockDim.x;  // 64 (midas_cluster_centers) or 256 (loop step: a chunk is one batch of loads)
+    const double* __restrict__ pc = part + (size_t)c * nbs * CL_MOM;  // the cluster's partials lie together, block after block
+    // 256 threads: a chunk of CB blocks is ONE batch of loads, and the next chunk's batch is in flight while this one's chain is
+    // walked (at N = 100k - 391 blocks, four chunks - the chunks' trips came one after the other: 22 us)
+    const bool one_batch = NT * LB >= CB * CL_MOM;
+    double e_mx = -INFINITY, e_mn = INFINITY, e_first_mx = 0.0, e_first_mn = 0.0;  // (second wave: the extrema, see below)
+    double xn[LB];
+    auto issue = [&](int b0n) {
+        const int nbn = nblocks - b0n < CB ? nblocks - b0n : CB;
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+            const int i = t + NT * j, ic = i < nbn * CL_MOM ? i : nbn * CL_MOM - 1;
+            xn[j] = pc[(size_t)b0n * CL_MOM + ic];
+        }
+    };
+    if (one_batch && nblocks > 0) issue(0);
     for (int b0 = 0; b0 < nblocks; b0 += CB) {
         const int nb = nblocks - b0 < CB ? nblocks - b0 : CB;
-        // (eighteen loads in flight per thread before the first LDS store: left as one load and one store per iteration the
-        // compiler waits for each load in turn - 72 dependent trips, slower than the form this replaces)
-        constexpr int LB = 18;
-        const int NT = (int)blockDim.x;  // 64 (midas_cluster_centers) or 256 (loop step: a chunk is one batch of loads)
-        for (int i0 = t; i0 < nb * CL_MOM; i0 += NT * LB) {
-            double x[LB];
-#pragma unroll
-            for (int j = 0; j < LB; ++j) {
-                const int i = i0 + NT * j, ic = i < nb * CL_MOM ? i : nb * CL_MOM - 1;
-                const int b = ic / CL_MOM, m = ic - b * CL_MOM;
-                x[j] = part[((size_t)c * nbs + (size_t)(b0 + b)) * CL_MOM + m];
-            }
+        if (one_batch) {
 #pragma unroll
             for (int j = 0; j < LB; ++j)
-                if (i0 + NT * j < nb * CL_MOM) s_part[i0 + NT * j] = x[j];
+                if (t + NT * j < nb * CL_MOM) s_part[t + NT * j] = xn[j];
+        } else {
+            for (int i0 = t; i0 < nb * CL_MOM; i0 += NT * LB) {
+                double x[LB];
+#pragma unroll
+                for (int j = 0; j < LB; ++j) {
+                    const int i = i0 + NT * j, ic = i < nb * CL_MOM ? i : nb * CL_MOM - 1;
+                    x[j] = pc[(size_t)b0 * CL_MOM + ic];
+                }
+#pragma unroll
+                for (int j = 0; j < LB; ++j)
+                    if (i0 + NT * j < nb * CL_MOM) s_part[i0 + NT * j] = x[j];
+            }
         }
         __syncthreads();
+        if (one_batch && b0 + CB < nblocks) issue(b0 + CB);
         // sixteen LDS reads in flight, then the chain in block order.  The sums' chain is ONE dependent addition per block: the
         // two extrema (selects in the chain) are walked by lanes of their own where the workgroup has a second wave; whole batches
         // first, the remainder one by one (no guards in the chain).  With a read, a wait and three branches per block the walk was
@@ -314,7 +335,21 @@ MD void cluster_finish_body(int nblocks, size_t nbs, int c, const double* __rest
             }
             for (; b1 < nb; ++b1) r = r + s_part[b1 * CL_MOM + m];
         }
-        if (ext) {
+        if (two_waves) {
+            // The extrema need no order: `x > r ? x : r` walked from the first block's value takes the largest value that is not NaN
+            // (NaN never wins) unless the FIRST is NaN (then nothing replaces it) - the second wave's lanes take every 64th block
+            // each and meet at the end; walked block after block by one lane the two selects a block were the longest chain of
+            // the kernel at 391 blocks.
+            if (t >= 64 && t < 128) {
+                const int l = t - 64;
+                if (b0 == 0) { e_first_mx = s_part[M_WMAX]; e_first_mn = s_part[M_WMIN]; }
+                for (int b1 = l; b1 < nb; b1 += 64) {
+                    const double x = s_part[b1 * CL_MOM + M_WMAX], y = s_part[b1 * CL_MOM + M_WMIN];
+                    e_mx = x > e_mx ? x : e_mx;
+                    e_mn = y < e_mn ? y : e_mn;
+                }
+            }
+        } else if (ext) {
             const bool is_max = m == M_WMAX;
             int b1 = 0;
             if (b0 == 0) { r = s_part[m]; b1 = 1; }
@@ -334,8 +369,13 @@ MD void cluster_finish_body(int nblocks, size_t nbs, int c, const double* __rest
     }
     {
         const bool two_waves = blockDim.x >= 128;
-        if (two_waves && (t == 64 || t == 65)) s_m[t == 64 ? M_WMAX : M_WMIN] = r;
-        else if (t < CL_MOM && !(two_waves && (t == M_WMAX || t == M_WMIN))) s_m[t] = r;
+        if (two_waves && t >= 64 && t < 128) {
+            const double mx = wave_max_dpp(e_mx), mn = wave_min_dpp(e_mn);
+            if (t == 64) {
+                s_m[M_WMAX] = nblocks > 0 ? (e_first_mx != e_first_mx ? e_first_mx : mx) : 0.0;
+                s_m[M_WMIN] = nblocks > 0 ? (e_first_mn != e_first_mn ? e_first_mn : mn) : 0.0;
+            }
+        } else if (t < CL_MOM && !(two_waves && (t == M_WMAX || t == M_WMIN))) s_m[t] = r;
     }
     __syncthreads();
     if (t != 0) return;

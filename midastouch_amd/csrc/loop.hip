@@ -971,15 +971,20 @@ __global__ __launch_bounds__(256) void k_loop_resample(LoopResampleArgs a) {
     const int t = threadIdx.x;
     // Chunk ends, block totals and NaN flags leave before the control block is looked at (it is a trip of its own): by position,
     // bounded by what the launch was sized for - what lies behind the live count is not used.
+    // The table's stride is 16 slots while the launch's bound fits the table, else the next power of two that does (64 slots at
+    // N = 100k: eleven probes of LDS + six of memory instead of seventeen dependent probes of memory with a division each -
+    // 17 us of a 99 us frame).
     constexpr int RS_PRE = RS_CHUNKS / 256;
-    const int64_t nch_cap = ((int64_t)a.cap2 + 15) >> 4;
+    int ssh = 4;
+    while ((((int64_t)a.cap2 + ((int64_t)1 << ssh) - 1) >> ssh) > RS_CHUNKS) ++ssh;
+    const int64_t stride = (int64_t)1 << ssh;
     const int nb_cap = (int)(((int64_t)a.cap2 + SCAN_BLOCK - 1) / SCAN_BLOCK);
     double ce[RS_PRE];
-    const bool pre = nch_cap <= RS_CHUNKS && a.cap2 > 0;
+    const bool pre = a.cap2 > 0;
     if (pre) {
 #pragma unroll
         for (int k = 0; k < RS_PRE; ++k) {
-            const int64_t p = (int64_t)16 * (t + 256 * k) + 15;
+            const int64_t p = stride * (t + 256 * k) + stride - 1;
             ce[k] = a.lp[p < a.cap2 ? p : a.cap2 - 1];
         }
     }
@@ -997,17 +1002,13 @@ __global__ __launch_bounds__(256) void k_loop_resample(LoopResampleArgs a) {
     if ((int64_t)blockIdx.x * 256 >= n2 && !book) return;
     RCK(16);
     const int nb = (int)((n2 + SCAN_BLOCK - 1) / SCAN_BLOCK);
-    const int64_t nch = (n2 + 15) >> 4;
+    const int64_t nch = (n2 + stride - 1) >> ssh;  // (<= RS_CHUNKS while n2 <= cap2)
     const bool two_level = a.ctl_i[LOOP_I_RAW] == 0 && nch <= RS_CHUNKS && n2 > 0;
-    if (two_level) {
-        if (pre) {  // (the chunk that straddles the live count ends at slot n2 - 1)
+    if (two_level) {  // (the chunk that straddles the live count ends at slot n2 - 1)
 #pragma unroll
-            for (int k = 0; k < RS_PRE; ++k) {
-                const int c = t + 256 * k;
-                if (c < (int)nch) s_ce[c] = (int64_t)16 * c + 15 < n2 ? ce[k] : a.lp[n2 - 1];
-            }
-        } else {
-            for (int c = t; c < (int)nch; c += 256) { const int64_t p = (int64_t)16 * c + 15; s_ce[c] = a.lp[p < n2 ? p : n2 - 1]; }
+        for (int k = 0; k < RS_PRE; ++k) {
+            const int c = t + 256 * k;
+            if (c < (int)nch) s_ce[c] = stride * c + stride - 1 < n2 ? ce[k] : a.lp[n2 - 1];
         }
     }
     const int nbl = nb < nb_cap ? nb : nb_cap;  // (more alive than the launch was sized for: flagged elsewhere; stay inside the arrays)
@@ -1057,10 +1058,10 @@ __global__ __launch_bounds__(256) void k_loop_resample(LoopResampleArgs a) {
                 int cl = 0, ch = (int)nch;
                 while (ch > cl) {
                     const int cm = cl + ((ch - cl) >> 1);
-                    if (left_fast((int64_t)16 * cm + 15, s_ce[cm])) cl = cm + 1; else ch = cm;
+                    if (left_fast(stride * cm + stride - 1, s_ce[cm])) cl = cm + 1; else ch = cm;
                 }
-                lo = (int64_t)16 * cl;
-                hi = lo + 16 < n2 ? lo + 16 : n2;
+                lo = stride * cl;
+                hi = lo + stride < n2 ? lo + stride : n2;
                 if (cl >= (int)nch) lo = hi = n2;
                 // (inside the chunk: four dependent probes of one cache line; its sixteen values fetched together - eight 16-byte
                 // loads a lane, every lane a line of its own - made the kernel 1 us slower)
