@@ -66,7 +66,14 @@ __global__ __launch_bounds__(256) void k_loop_xe(const int32_t* __restrict__ ctl
                                                  const int32_t* __restrict__ nn_idx, const uint8_t* __restrict__ valid,
                                                  int32_t softmax, int32_t unit, double* __restrict__ x_out, double* __restrict__ e_out,
                                                  double* __restrict__ bsum, double* __restrict__ bmax, double* __restrict__ bmin,
-                                                 int32_t* __restrict__ bkept, int32_t* __restrict__ bnan, int32_t cap_n, int64_t K) {
+                                                 int32_t* __restrict__ bkept, int32_t* __restrict__ bnan, int32_t cap_n, int64_t K,
+                                                 double* __restrict__ clk = nullptr) {
+#ifdef MIDAS_ANNEAL_CLOCKS  // phase clocks of workgroup 0, thread 0 (tools/anneal_clocks.py; slots 36 .. 39 of the profiling block)
+    const long long xck0 = wall_clock64();
+#define XCK(i) do { if (clk && blockIdx.x == 0 && threadIdx.x == 0) clk[56 + (i)] += (double)(wall_clock64() - xck0); } while (0)
+#else
+#define XCK(i) do { } while (0)
+#endif
     __shared__ double s_gtot[16];
     __shared__ double s_mx[4], s_mn[4];
     __shared__ int s_k[4], s_f[4];
@@ -91,6 +98,7 @@ __global__ __launch_bounds__(256) void k_loop_xe(const int32_t* __restrict__ ctl
     const int64_t n = ctl_i[LOOP_I_N];
     if (bbase >= n) return;
     double mx = -INFINITY, mn = INFINITY;
+    XCK(36);
     int kept = 0;
     bool nan = false;
 #pragma unroll
@@ -104,6 +112,7 @@ __global__ __launch_bounds__(256) void k_loop_xe(const int32_t* __restrict__ ctl
         nan |= in && xv != xv;
         if (in) x_out[i] = xv;
     }
+    XCK(37);  // scores there
     if (softmax) {
 #pragma unroll
         for (int k = 0; k < SCAN_CHUNK; ++k) {
@@ -120,16 +129,14 @@ __global__ __launch_bounds__(256) void k_loop_xe(const int32_t* __restrict__ ctl
         if (in) e_out[bbase + il] = v[k];
         s_t[lds_chunk_pos(il)] = in ? v[k] : 0.0;
     }
+    XCK(38);  // exponentials done, values stored
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < SCAN_CHUNK; ++j) v[j] = s_t[17 * t + j];  // the own chunk: slots 16 t .. 16 t + 15 of the block
     const double W = block_total(v, s_gtot);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double a = __shfl_xor(mx, o), c = __shfl_xor(mn, o);
-        mx = a > mx ? a : mx;
-        mn = c < mn ? c : mn;
-    }
+    XCK(39);  // block total
+    mx = wave_max_dpp(mx);  // (register moves; NaN never wins, as in the shuffle form - flagged beside)
+    mn = wave_min_dpp(mn);
     kept = lw_isum(kept);
     const bool wnan = __any(nan);
     if ((t & 63) == 0) { s_mx[t >> 6] = mx; s_mn[t >> 6] = mn; s_k[t >> 6] = kept; s_f[t >> 6] = wnan ? 1 : 0; }
@@ -147,6 +154,10 @@ __global__ __launch_bounds__(256) void k_loop_xe(const int32_t* __restrict__ ctl
         bkept[blk] = kept;
         bnan[blk] = f;
     }
+    XCK(40);
+#ifdef MIDAS_ANNEAL_CLOCKS
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) clk[56 + 41] += 1.0;
+#endif
 }
 
 // S = blocks summed in order; guard; w = (e or x) / S * valid; every particle back onto its codebook pose when all of them
@@ -1272,7 +1283,13 @@ int launch_loop_step(midas_ctx* ctx, const midas_codebook* cb, const midas_tree*
         int32_t* bnan = bkept + nbcap;
         hipLaunchKernelGGL(k_loop_xe, dim3(nbcap), dim3(256), 0, st, (const int32_t*)s.ctl_i_dev, (const double*)s.scores_dev,
                            (const int32_t*)s.nn_idx_dev, (const uint8_t*)s.valid_dev, s.softmax, s.unit_weights, s.x_dev, s.e_dev, bsum, bmax, bmin,
-                           bkept, bnan, (int32_t)(cap < (1 << 30) ? cap : (1 << 30)), cb->K);
+                           bkept, bnan, (int32_t)(cap < (1 << 30) ? cap : (1 << 30)), cb->K,
+#ifdef MIDAS_ANNEAL_CLOCKS
+                           s.ctl_d_dev
+#else
+                           (double*)nullptr
+#endif
+                           );
         wa.ctl_i = s.ctl_i_dev; wa.ctl_d = s.ctl_d_dev; wa.grid_n = (int32_t)(cap < (1 << 30) ? cap : (1 << 30)); wa.nbl = (int32_t)nbcap;
         wa.bsum = bsum; wa.bmax = bmax; wa.bmin = bmin; wa.bkept = bkept; wa.bnan = bnan;
         wa.x = (const double*)s.x_dev; wa.e = (const double*)s.e_dev; wa.valid = (const uint8_t*)s.valid_dev;

@@ -64,7 +64,7 @@ class LoopEngine:
         if cap < 1 or cap > (1 << 20):
             raise MidasError("LoopEngine holds 1 .. 2^20 particles")
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=d)  # noqa: E731
-        self.ctl_i, self.ctl_d = z(32, torch.int32), z(96 if os.environ.get("MIDAS_ANNEAL_CLOCKS") else 16, torch.float64)  # (96: profiling builds)
+        self.ctl_i, self.ctl_d = z(32, torch.int32), z(104 if os.environ.get("MIDAS_ANNEAL_CLOCKS") else 16, torch.float64)  # (104: profiling builds)
         self._poses, self.poses_prop = z((cap, 4, 4), torch.float32), z((cap, 4, 4), torch.float32)
         self._hint = torch.full((cap,), -1, dtype=torch.int32, device=d)
         self._nn_idx, self._valid = z(cap, torch.int32), z(cap, torch.uint8)

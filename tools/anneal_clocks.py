@@ -16,7 +16,7 @@ cfg = load_config(["expt.params.num_particles=100000", "expt.codebook_size=50000
 dev = torch.device("cuda", 0)
 seq = synthetic_sequence(cfg, dev, T=150, D=512)
 run_filter(cfg, seq, device=dev, cluster=True, draws="device", floor=1000, max_frames=150)
-c = engines[-1].ctl_d.cpu().numpy()[56:96]
+c = engines[-1].ctl_d.cpu().numpy()[56:104]
 n2 = max(c[6], 1.0)
 print("launches with mode 2:", int(c[6]), "mean k", c[8] / n2)
 print("cumulative ticks (100 MHz -> us = /100) summed over ALL launches: after decide %.0f, keys %.0f, select %.0f, compaction %.0f | mode-2 only: sort %.0f, write %.0f | rotations block %.0f" % tuple(c[i] / 100 for i in (0, 1, 2, 3, 4, 5, 7)))
@@ -38,3 +38,6 @@ print("k_loop_weights_moments per launch (us): loads %.2f head %.2f weight %.2f 
 na = max(c[35], 1.0)
 print("k_loop_anneal_small per launch (us): decide %.2f keys %.2f own %.2f wave %.2f barrier %.2f all %.2f eq %.2f extrema-phase-end %.2f select %.2f compaction %.2f (launches %d; returns before the keys are not in the later stamps)" % tuple(
     [c[i] / 100 / na for i in (0, 1, 30, 31, 32, 33, 34, 9, 2, 3)] + [na]))
+# k_loop_xe, workgroup 0 / thread 0: live count + indices there [36], scores there [37], exponentials + stores [38], block total [39], end [40]; launches [41]
+nx = max(c[41], 1.0)
+print("k_loop_xe per launch (us): indices %.2f scores %.2f exps %.2f total %.2f end %.2f (launches %d)" % tuple([c[i] / 100 / nx for i in (36, 37, 38, 39, 40)] + [nx]))
