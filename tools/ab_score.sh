@@ -10,7 +10,7 @@ while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   ( /opt/rocm/bin/hipcc $F $flags -c score.hip -o build/variants/$name.score.o
     objs="build/variants/$name.score.o"
-    for f in particles resample cluster topn selfsim loop dbscan dbscan_nd index_build mt19937 comm api; do objs="$objs build/$f.o"; done
+    for f in particles resample cluster topn selfsim loop topk_aten dbscan dbscan_nd index_build mt19937 comm api; do objs="$objs build/$f.o"; done
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/$name.so $objs -ldl && echo built $name ) &
 done
 wait
