@@ -118,10 +118,15 @@ int launch_score(midas_ctx* ctx, const midas_codebook* cb, int32_t B, const doub
 // longest SIMD has 13 tiles - 22.2 us).  Round 3 had 196 workgroups of 256 rows on 256 CUs, two 1 KB row pieces in flight per
 // wave (47 us, 70 TFLOP/s); a wave now keeps MF_PF = 4 + 4 pieces in flight and twelve to sixteen waves per CU are live.
 constexpr int MF_ROWS_PER_WAVE = 16;
+// Waves per workgroup.  Rounds 4 - 5 ran twelve (three slots a SIMD, 170 registers a wave: 46.0 us + the prepare launch).  With the
+// prepare folded into the staging (round 6) sixteen are better: the 64 codes are then ONE pass of 64 quarter-waves - twelve waves
+// are 48, and the sixteen codes left over were a second round trip of a quarter of the workgroup while the rest waited at the
+// barrier (staged at 8.7 us, tools/mf_clocks.py) - and the fourth slot takes the tile-units.  K 50k x D 512 x B 64: 46.6 -> 44.1 us
+// (70.3 -> 74.3 TFLOP/s), D 256: 32.6 -> 30.1, B 128: 92.1 -> 86.8; K 500k: 381.6 -> 387.6 (127 registers, no spills).
 #ifndef MIDAS_MF_WAVES
-#define MIDAS_MF_WAVES 12
+#define MIDAS_MF_WAVES 16
 #endif
-constexpr int MF_WAVES = MIDAS_MF_WAVES;   // waves per workgroup: three slots on each of the CU's four SIMDs (170 registers a wave); 16: a fourth slot for the tile-units
+constexpr int MF_WAVES = MIDAS_MF_WAVES;
 constexpr int MF_CODES = 64;   // codes per pass (4 N-tiles)
 
 #ifndef MIDAS_MF_PF
