@@ -515,7 +515,11 @@ int launch_score_batch(midas_ctx* ctx, const midas_codebook* cb, int32_t B, cons
     // folded staging (the workgroups convert the float64 codes and form their norms themselves: no k_codes_prepare launch) where the
     // 64 norms fit behind the staged codes and a lane's columns fit its registers (D <= 624: D = 128 .. 512)
     // (K 50k x D 512 x B 64: 52.3 -> 46.6 us per call, 62.7 -> 70.3 TFLOP/s; the k_codes_prepare form stays for D = 640 and D > 640)
+#ifdef MIDAS_MF_NOFOLD  // (A/B builds: the k_codes_prepare form at every D)
+    const bool fold = false;
+#else
     const bool fold = codes_lds && D <= 624 && (uintptr_t)codes % 8 == 0;
+#endif
     const size_t lds = codes_lds ? (size_t)MF_CODES * D * sizeof(float) + (fold ? MF_CODES * sizeof(double) : 0) : 0;
     const int Bpad = (int)ceil_div(B, MF_CODES) * MF_CODES;
     void *cn = nullptr, *c32 = nullptr;
