@@ -425,6 +425,7 @@ __global__ __launch_bounds__(64 * MF_WAVES) void k_score_mfma(const float* __res
         const int qw0 = (int)threadIdx.x >> 4, s = (int)threadIdx.x & 15;
 #pragma unroll
         for (int k = 0; k < FOLD_MAXC; ++k) asm volatile("" : "+v"(fv[k]));  // (pinned: requested above, in front of the first row burst)
+        MF_STAMP(5);  // the codes' float64 values are there
         for (int pass = 0; pass * NQ < MF_CODES; ++pass) {
             const int b = qw0 + NQ * pass;
             if (b >= MF_CODES) break;  // (with twelve waves: quarter-waves 16 .. 47 have no second code)
@@ -446,6 +447,7 @@ __global__ __launch_bounds__(64 * MF_WAVES) void k_score_mfma(const float* __res
             acc2 = quarter_reduce(acc2);
             if (s == 0) { const double n = __builtin_sqrt(acc2); s_cn[b] = real ? (n < COS_EPS ? COS_EPS : n) : 1.0; }
         }
+        MF_STAMP(6);  // converted, stored, norms formed: at the barrier
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (first4) u4.set_cn(s_cn - b0, b0, nb);
     }

@@ -22,4 +22,7 @@ for s in range(W // 4):
     m = c[:, slot == s, :]
     print(f"slot {s}: entry {np.median(m[..., 0] - t0):6.1f} | staged {np.median(m[..., 1] - t0):6.1f} | multiplies done {np.median(m[..., 2] - t0):6.1f} "
           f"(p10 {np.percentile(m[..., 2] - t0, 10):.1f} p90 {np.percentile(m[..., 2] - t0, 90):.1f}) | epilogue done {np.median(m[..., 3] - t0):6.1f} | exit {np.median(m[..., 4] - t0):6.1f} max {np.max(m[..., 4] - t0):6.1f}")
+print("all waves: codes' values there %.1f (p10 %.1f p90 %.1f) | at the staging barrier %.1f (p10 %.1f p90 %.1f, max %.1f)" % (
+    np.median(c[..., 5] - t0), np.percentile(c[..., 5] - t0, 10), np.percentile(c[..., 5] - t0, 90),
+    np.median(c[..., 6] - t0), np.percentile(c[..., 6] - t0, 10), np.percentile(c[..., 6] - t0, 90), (c[..., 6] - t0).max()))
 print("kernel span (first entry -> last exit): %.1f us; entry spread p90 %.1f us" % (c[:, :, 4].max() - t0, np.percentile(c[:, :, 0] - t0, 90)))
